@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "tip_forward_golden.npz")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    z = np.load(GOLDEN)
+    cases = {}
+    for k in z.files:
+        tag, name = k.split("/")
+        cases.setdefault(tag, {})[name] = z[k]
+    return cases
+
+
+def cfg_for_tag(tag):
+    import tip_amd
+    s = tip_amd.synth
+    if tag.startswith("paper"):
+        return s.PAPER
+    if tag.startswith("tiny_nornn"):
+        return dict(s.TINY, with_rnn=False)
+    if tag.startswith("tiny_noacc"):
+        return dict(s.TINY, with_acc_sum=False)
+    if tag.startswith("tiny"):
+        return s.TINY
+    raise KeyError(tag)
+
+
+def seed_for_tag(tag):
+    return int(tag.split("_s")[1].split("_")[0])

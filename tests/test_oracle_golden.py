@@ -1,0 +1,93 @@
+"""Pins the CPU oracle (oracle/tip_oracle.c) against golden vectors captured from the reference module
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+import tip_amd
+from tip_amd import synth
+from oracle import oracle
+from conftest import cfg_for_tag, seed_for_tag
+
+
+def _weights_for(tag, case):
+    cfg = cfg_for_tag(tag)
+    w = synth.make_weights(cfg, seed=seed_for_tag(tag))
+    s = sum(float(v.astype(np.float64).sum()) for v in w.values())
+    s2 = sum(float((v.astype(np.float64) ** 2).sum()) for v in w.values())
+    np.testing.assert_allclose([s, s2], case["wsum"], rtol=1e-12, err_msg="synthetic weight generator drifted")
+    return cfg, w
+
+
+def test_inputs_regenerate_bit_exact(golden):
+    for tag, case in golden.items():
+        if "mask" in tag:
+            continue
+        cfg = cfg_for_tag(tag)
+        B, T = case["x_imu"].shape[:2]
+        x_imu, x_s = synth.make_inputs(cfg, B, T, seed=1234 + seed_for_tag(tag))
+        assert np.array_equal(x_imu, case["x_imu"])
+        assert np.array_equal(x_s, case["x_s"], equal_nan=True)
+
+
+def test_oracle_f64_matches_reference_f64(golden):
+    for tag, case in golden.items():
+        cfg, w = _weights_for(tag, case)
+        km = case.get("mask")
+        ks = 1.0 / (1.0 - float(case["p"][0])) if km is not None else 1.0
+        y = oracle.forward(cfg, w, case["x_imu"], case["x_s"], keep_mask=km, keep_scale=ks, dtype=np.float64)
+        err = np.abs(y - case["y64"]).max()
+        assert err < 1e-12, (tag, err)
+
+
+def test_oracle_f32_matches_reference_f32(golden):
+    for tag, case in golden.items():
+        cfg, w = _weights_for(tag, case)
+        km = case.get("mask")
+        ks = 1.0 / (1.0 - float(case["p"][0])) if km is not None else 1.0
+        y = oracle.forward(cfg, w, case["x_imu"], case["x_s"], keep_mask=km, keep_scale=ks, dtype=np.float32)
+        err = np.abs(y - case["y32"]).max()
+        err64 = np.abs(y.astype(np.float64) - case["y64"]).max()
+        assert err < 5e-6 and err64 < 5e-6, (tag, err, err64)
+
+
+def test_oracle_taps_match_reference_hooks(golden):
+    for tag, case in golden.items():
+        if "tap_layer0" not in case:
+            continue
+        cfg, w = _weights_for(tag, case)
+        y, taps = oracle.forward(cfg, w, case["x_imu"], case["x_s"], dtype=np.float64, taps=True)
+        D, H = cfg["tf_in_dim"], cfg["n_heads"]
+        raw = case["tap_in_linear_raw"].astype(np.float64)              # before the channel shuffle
+        B, T = raw.shape[:2]
+        shuf = raw.reshape(B, T, H, D // H).transpose(0, 1, 3, 2).reshape(B, T, D)
+        assert np.abs(taps["in"] - shuf).max() < 5e-6, tag
+        for l in range(cfg["tf_layers"]):
+            assert np.abs(taps["layers"][l] - case[f"tap_layer{l}"]).max() < 1e-5, (tag, l)
+        if cfg.get("with_rnn", True):
+            assert np.abs(taps["rnn"] - case["tap_rnn"]).max() < 1e-5, tag
+
+
+def test_oracle_properties():
+    cfg = synth.TINY
+    w = synth.make_weights(cfg, seed=3)
+    x_imu, x_s = synth.make_inputs(cfg, 2, 12, seed=5)
+    y = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
+    # causality: a prefix run reproduces the prefix rows
+    yp = oracle.forward(cfg, w, x_imu[:, :5], x_s[:, :5], dtype=np.float64)
+    assert np.abs(y[:, :5] - yp).max() < 1e-12
+    # root-velocity history columns never reach the output (:75)
+    xs2 = x_s.copy()
+    xs2[:, :, 108:111] = 123.0
+    y2 = oracle.forward(cfg, w, x_imu, xs2, dtype=np.float64)
+    assert np.array_equal(y, y2)
+    # NaN == 0 in x_s (:65)
+    xs3 = np.nan_to_num(x_s, nan=0.0)
+    y3 = oracle.forward(cfg, w, x_imu, xs3, dtype=np.float64)
+    assert np.array_equal(y, y3)
+    # batch independence
+    y0 = oracle.forward(cfg, w, x_imu[1:], x_s[1:], dtype=np.float64)
+    assert np.array_equal(y[1:], y0)
+    # thread count does not change results
+    ya = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float32, nthreads=1)
+    yb = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float32, nthreads=4)
+    assert np.array_equal(ya, yb)
