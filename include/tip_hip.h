@@ -1,0 +1,109 @@
+/* tip_hip.h — C-ABI of the MI355X-native TIP forward pass (libtip_hip.so).
+ *
+ * The reference has no FFI layer: its boundary for this path is the Python nn.Module
+ * `TF_RNN_Past_State` (/root/reference/simple_transformer_with_state.py:8-102).  Each entry point below
+ * names the piece of that interface it replaces; the Python host in
+ * transformer-inertial-poser_amd/simple_transformer_with_state.py binds them with ctypes.
+ *
+ * Conventions: plain C, no torch types, no exceptions; every function returns 0 or a negative
+ * tip_status; device pointers are caller-owned, contiguous, row-major fp32; tip_forward is asynchronous on
+ * the caller's HIP stream; one handle per GPU, used from one thread at a time; the library allocates no
+ * device memory (packed weights and workspace are caller-provided buffers).
+ */
+#ifndef TIP_HIP_H
+#define TIP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TIP_ABI_VERSION 1
+
+typedef struct tip_handle tip_handle;
+typedef void* tip_stream_t; /* hipStream_t */
+
+/* Constructor arguments of TF_RNN_Past_State (simple_transformer_with_state.py:9-17). */
+typedef struct tip_config {
+    int32_t input_size_imu;  /* 72 */
+    int32_t size_s;          /* 131 */
+    int32_t rnn_hid_size;    /* 512 */
+    int32_t tf_hid_size;     /* 1024 (dim_feedforward) */
+    int32_t tf_in_dim;       /* 256  (d_model) */
+    int32_t n_heads;         /* 16 */
+    int32_t tf_layers;       /* 4 */
+    int32_t with_rnn;        /* :15 */
+    int32_t with_acc_sum;    /* :16  (+18 input columns, :20-22) */
+    int32_t t_max;           /* longest window the handle must serve (40; 80 for the scaled config) */
+} tip_config;
+
+typedef enum tip_status {
+    TIP_OK = 0,
+    TIP_ERR_INVALID_ARG = -1,
+    TIP_ERR_UNSUPPORTED_CONFIG = -2,
+    TIP_ERR_NOT_READY = -3,      /* tip_forward before tip_attach_packed */
+    TIP_ERR_WORKSPACE = -4,      /* workspace too small / misaligned */
+    TIP_ERR_HIP = -5,            /* a HIP runtime call failed; see tip_last_hip_error */
+    TIP_ERR_NO_DEVICE = -6,
+    TIP_ERR_ALLOC = -7
+} tip_status;
+
+/* tip_forward flags */
+#define TIP_FWD_LAST_ROW_ONLY 0x1 /* y is [B, size_s] = row T-1 of every window: what RTRunnerMin.step consumes
+                                     (real_time_runner_minimal.py:150) */
+#define TIP_FWD_KEEP_MASK     0x2 /* keep_mask [B,T,size_s] supplied: x_s * mask * keep_scale, replaces the Bernoulli
+                                     draw of nn.Dropout(past_state_dropout) (simple_transformer_with_state.py:77) */
+
+/* execution plans (tip_set_option(TIP_OPT_PLAN, ...)) */
+#define TIP_PLAN_AUTO    0
+#define TIP_PLAN_GENERAL 1 /* layer-by-layer MFMA GEMM kernels, any configuration */
+#define TIP_PLAN_FUSED   2 /* one workgroup = one window through all encoder layers (paper configuration) */
+
+#define TIP_OPT_PLAN        1
+#define TIP_OPT_PROFILE     2 /* 1: bracket every stage with HIP events (read with tip_profile_read) */
+#define TIP_OPT_RNN_CLUSTER 3 /* workgroups cooperating on one RNN window-tile (1,2,4,8); 0 = auto */
+
+/* ---- lifetime: replaces TF_RNN_Past_State.__init__ (simple_transformer_with_state.py:9-54) ---------------- */
+int tip_abi_version(void);
+int tip_create(const tip_config* cfg, tip_handle** out);
+void tip_destroy(tip_handle* h);
+const char* tip_strerror(int status);
+const char* tip_last_hip_error(const tip_handle* h);
+int tip_set_option(tip_handle* h, int option, int value);
+int tip_get_option(const tip_handle* h, int option, int* value);
+
+/* ---- parameters: replaces state_dict()/load_state_dict() (train_model.py:109-111,220-225;
+ *      offline_testing_simple.py:96).  Tensor i is the i-th entry of the reference's state_dict(), same shape. */
+int tip_num_tensors(const tip_handle* h);
+int tip_tensor_info(const tip_handle* h, int i, const char** name, int* rows, int* cols /* 0 for 1-D */);
+/* size of the packed weight image (padded / permuted / folded copy the kernels read) */
+int tip_packed_bytes(const tip_handle* h, size_t* bytes);
+/* host: build the packed image from the n state-dict tensors (host pointers, fp32, reference layout).
+ * Folds applied here: channel shuffle :88-89 into in_linear rows; root-velocity zeroing :75 into in_linear
+ * columns; 1/sqrt(d_head) into W_q/b_q when exact; b_ih + b_hh; MFMA-fragment ordering of W_hh. */
+int tip_pack_weights(const tip_handle* h, const float* const* host_tensors, int n, void* packed_host_out, size_t bytes);
+/* device: point the handle at a packed image resident in HBM (caller-owned; e.g. the buffer every rank
+ * receives from the one-time RCCL broadcast).  Must stay valid until the next attach / destroy. */
+int tip_attach_packed(tip_handle* h, const void* packed_device, size_t bytes);
+
+/* ---- forward: replaces TF_RNN_Past_State.forward(x_imu, x_s) (simple_transformer_with_state.py:60-102) ---- */
+int tip_workspace_bytes(const tip_handle* h, int B, int T, size_t* bytes);
+/* x_imu [B,T,input_size_imu(+18)], x_s [B,T,size_s] (NaNs allowed, :65), y [B,T,size_s] (or [B,size_s] with
+ * TIP_FWD_LAST_ROW_ONLY).  Inputs are not modified (:63-64).  keep_mask may be NULL. */
+int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
+                const float* keep_mask, float keep_scale, void* workspace, size_t workspace_bytes,
+                tip_stream_t stream);
+
+/* ---- measurement ------------------------------------------------------------------------------------------ */
+/* number of tip_forward calls that launched HIP kernels since tip_create (lets tests prove the HIP path ran) */
+int tip_forward_count(const tip_handle* h, uint64_t* n);
+/* after the stream is synchronised: per-stage times of the LAST profiled forward.  names/ms arrays of length
+ * `cap`; returns the number of stages (<= cap) or a negative status. */
+int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIP_HIP_H */

@@ -1,0 +1,186 @@
+"""GPU parity tests: the HIP path (through the C-ABI) vs golden vectors captured from the reference and vs the
+CPU oracle on the same seeded inputs.  Tolerance (north_star): 1e-4 max-abs, fp32, dropout disabled."""
+import numpy as np
+import pytest
+import torch
+
+import tip_amd
+from tip_amd import synth
+from tip_amd import lib as tlib
+from oracle import oracle
+from conftest import cfg_for_tag, seed_for_tag
+from test_host_cpu import make_model, load_synth
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # north_star: outputs within 1e-4 max-abs of the reference fp32 forward
+TOL_TIGHT = 2e-5    # what fp32 MFMA actually achieves against the fp64 reference on these inputs
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu-marked test needs an MI355X"
+    return torch.device("cuda:0")
+
+
+def _gpu_model(cfg, seed, **kw):
+    m = make_model(cfg, **kw)
+    w = load_synth(m, cfg, seed)
+    return m.cuda().eval(), w
+
+
+def _run(m, x_imu, x_s, last=False):
+    n0 = m.hip_forward_count()
+    with torch.no_grad():
+        xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+        xi0, xs0 = xi.clone(), xs.clone()
+        y = (m.forward_last if last else m)(xi, xs)
+        torch.cuda.synchronize()
+    assert m.hip_forward_count() == n0 + 1, "the HIP path did not run"
+    assert torch.equal(xi, xi0) and torch.equal(torch.nan_to_num(xs, nan=7.0), torch.nan_to_num(xs0, nan=7.0)), \
+        "inputs were modified (reference clones them, simple_transformer_with_state.py:63-64)"
+    return y.cpu().numpy()
+
+
+PLANS = ["general", "auto"]
+
+
+@pytest.mark.parametrize("plan", PLANS)
+def test_golden_vectors(golden, plan):
+    _dev()
+    models = {}
+    for tag, case in golden.items():
+        if "mask" in tag:
+            continue
+        cfg = cfg_for_tag(tag)
+        key = (tag.split("_B")[0])
+        if key not in models:
+            models[key] = _gpu_model(cfg, seed_for_tag(tag))[0]
+            models[key].set_plan(plan)
+        y = _run(models[key], case["x_imu"], case["x_s"])
+        e32 = np.abs(y - case["y32"]).max()
+        e64 = np.abs(y - case["y64"]).max()
+        assert np.isfinite(y).all(), tag
+        assert e32 < TOL and e64 < TOL, (tag, plan, e32, e64)
+        assert e64 < TOL_TIGHT, (tag, plan, e64)
+
+
+@pytest.mark.parametrize("cluster", [1, 2, 4, 8])
+def test_rnn_cluster_variants_bit_identical(cluster):
+    """Splitting an RNN window-tile over 1/2/4/8 cooperating workgroups must not change a single bit."""
+    cfg = synth.PAPER
+    m, w = _gpu_model(cfg, 0)
+    x_imu, x_s = synth.make_inputs(cfg, 37, 40, seed=11)
+    m.set_plan("general", rnn_cluster=1)
+    y1 = _run(m, x_imu, x_s)
+    m.set_plan("general", rnn_cluster=cluster)
+    for _ in range(3):
+        yc = _run(m, x_imu, x_s)
+        assert np.array_equal(y1, yc)
+    yo = oracle.forward(cfg, w, x_imu[:4], x_s[:4], dtype=np.float64)
+    assert np.abs(y1[:4] - yo).max() < TOL_TIGHT
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 40), (3, 2), (17, 39), (64, 40), (130, 7)])
+def test_vs_oracle_shapes(B, T):
+    cfg = synth.PAPER
+    m, w = _gpu_model(cfg, 1)
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=100 + B)
+    y = _run(m, x_imu, x_s)
+    yo = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float32)
+    assert y.shape == (B, T, cfg["size_s"])
+    assert np.abs(y - yo).max() < TOL_TIGHT, np.abs(y - yo).max()
+
+
+def test_last_row_only_equals_full():
+    cfg = synth.PAPER
+    m, _ = _gpu_model(cfg, 0)
+    x_imu, x_s = synth.make_inputs(cfg, 33, 40, seed=5)
+    y = _run(m, x_imu, x_s)
+    yl = _run(m, x_imu, x_s, last=True)
+    assert yl.shape == (33, cfg["size_s"])
+    assert np.array_equal(y[:, -1], yl)
+
+
+def test_streaming_growth_T_1_to_40():
+    """RTRunnerMin warm-up: T grows 1,2,...,40 (real_time_runner_minimal.py:131); every call consumes row T-1."""
+    cfg = synth.PAPER
+    m, w = _gpu_model(cfg, 0)
+    x_imu, x_s = synth.make_inputs(cfg, 1, 40, seed=9)
+    yfull = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
+    for T in list(range(1, 41)):
+        yl = _run(m, x_imu[:, :T], x_s[:, :T], last=True)
+        # causal: the prefix run reproduces row T-1 of the full run
+        assert np.abs(yl[0] - yfull[0, T - 1]).max() < TOL_TIGHT, T
+
+
+def test_keep_mask_semantics(golden):
+    """TIP_FWD_KEEP_MASK: x_s * mask / (1-p) == nn.Dropout with the same Bernoulli draw (golden from the reference)."""
+    case = golden["paper_mask_s0_B2_T40"]
+    cfg = synth.PAPER
+    m, _ = _gpu_model(cfg, 0)
+    h = m._ensure_handle()
+    m.refresh_packed(torch.device("cuda:0"))
+    xi, xs = torch.tensor(case["x_imu"]).cuda(), torch.tensor(case["x_s"]).cuda()
+    mask = torch.tensor(case["mask"]).cuda()
+    p = float(case["p"][0])
+    y = torch.empty(2, 40, 131, device="cuda")
+    ws = torch.empty(h.workspace_bytes(2, 40), dtype=torch.uint8, device="cuda")
+    h.forward(xi.data_ptr(), xs.data_ptr(), y.data_ptr(), 2, 40, tlib.TIP_FWD_KEEP_MASK, mask.data_ptr(),
+              1.0 / (1.0 - p), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.abs(y.cpu().numpy() - case["y64"]).max() < TOL_TIGHT
+
+
+def test_past_state_dropout_is_live_in_eval():
+    """The reference's fresh nn.Dropout (:77) is stochastic even under .eval(): two calls differ; p=0 calls agree."""
+    cfg = synth.TINY
+    m, _ = _gpu_model(cfg, 0, p_state=0.8)
+    x_imu, x_s = synth.make_inputs(cfg, 4, 20, seed=2)
+    a, b = _run(m, x_imu, x_s), _run(m, x_imu, x_s)
+    assert np.abs(a - b).max() > 1e-3
+    m0, _ = _gpu_model(cfg, 0, p_state=0.0)
+    a, b = _run(m0, x_imu, x_s), _run(m0, x_imu, x_s)
+    assert np.array_equal(a, b)
+
+
+def test_properties_at_full_size():
+    """BASELINE sizes (B=1024 streams per GPU, T=40): batch independence (a stream's output does not depend on
+    which other streams share the launch), NaN scrub (:65), root-velocity columns ignored (:75)."""
+    cfg = synth.PAPER
+    m, _ = _gpu_model(cfg, 0)
+    B = 1024
+    x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=77)
+    y = _run(m, x_imu, x_s)
+    assert np.isfinite(y).all()
+    sel = np.array([0, 1, 15, 16, 17, 255, 256, 511, 1000, 1023])
+    ysub = _run(m, x_imu[sel], x_s[sel])
+    assert np.array_equal(y[sel], ysub)
+    xs2 = np.nan_to_num(x_s, nan=0.0)
+    xs2[:, :, 108:111] = 3.25
+    y2 = _run(m, x_imu, xs2)
+    assert np.array_equal(y, y2)
+    # sharding == concatenation (what bench.py --gpus N relies on): two half-batches reproduce the full batch
+    ya, yb = _run(m, x_imu[:512], x_s[:512]), _run(m, x_imu[512:], x_s[512:])
+    assert np.array_equal(np.concatenate([ya, yb]), y)
+
+
+def test_scaled_config_reduced_depth():
+    """BASELINE configs[4] widths (d=1024, ffn=4096, dh=64, T=80) at 2 layers so the oracle finishes in seconds."""
+    cfg = dict(synth.SCALED, tf_layers=2)
+    m, w = _gpu_model(cfg, 0)
+    x_imu, x_s = synth.make_inputs(cfg, 3, 80, seed=4)
+    y = _run(m, x_imu, x_s)
+    yo = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
+    assert np.abs(y - yo).max() < TOL_TIGHT, np.abs(y - yo).max()
+
+
+def test_load_state_dict_refreshes_packed_image():
+    cfg = synth.TINY
+    m, w0 = _gpu_model(cfg, 0)
+    x_imu, x_s = synth.make_inputs(cfg, 2, 10, seed=1)
+    y0 = _run(m, x_imu, x_s)
+    w1 = synth.make_weights(cfg, seed=5)
+    m.load_state_dict({k: torch.tensor(v) for k, v in w1.items()})
+    y1 = _run(m, x_imu, x_s)
+    yo = oracle.forward(cfg, w1, x_imu, x_s, dtype=np.float64)
+    assert np.abs(y1 - yo).max() < TOL_TIGHT and np.abs(y1 - y0).max() > 1e-3

@@ -1,0 +1,156 @@
+"""Host-side logic that needs no GPU: module surface, state-dict contract, packed-image folds, C-ABI exports,
+torch-op composite vs the golden vectors."""
+import ctypes
+import io
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import tip_amd
+from tip_amd import synth
+from tip_amd import lib as tlib
+from conftest import ROOT, cfg_for_tag, seed_for_tag
+
+
+def make_model(cfg, p_state=0.0, dropout=0.0):
+    return tip_amd.TF_RNN_Past_State(
+        cfg["input_size_imu"], cfg["size_s"], rnn_hid_size=cfg["rnn_hid_size"], tf_hid_size=cfg["tf_hid_size"],
+        tf_in_dim=cfg["tf_in_dim"], n_heads=cfg["n_heads"], tf_layers=cfg["tf_layers"], dropout=dropout,
+        in_dropout=0.0, past_state_dropout=p_state, with_rnn=cfg.get("with_rnn", True),
+        with_acc_sum=cfg.get("with_acc_sum", False))
+
+
+def load_synth(model, cfg, seed):
+    w = synth.make_weights(cfg, seed=seed)
+    model.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    return w
+
+
+@pytest.mark.parametrize("cfg", [synth.PAPER, synth.TINY, dict(synth.TINY, with_rnn=False),
+                                 dict(synth.TINY, with_acc_sum=False)])
+def test_state_dict_contract(cfg):
+    m = make_model(cfg)
+    sd = m.state_dict()
+    lay = synth.state_dict_layout(cfg)
+    assert list(sd.keys()) == list(lay.keys())
+    for k, shape in lay.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    if cfg is synth.PAPER:
+        assert len(sd) == 56 and sum(v.numel() for v in sd.values()) == 3677315
+
+
+def test_torch_save_round_trip():
+    m = make_model(synth.TINY)
+    load_synth(m, synth.TINY, 3)
+    buf = io.BytesIO()
+    torch.save(m.state_dict(), buf)   # train_model.py:220-225
+    buf.seek(0)
+    m2 = make_model(synth.TINY)
+    m2.load_state_dict(torch.load(buf))  # offline_testing_simple.py:96
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_autograd_composite_matches_golden(golden):
+    """train_model.py:175,192 — in grad mode the module runs torch ops; must equal the reference forward."""
+    for tag, case in golden.items():
+        if "mask" in tag:
+            continue
+        cfg = cfg_for_tag(tag)
+        m = make_model(cfg)
+        load_synth(m, cfg, seed_for_tag(tag))
+        m.eval()
+        with pytest.warns(UserWarning):
+            y = m(torch.tensor(case["x_imu"]), torch.tensor(case["x_s"]))
+        assert y.requires_grad
+        err = np.abs(y.detach().numpy() - case["y32"]).max()
+        assert err < 1e-5, (tag, err)
+    y.sum().backward()
+    assert m.in_linear.weight.grad is not None and torch.isfinite(m.in_linear.weight.grad).all()
+
+
+def test_inference_on_cpu_fails_loudly():
+    m = make_model(synth.TINY)
+    x_imu, x_s = synth.make_inputs(synth.TINY, 1, 4)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.tensor(x_imu), torch.tensor(x_s))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tip_hip.h")).read()
+    declared = set(re.findall(r"\b(tip_[a-z_]+)\s*\(", hdr)) - {"tip_stream_t"}
+    assert declared == set(tlib.EXPORTS), declared ^ set(tlib.EXPORTS)
+    lib = ctypes.CDLL(tlib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert tlib.load().tip_abi_version() == 1
+
+
+def test_handle_table_status_and_errors():
+    cfg = synth.PAPER
+    m = make_model(cfg)
+    h = m._ensure_handle()
+    table = h.tensor_table()
+    assert [n for n, _ in table] == list(synth.state_dict_layout(cfg).keys())
+    assert [tuple(s) for _, s in table] == [tuple(s) for s in synth.state_dict_layout(cfg).values()]
+    assert h.packed_bytes() % 256 == 0 and h.packed_bytes() >= 3677315 * 4
+    assert h.workspace_bytes(256, 40) > 256 * 40 * 256 * 4
+    lib = tlib.load()
+    assert lib.tip_strerror(0) == b"ok" and b"workspace" in lib.tip_strerror(-4)
+    bad = tlib.TipConfig(72, 131, 512, 1024, 250, 16, 4, 1, 1, 40)   # 250 % 16 != 0
+    with pytest.raises(tlib.TipStatusError):
+        tlib.Handle(bad)
+    # forward before weights are attached -> TIP_ERR_NOT_READY (no kernel launched, safe without a GPU)
+    h2 = tlib.Handle(m._tip_config())
+    with pytest.raises(tlib.TipStatusError) as ei:
+        h2.forward(1, 1, 1, 1, 1, 0, None, 1.0, 0, 0, 0)
+    assert ei.value.status == -3
+    with pytest.raises(tlib.TipStatusError):
+        h2.forward(0, 1, 1, 1, 1, 0, None, 1.0, 0, 0, 0)
+
+
+def _unpack_linear(img, off_w, off_b, N, K, Npad, Kpad):
+    W = img[off_w: off_w + Npad * Kpad].reshape(Npad, Kpad)
+    return W[:N, :K], img[off_b: off_b + N], W
+
+
+def test_packed_image_folds():
+    """The packed image must encode: shuffle :88-89 in in_linear rows, root-vel zero :75 in its columns,
+    0.25 in W_q, b_ih+b_hh, and W_hh in 16x16x4 B-fragment order."""
+    cfg = synth.PAPER
+    m = make_model(cfg)
+    w = load_synth(m, cfg, 0)
+    img = m.pack_host().numpy().view(np.float32)
+    D, H, In = 256, 16, 221
+    dh = D // H
+    KB = 224
+    Win = img[0: 256 * KB].reshape(256, KB)
+    ref = w["in_linear.weight"].copy()
+    ref[:, 90 + 108: 90 + 111] = 0.0
+    perm = np.array([(n % H) * dh + n // H for n in range(D)])   # packed row a*H+b <- reference row b*dh+a
+    assert np.array_equal(Win[:, :In], ref[perm])
+    assert np.all(Win[:, In:] == 0)
+    # semantic check of the fold against the oracle's in-linear tap
+    from oracle import oracle
+    x_imu, x_s = synth.make_inputs(cfg, 1, 3)
+    _, taps = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64, taps=True)
+    u = np.concatenate([x_imu, np.nan_to_num(x_s, nan=0.0)], axis=2)[0].astype(np.float64)
+    b_in = img[256 * KB: 256 * KB + 256]
+    z = u @ Win[:, :In].astype(np.float64).T + b_in
+    assert np.abs(z - taps["in"][0]).max() < 1e-6
+    # W_hh fragments
+    R = 512
+    flat = img
+    whh = w["rnn.weight_hh_l0"]
+    # locate the fragment section by searching for its first element pattern: nb=0,kb=0,lane=0 -> W[0][0..3]
+    frag0 = np.array([whh[l & 15, 4 * (l >> 4) + s] for l in range(64) for s in range(4)], dtype=np.float32)
+    hits = [i for i in range(0, flat.size - 256, 64) if flat[i] == frag0[0] and np.array_equal(flat[i:i + 256], frag0)]
+    assert len(hits) >= 1
+    off = hits[0]
+    nb, kb = 5, 17
+    blk = flat[off + (nb * 32 + kb) * 256: off + (nb * 32 + kb + 1) * 256].reshape(64, 4)
+    exp = np.array([[whh[nb * 16 + (l & 15), kb * 16 + 4 * (l >> 4) + s] for s in range(4)] for l in range(64)])
+    assert np.array_equal(blk, exp)

@@ -1,0 +1,519 @@
+// tip_abi.hip — the C-ABI of libtip_hip.so (include/tip_hip.h): handle, packed weight image, workspace
+// carve-up and the forward orchestration.  No torch types, no exceptions across the boundary.
+#include <math.h>
+#include <string.h>
+
+#include <new>
+
+#include "tip_internal.h"
+
+using namespace tip;
+
+namespace {
+
+const char* kStatusText[] = {
+    "ok",
+    "invalid argument",
+    "unsupported configuration",
+    "not ready: no packed weights attached",
+    "workspace too small or misaligned",
+    "HIP runtime error",
+    "no HIP device",
+    "allocation failure",
+};
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// packed image builder: offsets are in floats, every section 64-float (256 B) aligned
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t n) {
+        size_t o = off;
+        off = align_up(off + n, 64);
+        return o;
+    }
+};
+
+PackedLinear carve_linear(Carver& c, int N, int K) {
+    PackedLinear p;
+    p.N = N;
+    p.K = K;
+    p.Npad = round_up(N, kGemmBN);
+    p.Kpad = round_up(K, kGemmBK);
+    p.w_off = c.take((size_t)p.Npad * p.Kpad);
+    p.b_off = c.take((size_t)p.Npad);
+    return p;
+}
+
+void build_layout(tip_handle* h) {
+    const Dims& d = h->d;
+    Carver c;
+    PackedLayout& L = h->lay;
+    L.in_lin = carve_linear(c, d.D, d.In);
+    L.layers.resize(d.L);
+    for (int l = 0; l < d.L; ++l) {
+        PackedLayer& pl = L.layers[l];
+        pl.qkv = carve_linear(c, 3 * d.D, d.D);
+        pl.out = carve_linear(c, d.D, d.D);
+        pl.ff1 = carve_linear(c, d.F, d.D);
+        pl.ff2 = carve_linear(c, d.D, d.F);
+        pl.g1_off = c.take(d.D);
+        pl.be1_off = c.take(d.D);
+        pl.g2_off = c.take(d.D);
+        pl.be2_off = c.take(d.D);
+    }
+    if (d.with_rnn) {
+        L.rnn_ih = carve_linear(c, d.R, d.D);
+        L.whh_frag_off = c.take((size_t)d.R * d.R);
+        L.out_lin = carve_linear(c, d.S, d.R);
+    } else {
+        L.rnn_ih = PackedLinear{};
+        L.whh_frag_off = 0;
+        L.out_lin = carve_linear(c, d.S, d.D);
+    }
+    L.fused_floats = fused_packed_floats(d);
+    L.fused_off = c.take(L.fused_floats);
+    L.total_floats = c.off;
+}
+
+void build_tensor_table(tip_handle* h) {
+    const Dims& d = h->d;
+    auto add = [&](const std::string& n, int r, int cdim) {
+        h->tensor_names.push_back(n);
+        h->tensor_shapes.push_back({r, cdim});
+    };
+    add("in_linear.weight", d.D, d.In);
+    add("in_linear.bias", d.D, 0);
+    for (int l = 0; l < d.L; ++l) {
+        const std::string p = "tf_encode.layers." + std::to_string(l) + ".";
+        add(p + "self_attn.in_proj_weight", 3 * d.D, d.D);
+        add(p + "self_attn.in_proj_bias", 3 * d.D, 0);
+        add(p + "self_attn.out_proj.weight", d.D, d.D);
+        add(p + "self_attn.out_proj.bias", d.D, 0);
+        add(p + "linear1.weight", d.F, d.D);
+        add(p + "linear1.bias", d.F, 0);
+        add(p + "linear2.weight", d.D, d.F);
+        add(p + "linear2.bias", d.D, 0);
+        add(p + "norm1.weight", d.D, 0);
+        add(p + "norm1.bias", d.D, 0);
+        add(p + "norm2.weight", d.D, 0);
+        add(p + "norm2.bias", d.D, 0);
+    }
+    if (d.with_rnn) {
+        add("rnn.weight_ih_l0", d.R, d.D);
+        add("rnn.weight_hh_l0", d.R, d.R);
+        add("rnn.bias_ih_l0", d.R, 0);
+        add("rnn.bias_hh_l0", d.R, 0);
+        add("linear.weight", d.S, d.R);
+    } else {
+        add("linear.weight", d.S, d.D);
+    }
+    add("linear.bias", d.S, 0);
+}
+
+void pack_linear(float* img, const PackedLinear& p, const float* W, const float* b) {
+    float* w = img + p.w_off;
+    memset(w, 0, sizeof(float) * (size_t)p.Npad * p.Kpad);
+    for (int n = 0; n < p.N; ++n) memcpy(w + (size_t)n * p.Kpad, W + (size_t)n * p.K, sizeof(float) * p.K);
+    float* bb = img + p.b_off;
+    memset(bb, 0, sizeof(float) * p.Npad);
+    if (b) memcpy(bb, b, sizeof(float) * p.N);
+}
+
+Workspace carve_workspace(const Dims& d, int B, int T) {
+    Workspace w;
+    const size_t M = (size_t)B * T;
+    const size_t Mp = align_up(M, 16);
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off = align_up(off + n, 64); return o; };
+    int big = 3 * d.D;
+    if (d.F > big) big = d.F;
+    if (d.R > big) big = d.R;
+    if (d.InPad > big) big = d.InPad;
+    w.xa = take(Mp * d.D);
+    w.xb = take(Mp * d.D);
+    w.big = take(Mp * big);
+    w.att = take(Mp * d.D);
+    w.hall = take(Mp * (d.with_rnn ? d.R : 1));
+    w.flags = take(rnn_flag_words(B, T) + 64);
+    w.total_bytes = off * sizeof(float);
+    return w;
+}
+
+int fail_hip(tip_handle* h, hipError_t e, const char* where) {
+    h->last_hip_error = std::string(where) + ": " + hipGetErrorString(e);
+    return TIP_ERR_HIP;
+}
+
+struct StageScope {
+    tip_handle* h;
+    hipStream_t s;
+    int idx = -1;
+    StageScope(tip_handle* hh, hipStream_t ss, const char* name, int launches) : h(hh), s(ss) {
+        if (!h->profile) return;
+        for (size_t i = 0; i < h->timers.size(); ++i)
+            if (h->timers[i].name == name && !h->timers[i].used) { idx = (int)i; break; }
+        if (idx < 0) {
+            StageTimer t;
+            t.name = name;
+            hipEventCreate(&t.e0);
+            hipEventCreate(&t.e1);
+            h->timers.push_back(t);
+            idx = (int)h->timers.size() - 1;
+        }
+        h->timers[idx].used = true;
+        h->timers[idx].launches = launches;
+        hipEventRecord(h->timers[idx].e0, s);
+    }
+    ~StageScope() {
+        if (idx >= 0) hipEventRecord(h->timers[idx].e1, s);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+int tip_abi_version(void) { return TIP_ABI_VERSION; }
+
+const char* tip_strerror(int status) {
+    const int i = -status;
+    if (i < 0 || i >= (int)(sizeof(kStatusText) / sizeof(kStatusText[0]))) return "unknown status";
+    return kStatusText[i];
+}
+
+int tip_create(const tip_config* cfg, tip_handle** out) {
+    if (!cfg || !out) return TIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    Dims d{};
+    d.n_imu_total = cfg->input_size_imu + (cfg->with_acc_sum ? 18 : 0);  // simple_transformer_with_state.py:20-24
+    d.S = cfg->size_s;
+    d.In = d.n_imu_total + d.S;
+    d.InPad = round_up(d.In, kGemmBK);
+    d.D = cfg->tf_in_dim;
+    d.H = cfg->n_heads;
+    d.F = cfg->tf_hid_size;
+    d.L = cfg->tf_layers;
+    d.R = cfg->with_rnn ? cfg->rnn_hid_size : 0;
+    d.with_rnn = cfg->with_rnn ? 1 : 0;
+    d.t_max = cfg->t_max > 0 ? cfg->t_max : 40;
+    d.rootv0 = 18 * 6;       // :75
+    d.rootv1 = 18 * 6 + 3;
+    if (cfg->input_size_imu <= 0 || d.S <= 0 || d.D <= 0 || d.H <= 0 || d.F <= 0 || d.L < 0) return TIP_ERR_INVALID_ARG;
+    if (d.D % d.H) return TIP_ERR_INVALID_ARG;  // nn.MultiheadAttention asserts the same
+    d.dh = d.D / d.H;
+    if (d.D % 16 || d.F % 16 || (d.with_rnn && (d.R % 64)) ||
+        !(d.dh == 8 || d.dh == 16 || d.dh == 32 || d.dh == 64) || d.D > 2048 || d.S < d.rootv1)
+        return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (d.with_rnn && ((d.R / 16) + 3) / 4 > 8) return TIP_ERR_UNSUPPORTED_CONFIG;
+    // 1/sqrt(dh) is a power of two for dh in {16, 64}: fold it into W_q / b_q exactly
+    const float sc = 1.0f / sqrtf((float)d.dh);
+    d.fold_q_scale = (d.dh == 16 || d.dh == 64) ? 1 : 0;
+    d.q_scale = d.fold_q_scale ? 1.0f : sc;
+
+    tip_handle* h = new (std::nothrow) tip_handle();
+    if (!h) return TIP_ERR_ALLOC;
+    h->cfg = *cfg;
+    h->d = d;
+    build_tensor_table(h);
+    build_layout(h);
+    int dev = -1;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0) {
+        h->device = dev;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            h->num_cus = prop.multiProcessorCount;
+    } else {
+        (void)hipGetLastError();
+    }
+    *out = h;
+    return TIP_OK;
+}
+
+void tip_destroy(tip_handle* h) {
+    if (!h) return;
+    for (auto& t : h->timers) {
+        if (t.e0) hipEventDestroy(t.e0);
+        if (t.e1) hipEventDestroy(t.e1);
+    }
+    delete h;
+}
+
+const char* tip_last_hip_error(const tip_handle* h) { return h ? h->last_hip_error.c_str() : ""; }
+
+int tip_set_option(tip_handle* h, int option, int value) {
+    if (!h) return TIP_ERR_INVALID_ARG;
+    switch (option) {
+        case TIP_OPT_PLAN:
+            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED) return TIP_ERR_INVALID_ARG;
+            h->plan = value;
+            return TIP_OK;
+        case TIP_OPT_PROFILE: h->profile = value ? 1 : 0; return TIP_OK;
+        case TIP_OPT_RNN_CLUSTER:
+            if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) return TIP_ERR_INVALID_ARG;
+            h->rnn_cluster = value;
+            return TIP_OK;
+        default: return TIP_ERR_INVALID_ARG;
+    }
+}
+
+int tip_get_option(const tip_handle* h, int option, int* value) {
+    if (!h || !value) return TIP_ERR_INVALID_ARG;
+    switch (option) {
+        case TIP_OPT_PLAN: *value = h->plan; return TIP_OK;
+        case TIP_OPT_PROFILE: *value = h->profile; return TIP_OK;
+        case TIP_OPT_RNN_CLUSTER: *value = h->rnn_cluster; return TIP_OK;
+        default: return TIP_ERR_INVALID_ARG;
+    }
+}
+
+int tip_num_tensors(const tip_handle* h) { return h ? (int)h->tensor_names.size() : TIP_ERR_INVALID_ARG; }
+
+int tip_tensor_info(const tip_handle* h, int i, const char** name, int* rows, int* cols) {
+    if (!h || i < 0 || i >= (int)h->tensor_names.size()) return TIP_ERR_INVALID_ARG;
+    if (name) *name = h->tensor_names[i].c_str();
+    if (rows) *rows = h->tensor_shapes[i].first;
+    if (cols) *cols = h->tensor_shapes[i].second;
+    return TIP_OK;
+}
+
+int tip_packed_bytes(const tip_handle* h, size_t* bytes) {
+    if (!h || !bytes) return TIP_ERR_INVALID_ARG;
+    *bytes = h->lay.total_floats * sizeof(float);
+    return TIP_OK;
+}
+
+int tip_pack_weights(const tip_handle* h, const float* const* t, int n, void* packed_host_out, size_t bytes) {
+    if (!h || !t || !packed_host_out) return TIP_ERR_INVALID_ARG;
+    if (n != (int)h->tensor_names.size()) return TIP_ERR_INVALID_ARG;
+    if (bytes < h->lay.total_floats * sizeof(float)) return TIP_ERR_INVALID_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!t[i]) return TIP_ERR_INVALID_ARG;
+    const Dims& d = h->d;
+    const PackedLayout& L = h->lay;
+    float* img = static_cast<float*>(packed_host_out);
+    memset(img, 0, L.total_floats * sizeof(float));
+
+    // in_linear with the channel shuffle (:88-89) folded into its rows and the root-velocity zeroing (:75)
+    // folded into its columns: packed row a*H + b = reference row b*dh + a.
+    {
+        const PackedLinear& p = L.in_lin;
+        float* w = img + p.w_off;
+        float* b = img + p.b_off;
+        for (int a = 0; a < d.dh; ++a)
+            for (int hb = 0; hb < d.H; ++hb) {
+                const int nn = a * d.H + hb, old = hb * d.dh + a;
+                memcpy(w + (size_t)nn * p.Kpad, t[0] + (size_t)old * d.In, sizeof(float) * d.In);
+                for (int c = d.rootv0; c < d.rootv1; ++c) w[(size_t)nn * p.Kpad + d.n_imu_total + c] = 0.f;
+                b[nn] = t[1][old];
+            }
+    }
+    for (int l = 0; l < d.L; ++l) {
+        const float* const* lw = t + 2 + 12 * l;
+        const PackedLayer& pl = L.layers[l];
+        pack_linear(img, pl.qkv, lw[0], lw[1]);
+        if (d.fold_q_scale) {
+            const float sc = 1.0f / sqrtf((float)d.dh);  // power of two: exact
+            float* w = img + pl.qkv.w_off;
+            float* b = img + pl.qkv.b_off;
+            for (size_t i = 0; i < (size_t)d.D * pl.qkv.Kpad; ++i) w[i] *= sc;
+            for (int i = 0; i < d.D; ++i) b[i] *= sc;
+        }
+        pack_linear(img, pl.out, lw[2], lw[3]);
+        pack_linear(img, pl.ff1, lw[4], lw[5]);
+        pack_linear(img, pl.ff2, lw[6], lw[7]);
+        memcpy(img + pl.g1_off, lw[8], sizeof(float) * d.D);
+        memcpy(img + pl.be1_off, lw[9], sizeof(float) * d.D);
+        memcpy(img + pl.g2_off, lw[10], sizeof(float) * d.D);
+        memcpy(img + pl.be2_off, lw[11], sizeof(float) * d.D);
+    }
+    const float* const* tw = t + 2 + 12 * d.L;
+    if (d.with_rnn) {
+        pack_linear(img, L.rnn_ih, tw[0], tw[2]);
+        float* b = img + L.rnn_ih.b_off;
+        for (int i = 0; i < d.R; ++i) b[i] = tw[2][i] + tw[3][i];  // b_ih + b_hh
+        const int KB = d.R / 16;
+        float* f = img + L.whh_frag_off;
+        for (int nb = 0; nb < KB; ++nb)
+            for (int kb = 0; kb < KB; ++kb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s = 0; s < 4; ++s)
+                        f[((size_t)(nb * KB + kb) * 64 + lane) * 4 + s] =
+                            tw[1][(size_t)(nb * 16 + (lane & 15)) * d.R + kb * 16 + 4 * (lane >> 4) + s];
+        pack_linear(img, L.out_lin, tw[4], tw[5]);
+    } else {
+        pack_linear(img, L.out_lin, tw[0], tw[1]);
+    }
+    if (L.fused_floats) fused_pack(d, t, img + L.fused_off);
+    return TIP_OK;
+}
+
+int tip_attach_packed(tip_handle* h, const void* packed_device, size_t bytes) {
+    if (!h || !packed_device) return TIP_ERR_INVALID_ARG;
+    if (bytes < h->lay.total_floats * sizeof(float)) return TIP_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(packed_device) % 256) return TIP_ERR_INVALID_ARG;
+    h->packed_dev = static_cast<const float*>(packed_device);
+    return TIP_OK;
+}
+
+int tip_workspace_bytes(const tip_handle* h, int B, int T, size_t* bytes) {
+    if (!h || !bytes || B < 0 || T < 1) return TIP_ERR_INVALID_ARG;
+    *bytes = carve_workspace(h->d, B, T).total_bytes + 256;
+    return TIP_OK;
+}
+
+int tip_forward_count(const tip_handle* h, uint64_t* n) {
+    if (!h || !n) return TIP_ERR_INVALID_ARG;
+    *n = h->forward_count;
+    return TIP_OK;
+}
+
+int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches, int cap) {
+    if (!h || cap < 0) return TIP_ERR_INVALID_ARG;
+    int n = 0;
+    for (auto& t : h->timers) {
+        if (!t.used) continue;
+        if (n < cap) {
+            float v = 0.f;
+            hipError_t e = hipEventElapsedTime(&v, t.e0, t.e1);
+            if (e != hipSuccess) return fail_hip(h, e, "hipEventElapsedTime");
+            if (names) names[n] = t.name.c_str();
+            if (ms) ms[n] = v;
+            if (launches) launches[n] = t.launches;
+        }
+        ++n;
+    }
+    return n < cap ? n : cap;
+}
+
+int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
+                const float* keep_mask, float keep_scale, void* workspace, size_t workspace_bytes,
+                tip_stream_t stream) {
+    if (!h || !x_imu || !x_s || !y || B < 0 || T < 1) return TIP_ERR_INVALID_ARG;
+    if (T > h->d.t_max) return TIP_ERR_INVALID_ARG;
+    if ((flags & TIP_FWD_KEEP_MASK) && !keep_mask) return TIP_ERR_INVALID_ARG;
+    if (!h->packed_dev) return TIP_ERR_NOT_READY;
+    if (B == 0) return TIP_OK;
+    const Dims& d = h->d;
+    const Workspace ws = carve_workspace(d, B, T);
+    if (!workspace || reinterpret_cast<uintptr_t>(workspace) % 256 || workspace_bytes < ws.total_bytes)
+        return TIP_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float* P = h->packed_dev;
+    const PackedLayout& L = h->lay;
+    float* W0 = static_cast<float*>(workspace);
+    float* xa = W0 + ws.xa;
+    float* xb = W0 + ws.xb;
+    float* big = W0 + ws.big;
+    float* att = W0 + ws.att;
+    float* hall = W0 + ws.hall;
+    unsigned* rflags = reinterpret_cast<unsigned*>(W0 + ws.flags);
+    const int M = B * T;
+    const float* mask = (flags & TIP_FWD_KEEP_MASK) ? keep_mask : nullptr;
+    if (!mask) keep_scale = 1.f;
+    for (auto& t : h->timers) t.used = false;
+    hipError_t e;
+
+#define TIP_TRY(expr, what)                          \
+    do {                                             \
+        e = (expr);                                  \
+        if (e != hipSuccess) return fail_hip(h, e, what); \
+    } while (0)
+
+    int plan = h->plan;
+    if (plan == TIP_PLAN_AUTO) plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
+    if (plan == TIP_PLAN_FUSED && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+
+    float* enc_out = xa;  // encoder output [M, D]
+    if (plan == TIP_PLAN_FUSED) {
+        StageScope sc(h, s, "fused_encoder", 1);
+        TIP_TRY(launch_fused_encoder(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, xa, B, T, h->num_cus, s),
+                "fused_encoder");
+    } else {
+        {
+            StageScope sc(h, s, "prologue", 1);
+            TIP_TRY(launch_prologue(d, x_imu, x_s, mask, keep_scale, big, M, s), "prologue");
+        }
+        {
+            StageScope sc(h, s, "in_linear", 1);
+            TIP_TRY(launch_gemm(big, d.InPad, P + L.in_lin.w_off, L.in_lin.Kpad, P + L.in_lin.b_off, nullptr, 0, xa,
+                                d.D, M, d.D, L.in_lin.Npad, 0, s), "in_linear");
+        }
+        for (int l = 0; l < d.L; ++l) {
+            const PackedLayer& pl = L.layers[l];
+            {
+                StageScope sc(h, s, "qkv_gemm", 1);
+                TIP_TRY(launch_gemm(xa, d.D, P + pl.qkv.w_off, pl.qkv.Kpad, P + pl.qkv.b_off, nullptr, 0, big, 3 * d.D,
+                                    M, 3 * d.D, pl.qkv.Npad, 0, s), "qkv_gemm");
+            }
+            {
+                StageScope sc(h, s, "attention", 1);
+                TIP_TRY(launch_attention(d, big, att, B, T, s), "attention");
+            }
+            {
+                StageScope sc(h, s, "out_proj_gemm", 1);
+                TIP_TRY(launch_gemm(att, d.D, P + pl.out.w_off, pl.out.Kpad, P + pl.out.b_off, xa, d.D, xb, d.D, M, d.D,
+                                    pl.out.Npad, 2, s), "out_proj_gemm");
+            }
+            {
+                StageScope sc(h, s, "layernorm1", 1);
+                TIP_TRY(launch_layernorm(xb, P + pl.g1_off, P + pl.be1_off, M, d.D, s), "layernorm1");
+            }
+            {
+                StageScope sc(h, s, "ffn1_gemm", 1);
+                TIP_TRY(launch_gemm(xb, d.D, P + pl.ff1.w_off, pl.ff1.Kpad, P + pl.ff1.b_off, nullptr, 0, big, d.F, M,
+                                    d.F, pl.ff1.Npad, 1, s), "ffn1_gemm");
+            }
+            {
+                StageScope sc(h, s, "ffn2_gemm", 1);
+                TIP_TRY(launch_gemm(big, d.F, P + pl.ff2.w_off, pl.ff2.Kpad, P + pl.ff2.b_off, xb, d.D, xa, d.D, M, d.D,
+                                    pl.ff2.Npad, 2, s), "ffn2_gemm");
+            }
+            {
+                StageScope sc(h, s, "layernorm2", 1);
+                TIP_TRY(launch_layernorm(xa, P + pl.g2_off, P + pl.be2_off, M, d.D, s), "layernorm2");
+            }
+        }
+    }
+
+    const bool last_only = (flags & TIP_FWD_LAST_ROW_ONLY) != 0;
+    const float* head_in = enc_out;
+    int head_ld = d.D;
+    if (d.with_rnn) {
+        {
+            StageScope sc(h, s, "rnn_ih_gemm", 1);
+            TIP_TRY(launch_gemm(enc_out, d.D, P + L.rnn_ih.w_off, L.rnn_ih.Kpad, P + L.rnn_ih.b_off, nullptr, 0, big,
+                                d.R, M, d.R, L.rnn_ih.Npad, 0, s), "rnn_ih_gemm");
+        }
+        {
+            StageScope sc(h, s, "rnn_recurrence", 1);
+            int cluster = h->rnn_cluster;
+            if (cluster == 0) {
+                // auto: spread one window-tile over as many CUs as the tile count leaves idle
+                const int ntiles = (B + kRnnTile - 1) / kRnnTile;
+                cluster = 8;
+                while (cluster > 1 && ntiles * cluster > h->num_cus) cluster >>= 1;
+            }
+            TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, cluster, h->num_cus, s),
+                    "rnn_recurrence");
+        }
+        head_in = hall;
+        head_ld = d.R;
+    }
+    {
+        StageScope sc(h, s, "out_linear", 1);
+        if (last_only) {
+            // only row T-1 of every window is consumed by the streaming runner (real_time_runner_minimal.py:150)
+            TIP_TRY(launch_gemm(head_in + (size_t)(T - 1) * head_ld, T * head_ld, P + L.out_lin.w_off, L.out_lin.Kpad,
+                                P + L.out_lin.b_off, nullptr, 0, y, d.S, B, d.S, L.out_lin.Npad, 0, s), "out_linear");
+        } else {
+            TIP_TRY(launch_gemm(head_in, head_ld, P + L.out_lin.w_off, L.out_lin.Kpad, P + L.out_lin.b_off, nullptr, 0,
+                                y, d.S, M, d.S, L.out_lin.Npad, 0, s), "out_linear");
+        }
+    }
+#undef TIP_TRY
+    h->forward_count++;
+    return TIP_OK;
+}
+
+}  // extern "C"

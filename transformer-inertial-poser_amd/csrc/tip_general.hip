@@ -1,0 +1,481 @@
+// tip_general.hip — "general" execution plan: the forward pass as layer-by-layer gfx950 kernels.
+// Works for any configuration (paper, scaled, tiny); the fused plan (tip_fused.hip) specialises the
+// paper configuration.  All arithmetic is fp32; GEMMs run on v_mfma_f32_32x32x2_f32 /
+// v_mfma_f32_16x16x4_f32 (exact fp32, fmaf-chain numerics).
+//
+// Stage map (reference: /root/reference/simple_transformer_with_state.py)
+//   prologue_kernel     :63-78   clone, NaN scrub, past-state keep-mask, concat (root-vel zero :75 is folded
+//                                into the packed in_linear columns; the scrub must stay in-kernel: 0*NaN = NaN)
+//   gemm_kernel         :79 in_linear (+ channel shuffle :88-89 folded into its rows), QKV / out_proj /
+//                                linear1 / linear2 of every encoder layer (:91), RNN input projection (:99),
+//                                output projection (:102)
+//   attention_kernel    :85,:91  causal 16-head scaled-dot-product attention (torch functional.py SDPA)
+//   layernorm_kernel    :91      post-norm LayerNorm (eps 1e-5, biased variance)
+//   rnn_kernel          :98-99   h_t = tanh(ih_t + W_hh h_{t-1}), h_0 = 0
+#include "tip_internal.h"
+
+namespace tip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// prologue: U[row][0:InPad] = [x_imu | scrub(x_s) * mask * scale | 0-pad]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prologue_kernel(const float* __restrict__ x_imu,
+                                                       const float* __restrict__ x_s,
+                                                       const float* __restrict__ keep_mask, float keep_scale,
+                                                       float* __restrict__ U, int M, int NI, int S, int InPad) {
+    const size_t total = (size_t)M * InPad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / InPad);
+        const int c = (int)(i - (size_t)row * InPad);
+        float v = 0.f;
+        if (c < NI) {
+            v = x_imu[(size_t)row * NI + c];
+        } else if (c < NI + S) {
+            const size_t j = (size_t)row * S + (c - NI);
+            v = x_s[j];
+            if (v != v) v = 0.f;  // :65 x_s[x_s.isnan()] = 0
+            if (keep_mask) v = v * keep_mask[j] * keep_scale;  // :77 with an explicit Bernoulli keep-mask
+        }
+        U[i] = v;
+    }
+}
+
+hipError_t launch_prologue(const Dims& d, const float* x_imu, const float* x_s, const float* keep_mask,
+                           float keep_scale, float* U, int M, hipStream_t s) {
+    const size_t total = (size_t)M * d.InPad;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(prologue_kernel, dim3(blocks), dim3(256), 0, s, x_imu, x_s, keep_mask, keep_scale, U, M,
+                       d.n_imu_total, d.S, d.InPad);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM: C[M,N] = epi(A[M,K] * W[Npad,K]^T + bias (+res)).  128x128x16 block tile, 4 waves as 2x2, each wave
+// 64x64 = 2x2 tiles of v_mfma_f32_32x32x2_f32.  A and W tiles are staged through LDS k-major
+// ([k][row], row stride 130 floats) so both the transposing ds_write_b32 and the fragment ds_read_b32 are
+// bank-conflict free; global->register prefetch of tile k+1 overlaps the MFMAs of tile k.
+// ------------------------------------------------------------------------------------------------
+constexpr int LDT = kGemmBM + 2;
+
+template <int FLAGS>
+__global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W,
+                                                   int K, const float* __restrict__ bias,
+                                                   const float* __restrict__ res, int ldres, float* __restrict__ C,
+                                                   int ldc, int M, int N) {
+    __shared__ float As[2][kGemmBK][LDT];
+    __shared__ float Bs[2][kGemmBK][LDT];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int bm = blockIdx.y, bn = blockIdx.x;
+    const int lr = tid >> 2;         // 0..63
+    const int lk = (tid & 3) * 4;    // 0,4,8,12
+
+    const int arow0 = bm * kGemmBM + lr, arow1 = arow0 + 64;
+    const bool av0 = arow0 < M, av1 = arow1 < M;
+    const float* ap0 = A + (size_t)(av0 ? arow0 : 0) * lda + lk;
+    const float* ap1 = A + (size_t)(av1 ? arow1 : 0) * lda + lk;
+    const float* wp0 = W + (size_t)(bn * kGemmBN + lr) * K + lk;   // packed W is padded: always in range
+    const float* wp1 = wp0 + (size_t)64 * K;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ra0, ra1, rb0, rb1;
+    ra0 = av0 ? *reinterpret_cast<const float4*>(ap0) : zero4;
+    ra1 = av1 ? *reinterpret_cast<const float4*>(ap1) : zero4;
+    rb0 = *reinterpret_cast<const float4*>(wp0);
+    rb1 = *reinterpret_cast<const float4*>(wp1);
+
+    auto stage = [&](int buf) {
+        As[buf][lk + 0][lr] = ra0.x; As[buf][lk + 1][lr] = ra0.y; As[buf][lk + 2][lr] = ra0.z; As[buf][lk + 3][lr] = ra0.w;
+        As[buf][lk + 0][lr + 64] = ra1.x; As[buf][lk + 1][lr + 64] = ra1.y; As[buf][lk + 2][lr + 64] = ra1.z; As[buf][lk + 3][lr + 64] = ra1.w;
+        Bs[buf][lk + 0][lr] = rb0.x; Bs[buf][lk + 1][lr] = rb0.y; Bs[buf][lk + 2][lr] = rb0.z; Bs[buf][lk + 3][lr] = rb0.w;
+        Bs[buf][lk + 0][lr + 64] = rb1.x; Bs[buf][lk + 1][lr + 64] = rb1.y; Bs[buf][lk + 2][lr + 64] = rb1.z; Bs[buf][lk + 3][lr + 64] = rb1.w;
+    };
+    stage(0);
+    __syncthreads();
+
+    const int nk = K / kGemmBK;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            const int ko = (kt + 1) * kGemmBK;
+            ra0 = av0 ? *reinterpret_cast<const float4*>(ap0 + ko) : zero4;
+            ra1 = av1 ? *reinterpret_cast<const float4*>(ap1 + ko) : zero4;
+            rb0 = *reinterpret_cast<const float4*>(wp0 + ko);
+            rb1 = *reinterpret_cast<const float4*>(wp1 + ko);
+        }
+#pragma unroll
+        for (int kk = 0; kk < kGemmBK / 2; ++kk) {
+            const int k = kk * 2 + lhi;
+            float a[2], b[2];
+            a[0] = As[cur][k][wm * 64 + l31];
+            a[1] = As[cur][k][wm * 64 + 32 + l31];
+            b[0] = Bs[cur][k][wn * 64 + l31];
+            b[1] = Bs[cur][k][wn * 64 + 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = bn * kGemmBN + wn * 64 + j * 32 + l31;
+            if (col >= N) continue;
+            const float bv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bm * kGemmBM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (FLAGS & 2) v += res[(size_t)row * ldres + col];
+                    if (FLAGS & 1) v = v > 0.f ? v : 0.f;
+                    C[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_gemm(const float* A, int lda, const float* W, int Kpad, const float* bias, const float* res,
+                       int ldres, float* C, int ldc, int M, int N, int Npad, int flags, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    dim3 grid(Npad / kGemmBN, (M + kGemmBM - 1) / kGemmBM);
+    dim3 block(256);
+    switch (flags & 3) {
+        case 0: hipLaunchKernelGGL(gemm_kernel<0>, grid, block, 0, s, A, lda, W, Kpad, bias, res, ldres, C, ldc, M, N); break;
+        case 1: hipLaunchKernelGGL(gemm_kernel<1>, grid, block, 0, s, A, lda, W, Kpad, bias, res, ldres, C, ldc, M, N); break;
+        case 2: hipLaunchKernelGGL(gemm_kernel<2>, grid, block, 0, s, A, lda, W, Kpad, bias, res, ldres, C, ldc, M, N); break;
+        default: hipLaunchKernelGGL(gemm_kernel<3>, grid, block, 0, s, A, lda, W, Kpad, bias, res, ldres, C, ldc, M, N); break;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention: one wave per (window, head).  K and V of the head are staged in LDS; lane i owns query row i
+// (and i+64 when T > 64): q and the output accumulator live in registers, scores never leave the lane
+// (online softmax), so the row reductions need no cross-lane traffic at all.
+// ------------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B,
+                                                        int T, int H, float q_scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int waves = blockDim.x >> 6;
+    const int D = H * DH;
+    const int ld = 3 * D;
+    const int bh = blockIdx.x * waves + wave;
+    float* Ks = smem + (size_t)wave * 2 * T * DH;
+    float* Vs = Ks + (size_t)T * DH;
+    const bool active = bh < B * H;
+    const int b = active ? bh / H : 0, h = active ? bh % H : 0;
+    const float* base = qkv + (size_t)b * T * ld + h * DH;
+    if (active) {
+        constexpr int V4 = DH / 4;
+        for (int f = lane; f < T * V4; f += 64) {
+            const int j = f / V4, e = (f % V4) * 4;
+            *reinterpret_cast<float4*>(Ks + j * DH + e) = *reinterpret_cast<const float4*>(base + (size_t)j * ld + D + e);
+            *reinterpret_cast<float4*>(Vs + j * DH + e) = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * D + e);
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    for (int r0 = 0; r0 < T; r0 += 64) {
+        const int i = r0 + lane;
+        const bool rv = i < T;
+        float q[DH], o[DH];
+        const float* qp = base + (size_t)(rv ? i : 0) * ld;
+#pragma unroll
+        for (int e = 0; e < DH; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(qp + e);
+            q[e] = t.x * q_scale; q[e + 1] = t.y * q_scale; q[e + 2] = t.z * q_scale; q[e + 3] = t.w * q_scale;
+        }
+#pragma unroll
+        for (int e = 0; e < DH; ++e) o[e] = 0.f;
+        float m = -INFINITY, l = 0.f;
+        const int jmax = min(T, r0 + 64);  // keys needed by the last row of this chunk
+        for (int j = 0; j < jmax; ++j) {
+            const float* kj = Ks + j * DH;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; e += 4) {
+                const float4 kv = *reinterpret_cast<const float4*>(kj + e);
+                s0 = fmaf(q[e], kv.x, s0); s1 = fmaf(q[e + 1], kv.y, s1);
+                s2 = fmaf(q[e + 2], kv.z, s2); s3 = fmaf(q[e + 3], kv.w, s3);
+            }
+            const float sc = (s0 + s1) + (s2 + s3);
+            if (j <= i) {  // causal mask (:56-58): key j visible to query i iff j <= i
+                const float mn = fmaxf(m, sc);
+                const float corr = expf(m - mn);   // exp(-inf) = 0 on the first key
+                const float p = expf(sc - mn);
+                l = l * corr + p;
+                const float* vj = Vs + j * DH;
+#pragma unroll
+                for (int e = 0; e < DH; e += 4) {
+                    const float4 vv = *reinterpret_cast<const float4*>(vj + e);
+                    o[e] = fmaf(o[e], corr, p * vv.x); o[e + 1] = fmaf(o[e + 1], corr, p * vv.y);
+                    o[e + 2] = fmaf(o[e + 2], corr, p * vv.z); o[e + 3] = fmaf(o[e + 3], corr, p * vv.w);
+                }
+                m = mn;
+            }
+        }
+        if (rv) {
+            const float inv = 1.f / l;
+            float* op = out + (size_t)(b * T + i) * D + h * DH;
+#pragma unroll
+            for (int e = 0; e < DH; e += 4)
+                *reinterpret_cast<float4*>(op + e) = make_float4(o[e] * inv, o[e + 1] * inv, o[e + 2] * inv, o[e + 3] * inv);
+        }
+    }
+}
+
+hipError_t launch_attention(const Dims& d, const float* qkv, float* out, int B, int T, hipStream_t s) {
+    const size_t per_wave = (size_t)2 * T * d.dh * sizeof(float);
+    int waves = 4;
+    while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
+    const int nbh = B * d.H;
+    dim3 grid((nbh + waves - 1) / waves), block(64 * waves);
+    const size_t smem = per_wave * waves;
+    switch (d.dh) {
+        case 8: hipLaunchKernelGGL(attention_kernel<8>, grid, block, smem, s, qkv, out, B, T, d.H, d.q_scale); break;
+        case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, block, smem, s, qkv, out, B, T, d.H, d.q_scale); break;
+        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, block, smem, s, qkv, out, B, T, d.H, d.q_scale); break;
+        case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, block, smem, s, qkv, out, B, T, d.H, d.q_scale); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (in place): one wave per row, two-pass in registers, wave-shuffle reductions.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int NV>  // float4 per lane: D <= NV*256
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ be, int M, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float* xr = x + (size_t)row * D;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < D ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+            q += (a * a + b * b) + (cc * cc + dd * dd);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < D) {
+            const float4 gg = *reinterpret_cast<const float4*>(g + c);
+            const float4 bb = *reinterpret_cast<const float4*>(be + c);
+            float4 o;
+            o.x = (v[i].x - mean) * rstd * gg.x + bb.x;
+            o.y = (v[i].y - mean) * rstd * gg.y + bb.y;
+            o.z = (v[i].z - mean) * rstd * gg.z + bb.z;
+            o.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+            *reinterpret_cast<float4*>(xr + c) = o;
+        }
+    }
+}
+
+hipError_t launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    dim3 grid((M + 3) / 4), block(256);
+    if (D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, g, b, M, D);
+    else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, g, b, M, D);
+    else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, g, b, M, D);
+    else if (D <= 2048) hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, s, x, g, b, M, D);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// RNN recurrence.  A tile of 16 windows is the M dimension of v_mfma_f32_16x16x4_f32; the 40 (T) steps are
+// serial.  `cluster` workgroups share one tile, each owning R/cluster output columns; after every step the
+// column slices are exchanged through HALL itself (the [B,T,R] output the out-linear GEMM reads next) with
+// an agent-scope release / counter / acquire hand-off (cdna_hip_programming.md section 6 Guideline 16).
+// W_hh is pre-packed in B-fragment order: one coalesced 1-KiB dwordx4 load per 16x16 block per wave.
+//   whh_frag[((nb*KB + kb)*64 + lane)*4 + s] = W_hh[nb*16 + (lane&15)][kb*16 + 4*(lane>>4) + s]
+// and the A fragment of MFMA step s is h[lane&15][kb*16 + 4*(lane>>4) + s]  (same k permutation on both
+// operands, so each group of 4 MFMAs covers 16 consecutive k).
+// ------------------------------------------------------------------------------------------------
+template <int NBW>  // 16-column blocks per wave: R / (16 * 4 * cluster)
+__global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, const float* __restrict__ whh_frag,
+                                                  float* __restrict__ hall, unsigned* __restrict__ flags, int B, int T,
+                                                  int R, int cluster, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // h tile [16][R+4]
+    const int LDH = R + 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KB = R / 16;                 // k blocks
+    const int cid = blockIdx.x % cluster;  // member index inside the cluster
+    const int group = blockIdx.x / cluster;
+    const int ngroups = gridDim.x / cluster;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nb0 = (cid * 4 + wave) * NBW;  // first global column block of this wave
+    const float4* wf = reinterpret_cast<const float4*>(whh_frag) + (size_t)nb0 * KB * 64 + lane;
+
+    for (int tile = group; tile < ntiles; tile += ngroups) {
+        const int b0 = tile * kRnnTile;
+        for (int i = tid; i < kRnnTile * LDH; i += 256) smem[i] = 0.f;  // h_{-1} = 0
+        __syncthreads();
+        for (int t = 0; t < T; ++t) {
+            // input projection of this step (bias b_ih + b_hh already folded in): issued early, used after the MFMAs
+            float ihv[NBW][4];
+#pragma unroll
+            for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int bb = b0 + lg * 4 + r;
+                    ihv[n][r] = bb < B ? ih[((size_t)bb * T + t) * R + (nb0 + n) * 16 + l15] : 0.f;
+                }
+            if (t > 0 && cluster > 1) {
+                // wait for every member's slice of h_{t-1}, then pull the full [16][R] tile from HALL
+                if (tid == 0) {
+                    unsigned* f = flags + (size_t)tile * T + (t - 1);
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)cluster)
+                        __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                for (int i = tid; i < kRnnTile * (R / 4); i += 256) {
+                    const int m = i / (R / 4), c = (i % (R / 4)) * 4;
+                    const int bb = b0 + m;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (bb < B) v = *reinterpret_cast<const float4*>(hall + ((size_t)bb * T + (t - 1)) * R + c);
+                    *reinterpret_cast<float4*>(smem + m * LDH + c) = v;
+                }
+                __syncthreads();
+            }
+            f32x4 acc[NBW];
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (t > 0) {
+                float4 wc[NBW], wn[NBW];
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) wc[n] = wf[(size_t)(n * KB) * 64];
+                for (int kb = 0; kb < KB; ++kb) {
+                    const int kn = kb + 1 < KB ? kb + 1 : kb;
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n) wn[n] = wf[(size_t)(n * KB + kn) * 64];
+                    const float4 a = *reinterpret_cast<const float4*>(smem + l15 * LDH + kb * 16 + lg * 4);
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wc[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wc[n].y, acc[n], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wc[n].z, acc[n], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wc[n].w, acc[n], 0, 0, 0);
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n) wc[n] = wn[n];
+                }
+            }
+            __syncthreads();  // everyone is done reading h_{t-1} from LDS
+            // epilogue: D layout of 16x16: col = lane&15, row = 4*(lane>>4) + r
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) {
+                const int col = (nb0 + n) * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = lg * 4 + r;
+                    const int bb = b0 + m;
+                    float hv = 0.f;
+                    if (bb < B) {
+                        hv = tanhf(acc[n][r] + ihv[n][r]);
+                        hall[((size_t)bb * T + t) * R + col] = hv;
+                    }
+                    smem[m * LDH + col] = hv;
+                }
+            }
+            if (cluster > 1) {
+                // publish this slice of h_t: drain stores, workgroup barrier, one agent-scope release, counter++
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(flags + (size_t)tile * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+    }
+}
+
+size_t rnn_flag_words(int B, int T) { return (size_t)((B + kRnnTile - 1) / kRnnTile) * (size_t)T; }
+
+hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
+                      int T, int cluster, int num_cus, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    const int R = d.R;
+    const int ntiles = (B + kRnnTile - 1) / kRnnTile;
+    if (cluster < 1) cluster = 1;
+    const int KB = R / 16;
+    while (cluster > 1 && (KB % (4 * cluster))) cluster >>= 1;
+    if (KB % (4 * cluster)) return hipErrorInvalidValue;
+    const int nbw = KB / (4 * cluster);
+    int groups = ntiles;
+    if (cluster > 1) {
+        // every workgroup of a cluster must be co-resident: keep the grid within one workgroup per CU
+        const int maxg = num_cus / cluster > 0 ? num_cus / cluster : 1;
+        if (groups > maxg) groups = maxg;
+        hipError_t e = hipMemsetAsync(flags, 0, (size_t)ntiles * T * sizeof(unsigned), s);
+        if (e != hipSuccess) return e;
+    }
+    const size_t smem = (size_t)kRnnTile * (R + 4) * sizeof(float);
+    const dim3 grid(groups * cluster), block(256);
+#define TIP_RNN_CASE(N) \
+    case N: hipLaunchKernelGGL(rnn_kernel<N>, grid, block, smem, s, ih, whh_frag, hall, flags, B, T, R, cluster, ntiles); break;
+    switch (nbw) {
+        TIP_RNN_CASE(1) TIP_RNN_CASE(2) TIP_RNN_CASE(3) TIP_RNN_CASE(4) TIP_RNN_CASE(5) TIP_RNN_CASE(6)
+        TIP_RNN_CASE(7) TIP_RNN_CASE(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef TIP_RNN_CASE
+    return hipGetLastError();
+}
+
+}  // namespace tip

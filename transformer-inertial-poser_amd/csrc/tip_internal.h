@@ -1,0 +1,112 @@
+// tip_internal.h — shared between the C-ABI translation unit and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/tip_hip.h"
+
+namespace tip {
+
+constexpr int kGemmBM = 128;   // general GEMM block tile (rows)
+constexpr int kGemmBN = 128;   // general GEMM block tile (cols); packed weights are padded to this
+constexpr int kGemmBK = 16;    // K tile; packed K is padded to this
+constexpr int kRnnTile = 16;   // windows per RNN tile (= MFMA 16x16x4 row count)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+struct Dims {
+    int n_imu_total;  // input_size_imu (+18)
+    int S;            // size_s
+    int In;           // n_imu_total + S
+    int InPad;        // In rounded to kGemmBK
+    int D, H, dh, F, L, R;
+    int with_rnn;
+    int t_max;
+    int rootv0, rootv1;  // x_s columns zeroed at simple_transformer_with_state.py:75
+    float q_scale;       // applied inside the attention kernel (1 when folded into W_q)
+    int fold_q_scale;
+};
+
+// One GEMM operand in the packed image: W [Npad][Kpad] row-major (zero padded) + bias [Npad].
+struct PackedLinear {
+    size_t w_off;   // float offset into the packed image
+    size_t b_off;
+    int N, K, Npad, Kpad;
+};
+
+struct PackedLayer {
+    PackedLinear qkv, out, ff1, ff2;
+    size_t g1_off, be1_off, g2_off, be2_off;  // [D] each
+};
+
+struct PackedLayout {
+    PackedLinear in_lin;
+    std::vector<PackedLayer> layers;
+    PackedLinear rnn_ih;       // bias = b_ih + b_hh
+    size_t whh_frag_off;       // W_hh in MFMA 16x16x4 B-fragment order: [R/16 nb][R/16 kb][64 lanes][4]
+    PackedLinear out_lin;
+    // fused-plan section (paper configuration): weights in 16x16x4 B-fragment order, see tip_fused.hip
+    size_t fused_off;
+    size_t fused_floats;
+    size_t total_floats;
+};
+
+// Workspace carve-up for the general plan (float offsets), M = B*T rows.
+struct Workspace {
+    size_t xa, xb, big, att, hall, flags;  // float offsets
+    size_t total_bytes;
+};
+
+struct StageTimer {
+    std::string name;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int launches = 0;
+    bool used = false;
+};
+
+}  // namespace tip
+
+struct tip_handle {
+    tip_config cfg;
+    tip::Dims d;
+    tip::PackedLayout lay;
+    std::vector<std::string> tensor_names;
+    std::vector<std::pair<int, int>> tensor_shapes;  // rows, cols (cols = 0 for 1-D)
+    const float* packed_dev = nullptr;
+    int device = -1;
+    int num_cus = 256;
+    int plan = TIP_PLAN_AUTO;
+    int profile = 0;
+    int rnn_cluster = 0;
+    uint64_t forward_count = 0;
+    std::string last_hip_error;
+    std::vector<tip::StageTimer> timers;
+    int cur_timer = -1;
+};
+
+namespace tip {
+
+// ---- launchers implemented in tip_general.hip (all asynchronous on `s`) ----
+hipError_t launch_prologue(const Dims& d, const float* x_imu, const float* x_s, const float* keep_mask,
+                           float keep_scale, float* U, int M, hipStream_t s);
+// C[M,N] = epi(A[M,K(lda)] * W[Npad,Kpad]^T + bias (+ res)); flags: 1 = relu, 2 = residual
+hipError_t launch_gemm(const float* A, int lda, const float* W, int Kpad, const float* bias, const float* res,
+                       int ldres, float* C, int ldc, int M, int N, int Npad, int flags, hipStream_t s);
+hipError_t launch_attention(const Dims& d, const float* qkv, float* out, int B, int T, hipStream_t s);
+hipError_t launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s);
+hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
+                      int T, int cluster, int num_cus, hipStream_t s);
+size_t rnn_flag_words(int B, int T);
+
+// ---- fused plan (tip_fused.hip) ----
+bool fused_supported(const Dims& d, int T);
+size_t fused_packed_floats(const Dims& d);
+void fused_pack(const Dims& d, const float* const* tensors, float* dst);
+hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
+                                const float* keep_mask, float keep_scale, float* xout, int B, int T, int num_cus,
+                                hipStream_t s);
+
+}  // namespace tip

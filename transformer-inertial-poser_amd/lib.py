@@ -1,0 +1,178 @@
+"""ctypes binding of libtip_hip.so (include/tip_hip.h).  No fallback: if the library is missing or fails to
+load, everything that needs it raises TipLibraryError."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import List, Optional, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libtip_hip.so")
+
+TIP_FWD_LAST_ROW_ONLY = 0x1
+TIP_FWD_KEEP_MASK = 0x2
+TIP_PLAN_AUTO, TIP_PLAN_GENERAL, TIP_PLAN_FUSED = 0, 1, 2
+TIP_OPT_PLAN, TIP_OPT_PROFILE, TIP_OPT_RNN_CLUSTER = 1, 2, 3
+
+# every symbol include/tip_hip.h declares (tests check the .so exports exactly these)
+EXPORTS = (
+    "tip_abi_version", "tip_create", "tip_destroy", "tip_strerror", "tip_last_hip_error", "tip_set_option",
+    "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
+    "tip_attach_packed", "tip_workspace_bytes", "tip_forward", "tip_forward_count", "tip_profile_read",
+)
+
+
+class TipLibraryError(RuntimeError):
+    pass
+
+
+class TipStatusError(RuntimeError):
+    def __init__(self, status: int, text: str):
+        super().__init__(f"libtip_hip: {text} (status {status})")
+        self.status = status
+
+
+class TipConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "input_size_imu", "size_s", "rnn_hid_size", "tf_hid_size", "tf_in_dim", "n_heads", "tf_layers",
+        "with_rnn", "with_acc_sum", "t_max")]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into csrc/libtip_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else []) + ["libtip_hip.so"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+    if res.returncode != 0:
+        raise TipLibraryError("building libtip_hip.so failed:\n" + res.stdout[-4000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TipLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C transformer-inertial-poser_amd/csrc`).  There is no non-HIP fallback for the forward path.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise TipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    lib.tip_abi_version.restype = i32
+    lib.tip_create.argtypes = [ctypes.POINTER(TipConfig), ctypes.POINTER(vp)]
+    lib.tip_destroy.argtypes = [vp]
+    lib.tip_destroy.restype = None
+    lib.tip_strerror.argtypes = [i32]
+    lib.tip_strerror.restype = ctypes.c_char_p
+    lib.tip_last_hip_error.argtypes = [vp]
+    lib.tip_last_hip_error.restype = ctypes.c_char_p
+    lib.tip_set_option.argtypes = [vp, i32, i32]
+    lib.tip_get_option.argtypes = [vp, i32, ctypes.POINTER(i32)]
+    lib.tip_num_tensors.argtypes = [vp]
+    lib.tip_tensor_info.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    lib.tip_packed_bytes.argtypes = [vp, ctypes.POINTER(sz)]
+    lib.tip_pack_weights.argtypes = [vp, ctypes.POINTER(vp), i32, vp, sz]
+    lib.tip_attach_packed.argtypes = [vp, vp, sz]
+    lib.tip_workspace_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
+    lib.tip_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, ctypes.c_float, vp, sz, vp]
+    lib.tip_forward_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.tip_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
+                                     ctypes.POINTER(i32), i32]
+    for name in EXPORTS:
+        if name not in ("tip_destroy", "tip_strerror", "tip_last_hip_error"):
+            getattr(lib, name).restype = i32
+    if lib.tip_abi_version() != 1:
+        raise TipLibraryError("libtip_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class Handle:
+    """Owns one tip_handle (one per GPU)."""
+
+    def __init__(self, cfg: TipConfig):
+        self.lib = load()
+        self._h = ctypes.c_void_p()
+        self.cfg = cfg
+        self._check(self.lib.tip_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+
+    def _check(self, status: int) -> int:
+        if status < 0:
+            text = self.lib.tip_strerror(status).decode()
+            if status == -5 and self._h:
+                text += " — " + self.lib.tip_last_hip_error(self._h).decode()
+            raise TipStatusError(status, text)
+        return status
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.tip_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameters ---------------------------------------------------------------------------------
+    def tensor_table(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        out = []
+        for i in range(self._check(self.lib.tip_num_tensors(self._h))):
+            name = ctypes.c_char_p()
+            r, c = ctypes.c_int(), ctypes.c_int()
+            self._check(self.lib.tip_tensor_info(self._h, i, ctypes.byref(name), ctypes.byref(r), ctypes.byref(c)))
+            out.append((name.value.decode(), (r.value, c.value) if c.value else (r.value,)))
+        return out
+
+    def packed_bytes(self) -> int:
+        n = ctypes.c_size_t()
+        self._check(self.lib.tip_packed_bytes(self._h, ctypes.byref(n)))
+        return n.value
+
+    def pack_weights(self, host_ptrs: List[int], out_ptr: int, out_bytes: int):
+        arr = (ctypes.c_void_p * len(host_ptrs))(*host_ptrs)
+        self._check(self.lib.tip_pack_weights(self._h, arr, len(host_ptrs), ctypes.c_void_p(out_ptr), out_bytes))
+
+    def attach_packed(self, dev_ptr: int, nbytes: int):
+        self._check(self.lib.tip_attach_packed(self._h, ctypes.c_void_p(dev_ptr), nbytes))
+
+    # -- forward ------------------------------------------------------------------------------------
+    def workspace_bytes(self, B: int, T: int) -> int:
+        n = ctypes.c_size_t()
+        self._check(self.lib.tip_workspace_bytes(self._h, B, T, ctypes.byref(n)))
+        return n.value
+
+    def forward(self, x_imu: int, x_s: int, y: int, B: int, T: int, flags: int, keep_mask: Optional[int],
+                keep_scale: float, workspace: int, workspace_bytes: int, stream: int):
+        self._check(self.lib.tip_forward(self._h, x_imu, x_s, y, B, T, flags, keep_mask, keep_scale, workspace,
+                                         workspace_bytes, stream))
+
+    def forward_count(self) -> int:
+        n = ctypes.c_uint64()
+        self._check(self.lib.tip_forward_count(self._h, ctypes.byref(n)))
+        return n.value
+
+    def set_option(self, opt: int, value: int):
+        self._check(self.lib.tip_set_option(self._h, opt, value))
+
+    def get_option(self, opt: int) -> int:
+        v = ctypes.c_int()
+        self._check(self.lib.tip_get_option(self._h, opt, ctypes.byref(v)))
+        return v.value
+
+    def profile_read(self, cap: int = 128):
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_float * cap)()
+        launches = (ctypes.c_int * cap)()
+        n = self._check(self.lib.tip_profile_read(self._h, names, ms, launches, cap))
+        return [(names[i].decode(), float(ms[i]), int(launches[i])) for i in range(n)]

@@ -1,0 +1,287 @@
+"""Drop-in for the reference module of the same name: `from simple_transformer_with_state import TF_RNN_Past_State`.
+
+Mirrors the reference's module surface (/root/reference/simple_transformer_with_state.py):
+  * constructor signature                                   (:9-17)
+  * state_dict() keys / shapes / order — 56 tensors         (:22-46)
+  * forward(x_imu [B,T,72(+18)], x_s [B,T,size_s]) -> [B,T,size_s], inputs untouched, NaNs in x_s scrubbed (:60-102)
+  * nn.Module services the callers use: .cuda(), .eval()/.train(), .parameters(), load_state_dict, torch.save
+
+Execution:
+  * inference (no autograd) on a ROCm device, fp32  ->  hand-written HIP kernels through the C-ABI
+    (csrc/libtip_hip.so, include/tip_hip.h).  No fallback: a missing library or a CPU tensor raises.
+  * autograd requested (train_model.py:175,192)      ->  a torch-op composite on the caller's device so the
+    training script keeps working; it is NOT the accelerated path (backward kernels are SURVEY.md 8f-2).
+
+Dropout semantics kept from the reference: `nn.Dropout(p)(x)` is constructed inside forward (:73,:77), i.e. it is
+always in training mode, so past_state_dropout / in_dropout are live even under .eval().  The HIP path draws the
+Bernoulli keep-mask with torch's device RNG and hands it to the kernel (TIP_FWD_KEEP_MASK).
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import lib as _lib
+
+
+class _Leaf(nn.Module):
+    """A namespace of explicitly registered parameters (keeps the reference's state-dict key names)."""
+
+    def __init__(self, **shapes):
+        super().__init__()
+        for name, shape in shapes.items():
+            self.register_parameter(name, nn.Parameter(torch.empty(shape)))
+
+
+class _EncoderLayerParams(nn.Module):
+    def __init__(self, d_model: int, d_ff: int):
+        super().__init__()
+        self.self_attn = _Leaf(in_proj_weight=(3 * d_model, d_model), in_proj_bias=(3 * d_model,))
+        self.self_attn.out_proj = _Leaf(weight=(d_model, d_model), bias=(d_model,))
+        self.linear1 = _Leaf(weight=(d_ff, d_model), bias=(d_ff,))
+        self.linear2 = _Leaf(weight=(d_model, d_ff), bias=(d_model,))
+        self.norm1 = _Leaf(weight=(d_model,), bias=(d_model,))
+        self.norm2 = _Leaf(weight=(d_model,), bias=(d_model,))
+
+
+def _uniform_(t: torch.Tensor, bound: float):
+    with torch.no_grad():
+        t.uniform_(-bound, bound)
+
+
+class TF_RNN_Past_State(nn.Module):
+    def __init__(self, input_size_imu, size_s, rnn_hid_size, tf_hid_size, tf_in_dim, n_heads, tf_layers,
+                 dropout, in_dropout, past_state_dropout, with_rnn=True, with_acc_sum=False):
+        super().__init__()
+        self.input_size_imu = int(input_size_imu)
+        self.size_s = int(size_s)
+        self.rnn_hid_size = int(rnn_hid_size)
+        self.tf_hid_size = int(tf_hid_size)
+        self.tf_in_dim = int(tf_in_dim)
+        self.n_heads = int(n_heads)
+        self.tf_layers = int(tf_layers)
+        self.dropout = float(dropout)
+        self.in_dropout = float(in_dropout)
+        self.past_state_dropout = float(past_state_dropout)
+        self.with_rnn = bool(with_rnn)
+        self.with_acc_sum = bool(with_acc_sum)
+        if self.tf_in_dim % self.n_heads:
+            raise AssertionError("embed_dim must be divisible by num_heads")
+
+        n_in = self.input_size_imu + self.size_s + (18 if self.with_acc_sum else 0)
+        D, Fh, R, S = self.tf_in_dim, self.tf_hid_size, self.rnn_hid_size, self.size_s
+        if self.with_acc_sum:
+            print("model with acc sum")
+        self.in_linear = _Leaf(weight=(D, n_in), bias=(D,))
+        self.tf_encode = nn.Module()
+        self.tf_encode.layers = nn.ModuleList([_EncoderLayerParams(D, Fh) for _ in range(self.tf_layers)])
+        if self.with_rnn:
+            self.rnn = _Leaf(weight_ih_l0=(R, D), weight_hh_l0=(R, R), bias_ih_l0=(R,), bias_hh_l0=(R,))
+            self.linear = _Leaf(weight=(S, R), bias=(S,))
+        else:
+            print("no RNN layer")
+            self.rnn = None
+            self.linear = _Leaf(weight=(S, D), bias=(S,))
+        self.reset_parameters()
+        print("number of parameters: %e", sum(p.numel() for p in self.parameters()))
+
+        # HIP-side state (created lazily on the first accelerated forward)
+        self._handle: Optional[_lib.Handle] = None
+        self._packed_dev: Optional[torch.Tensor] = None
+        self._packed_key = None
+        self._workspace: Optional[torch.Tensor] = None
+        self._frozen = False
+        self._warned_autograd = False
+        self.t_max = 80
+
+    # ------------------------------------------------------------------------------------------
+    # initialisation: same distributions torch's nn.Linear / nn.MultiheadAttention / nn.LayerNorm / nn.RNN use
+    # ------------------------------------------------------------------------------------------
+    def reset_parameters(self):
+        def linear_(leaf):
+            fan_in = leaf.weight.shape[1]
+            _uniform_(leaf.weight, 1.0 / math.sqrt(fan_in))
+            _uniform_(leaf.bias, 1.0 / math.sqrt(fan_in))
+
+        linear_(self.in_linear)
+        for layer in self.tf_encode.layers:
+            w = layer.self_attn.in_proj_weight
+            _uniform_(w, math.sqrt(6.0 / (w.shape[0] + w.shape[1])))  # xavier_uniform_
+            with torch.no_grad():
+                layer.self_attn.in_proj_bias.zero_()
+                layer.self_attn.out_proj.bias.zero_()
+                layer.norm1.weight.fill_(1.0), layer.norm1.bias.zero_()
+                layer.norm2.weight.fill_(1.0), layer.norm2.bias.zero_()
+            _uniform_(layer.self_attn.out_proj.weight, 1.0 / math.sqrt(self.tf_in_dim))
+            linear_(layer.linear1)
+            linear_(layer.linear2)
+        if self.rnn is not None:
+            for p in self.rnn.parameters():
+                _uniform_(p, 1.0 / math.sqrt(self.rnn_hid_size))
+        linear_(self.linear)
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def forward(self, x_imu, x_s):
+        if self._wants_torch_ops(x_imu, x_s):
+            return self._forward_torch_ops(x_imu, x_s)
+        return self._forward_hip(x_imu, x_s, last_row_only=False)
+
+    def forward_last(self, x_imu, x_s):
+        """Row T-1 of every window only ([B, size_s]) — what RTRunnerMin.step consumes
+        (real_time_runner_minimal.py:150).  Extension over the reference API; same numerics as forward()[:, -1]."""
+        if self._wants_torch_ops(x_imu, x_s):
+            return self._forward_torch_ops(x_imu, x_s)[:, -1]
+        return self._forward_hip(x_imu, x_s, last_row_only=True)
+
+    def _wants_torch_ops(self, x_imu, x_s) -> bool:
+        if torch.is_grad_enabled() and (x_imu.requires_grad or x_s.requires_grad or
+                                        any(p.requires_grad for p in self.parameters())):
+            if not self._warned_autograd:
+                warnings.warn("tip_amd: autograd requested — using the torch-op training composite; the HIP kernels "
+                              "cover the inference forward only (call under torch.no_grad() for the accelerated path)")
+                self._warned_autograd = True
+            return True
+        if self.training and self.dropout > 0.0:
+            return True  # encoder dropout (p=dropout) is live in train mode: only the torch-op path draws it
+        return False
+
+    # -- HIP path -------------------------------------------------------------------------------
+    def _tip_config(self) -> _lib.TipConfig:
+        return _lib.TipConfig(self.input_size_imu, self.size_s, self.rnn_hid_size, self.tf_hid_size, self.tf_in_dim,
+                              self.n_heads, self.tf_layers, 1 if self.with_rnn else 0, 1 if self.with_acc_sum else 0,
+                              int(self.t_max))
+
+    def _ensure_handle(self) -> _lib.Handle:
+        if self._handle is None:
+            self._handle = _lib.Handle(self._tip_config())
+            names = [n for n, _ in self._handle.tensor_table()]
+            if names != list(self.state_dict().keys()):
+                raise RuntimeError("libtip_hip tensor table does not match the module's state_dict order")
+        return self._handle
+
+    def _param_key(self, device):
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def pack_host(self) -> torch.Tensor:
+        """Build the packed weight image (uint8 CPU tensor) from the current parameters."""
+        h = self._ensure_handle()
+        host = [p.detach().to("cpu", torch.float32).contiguous() for p in self.state_dict().values()]
+        out = torch.empty(h.packed_bytes(), dtype=torch.uint8)
+        h.pack_weights([t.data_ptr() for t in host], out.data_ptr(), out.numel())
+        return out
+
+    def attach_packed(self, packed_dev: torch.Tensor):
+        """Point the kernels at a packed image already resident on this GPU (e.g. received by RCCL broadcast)."""
+        h = self._ensure_handle()
+        assert packed_dev.is_cuda and packed_dev.dtype == torch.uint8 and packed_dev.is_contiguous()
+        h.attach_packed(packed_dev.data_ptr(), packed_dev.numel())
+        self._packed_dev = packed_dev
+        self._packed_key = self._param_key(packed_dev.device)
+
+    def refresh_packed(self, device=None):
+        device = device if device is not None else next(self.parameters()).device
+        self.attach_packed(self.pack_host().to(device, non_blocking=False))
+
+    def freeze_packed(self, frozen: bool = True):
+        """Skip the per-call 'did the parameters change' check (streaming hot loop)."""
+        self._frozen = bool(frozen)
+
+    def set_plan(self, plan: str = "auto", rnn_cluster: int = 0, profile: bool = False):
+        h = self._ensure_handle()
+        h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2}[plan])
+        h.set_option(_lib.TIP_OPT_RNN_CLUSTER, int(rnn_cluster))
+        h.set_option(_lib.TIP_OPT_PROFILE, 1 if profile else 0)
+
+    def profile_read(self):
+        return self._ensure_handle().profile_read()
+
+    def hip_forward_count(self) -> int:
+        return self._handle.forward_count() if self._handle is not None else 0
+
+    def _forward_hip(self, x_imu, x_s, last_row_only: bool):
+        if not (x_imu.is_cuda and x_s.is_cuda):
+            raise RuntimeError("tip_amd.TF_RNN_Past_State: the inference forward runs on an MI355X through "
+                               "libtip_hip.so only — move the module and its inputs to the GPU (.cuda()); "
+                               "there is no CPU fallback")
+        if x_imu.dtype != torch.float32 or x_s.dtype != torch.float32:
+            raise RuntimeError("tip_amd.TF_RNN_Past_State: the HIP path computes in fp32; got "
+                               f"{x_imu.dtype}/{x_s.dtype}")
+        dev = x_imu.device
+        if x_imu.dim() != 3 or x_s.dim() != 3 or x_imu.shape[:2] != x_s.shape[:2]:
+            raise RuntimeError("expected x_imu [B,T,n_imu] and x_s [B,T,size_s]")
+        B, T = int(x_imu.shape[0]), int(x_imu.shape[1])
+        n_imu = self.input_size_imu + (18 if self.with_acc_sum else 0)
+        if x_imu.shape[2] != n_imu or x_s.shape[2] != self.size_s:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied: got feature widths "
+                               f"{x_imu.shape[2]}+{x_s.shape[2]}, in_linear expects {n_imu}+{self.size_s}")
+        if T > self.t_max:
+            raise RuntimeError(f"window length {T} exceeds t_max={self.t_max}")
+        h = self._ensure_handle()
+        with torch.cuda.device(dev):
+            if self._packed_dev is None or self._packed_dev.device != dev or \
+                    (not self._frozen and self._packed_key != self._param_key(dev)):
+                self.refresh_packed(dev)
+            x_imu_c = x_imu.contiguous()
+            x_s_c = x_s.contiguous()
+            if self.in_dropout > 0.0:  # :73 — a fresh nn.Dropout is always in training mode
+                x_imu_c = F.dropout(x_imu_c, self.in_dropout, training=True)
+            flags = 0
+            mask_ptr, scale = None, 1.0
+            if self.past_state_dropout > 0.0:  # :77
+                p = self.past_state_dropout
+                mask = (torch.rand_like(x_s_c) >= p).to(torch.float32)
+                mask_ptr, scale = mask.data_ptr(), (1.0 / (1.0 - p) if p < 1.0 else 0.0)
+                flags |= _lib.TIP_FWD_KEEP_MASK
+            if last_row_only:
+                flags |= _lib.TIP_FWD_LAST_ROW_ONLY
+                y = torch.empty((B, self.size_s), dtype=torch.float32, device=dev)
+            else:
+                y = torch.empty((B, T, self.size_s), dtype=torch.float32, device=dev)
+            need = h.workspace_bytes(B, T)
+            if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need:
+                self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            h.forward(x_imu_c.data_ptr(), x_s_c.data_ptr(), y.data_ptr(), B, T, flags, mask_ptr, scale,
+                      self._workspace.data_ptr(), self._workspace.numel(), stream)
+        return y
+
+    # -- torch-op composite (autograd / training) -----------------------------------------------
+    def _forward_torch_ops(self, x_imu, x_s):
+        B, T = x_imu.shape[0], x_imu.shape[1]
+        D, H = self.tf_in_dim, self.n_heads
+        dh = D // H
+        s = torch.nan_to_num(x_s, nan=0.0) if not x_s.requires_grad else torch.where(x_s.isnan(), torch.zeros_like(x_s), x_s)
+        keep = torch.ones(self.size_s, dtype=s.dtype, device=s.device)
+        keep[18 * 6: 18 * 6 + 3] = 0.0                                  # :75
+        s = s * keep
+        xi = F.dropout(x_imu, self.in_dropout, training=True) if self.in_dropout > 0 else x_imu   # :73
+        s = F.dropout(s, self.past_state_dropout, training=True) if self.past_state_dropout > 0 else s  # :77
+        z = F.linear(torch.cat((xi, s), dim=2), self.in_linear.weight, self.in_linear.bias)
+        z = z.reshape(B, T, H, dh).transpose(2, 3).reshape(B, T, D)      # :88-89 (batch-first view of the same shuffle)
+        pdrop = self.dropout if self.training else 0.0
+        for layer in self.tf_encode.layers:
+            qkv = F.linear(z, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias)
+            q, k, v = (t.reshape(B, T, H, dh).transpose(1, 2) for t in qkv.split(D, dim=2))
+            a = F.scaled_dot_product_attention(q, k, v, dropout_p=pdrop, is_causal=True)
+            a = a.transpose(1, 2).reshape(B, T, D)
+            a = F.linear(a, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias)
+            z = F.layer_norm(z + F.dropout(a, pdrop, self.training), (D,), layer.norm1.weight, layer.norm1.bias, 1e-5)
+            f = F.relu(F.linear(z, layer.linear1.weight, layer.linear1.bias))
+            f = F.linear(F.dropout(f, pdrop, self.training), layer.linear2.weight, layer.linear2.bias)
+            z = F.layer_norm(z + F.dropout(f, pdrop, self.training), (D,), layer.norm2.weight, layer.norm2.bias, 1e-5)
+        if self.rnn is not None:
+            ih = F.linear(z, self.rnn.weight_ih_l0, self.rnn.bias_ih_l0 + self.rnn.bias_hh_l0)
+            hcur = torch.zeros(B, self.rnn_hid_size, dtype=z.dtype, device=z.device)
+            hs = []
+            for t in range(T):
+                hcur = torch.tanh(ih[:, t] + F.linear(hcur, self.rnn.weight_hh_l0))
+                hs.append(hcur)
+            z = torch.stack(hs, dim=1)
+        return F.linear(z, self.linear.weight, self.linear.bias)
