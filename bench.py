@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py — IMU frames/s of the TIP forward pass on N MI355X GPUs (BASELINE.json metric).
+
+One "step" = one forward of TF_RNN_Past_State over a batch of B synthetic 40-frame IMU windows per GPU
+(BASELINE.json configs[1]: batch=256, seq_len=40, 4 layers / 16 heads / d=256 / ffn=1024 / rnn=512), inputs
+resident in HBM, full [B,T,131] output.  In streaming, one window forward consumes one new IMU frame per stream,
+so frames/s == windows/s.  Streams shard on the batch axis (weak scaling, no data-path
+collective; one RCCL weight broadcast before the timed region).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import tip_amd  # noqa: E402
+from tip_amd import synth  # noqa: E402
+from tip_amd import dist as tdist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense, 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def build_model(cfg, seed, load):
+    m = tip_amd.TF_RNN_Past_State(
+        cfg["input_size_imu"], cfg["size_s"], rnn_hid_size=cfg["rnn_hid_size"], tf_hid_size=cfg["tf_hid_size"],
+        tf_in_dim=cfg["tf_in_dim"], n_heads=cfg["n_heads"], tf_layers=cfg["tf_layers"], dropout=0.0, in_dropout=0.0,
+        past_state_dropout=0.0, with_rnn=cfg.get("with_rnn", True), with_acc_sum=cfg.get("with_acc_sum", False))
+    if load:
+        w = synth.make_weights(cfg, seed=seed)
+        m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    return m
+
+
+def stage_flops(cfg, name, B, T):
+    """Algorithmic FLOPs of ONE launch of a stage ('Kernels')."""
+    In = cfg["input_size_imu"] + cfg["size_s"] + (18 if cfg.get("with_acc_sum") else 0)
+    D, F, L = cfg["tf_in_dim"], cfg["tf_hid_size"], cfg["tf_layers"]
+    M = B * T
+    if name == "fused_encoder":
+        return B * (2.0 * T * In * D + L * (2.0 * T * D * 3 * D + 4.0 * T * T * D + 2.0 * T * D * D + 4.0 * T * D * F))
+    if name in ("ffn1_gemm", "ffn2_gemm"):
+        return 2.0 * M * D * F
+    return None
+
+
+def p50_latency_ms(model, xi, xs, iters, last=False):
+    ts = []
+    fn = model.forward_last if last else model
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(xi, xs)
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def cpu_baseline(cfg, B, T, budget_s=12.0):
+    """The reference's CPU path restated with the same torch ops (validated against the golden vectors in
+    tests/test_host_cpu.py), timed on this box's host cores on a bounded sample of the bench workload."""
+    m = build_model(cfg, 0, True).eval()
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=1234)
+    xi, xs = torch.tensor(x_imu), torch.tensor(x_s)
+    cores = torch.get_num_threads()
+    with torch.no_grad():
+        m._forward_torch_ops(xi, xs)  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            m._forward_torch_ops(xi, xs)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 40:
+                break
+    out = {"value": B * n / el, "unit": "IMU frames/s", "cores": cores, "kind": "port",
+           "sample": f"{n} forwards of B={B},T={T} (paper config) with the torch-op restatement of the reference CPU "
+                     f"path, torch.set_num_threads({cores}), {el:.1f} s"}
+    # the C oracle (scalar port, OpenMP over windows), same workload, bounded
+    try:
+        from oracle import oracle
+        w = synth.make_weights(cfg, seed=0)
+        nt = oracle.max_threads()
+        nb = max(nt, 8)
+        t0 = time.perf_counter()
+        oracle.forward(cfg, w, x_imu[:nb], x_s[:nb], dtype=np.float32, nthreads=nt)
+        el = time.perf_counter() - t0
+        out["oracle_c"] = {"value": nb / el, "unit": "IMU frames/s", "cores": nt,
+                           "sample": f"{nb} windows T={T}, scalar C restatement, {el:.1f} s"}
+    except Exception as e:  # the oracle is optional for the baseline leg
+        out["oracle_c"] = {"error": str(e)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="windows (IMU streams) per GPU")
+    ap.add_argument("--seq-len", type=int, default=40)
+    ap.add_argument("--plan", default="auto", choices=["auto", "general", "fused"])
+    ap.add_argument("--rnn-cluster", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="print a per-stage time table (separate pass)")
+    args = ap.parse_args()
+
+    rank, local_rank, world = tdist.env_rank()
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    cfg = synth.PAPER
+    B, T = args.batch, args.seq_len
+    model = build_model(cfg, 0, load=(rank == 0)).to(dev).eval()
+    t_b0 = time.perf_counter()
+    tdist.broadcast_packed(model, src=0, device=dev)      # one-time RCCL broadcast (no-op collective at N=1)
+    torch.cuda.synchronize()
+    bcast_ms = (time.perf_counter() - t_b0) * 1e3
+    model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=0)
+
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=1234 + rank)
+    xi, xs = torch.tensor(x_imu).to(dev), torch.tensor(x_s).to(dev)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = model(xi, xs)
+        model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=2)   # event pair around the dominant kernel
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = model(xi, xs)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        prof = model.profile_read()
+        model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=0)
+    assert torch.isfinite(y).all()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    global_b = B * world
+    value = global_b * args.steps / elapsed
+
+    roofline = None
+    if prof:
+        name, ms, launches = max(prof, key=lambda r: r[1])
+        fl = stage_flops(cfg, name, B, T)
+        if fl and launches:
+            avg_ms = ms / launches
+            ach = fl / (avg_ms * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(name, {}).get(f"B{B}_T{T}")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                        "avg_launch_ms": avg_ms, "launches_timed": launches, "flops_per_launch": fl}
+
+    extra = {}
+    with torch.no_grad():
+        if not args.no_latency and rank == 0:
+            extra["p50_forward_ms_batch"] = p50_latency_ms(model, xi, xs, 40)
+            x1i, x1s = xi[:1].contiguous(), xs[:1].contiguous()
+            for _ in range(5):
+                model(x1i, x1s)
+            lat1 = p50_latency_ms(model, x1i, x1s, 200)
+            extra["p50_forward_ms_b1"] = lat1
+            extra["p50_forward_last_row_ms_b1"] = p50_latency_ms(model, x1i, x1s, 200, last=True)
+            extra["b1_realtime_factor_60fps"] = (1000.0 / lat1) / 60.0
+        if args.profile_all and rank == 0:
+            model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=1)
+            for _ in range(5):
+                model(xi, xs)
+            torch.cuda.synchronize()
+            table = {}
+            for n, ms, k in model.profile_read():
+                table[n] = {"ms_per_forward": ms / 5, "launches_per_forward": k / 5}
+            extra["stage_ms"] = table
+            model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=0)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, B, T)
+
+    if rank == 0:
+        fpw = synth.flops_per_window(cfg, T)
+        line = {
+            "metric": "IMU frames/sec (whole node), seq_len=40 batch=256/GPU",
+            "value": value, "unit": "IMU frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"TIP paper config (4 layers, 16 heads, d=256, ffn=1024, rnn=512), "
+                                   f"{B} windows/GPU x {T} frames, full [B,T,131] output, inputs resident in HBM",
+                       "global_batch": global_b, "seq_len": T, "plan": args.plan,
+                       "parallelism": f"batch-sharded x{world}, one-time RCCL weight broadcast, no per-step collective"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "whole_forward_tflops": value * fpw / 1e12,
+            "whole_forward_frac_of_fp32_mfma_peak": value * fpw / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
+            "weight_broadcast_ms": bcast_ms,
+            "extra": extra,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

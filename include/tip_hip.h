@@ -62,7 +62,8 @@ typedef enum tip_status {
 #define TIP_PLAN_FUSED   2 /* one workgroup = one window through all encoder layers (paper configuration) */
 
 #define TIP_OPT_PLAN        1
-#define TIP_OPT_PROFILE     2 /* 1: bracket every stage with HIP events (read with tip_profile_read) */
+#define TIP_OPT_PROFILE     2 /* 0 off; 1: bracket every stage with a HIP event pair; 2: only the dominant stage
+                                 (cheap enough for a timed region).  Setting it resets the accumulated times. */
 #define TIP_OPT_RNN_CLUSTER 3 /* workgroups cooperating on one RNN window-tile (1,2,4,8); 0 = auto */
 
 /* ---- lifetime: replaces TF_RNN_Past_State.__init__ (simple_transformer_with_state.py:9-54) ---------------- */
@@ -99,8 +100,9 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 /* number of tip_forward calls that launched HIP kernels since tip_create (lets tests prove the HIP path ran) */
 int tip_forward_count(const tip_handle* h, uint64_t* n);
-/* after the stream is synchronised: per-stage times of the LAST profiled forward.  names/ms arrays of length
- * `cap`; returns the number of stages (<= cap) or a negative status. */
+/* after the stream is synchronised: per-stage totals accumulated since TIP_OPT_PROFILE was last set.
+ * ms[i] = summed duration of stage names[i], launches[i] = event pairs summed.  Arrays of length `cap`;
+ * returns the number of stages (<= cap) or a negative status. */
 int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches, int cap);
 
 #ifdef __cplusplus

@@ -145,28 +145,39 @@ int fail_hip(tip_handle* h, hipError_t e, const char* where) {
     return TIP_ERR_HIP;
 }
 
+// profile == 1: every stage; profile == 2: only the dominant stage of the active plan (cheap enough to leave on
+// inside a timed region).  One event pair per launch, accumulated until tip_set_option(TIP_OPT_PROFILE, ...).
+bool stage_is_dominant(const char* name) {
+    return !strcmp(name, "fused_encoder") || !strcmp(name, "ffn1_gemm");
+}
+
 struct StageScope {
     tip_handle* h;
     hipStream_t s;
-    int idx = -1;
-    StageScope(tip_handle* hh, hipStream_t ss, const char* name, int launches) : h(hh), s(ss) {
+    hipEvent_t stop = nullptr;
+    StageScope(tip_handle* hh, hipStream_t ss, const char* name) : h(hh), s(ss) {
         if (!h->profile) return;
-        for (size_t i = 0; i < h->timers.size(); ++i)
-            if (h->timers[i].name == name && !h->timers[i].used) { idx = (int)i; break; }
-        if (idx < 0) {
-            StageTimer t;
-            t.name = name;
-            hipEventCreate(&t.e0);
-            hipEventCreate(&t.e1);
-            h->timers.push_back(t);
-            idx = (int)h->timers.size() - 1;
+        if (h->profile == 2 && !stage_is_dominant(name)) return;
+        StageTimer* t = nullptr;
+        for (auto& x : h->timers)
+            if (x.name == name) { t = &x; break; }
+        if (!t) {
+            h->timers.emplace_back();
+            t = &h->timers.back();
+            t->name = name;
         }
-        h->timers[idx].used = true;
-        h->timers[idx].launches = launches;
-        hipEventRecord(h->timers[idx].e0, s);
+        if (t->used == t->pairs.size()) {
+            if (t->pairs.size() >= kMaxTimerPairs) return;
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            t->pairs.push_back({a, b});
+        }
+        auto& pr = t->pairs[t->used++];
+        (void)hipEventRecord(pr.first, s);
+        stop = pr.second;
     }
     ~StageScope() {
-        if (idx >= 0) hipEventRecord(h->timers[idx].e1, s);
+        if (stop) (void)hipEventRecord(stop, s);
     }
 };
 
@@ -232,10 +243,11 @@ int tip_create(const tip_config* cfg, tip_handle** out) {
 
 void tip_destroy(tip_handle* h) {
     if (!h) return;
-    for (auto& t : h->timers) {
-        if (t.e0) hipEventDestroy(t.e0);
-        if (t.e1) hipEventDestroy(t.e1);
-    }
+    for (auto& t : h->timers)
+        for (auto& pr : t.pairs) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
     delete h;
 }
 
@@ -248,7 +260,11 @@ int tip_set_option(tip_handle* h, int option, int value) {
             if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED) return TIP_ERR_INVALID_ARG;
             h->plan = value;
             return TIP_OK;
-        case TIP_OPT_PROFILE: h->profile = value ? 1 : 0; return TIP_OK;
+        case TIP_OPT_PROFILE:
+            if (value < 0 || value > 2) return TIP_ERR_INVALID_ARG;
+            h->profile = value;
+            for (auto& t : h->timers) t.used = 0;  // reset the accumulators
+            return TIP_OK;
         case TIP_OPT_RNN_CLUSTER:
             if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) return TIP_ERR_INVALID_ARG;
             h->rnn_cluster = value;
@@ -374,16 +390,20 @@ int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches
     for (auto& t : h->timers) {
         if (!t.used) continue;
         if (n < cap) {
-            float v = 0.f;
-            hipError_t e = hipEventElapsedTime(&v, t.e0, t.e1);
-            if (e != hipSuccess) return fail_hip(h, e, "hipEventElapsedTime");
+            double total = 0.0;
+            for (size_t i = 0; i < t.used; ++i) {
+                float v = 0.f;
+                hipError_t e = hipEventElapsedTime(&v, t.pairs[i].first, t.pairs[i].second);
+                if (e != hipSuccess) return fail_hip(h, e, "hipEventElapsedTime");
+                total += v;
+            }
             if (names) names[n] = t.name.c_str();
-            if (ms) ms[n] = v;
-            if (launches) launches[n] = t.launches;
+            if (ms) ms[n] = (float)total;
+            if (launches) launches[n] = (int)t.used;
+            ++n;
         }
-        ++n;
     }
-    return n < cap ? n : cap;
+    return n;
 }
 
 int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
@@ -411,7 +431,6 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     const int M = B * T;
     const float* mask = (flags & TIP_FWD_KEEP_MASK) ? keep_mask : nullptr;
     if (!mask) keep_scale = 1.f;
-    for (auto& t : h->timers) t.used = false;
     hipError_t e;
 
 #define TIP_TRY(expr, what)                          \
@@ -426,51 +445,51 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
 
     float* enc_out = xa;  // encoder output [M, D]
     if (plan == TIP_PLAN_FUSED) {
-        StageScope sc(h, s, "fused_encoder", 1);
+        StageScope sc(h, s, "fused_encoder");
         TIP_TRY(launch_fused_encoder(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, xa, B, T, h->num_cus, s),
                 "fused_encoder");
     } else {
         {
-            StageScope sc(h, s, "prologue", 1);
+            StageScope sc(h, s, "prologue");
             TIP_TRY(launch_prologue(d, x_imu, x_s, mask, keep_scale, big, M, s), "prologue");
         }
         {
-            StageScope sc(h, s, "in_linear", 1);
+            StageScope sc(h, s, "in_linear");
             TIP_TRY(launch_gemm(big, d.InPad, P + L.in_lin.w_off, L.in_lin.Kpad, P + L.in_lin.b_off, nullptr, 0, xa,
                                 d.D, M, d.D, L.in_lin.Npad, 0, s), "in_linear");
         }
         for (int l = 0; l < d.L; ++l) {
             const PackedLayer& pl = L.layers[l];
             {
-                StageScope sc(h, s, "qkv_gemm", 1);
+                StageScope sc(h, s, "qkv_gemm");
                 TIP_TRY(launch_gemm(xa, d.D, P + pl.qkv.w_off, pl.qkv.Kpad, P + pl.qkv.b_off, nullptr, 0, big, 3 * d.D,
                                     M, 3 * d.D, pl.qkv.Npad, 0, s), "qkv_gemm");
             }
             {
-                StageScope sc(h, s, "attention", 1);
+                StageScope sc(h, s, "attention");
                 TIP_TRY(launch_attention(d, big, att, B, T, s), "attention");
             }
             {
-                StageScope sc(h, s, "out_proj_gemm", 1);
+                StageScope sc(h, s, "out_proj_gemm");
                 TIP_TRY(launch_gemm(att, d.D, P + pl.out.w_off, pl.out.Kpad, P + pl.out.b_off, xa, d.D, xb, d.D, M, d.D,
                                     pl.out.Npad, 2, s), "out_proj_gemm");
             }
             {
-                StageScope sc(h, s, "layernorm1", 1);
+                StageScope sc(h, s, "layernorm1");
                 TIP_TRY(launch_layernorm(xb, P + pl.g1_off, P + pl.be1_off, M, d.D, s), "layernorm1");
             }
             {
-                StageScope sc(h, s, "ffn1_gemm", 1);
+                StageScope sc(h, s, "ffn1_gemm");
                 TIP_TRY(launch_gemm(xb, d.D, P + pl.ff1.w_off, pl.ff1.Kpad, P + pl.ff1.b_off, nullptr, 0, big, d.F, M,
                                     d.F, pl.ff1.Npad, 1, s), "ffn1_gemm");
             }
             {
-                StageScope sc(h, s, "ffn2_gemm", 1);
+                StageScope sc(h, s, "ffn2_gemm");
                 TIP_TRY(launch_gemm(big, d.F, P + pl.ff2.w_off, pl.ff2.Kpad, P + pl.ff2.b_off, xb, d.D, xa, d.D, M, d.D,
                                     pl.ff2.Npad, 2, s), "ffn2_gemm");
             }
             {
-                StageScope sc(h, s, "layernorm2", 1);
+                StageScope sc(h, s, "layernorm2");
                 TIP_TRY(launch_layernorm(xa, P + pl.g2_off, P + pl.be2_off, M, d.D, s), "layernorm2");
             }
         }
@@ -481,12 +500,12 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     int head_ld = d.D;
     if (d.with_rnn) {
         {
-            StageScope sc(h, s, "rnn_ih_gemm", 1);
+            StageScope sc(h, s, "rnn_ih_gemm");
             TIP_TRY(launch_gemm(enc_out, d.D, P + L.rnn_ih.w_off, L.rnn_ih.Kpad, P + L.rnn_ih.b_off, nullptr, 0, big,
                                 d.R, M, d.R, L.rnn_ih.Npad, 0, s), "rnn_ih_gemm");
         }
         {
-            StageScope sc(h, s, "rnn_recurrence", 1);
+            StageScope sc(h, s, "rnn_recurrence");
             int cluster = h->rnn_cluster;
             if (cluster == 0) {
                 // auto: spread one window-tile over as many CUs as the tile count leaves idle
@@ -501,7 +520,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         head_ld = d.R;
     }
     {
-        StageScope sc(h, s, "out_linear", 1);
+        StageScope sc(h, s, "out_linear");
         if (last_only) {
             // only row T-1 of every window is consumed by the streaming runner (real_time_runner_minimal.py:150)
             TIP_TRY(launch_gemm(head_in + (size_t)(T - 1) * head_ld, T * head_ld, P + L.out_lin.w_off, L.out_lin.Kpad,

@@ -62,10 +62,10 @@ struct Workspace {
 
 struct StageTimer {
     std::string name;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    int launches = 0;
-    bool used = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;  // one (start, stop) per recorded launch
+    size_t used = 0;                                        // pairs recorded since the last reset
 };
+constexpr size_t kMaxTimerPairs = 1 << 16;
 
 }  // namespace tip
 

@@ -58,6 +58,9 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; importing it first makes libtip_hip.so bind to that same HIP runtime
+    # (two runtimes in one process do not share devices, streams or allocations).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise TipLibraryError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -193,11 +193,11 @@ class TF_RNN_Past_State(nn.Module):
         """Skip the per-call 'did the parameters change' check (streaming hot loop)."""
         self._frozen = bool(frozen)
 
-    def set_plan(self, plan: str = "auto", rnn_cluster: int = 0, profile: bool = False):
+    def set_plan(self, plan: str = "auto", rnn_cluster: int = 0, profile: int = 0):
         h = self._ensure_handle()
         h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2}[plan])
         h.set_option(_lib.TIP_OPT_RNN_CLUSTER, int(rnn_cluster))
-        h.set_option(_lib.TIP_OPT_PROFILE, 1 if profile else 0)
+        h.set_option(_lib.TIP_OPT_PROFILE, int(profile))
 
     def profile_read(self):
         return self._ensure_handle().profile_read()
