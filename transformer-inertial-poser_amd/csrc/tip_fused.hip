@@ -1,14 +1,434 @@
-// tip_fused.hip — fused execution plan (paper configuration): placeholder until the kernel lands.
+// tip_fused.hip — fused execution plan for the paper configuration (d=256, 16 heads x 16, ffn=1024, T<=40).
+//
+// One 512-thread workgroup (8 waves, 2 per SIMD) carries ONE 40-frame window through the prologue, in_linear
+// and all encoder layers without leaving the CU: the activations [48 x 256] live in LDS for the whole pass,
+// every GEMM is v_mfma_f32_16x16x4_f32 with the A operand read from LDS (ds_read_b128 = 4 k-steps) and the B
+// operand streamed straight from L2 in pre-packed fragment order (one coalesced 1-KiB global_load_dwordx4 per
+// 16x16 weight block per wave, register double-buffered), attention runs one head per wave between the QKV
+// GEMM and the out-projection with no inter-wave dependency, LayerNorm uses wave shuffles.  HBM sees only the
+// window's inputs (35 KB) and the encoder output (40 KB); weights (12.6 MB) are L2/Infinity-Cache resident and
+// shared by all 256 CUs.  Reference: /root/reference/simple_transformer_with_state.py:63-91.
+//
+// LDS map (floats):  X [48][260] residual stream | C chunk region [3][48][132] = Q|K|V of 8 heads, reused as
+//                    U [48][228] (prologue) and Hc [48][260] (FFN hidden chunk).  125,952 B.
+#include <string.h>
+
 #include "tip_internal.h"
 
 namespace tip {
 
-bool fused_supported(const Dims&, int) { return false; }
-size_t fused_packed_floats(const Dims&) { return 0; }
-void fused_pack(const Dims&, const float* const*, float*) {}
-hipError_t launch_fused_encoder(const Dims&, const float*, const float*, const float*, const float*, float, float*, int,
-                                int, int, hipStream_t) {
-    return hipErrorNotSupported;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace fz {
+constexpr int D = 256, H = 16, DH = 16, F = 1024, RP = 48, RB = 3, TMAX = 40;
+constexpr int KIN = 224;            // in_linear K, zero padded (221 with acc-sum, 203 without)
+constexpr int LDX = D + 4;          // 260
+constexpr int LDC = 128 + 4;        // 132: one Q / K / V plane of an 8-head chunk
+constexpr int LDU = KIN + 4;        // 228
+constexpr int X_FLOATS = RP * LDX;              // 12480
+constexpr int C_FLOATS = 3 * RP * LDC;          // 19008
+constexpr int LDS_BYTES = (X_FLOATS + C_FLOATS) * 4;
+constexpr int THREADS = 512;
+// packed section (floats)
+constexpr size_t IN_W = 0;
+constexpr size_t IN_B = IN_W + (size_t)D * KIN;
+constexpr size_t LAYER0 = IN_B + D;
+constexpr size_t QKV_W = 0;
+constexpr size_t QKV_B = QKV_W + (size_t)3 * D * D;
+constexpr size_t WO_W = QKV_B + 3 * D;
+constexpr size_t WO_B = WO_W + (size_t)D * D;
+constexpr size_t W1_W = WO_B + D;
+constexpr size_t W1_B = W1_W + (size_t)F * D;
+constexpr size_t W2_W = W1_B + F;
+constexpr size_t W2_B = W2_W + (size_t)D * F;
+constexpr size_t G1 = W2_B + D;
+constexpr size_t BE1 = G1 + D;
+constexpr size_t G2 = BE1 + D;
+constexpr size_t BE2 = G2 + D;
+constexpr size_t LAYER_FLOATS = BE2 + D;
+constexpr size_t TAIL_PAD = 4096;      // the k-loop prefetches up to 2 blocks (2 KiB) past a wave's last block
+}  // namespace fz
+
+bool fused_supported(const Dims& d, int T) {
+    return d.D == fz::D && d.H == fz::H && d.F == fz::F && d.In <= fz::KIN && T >= 1 && T <= fz::TMAX && d.L >= 1;
+}
+
+size_t fused_packed_floats(const Dims& d) {
+    if (!(d.D == fz::D && d.H == fz::H && d.F == fz::F && d.In <= fz::KIN)) return 0;
+    return fz::LAYER0 + (size_t)d.L * fz::LAYER_FLOATS + fz::TAIL_PAD;
+}
+
+// W [N][K] row-major (K <= Kpad) -> 16x16x4 B-fragment order [N/16][Kpad/16][64 lanes][4]:
+//   dst[((nb*KB + kb)*64 + lane)*4 + s] = W[nb*16 + (lane&15)][kb*16 + 4*(lane>>4) + s]
+static void pack_frag(float* dst, const float* W, int N, int K, int Kpad, const int* row_map, float scale_rows_lt,
+                      int scale_n) {
+    const int KB = Kpad / 16;
+    for (int nb = 0; nb < N / 16; ++nb)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int s = 0; s < 4; ++s) {
+                    const int n = nb * 16 + (lane & 15), k = kb * 16 + 4 * (lane >> 4) + s;
+                    const int src = row_map ? row_map[n] : n;
+                    float v = k < K ? W[(size_t)src * K + k] : 0.f;
+                    if (n < scale_n) v *= scale_rows_lt;
+                    dst[((size_t)(nb * KB + kb) * 64 + lane) * 4 + s] = v;
+                }
+}
+
+void fused_pack(const Dims& d, const float* const* t, float* dst) {
+    using namespace fz;
+    // in_linear: channel shuffle (:88-89) folded into rows, root-velocity columns (:75) zeroed
+    std::vector<int> map(D);
+    for (int a = 0; a < DH; ++a)
+        for (int b = 0; b < H; ++b) map[a * H + b] = b * DH + a;
+    std::vector<float> win((size_t)D * d.In);
+    memcpy(win.data(), t[0], sizeof(float) * win.size());
+    for (int n = 0; n < D; ++n)
+        for (int c = d.rootv0; c < d.rootv1; ++c) win[(size_t)n * d.In + d.n_imu_total + c] = 0.f;
+    pack_frag(dst + IN_W, win.data(), D, d.In, KIN, map.data(), 1.f, 0);
+    for (int n = 0; n < D; ++n) dst[IN_B + n] = t[1][map[n]];
+    for (int l = 0; l < d.L; ++l) {
+        const float* const* lw = t + 2 + 12 * l;
+        float* L = dst + LAYER0 + (size_t)l * LAYER_FLOATS;
+        pack_frag(L + QKV_W, lw[0], 3 * D, D, D, nullptr, 0.25f, D);  // 1/sqrt(16) folded into W_q (exact)
+        for (int i = 0; i < 3 * D; ++i) L[QKV_B + i] = lw[1][i] * (i < D ? 0.25f : 1.f);
+        pack_frag(L + WO_W, lw[2], D, D, D, nullptr, 1.f, 0);
+        memcpy(L + WO_B, lw[3], sizeof(float) * D);
+        pack_frag(L + W1_W, lw[4], F, D, D, nullptr, 1.f, 0);
+        memcpy(L + W1_B, lw[5], sizeof(float) * F);
+        pack_frag(L + W2_W, lw[6], D, F, F, nullptr, 1.f, 0);
+        memcpy(L + W2_B, lw[7], sizeof(float) * D);
+        memcpy(L + G1, lw[8], sizeof(float) * D);
+        memcpy(L + BE1, lw[9], sizeof(float) * D);
+        memcpy(L + G2, lw[10], sizeof(float) * D);
+        memcpy(L + BE2, lw[11], sizeof(float) * D);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// device pieces
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int NBW>
+__device__ __forceinline__ void mfma_block(f32x4 (&acc)[fz::RB][NBW], const float4 (&a)[fz::RB], const float4 (&w)[NBW]) {
+#pragma unroll
+    for (int r = 0; r < fz::RB; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].x, w[n].x, acc[r][n], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < fz::RB; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].y, w[n].y, acc[r][n], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < fz::RB; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].z, w[n].z, acc[r][n], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < fz::RB; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].w, w[n].w, acc[r][n], 0, 0, 0);
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// One 1-KiB fragment block: lane l gets bytes [16 l, 16 l + 16) of the block at byte offset `soff`.
+// raw buffer loads (SGPR descriptor + scalar offset) instead of flat loads: the optimiser treats them as opaque
+// calls, so the software-pipelined prefetch below survives (flat loads from __restrict__ memory were re-sunk to
+// their use, exposing the L2 latency every k-step), and addresses cost one VGPR.
+__device__ __forceinline__ float4 load_frag(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    // NB: bit-cast the whole vector — __builtin_bit_cast(float, v[i]) on a vector ELEMENT is miscompiled by this
+    // clang (every element reads lane 0 of the vector).
+    const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+
+// acc[r][n] += A[48 x 16*KB] (LDS, leading dim lda) * Wblock(n, kb)   for kb in [0, KB)
+//   soff: byte offset (wave-uniform) of the wave's first block at kb = 0; block n is + n*nstride_b; k-block kb is + kb*1024.
+//   The prefetch runs two k-blocks ahead and is unconditional (branch-free loop => counted vmcnt waits); past the
+//   last k-block it reads the following packed block (in bounds: the section carries a tail pad).
+template <int NBW, int KB>
+__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[fz::RB][NBW], const float* As, int lda, __amdgpu_buffer_rsrc_t rsrc,
+                                           int voff, int soff, int nstride_b) {
+    static_assert(KB % 2 == 0, "k-blocks are processed in pairs");
+    float4 w0[NBW], w1[NBW];
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+        w0[n] = load_frag(rsrc, voff, soff + n * nstride_b);
+        w1[n] = load_frag(rsrc, voff, soff + n * nstride_b + 1024);
+    }
+#pragma unroll 1
+    for (int kb = 0; kb < KB; kb += 2) {
+        float4 a[fz::RB];
+#pragma unroll
+        for (int r = 0; r < fz::RB; ++r) a[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda + kb * 16);
+        mfma_block<NBW>(acc, a, w0);
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) w0[n] = load_frag(rsrc, voff, soff + n * nstride_b + (kb + 2) * 1024);
+#pragma unroll
+        for (int r = 0; r < fz::RB; ++r) a[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda + (kb + 1) * 16);
+        mfma_block<NBW>(acc, a, w1);
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) w1[n] = load_frag(rsrc, voff, soff + n * nstride_b + (kb + 3) * 1024);
+    }
+}
+
+template <int NBW>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[fz::RB][NBW]) {
+#pragma unroll
+    for (int r = 0; r < fz::RB; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+// LayerNorm over the 48 rows of X (eps 1e-5, biased variance): wave w owns rows w, w+8, ...
+__device__ __forceinline__ void layernorm_rows(float* X, const float* __restrict__ g, const float* __restrict__ be, int wave,
+                                               int lane) {
+    const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
+    const float4 bb = *reinterpret_cast<const float4*>(be + lane * 4);
+    for (int row = wave; row < fz::RP; row += 8) {
+        float4* p = reinterpret_cast<float4*>(X + row * fz::LDX + lane * 4);
+        float4 v = *p;
+        const float mean = wsum((v.x + v.y) + (v.z + v.w)) * (1.f / fz::D);
+        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        const float var = wsum((a * a + b * b) + (c * c + d * d)) * (1.f / fz::D);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        v.x = a * rstd * gg.x + bb.x;
+        v.y = b * rstd * gg.y + bb.y;
+        v.z = c * rstd * gg.z + bb.z;
+        v.w = d * rstd * gg.w + bb.w;
+        *p = v;
+    }
+}
+
+// Causal attention of ONE head by ONE wave: lane i = query row i.  Q/K/V planes hold the head at column c0.
+// Output overwrites the head's Q columns (each lane only ever reads its own Q row).
+__device__ __forceinline__ void attention_head(float* Qc, const float* Kc, const float* Vc, int c0, int T, int lane) {
+    using namespace fz;
+    const int i = lane;
+    if (i < T) {
+        float q[DH], o[DH];
+#pragma unroll
+        for (int e = 0; e < DH; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(Qc + i * LDC + c0 + e);
+            q[e] = t.x; q[e + 1] = t.y; q[e + 2] = t.z; q[e + 3] = t.w;
+            o[e] = 0.f; o[e + 1] = 0.f; o[e + 2] = 0.f; o[e + 3] = 0.f;
+        }
+        float m = -INFINITY, l = 0.f;
+#pragma unroll 1
+        for (int j = 0; j < T; ++j) {
+            if (j <= i) {  // causal mask (:56-58)
+                const float* kj = Kc + j * LDC + c0;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+                for (int e = 0; e < DH; e += 4) {
+                    const float4 kv = *reinterpret_cast<const float4*>(kj + e);
+                    s0 = fmaf(q[e], kv.x, s0); s1 = fmaf(q[e + 1], kv.y, s1);
+                    s2 = fmaf(q[e + 2], kv.z, s2); s3 = fmaf(q[e + 3], kv.w, s3);
+                }
+                const float sc = (s0 + s1) + (s2 + s3);
+                const float mn = fmaxf(m, sc);
+                const float corr = expf(m - mn);
+                const float p = expf(sc - mn);
+                l = l * corr + p;
+                const float* vj = Vc + j * LDC + c0;
+#pragma unroll
+                for (int e = 0; e < DH; e += 4) {
+                    const float4 vv = *reinterpret_cast<const float4*>(vj + e);
+                    o[e] = fmaf(o[e], corr, p * vv.x); o[e + 1] = fmaf(o[e + 1], corr, p * vv.y);
+                    o[e + 2] = fmaf(o[e + 2], corr, p * vv.z); o[e + 3] = fmaf(o[e + 3], corr, p * vv.w);
+                }
+                m = mn;
+            }
+        }
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int e = 0; e < DH; e += 4)
+            *reinterpret_cast<float4*>(Qc + i * LDC + c0 + e) = make_float4(o[e] * inv, o[e + 1] * inv, o[e + 2] * inv, o[e + 3] * inv);
+    }
+}
+
+__global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
+    const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
+    const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ xout, int B, int T, int NI, int S, int L,
+    int wbytes) {
+    using namespace fz;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;
+    float* C = smem + X_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, wbytes, 0x00020000);
+    const int voff = lane * 16;
+
+    for (int win = blockIdx.x; win < B; win += gridDim.x) {
+        // ---- P0 prologue (:63-78): U = [x_imu | scrub(x_s) * mask | 0], rows >= T zero ---------------------------
+        float* U = C;
+        for (int i = tid; i < RP * LDU; i += THREADS) U[i] = 0.f;
+        __syncthreads();
+        {
+            const float* xi = x_imu + (size_t)win * T * NI;
+            for (int i = tid; i < T * NI; i += THREADS) {
+                const int r = i / NI, c = i - r * NI;
+                U[r * LDU + c] = xi[i];
+            }
+            const float* xs = x_s + (size_t)win * T * S;
+            const float* km = keep_mask ? keep_mask + (size_t)win * T * S : nullptr;
+            for (int i = tid; i < T * S; i += THREADS) {
+                const int r = i / S, c = i - r * S;
+                float v = xs[i];
+                if (v != v) v = 0.f;                  // :65
+                if (km) v = v * km[i] * keep_scale;   // :77 with an explicit keep-mask
+                U[r * LDU + NI + c] = v;
+            }
+        }
+        __syncthreads();
+        // ---- P1 in_linear (:79) + channel shuffle (:88-89, folded into the packed rows) ---------------------------
+        {
+            f32x4 acc[RB][2];
+            zero_acc<2>(acc);
+            gemm_phase<2, KIN / 16>(acc, U + l15 * LDU + lg * 4, LDU, rsrc, voff,
+                                    (int)(IN_W * 4) + (wave * 2) * (KIN / 16) * 1024, (KIN / 16) * 1024);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = (wave * 2 + n) * 16 + l15;
+                const float bv = wts[IN_B + col];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] = acc[r][n][e] + bv;
+            }
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int layer = 0; layer < L; ++layer) {
+            const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
+            const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
+            float* Qc = C;
+            float* Kc = C + RP * LDC;
+            float* Vc = C + 2 * RP * LDC;
+            // ---- self-attention block: two chunks of 8 heads; wave w owns head 8c + w end to end -----------------
+            f32x4 acc_o[RB][2];
+            zero_acc<2>(acc_o);
+#pragma unroll 1
+            for (int c = 0; c < 2; ++c) {
+                {
+                    const int head = c * 8 + wave;
+                    f32x4 acc[RB][3];
+                    zero_acc<3>(acc);
+                    // column blocks of this head in the packed [48 nb][16 kb] QKV matrix: Q = head, K = 16+head, V = 32+head
+                    gemm_phase<3, 16>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, lbase + (int)(QKV_W * 4) + head * 16 * 1024,
+                                      16 * 16 * 1024);
+                    const float bq = LW[QKV_B + head * 16 + l15];
+                    const float bk = LW[QKV_B + D + head * 16 + l15];
+                    const float bv = LW[QKV_B + 2 * D + head * 16 + l15];
+                    const int col = wave * 16 + l15;
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = r * 16 + lg * 4 + e;
+                            Qc[row * LDC + col] = acc[r][0][e] + bq;
+                            Kc[row * LDC + col] = acc[r][1][e] + bk;
+                            Vc[row * LDC + col] = acc[r][2][e] + bv;
+                        }
+                }
+                __syncthreads();
+                attention_head(Qc, Kc, Vc, wave * 16, T, lane);
+                __syncthreads();
+                // out-projection partial: acc_o += O_chunk[48 x 128] * Wo[:, 128c .. 128c+127]^T
+                {
+                    gemm_phase<2, 8>(acc_o, Qc + l15 * LDC + lg * 4, LDC, rsrc, voff,
+                                     lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + c * 8) * 1024, 16 * 1024);
+                }
+                __syncthreads();
+            }
+            // residual + bias, then LayerNorm1
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = (wave * 2 + n) * 16 + l15;
+                const float bv = LW[WO_B + col];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_o[r][n][e] + bv;
+            }
+            __syncthreads();
+            layernorm_rows(X, LW + G1, LW + BE1, wave, lane);
+            __syncthreads();
+            // ---- feed-forward block: hidden processed in 4 chunks of 256, second GEMM accumulates in registers -----
+            float* Hc = C;
+            f32x4 acc_f[RB][2];
+            zero_acc<2>(acc_f);
+#pragma unroll 1
+            for (int f = 0; f < 4; ++f) {
+                {
+                    f32x4 acc[RB][2];
+                    zero_acc<2>(acc);
+                    const int nb0 = f * 16 + wave * 2;
+                    gemm_phase<2, 16>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, lbase + (int)(W1_W * 4) + nb0 * 16 * 1024,
+                                      16 * 1024);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int col = (wave * 2 + n) * 16 + l15;
+                        const float bv = LW[W1_B + f * 256 + col];
+#pragma unroll
+                        for (int r = 0; r < RB; ++r)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) Hc[(r * 16 + lg * 4 + e) * LDX + col] = fmaxf(acc[r][n][e] + bv, 0.f);
+                    }
+                }
+                __syncthreads();
+                {
+                    gemm_phase<2, 16>(acc_f, Hc + l15 * LDX + lg * 4, LDX, rsrc, voff,
+                                      lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024, 64 * 1024);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = (wave * 2 + n) * 16 + l15;
+                const float bv = LW[W2_B + col];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_f[r][n][e] + bv;
+            }
+            __syncthreads();
+            layernorm_rows(X, LW + G2, LW + BE2, wave, lane);
+            __syncthreads();
+        }
+        // ---- encoder output rows 0..T-1 -> HBM ---------------------------------------------------------------------
+        float* out = xout + (size_t)win * T * D;
+        for (int i = tid; i < T * (D / 4); i += THREADS) {
+            const int r = i / (D / 4), c4 = i - r * (D / 4);
+            *reinterpret_cast<float4*>(out + (size_t)r * D + c4 * 4) = *reinterpret_cast<const float4*>(X + r * LDX + c4 * 4);
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
+                                const float* keep_mask, float keep_scale, float* xout, int B, int T, int num_cus,
+                                hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = B < num_cus ? B : num_cus;
+    hipLaunchKernelGGL(fused_encoder_kernel, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s,
+                       keep_mask, keep_scale, xout, B, T, d.n_imu_total, d.S, d.L, (int)(fused_packed_floats(d) * 4));
+    return hipGetLastError();
 }
 
 }  // namespace tip
