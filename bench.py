@@ -12,6 +12,7 @@ collective; one RCCL weight broadcast before the timed region).
         bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -33,6 +34,11 @@ PEAK_HBM_GBS = 8000.0
 
 
 def build_model(cfg, seed, load):
+    with contextlib.redirect_stdout(sys.stderr):   # the reference's constructor prints; stdout carries ONE JSON line
+        return _build_model(cfg, seed, load)
+
+
+def _build_model(cfg, seed, load):
     m = tip_amd.TF_RNN_Past_State(
         cfg["input_size_imu"], cfg["size_s"], rnn_hid_size=cfg["rnn_hid_size"], tf_hid_size=cfg["tf_hid_size"],
         tf_in_dim=cfg["tf_in_dim"], n_heads=cfg["n_heads"], tf_layers=cfg["tf_layers"], dropout=0.0, in_dropout=0.0,

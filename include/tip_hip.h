@@ -64,7 +64,7 @@ typedef enum tip_status {
 #define TIP_OPT_PLAN        1
 #define TIP_OPT_PROFILE     2 /* 0 off; 1: bracket every stage with a HIP event pair; 2: only the dominant stage
                                  (cheap enough for a timed region).  Setting it resets the accumulated times. */
-#define TIP_OPT_RNN_CLUSTER 3 /* workgroups cooperating on one RNN window-tile (1,2,4,8); 0 = auto */
+#define TIP_OPT_RNN_CLUSTER 3 /* workgroups cooperating on one RNN window-tile (1,2,4,8,16); 0 = auto */
 
 /* ---- lifetime: replaces TF_RNN_Past_State.__init__ (simple_transformer_with_state.py:9-54) ---------------- */
 int tip_abi_version(void);

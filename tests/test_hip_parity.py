@@ -66,20 +66,23 @@ def test_golden_vectors(golden, plan):
         assert e64 < TOL_TIGHT, (tag, plan, e64)
 
 
-@pytest.mark.parametrize("cluster", [1, 2, 4, 8])
-def test_rnn_cluster_variants_bit_identical(cluster):
-    """Splitting an RNN window-tile over 1/2/4/8 cooperating workgroups must not change a single bit."""
+@pytest.mark.parametrize("cluster", [1, 2, 4, 8, 16])
+def test_rnn_cluster_variants(cluster):
+    """Splitting an RNN window-tile over 1..16 cooperating workgroups (streamed or register-resident W_hh) must not
+    change a single bit: every variant uses the same canonical k-summation order, so a stream's output cannot
+    depend on how many streams share the launch (which is what picks the cluster size)."""
     cfg = synth.PAPER
     m, w = _gpu_model(cfg, 0)
     x_imu, x_s = synth.make_inputs(cfg, 37, 40, seed=11)
     m.set_plan("general", rnn_cluster=1)
     y1 = _run(m, x_imu, x_s)
     m.set_plan("general", rnn_cluster=cluster)
-    for _ in range(3):
-        yc = _run(m, x_imu, x_s)
-        assert np.array_equal(y1, yc)
-    yo = oracle.forward(cfg, w, x_imu[:4], x_s[:4], dtype=np.float64)
-    assert np.abs(y1[:4] - yo).max() < TOL_TIGHT
+    yc = _run(m, x_imu, x_s)
+    assert np.array_equal(y1, yc), np.abs(y1 - yc).max()
+    for _ in range(5):
+        assert np.array_equal(yc, _run(m, x_imu, x_s)), "hand-off race: run-to-run difference"
+    yo = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
+    assert np.abs(yc - yo).max() < TOL_TIGHT
 
 
 @pytest.mark.parametrize("plan", PLANS)

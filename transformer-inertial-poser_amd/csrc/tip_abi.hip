@@ -266,7 +266,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
             for (auto& t : h->timers) t.used = 0;  // reset the accumulators
             return TIP_OK;
         case TIP_OPT_RNN_CLUSTER:
-            if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) return TIP_ERR_INVALID_ARG;
+            if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) return TIP_ERR_INVALID_ARG;
             h->rnn_cluster = value;
             return TIP_OK;
         default: return TIP_ERR_INVALID_ARG;
@@ -510,7 +510,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
             if (cluster == 0) {
                 // auto: spread one window-tile over as many CUs as the tile count leaves idle
                 const int ntiles = (B + kRnnTile - 1) / kRnnTile;
-                cluster = 8;
+                cluster = 16;
                 while (cluster > 1 && ntiles * cluster > h->num_cus) cluster >>= 1;
             }
             TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, cluster, h->num_cus, s),

@@ -18,6 +18,7 @@ namespace tip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // prologue: U[row][0:InPad] = [x_imu | scrub(x_s) * mask * scale | 0-pad]
@@ -353,7 +354,11 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
     const int ngroups = gridDim.x / cluster;
     const int l15 = lane & 15, lg = lane >> 4;
     const int nb0 = (cid * 4 + wave) * NBW;  // first global column block of this wave
-    const float4* wf = reinterpret_cast<const float4*>(whh_frag) + (size_t)nb0 * KB * 64 + lane;
+    // W_hh fragments through a buffer descriptor: opaque to the optimiser, so the one-block-ahead prefetch survives
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(whh_frag), 0, R * R * 4, 0x00020000);
+    auto ldw = [&](int n, int kb) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, ((nb0 + n) * KB + kb) * 1024, 0));
+    };
 
     for (int tile = group; tile < ntiles; tile += ngroups) {
         const int b0 = tile * kRnnTile;
@@ -373,8 +378,10 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
                 // wait for every member's slice of h_{t-1}, then pull the full [16][R] tile from HALL
                 if (tid == 0) {
                     unsigned* f = flags + (size_t)tile * T + (t - 1);
-                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)cluster)
+                    for (unsigned spins = 0; spins < (1u << 22); ++spins) {  // bounded: never hang the GPU
+                        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)cluster) break;
                         __builtin_amdgcn_s_sleep(1);
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
                 __syncthreads();
@@ -387,29 +394,53 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
                 }
                 __syncthreads();
             }
+            // Canonical accumulation order (shared by every RNN kernel variant so that a stream's result does not
+            // depend on how many streams share the launch): four fmaf chains per output — k-blocks of the lower /
+            // upper half of K, even / odd — combined as (c00 + c01) + (c10 + c11).
             f32x4 acc[NBW];
-#pragma unroll
-            for (int n = 0; n < NBW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (t > 0) {
-                float4 wc[NBW], wn[NBW];
+                f32x4 ch[4][NBW];
 #pragma unroll
-                for (int n = 0; n < NBW; ++n) wc[n] = wf[(size_t)(n * KB) * 64];
-                for (int kb = 0; kb < KB; ++kb) {
-                    const int kn = kb + 1 < KB ? kb + 1 : kb;
+                for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int n = 0; n < NBW; ++n) wn[n] = wf[(size_t)(n * KB + kn) * 64];
-                    const float4 a = *reinterpret_cast<const float4*>(smem + l15 * LDH + kb * 16 + lg * 4);
+                    for (int n = 0; n < NBW; ++n) ch[c][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                f32x4 wc[NBW], wn[NBW];
 #pragma unroll
-                    for (int n = 0; n < NBW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wc[n].x, acc[n], 0, 0, 0);
+                for (int n = 0; n < NBW; ++n) wc[n] = ldw(n, 0);
 #pragma unroll
-                    for (int n = 0; n < NBW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wc[n].y, acc[n], 0, 0, 0);
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll 1
+                    for (int kb = half * (KB / 2); kb < (half + 1) * (KB / 2); kb += 2) {
 #pragma unroll
-                    for (int n = 0; n < NBW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wc[n].z, acc[n], 0, 0, 0);
+                        for (int n = 0; n < NBW; ++n) wn[n] = ldw(n, kb + 1);
+                        const float4 a0 = *reinterpret_cast<const float4*>(smem + l15 * LDH + kb * 16 + lg * 4);
 #pragma unroll
-                    for (int n = 0; n < NBW; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wc[n].w, acc[n], 0, 0, 0);
+                        for (int n = 0; n < NBW; ++n) ch[half * 2][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wc[n].x, ch[half * 2][n], 0, 0, 0);
 #pragma unroll
-                    for (int n = 0; n < NBW; ++n) wc[n] = wn[n];
+                        for (int n = 0; n < NBW; ++n) ch[half * 2][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wc[n].y, ch[half * 2][n], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) ch[half * 2][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wc[n].z, ch[half * 2][n], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) ch[half * 2][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wc[n].w, ch[half * 2][n], 0, 0, 0);
+                        const int k2 = kb + 2 < KB ? kb + 2 : kb;
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) wc[n] = ldw(n, k2);
+                        const float4 a1 = *reinterpret_cast<const float4*>(smem + l15 * LDH + (kb + 1) * 16 + lg * 4);
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) ch[half * 2 + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wn[n].x, ch[half * 2 + 1][n], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) ch[half * 2 + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wn[n].y, ch[half * 2 + 1][n], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) ch[half * 2 + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wn[n].z, ch[half * 2 + 1][n], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < NBW; ++n) ch[half * 2 + 1][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wn[n].w, ch[half * 2 + 1][n], 0, 0, 0);
+                    }
                 }
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) acc[n] = (ch[0][n] + ch[1][n]) + (ch[2][n] + ch[3][n]);
+            } else {
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             __syncthreads();  // everyone is done reading h_{t-1} from LDS
             // epilogue: D layout of 16x16: col = lane&15, row = 4*(lane>>4) + r
@@ -445,7 +476,148 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// RNN recurrence, register-resident variant (R = 512).  The serial 40-step chain is latency-bound, so the
+// 16-window tile is spread over CLUSTER = 512 / (16*WAVES/KSPLIT) workgroups; every wave keeps its
+// [16 cols x 512/KSPLIT] slice of W_hh in VGPRs for the whole launch (64 or 128 registers per lane) — nothing is
+// re-read per step except the 32-KB hidden tile.  Per step: sc1 (write-through) stores of the new h slice into
+// HALL -> per-(tile,step) arrival counter -> the other members poll it and pull the tile back with sc1 loads
+// (agent-scope coherent across the 8 XCD L2s; no fences on the critical path).
+// ------------------------------------------------------------------------------------------------
+template <int WAVES, int KSPLIT>
+__global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* __restrict__ ih,
+                                                                   const float* __restrict__ whh_frag,
+                                                                   float* __restrict__ hall, unsigned* __restrict__ flags,
+                                                                   int B, int T, int ntiles, int hall_bytes) {
+    constexpr int R = 512, KB = R / 16, KBW = KB / KSPLIT;      // k-blocks per wave
+    constexpr int CBW = WAVES / KSPLIT;                          // 16-column blocks per workgroup
+    constexpr int CLUSTER = KB / CBW;
+    constexpr int LDH = R + 4;
+    constexpr int THREADS = WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // h tile [16][LDH] | k-split partials
+    float* red = smem + kRnnTile * LDH;                           // [KSPLIT-1][CBW][64 lanes][4]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = wave % CBW, ks = wave / CBW;
+    const int cid = blockIdx.x % CLUSTER, group = blockIdx.x / CLUSTER, ngroups = gridDim.x / CLUSTER;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nb = cid * CBW + cb;                                // global 16-column block of this wave
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hall, 0, hall_bytes, 0x00020000);
+
+    // W_hh slice -> registers, once
+    float4 wreg[KBW];
+    {
+        const float4* wf = reinterpret_cast<const float4*>(whh_frag) + ((size_t)nb * KB + ks * KBW) * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < KBW; ++k) wreg[k] = wf[(size_t)k * 64];
+    }
+
+    for (int tile = group; tile < ntiles; tile += ngroups) {
+        const int b0 = tile * kRnnTile;
+        for (int t = 0; t < T; ++t) {
+            float ihv[4];
+            if (ks == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int bb = b0 + lg * 4 + r;
+                    ihv[r] = bb < B ? ih[((size_t)bb * T + t) * R + nb * 16 + l15] : 0.f;
+                }
+            }
+            // canonical accumulation (see rnn_kernel): chains {lower,upper half of K} x {even,odd k-block}
+            constexpr int NH = KSPLIT == 1 ? 2 : 1;   // K halves handled by this wave
+            static_assert(KSPLIT == 1 || KSPLIT == 2, "canonical order is defined on two K halves");
+            f32x4 chn[NH][2];
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) chn[hh][0] = chn[hh][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (t > 0) {
+                if (tid == 0) {
+                    // bounded spin: a cluster member that never arrives must not hang the GPU (result is then wrong,
+                    // which the parity tests catch)
+                    const unsigned* f = flags + (size_t)tile * T + (t - 1);
+                    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)CLUSTER) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                __syncthreads();
+                // pull h_{t-1} [16][512] with sc1 loads (aux = 16): bypass this CU's L1, coherent at agent scope
+                for (int i = tid; i < kRnnTile * (R / 4); i += THREADS) {
+                    const int m = i / (R / 4), c = (i % (R / 4)) * 4;
+                    const int bb = b0 + m;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (bb < B)
+                        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                          hrs, (int)((((size_t)bb * T + (t - 1)) * R + c) * 4), 0, 16));
+                    *reinterpret_cast<f32x4*>(smem + m * LDH + c) = v;
+                }
+                __syncthreads();
+                const float* ap = smem + l15 * LDH + ks * KBW * 16 + lg * 4;
+#pragma unroll
+                for (int hh = 0; hh < NH; ++hh) {
+#pragma unroll
+                    for (int k = hh * (KBW / NH); k < (hh + 1) * (KBW / NH); k += 2) {
+                        const float4 a0 = *reinterpret_cast<const float4*>(ap + k * 16);
+                        const float4 a1 = *reinterpret_cast<const float4*>(ap + (k + 1) * 16);
+                        chn[hh][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wreg[k].x, chn[hh][0], 0, 0, 0);
+                        chn[hh][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wreg[k + 1].x, chn[hh][1], 0, 0, 0);
+                        chn[hh][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wreg[k].y, chn[hh][0], 0, 0, 0);
+                        chn[hh][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wreg[k + 1].y, chn[hh][1], 0, 0, 0);
+                        chn[hh][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wreg[k].z, chn[hh][0], 0, 0, 0);
+                        chn[hh][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wreg[k + 1].z, chn[hh][1], 0, 0, 0);
+                        chn[hh][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wreg[k].w, chn[hh][0], 0, 0, 0);
+                        chn[hh][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wreg[k + 1].w, chn[hh][1], 0, 0, 0);
+                    }
+                }
+            }
+            f32x4 acc = chn[0][0] + chn[0][1];
+            if (NH == 2) acc = acc + (chn[NH - 1][0] + chn[NH - 1][1]);
+            if (KSPLIT > 1) {
+                if (ks > 0) *reinterpret_cast<f32x4*>(red + (((ks - 1) * CBW + cb) * 64 + lane) * 4) = acc;
+                __syncthreads();
+                if (ks == 0) {
+#pragma unroll
+                    for (int q = 1; q < KSPLIT; ++q) acc += *reinterpret_cast<const f32x4*>(red + (((q - 1) * CBW + cb) * 64 + lane) * 4);
+                }
+            }
+            if (ks == 0) {
+                // D layout of 16x16: col = lane&15, row = 4*(lane>>4) + r.  sc1 (write-through) stores.
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int bb = b0 + lg * 4 + r;
+                    if (bb < B) {
+                        const float hv = tanhf(acc[r] + ihv[r]);
+                        __hip_atomic_store(hall + ((size_t)bb * T + t) * R + nb * 16 + l15, hv, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            // publish: every storing wave drains its stores, workgroup barrier, one arrival
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_fetch_add(flags + (size_t)tile * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 size_t rnn_flag_words(int B, int T) { return (size_t)((B + kRnnTile - 1) / kRnnTile) * (size_t)T; }
+
+template <int WAVES, int KSPLIT>
+static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T,
+                                      int ntiles, int num_cus, hipStream_t s) {
+    constexpr int CLUSTER = (512 / 16) / (WAVES / KSPLIT);
+    int groups = ntiles;
+    const int maxg = num_cus / CLUSTER > 0 ? num_cus / CLUSTER : 1;   // keep every cluster co-resident
+    if (groups > maxg) groups = maxg;
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)ntiles * T * sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    const size_t smem = ((size_t)kRnnTile * (512 + 4) + (size_t)(KSPLIT - 1) * (WAVES / KSPLIT) * 256) * sizeof(float);
+    const long long hb = (long long)B * T * 512 * 4;
+    if (hb > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
+                       whh_frag, hall, flags, B, T, ntiles, (int)hb);
+    return hipGetLastError();
+}
 
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
                       int T, int cluster, int num_cus, hipStream_t s) {
@@ -453,6 +625,13 @@ hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, flo
     const int R = d.R;
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
     if (cluster < 1) cluster = 1;
+    if (R == 512 && (long long)B * T * 512 * 4 <= 0x7fffffffLL) {
+        // register-resident clustered kernel: W_hh slice lives in VGPRs, 4/8/16 workgroups per window tile
+        if (cluster >= 16) return launch_rnn_resident<4, 2>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, s);
+        if (cluster == 8) return launch_rnn_resident<4, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, s);
+        if (cluster == 4) return launch_rnn_resident<8, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, s);
+    }
+    if (cluster > 8) cluster = 8;
     const int KB = R / 16;
     while (cluster > 1 && (KB % (4 * cluster))) cluster >>= 1;
     if (KB % (4 * cluster)) return hipErrorInvalidValue;
