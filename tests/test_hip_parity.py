@@ -193,3 +193,32 @@ def test_load_state_dict_refreshes_packed_image():
     y1 = _run(m, x_imu, x_s)
     yo = oracle.forward(cfg, w1, x_imu, x_s, dtype=np.float64)
     assert np.abs(y1 - yo).max() < TOL_TIGHT and np.abs(y1 - y0).max() > 1e-3
+
+
+def test_eval_mode_with_autograd_uses_hip_forward_and_torch_backward():
+    """The reference's runners call the model with autograd enabled (real_time_runner_minimal.py:149-150 ends in
+    .detach()).  In .eval() mode the forward values must still come from the HIP kernels, and .backward() must work."""
+    cfg = synth.TINY
+    m, _ = _gpu_model(cfg, 0)
+    x_imu, x_s = synth.make_inputs(cfg, 3, 12, seed=6)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    with torch.no_grad():
+        y_ng = m(xi, xs)
+    n0 = m.hip_forward_count()
+    y = m(xi, xs)                      # grad enabled, parameters require grad
+    assert m.hip_forward_count() == n0 + 1 and y.requires_grad
+    assert torch.equal(y.detach(), y_ng)
+    y.square().sum().backward()
+    g_hip = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    y2 = m._forward_torch_ops(xi, xs)  # pure torch-op reference for the gradients
+    y2.square().sum().backward()
+    for k, p in m.named_parameters():
+        assert torch.allclose(g_hip[k], p.grad, rtol=1e-3, atol=1e-4), k
+    # .train() mode + autograd -> torch-op composite (encoder dropout p=0.1 live, like the reference)
+    m.train()
+    n1 = m.hip_forward_count()
+    with pytest.warns(UserWarning):
+        yt = m(xi, xs)
+    assert m.hip_forward_count() == n1 and yt.requires_grad
+    assert (yt.detach() - y_ng).abs().max() > 1e-3   # dropout makes it differ

@@ -154,3 +154,18 @@ def test_packed_image_folds():
     blk = flat[off + (nb * 32 + kb) * 256: off + (nb * 32 + kb + 1) * 256].reshape(64, 4)
     exp = np.array([[whh[nb * 16 + (l & 15), kb * 16 + 4 * (l >> 4) + s] for s in range(4)] for l in range(64)])
     assert np.array_equal(blk, exp)
+
+
+def test_zero_edit_drop_in_import_path():
+    """`from simple_transformer_with_state import TF_RNN_Past_State` (train_model.py:14) must resolve to our module
+    when the package directory is put first on PYTHONPATH."""
+    import subprocess
+    import sys
+    code = ("from simple_transformer_with_state import TF_RNN_Past_State as M; import inspect;"
+            "m = M(72, 131, rnn_hid_size=64, tf_hid_size=32, tf_in_dim=32, n_heads=4, tf_layers=1, dropout=0.0,"
+            "in_dropout=0.0, past_state_dropout=0.8, with_acc_sum=True);"
+            "print(len(m.state_dict()), 'tip_amd' in inspect.getsourcefile(M) or 'inertial-poser_amd' in inspect.getsourcefile(M))")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "transformer-inertial-poser_amd"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd="/tmp")
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1] == "20 True"

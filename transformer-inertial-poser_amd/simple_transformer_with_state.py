@@ -6,11 +6,19 @@ Mirrors the reference's module surface (/root/reference/simple_transformer_with_
   * forward(x_imu [B,T,72(+18)], x_s [B,T,size_s]) -> [B,T,size_s], inputs untouched, NaNs in x_s scrubbed (:60-102)
   * nn.Module services the callers use: .cuda(), .eval()/.train(), .parameters(), load_state_dict, torch.save
 
-Execution:
-  * inference (no autograd) on a ROCm device, fp32  ->  hand-written HIP kernels through the C-ABI
-    (csrc/libtip_hip.so, include/tip_hip.h).  No fallback: a missing library or a CPU tensor raises.
-  * autograd requested (train_model.py:175,192)      ->  a torch-op composite on the caller's device so the
-    training script keeps working; it is NOT the accelerated path (backward kernels are SURVEY.md 8f-2).
+Execution (ROCm tensors, fp32):
+  * forward values ALWAYS come from the hand-written HIP kernels through the C-ABI (csrc/libtip_hip.so,
+    include/tip_hip.h) unless encoder dropout has to be drawn (next bullet).  No fallback: a missing library, a CPU
+    tensor under no_grad or an fp64 tensor raises.
+  * module in .train() mode AND autograd needed (train_model.py:132,175,192): the reference's encoder layers carry
+    torch's default dropout p=0.1 (nn.TransformerEncoderLayer default; the constructor's `dropout` argument only
+    reaches nn.RNN, where it is a no-op for one layer), live in train mode.  The HIP kernels do not draw it, so this
+    case runs a torch-op composite with that dropout — the training path, not the accelerated one.
+  * .eval() mode with autograd on (the runners never call no_grad): HIP forward wrapped in an autograd.Function
+    whose backward recomputes the torch-op composite, so .backward() still works.
+  NOTE the reference's inference scripts never call .eval() (offline_testing_simple.py:98 is commented out), i.e.
+  they run with encoder dropout accidentally live.  Under torch.no_grad() this module treats a .train()-mode call
+  as inference and does NOT replicate those stochastic encoder-dropout draws.
 
 Dropout semantics kept from the reference: `nn.Dropout(p)(x)` is constructed inside forward (:73,:77), i.e. it is
 always in training mode, so past_state_dropout / in_dropout are live even under .eval().  The HIP path draws the
@@ -26,7 +34,14 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import lib as _lib
+try:
+    from . import lib as _lib
+except ImportError:  # imported as the top-level module `simple_transformer_with_state` (zero-edit drop-in:
+    # PYTHONPATH=<repo>/transformer-inertial-poser_amd ahead of the reference directory)
+    import os as _os
+    import sys as _sys
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    from tip_amd import lib as _lib
 
 
 class _Leaf(nn.Module):
@@ -128,29 +143,39 @@ class TF_RNN_Past_State(nn.Module):
     # ------------------------------------------------------------------------------------------
     # forward
     # ------------------------------------------------------------------------------------------
+    ENCODER_DROPOUT = 0.1   # nn.TransformerEncoderLayer's default; the reference never overrides it (:26-28)
+
     def forward(self, x_imu, x_s):
-        if self._wants_torch_ops(x_imu, x_s):
-            return self._forward_torch_ops(x_imu, x_s)
-        return self._forward_hip(x_imu, x_s, last_row_only=False)
+        return self._dispatch(x_imu, x_s, last_row_only=False)
 
     def forward_last(self, x_imu, x_s):
         """Row T-1 of every window only ([B, size_s]) — what RTRunnerMin.step consumes
         (real_time_runner_minimal.py:150).  Extension over the reference API; same numerics as forward()[:, -1]."""
-        if self._wants_torch_ops(x_imu, x_s):
-            return self._forward_torch_ops(x_imu, x_s)[:, -1]
-        return self._forward_hip(x_imu, x_s, last_row_only=True)
+        return self._dispatch(x_imu, x_s, last_row_only=True)
 
-    def _wants_torch_ops(self, x_imu, x_s) -> bool:
-        if torch.is_grad_enabled() and (x_imu.requires_grad or x_s.requires_grad or
-                                        any(p.requires_grad for p in self.parameters())):
+    def _dispatch(self, x_imu, x_s, last_row_only: bool):
+        needs_grad = torch.is_grad_enabled() and (x_imu.requires_grad or x_s.requires_grad or
+                                                  any(p.requires_grad for p in self.parameters()))
+        if needs_grad and (self.training or not x_imu.is_cuda):
             if not self._warned_autograd:
-                warnings.warn("tip_amd: autograd requested — using the torch-op training composite; the HIP kernels "
-                              "cover the inference forward only (call under torch.no_grad() for the accelerated path)")
+                warnings.warn("tip_amd: autograd in .train() mode (or on CPU) — using the torch-op training composite "
+                              "(encoder dropout p=0.1 live, as in the reference); the HIP kernels serve .eval() / "
+                              "torch.no_grad() forwards")
                 self._warned_autograd = True
-            return True
-        if self.training and self.dropout > 0.0:
-            return True  # encoder dropout (p=dropout) is live in train mode: only the torch-op path draws it
-        return False
+            y = self._forward_torch_ops(x_imu, x_s)
+            return y[:, -1] if last_row_only else y
+        if not needs_grad:
+            return self._forward_hip(x_imu, x_s, last_row_only)
+        # eval mode, autograd on: HIP forward, torch-op recompute in backward
+        xi = F.dropout(x_imu, self.in_dropout, training=True) if self.in_dropout > 0.0 else x_imu   # :73
+        mask = self._draw_keep_mask(x_s)
+        return _HipForwardTorchBackward.apply(self, last_row_only, xi, x_s, mask, *self.parameters())
+
+    def _draw_keep_mask(self, x_s):
+        """Bernoulli keep-mask of the always-on past-state dropout (:77); None when p == 0."""
+        if self.past_state_dropout <= 0.0:
+            return None
+        return (torch.rand_like(x_s) >= self.past_state_dropout).to(x_s.dtype)
 
     # -- HIP path -------------------------------------------------------------------------------
     def _tip_config(self) -> _lib.TipConfig:
@@ -205,7 +230,7 @@ class TF_RNN_Past_State(nn.Module):
     def hip_forward_count(self) -> int:
         return self._handle.forward_count() if self._handle is not None else 0
 
-    def _forward_hip(self, x_imu, x_s, last_row_only: bool):
+    def _forward_hip(self, x_imu, x_s, last_row_only: bool, keep_mask="draw", apply_in_dropout=True):
         if not (x_imu.is_cuda and x_s.is_cuda):
             raise RuntimeError("tip_amd.TF_RNN_Past_State: the inference forward runs on an MI355X through "
                                "libtip_hip.so only — move the module and its inputs to the GPU (.cuda()); "
@@ -230,13 +255,14 @@ class TF_RNN_Past_State(nn.Module):
                 self.refresh_packed(dev)
             x_imu_c = x_imu.contiguous()
             x_s_c = x_s.contiguous()
-            if self.in_dropout > 0.0:  # :73 — a fresh nn.Dropout is always in training mode
+            if apply_in_dropout and self.in_dropout > 0.0:  # :73 — a fresh nn.Dropout is always in training mode
                 x_imu_c = F.dropout(x_imu_c, self.in_dropout, training=True)
             flags = 0
             mask_ptr, scale = None, 1.0
-            if self.past_state_dropout > 0.0:  # :77
+            mask = self._draw_keep_mask(x_s_c) if isinstance(keep_mask, str) else keep_mask   # :77
+            if mask is not None:
                 p = self.past_state_dropout
-                mask = (torch.rand_like(x_s_c) >= p).to(torch.float32)
+                mask = mask.to(torch.float32).contiguous()
                 mask_ptr, scale = mask.data_ptr(), (1.0 / (1.0 - p) if p < 1.0 else 0.0)
                 flags |= _lib.TIP_FWD_KEEP_MASK
             if last_row_only:
@@ -253,7 +279,7 @@ class TF_RNN_Past_State(nn.Module):
         return y
 
     # -- torch-op composite (autograd / training) -----------------------------------------------
-    def _forward_torch_ops(self, x_imu, x_s):
+    def _forward_torch_ops(self, x_imu, x_s, keep_mask="draw", apply_in_dropout=True):
         B, T = x_imu.shape[0], x_imu.shape[1]
         D, H = self.tf_in_dim, self.n_heads
         dh = D // H
@@ -261,11 +287,14 @@ class TF_RNN_Past_State(nn.Module):
         keep = torch.ones(self.size_s, dtype=s.dtype, device=s.device)
         keep[18 * 6: 18 * 6 + 3] = 0.0                                  # :75
         s = s * keep
-        xi = F.dropout(x_imu, self.in_dropout, training=True) if self.in_dropout > 0 else x_imu   # :73
-        s = F.dropout(s, self.past_state_dropout, training=True) if self.past_state_dropout > 0 else s  # :77
+        xi = F.dropout(x_imu, self.in_dropout, training=True) if (apply_in_dropout and self.in_dropout > 0) else x_imu  # :73
+        mask = self._draw_keep_mask(s) if isinstance(keep_mask, str) else keep_mask                     # :77
+        if mask is not None:
+            p = self.past_state_dropout
+            s = s * mask * (1.0 / (1.0 - p) if p < 1.0 else 0.0)
         z = F.linear(torch.cat((xi, s), dim=2), self.in_linear.weight, self.in_linear.bias)
         z = z.reshape(B, T, H, dh).transpose(2, 3).reshape(B, T, D)      # :88-89 (batch-first view of the same shuffle)
-        pdrop = self.dropout if self.training else 0.0
+        pdrop = self.ENCODER_DROPOUT if self.training else 0.0   # torch default inside nn.TransformerEncoderLayer
         for layer in self.tf_encode.layers:
             qkv = F.linear(z, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias)
             q, k, v = (t.reshape(B, T, H, dh).transpose(1, 2) for t in qkv.split(D, dim=2))
@@ -285,3 +314,39 @@ class TF_RNN_Past_State(nn.Module):
                 hs.append(hcur)
             z = torch.stack(hs, dim=1)
         return F.linear(z, self.linear.weight, self.linear.bias)
+
+
+class _HipForwardTorchBackward(torch.autograd.Function):
+    """.eval()-mode forward on the HIP kernels with autograd still enabled (the reference's runners never enter
+    no_grad): values come from libtip_hip.so; if backward is ever called, the torch-op composite is recomputed
+    on the saved inputs (same keep-mask) and differentiated."""
+
+    @staticmethod
+    def forward(ctx, module, last_row_only, x_imu, x_s, mask, *params):
+        ctx.module, ctx.last = module, last_row_only
+        ctx.has_mask = mask is not None
+        ctx.save_for_backward(x_imu, x_s, *( [mask] if mask is not None else [] ))
+        with torch.no_grad():
+            return module._forward_hip(x_imu, x_s, last_row_only, keep_mask=mask, apply_in_dropout=False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved = ctx.saved_tensors
+        x_imu, x_s = saved[0], saved[1]
+        mask = saved[2] if ctx.has_mask else None
+        m = ctx.module
+        with torch.enable_grad():
+            xi = x_imu.detach().requires_grad_(ctx.needs_input_grad[2])
+            xs = x_s.detach().requires_grad_(ctx.needs_input_grad[3])
+            y = m._forward_torch_ops(xi, xs, keep_mask=mask, apply_in_dropout=False)
+            if ctx.last:
+                y = y[:, -1]
+            params = list(m.parameters())
+            wanted = [t for t in [xi, xs] + params if t.requires_grad]
+            grads = torch.autograd.grad(y, wanted, gy, allow_unused=True)
+        it = iter(grads)
+        out = [None, None]
+        for t in [xi, xs] + params:
+            out.append(next(it) if t.requires_grad else None)
+        out.insert(4, None)  # mask
+        return tuple(out)
