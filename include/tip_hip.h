@@ -60,6 +60,8 @@ typedef enum tip_status {
 #define TIP_PLAN_AUTO    0
 #define TIP_PLAN_GENERAL 1 /* layer-by-layer MFMA GEMM kernels, any configuration */
 #define TIP_PLAN_FUSED   2 /* one workgroup = one window through all encoder layers (paper configuration) */
+#define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);
+                              AUTO picks it for B <= 32 */
 
 #define TIP_OPT_PLAN        1
 #define TIP_OPT_PROFILE     2 /* 0 off; 1: bracket every stage with a HIP event pair; 2: only the dominant stage

@@ -66,10 +66,12 @@ void build_layout(tip_handle* h) {
         L.rnn_ih = carve_linear(c, d.R, d.D);
         L.whh_frag_off = c.take((size_t)d.R * d.R);
         L.out_lin = carve_linear(c, d.S, d.R);
+        L.out_frag_off = c.take((size_t)round_up(d.S, 16) * d.R);
     } else {
         L.rnn_ih = PackedLinear{};
         L.whh_frag_off = 0;
         L.out_lin = carve_linear(c, d.S, d.D);
+        L.out_frag_off = c.take((size_t)round_up(d.S, 16) * d.D);
     }
     L.fused_floats = fused_packed_floats(d);
     L.fused_off = c.take(L.fused_floats);
@@ -136,6 +138,7 @@ Workspace carve_workspace(const Dims& d, int B, int T) {
     w.att = take(Mp * d.D);
     w.hall = take(Mp * (d.with_rnn ? d.R : 1));
     w.flags = take(rnn_flag_words(B, T) + 64);
+    w.lat = take(latency_supported(d, B, T) ? latency_workspace_floats(B, T) : 0);
     w.total_bytes = off * sizeof(float);
     return w;
 }
@@ -257,7 +260,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
     if (!h) return TIP_ERR_INVALID_ARG;
     switch (option) {
         case TIP_OPT_PLAN:
-            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED) return TIP_ERR_INVALID_ARG;
+            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_LATENCY) return TIP_ERR_INVALID_ARG;
             h->plan = value;
             return TIP_OK;
         case TIP_OPT_PROFILE:
@@ -360,6 +363,19 @@ int tip_pack_weights(const tip_handle* h, const float* const* t, int n, void* pa
     } else {
         pack_linear(img, L.out_lin, tw[0], tw[1]);
     }
+    {
+        // out-linear in fragment order for the skinny head GEMM
+        const int K = d.with_rnn ? d.R : d.D, KB = K / 16, NBo = round_up(d.S, 16) / 16;
+        const float* Wo = d.with_rnn ? tw[4] : tw[0];
+        float* f = img + L.out_frag_off;
+        for (int nb = 0; nb < NBo; ++nb)
+            for (int kb = 0; kb < KB; ++kb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const int n = nb * 16 + (lane & 15), k = kb * 16 + 4 * (lane >> 4) + s4;
+                        f[((size_t)(nb * KB + kb) * 64 + lane) * 4 + s4] = n < d.S ? Wo[(size_t)n * K + k] : 0.f;
+                    }
+    }
     if (L.fused_floats) fused_pack(d, t, img + L.fused_off);
     return TIP_OK;
 }
@@ -440,14 +456,26 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     } while (0)
 
     int plan = h->plan;
-    if (plan == TIP_PLAN_AUTO) plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
+    if (plan == TIP_PLAN_AUTO) {
+        if (latency_supported(d, B, T) && B <= 32) plan = TIP_PLAN_LATENCY;   // few streams: spread each window over many CUs
+        else plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
+    }
     if (plan == TIP_PLAN_FUSED && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
 
     float* enc_out = xa;  // encoder output [M, D]
-    if (plan == TIP_PLAN_FUSED) {
+    bool ih_done = false;  // the fused plan also emits the RNN input projection
+    bool rnn_done = false;
+    if (plan == TIP_PLAN_LATENCY) {
+        StageScope sc(h, s, "latency_chain");
+        TIP_TRY(launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall,
+                                    B, T, s), "latency_chain");
+        rnn_done = true;
+    } else if (plan == TIP_PLAN_FUSED) {
         StageScope sc(h, s, "fused_encoder");
-        TIP_TRY(launch_fused_encoder(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, xa, B, T, h->num_cus, s),
-                "fused_encoder");
+        ih_done = fused_has_rnn_ih(d);
+        TIP_TRY(launch_fused_encoder(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, ih_done ? nullptr : xa,
+                                     ih_done ? big : nullptr, B, T, h->num_cus, s), "fused_encoder");
     } else {
         {
             StageScope sc(h, s, "prologue");
@@ -498,8 +526,11 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     const bool last_only = (flags & TIP_FWD_LAST_ROW_ONLY) != 0;
     const float* head_in = enc_out;
     int head_ld = d.D;
-    if (d.with_rnn) {
-        {
+    if (d.with_rnn && rnn_done) {
+        head_in = hall;
+        head_ld = d.R;
+    } else if (d.with_rnn) {
+        if (!ih_done) {
             StageScope sc(h, s, "rnn_ih_gemm");
             TIP_TRY(launch_gemm(enc_out, d.D, P + L.rnn_ih.w_off, L.rnn_ih.Kpad, P + L.rnn_ih.b_off, nullptr, 0, big,
                                 d.R, M, d.R, L.rnn_ih.Npad, 0, s), "rnn_ih_gemm");
@@ -521,13 +552,15 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     }
     {
         StageScope sc(h, s, "out_linear");
-        if (last_only) {
-            // only row T-1 of every window is consumed by the streaming runner (real_time_runner_minimal.py:150)
-            TIP_TRY(launch_gemm(head_in + (size_t)(T - 1) * head_ld, T * head_ld, P + L.out_lin.w_off, L.out_lin.Kpad,
-                                P + L.out_lin.b_off, nullptr, 0, y, d.S, B, d.S, L.out_lin.Npad, 0, s), "out_linear");
+        const int Kh = d.with_rnn ? d.R : d.D;
+        // rows the projection runs on: all M, or row T-1 of every window (real_time_runner_minimal.py:150)
+        const float* hA = last_only ? head_in + (size_t)(T - 1) * head_ld : head_in;
+        const long long hlda = last_only ? (long long)T * head_ld : head_ld;
+        const int hM = last_only ? B : M;
+        if (plan == TIP_PLAN_LATENCY) {
+            TIP_TRY(launch_latency_head(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, hM, d.S, s), "out_linear");
         } else {
-            TIP_TRY(launch_gemm(head_in, head_ld, P + L.out_lin.w_off, L.out_lin.Kpad, P + L.out_lin.b_off, nullptr, 0,
-                                y, d.S, M, d.S, L.out_lin.Npad, 0, s), "out_linear");
+            TIP_TRY(launch_head_gemm(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, hM, d.S, Kh, s), "out_linear");
         }
     }
 #undef TIP_TRY

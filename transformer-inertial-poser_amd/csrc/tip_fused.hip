@@ -20,7 +20,7 @@ namespace tip {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace fz {
-constexpr int D = 256, H = 16, DH = 16, F = 1024, RP = 48, RB = 3, TMAX = 40;
+constexpr int D = 256, H = 16, DH = 16, F = 1024, RP = 48, RB = 3, TMAX = 40, R = 512;
 constexpr int KIN = 224;            // in_linear K, zero padded (221 with acc-sum, 203 without)
 constexpr int LDX = D + 4;          // 260
 constexpr int LDC = 128 + 4;        // 132: one Q / K / V plane of an 8-head chunk
@@ -53,9 +53,13 @@ bool fused_supported(const Dims& d, int T) {
     return d.D == fz::D && d.H == fz::H && d.F == fz::F && d.In <= fz::KIN && T >= 1 && T <= fz::TMAX && d.L >= 1;
 }
 
+// RNN input projection (R = 512) rides at the end of the fused section: [32 nb][16 kb] fragments + (b_ih + b_hh)
+bool fused_has_rnn_ih(const Dims& d) { return d.with_rnn && d.R == fz::R; }
+static size_t fused_ih_off(const Dims& d) { return fz::LAYER0 + (size_t)d.L * fz::LAYER_FLOATS; }
+
 size_t fused_packed_floats(const Dims& d) {
     if (!(d.D == fz::D && d.H == fz::H && d.F == fz::F && d.In <= fz::KIN)) return 0;
-    return fz::LAYER0 + (size_t)d.L * fz::LAYER_FLOATS + fz::TAIL_PAD;
+    return fused_ih_off(d) + (fused_has_rnn_ih(d) ? (size_t)fz::R * fz::D + fz::R : 0) + fz::TAIL_PAD;
 }
 
 // W [N][K] row-major (K <= Kpad) -> 16x16x4 B-fragment order [N/16][Kpad/16][64 lanes][4]:
@@ -102,6 +106,12 @@ void fused_pack(const Dims& d, const float* const* t, float* dst) {
         memcpy(L + BE1, lw[9], sizeof(float) * D);
         memcpy(L + G2, lw[10], sizeof(float) * D);
         memcpy(L + BE2, lw[11], sizeof(float) * D);
+    }
+    if (fused_has_rnn_ih(d)) {
+        const float* const* tw = t + 2 + 12 * d.L;
+        float* I = dst + fused_ih_off(d);
+        pack_frag(I, tw[0], R, D, D, nullptr, 1.f, 0);
+        for (int i = 0; i < R; ++i) I[(size_t)R * D + i] = tw[2][i] + tw[3][i];
     }
 }
 
@@ -161,17 +171,21 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[fz::RB][NBW], const floa
         w0[n] = load_frag(rsrc, voff, soff + n * nstride_b);
         w1[n] = load_frag(rsrc, voff, soff + n * nstride_b + 1024);
     }
+    // A fragments are double-buffered too: the ds_read_b128 of k-block kb+1 is in flight while the MFMAs of kb issue.
+    // (Reads past the last k-block stay inside the LDS allocation and are never used.)
+    float4 a0[fz::RB], a1[fz::RB];
+#pragma unroll
+    for (int r = 0; r < fz::RB; ++r) a0[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda);
 #pragma unroll 1
     for (int kb = 0; kb < KB; kb += 2) {
-        float4 a[fz::RB];
 #pragma unroll
-        for (int r = 0; r < fz::RB; ++r) a[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda + kb * 16);
-        mfma_block<NBW>(acc, a, w0);
+        for (int r = 0; r < fz::RB; ++r) a1[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda + (kb + 1) * 16);
+        mfma_block<NBW>(acc, a0, w0);
 #pragma unroll
         for (int n = 0; n < NBW; ++n) w0[n] = load_frag(rsrc, voff, soff + n * nstride_b + (kb + 2) * 1024);
 #pragma unroll
-        for (int r = 0; r < fz::RB; ++r) a[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda + (kb + 1) * 16);
-        mfma_block<NBW>(acc, a, w1);
+        for (int r = 0; r < fz::RB; ++r) a0[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda + (kb + 2) * 16);
+        mfma_block<NBW>(acc, a1, w1);
 #pragma unroll
         for (int n = 0; n < NBW; ++n) w1[n] = load_frag(rsrc, voff, soff + n * nstride_b + (kb + 3) * 1024);
     }
@@ -254,8 +268,8 @@ __device__ __forceinline__ void attention_head(float* Qc, const float* Kc, const
 
 __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
     const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
-    const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ xout, int B, int T, int NI, int S, int L,
-    int wbytes) {
+    const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ xout, float* __restrict__ ih_out, int B,
+    int T, int NI, int S, int L, int wbytes, int ih_off_b) {
     using namespace fz;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;
@@ -404,19 +418,40 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
             layernorm_rows(X, LW + G2, LW + BE2, wave, lane);
             __syncthreads();
         }
-        // ---- encoder output rows 0..T-1 -> HBM ---------------------------------------------------------------------
-        float* out = xout + (size_t)win * T * D;
-        for (int i = tid; i < T * (D / 4); i += THREADS) {
-            const int r = i / (D / 4), c4 = i - r * (D / 4);
-            *reinterpret_cast<float4*>(out + (size_t)r * D + c4 * 4) = *reinterpret_cast<const float4*>(X + r * LDX + c4 * 4);
+        // ---- RNN input projection (:99, first half of nn.RNN): IH = X W_ih^T + (b_ih + b_hh), rows 0..T-1 -> HBM ----
+        if (ih_out) {
+            f32x4 acc[RB][4];
+            zero_acc<4>(acc);
+            gemm_phase<4, 16>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, ih_off_b + (wave * 4) * 16 * 1024, 16 * 1024);
+            float* io = ih_out + (size_t)win * T * R;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int col = (wave * 4 + n) * 16 + l15;
+                const float bv = wts[ih_off_b / 4 + R * D + col];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = r * 16 + lg * 4 + e;
+                        if (row < T) io[(size_t)row * R + col] = acc[r][n][e] + bv;
+                    }
+            }
+        }
+        // ---- encoder output rows 0..T-1 -> HBM (only when a caller wants it) ---------------------------------------
+        if (xout) {
+            float* out = xout + (size_t)win * T * D;
+            for (int i = tid; i < T * (D / 4); i += THREADS) {
+                const int r = i / (D / 4), c4 = i - r * (D / 4);
+                *reinterpret_cast<float4*>(out + (size_t)r * D + c4 * 4) = *reinterpret_cast<const float4*>(X + r * LDX + c4 * 4);
+            }
         }
         __syncthreads();
     }
 }
 
 hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
-                                const float* keep_mask, float keep_scale, float* xout, int B, int T, int num_cus,
-                                hipStream_t s) {
+                                const float* keep_mask, float keep_scale, float* xout, float* ih_out, int B, int T,
+                                int num_cus, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
@@ -427,7 +462,8 @@ hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float
     }
     const int grid = B < num_cus ? B : num_cus;
     hipLaunchKernelGGL(fused_encoder_kernel, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s,
-                       keep_mask, keep_scale, xout, B, T, d.n_imu_total, d.S, d.L, (int)(fused_packed_floats(d) * 4));
+                       keep_mask, keep_scale, xout, fused_has_rnn_ih(d) ? ih_out : nullptr, B, T, d.n_imu_total, d.S, d.L,
+                       (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4));
     return hipGetLastError();
 }
 

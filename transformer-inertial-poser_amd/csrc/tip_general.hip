@@ -174,6 +174,91 @@ hipError_t launch_gemm(const float* A, int lda, const float* W, int Kpad, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Skinny "head" GEMM (:102 output projection, N = 131): Y[M,N] = A[M,K] * W^T + b.  N is far below the 128-wide
+// block tile, so every wave owns 16 rows x ALL column blocks (v_mfma_f32_16x16x4_f32): its A fragments come
+// straight from global memory (each row is read exactly once, 64 B per lane group) and the weight fragments
+// (fragment-ordered, L2-resident, <= 288 KB) through a buffer descriptor, register double-buffered.
+// ------------------------------------------------------------------------------------------------
+template <int NBO>   // 16-column blocks per workgroup (9 = all of N = 131; 1 when M is small and grid.y walks the blocks)
+__global__ __launch_bounds__(256) void head_gemm_kernel(const float* __restrict__ A, long long lda,
+                                                        const float* __restrict__ wfrag, const float* __restrict__ bias,
+                                                        float* __restrict__ Y, int ldy, int M, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int row0 = (blockIdx.x * 4 + wave) * 16;
+    if (row0 >= M) return;
+    const int KB = K / 16;
+    const int nbase = blockIdx.y * NBO;   // first column block of this workgroup
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wfrag), 0, ((N + 15) / 16) * K * 64, 0x00020000);
+    auto ldw = [&](int n, int kb) -> f32x4 {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 16, ((nbase + n) * KB + kb) * 1024, 0));
+    };
+    const int arow = row0 + l15 < M ? row0 + l15 : M - 1;   // clamp: padded rows are computed but never stored
+    const float* ap = A + (size_t)arow * lda + lg * 4;
+    f32x4 acc[NBO];
+#pragma unroll
+    for (int n = 0; n < NBO; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 wc[NBO], wn[NBO];
+#pragma unroll
+    for (int n = 0; n < NBO; ++n) wc[n] = ldw(n, 0);
+    float4 a = *reinterpret_cast<const float4*>(ap);
+#pragma unroll 1
+    for (int kb = 0; kb < KB; ++kb) {
+        const int kn = kb + 1 < KB ? kb + 1 : kb;
+#pragma unroll
+        for (int n = 0; n < NBO; ++n) wn[n] = ldw(n, kn);
+        const float4 an = *reinterpret_cast<const float4*>(ap + kn * 16);
+#pragma unroll
+        for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wc[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wc[n].y, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wc[n].z, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wc[n].w, acc[n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < NBO; ++n) wc[n] = wn[n];
+        a = an;
+    }
+#pragma unroll
+    for (int n = 0; n < NBO; ++n) {
+        const int col = (nbase + n) * 16 + l15;
+        if (col < N) {
+            const float bv = bias[col];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = row0 + lg * 4 + e;
+                if (row < M) Y[(size_t)row * ldy + col] = acc[n][e] + bv;
+            }
+        }
+    }
+}
+
+hipError_t launch_head_gemm(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy,
+                            int M, int N, int K, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    const int nbo = (N + 15) / 16;
+    const dim3 block(256);
+    if ((M + 63) / 64 * 4 < 256) {
+        // few rows: one column block per workgroup so the (rows x column blocks) grid still covers many CUs
+        hipLaunchKernelGGL(head_gemm_kernel<1>, dim3((M + 63) / 64, nbo), block, 0, s, A, lda, wfrag, bias, Y, ldy, M, N, K);
+        return hipGetLastError();
+    }
+    const dim3 grid((M + 63) / 64);
+#define TIP_HEAD_CASE(NB) \
+    case NB: hipLaunchKernelGGL(head_gemm_kernel<NB>, grid, block, 0, s, A, lda, wfrag, bias, Y, ldy, M, N, K); break;
+    switch (nbo) {
+        TIP_HEAD_CASE(1) TIP_HEAD_CASE(2) TIP_HEAD_CASE(3) TIP_HEAD_CASE(4) TIP_HEAD_CASE(5) TIP_HEAD_CASE(6)
+        TIP_HEAD_CASE(7) TIP_HEAD_CASE(8) TIP_HEAD_CASE(9) TIP_HEAD_CASE(10) TIP_HEAD_CASE(11) TIP_HEAD_CASE(12)
+        default: return hipErrorInvalidValue;
+    }
+#undef TIP_HEAD_CASE
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // attention: one wave per (window, head).  K and V of the head are staged in LDS; lane i owns query row i
 // (and i+64 when T > 64): q and the output accumulator live in registers, scores never leave the lane
 // (online softmax), so the row reductions need no cross-lane traffic at all.

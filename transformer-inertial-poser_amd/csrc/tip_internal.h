@@ -48,6 +48,7 @@ struct PackedLayout {
     PackedLinear rnn_ih;       // bias = b_ih + b_hh
     size_t whh_frag_off;       // W_hh in MFMA 16x16x4 B-fragment order: [R/16 nb][R/16 kb][64 lanes][4]
     PackedLinear out_lin;
+    size_t out_frag_off;       // out-linear weight in B-fragment order [ceil(S/16)][K/16][64][4] (zero padded rows)
     // fused-plan section (paper configuration): weights in 16x16x4 B-fragment order, see tip_fused.hip
     size_t fused_off;
     size_t fused_floats;
@@ -56,7 +57,7 @@ struct PackedLayout {
 
 // Workspace carve-up for the general plan (float offsets), M = B*T rows.
 struct Workspace {
-    size_t xa, xb, big, att, hall, flags;  // float offsets
+    size_t xa, xb, big, att, hall, flags, lat;  // float offsets
     size_t total_bytes;
 };
 
@@ -105,8 +106,23 @@ size_t rnn_flag_words(int B, int T);
 bool fused_supported(const Dims& d, int T);
 size_t fused_packed_floats(const Dims& d);
 void fused_pack(const Dims& d, const float* const* tensors, float* dst);
+bool fused_has_rnn_ih(const Dims& d);
+// xout [B,T,D] and/or ih_out [B,T,R] (RNN input projection incl. b_ih+b_hh); either may be null
 hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
-                                const float* keep_mask, float keep_scale, float* xout, int B, int T, int num_cus,
-                                hipStream_t s);
+                                const float* keep_mask, float keep_scale, float* xout, float* ih_out, int B, int T,
+                                int num_cus, hipStream_t s);
+// Y[M,N] = A[M,K(lda)] * Wfrag^T + bias with Wfrag in 16x16x4 B-fragment order [ceil(N/16)][K/16][64][4]
+hipError_t launch_head_gemm(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy,
+                            int M, int N, int K, hipStream_t s);
+
+// ---- latency plan (tip_latency.hip): one window spread over many CUs, for few concurrent streams ----
+bool latency_supported(const Dims& d, int B, int T);
+size_t latency_workspace_floats(int B, int T);
+hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float* whh_frag, const float* x_imu,
+                               const float* x_s, const float* keep_mask, float keep_scale, float* ws, float* hall, int B,
+                               int T, hipStream_t s);
+
+hipError_t launch_latency_head(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy,
+                               int M, int N, hipStream_t s);
 
 }  // namespace tip

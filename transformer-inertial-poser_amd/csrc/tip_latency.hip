@@ -1,0 +1,602 @@
+// tip_latency.hip — "latency" execution plan for few concurrent streams (B <= 32), paper configuration.
+//
+// The fused plan gives one window to one CU (0.75 ms): fine for throughput, 13x too slow for a single 60-Hz
+// stream.  Here ONE window is spread over up to 64 CUs per GEMM: every workgroup owns ONE 16-column block of the
+// output, its 4 (or 8) waves split K, partial accumulators meet in LDS.  Stages are cut at every all-to-all seam
+// (kernel boundary ~1.5 us is cheaper on this chip than an in-kernel grid exchange, cdna_hip_programming.md 5.6):
+//
+//   lat_in        prologue (:63-78) + in_linear (:79, shuffle folded)           grid (16, B)
+//   per layer:    lat_qkv   [LN2 of previous layer] + QKV projection            grid (48, B)
+//                 lat_attn  causal attention, keys split over 4 waves           grid (16, B)
+//                 lat_out   out-proj + residual (pre-LN1 sum)                   grid (16, B)
+//                 lat_ffn1  LN1 + linear1 + ReLU                                grid (64, B)
+//                 lat_ffn2  linear2 + residual (pre-LN2 sum), 8 waves split K   grid (16, B)
+//   lat_ih        LN2 of the last layer + RNN input projection                  grid (32, B)
+//   rnn_gemv      tanh recurrence (:98-99) as a VALU GEMV (M = 1 per stream: MFMA would idle 15/16 rows);
+//                 4 workgroups per stream keep W_hh in VGPRs (128 per lane) and exchange the 512-float hidden
+//                 vector through 8-byte {step tag, value} granules (the data is the flag; no fence, no counter)
+//   head_gemm     output projection (tip_general.hip)
+//
+// LayerNorm is never a kernel of its own: producers store the pre-norm sum, every consumer re-normalises the
+// rows it stages (40 x 256, ~1 us) and the first workgroup publishes (mean, rstd) per row for the kernels that
+// only need the normalised residual of their own 16 columns.
+// Weights: the fused plan's fragment-ordered image (tip_fused.hip) — nothing is packed twice.
+#include "tip_internal.h"
+
+namespace tip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace lz {
+constexpr int D = 256, DH = 16, F = 1024, R = 512, RP = 48, RB = 3, TMAX = 40, KIN = 224;
+constexpr int LDX = D + 4, LDU = KIN + 4;
+}  // namespace lz
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ f32x4 ldfrag(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+}
+
+// Stage a [T x 256] activation into LDS [48][260] (rows >= T zero) and optionally LayerNorm it in place
+// (eps 1e-5, biased variance).  Row statistics go to `stats_out` ([48][2] = mean, rstd) when non-null.
+template <int THREADS>
+__device__ __forceinline__ void stage_rows_ln(float* Xs, const float* __restrict__ src, int T, const float* __restrict__ g,
+                                              const float* __restrict__ be, float* __restrict__ stats_out) {
+    using namespace lz;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = THREADS / 64, RPW = RP / NW;   // rows per wave
+    // all of this wave's rows are requested before the first reduction: one L2 round trip, not RPW of them
+    float4 v[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int row = wave + i * NW;
+        v[i] = row < T ? *reinterpret_cast<const float4*>(src + (size_t)row * D + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 gg = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g) {
+        gg = *reinterpret_cast<const float4*>(g + lane * 4);
+        bb = *reinterpret_cast<const float4*>(be + lane * 4);
+    }
+    if (g) {
+        // the RPW row reductions advance together through every shuffle step (independent chains interleave)
+        float mean[RPW], var[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) mean[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) mean[i] += __shfl_xor(mean[i], off, 64);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            mean[i] *= (1.f / D);
+            v[i].x -= mean[i]; v[i].y -= mean[i]; v[i].z -= mean[i]; v[i].w -= mean[i];
+            var[i] = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) var[i] += __shfl_xor(var[i], off, 64);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int row = wave + i * NW;
+            const float rstd = 1.0f / sqrtf(var[i] * (1.f / D) + 1e-5f);
+            v[i].x = v[i].x * rstd * gg.x + bb.x; v[i].y = v[i].y * rstd * gg.y + bb.y;
+            v[i].z = v[i].z * rstd * gg.z + bb.z; v[i].w = v[i].w * rstd * gg.w + bb.w;
+            if (row >= T) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (stats_out && lane == 0 && row < T) { stats_out[row * 2] = mean[i]; stats_out[row * 2 + 1] = rstd; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) *reinterpret_cast<float4*>(Xs + (wave + i * NW) * LDX + lane * 4) = v[i];
+}
+
+// This wave's K slice (k-blocks kb0 .. kb0+nkb) of ONE 16-column block: weights first (they do not depend on the
+// activations, so callers request them BEFORE staging / normalising the rows), MFMAs later.
+template <int KBW>
+__device__ __forceinline__ void load_kslice(f32x4 (&w)[KBW], __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nkb) {
+#pragma unroll
+    for (int k = 0; k < KBW; ++k) w[k] = k < nkb ? ldfrag(rsrc, voff, soff + k * 1024) : (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+template <int KBW>
+__device__ __forceinline__ void mma_kslice(f32x4 (&acc)[lz::RB], const float* As /* + l15*lda + lg*4 + kb0*16 */, int lda,
+                                           const f32x4 (&w)[KBW], int nkb) {
+#pragma unroll
+    for (int k = 0; k < KBW; ++k) {
+        if (k < nkb) {
+            float4 a[lz::RB];
+#pragma unroll
+            for (int r = 0; r < lz::RB; ++r) a[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda + k * 16);
+#pragma unroll
+            for (int r = 0; r < lz::RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].x, w[k].x, acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < lz::RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].y, w[k].y, acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < lz::RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].z, w[k].z, acc[r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < lz::RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].w, w[k].w, acc[r], 0, 0, 0);
+        }
+    }
+}
+
+// Cross-wave reduction of the K-split partials: wave r (< 3) ends up with the full row-block r of the 48x16 tile
+// in the MFMA C layout (row = 16 r + 4 (lane>>4) + e, col = lane & 15).  red: [NW][3][64][4] floats.
+template <int NW>
+__device__ __forceinline__ f32x4 reduce_partials(float* red, const f32x4 (&acc)[lz::RB], int wave, int lane) {
+#pragma unroll
+    for (int r = 0; r < lz::RB; ++r) *reinterpret_cast<f32x4*>(red + ((wave * 3 + r) * 64 + lane) * 4) = acc[r];
+    __syncthreads();
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (wave < lz::RB) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += *reinterpret_cast<const f32x4*>(red + ((w * 3 + wave) * 64 + lane) * 4);
+    }
+    return s;
+}
+
+// ---- lat_in: prologue + in_linear --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lat_in_kernel(const float* __restrict__ wts, int wbytes, const float* __restrict__ x_imu,
+                                                     const float* __restrict__ x_s, const float* __restrict__ keep_mask,
+                                                     float keep_scale, float* __restrict__ xpre, int T, int NI, int S,
+                                                     int in_w_off_b, int in_b_off, unsigned long long* __restrict__ gran) {
+    using namespace lz;
+    __shared__ __attribute__((aligned(16))) float U[RP * LDU];
+    __shared__ __attribute__((aligned(16))) float red[4 * 3 * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nb = blockIdx.x, win = blockIdx.y;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, wbytes, 0x00020000);
+    constexpr int KB = KIN / 16;  // 14 k-blocks: waves take 4,4,4,2
+    const int kb0 = wave * 4;
+    const int nkb = KB - kb0 < 4 ? KB - kb0 : 4;
+    f32x4 w[4];
+    load_kslice<4>(w, rsrc, lane * 16, in_w_off_b + (nb * KB + kb0) * 1024, nkb);
+    // the first column block also clears this stream's RNN hand-off granules (tags must start at 0 every launch)
+    if (nb == 0) {
+        unsigned long long* gq = gran + (size_t)win * 2 * R;
+        for (int i = tid; i < 2 * R; i += 256) gq[i] = 0ull;
+    }
+    // window inputs -> U[row][0:NI | NI:NI+S | zero pad]; wave w stages rows w, w+4, ...; lanes walk the columns.
+    // All global loads of a wave are requested before its first LDS store.
+    {
+        const float* xi = x_imu + (size_t)win * T * NI;
+        const float* xs = x_s + (size_t)win * T * S;
+        const float* km = keep_mask ? keep_mask + (size_t)win * T * S : nullptr;
+        constexpr int RPW = RP / 4, NCH = (KIN + 4 + 63) / 64;   // 12 rows per wave, 4 column chunks of 64
+        float v[RPW][NCH];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int row = wave + i * 4;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = ch * 64 + lane;
+                float x = 0.f;
+                if (row < T) {
+                    if (c < NI) {
+                        x = xi[(size_t)row * NI + c];
+                    } else if (c < NI + S) {
+                        const size_t j = (size_t)row * S + (c - NI);
+                        x = xs[j];
+                        if (x != x) x = 0.f;                    // :65
+                        if (km) x = x * km[j] * keep_scale;     // :77
+                    }
+                }
+                v[i][ch] = x;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int c = ch * 64 + lane;
+                if (c < LDU) U[(wave + i * 4) * LDU + c] = v[i][ch];
+            }
+    }
+    __syncthreads();
+    f32x4 acc[RB] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    mma_kslice<4>(acc, U + l15 * LDU + lg * 4 + kb0 * 16, LDU, w, nkb);
+    const f32x4 s = reduce_partials<4>(red, acc, wave, lane);
+    if (wave < RB) {
+        const int col = nb * 16 + l15;
+        const float bv = wts[in_b_off + col];
+        float* o = xpre + (size_t)win * T * D;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = wave * 16 + lg * 4 + e;
+            if (row < T) o[(size_t)row * D + col] = s[e] + bv;
+        }
+    }
+}
+
+// ---- generic "LN(optional) -> one 16-column block of X W^T" kernel: QKV, FFN1 (+ReLU), RNN-ih ----------------
+//   xpre [B][T][256] pre-norm activations; g/be: LayerNorm applied while staging (null: none);
+//   out [B][T][ldo]; stats [B][48][2] written by column-block 0 (null: skip)
+template <bool RELU, bool BLOCKED_OUT>
+__global__ __launch_bounds__(256) void lat_ln_gemm_kernel(const float* __restrict__ wts, int wbytes, const float* __restrict__ xpre,
+                                                          const float* __restrict__ g, const float* __restrict__ be,
+                                                          int w_off_b, int b_off, float* __restrict__ out, int ldo,
+                                                          float* __restrict__ stats, int T) {
+    using namespace lz;
+    __shared__ __attribute__((aligned(16))) float Xs[RP * LDX];
+    __shared__ __attribute__((aligned(16))) float red[4 * 3 * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nb = blockIdx.x, win = blockIdx.y;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, wbytes, 0x00020000);
+    const int kb0 = wave * 4;  // K = 256: 16 k-blocks, 4 per wave
+    f32x4 w[4];
+    load_kslice<4>(w, rsrc, lane * 16, w_off_b + (nb * 16 + kb0) * 1024, 4);
+    stage_rows_ln<256>(Xs, xpre + (size_t)win * T * D, T, g, be,
+                       (stats && nb == 0) ? stats + (size_t)win * RP * 2 : nullptr);
+    __syncthreads();
+    f32x4 acc[RB] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    mma_kslice<4>(acc, Xs + l15 * LDX + lg * 4 + kb0 * 16, LDX, w, 4);
+    const f32x4 s = reduce_partials<4>(red, acc, wave, lane);
+    if (wave < RB) {
+        const int col = nb * 16 + l15;
+        const float bv = wts[b_off + col];
+        float* o = out + (size_t)win * T * ldo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = wave * 16 + lg * 4 + e;
+            float v = s[e] + bv;
+            if (RELU) v = fmaxf(v, 0.f);
+            if (row < T) {
+                if (BLOCKED_OUT) o[((size_t)nb * T + row) * 16 + l15] = v;   // [N/16][T][16] for the fragment-shaped consumer
+                else o[(size_t)row * ldo + col] = v;
+            }
+        }
+    }
+}
+
+// ---- lat_qkv_attn: [pending LN] + Q/K/V projection of ONE head + its causal attention ---------------------------
+//   grid (16 heads, B).  The head's three 16-column blocks are computed with K split over the 4 waves, reduced
+//   into LDS planes, then the 4 waves split the keys (lane = query) and the partial softmax states are merged.
+//   Output O in K-blocked layout [16 heads][T][16] (head = k-block of the out-projection).
+__global__ __launch_bounds__(256) void lat_qkv_attn_kernel(const float* __restrict__ wts, int wbytes, const float* __restrict__ xpre,
+                                                           const float* __restrict__ g, const float* __restrict__ be,
+                                                           int w_off_b, int b_off, float* __restrict__ o_out,
+                                                           float* __restrict__ stats, int T) {
+    using namespace lz;
+    __shared__ __attribute__((aligned(16))) float Xs[RP * LDX];
+    __shared__ __attribute__((aligned(16))) float red[4 * 3 * 256];       // K-split partials; later softmax partials
+    __shared__ __attribute__((aligned(16))) float QKVs[3][RP][DH + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int head = blockIdx.x, win = blockIdx.y;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, wbytes, 0x00020000);
+    const int kb0 = wave * 4;
+    f32x4 w[3][4];   // Q, K, V column block of this head: nb = which*16 + head
+#pragma unroll
+    for (int which = 0; which < 3; ++which)
+        load_kslice<4>(w[which], rsrc, lane * 16, w_off_b + ((which * 16 + head) * 16 + kb0) * 1024, 4);
+    stage_rows_ln<256>(Xs, xpre + (size_t)win * T * D, T, g, be,
+                       (stats && head == 0) ? stats + (size_t)win * RP * 2 : nullptr);
+    __syncthreads();
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        f32x4 acc[RB] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const int nb = which * 16 + head;
+        mma_kslice<4>(acc, Xs + l15 * LDX + lg * 4 + kb0 * 16, LDX, w[which], 4);
+        const f32x4 sres = reduce_partials<4>(red, acc, wave, lane);
+        if (wave < RB) {
+            const float bv = wts[b_off + nb * 16 + l15];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) QKVs[which][wave * 16 + lg * 4 + e][l15] = sres[e] + bv;
+        }
+        __syncthreads();
+    }
+    // attention: lane = query row, wave w takes keys w, w+4, ...
+    const int i = lane;
+    float q[DH], o[DH];
+#pragma unroll
+    for (int e = 0; e < DH; e += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(&QKVs[0][i < RP ? i : 0][e]);
+        q[e] = t.x; q[e + 1] = t.y; q[e + 2] = t.z; q[e + 3] = t.w;
+        o[e] = o[e + 1] = o[e + 2] = o[e + 3] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int j = wave; j < T; j += 4) {
+        if (j <= i) {   // causal mask (:56-58)
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int e = 0; e < DH; e += 4) {
+                const float4 kv = *reinterpret_cast<const float4*>(&QKVs[1][j][e]);
+                s0 = fmaf(q[e], kv.x, s0); s1 = fmaf(q[e + 1], kv.y, s1);
+                s2 = fmaf(q[e + 2], kv.z, s2); s3 = fmaf(q[e + 3], kv.w, s3);
+            }
+            const float sc = (s0 + s1) + (s2 + s3);
+            const float mn = fmaxf(m, sc);
+            const float corr = expf(m - mn), p = expf(sc - mn);
+            l = l * corr + p;
+#pragma unroll
+            for (int e = 0; e < DH; e += 4) {
+                const float4 vv = *reinterpret_cast<const float4*>(&QKVs[2][j][e]);
+                o[e] = fmaf(o[e], corr, p * vv.x); o[e + 1] = fmaf(o[e + 1], corr, p * vv.y);
+                o[e + 2] = fmaf(o[e + 2], corr, p * vv.z); o[e + 3] = fmaf(o[e + 3], corr, p * vv.w);
+            }
+            m = mn;
+        }
+    }
+    float* part = red;   // [4 waves][64 lanes][18]: o[16], m, l  (4608 floats > 3072? no: 4*64*18 = 4608) -> use Xs instead
+    part = Xs;           // Xs is dead after the projections (all waves passed the barrier above)
+#pragma unroll
+    for (int e = 0; e < DH; ++e) part[(wave * 64 + lane) * 18 + e] = o[e];
+    part[(wave * 64 + lane) * 18 + DH] = m;
+    part[(wave * 64 + lane) * 18 + DH + 1] = l;
+    __syncthreads();
+    const int row = tid >> 2, c0 = (tid & 3) * 4;   // thread finishes 4 channels of one query row
+    if (row < T) {
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, part[(w * 64 + row) * 18 + DH]);
+        float den = 0.f, acc4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = expf(part[(w * 64 + row) * 18 + DH] - M);   // exp(-inf) = 0: that wave saw no visible key
+            den += part[(w * 64 + row) * 18 + DH + 1] * f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc4[e] += part[(w * 64 + row) * 18 + c0 + e] * f;
+        }
+        const float inv = 1.f / den;
+        *reinterpret_cast<float4*>(o_out + (size_t)win * T * D + ((size_t)head * T + row) * 16 + c0) =
+            make_float4(acc4[0] * inv, acc4[1] * inv, acc4[2] * inv, acc4[3] * inv);
+    }
+}
+
+// ---- residual GEMMs: out[row][col] = resid(xpre)[row][col] + (A W^T + b)[row][col] ---------------------------
+//   resid = LayerNorm(xpre) via the published row statistics when g != null, else xpre itself.
+//   NW waves split K (= 16*KBT k-blocks); A is read straight from global in fragment shape, from a K-BLOCKED
+//   layout [K/16][T][16] written by the producer kernel: the 16 rows x 64 B a wave touches per load are one
+//   contiguous KiB (a row-major [T][K] image would put the 16 rows 1-4 KB apart on the same channel).
+template <int NW, int KBT>
+__global__ __launch_bounds__(NW * 64) void lat_res_gemm_kernel(const float* __restrict__ wts, int wbytes, const float* __restrict__ A,
+                                                               int lda, const float* __restrict__ xpre, const float* __restrict__ stats,
+                                                               const float* __restrict__ g, const float* __restrict__ be, int w_off_b,
+                                                               int b_off, float* __restrict__ out, int T) {
+    using namespace lz;
+    constexpr int KBW = KBT / NW;
+    __shared__ __attribute__((aligned(16))) float red[NW * 3 * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nb = blockIdx.x, win = blockIdx.y;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, wbytes, 0x00020000);
+    const int kb0 = wave * KBW;
+    f32x4 w[KBW];
+#pragma unroll
+    for (int k = 0; k < KBW; ++k) w[k] = ldfrag(rsrc, lane * 16, w_off_b + (nb * KBT + kb0 + k) * 1024);
+    const float* Ab = A + (size_t)win * T * lda + lg * 4;   // lda = K: a window's blocked image has T*K floats
+    float4 a[RB][KBW];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int row = r * 16 + l15;
+#pragma unroll
+        for (int k = 0; k < KBW; ++k)
+            a[r][k] = row < T ? *reinterpret_cast<const float4*>(Ab + ((size_t)(kb0 + k) * T + row) * 16)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x4 acc[RB] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int k = 0; k < KBW; ++k) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][k].x, w[k].x, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][k].y, w[k].y, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][k].z, w[k].z, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][k].w, w[k].w, acc[r], 0, 0, 0);
+    }
+    const f32x4 s = reduce_partials<NW>(red, acc, wave, lane);
+    if (wave < RB) {
+        const int col = nb * 16 + l15;
+        const float bv = wts[b_off + col];
+        const float gc = g ? g[col] : 1.f, bc = g ? be[col] : 0.f;
+        const float* xp = xpre + (size_t)win * T * D;
+        const float* st = stats + (size_t)win * RP * 2;
+        float* o = out + (size_t)win * T * D;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = wave * 16 + lg * 4 + e;
+            if (row < T) {
+                float x = xp[(size_t)row * D + col];
+                if (g) x = (x - st[row * 2]) * st[row * 2 + 1] * gc + bc;
+                o[(size_t)row * D + col] = x + s[e] + bv;
+            }
+        }
+    }
+}
+
+// ---- lat_head: output projection (:102) for few rows: one 16-column block x 48 rows per workgroup, K split --------
+__global__ __launch_bounds__(256) void lat_head_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ wfrag,
+                                                       const float* __restrict__ bias, float* __restrict__ Y, int ldy, int M,
+                                                       int N) {
+    using namespace lz;
+    constexpr int KBT = R / 16, KBW = KBT / 4;
+    __shared__ __attribute__((aligned(16))) float red[4 * 3 * 256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nb = blockIdx.x, m0 = blockIdx.y * RP;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wfrag), 0, ((N + 15) / 16) * R * 64, 0x00020000);
+    const int kb0 = wave * KBW;
+    f32x4 w[KBW];
+#pragma unroll
+    for (int k = 0; k < KBW; ++k) w[k] = ldfrag(rsrc, lane * 16, (nb * KBT + kb0 + k) * 1024);
+    float4 a[RB][KBW];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int row = m0 + r * 16 + l15;
+        const float* ap = A + (size_t)(row < M ? row : 0) * lda + kb0 * 16 + lg * 4;
+#pragma unroll
+        for (int k = 0; k < KBW; ++k)
+            a[r][k] = row < M ? *reinterpret_cast<const float4*>(ap + k * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    f32x4 acc[RB] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int k = 0; k < KBW; ++k) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][k].x, w[k].x, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][k].y, w[k].y, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][k].z, w[k].z, acc[r], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][k].w, w[k].w, acc[r], 0, 0, 0);
+    }
+    const f32x4 sres = reduce_partials<4>(red, acc, wave, lane);
+    if (wave < RB) {
+        const int col = nb * 16 + l15;
+        if (col < N) {
+            const float bv = bias[col];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m0 + wave * 16 + lg * 4 + e;
+                if (row < M) Y[(size_t)row * ldy + col] = sres[e] + bv;
+            }
+        }
+    }
+}
+
+hipError_t launch_latency_head(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy,
+                               int M, int N, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lat_head_kernel, dim3((N + 15) / 16, (M + lz::RP - 1) / lz::RP), dim3(256), 0, s, A, lda, wfrag, bias, Y,
+                       ldy, M, N);
+    return hipGetLastError();
+}
+
+// ---- rnn_gemv: the recurrence for one stream on a cluster of 4 workgroups --------------------------------------
+//   thread (wave, lane): hidden unit row = wg*128 + wave*16 + (lane & 15); K quarter = lane >> 4 (128 k each).
+//   W_hh is read once from the MFMA-fragment image: fragment (nb, kb) lane' = 16*lg' + l15 holds
+//   W[nb*16 + l15][kb*16 + 4 lg' .. +3].
+//   granules: hb[win][parity][512] of {tag = step + 1, value}; zeroed before every launch.
+typedef unsigned long long u64;
+__global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__ ih, const float* __restrict__ whh_frag,
+                                                       float* __restrict__ hall, u64* __restrict__ hb, int T) {
+    using namespace lz;
+    __shared__ __attribute__((aligned(16))) float hs[4 * 132];   // 4 K-quarters of 128, padded: distinct banks per quarter
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wg = blockIdx.x & 3, win = blockIdx.x >> 2;
+    const int row = wg * 128 + wave * 16 + l15;
+    float4 w[32];
+    {
+        const float4* wf = reinterpret_cast<const float4*>(whh_frag);
+        const int nb = row >> 4;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int kb = lg * 8 + (j >> 2), lgp = j & 3;   // k = lg*128 + 4 j .. +3
+            w[j] = wf[(size_t)(nb * 32 + kb) * 64 + lgp * 16 + l15];
+        }
+    }
+    u64* hbw = hb + (size_t)win * 2 * R;
+    const float* ihw = ih + (size_t)win * T * R;
+    float* hw = hall + (size_t)win * T * R;
+    for (int t = 0; t < T; ++t) {
+        const float ihv = ihw[(size_t)t * R + row];
+        float acc = 0.f;
+        if (t > 0) {
+            // gather h_{t-1}: thread i polls granule i until its tag says "step t" (bounded: never hang the GPU)
+            const u64* gp = hbw + (size_t)((t - 1) & 1) * R + tid;
+            u64 v = 0;
+            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v >> 32) == (unsigned)t) break;
+            }
+            hs[(tid >> 7) * 132 + (tid & 127)] = __uint_as_float((unsigned)v);
+            __syncthreads();
+            const float* hq = hs + lg * 132;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const float4 hv = *reinterpret_cast<const float4*>(hq + j * 4);
+                a0 = fmaf(w[j].x, hv.x, a0); a1 = fmaf(w[j].y, hv.y, a1);
+                a2 = fmaf(w[j].z, hv.z, a2); a3 = fmaf(w[j].w, hv.w, a3);
+            }
+            acc = (a0 + a1) + (a2 + a3);
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            __syncthreads();   // hs is rewritten next step
+        }
+        if (lg == 0) {
+            const float hv = tanhf(acc + ihv);
+            hw[(size_t)t * R + row] = hv;
+            const u64 gran = ((u64)(unsigned)(t + 1) << 32) | (u64)__float_as_uint(hv);
+            __hip_atomic_store(hbw + (size_t)(t & 1) * R + row, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+bool latency_supported(const Dims& d, int B, int T) {
+    return fused_supported(d, T) && fused_has_rnn_ih(d) && B >= 1 && B <= 64;
+}
+
+// workspace (floats): xa, xb [B][T][256]; qkv [B][T][768]; o [B][T][256]; hid [B][T][1024]; ih [B][T][512];
+//                     stats [2][B][48][2]; granules [B][2][512] u64
+size_t latency_workspace_floats(int B, int T) {
+    const size_t bt = (size_t)B * T;
+    return bt * (256 + 256 + 768 + 256 + 1024 + 512) + (size_t)2 * B * 48 * 2 + (size_t)B * 2 * 512 * 2 + 1024;
+}
+
+hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float* whh_frag, const float* x_imu,
+                               const float* x_s, const float* keep_mask, float keep_scale, float* ws, float* hall, int B,
+                               int T, hipStream_t s) {
+    using namespace lz;
+    const size_t bt = (size_t)B * T;
+    float* xa = ws;
+    float* xb = xa + bt * 256;
+    float* o = xb + bt * 256 + bt * 768;   // (the QKV slot of the workspace is unused since QKV + attention merged)
+    float* hid = o + bt * 256;
+    float* ihb = hid + bt * 1024;
+    float* st0 = ihb + bt * 512;
+    float* st1 = st0 + (size_t)B * 48 * 2;
+    u64* gran = reinterpret_cast<u64*>(st1 + (size_t)B * 48 * 2);   // every term above is an even float count: 8-B aligned
+    const int wbytes = (int)(fused_packed_floats(d) * 4);
+    // offsets inside the fused section (tip_fused.hip)
+    constexpr size_t IN_W = 0, IN_B = (size_t)D * KIN, LAYER0 = IN_B + D;
+    constexpr size_t QKV_W = 0, QKV_B = QKV_W + (size_t)3 * D * D, WO_W = QKV_B + 3 * D, WO_B = WO_W + (size_t)D * D;
+    constexpr size_t W1_W = WO_B + D, W1_B = W1_W + (size_t)F * D, W2_W = W1_B + F, W2_B = W2_W + (size_t)D * F;
+    constexpr size_t G1 = W2_B + D, BE1 = G1 + D, G2 = BE1 + D, BE2 = G2 + D, LAYER_FLOATS = BE2 + D;
+    hipLaunchKernelGGL(lat_in_kernel, dim3(16, B), dim3(256), 0, s, fused_w, wbytes, x_imu, x_s, keep_mask, keep_scale, xa, T,
+                       d.n_imu_total, d.S, (int)(IN_W * 4), (int)IN_B, gran);
+    const float* pg = nullptr;   // LayerNorm pending on the residual stream (norm2 of the previous layer)
+    const float* pb = nullptr;
+    for (int l = 0; l < d.L; ++l) {
+        const size_t lo = LAYER0 + (size_t)l * LAYER_FLOATS;
+        const float* LW = fused_w + lo;
+        // xa = pre-norm input of the layer; st0 = its row statistics (when pg != null)
+        hipLaunchKernelGGL(lat_qkv_attn_kernel, dim3(16, B), dim3(256), 0, s, fused_w, wbytes, xa, pg, pb,
+                           (int)((lo + QKV_W) * 4), (int)(lo + QKV_B), o, st0, T);
+        hipLaunchKernelGGL((lat_res_gemm_kernel<4, 16>), dim3(16, B), dim3(256), 0, s, fused_w, wbytes, o, D, xa, st0, pg, pb,
+                           (int)((lo + WO_W) * 4), (int)(lo + WO_B), xb, T);
+        // xb = pre-LN1 sum
+        hipLaunchKernelGGL((lat_ln_gemm_kernel<true, true>), dim3(64, B), dim3(256), 0, s, fused_w, wbytes, xb, LW + G1,
+                           LW + BE1, (int)((lo + W1_W) * 4), (int)(lo + W1_B), hid, F, st1, T);
+        hipLaunchKernelGGL((lat_res_gemm_kernel<8, 64>), dim3(16, B), dim3(512), 0, s, fused_w, wbytes, hid, F, xb, st1, LW + G1,
+                           LW + BE1, (int)((lo + W2_W) * 4), (int)(lo + W2_B), xa, T);
+        pg = LW + G2;
+        pb = LW + BE2;
+    }
+    const size_t ih_off = LAYER0 + (size_t)d.L * LAYER_FLOATS;
+    hipLaunchKernelGGL((lat_ln_gemm_kernel<false, false>), dim3(32, B), dim3(256), 0, s, fused_w, wbytes, xa, pg, pb, (int)(ih_off * 4),
+                       (int)(ih_off + (size_t)R * D), ihb, R, (float*)nullptr, T);
+    hipLaunchKernelGGL(rnn_gemv_kernel, dim3(4 * B), dim3(512), 0, s, ihb, whh_frag, hall, gran, T);
+    return hipGetLastError();
+}
+
+}  // namespace tip
