@@ -54,8 +54,10 @@ def stage_flops(cfg, name, B, T):
     In = cfg["input_size_imu"] + cfg["size_s"] + (18 if cfg.get("with_acc_sum") else 0)
     D, F, L = cfg["tf_in_dim"], cfg["tf_hid_size"], cfg["tf_layers"]
     M = B * T
-    if name == "fused_encoder":
-        return B * (2.0 * T * In * D + L * (2.0 * T * D * 3 * D + 4.0 * T * T * D + 2.0 * T * D * D + 4.0 * T * D * F))
+    if name == "fused_encoder":   # prologue + in_linear + L encoder layers + RNN input projection (fused at its tail)
+        R = cfg["rnn_hid_size"]
+        return B * (2.0 * T * In * D + L * (2.0 * T * D * 3 * D + 4.0 * T * T * D + 2.0 * T * D * D + 4.0 * T * D * F)
+                    + 2.0 * T * D * R)
     if name in ("ffn1_gemm", "ffn2_gemm"):
         return 2.0 * M * D * F
     return None

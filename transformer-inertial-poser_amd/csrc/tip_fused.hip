@@ -9,11 +9,12 @@
 // window's inputs (35 KB) and the encoder output (40 KB); weights (12.6 MB) are L2/Infinity-Cache resident and
 // shared by all 256 CUs.  Reference: /root/reference/simple_transformer_with_state.py:63-91.
 //
-// LDS map (floats):  X [48][260] residual stream | C chunk region [3][48][132] = Q|K|V of 8 heads, reused as
-//                    U [48][228] (prologue) and Hc [48][260] (FFN hidden chunk).  125,952 B.
+// LDS map (floats):  X [48][260] residual stream | C chunk region: Q [48][132] | K [48][132] | V^T [128][52] of 8
+//                    heads, reused as U [48][228] (prologue) and Hc [48][260] (FFN hidden chunk).  127,232 B.
 #include <string.h>
 
 #include "tip_internal.h"
+#include "tip_attention.h"
 
 namespace tip {
 
@@ -23,10 +24,11 @@ namespace fz {
 constexpr int D = 256, H = 16, DH = 16, F = 1024, RP = 48, RB = 3, TMAX = 40, R = 512;
 constexpr int KIN = 224;            // in_linear K, zero padded (221 with acc-sum, 203 without)
 constexpr int LDX = D + 4;          // 260
-constexpr int LDC = 128 + 4;        // 132: one Q / K / V plane of an 8-head chunk
+constexpr int LDC = 128 + 4;        // 132: one Q / K plane of an 8-head chunk, [48 rows][128 channels]
+constexpr int LDV = RP + 4;         // 52: V is kept TRANSPOSED, [128 channels][48 keys], so P.V reads B fragments as b128
 constexpr int LDU = KIN + 4;        // 228
 constexpr int X_FLOATS = RP * LDX;              // 12480
-constexpr int C_FLOATS = 3 * RP * LDC;          // 19008
+constexpr int C_FLOATS = 2 * RP * LDC + 128 * LDV;   // 19328
 constexpr int LDS_BYTES = (X_FLOATS + C_FLOATS) * 4;
 constexpr int THREADS = 512;
 // packed section (floats)
@@ -219,53 +221,6 @@ __device__ __forceinline__ void layernorm_rows(float* X, const float* __restrict
     }
 }
 
-// Causal attention of ONE head by ONE wave: lane i = query row i.  Q/K/V planes hold the head at column c0.
-// Output overwrites the head's Q columns (each lane only ever reads its own Q row).
-__device__ __forceinline__ void attention_head(float* Qc, const float* Kc, const float* Vc, int c0, int T, int lane) {
-    using namespace fz;
-    const int i = lane;
-    if (i < T) {
-        float q[DH], o[DH];
-#pragma unroll
-        for (int e = 0; e < DH; e += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(Qc + i * LDC + c0 + e);
-            q[e] = t.x; q[e + 1] = t.y; q[e + 2] = t.z; q[e + 3] = t.w;
-            o[e] = 0.f; o[e + 1] = 0.f; o[e + 2] = 0.f; o[e + 3] = 0.f;
-        }
-        float m = -INFINITY, l = 0.f;
-#pragma unroll 1
-        for (int j = 0; j < T; ++j) {
-            if (j <= i) {  // causal mask (:56-58)
-                const float* kj = Kc + j * LDC + c0;
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-                for (int e = 0; e < DH; e += 4) {
-                    const float4 kv = *reinterpret_cast<const float4*>(kj + e);
-                    s0 = fmaf(q[e], kv.x, s0); s1 = fmaf(q[e + 1], kv.y, s1);
-                    s2 = fmaf(q[e + 2], kv.z, s2); s3 = fmaf(q[e + 3], kv.w, s3);
-                }
-                const float sc = (s0 + s1) + (s2 + s3);
-                const float mn = fmaxf(m, sc);
-                const float corr = expf(m - mn);
-                const float p = expf(sc - mn);
-                l = l * corr + p;
-                const float* vj = Vc + j * LDC + c0;
-#pragma unroll
-                for (int e = 0; e < DH; e += 4) {
-                    const float4 vv = *reinterpret_cast<const float4*>(vj + e);
-                    o[e] = fmaf(o[e], corr, p * vv.x); o[e + 1] = fmaf(o[e + 1], corr, p * vv.y);
-                    o[e + 2] = fmaf(o[e + 2], corr, p * vv.z); o[e + 3] = fmaf(o[e + 3], corr, p * vv.w);
-                }
-                m = mn;
-            }
-        }
-        const float inv = 1.f / l;
-#pragma unroll
-        for (int e = 0; e < DH; e += 4)
-            *reinterpret_cast<float4*>(Qc + i * LDC + c0 + e) = make_float4(o[e] * inv, o[e + 1] * inv, o[e + 2] * inv, o[e + 3] * inv);
-    }
-}
-
 __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
     const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
     const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ xout, float* __restrict__ ih_out, int B,
@@ -326,7 +281,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
             const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
             float* Qc = C;
             float* Kc = C + RP * LDC;
-            float* Vc = C + 2 * RP * LDC;
+            float* Vt = C + 2 * RP * LDC;   // V^T [128 channels][LDV]
             // ---- self-attention block: two chunks of 8 heads; wave w owns head 8c + w end to end -----------------
             f32x4 acc_o[RB][2];
             zero_acc<2>(acc_o);
@@ -344,17 +299,19 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     const float bv = LW[QKV_B + 2 * D + head * 16 + l15];
                     const int col = wave * 16 + l15;
 #pragma unroll
-                    for (int r = 0; r < RB; ++r)
+                    for (int r = 0; r < RB; ++r) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int row = r * 16 + lg * 4 + e;
                             Qc[row * LDC + col] = acc[r][0][e] + bq;
                             Kc[row * LDC + col] = acc[r][1][e] + bk;
-                            Vc[row * LDC + col] = acc[r][2][e] + bv;
                         }
+                        // V transposed: this lane's 4 keys of channel `col` are contiguous -> one b128 store
+                        *reinterpret_cast<f32x4*>(Vt + col * LDV + r * 16 + lg * 4) = acc[r][2] + bv;
+                    }
                 }
                 __syncthreads();
-                attention_head(Qc, Kc, Vc, wave * 16, T, lane);
+                attention_head_mfma<LDC, LDV>(Qc, Kc, Vt, wave * 16, lane);
                 __syncthreads();
                 // out-projection partial: acc_o += O_chunk[48 x 128] * Wo[:, 128c .. 128c+127]^T
                 {

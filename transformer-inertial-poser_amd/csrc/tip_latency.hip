@@ -22,6 +22,7 @@
 // only need the normalised residual of their own 16 columns.
 // Weights: the fused plan's fragment-ordered image (tip_fused.hip) — nothing is packed twice.
 #include "tip_internal.h"
+#include "tip_attention.h"
 
 namespace tip {
 
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void lat_qkv_attn_kernel(const float* __restri
     using namespace lz;
     __shared__ __attribute__((aligned(16))) float Xs[RP * LDX];
     __shared__ __attribute__((aligned(16))) float red[4 * 3 * 256];       // K-split partials; later softmax partials
-    __shared__ __attribute__((aligned(16))) float QKVs[3][RP][DH + 4];
+    __shared__ __attribute__((aligned(16))) float Qs[RP * (DH + 4)], Ks[RP * (DH + 4)], Vts[DH * (RP + 4)];   // V transposed
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
@@ -289,66 +290,25 @@ __global__ __launch_bounds__(256) void lat_qkv_attn_kernel(const float* __restri
         const f32x4 sres = reduce_partials<4>(red, acc, wave, lane);
         if (wave < RB) {
             const float bv = wts[b_off + nb * 16 + l15];
+            if (which < 2) {
+                float* dst = which == 0 ? Qs : Ks;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) QKVs[which][wave * 16 + lg * 4 + e][l15] = sres[e] + bv;
+                for (int e = 0; e < 4; ++e) dst[(wave * 16 + lg * 4 + e) * (DH + 4) + l15] = sres[e] + bv;
+            } else {
+                *reinterpret_cast<f32x4*>(Vts + l15 * (RP + 4) + wave * 16 + lg * 4) = sres + bv;
+            }
         }
         __syncthreads();
     }
-    // attention: lane = query row, wave w takes keys w, w+4, ...
-    const int i = lane;
-    float q[DH], o[DH];
-#pragma unroll
-    for (int e = 0; e < DH; e += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(&QKVs[0][i < RP ? i : 0][e]);
-        q[e] = t.x; q[e + 1] = t.y; q[e + 2] = t.z; q[e + 3] = t.w;
-        o[e] = o[e + 1] = o[e + 2] = o[e + 3] = 0.f;
-    }
-    float m = -INFINITY, l = 0.f;
-    for (int j = wave; j < T; j += 4) {
-        if (j <= i) {   // causal mask (:56-58)
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-            for (int e = 0; e < DH; e += 4) {
-                const float4 kv = *reinterpret_cast<const float4*>(&QKVs[1][j][e]);
-                s0 = fmaf(q[e], kv.x, s0); s1 = fmaf(q[e + 1], kv.y, s1);
-                s2 = fmaf(q[e + 2], kv.z, s2); s3 = fmaf(q[e + 3], kv.w, s3);
-            }
-            const float sc = (s0 + s1) + (s2 + s3);
-            const float mn = fmaxf(m, sc);
-            const float corr = expf(m - mn), p = expf(sc - mn);
-            l = l * corr + p;
-#pragma unroll
-            for (int e = 0; e < DH; e += 4) {
-                const float4 vv = *reinterpret_cast<const float4*>(&QKVs[2][j][e]);
-                o[e] = fmaf(o[e], corr, p * vv.x); o[e + 1] = fmaf(o[e + 1], corr, p * vv.y);
-                o[e + 2] = fmaf(o[e + 2], corr, p * vv.z); o[e + 3] = fmaf(o[e + 3], corr, p * vv.w);
-            }
-            m = mn;
-        }
-    }
-    float* part = red;   // [4 waves][64 lanes][18]: o[16], m, l  (4608 floats > 3072? no: 4*64*18 = 4608) -> use Xs instead
-    part = Xs;           // Xs is dead after the projections (all waves passed the barrier above)
-#pragma unroll
-    for (int e = 0; e < DH; ++e) part[(wave * 64 + lane) * 18 + e] = o[e];
-    part[(wave * 64 + lane) * 18 + DH] = m;
-    part[(wave * 64 + lane) * 18 + DH + 1] = l;
+    // attention on the matrix cores by wave 0 (48 MFMAs + a 16-lane-shuffle softmax: ~2 us; the other waves idle)
+    if (wave == 0) attention_head_mfma<DH + 4, RP + 4>(Qs, Ks, Vts, 0, lane);
     __syncthreads();
-    const int row = tid >> 2, c0 = (tid & 3) * 4;   // thread finishes 4 channels of one query row
-    if (row < T) {
-        float M = -INFINITY;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) M = fmaxf(M, part[(w * 64 + row) * 18 + DH]);
-        float den = 0.f, acc4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float f = expf(part[(w * 64 + row) * 18 + DH] - M);   // exp(-inf) = 0: that wave saw no visible key
-            den += part[(w * 64 + row) * 18 + DH + 1] * f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc4[e] += part[(w * 64 + row) * 18 + c0 + e] * f;
-        }
-        const float inv = 1.f / den;
-        *reinterpret_cast<float4*>(o_out + (size_t)win * T * D + ((size_t)head * T + row) * 16 + c0) =
-            make_float4(acc4[0] * inv, acc4[1] * inv, acc4[2] * inv, acc4[3] * inv);
+    // O (in the Q plane) -> K-blocked global layout [16 heads][T][16]
+    {
+        const int row = tid >> 2, c0 = (tid & 3) * 4;
+        if (row < T)
+            *reinterpret_cast<float4*>(o_out + (size_t)win * T * D + ((size_t)head * T + row) * 16 + c0) =
+                *reinterpret_cast<const float4*>(Qs + row * (DH + 4) + c0);
     }
 }
 
