@@ -129,7 +129,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_pg = "RANK" in os.environ          # launched by torch.distributed.run (also exercised with one rank)
+    if use_pg:
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -147,7 +148,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -164,7 +165,7 @@ def main():
         prof = model.profile_read()
         model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=0)
     assert torch.isfinite(y).all()
-    if world > 1:
+    if use_pg:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -235,7 +236,7 @@ def main():
             "extra": extra,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -35,33 +35,51 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
             S[r][cb] = t;
         }
     // row softmax (un-normalised): element e of S[r][cb] is query 16r + 4lg + e, key 16cb + l15; causal mask (:56-58)
-    // only bites on the diagonal tiles: key-in-block <= query-in-block.
-    float rsum[RB][4];
+    // only bites on the diagonal tiles: key-in-block <= query-in-block.  The 12 row reductions of a lane advance
+    // TOGETHER through each xor-shuffle step, so their latencies overlap instead of forming 96 dependent hops.
+    float mx[RB][4], rsum[RB][4];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
+    for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const bool vis = l15 <= lg * 4 + e;
-            float mx = vis ? S[r][r][e] : -INFINITY;
+            float m = vis ? S[r][r][e] : -INFINITY;
 #pragma unroll
-            for (int cb = 0; cb < r; ++cb) mx = fmaxf(mx, S[r][cb][e]);
+            for (int cb = 0; cb < r; ++cb) m = fmaxf(m, S[r][cb][e]);
+            mx[r][e] = m;
+        }
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx[r][e] = fmaxf(mx[r][e], __shfl_xor(mx[r][e], off, 64));
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool vis = l15 <= lg * 4 + e;
             float sm = 0.f;
 #pragma unroll
             for (int cb = 0; cb < r; ++cb) {
-                const float p = expf(S[r][cb][e] - mx);
+                const float p = expf(S[r][cb][e] - mx[r][e]);
                 S[r][cb][e] = p;
                 sm += p;
             }
-            const float pd = vis ? expf(S[r][r][e] - mx) : 0.f;
+            const float pd = vis ? expf(S[r][r][e] - mx[r][e]) : 0.f;
             S[r][r][e] = pd;
-            sm += pd;
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) sm += __shfl_xor(sm, off, 64);
-            rsum[r][e] = sm;
+            rsum[r][e] = sm + pd;
         }
-    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rsum[r][e] += __shfl_xor(rsum[r][e], off, 64);
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rsum[r][e] = 1.0f / rsum[r][e];
     // P V per query block
     float* Pt = Kc + c0;   // P^T[key j][query-in-block i] at Pt[j*LDC + i]  (the head's K columns: dead after kf was read)
 #pragma unroll
@@ -83,7 +101,7 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
             o = __builtin_amdgcn_mfma_f32_16x16x4f32(p3, vb.w, o, 0, 0, 0);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Qc[(r * 16 + lg * 4 + e) * LDC + c0 + l15] = o[e] / rsum[r][e];
+        for (int e = 0; e < 4; ++e) Qc[(r * 16 + lg * 4 + e) * LDC + c0 + l15] = o[e] * rsum[r][e];
     }
 }
 

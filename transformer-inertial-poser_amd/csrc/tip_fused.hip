@@ -11,6 +11,7 @@
 //
 // LDS map (floats):  X [48][260] residual stream | C chunk region: Q [48][132] | K [48][132] | V^T [128][52] of 8
 //                    heads, reused as U [48][228] (prologue) and Hc [48][260] (FFN hidden chunk).  127,232 B.
+#include <stdlib.h>
 #include <string.h>
 
 #include "tip_internal.h"
@@ -159,20 +160,33 @@ __device__ __forceinline__ float4 load_frag(__amdgpu_buffer_rsrc_t rsrc, int vof
     return make_float4(f.x, f.y, f.z, f.w);
 }
 
-// acc[r][n] += A[48 x 16*KB] (LDS, leading dim lda) * Wblock(n, kb)   for kb in [0, KB)
-//   soff: byte offset (wave-uniform) of the wave's first block at kb = 0; block n is + n*nstride_b; k-block kb is + kb*1024.
-//   The prefetch runs two k-blocks ahead and is unconditional (branch-free loop => counted vmcnt waits); past the
-//   last k-block it reads the following packed block (in bounds: the section carries a tail pad).
-template <int NBW, int KB>
-__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[fz::RB][NBW], const float* As, int lda, __amdgpu_buffer_rsrc_t rsrc,
-                                           int voff, int soff, int nstride_b) {
-    static_assert(KB % 2 == 0, "k-blocks are processed in pairs");
+// Register ring of weight fragments: k-blocks (even, odd) of the NBW column blocks a wave owns.
+template <int NBW>
+struct WRing {
     float4 w0[NBW], w1[NBW];
+};
+
+// Prime a ring with k-blocks 0 and 1 of a phase.  Called EARLY (before the epilogue / barrier / LayerNorm /
+// attention that precedes the phase) so the L2 latency of a phase's first fragments is never exposed.
+template <int NBW>
+__device__ __forceinline__ void ring_prefetch(WRing<NBW>& g, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b) {
 #pragma unroll
     for (int n = 0; n < NBW; ++n) {
-        w0[n] = load_frag(rsrc, voff, soff + n * nstride_b);
-        w1[n] = load_frag(rsrc, voff, soff + n * nstride_b + 1024);
+        g.w0[n] = load_frag(rsrc, voff, soff + n * nstride_b);
+        g.w1[n] = load_frag(rsrc, voff, soff + n * nstride_b + 1024);
     }
+}
+
+// acc[r][n] += A[48 x 16*KB] (LDS, leading dim lda) * Wblock(n, kb)   for kb in [0, KB)
+//   soff: byte offset (wave-uniform) of the wave's first block at kb = 0; block n is + n*nstride_b; k-block kb is + kb*1024.
+//   The ring holds k-blocks 0,1 on entry.  The prefetch runs two k-blocks ahead and is unconditional (branch-free
+//   loop => counted vmcnt waits); for the LAST pair it is redirected to k-blocks 0,1 of the NEXT phase
+//   (nsoff / nnstride_b), so on exit the ring is already primed for a following phase of the same width.
+//   Callers without such a successor pass their own soff (a harmless in-bounds reload).
+template <int NBW, int KB, bool NOMMA = false>
+__device__ __forceinline__ void gemm_phase(f32x4 (&acc)[fz::RB][NBW], const float* As, int lda, __amdgpu_buffer_rsrc_t rsrc,
+                                           int voff, int soff, int nstride_b, WRing<NBW>& g, int nsoff, int nnstride_b) {
+    static_assert(KB % 2 == 0, "k-blocks are processed in pairs");
     // A fragments are double-buffered too: the ds_read_b128 of k-block kb+1 is in flight while the MFMAs of kb issue.
     // (Reads past the last k-block stay inside the LDS allocation and are never used.)
     float4 a0[fz::RB], a1[fz::RB];
@@ -180,16 +194,21 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[fz::RB][NBW], const floa
     for (int r = 0; r < fz::RB; ++r) a0[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda);
 #pragma unroll 1
     for (int kb = 0; kb < KB; kb += 2) {
+        const bool last = kb + 2 >= KB;                       // wave-uniform: scalar selects, no branch
+        const int o = last ? nsoff : soff + (kb + 2) * 1024;
+        const int st = last ? nnstride_b : nstride_b;
 #pragma unroll
         for (int r = 0; r < fz::RB; ++r) a1[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda + (kb + 1) * 16);
-        mfma_block<NBW>(acc, a0, w0);
+        if (!NOMMA) mfma_block<NBW>(acc, a0, g.w0);
+        else { asm volatile("" :: "v"(a0[0].x), "v"(g.w0[0].x)); }
 #pragma unroll
-        for (int n = 0; n < NBW; ++n) w0[n] = load_frag(rsrc, voff, soff + n * nstride_b + (kb + 2) * 1024);
+        for (int n = 0; n < NBW; ++n) g.w0[n] = load_frag(rsrc, voff, o + n * st);
 #pragma unroll
         for (int r = 0; r < fz::RB; ++r) a0[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda + (kb + 2) * 16);
-        mfma_block<NBW>(acc, a1, w1);
+        if (!NOMMA) mfma_block<NBW>(acc, a1, g.w1);
+        else { asm volatile("" :: "v"(a1[0].x), "v"(g.w1[0].x)); }
 #pragma unroll
-        for (int n = 0; n < NBW; ++n) w1[n] = load_frag(rsrc, voff, soff + n * nstride_b + (kb + 3) * 1024);
+        for (int n = 0; n < NBW; ++n) g.w1[n] = load_frag(rsrc, voff, o + n * st + 1024);
     }
 }
 
@@ -201,26 +220,49 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[fz::RB][NBW]) {
         for (int n = 0; n < NBW; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// LayerNorm over the 48 rows of X (eps 1e-5, biased variance): wave w owns rows w, w+8, ...
+// LayerNorm over the 48 rows of X (eps 1e-5, biased variance): wave w owns rows w, w+8, ... (6 rows); the six row
+// reductions advance together through every shuffle step so their latencies overlap.
 __device__ __forceinline__ void layernorm_rows(float* X, const float* __restrict__ g, const float* __restrict__ be, int wave,
                                                int lane) {
+    constexpr int NR = fz::RP / 8;
     const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
     const float4 bb = *reinterpret_cast<const float4*>(be + lane * 4);
-    for (int row = wave; row < fz::RP; row += 8) {
-        float4* p = reinterpret_cast<float4*>(X + row * fz::LDX + lane * 4);
-        float4 v = *p;
-        const float mean = wsum((v.x + v.y) + (v.z + v.w)) * (1.f / fz::D);
-        const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-        const float var = wsum((a * a + b * b) + (c * c + d * d)) * (1.f / fz::D);
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
-        v.x = a * rstd * gg.x + bb.x;
-        v.y = b * rstd * gg.y + bb.y;
-        v.z = c * rstd * gg.z + bb.z;
-        v.w = d * rstd * gg.w + bb.w;
-        *p = v;
+    float4 v[NR];
+    float mean[NR], var[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        v[i] = *reinterpret_cast<const float4*>(X + (wave + 8 * i) * fz::LDX + lane * 4);
+        mean[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) mean[i] += __shfl_xor(mean[i], off, 64);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        mean[i] *= (1.f / fz::D);
+        v[i].x -= mean[i]; v[i].y -= mean[i]; v[i].z -= mean[i]; v[i].w -= mean[i];
+        var[i] = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) var[i] += __shfl_xor(var[i], off, 64);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const float rstd = 1.0f / sqrtf(var[i] * (1.f / fz::D) + 1e-5f);
+        float4 o;
+        o.x = v[i].x * rstd * gg.x + bb.x;
+        o.y = v[i].y * rstd * gg.y + bb.y;
+        o.z = v[i].z * rstd * gg.z + bb.z;
+        o.w = v[i].w * rstd * gg.w + bb.w;
+        *reinterpret_cast<float4*>(X + (wave + 8 * i) * fz::LDX + lane * 4) = o;
     }
 }
 
+// ABL != 0 builds are MEASUREMENT-ONLY ablations (wrong results): 1 = no attention, 2 = no LayerNorm, 4 = no MFMA,
+// 8 = no epilogue LDS traffic.  Selected with TIP_FUSED_ABLATE=<mask>; the product path always runs ABL = 0.
+template <int ABL>
 __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
     const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
     const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ xout, float* __restrict__ ih_out, int B,
@@ -236,6 +278,11 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
     const int voff = lane * 16;
 
     for (int win = blockIdx.x; win < B; win += gridDim.x) {
+        // weight fragments of the first GEMM are requested before the window's inputs are even staged
+        const int in_soff = (int)(IN_W * 4) + (wave * 2) * (KIN / 16) * 1024;
+        WRing<2> g_in;
+        ring_prefetch<2>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
+        WRing<3> g_qkv;   // primed one phase ahead of every QKV projection
         // ---- P0 prologue (:63-78): U = [x_imu | scrub(x_s) * mask | 0], rows >= T zero ---------------------------
         float* U = C;
         for (int i = tid; i < RP * LDU; i += THREADS) U[i] = 0.f;
@@ -261,8 +308,10 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
         {
             f32x4 acc[RB][2];
             zero_acc<2>(acc);
-            gemm_phase<2, KIN / 16>(acc, U + l15 * LDU + lg * 4, LDU, rsrc, voff,
-                                    (int)(IN_W * 4) + (wave * 2) * (KIN / 16) * 1024, (KIN / 16) * 1024);
+            gemm_phase<2, KIN / 16, (ABL & 4) != 0>(acc, U + l15 * LDU + lg * 4, LDU, rsrc, voff, in_soff, (KIN / 16) * 1024, g_in, in_soff,
+                                    (KIN / 16) * 1024);
+            // layer 0, chunk 0 QKV fragments fly during the epilogue + barrier
+            ring_prefetch<3>(g_qkv, rsrc, voff, (int)(LAYER0 * 4) + (int)(QKV_W * 4) + wave * 16 * 1024, 16 * 16 * 1024);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int col = (wave * 2 + n) * 16 + l15;
@@ -285,6 +334,8 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
             // ---- self-attention block: two chunks of 8 heads; wave w owns head 8c + w end to end -----------------
             f32x4 acc_o[RB][2];
             zero_acc<2>(acc_o);
+            WRing<2> g_o, g_f;
+
 #pragma unroll 1
             for (int c = 0; c < 2; ++c) {
                 {
@@ -292,11 +343,14 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     f32x4 acc[RB][3];
                     zero_acc<3>(acc);
                     // column blocks of this head in the packed [48 nb][16 kb] QKV matrix: Q = head, K = 16+head, V = 32+head
-                    gemm_phase<3, 16>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, lbase + (int)(QKV_W * 4) + head * 16 * 1024,
-                                      16 * 16 * 1024);
+                    const int qsoff = lbase + (int)(QKV_W * 4) + head * 16 * 1024;
                     const float bq = LW[QKV_B + head * 16 + l15];
                     const float bk = LW[QKV_B + D + head * 16 + l15];
                     const float bv = LW[QKV_B + 2 * D + head * 16 + l15];
+                    gemm_phase<3, 16, (ABL & 4) != 0>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, qsoff, 16 * 16 * 1024, g_qkv, qsoff,
+                                      16 * 16 * 1024);
+                    // out-projection fragments of this chunk fly during the epilogue, the barrier and the attention
+                    ring_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + c * 8) * 1024, 16 * 1024);
                     const int col = wave * 16 + l15;
 #pragma unroll
                     for (int r = 0; r < RB; ++r) {
@@ -311,12 +365,17 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     }
                 }
                 __syncthreads();
-                attention_head_mfma<LDC, LDV>(Qc, Kc, Vt, wave * 16, lane);
+                if (!(ABL & 1)) attention_head_mfma<LDC, LDV>(Qc, Kc, Vt, wave * 16, lane);
                 __syncthreads();
+                // the next consumer's fragments go out before this phase's MFMAs: chunk 1's QKV, or the first FFN chunk
+                if (c == 0)
+                    ring_prefetch<3>(g_qkv, rsrc, voff, lbase + (int)(QKV_W * 4) + (8 + wave) * 16 * 1024, 16 * 16 * 1024);
+                else
+                    ring_prefetch<2>(g_f, rsrc, voff, lbase + (int)(W1_W * 4) + (wave * 2) * 16 * 1024, 16 * 1024);
                 // out-projection partial: acc_o += O_chunk[48 x 128] * Wo[:, 128c .. 128c+127]^T
                 {
-                    gemm_phase<2, 8>(acc_o, Qc + l15 * LDC + lg * 4, LDC, rsrc, voff,
-                                     lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + c * 8) * 1024, 16 * 1024);
+                    const int osoff = lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + c * 8) * 1024;
+                    gemm_phase<2, 8, (ABL & 4) != 0>(acc_o, Qc + l15 * LDC + lg * 4, LDC, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
                 }
                 __syncthreads();
             }
@@ -331,7 +390,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_o[r][n][e] + bv;
             }
             __syncthreads();
-            layernorm_rows(X, LW + G1, LW + BE1, wave, lane);
+            if (!(ABL & 2)) layernorm_rows(X, LW + G1, LW + BE1, wave, lane);
             __syncthreads();
             // ---- feed-forward block: hidden processed in 4 chunks of 256, second GEMM accumulates in registers -----
             float* Hc = C;
@@ -343,8 +402,10 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     f32x4 acc[RB][2];
                     zero_acc<2>(acc);
                     const int nb0 = f * 16 + wave * 2;
-                    gemm_phase<2, 16>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, lbase + (int)(W1_W * 4) + nb0 * 16 * 1024,
-                                      16 * 1024);
+                    const int w1off = lbase + (int)(W1_W * 4) + nb0 * 16 * 1024;
+                    const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
+                    // chained: the tail of linear1(f) primes the ring with linear2(f)'s first fragments
+                    gemm_phase<2, 16, (ABL & 4) != 0>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, w1off, 16 * 1024, g_f, w2off, 64 * 1024);
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         const int col = (wave * 2 + n) * 16 + l15;
@@ -357,11 +418,18 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                 }
                 __syncthreads();
                 {
-                    gemm_phase<2, 16>(acc_f, Hc + l15 * LDX + lg * 4, LDX, rsrc, voff,
-                                      lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024, 64 * 1024);
+                    const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
+                    // ... and the tail of linear2(f) primes it with linear1(f+1)'s (its own again after the last chunk)
+                    const int nxt = f < 3 ? lbase + (int)(W1_W * 4) + ((f + 1) * 16 + wave * 2) * 16 * 1024 : w2off;
+                    gemm_phase<2, 16, (ABL & 4) != 0>(acc_f, Hc + l15 * LDX + lg * 4, LDX, rsrc, voff, w2off, 64 * 1024, g_f, nxt,
+                                      f < 3 ? 16 * 1024 : 64 * 1024);
                 }
                 __syncthreads();
             }
+            // next layer's first QKV fragments (or the RNN input projection's) fly during the epilogue + LayerNorm2
+            if (layer + 1 < L)
+                ring_prefetch<3>(g_qkv, rsrc, voff, lbase + (int)(LAYER_FLOATS * 4) + (int)(QKV_W * 4) + wave * 16 * 1024,
+                                 16 * 16 * 1024);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int col = (wave * 2 + n) * 16 + l15;
@@ -372,14 +440,18 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_f[r][n][e] + bv;
             }
             __syncthreads();
-            layernorm_rows(X, LW + G2, LW + BE2, wave, lane);
+            if (!(ABL & 2)) layernorm_rows(X, LW + G2, LW + BE2, wave, lane);
             __syncthreads();
         }
         // ---- RNN input projection (:99, first half of nn.RNN): IH = X W_ih^T + (b_ih + b_hh), rows 0..T-1 -> HBM ----
         if (ih_out) {
             f32x4 acc[RB][4];
             zero_acc<4>(acc);
-            gemm_phase<4, 16>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, ih_off_b + (wave * 4) * 16 * 1024, 16 * 1024);
+            const int isoff = ih_off_b + (wave * 4) * 16 * 1024;
+            WRing<4> g_ih;   // once per window: primed in place (one exposed L2 round trip per window)
+            ring_prefetch<4>(g_ih, rsrc, voff, isoff, 16 * 1024);
+
+            gemm_phase<4, 16, (ABL & 4) != 0>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
             float* io = ih_out + (size_t)win * T * R;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -410,17 +482,36 @@ hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float
                                 const float* keep_mask, float keep_scale, float* xout, float* ih_out, int B, int T,
                                 int num_cus, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+    static int abl = -1;
+    if (abl < 0) {
+        const char* e = getenv("TIP_FUSED_ABLATE");   // measurement-only (profiles/): never set in production
+        abl = e ? atoi(e) : 0;
     }
     const int grid = B < num_cus ? B : num_cus;
-    hipLaunchKernelGGL(fused_encoder_kernel, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s,
-                       keep_mask, keep_scale, xout, fused_has_rnn_ih(d) ? ih_out : nullptr, B, T, d.n_imu_total, d.S, d.L,
-                       (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4));
+    float* iho = fused_has_rnn_ih(d) ? ih_out : nullptr;
+    const int wb = (int)(fused_packed_floats(d) * 4), iob = (int)(fused_ih_off(d) * 4);
+#define TIP_FUSED_LAUNCH(A)                                                                                              \
+    {                                                                                                                    \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_kernel<A>),                   \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);               \
+            if (e != hipSuccess) return e;                                                                               \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL(fused_encoder_kernel<A>, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, \
+                           keep_mask, keep_scale, xout, iho, B, T, d.n_imu_total, d.S, d.L, wb, iob);                    \
+    }
+    switch (abl) {
+        case 0: TIP_FUSED_LAUNCH(0) break;
+        case 1: TIP_FUSED_LAUNCH(1) break;
+        case 2: TIP_FUSED_LAUNCH(2) break;
+        case 3: TIP_FUSED_LAUNCH(3) break;
+        case 4: TIP_FUSED_LAUNCH(4) break;
+        case 7: TIP_FUSED_LAUNCH(7) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef TIP_FUSED_LAUNCH
     return hipGetLastError();
 }
 
