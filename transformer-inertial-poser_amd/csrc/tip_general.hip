@@ -12,6 +12,8 @@
 //   attention_kernel    :85,:91  causal 16-head scaled-dot-product attention (torch functional.py SDPA)
 //   layernorm_kernel    :91      post-norm LayerNorm (eps 1e-5, biased variance)
 //   rnn_kernel          :98-99   h_t = tanh(ih_t + W_hh h_{t-1}), h_0 = 0
+#include <stdlib.h>
+
 #include "tip_internal.h"
 
 namespace tip {
@@ -569,7 +571,13 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
 // HALL -> per-(tile,step) arrival counter -> the other members poll it and pull the tile back with sc1 loads
 // (agent-scope coherent across the 8 XCD L2s; no fences on the critical path).
 // ------------------------------------------------------------------------------------------------
-template <int WAVES, int KSPLIT>
+// HANDOFF = 0: arrival counter (stores -> drain -> barrier -> counter; consumers poll the counter, then pull).
+// HANDOFF = 1: the data is the flag — HALL is pre-filled with an all-ones sentinel (a NaN bit pattern no arithmetic
+//              produces), producers just store, consumers re-pull until no sentinel word is left: two memory round
+//              trips (drain + counter) leave the per-step critical path.
+constexpr unsigned kRnnSentinel = 0xFFFFFFFFu;
+
+template <int WAVES, int KSPLIT, int HANDOFF>
 __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* __restrict__ ih,
                                                                    const float* __restrict__ whh_frag,
                                                                    float* __restrict__ hall, unsigned* __restrict__ flags,
@@ -615,25 +623,56 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
 #pragma unroll
             for (int hh = 0; hh < NH; ++hh) chn[hh][0] = chn[hh][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (t > 0) {
-                if (tid == 0) {
-                    // bounded spin: a cluster member that never arrives must not hang the GPU (result is then wrong,
-                    // which the parity tests catch)
-                    const unsigned* f = flags + (size_t)tile * T + (t - 1);
-                    for (unsigned spins = 0; spins < (1u << 22); ++spins) {
-                        if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)CLUSTER) break;
-                        __builtin_amdgcn_s_sleep(1);
+                constexpr int NLD = kRnnTile * (R / 4) / THREADS;   // float4 slots of the h tile per thread
+                if (HANDOFF == 0) {
+                    if (tid == 0) {
+                        // bounded spin: a cluster member that never arrives must not hang the GPU (result is then
+                        // wrong, which the parity tests catch)
+                        const unsigned* f = flags + (size_t)tile * T + (t - 1);
+                        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                            if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)CLUSTER) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
                 // pull h_{t-1} [16][512] with sc1 loads (aux = 16): bypass this CU's L1, coherent at agent scope
-                for (int i = tid; i < kRnnTile * (R / 4); i += THREADS) {
+                u32x4 v[NLD];
+                bool need[NLD];
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int i = tid + j * THREADS;
+                    need[j] = b0 + i / (R / 4) < B;
+                    v[j] = (u32x4){0u, 0u, 0u, 0u};
+                }
+                for (unsigned spins = 0; spins < (1u << 20); ++spins) {
+                    bool any = false;
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j) {
+                        if (need[j]) {
+                            const int i = tid + j * THREADS;
+                            const int m = i / (R / 4), c = (i % (R / 4)) * 4;
+                            v[j] = __builtin_amdgcn_raw_buffer_load_b128(hrs, (int)((((size_t)(b0 + m) * T + (t - 1)) * R + c) * 4), 0, 16);
+                        }
+                    }
+                    if (HANDOFF == 0) break;
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j) {
+                        if (need[j]) {
+                            const bool pend = v[j].x == kRnnSentinel || v[j].y == kRnnSentinel || v[j].z == kRnnSentinel ||
+                                              v[j].w == kRnnSentinel;
+                            need[j] = pend;
+                            any |= pend;
+                        }
+                    }
+                    if (!any) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    const int i = tid + j * THREADS;
                     const int m = i / (R / 4), c = (i % (R / 4)) * 4;
-                    const int bb = b0 + m;
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (bb < B)
-                        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                          hrs, (int)((((size_t)bb * T + (t - 1)) * R + c) * 4), 0, 16));
-                    *reinterpret_cast<f32x4*>(smem + m * LDH + c) = v;
+                    *reinterpret_cast<u32x4*>(smem + m * LDH + c) = v[j];
                 }
                 __syncthreads();
                 const float* ap = smem + l15 * LDH + ks * KBW * 16 + lg * 4;
@@ -676,11 +715,15 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                     }
                 }
             }
-            // publish: every storing wave drains its stores, workgroup barrier, one arrival
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0)
-                __hip_atomic_fetch_add(flags + (size_t)tile * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (HANDOFF == 0) {
+                // publish: every storing wave drains its stores, workgroup barrier, one arrival
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0)
+                    __hip_atomic_fetch_add(flags + (size_t)tile * T + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (KSPLIT == 1) {
+                __syncthreads();   // the h tile in LDS is rewritten by the next step's pull
+            }
         }
     }
 }
@@ -694,13 +737,25 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
     int groups = ntiles;
     const int maxg = num_cus / CLUSTER > 0 ? num_cus / CLUSTER : 1;   // keep every cluster co-resident
     if (groups > maxg) groups = maxg;
-    hipError_t e = hipMemsetAsync(flags, 0, (size_t)ntiles * T * sizeof(unsigned), s);
-    if (e != hipSuccess) return e;
+    static int handoff = -1;
+    if (handoff < 0) {
+        const char* e = getenv("TIP_RNN_HANDOFF");   // 0 = arrival counter, 1 = sentinel polling (default)
+        handoff = e ? atoi(e) : 1;
+    }
     const size_t smem = ((size_t)kRnnTile * (512 + 4) + (size_t)(KSPLIT - 1) * (WAVES / KSPLIT) * 256) * sizeof(float);
     const long long hb = (long long)B * T * 512 * 4;
     if (hb > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
-                       whh_frag, hall, flags, B, T, ntiles, (int)hb);
+    if (handoff == 0) {
+        hipError_t e = hipMemsetAsync(flags, 0, (size_t)ntiles * T * sizeof(unsigned), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 0>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
+                           whh_frag, hall, flags, B, T, ntiles, (int)hb);
+    } else {
+        hipError_t e = hipMemsetAsync(hall, 0xFF, (size_t)hb, s);   // every word = kRnnSentinel
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
+                           whh_frag, hall, flags, B, T, ntiles, (int)hb);
+    }
     return hipGetLastError();
 }
 
