@@ -107,6 +107,23 @@ int tip_forward_count(const tip_handle* h, uint64_t* n);
  * returns the number of stages (<= cap) or a negative status. */
 int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches, int cap);
 
+/* ---- streaming front/back-end: the model-facing half of RTRunnerMin.step
+ *      (real_time_runner_minimal.py:59-85 record_raw_imu / record_state_aa_and_c, :87-112 smooth_and_split_s_c,
+ *      :131-167 window build + pose assembly) for n_streams lock-stepped streams, entirely on the device.
+ *      `state` is a caller-owned device buffer of tip_stream_state_bytes(); frame / call counters are the caller's.
+ *      Per frame f = 0,1,2,...:  T = tip_stream_window_len(f);
+ *          tip_stream_ingest(state, raw_imu[n,72], n, f, x_imu[n,T,90], x_s[n,T,131], stream);
+ *          if (T > 0) { tip_forward(..., TIP_FWD_LAST_ROW_ONLY) -> y_last[n,131];
+ *                       tip_stream_consume(state, y_last, n, f - 5, s_rest[n,111] (= s_t[3:114]), c_t[n,20], stream); }
+ *      PyBullet FK and the SBP root-translation correction (:169-194) stay with the host. */
+int tip_stream_state_bytes(int n_streams, size_t* bytes);
+int tip_stream_reset(void* state, const float* s_init /* [n,114] device */, int n_streams, tip_stream_t stream);
+int tip_stream_window_len(int frame_idx); /* 0 while the 11-tap smoother primes (frames 0..4), then 1..40 */
+int tip_stream_ingest(void* state, const float* raw_imu, int n_streams, int frame_idx, float* x_imu, float* x_s,
+                      tip_stream_t stream);
+int tip_stream_consume(void* state, const float* y_last, int n_streams, int call_idx, float* s_rest, float* c_t,
+                       tip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

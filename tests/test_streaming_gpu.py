@@ -1,0 +1,129 @@
+"""GPU tests of the on-device streaming front/back-end (csrc/tip_stream.hip, streaming.py) against the trace of the
+REAL reference runner (tests/golden/tip_runner_golden.npz) and the numpy/scipy oracle."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import tip_amd
+from tip_amd import synth
+from tip_amd import lib as tlib
+from conftest import ROOT
+from test_host_cpu import make_model, load_synth
+
+pytestmark = pytest.mark.gpu
+RUNNER_GOLDEN = os.path.join(ROOT, "tests", "golden", "tip_runner_golden.npz")
+TOL_IO = 1e-4      # fp32 device arithmetic (rotation log/exp chain) vs the reference's float64 numpy, teacher-forced
+TOL_LOOP = 2e-3    # closed loop over 65 model calls (fp32 feedback through the network)
+
+
+@pytest.fixture(scope="module")
+def trace():
+    z = np.load(RUNNER_GOLDEN)
+    out = {}
+    for k in z.files:
+        tag, name = k.split("/")
+        out.setdefault(tag, {})[name] = z[k]
+    return [out["stream0"], out["stream1"]]
+
+
+def test_teacher_forced_matches_reference_runner(trace):
+    """Drive the C-ABI directly with the reference model's own outputs: every tensor the device hands to the model and
+    every decoded pose / SBP row must match what RTRunnerMin produced."""
+    lib = tlib.load()
+    n = 2
+    nb = ctypes.c_size_t()
+    assert lib.tip_stream_state_bytes(n, ctypes.byref(nb)) == 0
+    state = torch.empty(nb.value, dtype=torch.uint8, device="cuda")
+    s_init = torch.tensor(np.stack([t["s_init"] for t in trace]), dtype=torch.float32).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.tip_stream_reset(state.data_ptr(), s_init.data_ptr(), n, st) == 0
+    x_imu = torch.empty(n, 40, 90, device="cuda")
+    x_s = torch.empty(n, 40, 131, device="cuda")
+    s_rest = torch.empty(n, 111, device="cuda")
+    c_t = torch.empty(n, 20, device="cuda")
+    k = 0
+    worst = {"x_imu": 0.0, "x_s": 0.0, "pose": 0.0}
+    for f in range(70):
+        raw = torch.tensor(np.stack([t["raw_imu"][f] for t in trace]), dtype=torch.float32).cuda()
+        T = lib.tip_stream_window_len(f)
+        assert lib.tip_stream_ingest(state.data_ptr(), raw.data_ptr(), n, f, x_imu.data_ptr(), x_s.data_ptr(), st) == 0
+        if T == 0:
+            continue
+        assert T == trace[0]["call_T"][k]
+        torch.cuda.synchronize()
+        xi = x_imu.view(-1)[: n * T * 90].view(n, T, 90).cpu().numpy()
+        xs = x_s.view(-1)[: n * T * 131].view(n, T, 131).cpu().numpy()
+        for b, tr in enumerate(trace):
+            worst["x_imu"] = max(worst["x_imu"], np.abs(xi[b, -1] - tr["x_imu_last_rows"][k]).max())
+            worst["x_s"] = max(worst["x_s"], np.abs(xs[b, -1] - tr["x_s_last_rows"][k]).max())
+            assert np.abs(xi[b, -1] - tr["x_imu_last_rows"][k]).max() < TOL_IO, (f, b)
+            assert np.abs(xs[b, -1] - tr["x_s_last_rows"][k]).max() < TOL_IO, (f, b)
+            if f"x_imu_call{k}" in tr:
+                assert np.abs(xi[b] - tr[f"x_imu_call{k}"]).max() < TOL_IO
+                assert np.abs(xs[b] - tr[f"x_s_call{k}"]).max() < TOL_IO
+        y = torch.tensor(np.stack([t["y_last_rows"][k] for t in trace]), dtype=torch.float32).cuda()
+        assert lib.tip_stream_consume(state.data_ptr(), y.data_ptr(), n, k, s_rest.data_ptr(), c_t.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        for b, tr in enumerate(trace):
+            worst["pose"] = max(worst["pose"], np.abs(s_rest[b].cpu().numpy() - tr["qdq"][f][3:]).max())
+            assert np.abs(s_rest[b].cpu().numpy() - tr["qdq"][f][3:]).max() < TOL_IO, (f, b)
+            assert np.array_equal(c_t[b].cpu().numpy()[0::4], tr["ct"][f][0::4])
+            assert np.abs(c_t[b].cpu().numpy() - tr["ct"][f]).max() < TOL_IO
+        k += 1
+    assert k == 65
+    print("teacher-forced worst errors:", worst)
+
+
+def test_closed_loop_engine_tracks_reference_runner(trace):
+    """The whole loop on the device (HIP forward inside) vs the reference runner with the reference model on the CPU."""
+    cfg = synth.PAPER
+    m = make_model(cfg)
+    load_synth(m, cfg, 0)
+    m = m.cuda().eval()
+    eng = tip_amd.streaming.StreamingEngine(m, np.stack([t["s_init"] for t in trace]))
+    n0 = m.hip_forward_count()
+    worst = 0.0
+    for f in range(70):
+        out = eng.step(np.stack([t["raw_imu"][f] for t in trace]))
+        if f < 5:
+            assert out is None
+            continue
+        torch.cuda.synchronize()
+        for b, tr in enumerate(trace):
+            e = np.abs(out["s_rest"][b].cpu().numpy() - tr["qdq"][f][3:]).max()
+            worst = max(worst, e)
+            assert e < TOL_LOOP, (f, b, e)
+            k = f - 5
+            assert np.abs(out["y_last"][b].cpu().numpy() - tr["y_last_rows"][k]).max() < TOL_LOOP
+    assert m.hip_forward_count() == n0 + 65
+    print("closed-loop worst |pose - reference| =", worst)
+
+
+def test_many_streams_are_independent():
+    """1024 lock-stepped streams (BASELINE configs[2]): stream i of the big batch == the same stream run alone."""
+    cfg = synth.PAPER
+    m = make_model(cfg)
+    load_synth(m, cfg, 0)
+    m = m.cuda().eval()
+    m.set_plan("fused")
+    rng = np.random.RandomState(0)
+    B, F = 1024, 12
+    from scipy.spatial.transform import Rotation
+    raw = np.zeros((F, B, 72), dtype=np.float32)
+    base = Rotation.random(B * 6, random_state=1).as_matrix().reshape(B, 54)
+    for f in range(F):
+        raw[f, :, :54] = base
+        raw[f, :, 54:] = rng.randn(B, 18)
+    s_init = rng.randn(B, 114).astype(np.float32) * 0.2
+    eng = tip_amd.streaming.StreamingEngine(m, s_init)
+    sel = [0, 17, 1023]
+    eng1 = tip_amd.streaming.StreamingEngine(m, s_init[sel])
+    for f in range(F):
+        o = eng.step(raw[f])
+        o1 = eng1.step(raw[f][sel])
+        if o is None:
+            continue
+        assert torch.equal(o["s_rest"][sel], o1["s_rest"]) and torch.equal(o["c_t"][sel], o1["c_t"])

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[2]: closed-loop streaming, N concurrent IMU streams at 60 FPS on one MI355X.
+Measures frames/s of the on-device engine (ingest -> forward(last row) -> consume), with and without the per-frame
+PCIe hops a host application needs (raw IMU frame in, pose/SBP rows out).  One JSON line per N."""
+import contextlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import tip_amd  # noqa: E402
+from tip_amd import synth  # noqa: E402
+
+
+def main():
+    cfg = synth.PAPER
+    with contextlib.redirect_stdout(sys.stderr):
+        m = tip_amd.TF_RNN_Past_State(72, 131, rnn_hid_size=512, tf_hid_size=1024, tf_in_dim=256, n_heads=16, tf_layers=4,
+                                      dropout=0.0, in_dropout=0.0, past_state_dropout=0.0, with_acc_sum=True)
+    w = synth.make_weights(cfg, seed=0)
+    m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    m = m.cuda().eval()
+    m.refresh_packed()
+    m.freeze_packed(True)
+    from scipy.spatial.transform import Rotation
+    for n in (1, 64, 1024, 4096):
+        rng = np.random.RandomState(n)
+        base = Rotation.random(n * 6, random_state=n).as_matrix().reshape(n, 54).astype(np.float32)
+        s_init = (rng.randn(n, 114) * 0.2).astype(np.float32)
+        eng = tip_amd.streaming.StreamingEngine(m, s_init)
+        frames = [np.concatenate([base, rng.randn(n, 18).astype(np.float32)], axis=1) for _ in range(8)]
+        dev_frames = [torch.tensor(f).cuda() for f in frames]
+        for f in range(60):                      # prime the smoother and fill the 40-frame windows
+            eng.step(dev_frames[f % 8])
+        torch.cuda.synchronize()
+        iters = 60 if n <= 1024 else 20
+        t0 = time.perf_counter()
+        for f in range(iters):
+            eng.step(dev_frames[f % 8])
+        torch.cuda.synchronize()
+        t_dev = (time.perf_counter() - t0) / iters
+        pinned_in = [torch.tensor(f).pin_memory() for f in frames]
+        t0 = time.perf_counter()
+        for f in range(iters):
+            out = eng.step(pinned_in[f % 8])     # H2D of the raw frame
+            pose = out["s_rest"].cpu()           # D2H of what the host-side FK / visualiser needs (sync per frame)
+            ct = out["c_t"].cpu()
+        t_pcie = (time.perf_counter() - t0) / iters
+        print(json.dumps({"streams": n, "T": 40, "ms_per_frame_device_resident": t_dev * 1e3,
+                          "stream_frames_per_s": n / t_dev, "realtime_headroom_vs_60fps": (1.0 / t_dev) / 60.0,
+                          "ms_per_frame_with_pcie_io": t_pcie * 1e3, "stream_frames_per_s_with_pcie_io": n / t_pcie}),
+              flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -21,6 +21,7 @@ EXPORTS = (
     "tip_abi_version", "tip_create", "tip_destroy", "tip_strerror", "tip_last_hip_error", "tip_set_option",
     "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
     "tip_attach_packed", "tip_workspace_bytes", "tip_forward", "tip_forward_count", "tip_profile_read",
+    "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
 )
 
 
@@ -90,6 +91,11 @@ def load() -> ctypes.CDLL:
     lib.tip_forward_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.tip_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
                                      ctypes.POINTER(i32), i32]
+    lib.tip_stream_state_bytes.argtypes = [i32, ctypes.POINTER(sz)]
+    lib.tip_stream_reset.argtypes = [vp, vp, i32, vp]
+    lib.tip_stream_window_len.argtypes = [i32]
+    lib.tip_stream_ingest.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    lib.tip_stream_consume.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("tip_destroy", "tip_strerror", "tip_last_hip_error"):
             getattr(lib, name).restype = i32

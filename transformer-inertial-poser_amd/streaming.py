@@ -1,0 +1,75 @@
+"""On-device streaming engine: the model-facing half of the reference's RTRunnerMin.step
+(/root/reference/real_time_runner_minimal.py:114-167,196) for many lock-stepped IMU streams.
+
+    eng = StreamingEngine(model, s_init)          # s_init [B,114] (q, dq) like RTRunnerMin's
+    for frame in imu_frames:                       # frame [B,72]: 6 global rotations (row-major) + 6 accelerations
+        out = eng.step(frame)                      # None while the 11-tap smoother primes (first 5 frames, :125-128)
+        # out["s_rest"] [B,111] = s_t[3:114] (54 axis-angles, root velocity, zeros), out["c_t"] [B,20], out["y_last"]
+
+Everything between the raw IMU frame and the fed-back history row stays in HBM: ring buffers, smoothing, root-frame
+rotation, acc-sum feature, window gather, the forward pass (TIP_FWD_LAST_ROW_ONLY), output filter, SBP decode,
+6D <-> axis-angle and the pose averaging (csrc/tip_stream.hip).  PyBullet FK and the SBP root-translation correction
+(:169-194) remain the host's job (they never feed back into the model input).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+
+
+class StreamingEngine:
+    def __init__(self, model, s_init: torch.Tensor):
+        self.model = model
+        self.lib = _lib.load()
+        s_init = torch.as_tensor(s_init, dtype=torch.float32)
+        if s_init.dim() == 1:
+            s_init = s_init.unsqueeze(0)
+        assert s_init.shape[1] == 114, "s_init is (q, dq) with 57 dofs each (constants.py:24)"
+        self.device = next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise RuntimeError("tip_amd.StreamingEngine runs on an MI355X: move the model to the GPU first")
+        self.n = int(s_init.shape[0])
+        nbytes = ctypes.c_size_t()
+        self._check(self.lib.tip_stream_state_bytes(self.n, ctypes.byref(nbytes)))
+        self.state = torch.empty(max(nbytes.value, 4), dtype=torch.uint8, device=self.device)
+        self.s_init = s_init.to(self.device).contiguous()
+        self.x_imu = torch.empty((self.n, 40, 90), dtype=torch.float32, device=self.device)
+        self.x_s = torch.empty((self.n, 40, 131), dtype=torch.float32, device=self.device)
+        self.s_rest = torch.empty((self.n, 111), dtype=torch.float32, device=self.device)
+        self.c_t = torch.empty((self.n, 20), dtype=torch.float32, device=self.device)
+        self.reset()
+
+    def _check(self, status: int):
+        if status < 0:
+            raise _lib.TipStatusError(status, self.lib.tip_strerror(status).decode())
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def reset(self):
+        self.frame = 0
+        with torch.cuda.device(self.device):
+            self._check(self.lib.tip_stream_reset(self.state.data_ptr(), self.s_init.data_ptr(), self.n, self._stream()))
+
+    @torch.no_grad()
+    def step(self, raw_imu: torch.Tensor) -> Optional[dict]:
+        raw = torch.as_tensor(raw_imu, dtype=torch.float32).reshape(self.n, 72).to(self.device, non_blocking=True).contiguous()
+        f = self.frame
+        T = int(self.lib.tip_stream_window_len(f))
+        with torch.cuda.device(self.device):
+            # windows are written densely as [n, T, *] at the head of the preallocated buffers
+            self._check(self.lib.tip_stream_ingest(self.state.data_ptr(), raw.data_ptr(), self.n, f, self.x_imu.data_ptr(),
+                                                   self.x_s.data_ptr(), self._stream()))
+            self.frame += 1
+            if T == 0:
+                return None
+            x_imu = self.x_imu.view(-1)[: self.n * T * 90].view(self.n, T, 90)
+            x_s = self.x_s.view(-1)[: self.n * T * 131].view(self.n, T, 131)
+            y_last = self.model.forward_last(x_imu, x_s)
+            self._check(self.lib.tip_stream_consume(self.state.data_ptr(), y_last.data_ptr(), self.n, f - 5,
+                                                    self.s_rest.data_ptr(), self.c_t.data_ptr(), self._stream()))
+        return {"s_rest": self.s_rest, "c_t": self.c_t, "y_last": y_last, "T": T}
