@@ -82,9 +82,22 @@ def cpu_baseline(cfg, B, T, budget_s=12.0):
     m = build_model(cfg, 0, True).eval()
     x_imu, x_s = synth.make_inputs(cfg, B, T, seed=1234)
     xi, xs = torch.tensor(x_imu), torch.tensor(x_s)
-    cores = torch.get_num_threads()
+    max_threads = torch.get_num_threads()
     with torch.no_grad():
-        m._forward_torch_ops(xi, xs)  # warm-up
+        # pick the thread count that serves this workload best (the reference's own evaluation uses 1,
+        # offline_testing_simple.py:34; small GEMMs oversubscribe badly on a 128-thread host)
+        best, cores = None, 1
+        for nt in sorted({1, 8, 16, 32, 64, max_threads}):
+            if nt > max_threads:
+                continue
+            torch.set_num_threads(nt)
+            m._forward_torch_ops(xi, xs)  # warm-up
+            t0 = time.perf_counter()
+            m._forward_torch_ops(xi, xs)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, cores = dt, nt
+        torch.set_num_threads(cores)
         n, t0 = 0, time.perf_counter()
         while True:
             m._forward_torch_ops(xi, xs)
@@ -92,15 +105,16 @@ def cpu_baseline(cfg, B, T, budget_s=12.0):
             el = time.perf_counter() - t0
             if el > budget_s or n >= 40:
                 break
+        torch.set_num_threads(max_threads)
     out = {"value": B * n / el, "unit": "IMU frames/s", "cores": cores, "kind": "port",
            "sample": f"{n} forwards of B={B},T={T} (paper config) with the torch-op restatement of the reference CPU "
-                     f"path, torch.set_num_threads({cores}), {el:.1f} s"}
+                     f"path, best of 1/8/16/32/64/{max_threads} threads = {cores}, {el:.1f} s"}
     # the C oracle (scalar port, OpenMP over windows), same workload, bounded
     try:
         from oracle import oracle
         w = synth.make_weights(cfg, seed=0)
         nt = oracle.max_threads()
-        nb = max(nt, 8)
+        nb = max(4 * nt, 32)
         t0 = time.perf_counter()
         oracle.forward(cfg, w, x_imu[:nb], x_s[:nb], dtype=np.float32, nthreads=nt)
         el = time.perf_counter() - t0
