@@ -243,3 +243,27 @@ def test_latency_plan_is_deterministic_and_batch_independent():
     assert np.array_equal(yl, y[:, -1])
     yo = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
     assert np.abs(y - yo).max() < TOL_TIGHT
+
+
+def test_cluster_handoffs_under_uneven_load():
+    """Race screen for the inter-workgroup hand-offs (RNN clusters, GEMV granules): results must stay bit-identical
+    while a second stream keeps a varying subset of CUs busy, so cluster members are dispatched late / unevenly and
+    consumers run with warm L1s (cdna_hip_programming.md, Guideline 16: "test every hand-off under UNEVEN load")."""
+    cfg = synth.PAPER
+    m, _ = _gpu_model(cfg, 0)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    for plan, B in (("fused", 200), ("fused", 40), ("latency", 9)):
+        m.set_plan(plan)
+        x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=31)
+        xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+        with torch.no_grad():
+            ref = m(xi, xs).clone()
+            torch.cuda.synchronize()
+            for it in range(25):
+                with torch.cuda.stream(side):
+                    for _ in range(1 + it % 4):
+                        b = a[: 512 * (1 + it % 7)] @ a      # different CU footprints and durations
+                y = m(xi, xs)
+                torch.cuda.synchronize()
+                assert torch.equal(y, ref), (plan, B, it)
