@@ -267,3 +267,23 @@ def test_cluster_handoffs_under_uneven_load():
                 y = m(xi, xs)
                 torch.cuda.synchronize()
                 assert torch.equal(y, ref), (plan, B, it)
+
+
+@pytest.mark.parametrize("D,H,F,L,R,with_rnn,acc,B,T", [
+    (64, 8, 48, 1, 64, True, True, 3, 5),       # d_head 8, narrow FFN, one layer
+    (128, 4, 320, 2, 192, True, True, 5, 13),    # d_head 32 (attention scale applied in-kernel, not folded)
+    (256, 4, 512, 1, 128, True, False, 2, 17),   # d_head 64, no acc-sum columns
+    (192, 12, 208, 3, 0, False, True, 4, 9),     # no RNN: linear maps d_model -> size_s directly
+    (512, 16, 1024, 1, 512, True, True, 18, 60),  # d_head 32, T=60, register-resident RNN path (R=512)
+])
+def test_general_plan_configuration_sweep(D, H, F, L, R, with_rnn, acc, B, T):
+    """The general plan claims any configuration with d_model,ffn % 16 == 0, d_head in {8,16,32,64}, rnn % 64 == 0."""
+    cfg = dict(input_size_imu=72, size_s=131, rnn_hid_size=R if with_rnn else 64, tf_hid_size=F, tf_in_dim=D, n_heads=H,
+               tf_layers=L, with_rnn=with_rnn, with_acc_sum=acc)
+    m, w = _gpu_model(cfg, 2)
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=40 + D)
+    y = _run(m, x_imu, x_s)
+    yo = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
+    assert y.shape == yo.shape and np.abs(y - yo).max() < TOL_TIGHT, np.abs(y - yo).max()
+    yl = _run(m, x_imu, x_s, last=True)
+    assert np.array_equal(yl, y[:, -1])
