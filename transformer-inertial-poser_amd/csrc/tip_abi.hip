@@ -466,6 +466,14 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     float* enc_out = xa;  // encoder output [M, D]
     bool ih_done = false;  // the fused plan also emits the RNN input projection
     bool rnn_done = false;
+    bool hall_armed = false;
+    int rnn_cluster = h->rnn_cluster;
+    if (rnn_cluster == 0) {
+        // auto: spread one 16-window tile over as many CUs as the tile count leaves idle
+        const int ntiles = (B + kRnnTile - 1) / kRnnTile;
+        rnn_cluster = 16;
+        while (rnn_cluster > 1 && ntiles * rnn_cluster > h->num_cus) rnn_cluster >>= 1;
+    }
     if (plan == TIP_PLAN_LATENCY) {
         StageScope sc(h, s, "latency_chain");
         TIP_TRY(launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall,
@@ -474,8 +482,10 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     } else if (plan == TIP_PLAN_FUSED) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = fused_has_rnn_ih(d);
+        hall_armed = ih_done && rnn_uses_sentinel(d, B, T, rnn_cluster);   // the encoder pre-fills its HALL rows
         TIP_TRY(launch_fused_encoder(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, ih_done ? nullptr : xa,
-                                     ih_done ? big : nullptr, B, T, h->num_cus, s), "fused_encoder");
+                                     ih_done ? big : nullptr, hall_armed ? hall : nullptr, B, T, h->num_cus, s),
+                "fused_encoder");
     } else {
         {
             StageScope sc(h, s, "prologue");
@@ -537,14 +547,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         }
         {
             StageScope sc(h, s, "rnn_recurrence");
-            int cluster = h->rnn_cluster;
-            if (cluster == 0) {
-                // auto: spread one window-tile over as many CUs as the tile count leaves idle
-                const int ntiles = (B + kRnnTile - 1) / kRnnTile;
-                cluster = 16;
-                while (cluster > 1 && ntiles * cluster > h->num_cus) cluster >>= 1;
-            }
-            TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, cluster, h->num_cus, s),
+            TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, rnn_cluster, h->num_cus, hall_armed, s),
                     "rnn_recurrence");
         }
         head_in = hall;

@@ -265,8 +265,8 @@ __device__ __forceinline__ void layernorm_rows(float* X, const float* __restrict
 template <int ABL>
 __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
     const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
-    const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ xout, float* __restrict__ ih_out, int B,
-    int T, int NI, int S, int L, int wbytes, int ih_off_b) {
+    const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ xout, float* __restrict__ ih_out,
+    unsigned* __restrict__ hall_sentinel, int B, int T, int NI, int S, int L, int wbytes, int ih_off_b) {
     using namespace fz;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;
@@ -466,6 +466,11 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     }
             }
         }
+        // ---- arm the RNN hand-off: this window's rows of HALL start as the all-ones sentinel (saves a 21-MB memset) ---
+        if (hall_sentinel) {
+            uint4* hp = reinterpret_cast<uint4*>(hall_sentinel + (size_t)win * T * R);
+            for (int i = tid; i < T * (R / 4); i += THREADS) hp[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        }
         // ---- encoder output rows 0..T-1 -> HBM (only when a caller wants it) ---------------------------------------
         if (xout) {
             float* out = xout + (size_t)win * T * D;
@@ -479,8 +484,8 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
 }
 
 hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
-                                const float* keep_mask, float keep_scale, float* xout, float* ih_out, int B, int T,
-                                int num_cus, hipStream_t s) {
+                                const float* keep_mask, float keep_scale, float* xout, float* ih_out, float* hall_sentinel,
+                                int B, int T, int num_cus, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     static int abl = -1;
     if (abl < 0) {
@@ -500,7 +505,8 @@ hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float
             attr_set = true;                                                                                             \
         }                                                                                                                \
         hipLaunchKernelGGL(fused_encoder_kernel<A>, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, \
-                           keep_mask, keep_scale, xout, iho, B, T, d.n_imu_total, d.S, d.L, wb, iob);                    \
+                           keep_mask, keep_scale, xout, iho, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L, wb, \
+                           iob);                    \
     }
     switch (abl) {
         case 0: TIP_FUSED_LAUNCH(0) break;

@@ -205,24 +205,35 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const float* __restrict_
     f32x4 wc[NBO], wn[NBO];
 #pragma unroll
     for (int n = 0; n < NBO; ++n) wc[n] = ldw(n, 0);
-    float4 a = *reinterpret_cast<const float4*>(ap);
+    // A fragments come from HBM (HALL was just written by the RNN): keep 4 k-blocks of them in flight
+    constexpr int AD = 4;
+    float4 aq[AD];
+#pragma unroll
+    for (int j = 0; j < AD; ++j) aq[j] = *reinterpret_cast<const float4*>(ap + (j < KB ? j : KB - 1) * 16);
 #pragma unroll 1
-    for (int kb = 0; kb < KB; ++kb) {
-        const int kn = kb + 1 < KB ? kb + 1 : kb;
+    for (int kb0 = 0; kb0 < KB; kb0 += AD) {
 #pragma unroll
-        for (int n = 0; n < NBO; ++n) wn[n] = ldw(n, kn);
-        const float4 an = *reinterpret_cast<const float4*>(ap + kn * 16);
+        for (int j = 0; j < AD; ++j) {
+            const int kb = kb0 + j;
+            if (kb < KB) {
+                const int kn = kb + 1 < KB ? kb + 1 : kb;
 #pragma unroll
-        for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wc[n].x, acc[n], 0, 0, 0);
+                for (int n = 0; n < NBO; ++n) wn[n] = ldw(n, kn);
+                const float4 a = aq[j];
+                const int ka = kb + AD < KB ? kb + AD : KB - 1;
+                aq[j] = *reinterpret_cast<const float4*>(ap + ka * 16);
 #pragma unroll
-        for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wc[n].y, acc[n], 0, 0, 0);
+                for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wc[n].x, acc[n], 0, 0, 0);
 #pragma unroll
-        for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wc[n].z, acc[n], 0, 0, 0);
+                for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wc[n].y, acc[n], 0, 0, 0);
 #pragma unroll
-        for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wc[n].w, acc[n], 0, 0, 0);
+                for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wc[n].z, acc[n], 0, 0, 0);
 #pragma unroll
-        for (int n = 0; n < NBO; ++n) wc[n] = wn[n];
-        a = an;
+                for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wc[n].w, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NBO; ++n) wc[n] = wn[n];
+            }
+        }
     }
 #pragma unroll
     for (int n = 0; n < NBO; ++n) {
@@ -246,6 +257,11 @@ hipError_t launch_head_gemm(const float* A, long long lda, const float* wfrag, c
     if ((M + 63) / 64 * 4 < 256) {
         // few rows: one column block per workgroup so the (rows x column blocks) grid still covers many CUs
         hipLaunchKernelGGL(head_gemm_kernel<1>, dim3((M + 63) / 64, nbo), block, 0, s, A, lda, wfrag, bias, Y, ldy, M, N, K);
+        return hipGetLastError();
+    }
+    if (nbo % 3 == 0) {
+        // 3 column blocks per wave: three times the waves (every SIMD gets work, 2+ waves each hide the fragment latency)
+        hipLaunchKernelGGL(head_gemm_kernel<3>, dim3((M + 63) / 64, nbo / 3), block, 0, s, A, lda, wfrag, bias, Y, ldy, M, N, K);
         return hipGetLastError();
     }
     const dim3 grid((M + 63) / 64);
@@ -730,18 +746,27 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
 
 size_t rnn_flag_words(int B, int T) { return (size_t)((B + kRnnTile - 1) / kRnnTile) * (size_t)T; }
 
-template <int WAVES, int KSPLIT>
-static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T,
-                                      int ntiles, int num_cus, hipStream_t s) {
-    constexpr int CLUSTER = (512 / 16) / (WAVES / KSPLIT);
-    int groups = ntiles;
-    const int maxg = num_cus / CLUSTER > 0 ? num_cus / CLUSTER : 1;   // keep every cluster co-resident
-    if (groups > maxg) groups = maxg;
+static int rnn_handoff_mode() {
     static int handoff = -1;
     if (handoff < 0) {
         const char* e = getenv("TIP_RNN_HANDOFF");   // 0 = arrival counter, 1 = sentinel polling (default)
         handoff = e ? atoi(e) : 1;
     }
+    return handoff;
+}
+
+bool rnn_uses_sentinel(const Dims& d, int B, int T, int cluster) {
+    return d.R == 512 && (long long)B * T * 512 * 4 <= 0x7fffffffLL && cluster >= 4 && rnn_handoff_mode() == 1;
+}
+
+template <int WAVES, int KSPLIT>
+static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T,
+                                      int ntiles, int num_cus, bool hall_armed, hipStream_t s) {
+    constexpr int CLUSTER = (512 / 16) / (WAVES / KSPLIT);
+    int groups = ntiles;
+    const int maxg = num_cus / CLUSTER > 0 ? num_cus / CLUSTER : 1;   // keep every cluster co-resident
+    if (groups > maxg) groups = maxg;
+    const int handoff = rnn_handoff_mode();
     const size_t smem = ((size_t)kRnnTile * (512 + 4) + (size_t)(KSPLIT - 1) * (WAVES / KSPLIT) * 256) * sizeof(float);
     const long long hb = (long long)B * T * 512 * 4;
     if (hb > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -751,8 +776,10 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
         hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 0>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
                            whh_frag, hall, flags, B, T, ntiles, (int)hb);
     } else {
-        hipError_t e = hipMemsetAsync(hall, 0xFF, (size_t)hb, s);   // every word = kRnnSentinel
-        if (e != hipSuccess) return e;
+        if (!hall_armed) {
+            hipError_t e = hipMemsetAsync(hall, 0xFF, (size_t)hb, s);   // every word = kRnnSentinel
+            if (e != hipSuccess) return e;
+        }
         hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
                            whh_frag, hall, flags, B, T, ntiles, (int)hb);
     }
@@ -760,16 +787,16 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
 }
 
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
-                      int T, int cluster, int num_cus, hipStream_t s) {
+                      int T, int cluster, int num_cus, bool hall_armed, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     const int R = d.R;
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
     if (cluster < 1) cluster = 1;
     if (R == 512 && (long long)B * T * 512 * 4 <= 0x7fffffffLL) {
         // register-resident clustered kernel: W_hh slice lives in VGPRs, 4/8/16 workgroups per window tile
-        if (cluster >= 16) return launch_rnn_resident<4, 2>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, s);
-        if (cluster == 8) return launch_rnn_resident<4, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, s);
-        if (cluster == 4) return launch_rnn_resident<8, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, s);
+        if (cluster >= 16) return launch_rnn_resident<4, 2>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, s);
+        if (cluster == 8) return launch_rnn_resident<4, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, s);
+        if (cluster == 4) return launch_rnn_resident<8, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, s);
     }
     if (cluster > 8) cluster = 8;
     const int KB = R / 16;

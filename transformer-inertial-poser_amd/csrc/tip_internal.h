@@ -99,7 +99,7 @@ hipError_t launch_gemm(const float* A, int lda, const float* W, int Kpad, const 
 hipError_t launch_attention(const Dims& d, const float* qkv, float* out, int B, int T, hipStream_t s);
 hipError_t launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s);
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
-                      int T, int cluster, int num_cus, hipStream_t s);
+                      int T, int cluster, int num_cus, bool hall_armed, hipStream_t s);
 size_t rnn_flag_words(int B, int T);
 
 // ---- fused plan (tip_fused.hip) ----
@@ -109,8 +109,11 @@ void fused_pack(const Dims& d, const float* const* tensors, float* dst);
 bool fused_has_rnn_ih(const Dims& d);
 // xout [B,T,D] and/or ih_out [B,T,R] (RNN input projection incl. b_ih+b_hh); either may be null
 hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
-                                const float* keep_mask, float keep_scale, float* xout, float* ih_out, int B, int T,
-                                int num_cus, hipStream_t s);
+                                const float* keep_mask, float keep_scale, float* xout, float* ih_out, float* hall_sentinel,
+                                int B, int T, int num_cus, hipStream_t s);
+// true when launch_rnn(cluster) will run the sentinel-polling resident kernel (HALL must be pre-filled with all-ones;
+// the fused encoder can do that for its own rows, otherwise launch_rnn memsets)
+bool rnn_uses_sentinel(const Dims& d, int B, int T, int cluster);
 // Y[M,N] = A[M,K(lda)] * Wfrag^T + bias with Wfrag in 16x16x4 B-fragment order [ceil(N/16)][K/16][64][4]
 hipError_t launch_head_gemm(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy,
                             int M, int N, int K, hipStream_t s);
