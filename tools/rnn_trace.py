@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Measurement only: per-step timeline of the clustered RNN kernel (workgroup 0) from s_memtime stamps.
+usage: TIP_RNN_TRACE=1 python tools/rnn_trace.py [--cluster C]"""
+import contextlib, ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import tip_amd
+from tip_amd import synth, lib as tlib
+cfg = synth.PAPER
+with contextlib.redirect_stdout(sys.stderr):
+    m = tip_amd.TF_RNN_Past_State(72, 131, rnn_hid_size=512, tf_hid_size=1024, tf_in_dim=256, n_heads=16, tf_layers=4,
+                                  dropout=0.0, in_dropout=0.0, past_state_dropout=0.0, with_acc_sum=True)
+m.load_state_dict({k: torch.tensor(v) for k, v in synth.make_weights(cfg, seed=0).items()})
+m = m.cuda().eval()
+cl = int(sys.argv[sys.argv.index("--cluster") + 1]) if "--cluster" in sys.argv else 0
+m.set_plan("fused", rnn_cluster=cl)
+x_imu, x_s = synth.make_inputs(cfg, 256, 40)
+xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+with torch.no_grad():
+    for _ in range(5):
+        m(xi, xs)
+    torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 160)()
+lib = tlib.load()
+assert lib.tip_debug_read_rnn_trace(buf, 160) == 0
+t = np.array(buf[:160], dtype=np.float64).reshape(40, 4)
+ghz = 0.1  # s_memtime ticks at 100 MHz on this part if constant-rate; printed raw and as deltas
+pull, mma, done = t[1:, 0], t[1:, 1], t[1:, 2]
+print("ticks per step (median):", np.median(np.diff(t[1:, 0])))
+print("pull-done -> mfma-done  :", np.median(mma - pull))
+print("mfma-done -> stores-out :", np.median(done - mma))
+print("stores-out -> next pull :", np.median(pull[1:] - done[:-1]))
+print("first rows:", t[:4])

@@ -546,7 +546,13 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
                 for (int n = 0; n < NBW; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             __syncthreads();  // everyone is done reading h_{t-1} from LDS
-            // epilogue: D layout of 16x16: col = lane&15, row = 4*(lane>>4) + r
+            // epilogue: D layout of 16x16: col = lane&15, row = 4*(lane>>4) + r.  Values first, stores after (vmcnt counts
+            // stores too: interleaving them with uses of the prefetched ihv serialises on every store).
+            float hvv[NBW][4];
+#pragma unroll
+            for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hvv[n][r] = (b0 + lg * 4 + r < B) ? tip_tanh(acc[n][r] + ihv[n][r]) : 0.f;
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
                 const int col = (nb0 + n) * 16 + l15;
@@ -554,12 +560,8 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
                 for (int r = 0; r < 4; ++r) {
                     const int m = lg * 4 + r;
                     const int bb = b0 + m;
-                    float hv = 0.f;
-                    if (bb < B) {
-                        hv = tanhf(acc[n][r] + ihv[n][r]);
-                        hall[((size_t)bb * T + t) * R + col] = hv;
-                    }
-                    smem[m * LDH + col] = hv;
+                    if (bb < B) hall[((size_t)bb * T + t) * R + col] = hvv[n][r];
+                    smem[m * LDH + col] = hvv[n][r];
                 }
             }
             if (cluster > 1) {
@@ -593,7 +595,11 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
 //              trips (drain + counter) leave the per-step critical path.
 constexpr unsigned kRnnSentinel = 0xFFFFFFFFu;
 
-template <int WAVES, int KSPLIT, int HANDOFF>
+// measurement only (TIP_RNN_TRACE=1): per-step s_memtime stamps of workgroup 0 — after the pull, after the MFMAs,
+// after the reduce+tanh+stores — read back with tip_debug_read_rnn_trace().
+__device__ unsigned long long g_rnn_trace[64 * 4];
+
+template <int WAVES, int KSPLIT, int HANDOFF, bool TRACE = false>
 __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* __restrict__ ih,
                                                                    const float* __restrict__ whh_frag,
                                                                    float* __restrict__ hall, unsigned* __restrict__ flags,
@@ -608,10 +614,49 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cb = wave % CBW, ks = wave / CBW;
-    const int cid = blockIdx.x % CLUSTER, group = blockIdx.x / CLUSTER, ngroups = gridDim.x / CLUSTER;
+    // Cluster membership.  Workgroups are observed to land on XCD (blockIdx % 8); when the grid allows it the members of
+    // a cluster are chosen 8 blocks apart so that they share one XCD and its L2 (a SPEED choice only, see below).
+    const int ngroups = gridDim.x / CLUSTER;
+    int cid, group;
+    if (gridDim.x % (8 * CLUSTER) == 0) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        cid = j % CLUSTER;
+        group = x + 8 * (j / CLUSTER);
+    } else {
+        cid = blockIdx.x % CLUSTER;
+        group = blockIdx.x / CLUSTER;
+    }
     const int l15 = lane & 15, lg = lane >> 4;
     const int nb = cid * CBW + cb;                                // global 16-column block of this wave
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hall, 0, hall_bytes, 0x00020000);
+
+    // Same-XCD fast path, VERIFIED at run time (placement is never assumed): every member publishes the XCC id it
+    // really runs on (agent-scope), reads the others', and only if all 16 agree do producers use plain stores — which
+    // stay in the XCD's L2, where the members' L1-bypassing (sc1) loads find them after ~0.4 us instead of a
+    // write-through + fabric round trip.  Any disagreement (or HANDOFF == 0) keeps the write-through sc1 stores that
+    // are correct for every placement.
+    __shared__ int s_same_xcd;
+    if (HANDOFF == 1) {
+        if (tid == 0) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 0xf;
+            __hip_atomic_store(flags + group * CLUSTER + cid, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool same = true;
+            for (int m = 0; m < CLUSTER; ++m) {
+                unsigned v = 0;
+                for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                    v = __hip_atomic_load(flags + group * CLUSTER + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                same &= (v == xcc + 1u);
+            }
+            s_same_xcd = same ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    const bool same_xcd = HANDOFF == 1 && s_same_xcd != 0;
 
     // W_hh slice -> registers, once
     float4 wreg[KBW];
@@ -691,6 +736,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                     *reinterpret_cast<u32x4*>(smem + m * LDH + c) = v[j];
                 }
                 __syncthreads();
+                if (TRACE && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 0] = __builtin_amdgcn_s_memtime();
                 const float* ap = smem + l15 * LDH + ks * KBW * 16 + lg * 4;
 #pragma unroll
                 for (int hh = 0; hh < NH; ++hh) {
@@ -711,6 +757,10 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
             }
             f32x4 acc = chn[0][0] + chn[0][1];
             if (NH == 2) acc = acc + (chn[NH - 1][0] + chn[NH - 1][1]);
+            if (TRACE && blockIdx.x == 0 && tid == 0 && t < 64) {
+                asm volatile("" :: "v"(acc[0]));
+                g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
+            }
             if (KSPLIT > 1) {
                 if (ks > 0) *reinterpret_cast<f32x4*>(red + (((ks - 1) * CBW + cb) * 64 + lane) * 4) = acc;
                 __syncthreads();
@@ -721,16 +771,24 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
             }
             if (ks == 0) {
                 // D layout of 16x16: col = lane&15, row = 4*(lane>>4) + r.  sc1 (write-through) stores.
+                // All four values are finished BEFORE the first store is issued: gfx950's vmcnt also counts stores, so a
+                // store between two uses of the prefetched `ihv` makes the compiler wait for its write-through ack.
+                float hv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[r] = tip_tanh(acc[r] + ihv[r]);
+                // pin the four values here (the optimiser otherwise sinks each tanh back into its store's branch)
+                asm volatile("" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int bb = b0 + lg * 4 + r;
                     if (bb < B) {
-                        const float hv = tanhf(acc[r] + ihv[r]);
-                        __hip_atomic_store(hall + ((size_t)bb * T + t) * R + nb * 16 + l15, hv, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
+                        float* dst = hall + ((size_t)bb * T + t) * R + nb * 16 + l15;
+                        if (same_xcd) *dst = hv[r];   // lands in the shared L2 (L1 is write-through)
+                        else __hip_atomic_store(dst, hv[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1
                     }
                 }
             }
+            if (TRACE && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 2] = __builtin_amdgcn_s_memtime();
             if (HANDOFF == 0) {
                 // publish: every storing wave drains its stores, workgroup barrier, one arrival
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -744,7 +802,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
     }
 }
 
-size_t rnn_flag_words(int B, int T) { return (size_t)((B + kRnnTile - 1) / kRnnTile) * (size_t)T; }
+size_t rnn_flag_words(int B, int T) { return (size_t)((B + kRnnTile - 1) / kRnnTile) * (size_t)T + 1024; }
 
 static int rnn_handoff_mode() {
     static int handoff = -1;
@@ -780,8 +838,16 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
             hipError_t e = hipMemsetAsync(hall, 0xFF, (size_t)hb, s);   // every word = kRnnSentinel
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
-                           whh_frag, hall, flags, B, T, ntiles, (int)hb);
+        hipError_t e2 = hipMemsetAsync(flags, 0, (size_t)groups * CLUSTER * sizeof(unsigned), s);   // XCC-id exchange words
+        if (e2 != hipSuccess) return e2;
+        static int trace = -1;
+        if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
+        if (trace)
+            hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1, true>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s,
+                               ih, whh_frag, hall, flags, B, T, ntiles, (int)hb);
+        else
+            hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
+                               whh_frag, hall, flags, B, T, ntiles, (int)hb);
     }
     return hipGetLastError();
 }
@@ -825,3 +891,8 @@ hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, flo
 }
 
 }  // namespace tip
+
+extern "C" int tip_debug_read_rnn_trace(unsigned long long* out, int n) {
+    if (!out || n < 0 || n > 64 * 4) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tip::g_rnn_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
+}

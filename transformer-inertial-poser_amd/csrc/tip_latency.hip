@@ -491,7 +491,7 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
             __syncthreads();   // hs is rewritten next step
         }
         if (lg == 0) {
-            const float hv = tanhf(acc + ihv);
+            const float hv = tip_tanh(acc + ihv);
             hw[(size_t)t * R + row] = hv;
             const u64 gran = ((u64)(unsigned)(t + 1) << 32) | (u64)__float_as_uint(hv);
             __hip_atomic_store(hbw + (size_t)(t & 1) * R + row, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
