@@ -144,7 +144,8 @@ __device__ __forceinline__ f32x4 reduce_partials(float* red, const f32x4 (&acc)[
 __global__ __launch_bounds__(256) void lat_in_kernel(const float* __restrict__ wts, int wbytes, const float* __restrict__ x_imu,
                                                      const float* __restrict__ x_s, const float* __restrict__ keep_mask,
                                                      float keep_scale, float* __restrict__ xpre, int T, int NI, int S,
-                                                     int in_w_off_b, int in_b_off, unsigned long long* __restrict__ gran) {
+                                                     int in_w_off_b, int in_b_off, unsigned long long* __restrict__ gran,
+                                                     unsigned* __restrict__ xcc_words) {
     using namespace lz;
     __shared__ __attribute__((aligned(16))) float U[RP * LDU];
     __shared__ __attribute__((aligned(16))) float red[4 * 3 * 256];
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void lat_in_kernel(const float* __restrict__ w
     if (nb == 0) {
         unsigned long long* gq = gran + (size_t)win * 2 * R;
         for (int i = tid; i < 2 * R; i += 256) gq[i] = 0ull;
+        if (tid < 4) xcc_words[win * 4 + tid] = 0u;
     }
     // window inputs -> U[row][0:NI | NI:NI+S | zero pad]; wave w stages rows w, w+4, ...; lanes walk the columns.
     // All global loads of a wave are requested before its first LDS store.
@@ -443,14 +445,40 @@ hipError_t launch_latency_head(const float* A, long long lda, const float* wfrag
 //   granules: hb[win][parity][512] of {tag = step + 1, value}; zeroed before every launch.
 typedef unsigned long long u64;
 __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__ ih, const float* __restrict__ whh_frag,
-                                                       float* __restrict__ hall, u64* __restrict__ hb, int T) {
+                                                       float* __restrict__ hall, u64* __restrict__ hb,
+                                                       unsigned* __restrict__ xcc_words, int B, int T) {
     using namespace lz;
     __shared__ __attribute__((aligned(16))) float hs[4 * 132];   // 4 K-quarters of 128, padded: distinct banks per quarter
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
-    const int wg = blockIdx.x & 3, win = blockIdx.x >> 2;
+    // the 4 members of a stream's cluster are taken 8 blocks apart: observed to share an XCD (verified below)
+    const int wg = (blockIdx.x >> 3) & 3, win = (blockIdx.x & 7) + 8 * (blockIdx.x >> 5);
+    if (win >= B) return;
     const int row = wg * 128 + wave * 16 + l15;
+    // run-time check that all 4 members really sit on one XCD: only then may granules be published with plain 8-byte
+    // stores (they stay in the shared L2, where the peers' L1-bypassing loads see them after ~0.4 us); otherwise the
+    // write-through agent-scope stores that are correct for any placement are used.
+    __shared__ int s_same_xcd;
+    if (tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xf;
+        __hip_atomic_store(xcc_words + win * 4 + wg, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool same = true;
+        for (int m = 0; m < 4; ++m) {
+            unsigned v = 0;
+            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                v = __hip_atomic_load(xcc_words + win * 4 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            same &= (v == xcc + 1u);
+        }
+        s_same_xcd = same ? 1 : 0;
+    }
+    __syncthreads();
+    const bool same_xcd = s_same_xcd != 0;
     float4 w[32];
     {
         const float4* wf = reinterpret_cast<const float4*>(whh_frag);
@@ -494,7 +522,9 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
             const float hv = tip_tanh(acc + ihv);
             hw[(size_t)t * R + row] = hv;
             const u64 gran = ((u64)(unsigned)(t + 1) << 32) | (u64)__float_as_uint(hv);
-            __hip_atomic_store(hbw + (size_t)(t & 1) * R + row, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u64* gdst = hbw + (size_t)(t & 1) * R + row;
+            if (same_xcd) *gdst = gran;   // one aligned 8-byte store: single-copy atomic, lands in the shared L2
+            else __hip_atomic_store(gdst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -510,7 +540,7 @@ bool latency_supported(const Dims& d, int B, int T) {
 //                     stats [2][B][48][2]; granules [B][2][512] u64
 size_t latency_workspace_floats(int B, int T) {
     const size_t bt = (size_t)B * T;
-    return bt * (256 + 256 + 768 + 256 + 1024 + 512) + (size_t)2 * B * 48 * 2 + (size_t)B * 2 * 512 * 2 + 1024;
+    return bt * (256 + 256 + 768 + 256 + 1024 + 512) + (size_t)2 * B * 48 * 2 + (size_t)B * 2 * 512 * 2 + (size_t)B * 4 + 1024;
 }
 
 hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float* whh_frag, const float* x_imu,
@@ -526,6 +556,7 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
     float* st0 = ihb + bt * 512;
     float* st1 = st0 + (size_t)B * 48 * 2;
     u64* gran = reinterpret_cast<u64*>(st1 + (size_t)B * 48 * 2);   // every term above is an even float count: 8-B aligned
+    unsigned* xccw = reinterpret_cast<unsigned*>(gran + (size_t)B * 2 * R);   // 4 words per stream
     const int wbytes = (int)(fused_packed_floats(d) * 4);
     // offsets inside the fused section (tip_fused.hip)
     constexpr size_t IN_W = 0, IN_B = (size_t)D * KIN, LAYER0 = IN_B + D;
@@ -533,7 +564,7 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
     constexpr size_t W1_W = WO_B + D, W1_B = W1_W + (size_t)F * D, W2_W = W1_B + F, W2_B = W2_W + (size_t)D * F;
     constexpr size_t G1 = W2_B + D, BE1 = G1 + D, G2 = BE1 + D, BE2 = G2 + D, LAYER_FLOATS = BE2 + D;
     hipLaunchKernelGGL(lat_in_kernel, dim3(16, B), dim3(256), 0, s, fused_w, wbytes, x_imu, x_s, keep_mask, keep_scale, xa, T,
-                       d.n_imu_total, d.S, (int)(IN_W * 4), (int)IN_B, gran);
+                       d.n_imu_total, d.S, (int)(IN_W * 4), (int)IN_B, gran, xccw);
     const float* pg = nullptr;   // LayerNorm pending on the residual stream (norm2 of the previous layer)
     const float* pb = nullptr;
     for (int l = 0; l < d.L; ++l) {
@@ -555,7 +586,7 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
     const size_t ih_off = LAYER0 + (size_t)d.L * LAYER_FLOATS;
     hipLaunchKernelGGL((lat_ln_gemm_kernel<false, false>), dim3(32, B), dim3(256), 0, s, fused_w, wbytes, xa, pg, pb, (int)(ih_off * 4),
                        (int)(ih_off + (size_t)R * D), ihb, R, (float*)nullptr, T);
-    hipLaunchKernelGGL(rnn_gemv_kernel, dim3(4 * B), dim3(512), 0, s, ihb, whh_frag, hall, gran, T);
+    hipLaunchKernelGGL(rnn_gemv_kernel, dim3(32 * ((B + 7) / 8)), dim3(512), 0, s, ihb, whh_frag, hall, gran, xccw, B, T);
     return hipGetLastError();
 }
 
