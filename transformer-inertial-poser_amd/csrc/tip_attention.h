@@ -62,11 +62,11 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
             float sm = 0.f;
 #pragma unroll
             for (int cb = 0; cb < r; ++cb) {
-                const float p = expf(S[r][cb][e] - mx[r][e]);
+                const float p = __expf(S[r][cb][e] - mx[r][e]);
                 S[r][cb][e] = p;
                 sm += p;
             }
-            const float pd = vis ? expf(S[r][r][e] - mx[r][e]) : 0.f;
+            const float pd = vis ? __expf(S[r][r][e] - mx[r][e]) : 0.f;
             S[r][r][e] = pd;
             rsum[r][e] = sm + pd;
         }

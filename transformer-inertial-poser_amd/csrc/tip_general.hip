@@ -727,7 +727,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                         }
                     }
                     if (!any) break;
-                    __builtin_amdgcn_s_sleep(2);
+                    if (!same_xcd) __builtin_amdgcn_s_sleep(2);   // cross-XCD polls travel the fabric: pace them
                 }
 #pragma unroll
                 for (int j = 0; j < NLD; ++j) {
