@@ -106,6 +106,10 @@ int tip_forward_count(const tip_handle* h, uint64_t* n);
  * ms[i] = summed duration of stage names[i], launches[i] = event pairs summed.  Arrays of length `cap`;
  * returns the number of stages (<= cap) or a negative status. */
 int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches, int cap);
+/* (synchronises the device) number of inter-workgroup hand-off waits that gave up since the library was loaded.
+ * The cooperating kernels (RNN clusters) never spin forever; if a peer does not arrive within ~1 s they continue
+ * and bump this counter: non-zero => the outputs of that launch are invalid.  Must be 0 in a healthy process. */
+int tip_spin_timeouts(unsigned* count);
 
 /* ---- streaming front/back-end: the model-facing half of RTRunnerMin.step
  *      (real_time_runner_minimal.py:59-85 record_raw_imu / record_state_aa_and_c, :87-112 smooth_and_split_s_c,

@@ -41,3 +41,12 @@ def cfg_for_tag(tag):
 
 def seed_for_tag(tag):
     return int(tag.split("_s")[1].split("_")[0])
+
+
+@pytest.fixture(autouse=True)
+def _no_handoff_timeouts(request):
+    """After every GPU test: no inter-workgroup hand-off may have timed out (tip_spin_timeouts == 0)."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        from tip_amd import lib as tlib
+        assert tlib.spin_timeouts() == 0, "a cluster hand-off gave up: outputs of some launch were invalid"

@@ -422,6 +422,14 @@ int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches
     return n;
 }
 
+int tip_spin_timeouts(unsigned* count) {
+    if (!count) return TIP_ERR_INVALID_ARG;
+    unsigned a = 0, b = 0;
+    if (read_spin_timeouts_general(&a) != hipSuccess || read_spin_timeouts_latency(&b) != hipSuccess) return TIP_ERR_HIP;
+    *count = a + b;
+    return TIP_OK;
+}
+
 int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
                 const float* keep_mask, float keep_scale, void* workspace, size_t workspace_bytes,
                 tip_stream_t stream) {

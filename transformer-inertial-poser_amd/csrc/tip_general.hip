@@ -22,6 +22,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// every bounded hand-off spin that gives up bumps this counter (read with tip_spin_timeouts()): a non-zero value
+// means a cluster member never arrived and the outputs of that launch are invalid.
+__device__ unsigned g_spin_timeouts_general;
+__device__ __forceinline__ void note_spin_timeout() { atomicAdd(&g_spin_timeouts_general, 1u); }
+
 // ------------------------------------------------------------------------------------------------
 // prologue: U[row][0:InPad] = [x_imu | scrub(x_s) * mask * scale | 0-pad]
 // ------------------------------------------------------------------------------------------------
@@ -481,10 +486,12 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
                 // wait for every member's slice of h_{t-1}, then pull the full [16][R] tile from HALL
                 if (tid == 0) {
                     unsigned* f = flags + (size_t)tile * T + (t - 1);
-                    for (unsigned spins = 0; spins < (1u << 22); ++spins) {  // bounded: never hang the GPU
+                    unsigned spins = 0;
+                    for (; spins < (1u << 22); ++spins) {  // bounded: never hang the GPU
                         if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)cluster) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
+                    if (spins == (1u << 22)) note_spin_timeout();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
                 __syncthreads();
@@ -650,6 +657,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                     if (v) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
+                if (!v) note_spin_timeout();
                 same &= (v == xcc + 1u);
             }
             s_same_xcd = same ? 1 : 0;
@@ -690,10 +698,12 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                         // bounded spin: a cluster member that never arrives must not hang the GPU (result is then
                         // wrong, which the parity tests catch)
                         const unsigned* f = flags + (size_t)tile * T + (t - 1);
-                        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                        unsigned spins = 0;
+                        for (; spins < (1u << 22); ++spins) {
                             if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)CLUSTER) break;
                             __builtin_amdgcn_s_sleep(1);
                         }
+                        if (spins == (1u << 22)) note_spin_timeout();
                     }
                     __syncthreads();
                 }
@@ -706,6 +716,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                     need[j] = b0 + i / (R / 4) < B;
                     v[j] = (u32x4){0u, 0u, 0u, 0u};
                 }
+                bool gave_up = true;
                 for (unsigned spins = 0; spins < (1u << 20); ++spins) {
                     bool any = false;
 #pragma unroll
@@ -716,7 +727,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                             v[j] = __builtin_amdgcn_raw_buffer_load_b128(hrs, (int)((((size_t)(b0 + m) * T + (t - 1)) * R + c) * 4), 0, 16);
                         }
                     }
-                    if (HANDOFF == 0) break;
+                    if (HANDOFF == 0) { gave_up = false; break; }
 #pragma unroll
                     for (int j = 0; j < NLD; ++j) {
                         if (need[j]) {
@@ -726,9 +737,10 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                             any |= pend;
                         }
                     }
-                    if (!any) break;
+                    if (!any) { gave_up = false; break; }
                     if (!same_xcd) __builtin_amdgcn_s_sleep(2);   // cross-XCD polls travel the fabric: pace them
                 }
+                if (gave_up) note_spin_timeout();
 #pragma unroll
                 for (int j = 0; j < NLD; ++j) {
                     const int i = tid + j * THREADS;
@@ -890,6 +902,12 @@ hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, flo
     return hipGetLastError();
 }
 
+}  // namespace tip
+
+namespace tip {
+hipError_t read_spin_timeouts_general(unsigned* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spin_timeouts_general), sizeof(unsigned));
+}
 }  // namespace tip
 
 extern "C" int tip_debug_read_rnn_trace(unsigned long long* out, int n) {

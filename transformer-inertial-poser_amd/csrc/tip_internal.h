@@ -136,4 +136,7 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
 hipError_t launch_latency_head(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy,
                                int M, int N, hipStream_t s);
 
+hipError_t read_spin_timeouts_general(unsigned* out);
+hipError_t read_spin_timeouts_latency(unsigned* out);
+
 }  // namespace tip

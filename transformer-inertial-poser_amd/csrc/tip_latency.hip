@@ -444,6 +444,7 @@ hipError_t launch_latency_head(const float* A, long long lda, const float* wfrag
 //   W[nb*16 + l15][kb*16 + 4 lg' .. +3].
 //   granules: hb[win][parity][512] of {tag = step + 1, value}; zeroed before every launch.
 typedef unsigned long long u64;
+__device__ unsigned g_spin_timeouts_latency;   // see tip_spin_timeouts()
 __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__ ih, const float* __restrict__ whh_frag,
                                                        float* __restrict__ hall, u64* __restrict__ hb,
                                                        unsigned* __restrict__ xcc_words, int B, int T) {
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
                 if (v) break;
                 __builtin_amdgcn_s_sleep(1);
             }
+            if (!v) atomicAdd(&g_spin_timeouts_latency, 1u);
             same &= (v == xcc + 1u);
         }
         s_same_xcd = same ? 1 : 0;
@@ -503,6 +505,7 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
                 v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(v >> 32) == (unsigned)t) break;
             }
+            if ((unsigned)(v >> 32) != (unsigned)t) atomicAdd(&g_spin_timeouts_latency, 1u);
             hs[(tid >> 7) * 132 + (tid & 127)] = __uint_as_float((unsigned)v);
             __syncthreads();
             const float* hq = hs + lg * 132;
@@ -532,6 +535,10 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------
+hipError_t read_spin_timeouts_latency(unsigned* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spin_timeouts_latency), sizeof(unsigned));
+}
+
 bool latency_supported(const Dims& d, int B, int T) {
     return fused_supported(d, T) && fused_has_rnn_ih(d) && B >= 1 && B <= 64;
 }

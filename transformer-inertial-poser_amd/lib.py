@@ -21,7 +21,7 @@ EXPORTS = (
     "tip_abi_version", "tip_create", "tip_destroy", "tip_strerror", "tip_last_hip_error", "tip_set_option",
     "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
     "tip_attach_packed", "tip_workspace_bytes", "tip_forward", "tip_forward_count", "tip_profile_read",
-    "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
+    "tip_spin_timeouts", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
 )
 
 
@@ -91,6 +91,7 @@ def load() -> ctypes.CDLL:
     lib.tip_forward_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.tip_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
                                      ctypes.POINTER(i32), i32]
+    lib.tip_spin_timeouts.argtypes = [ctypes.POINTER(ctypes.c_uint)]
     lib.tip_stream_state_bytes.argtypes = [i32, ctypes.POINTER(sz)]
     lib.tip_stream_reset.argtypes = [vp, vp, i32, vp]
     lib.tip_stream_window_len.argtypes = [i32]
@@ -185,3 +186,12 @@ class Handle:
         launches = (ctypes.c_int * cap)()
         n = self._check(self.lib.tip_profile_read(self._h, names, ms, launches, cap))
         return [(names[i].decode(), float(ms[i]), int(launches[i])) for i in range(n)]
+
+
+def spin_timeouts() -> int:
+    """Hand-off waits that gave up since the library was loaded (synchronises the device); must be 0."""
+    n = ctypes.c_uint()
+    st = load().tip_spin_timeouts(ctypes.byref(n))
+    if st < 0:
+        raise TipStatusError(st, load().tip_strerror(st).decode())
+    return int(n.value)
