@@ -60,6 +60,8 @@ typedef enum tip_status {
 #define TIP_PLAN_AUTO    0
 #define TIP_PLAN_GENERAL 1 /* layer-by-layer MFMA GEMM kernels, any configuration */
 #define TIP_PLAN_FUSED   2 /* one workgroup = one window through all encoder layers (paper configuration) */
+#define TIP_PLAN_FUSED2  4 /* two windows per workgroup (80 rows = 5 MFMA row blocks, no padding); AUTO picks it for
+                              B >= 2 x CUs; bit-identical results to TIP_PLAN_FUSED */
 #define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);
                               AUTO picks it for B <= 32 */
 

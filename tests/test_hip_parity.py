@@ -101,6 +101,50 @@ def test_vs_oracle_shapes(B, T, plan):
     assert np.abs(y - yo).max() < TOL_TIGHT, np.abs(y - yo).max()
 
 
+@pytest.mark.parametrize("B", [1, 2, 5, 64, 257])
+def test_two_window_plan_bit_identical_to_one_window(B):
+    """"fused2" carries two windows per workgroup (80 rows = 5 MFMA row blocks, no padding).  Same packed image, same
+    per-element summation order, so it must reproduce the one-window plan bit for bit, for odd and even B."""
+    cfg = synth.PAPER
+    m, w = _gpu_model(cfg, 2)
+    x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=300 + B, nan_frac=0.01)
+    m.set_plan("fused")
+    y1 = _run(m, x_imu, x_s)
+    m.set_plan("fused2")
+    y2 = _run(m, x_imu, x_s)
+    assert np.array_equal(y1, y2), np.abs(y1 - y2).max()
+    yo = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float32)
+    assert np.abs(y2 - yo).max() < TOL_TIGHT
+    if B <= 5:   # T != 40 is outside the two-window plan: explicit request is an error, not a silent fallback
+        with pytest.raises(RuntimeError):
+            with torch.no_grad():
+                m(torch.tensor(x_imu[:, :17]).cuda(), torch.tensor(x_s[:, :17]).cuda())
+
+
+def test_two_window_plan_golden_and_auto_selection(golden):
+    cfg = synth.PAPER
+    models = {}
+    for tag, case in golden.items():
+        if not tag.startswith("paper") or "mask" in tag or case["x_imu"].shape[1] != 40:
+            continue
+        key = tag.split("_B")[0]
+        if key not in models:
+            models[key] = _gpu_model(cfg, seed_for_tag(tag))[0]
+            models[key].set_plan("fused2")
+        y = _run(models[key], case["x_imu"], case["x_s"])
+        assert np.abs(y - case["y64"]).max() < TOL_TIGHT, tag
+    # auto picks it once every CU has two windows; result identical to the explicit plans
+    m, _ = _gpu_model(cfg, 0)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    B = 2 * ncu + 3
+    x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=77)
+    m.set_plan("auto")
+    ya = _run(m, x_imu, x_s)
+    m.set_plan("fused")
+    yf = _run(m, x_imu, x_s)
+    assert np.array_equal(ya, yf)
+
+
 def test_last_row_only_equals_full():
     cfg = synth.PAPER
     m, _ = _gpu_model(cfg, 0)

@@ -260,7 +260,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
     if (!h) return TIP_ERR_INVALID_ARG;
     switch (option) {
         case TIP_OPT_PLAN:
-            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_LATENCY) return TIP_ERR_INVALID_ARG;
+            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED2) return TIP_ERR_INVALID_ARG;
             h->plan = value;
             return TIP_OK;
         case TIP_OPT_PROFILE:
@@ -468,7 +468,10 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         if (latency_supported(d, B, T) && B <= 32) plan = TIP_PLAN_LATENCY;   // few streams: spread each window over many CUs
         else plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
     }
+    if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO && fused2_supported(d, T) && B >= 2 * h->num_cus)
+        plan = TIP_PLAN_FUSED2;   // two windows per workgroup once every CU has at least two to chew on
     if (plan == TIP_PLAN_FUSED && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
 
     float* enc_out = xa;  // encoder output [M, D]
@@ -487,6 +490,12 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         TIP_TRY(launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall,
                                     B, T, s), "latency_chain");
         rnn_done = true;
+    } else if (plan == TIP_PLAN_FUSED2) {
+        StageScope sc(h, s, "fused_encoder");
+        ih_done = true;
+        hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
+        TIP_TRY(launch_fused_encoder2(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr, B,
+                                      h->num_cus, s), "fused_encoder2");
     } else if (plan == TIP_PLAN_FUSED) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = fused_has_rnn_ih(d);

@@ -11,9 +11,10 @@ typedef float f32x4_att __attribute__((ext_vector_type(4)));
 //               (lane: key = l15, queries 4*lg + e), so a row max / sum is an xor-shuffle over 16 lanes
 //   P V         per query block r: the un-normalised P_r is written TRANSPOSED into the head's (now dead) K slot,
 //               read back as A fragments, multiplied with V^T fragments (b128), divided by the row sums at the end.
-// Q/K planes hold the head at column c0; output overwrites the head's Q columns (out-projection A operand).
+// Q/K planes hold the head at column c0; output overwrites the head's Q columns (out-projection A operand); rows at or
+// beyond row_limit are not written (the two-window kernel packs another window's rows right behind).
 template <int LDC, int LDV>
-__device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const float* Vt, int c0, int lane) {
+__device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const float* Vt, int c0, int lane, int row_limit = 48) {
     constexpr int RB = 3;   // 48 padded rows
     const int l15 = lane & 15, lg = lane >> 4;
     float4 qf[RB], kf[RB];
@@ -101,7 +102,8 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
             o = __builtin_amdgcn_mfma_f32_16x16x4f32(p3, vb.w, o, 0, 0, 0);
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Qc[(r * 16 + lg * 4 + e) * LDC + c0 + l15] = o[e] * rsum[r][e];
+        for (int e = 0; e < 4; ++e)
+            if (r * 16 + lg * 4 + e < row_limit) Qc[(r * 16 + lg * 4 + e) * LDC + c0 + l15] = o[e] * rsum[r][e];
     }
 }
 

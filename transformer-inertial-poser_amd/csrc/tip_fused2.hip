@@ -1,0 +1,439 @@
+// tip_fused2.hip — two-window variant of the fused plan (paper configuration), used when there are at least two
+// windows per CU (B >= 512 on a 256-CU part).
+//
+// The one-window kernel (tip_fused.hip) pads T = 40 rows to 48 (3 MFMA row blocks): 17 % of its matrix-core issue
+// slots multiply zero rows.  Two windows are 80 rows = exactly 5 row blocks, so here ONE 512-thread workgroup carries
+// TWO windows through the encoder with no padding at all, and every weight fragment streamed from L2 is used for
+// 5 row blocks instead of 3.  Same packed weight image, same math, same summation order per output element.
+//
+// LDS (161,024 B): X [80][260] residual stream of both windows | C: per 4-head "quad" Q [96][68], K [96][68],
+// V^T [64][100] (window 1 starts at plane row 48 so each window has its own 8 pad rows for the 3x16-row attention
+// blocks), reused as U [80][228] (prologue) and Hc [80][132] (FFN hidden chunk of 128).
+// Per layer: 4 quads x { Q|K projection (one 16-column block per wave), V projection (head = wave&3, waves 0-3 take
+// row blocks 0-2, waves 4-7 row blocks 3-4), attention (wave = head x window), out-projection partial } ->
+// LayerNorm1 -> 8 x { linear1 chunk + ReLU, linear2 partial } -> LayerNorm2.
+#include <string.h>
+
+#include "tip_internal.h"
+#include "tip_attention.h"
+
+namespace tip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace f2 {
+constexpr int D = 256, F = 1024, R = 512, T = 40, ROWS = 80, RB = 5, KIN = 224;
+constexpr int LDX = D + 4;           // 260
+constexpr int LDQ = 64 + 4;          // 68: Q / K plane of one quad (4 heads x 16 channels)
+constexpr int PROWS = 96;            // plane rows: window w occupies rows 48w .. 48w+39 (+8 pad)
+constexpr int LDV = PROWS + 4;       // 100: V^T [64 channels][96 keys]
+constexpr int LDU = KIN + 4;         // 228
+constexpr int LDH = 128 + 4;         // 132: FFN hidden chunk
+constexpr int X_FLOATS = ROWS * LDX;                       // 20800
+constexpr int C_FLOATS = 2 * PROWS * LDQ + 64 * LDV;       // 19456
+constexpr int LDS_BYTES = (X_FLOATS + C_FLOATS) * 4;       // 161024
+constexpr int THREADS = 512;
+// packed fused section (identical to tip_fused.hip)
+constexpr size_t IN_W = 0, IN_B = IN_W + (size_t)D * KIN, LAYER0 = IN_B + D;
+constexpr size_t QKV_W = 0, QKV_B = QKV_W + (size_t)3 * D * D, WO_W = QKV_B + 3 * D, WO_B = WO_W + (size_t)D * D;
+constexpr size_t W1_W = WO_B + D, W1_B = W1_W + (size_t)F * D, W2_W = W1_B + F, W2_B = W2_W + (size_t)D * F;
+constexpr size_t G1 = W2_B + D, BE1 = G1 + D, G2 = BE1 + D, BE2 = G2 + D, LAYER_FLOATS = BE2 + D;
+static_assert(C_FLOATS >= ROWS * LDU && C_FLOATS >= ROWS * LDH, "chunk region must hold U and Hc");
+}  // namespace f2
+
+__device__ __forceinline__ float4 ldfrag2(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+    return make_float4(f.x, f.y, f.z, f.w);
+}
+
+template <int NBW>
+struct WRing2 {
+    float4 w0[NBW], w1[NBW];
+};
+
+template <int NBW>
+__device__ __forceinline__ void ring2_prefetch(WRing2<NBW>& g, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b) {
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+        g.w0[n] = ldfrag2(rsrc, voff, soff + n * nstride_b);
+        g.w1[n] = ldfrag2(rsrc, voff, soff + n * nstride_b + 1024);
+    }
+}
+
+template <int NRB, int NBW>
+__device__ __forceinline__ void mfma_block2(f32x4 (&acc)[NRB][NBW], const float4 (&a)[NRB], const float4 (&w)[NBW]) {
+#pragma unroll
+    for (int r = 0; r < NRB; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].x, w[n].x, acc[r][n], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < NRB; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].y, w[n].y, acc[r][n], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < NRB; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].z, w[n].z, acc[r][n], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < NRB; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].w, w[n].w, acc[r][n], 0, 0, 0);
+}
+
+// acc[r][n] += A(rows of block r) * Wblock(n, kb), kb in [0, KB).  lds + aoff[r]: this lane's LDS address of
+// (its row of row-block r, k-offset 4*(lane>>4)) — row blocks need not be equally spaced (remapped planes).
+// Ring semantics as in tip_fused.hip: k-blocks 0,1 on entry; the last pair of prefetches is redirected to the next
+// phase (nsoff, nnstride_b).
+template <int NRB, int NBW, int KB>
+__device__ __forceinline__ void gemm_phase2(f32x4 (&acc)[NRB][NBW], const float* lds, const int (&aoff)[NRB],
+                                            __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b, WRing2<NBW>& g,
+                                            int nsoff, int nnstride_b) {
+    static_assert(KB % 2 == 0, "k-blocks are processed in pairs");
+    float4 a0[NRB], a1[NRB];
+#pragma unroll
+    for (int r = 0; r < NRB; ++r) a0[r] = *reinterpret_cast<const float4*>(lds + aoff[r]);
+#pragma unroll 1
+    for (int kb = 0; kb < KB; kb += 2) {
+        const bool last = kb + 2 >= KB;
+        const int o = last ? nsoff : soff + (kb + 2) * 1024;
+        const int st = last ? nnstride_b : nstride_b;
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) a1[r] = *reinterpret_cast<const float4*>(lds + aoff[r] + (kb + 1) * 16);
+        mfma_block2<NRB, NBW>(acc, a0, g.w0);
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) g.w0[n] = ldfrag2(rsrc, voff, o + n * st);
+#pragma unroll
+        for (int r = 0; r < NRB; ++r) a0[r] = *reinterpret_cast<const float4*>(lds + aoff[r] + (kb + 2) * 16);
+        mfma_block2<NRB, NBW>(acc, a1, g.w1);
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) g.w1[n] = ldfrag2(rsrc, voff, o + n * st + 1024);
+    }
+}
+
+template <int NRB, int NBW>
+__device__ __forceinline__ void zero_acc2(f32x4 (&acc)[NRB][NBW]) {
+#pragma unroll
+    for (int r = 0; r < NRB; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+// LayerNorm over the 80 rows of X: wave w owns rows w, w+8, ... (10 rows), reductions interleaved.
+__device__ __forceinline__ void layernorm_rows2(float* X, const float* __restrict__ g, const float* __restrict__ be, int wave,
+                                                int lane) {
+    constexpr int NR = f2::ROWS / 8;
+    const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
+    const float4 bb = *reinterpret_cast<const float4*>(be + lane * 4);
+    float4 v[NR];
+    float mean[NR], var[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        v[i] = *reinterpret_cast<const float4*>(X + (wave + 8 * i) * f2::LDX + lane * 4);
+        mean[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) mean[i] += __shfl_xor(mean[i], off, 64);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        mean[i] *= (1.f / f2::D);
+        v[i].x -= mean[i]; v[i].y -= mean[i]; v[i].z -= mean[i]; v[i].w -= mean[i];
+        var[i] = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) var[i] += __shfl_xor(var[i], off, 64);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const float rstd = 1.0f / sqrtf(var[i] * (1.f / f2::D) + 1e-5f);
+        float4 o;
+        o.x = v[i].x * rstd * gg.x + bb.x;
+        o.y = v[i].y * rstd * gg.y + bb.y;
+        o.z = v[i].z * rstd * gg.z + bb.z;
+        o.w = v[i].w * rstd * gg.w + bb.w;
+        *reinterpret_cast<float4*>(X + (wave + 8 * i) * f2::LDX + lane * 4) = o;
+    }
+}
+
+// plane row of X row r: window 1 (rows 40..79) starts at plane row 48
+__device__ __forceinline__ int prow(int r) { return r + (r >= f2::T ? 8 : 0); }
+
+__global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
+    const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
+    const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ ih_out, unsigned* __restrict__ hall_sentinel,
+    int B, int NI, int S, int L, int wbytes, int ih_off_b) {
+    using namespace f2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;
+    float* C = smem + X_FLOATS;
+    float* Qp = C;
+    float* Kp = C + PROWS * LDQ;
+    float* Vt = C + 2 * PROWS * LDQ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, wbytes, 0x00020000);
+    const int voff = lane * 16;
+    const int npairs = (B + 1) / 2;
+
+    // this lane's A-fragment offsets (floats from smem) for an operand with leading dimension ld at region offset base
+    auto rows_off = [&](int (&off)[RB], int base, int ld) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) off[r] = base + (r * 16 + l15) * ld + lg * 4;
+    };
+    for (int i = tid; i < C_FLOATS; i += THREADS) C[i] = 0.f;   // pad rows of the planes must never hold NaN patterns
+    __syncthreads();
+
+    for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+        const int win0 = pair * 2;
+        const int nwin = (win0 + 1 < B) ? 2 : 1;
+        const int in_soff = (int)(IN_W * 4) + (wave * 2) * (KIN / 16) * 1024;
+        WRing2<2> g_in;
+        ring2_prefetch<2>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
+        // ---- prologue (:63-78) for both windows: U rows 40w + t ------------------------------------------------------
+        float* U = C;
+        for (int i = tid; i < ROWS * LDU; i += THREADS) U[i] = 0.f;
+        __syncthreads();
+        for (int w = 0; w < nwin; ++w) {
+            const float* xi = x_imu + (size_t)(win0 + w) * T * NI;
+            for (int i = tid; i < T * NI; i += THREADS) {
+                const int r = i / NI, c = i - r * NI;
+                U[(w * T + r) * LDU + c] = xi[i];
+            }
+            const float* xs = x_s + (size_t)(win0 + w) * T * S;
+            const float* km = keep_mask ? keep_mask + (size_t)(win0 + w) * T * S : nullptr;
+            for (int i = tid; i < T * S; i += THREADS) {
+                const int r = i / S, c = i - r * S;
+                float v = xs[i];
+                if (v != v) v = 0.f;                  // :65
+                if (km) v = v * km[i] * keep_scale;   // :77
+                U[(w * T + r) * LDU + NI + c] = v;
+            }
+        }
+        __syncthreads();
+        // ---- in_linear (:79) + channel shuffle (folded) -----------------------------------------------------------------
+        WRing2<1> g_q;   // Q|K projection ring of the next quad
+        {
+            f32x4 acc[RB][2];
+            zero_acc2<RB, 2>(acc);
+            int au[RB];
+            rows_off(au, X_FLOATS, LDU);
+            gemm_phase2<RB, 2, KIN / 16>(acc, smem, au, rsrc, voff, in_soff, (KIN / 16) * 1024, g_in, in_soff, (KIN / 16) * 1024);
+            // layer 0, quad 0: wave w < 4 -> Q block of head w, w >= 4 -> K block of head w-4
+            ring2_prefetch<1>(g_q, rsrc, voff,
+                              (int)(LAYER0 * 4) + (int)(QKV_W * 4) + ((wave >> 2) * 16 + (wave & 3)) * 16 * 1024, 0);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = (wave * 2 + n) * 16 + l15;
+                const float bv = wts[IN_B + col];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] = acc[r][n][e] + bv;
+            }
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int layer = 0; layer < L; ++layer) {
+            const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
+            const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
+            f32x4 acc_o[RB][2];
+            zero_acc2<RB, 2>(acc_o);
+            WRing2<2> g_o, g_f2r;
+            WRing2<1> g_v, g_f1;
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                const int hl = wave & 3;              // head inside the quad
+                const int head = q * 4 + hl;
+                // ---- Q | K projection: one 16-column block per wave, all 5 row blocks -------------------------------
+                {
+                    const int isk = wave >> 2;        // 0: Q, 1: K
+                    f32x4 acc[RB][1];
+                    zero_acc2<RB, 1>(acc);
+                    const int soff = lbase + (int)(QKV_W * 4) + (isk * 16 + head) * 16 * 1024;
+                    int ax[RB];
+                    rows_off(ax, 0, LDX);
+                    gemm_phase2<RB, 1, 16>(acc, smem, ax, rsrc, voff, soff, 0, g_q, soff, 0);
+                    // V fragments of this quad fly during the epilogue
+                    const int vsoff = lbase + (int)(QKV_W * 4) + (32 + head) * 16 * 1024;
+                    ring2_prefetch<1>(g_v, rsrc, voff, vsoff, 0);
+                    const float bv = LW[QKV_B + isk * D + head * 16 + l15];
+                    float* plane = isk ? Kp : Qp;
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            plane[prow(r * 16 + lg * 4 + e) * LDQ + hl * 16 + l15] = acc[r][0][e] + bv;
+                    // ---- V projection: head hl; waves 0-3 rows 0-47, waves 4-7 rows 48-79 ------------------------------
+                    const float bvv = LW[QKV_B + 2 * D + head * 16 + l15];
+                    if (wave < 4) {
+                        f32x4 av[3][1];
+                        zero_acc2<3, 1>(av);
+                        const int ar[3] = {ax[0], ax[1], ax[2]};
+                        gemm_phase2<3, 1, 16>(av, smem, ar, rsrc, voff, vsoff, 0, g_v, vsoff, 0);
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                Vt[(hl * 16 + l15) * LDV + prow(r * 16 + lg * 4 + e)] = av[r][0][e] + bvv;
+                    } else {
+                        f32x4 av[2][1];
+                        zero_acc2<2, 1>(av);
+                        const int ar[2] = {ax[3], ax[4]};
+                        gemm_phase2<2, 1, 16>(av, smem, ar, rsrc, voff, vsoff, 0, g_v, vsoff, 0);
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                Vt[(hl * 16 + l15) * LDV + prow((r + 3) * 16 + lg * 4 + e)] = av[r][0][e] + bvv;
+                    }
+                    // the 8 pad keys behind each window are multiplied by P = 0: they must be finite whatever the region held
+                    for (int i = tid; i < 64 * 16; i += THREADS) {
+                        const int ch = i >> 4, k = i & 15;
+                        Vt[ch * LDV + (k < 8 ? T + k : 48 + T + (k - 8))] = 0.f;
+                    }
+                    // out-projection fragments of this quad fly during the barrier and the attention
+                    ring2_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + q * 4) * 1024, 16 * 1024);
+                }
+                __syncthreads();
+                // ---- attention: wave = (head hl, window wave>>2); window w lives at plane rows 48w .. -------------------
+                {
+                    const int w = wave >> 2;
+                    if (w < nwin)
+                        attention_head_mfma<LDQ, LDV>(Qp + w * 48 * LDQ, Kp + w * 48 * LDQ, Vt + w * 48, hl * 16, lane, T);
+                }
+                __syncthreads();
+                // next Q|K ring (next quad of this layer) goes out before the out-projection MFMAs
+                if (q < 3)
+                    ring2_prefetch<1>(g_q, rsrc, voff,
+                                      lbase + (int)(QKV_W * 4) + ((wave >> 2) * 16 + (q + 1) * 4 + (wave & 3)) * 16 * 1024, 0);
+                else
+                    ring2_prefetch<1>(g_f1, rsrc, voff, lbase + (int)(W1_W * 4) + wave * 16 * 1024, 0);
+                // ---- out-projection partial: acc_o += O_quad [80 x 64] * Wo[:, 64q .. 64q+63]^T ---------------------------
+                {
+                    const int osoff = lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + q * 4) * 1024;
+                    int ao[RB];   // O rows live in the (remapped) Q plane
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) ao[r] = X_FLOATS + prow(r * 16 + l15) * LDQ + lg * 4;
+                    gemm_phase2<RB, 2, 4>(acc_o, smem, ao, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = (wave * 2 + n) * 16 + l15;
+                const float bv = LW[WO_B + col];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_o[r][n][e] + bv;
+            }
+            __syncthreads();
+            layernorm_rows2(X, LW + G1, LW + BE1, wave, lane);
+            __syncthreads();
+            // ---- feed-forward: 8 hidden chunks of 128; linear2 accumulates in registers ------------------------------------
+            float* Hc = C;
+            f32x4 acc_f[RB][2];
+            zero_acc2<RB, 2>(acc_f);
+#pragma unroll 1
+            for (int f = 0; f < 8; ++f) {
+                {
+                    f32x4 acc[RB][1];
+                    zero_acc2<RB, 1>(acc);
+                    const int w1off = lbase + (int)(W1_W * 4) + (f * 8 + wave) * 16 * 1024;
+                    int ax[RB];
+                    rows_off(ax, 0, LDX);
+                    gemm_phase2<RB, 1, 16>(acc, smem, ax, rsrc, voff, w1off, 0, g_f1, w1off, 0);
+                    ring2_prefetch<2>(g_f2r, rsrc, voff, lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 8) * 1024, 64 * 1024);
+                    const int col = wave * 16 + l15;
+                    const float bv = LW[W1_B + f * 128 + col];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) Hc[(r * 16 + lg * 4 + e) * LDH + col] = fmaxf(acc[r][0][e] + bv, 0.f);
+                }
+                __syncthreads();
+                {
+                    if (f < 7) ring2_prefetch<1>(g_f1, rsrc, voff, lbase + (int)(W1_W * 4) + ((f + 1) * 8 + wave) * 16 * 1024, 0);
+                    const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 8) * 1024;
+                    int ah[RB];
+                    rows_off(ah, X_FLOATS, LDH);
+                    gemm_phase2<RB, 2, 8>(acc_f, smem, ah, rsrc, voff, w2off, 64 * 1024, g_f2r, w2off, 64 * 1024);
+                }
+                __syncthreads();
+            }
+            if (layer + 1 < L)
+                ring2_prefetch<1>(g_q, rsrc, voff,
+                                  lbase + (int)(LAYER_FLOATS * 4) + (int)(QKV_W * 4) + ((wave >> 2) * 16 + (wave & 3)) * 16 * 1024, 0);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = (wave * 2 + n) * 16 + l15;
+                const float bv = LW[W2_B + col];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_f[r][n][e] + bv;
+            }
+            __syncthreads();
+            layernorm_rows2(X, LW + G2, LW + BE2, wave, lane);
+            __syncthreads();
+        }
+        // ---- RNN input projection: IH = X W_ih^T + (b_ih + b_hh) for both windows -> HBM -------------------------------------
+        {
+            f32x4 acc[RB][4];
+            zero_acc2<RB, 4>(acc);
+            const int isoff = ih_off_b + (wave * 4) * 16 * 1024;
+            WRing2<4> g_ih;
+            ring2_prefetch<4>(g_ih, rsrc, voff, isoff, 16 * 1024);
+            int ax[RB];
+            rows_off(ax, 0, LDX);
+            gemm_phase2<RB, 4, 16>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
+            float* io = ih_out + (size_t)win0 * T * R;   // the two windows are consecutive: rows 0..79 map 1:1
+            const int nrows = nwin * T;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int col = (wave * 4 + n) * 16 + l15;
+                const float bv = wts[ih_off_b / 4 + R * D + col];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = r * 16 + lg * 4 + e;
+                        if (row < nrows) io[(size_t)row * R + col] = acc[r][n][e] + bv;
+                    }
+            }
+        }
+        if (hall_sentinel) {
+            uint4* hp = reinterpret_cast<uint4*>(hall_sentinel + (size_t)win0 * T * R);
+            for (int i = tid; i < nwin * T * (R / 4); i += THREADS) hp[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        }
+        __syncthreads();
+    }
+}
+
+bool fused2_supported(const Dims& d, int T) { return fused_supported(d, T) && fused_has_rnn_ih(d) && T == f2::T; }
+
+hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
+                                 const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, int B,
+                                 int num_cus, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder2_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f2::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int npairs = (B + 1) / 2;
+    const int grid = npairs < num_cus ? npairs : num_cus;
+    const size_t ih_off = f2::LAYER0 + (size_t)d.L * f2::LAYER_FLOATS;
+    hipLaunchKernelGGL(fused_encoder2_kernel, dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+                       keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, d.n_imu_total, d.S, d.L,
+                       (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4));
+    return hipGetLastError();
+}
+
+}  // namespace tip

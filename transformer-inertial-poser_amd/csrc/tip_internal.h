@@ -139,4 +139,10 @@ hipError_t launch_latency_head(const float* A, long long lda, const float* wfrag
 hipError_t read_spin_timeouts_general(unsigned* out);
 hipError_t read_spin_timeouts_latency(unsigned* out);
 
+// ---- two-window fused encoder (tip_fused2.hip): 80 rows = 5 MFMA row blocks, no padding; for >= 2 windows per CU ----
+bool fused2_supported(const Dims& d, int T);
+hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
+                                 const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, int B,
+                                 int num_cus, hipStream_t s);
+
 }  // namespace tip
