@@ -1,0 +1,66 @@
+#!/bin/bash
+# Collect the round's measurement artefacts on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
+# Everything lands in gpurun_out/<round>/; copy what should be judged into profiles/<round>/ afterwards.
+# PMC passes are run separately from each other and with --kernel-trace only (no sys/hip/hsa trace domains).
+set -u
+ROUND=${1:-r01}
+OUT=$PWD/gpurun_out/$ROUND
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+BENCH="python $PWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+
+# 1. the default bench line (with cpu_baseline) and the same command under rocprofv3 --kernel-trace --stats
+timeout 600 python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
+for cfg in "256:" "1:--batch 1" "1024:--batch 1024"; do
+    tag=${cfg%%:*}; extra=${cfg#*:}
+    d=/tmp/prof_$tag; rm -rf $d
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- $BENCH $extra \
+        > "$OUT/bench_under_rocprof_B$tag.json" 2> /dev/null)
+    f=$(find $d -name '*kernel_stats.csv' | head -1)
+    [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_bench_B${tag}_T40.csv"
+    if [ "$tag" = 1 ]; then   # kernel timeline of one single-stream forward (latency plan)
+        t=$(find $d -name '*kernel_trace.csv' | head -1)
+        [ -n "$t" ] && python tools/timeline.py "$t" lat_in_kernel > "$OUT/timeline_B1.txt" 2> /dev/null
+    fi
+done
+
+# 2. PMC passes (B=256 and B=1024), one small counter group per pass
+PMCS=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES"
+      "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE")
+for tag in 256 1024; do
+    rm -rf /tmp/pmc_$tag; i=0
+    for grp in "${PMCS[@]}"; do
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmc_$tag/p$i -- \
+            $BENCH --batch $tag > /dev/null 2>&1)
+        i=$((i + 1))
+    done
+    python - "$tag" "$OUT" <<'EOF'
+import csv, glob, json, sys, collections
+tag, out = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for f in glob.glob(f"/tmp/pmc_{tag}/p*/**/*counter_collection.csv", recursive=True):
+    per = collections.defaultdict(float)   # (dispatch, kernel, counter) -> summed over XCD/SE instances
+    for r in csv.DictReader(open(f)):
+        per[(r["Dispatch_Id"], r["Kernel_Name"], r["Counter_Name"])] += float(r["Counter_Value"])
+    for (_, k, c), v in per.items():
+        if "tip::" not in k:
+            continue
+        a = acc[k.split("(")[0].replace("void ", "")][c]
+        a[0] += v
+        a[1] += 1
+res = {k: {c: {"mean_per_dispatch": s / n, "dispatches": n} for c, (s, n) in sorted(v.items())} for k, v in sorted(acc.items())}
+json.dump(res, open(f"{out}/pmc_counters_bench_B{tag}_T40.json", "w"), indent=1)
+# traffic per launch of the dominant kernel: (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction, MI355X_MICROARCH.md)
+for k, v in res.items():
+    if "fused_encoder" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        t = (2 * v["FETCH_SIZE"]["mean_per_dispatch"] + v["WRITE_SIZE"]["mean_per_dispatch"]) * 1024
+        print(f"traffic B{tag} {k}: {t:.0f} bytes/launch")
+        json.dump({"kernel": k, "bytes_per_launch": t}, open(f"{out}/traffic_B{tag}.json", "w"))
+EOF
+done
+
+# 3. sweeps
+timeout 900 python tools/sweep.py > "$OUT/sweep_n1.jsonl" 2> /dev/null
+timeout 600 python tools/stream_bench.py > "$OUT/stream_bench_n1.jsonl" 2> /dev/null
+ls -la "$OUT"
