@@ -130,6 +130,39 @@ int tip_stream_ingest(void* state, const float* raw_imu, int n_streams, int fram
 int tip_stream_consume(void* state, const float* y_last, int n_streams, int call_idx, float* s_rest, float* c_t,
                        tip_stream_t stream);
 
+/* ---- training step: the model call of train_model.py:171-196 ---------------------
+ * Replaces `y_pred = model(x_imu, x_s + noise)` in train mode (train_model.py:175) and the model part of
+ * `loss.backward()` (train_model.py:192).  Loss, gradient clipping and the optimiser stay in PyTorch.
+ *   params    host array of n_params device pointers: the state-dict tensors in tip_tensor_info() order, RAW (as the
+ *             optimiser updates them; nothing is packed by the caller)
+ *   keep_mask / keep_scale  as in tip_forward (past-state dropout :77); NULL = keep everything.  Input dropout :73 is
+ *             applied by the caller to x_imu (no gradient flows to the inputs)
+ *   p_drop, seed  dropout of the four nn.TransformerEncoderLayer sites (attention probabilities, after out_proj, after
+ *             ReLU, after linear2; torch default p = 0.1, simple_transformer_with_state.py:26-29).  A mask is never
+ *             stored: element idx of site s is kept iff  hi32(splitmix64_mix(seed + GOLDEN*(idx + (s<<40) + 1))) >=
+ *             floor(p * 2^32), GOLDEN = 0x9E3779B97F4A7C15, mix = the splitmix64 finaliser; site s = 4*layer + {0 attention
+ *             P [B,H,T,T], 1 out_proj [M,D], 2 ffn hidden [M,F], 3 linear2 [M,D]}, idx = row-major element index.
+ *             Kept values are scaled by 1/(1-p).  p_drop = 0 switches it off.
+ *   saved     activation stash written by the forward and read by the backward (tip_train_bytes: saved_bytes)
+ *   scratch   backward workspace (scratch_bytes); grads = one flat buffer, tensors in tip_tensor_info() order.
+ * Supported: with_rnn, rnn_hid_size 512, tf_in_dim 256/512/1024, head width 16/32/64, T <= 128 — else
+ * TIP_ERR_UNSUPPORTED_CONFIG (the Python module then differentiates its torch-op composite instead). */
+int tip_train_bytes(const tip_handle* h, int B, int T, size_t* saved_bytes, size_t* scratch_bytes);
+/* where one stashed activation of encoder layer `layer` lives inside `saved` (float offset, float count): */
+#define TIP_SAVED_QKV  0 /* [M,3D] in-projection output (q | k | v)                                   */
+#define TIP_SAVED_ATT  1 /* [M,D]  attention output before out_proj                                    */
+#define TIP_SAVED_X1   2 /* [M,D]  LayerNorm1 output                                                    */
+#define TIP_SAVED_HID  3 /* [M,F]  linear1 output after ReLU and dropout (> 0 exactly where the unit's gate is open) */
+#define TIP_SAVED_XOUT 4 /* [M,D]  layer output (LayerNorm2)                                            */
+#define TIP_SAVED_HALL 5 /* [M,R]  RNN states h_t (layer argument ignored but must be valid)           */
+int tip_train_saved_view(const tip_handle* h, int B, int T, int what, int layer, size_t* float_offset, size_t* floats);
+int tip_train_forward(tip_handle* h, const float* const* params, int n_params, const float* x_imu, const float* x_s,
+                      const float* keep_mask, float keep_scale, float p_drop, unsigned long long seed, float* y, void* saved,
+                      size_t saved_bytes, int B, int T, tip_stream_t stream);
+int tip_train_backward(tip_handle* h, const float* const* params, int n_params, const float* dy, const void* saved,
+                       size_t saved_bytes, void* scratch, size_t scratch_bytes, float* grads, size_t grads_floats, float p_drop,
+                       unsigned long long seed, int B, int T, tip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

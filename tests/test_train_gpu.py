@@ -1,0 +1,160 @@
+"""GPU: the HIP training step (tip_train_forward / tip_train_backward through the module's autograd function) against
+the training oracle and the reference's golden gradient digests."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import tip_amd
+from tip_amd import synth
+from oracle import train_oracle
+from test_host_cpu import make_model, load_synth
+from test_train_oracle import GOLD, CASES, digest_close
+
+pytestmark = pytest.mark.gpu
+
+from tip_amd import lib as tlib
+
+REL = 1e-5   # per-tensor relative L2 error of fp32 MFMA gradients (reductions over up to 10 240 rows) vs the fp64 oracle
+             # differentiating the same linear piece (ReLU gates taken from the run under test)
+
+
+def _train_model(cfg, seed, p_enc):
+    assert torch.cuda.is_available()
+    m = make_model(cfg)
+    w = load_synth(m, cfg, seed)
+    m = m.cuda().train()
+    m.ENCODER_DROPOUT = p_enc
+    m.keep_train_stash = True
+    return m, w
+
+
+def _gates(m, cfg, B, T):
+    return [(m.train_activation(tlib.TIP_SAVED_HID, l) > 0).cpu().numpy().reshape(B, T, cfg["tf_hid_size"])
+            for l in range(cfg["tf_layers"])]
+
+
+def _hip_step(m, x_imu, x_s, cot, seed=None):
+    """One model call + backward through the HIP path; returns (y, grads, seed used)."""
+    used = {}
+    if seed is not None:
+        orig = torch.randint
+
+        def fixed(*a, **k):
+            return torch.tensor([seed], dtype=torch.int64)
+        torch.randint = fixed
+    try:
+        n0 = m.hip_forward_count()
+        m.zero_grad(set_to_none=True)
+        y = m(torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda())
+        assert m.hip_forward_count() == n0 + 1, "the HIP training forward did not run"
+        assert type(y.grad_fn).__name__.startswith("_HipTrainFunction"), type(y.grad_fn).__name__
+        (y * torch.tensor(cot).cuda()).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        if seed is not None:
+            torch.randint = orig
+    return y.detach().cpu().numpy(), {n: p.grad.detach().cpu().numpy() for n, p in m.named_parameters()}, used
+
+
+def _check_grads(g, go, rel=REL):
+    worst = ("", 0.0)
+    for n, ref in go.items():
+        err = np.linalg.norm(g[n].astype(np.float64) - ref) / (np.linalg.norm(ref) + 1e-30)
+        if err > worst[1]:
+            worst = (n, err)
+        assert np.isfinite(g[n]).all(), n
+        assert err < rel, (n, err)
+    return worst
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_golden_reference_gradients(tag):
+    z = np.load(GOLD)
+    cfg = synth.PAPER
+    m, w = _train_model(cfg, CASES[tag], 0.0)
+    y, g, _ = _hip_step(m, z[tag + "/x_imu"], z[tag + "/x_s"], z[tag + "/cot"])
+    assert np.abs(y - z[tag + "/y"]).max() < 2e-5
+    for i, n in enumerate(w.keys()):
+        digest_close(n, train_oracle.digest(n, g[n]), z[tag + "/digests"][i], rtol=4e-4)
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (3, 40), (17, 23), (40, 40)])
+def test_step_matches_oracle_without_dropout(B, T):
+    cfg = synth.PAPER
+    m, w = _train_model(cfg, 2, 0.0)
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=40 + B)
+    cot = synth.normal(7, "cot", B * T * cfg["size_s"]).reshape(B, T, -1).astype(np.float32)
+    y, g, _ = _hip_step(m, x_imu, x_s, cot)
+    yo, go = train_oracle.step(cfg, w, x_imu, x_s, cot, relu_gates=_gates(m, cfg, B, T))
+    assert np.abs(y - yo).max() < 2e-5
+    print("worst tensor", _check_grads(g, go))
+    for _ in range(2):   # the clustered recurrence (forward and backward) is deterministic
+        y2, g2, _ = _hip_step(m, x_imu, x_s, cot)
+        assert np.array_equal(y, y2) and all(np.array_equal(g[n], g2[n]) for n in g)
+
+
+def test_step_matches_oracle_with_live_dropout():
+    """Encoder dropout p = 0.1 (what the reference trains with): the kernels regenerate the masks from (seed, site,
+    index); the oracle applies the same masks explicitly."""
+    cfg = synth.PAPER
+    m, w = _train_model(cfg, 3, 0.1)
+    B, T, seed = 5, 40, 123456789
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=77)
+    cot = synth.normal(8, "cot", B * T * cfg["size_s"]).reshape(B, T, -1).astype(np.float32)
+    y, g, _ = _hip_step(m, x_imu, x_s, cot, seed=seed)
+    yo, go = train_oracle.step(cfg, w, x_imu, x_s, cot, p_drop=0.1, seed=seed, relu_gates=_gates(m, cfg, B, T))
+    assert np.abs(y - yo).max() < 2e-5, np.abs(y - yo).max()
+    print("worst tensor", _check_grads(g, go))
+    # a different seed gives a different (but equally valid) step
+    y2, _, _ = _hip_step(m, x_imu, x_s, cot, seed=seed + 1)
+    assert np.abs(y2 - y).max() > 1e-3
+
+
+def test_past_state_dropout_mask_and_optimizer_step():
+    """train_model.py:192-198 end to end: backward, clip_grad_norm_, optimizer.step() change the weights the next HIP
+    forward sees; the always-on past-state dropout (:77) reaches the kernels as an explicit keep mask."""
+    cfg = synth.PAPER
+    m = make_model(cfg, p_state=0.5)
+    load_synth(m, cfg, 0)
+    m = m.cuda().train()
+    m.ENCODER_DROPOUT = 0.0
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    x_imu, x_s = synth.make_inputs(cfg, 8, 40, seed=1)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    tgt = torch.zeros(8, 40, cfg["size_s"], device="cuda")
+    losses = []
+    for it in range(6):
+        opt.zero_grad()
+        torch.manual_seed(5)            # same past-state mask every iteration -> the loss must go down
+        y = m(xi, xs)
+        loss = ((y - tgt) ** 2).mean()
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        assert torch.isfinite(gn)
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0] * 0.9, losses
+
+
+def test_batch_256_step_runs_and_matches_composite_on_gpu():
+    """BASELINE batch size (train_model.py default 256 x 40): HIP step vs the module's own torch-op composite on the
+    same GPU (fp32 vs fp32, so the tolerance is looser than against the fp64 oracle)."""
+    cfg = synth.PAPER
+    m, _ = _train_model(cfg, 1, 0.0)
+    x_imu, x_s = synth.make_inputs(cfg, 256, 40, seed=9)
+    cot = synth.normal(9, "cot", 256 * 40 * cfg["size_s"]).reshape(256, 40, -1).astype(np.float32)
+    y, g, _ = _hip_step(m, x_imu, x_s, cot)
+    m.use_hip_training = False
+    m.zero_grad(set_to_none=True)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        yc = m(torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda())
+    (yc * torch.tensor(cot).cuda()).sum().backward()
+    assert np.abs(y - yc.detach().cpu().numpy()).max() < 5e-5
+    for n, p in m.named_parameters():
+        ref = p.grad.detach().cpu().numpy().astype(np.float64)
+        err = np.linalg.norm(g[n] - ref) / (np.linalg.norm(ref) + 1e-30)
+        assert err < 1e-3, (n, err)

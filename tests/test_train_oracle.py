@@ -1,0 +1,68 @@
+"""CPU: the training-step oracle (oracle/train_oracle.py) against digests of the REAL reference's gradients
+(tests/golden/make_train_golden.py), and the module's torch-op composite against the same oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import tip_amd
+from tip_amd import synth
+from oracle import train_oracle
+from test_host_cpu import make_model, load_synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "tip_train_golden.npz")
+CASES = {"train_s0_B2_T40": 0, "train_s1_B3_T17": 1}
+
+
+def digest_close(name, got, want, rtol=2e-4):
+    """digest entries are sums over up to 262144 terms of fp32 reference gradients: compare relative to the tensor's
+    L2 norm (sqrt of entry 1), which is what bounds their rounding."""
+    scale = np.sqrt(max(want[1], 1e-30))
+    n_dir = scale * 1.0
+    assert abs(got[1] - want[1]) <= 4 * rtol * want[1] + 1e-12, (name, "sumsq", got[1], want[1])
+    assert abs(got[2] - want[2]) <= rtol * n_dir * 8 + 1e-9, (name, "projection", got[2], want[2])
+    assert np.all(np.abs(got[3:] - want[3:]) <= rtol * scale + 1e-7), (name, "entries", got[3:], want[3:])
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_oracle_matches_reference_gradients(tag):
+    z = np.load(GOLD)
+    cfg = synth.PAPER
+    w = synth.make_weights(cfg, seed=CASES[tag])
+    y, grads = train_oracle.step(cfg, w, z[tag + "/x_imu"], z[tag + "/x_s"], z[tag + "/cot"])
+    assert np.abs(y - z[tag + "/y"]).max() < 5e-6
+    names = list(w.keys())
+    gn = np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in grads.values()))
+    assert abs(gn - z[tag + "/gnorm"][0]) < 1e-4 * gn
+    for i, n in enumerate(names):
+        digest_close(n, train_oracle.digest(n, grads[n]), z[tag + "/digests"][i])
+
+
+def test_dropout_hash_statistics_and_determinism():
+    a = train_oracle.drop_scale(1234, 5, 200000, 0.1)
+    b = train_oracle.drop_scale(1234, 5, 200000, 0.1)
+    c = train_oracle.drop_scale(1234, 6, 200000, 0.1)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    keep = (a > 0).mean()
+    assert abs(keep - 0.9) < 0.004
+    assert np.allclose(a[a > 0], 1.0 / 0.9)
+    assert np.all(train_oracle.drop_scale(1, 0, 10, 0.0) == 1.0)
+
+
+def test_module_composite_matches_oracle_gradients():
+    """The torch-op composite the module differentiates when the HIP training path does not apply (CPU tensors,
+    unsupported configuration) computes the same gradients as the oracle."""
+    cfg = synth.PAPER
+    m = make_model(cfg)
+    w = load_synth(m, cfg, 0)
+    m = m.double().train()
+    m.ENCODER_DROPOUT = 0.0
+    x_imu, x_s = synth.make_inputs(cfg, 2, 9, seed=3)
+    cot = np.random.RandomState(0).randn(2, 9, cfg["size_s"])
+    y = m(torch.tensor(x_imu, dtype=torch.float64), torch.tensor(x_s, dtype=torch.float64))
+    (y * torch.tensor(cot)).sum().backward()
+    yo, go = train_oracle.step(cfg, w, x_imu, x_s, cot)
+    assert np.abs(y.detach().numpy() - yo).max() < 1e-9
+    for n, p in m.named_parameters():
+        assert np.abs(p.grad.numpy() - go[n]).max() <= 1e-8 * (1 + np.abs(go[n]).max()), n

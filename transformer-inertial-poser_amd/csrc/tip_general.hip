@@ -606,11 +606,15 @@ constexpr unsigned kRnnSentinel = 0xFFFFFFFFu;
 // after the reduce+tanh+stores — read back with tip_debug_read_rnn_trace().
 __device__ unsigned long long g_rnn_trace[64 * 4];
 
-template <int WAVES, int KSPLIT, int HANDOFF, bool TRACE = false>
+// BWD = true runs the backward recurrence of the training step on the same machinery (tip_train.hip):
+//   delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2),  t = T-1 .. 0
+// with `ih` = dH, `whh_frag` = fragments of W_hh^T, `gate` = the forward states h, `hall` = delta (output).
+template <int WAVES, int KSPLIT, int HANDOFF, bool TRACE = false, bool BWD = false>
 __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* __restrict__ ih,
                                                                    const float* __restrict__ whh_frag,
                                                                    float* __restrict__ hall, unsigned* __restrict__ flags,
-                                                                   int B, int T, int ntiles, int hall_bytes) {
+                                                                   int B, int T, int ntiles, int hall_bytes,
+                                                                   const float* __restrict__ gate) {
     constexpr int R = 512, KB = R / 16, KBW = KB / KSPLIT;      // k-blocks per wave
     constexpr int CBW = WAVES / KSPLIT;                          // 16-column blocks per workgroup
     constexpr int CLUSTER = KB / CBW;
@@ -677,12 +681,15 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
     for (int tile = group; tile < ntiles; tile += ngroups) {
         const int b0 = tile * kRnnTile;
         for (int t = 0; t < T; ++t) {
-            float ihv[4];
+            const int te = BWD ? T - 1 - t : t;        // time index this step produces
+            const int tp = BWD ? te + 1 : te - 1;      // time index of the state it consumes
+            float ihv[4], gv[4];
             if (ks == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int bb = b0 + lg * 4 + r;
-                    ihv[r] = bb < B ? ih[((size_t)bb * T + t) * R + nb * 16 + l15] : 0.f;
+                    ihv[r] = bb < B ? ih[((size_t)bb * T + te) * R + nb * 16 + l15] : 0.f;
+                    if (BWD) gv[r] = bb < B ? gate[((size_t)bb * T + te) * R + nb * 16 + l15] : 0.f;
                 }
             }
             // canonical accumulation (see rnn_kernel): chains {lower,upper half of K} x {even,odd k-block}
@@ -724,7 +731,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                         if (need[j]) {
                             const int i = tid + j * THREADS;
                             const int m = i / (R / 4), c = (i % (R / 4)) * 4;
-                            v[j] = __builtin_amdgcn_raw_buffer_load_b128(hrs, (int)((((size_t)(b0 + m) * T + (t - 1)) * R + c) * 4), 0, 16);
+                            v[j] = __builtin_amdgcn_raw_buffer_load_b128(hrs, (int)((((size_t)(b0 + m) * T + tp) * R + c) * 4), 0, 16);
                         }
                     }
                     if (HANDOFF == 0) { gave_up = false; break; }
@@ -787,14 +794,14 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                 // store between two uses of the prefetched `ihv` makes the compiler wait for its write-through ack.
                 float hv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hv[r] = tip_tanh(acc[r] + ihv[r]);
+                for (int r = 0; r < 4; ++r) hv[r] = BWD ? (acc[r] + ihv[r]) * (1.0f - gv[r] * gv[r]) : tip_tanh(acc[r] + ihv[r]);
                 // pin the four values here (the optimiser otherwise sinks each tanh back into its store's branch)
                 asm volatile("" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int bb = b0 + lg * 4 + r;
                     if (bb < B) {
-                        float* dst = hall + ((size_t)bb * T + t) * R + nb * 16 + l15;
+                        float* dst = hall + ((size_t)bb * T + te) * R + nb * 16 + l15;
                         if (same_xcd) *dst = hv[r];   // lands in the shared L2 (L1 is write-through)
                         else __hip_atomic_store(dst, hv[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1
                     }
@@ -831,7 +838,7 @@ bool rnn_uses_sentinel(const Dims& d, int B, int T, int cluster) {
 
 template <int WAVES, int KSPLIT>
 static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T,
-                                      int ntiles, int num_cus, bool hall_armed, hipStream_t s) {
+                                      int ntiles, int num_cus, bool hall_armed, hipStream_t s, const float* gate = nullptr) {
     constexpr int CLUSTER = (512 / 16) / (WAVES / KSPLIT);
     int groups = ntiles;
     const int maxg = num_cus / CLUSTER > 0 ? num_cus / CLUSTER : 1;   // keep every cluster co-resident
@@ -843,8 +850,12 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
     if (handoff == 0) {
         hipError_t e = hipMemsetAsync(flags, 0, (size_t)ntiles * T * sizeof(unsigned), s);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 0>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
-                           whh_frag, hall, flags, B, T, ntiles, (int)hb);
+        if (gate)
+            hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 0, false, true>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem,
+                               s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate);
+        else
+            hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 0>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
+                               whh_frag, hall, flags, B, T, ntiles, (int)hb, gate);
     } else {
         if (!hall_armed) {
             hipError_t e = hipMemsetAsync(hall, 0xFF, (size_t)hb, s);   // every word = kRnnSentinel
@@ -854,14 +865,28 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
         if (e2 != hipSuccess) return e2;
         static int trace = -1;
         if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
-        if (trace)
+        if (gate)
+            hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1, false, true>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem,
+                               s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate);
+        else if (trace)
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1, true>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s,
-                               ih, whh_frag, hall, flags, B, T, ntiles, (int)hb);
+                               ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate);
         else
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
-                               whh_frag, hall, flags, B, T, ntiles, (int)hb);
+                               whh_frag, hall, flags, B, T, ntiles, (int)hb, gate);
     }
     return hipGetLastError();
+}
+
+// backward recurrence of the training step (R = 512, cluster 4 / 8 / 16 only); see rnn_resident_kernel<.., BWD>
+hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_frag, const float* h_fwd, float* delta,
+                          unsigned* flags, int B, int T, int cluster, int num_cus, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (d.R != 512 || (long long)B * T * 512 * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
+    const int ntiles = (B + kRnnTile - 1) / kRnnTile;
+    if (cluster >= 16) return launch_rnn_resident<4, 2>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, s, h_fwd);
+    if (cluster == 8) return launch_rnn_resident<4, 1>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, s, h_fwd);
+    return launch_rnn_resident<8, 1>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, s, h_fwd);
 }
 
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,

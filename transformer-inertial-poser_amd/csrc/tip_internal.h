@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/tip_hip.h"
@@ -109,6 +110,9 @@ hipError_t launch_layernorm(float* x, const float* g, const float* b, int M, int
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
                       int T, int cluster, int num_cus, bool hall_armed, hipStream_t s);
 size_t rnn_flag_words(int B, int T);
+// training step, backward recurrence: delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2) (tip_train.hip)
+hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_frag, const float* h_fwd, float* delta,
+                          unsigned* flags, int B, int T, int cluster, int num_cus, hipStream_t s);
 
 // ---- fused plan (tip_fused.hip) ----
 bool fused_supported(const Dims& d, int T);

@@ -1,0 +1,1114 @@
+// tip_train.hip — training step of TF_RNN_Past_State on the HIP path.
+//
+// Reference call site: /root/reference/train_model.py:171-196 — model.train(); y = model(x_imu, x_s + noise);
+// loss.backward(); clip_grad_norm_; optimizer.step().  The loss and the optimiser stay in PyTorch; this file is the
+// model's forward in train mode (activations saved, encoder dropout live) and its backward, returning the gradient
+// of the 56 state-dict tensors (simple_transformer_with_state.py:20-46) in state-dict order.
+//
+// Forward (train) = the layer-by-layer pipeline of the general plan, reading the RAW parameter tensors (they change
+// every optimiser step, so nothing is packed on the host):
+//   prep (in_linear rows shuffled :88-89 / padded, b_ih + b_hh, W_hh and W_hh^T in MFMA fragment order)
+//   -> prologue :63-78 -> in_linear :79 -> L x { QKV, causal SDPA (+P dropout), out-proj + dropout1 + residual, LN1,
+//      linear1 + ReLU + dropout, linear2 + dropout2 + residual, LN2 }  (torch TransformerEncoderLayer, post-norm)
+//   -> RNN input projection, tanh recurrence :98-99 (clustered register-resident kernel), output projection :102.
+// Backward = the same chain reversed: one flexible fp32-MFMA GEMM (three operand-orientation variants) does every
+// dX = dY W and, split over the 10 240 row reduction, every dW = dY^T X; LayerNorm / attention / recurrence have
+// their own kernels.  The recurrence backward  delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2)  has the same shape as
+// the forward recurrence, so it runs on the same clustered kernel with W_hh^T fragments, time reversed.
+//
+// Dropout (encoder p = 0.1, torch default, live in train mode): masks are never stored.  keep(site, idx) is a pure
+// function of (seed, site, element index) — splitmix64 finaliser, documented in include/tip_hip.h — evaluated in the
+// forward epilogues and again in the backward.  Tests rebuild the same masks in numpy.
+#include <string.h>
+
+#include "tip_internal.h"
+
+namespace tip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dropout: keep(seed, site, idx) = hash >= thresh, thresh = floor(p * 2^32)
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned site, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + ((unsigned long long)site << 40) + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32);
+}
+
+struct Drop {
+    unsigned long long seed;
+    unsigned site;
+    unsigned thresh;   // 0 => dropout off
+    float scale;       // 1 / (1 - p)
+};
+
+__device__ __forceinline__ float drop_factor(const Drop d, unsigned long long idx) {
+    if (d.thresh == 0) return 1.f;
+    return drop_hash(d.seed, d.site, idx) >= d.thresh ? d.scale : 0.f;
+}
+
+static Drop make_drop(float p, unsigned long long seed, unsigned site) {
+    Drop d;
+    d.seed = seed;
+    d.site = site;
+    if (p <= 0.f) {
+        d.thresh = 0;
+        d.scale = 1.f;
+    } else {
+        double t = (double)p * 4294967296.0;
+        if (t > 4294967295.0) t = 4294967295.0;
+        d.thresh = (unsigned)t;
+        if (d.thresh == 0) d.thresh = 1;
+        d.scale = 1.0f / (1.0f - p);
+    }
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tgemm: C[i][j] = epi( sum_k A(i,k) * B(j,k) ),  128x128x16 block tile, 32x32x2 fp32 MFMA, 4 waves as 2x2.
+//   operand mode 0: element (r,k) at P[r*ld + k]  (k contiguous: activations, weights as stored)
+//   operand mode 1: element (r,k) at P[k*ld + r]  (r contiguous: a weight read transposed, or a [rows x features]
+//                                                  activation whose ROW index is the reduction, as in dW = dY^T X)
+// Rows beyond `mm`/`nn` and k beyond `kva`/`kvb` read as zero.  blockIdx.z splits the reduction (partials at
+// C + z*c_zstride, no epilogue) for the dW GEMMs.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TG {
+    const float* A; long long lda;
+    const float* B; long long ldb;
+    float* C; long long ldc;
+    int mm, nn, kk;         // extents (kk = loop extent, multiple of 16)
+    int kva, kvb;           // valid k of each operand
+    int c_rows;             // rows of C actually stored (<= mm)
+    int klen;               // reduction length per blockIdx.z (multiple of 16)
+    long long c_zstride;
+    const float* bias;      // [nn] or null
+    int relu;
+    Drop drop;              // on the value before gate / residual
+    const float* gate; long long ldgate; float gate_scale;   // v *= gate[i][j] > 0 ? gate_scale : 0
+    const float* res; long long ldres;                       // v += res[i][j]
+};
+
+template <int MODE>
+struct TileLoader {
+    static constexpr int LDT = MODE ? 132 : 130;
+    float4 r0, r1;
+    __device__ __forceinline__ void load(const float* P, long long ld, int r_base, int rows, int k0, int kvalid, int tid) {
+        // explicit branches: a `cond ? *p : zero` select makes the compiler pick between two ADDRESSES and park the zero
+        // vector in scratch
+        r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 0) {
+            const int lr = tid >> 2, lk = (tid & 3) * 4;
+            const int ra = r_base + lr, rb = ra + 64, k = k0 + lk;
+            if (k < kvalid) {
+                if (ra < rows) r0 = *reinterpret_cast<const float4*>(P + (long long)ra * ld + k);
+                if (rb < rows) r1 = *reinterpret_cast<const float4*>(P + (long long)rb * ld + k);
+            }
+        } else {
+            const int kr = tid >> 4, ic = (tid & 15) * 4;
+            const int k = k0 + kr, ia = r_base + ic, ib = ia + 64;
+            if (k < kvalid) {
+                if (ia < rows) r0 = *reinterpret_cast<const float4*>(P + (long long)k * ld + ia);
+                if (ib < rows) r1 = *reinterpret_cast<const float4*>(P + (long long)k * ld + ib);
+            }
+        }
+    }
+    __device__ __forceinline__ void stage(float (*S)[LDT], int tid) const {
+        if (MODE == 0) {
+            const int lr = tid >> 2, lk = (tid & 3) * 4;
+            S[lk + 0][lr] = r0.x; S[lk + 1][lr] = r0.y; S[lk + 2][lr] = r0.z; S[lk + 3][lr] = r0.w;
+            S[lk + 0][lr + 64] = r1.x; S[lk + 1][lr + 64] = r1.y; S[lk + 2][lr + 64] = r1.z; S[lk + 3][lr + 64] = r1.w;
+        } else {
+            const int kr = tid >> 4, ic = (tid & 15) * 4;
+            *reinterpret_cast<float4*>(&S[kr][ic]) = r0;
+            *reinterpret_cast<float4*>(&S[kr][ic + 64]) = r1;
+        }
+    }
+};
+
+template <int AM, int BM>
+__global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
+    constexpr int LDA_T = TileLoader<AM>::LDT, LDB_T = TileLoader<BM>::LDT;
+    __shared__ __attribute__((aligned(16))) float As[2][16][LDA_T];
+    __shared__ __attribute__((aligned(16))) float Bs[2][16][LDB_T];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    const int kbeg = blockIdx.z * g.klen;
+    const int kend = min(g.kk, kbeg + g.klen);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    TileLoader<AM> la;
+    TileLoader<BM> lb;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    if (kbeg < kend) {
+        la.load(g.A, g.lda, i0, g.mm, kbeg, g.kva, tid);
+        lb.load(g.B, g.ldb, j0, g.nn, kbeg, g.kvb, tid);
+        la.stage(As[0], tid);
+        lb.stage(Bs[0], tid);
+        __syncthreads();
+        int cur = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += 16) {
+            const bool more = k0 + 16 < kend;
+            if (more) {
+                la.load(g.A, g.lda, i0, g.mm, k0 + 16, g.kva, tid);
+                lb.load(g.B, g.ldb, j0, g.nn, k0 + 16, g.kvb, tid);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int k = kk * 2 + lhi;
+                float a[2], b[2];
+                a[0] = As[cur][k][wm * 64 + l31];
+                a[1] = As[cur][k][wm * 64 + 32 + l31];
+                b[0] = Bs[cur][k][wn * 64 + l31];
+                b[1] = Bs[cur][k][wn * 64 + 32 + l31];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) {
+                la.stage(As[cur ^ 1], tid);
+                lb.stage(Bs[cur ^ 1], tid);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    float* C = g.C + (long long)blockIdx.z * g.c_zstride;
+    const bool plain = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = j0 + wn * 64 + j * 32 + l31;
+            if (col >= g.nn) continue;
+            const float bv = (!plain && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row >= g.c_rows) continue;
+                float v = acc[i][j][r];
+                if (!plain) {
+                    v += bv;
+                    if (g.relu) v = v > 0.f ? v : 0.f;
+                    v *= drop_factor(g.drop, (unsigned long long)row * (unsigned)g.nn + (unsigned)col);
+                    if (g.gate) v *= g.gate[(long long)row * g.ldgate + col] > 0.f ? g.gate_scale : 0.f;
+                    if (g.res) v += g.res[(long long)row * g.ldres + col];
+                }
+                C[(long long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+static TG tg_base(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int mm, int nn, int kk) {
+    TG g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+    g.mm = mm; g.nn = nn; g.kk = round_up(kk, 16);
+    g.kva = kk; g.kvb = kk;
+    g.c_rows = mm;
+    g.klen = g.kk;
+    g.drop.thresh = 0; g.drop.scale = 1.f;
+    g.gate_scale = 1.f;
+    return g;
+}
+
+template <int AM, int BM>
+static hipError_t tgemm_launch(const TG& g, int splits, hipStream_t s) {
+    dim3 grid((g.nn + 127) / 128, (g.mm + 127) / 128, splits);
+    hipLaunchKernelGGL((tgemm_kernel<AM, BM>), grid, dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+// out[i] = sum_z part[z*stride + i]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, long long stride, int Z,
+                                                            float* __restrict__ out, long long n) {
+    const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    if (i4 + 3 < n) {
+        float4 a = *reinterpret_cast<const float4*>(part + i4);
+        for (int z = 1; z < Z; ++z) {
+            const float4 b = *reinterpret_cast<const float4*>(part + z * stride + i4);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if ((reinterpret_cast<uintptr_t>(out + i4) & 15) == 0) {
+            *reinterpret_cast<float4*>(out + i4) = a;
+        } else {
+            out[i4] = a.x; out[i4 + 1] = a.y; out[i4 + 2] = a.z; out[i4 + 3] = a.w;
+        }
+    } else {
+        for (long long i = i4; i < n; ++i) {
+            float a = part[i];
+            for (int z = 1; z < Z; ++z) a += part[z * stride + i];
+            out[i] = a;
+        }
+    }
+}
+
+// dW[N x K] = dY^T X with the reduction over the M rows split across the grid; deterministic two-stage sum.
+// A(i = n, k = m) = dY[m*ldy + n], B(j = k', k = m) = X[m*ldx + k'].
+static hipError_t grad_weight(const float* dY, long long ldy, int n_rows_pad, int n_store, const float* X, long long ldx, int K,
+                              int M, float* part, size_t part_floats, float* out, int num_cus, hipStream_t s) {
+    TG g = tg_base(dY, ldy, X, ldx, part, K, n_rows_pad, K, M);
+    g.c_rows = n_store;
+    const int tiles = ((K + 127) / 128) * ((n_rows_pad + 127) / 128);
+    int splits = (2 * num_cus + tiles - 1) / tiles;
+    const long long per = (long long)n_store * K;
+    const long long stride = (per + 3) / 4 * 4;
+    if ((long long)splits * stride > (long long)part_floats) splits = (int)((long long)part_floats / stride);
+    if (splits < 1) return hipErrorInvalidValue;
+    int klen = round_up((g.kk + splits - 1) / splits, 16);
+    splits = (g.kk + klen - 1) / klen;
+    g.klen = klen;
+    g.c_zstride = stride;
+    hipError_t e;
+    if (splits == 1) {
+        g.C = out;
+        return tgemm_launch<1, 1>(g, 1, s);
+    }
+    e = tgemm_launch<1, 1>(g, splits, s);
+    if (e != hipSuccess) return e;
+    const long long n4 = (per + 3) / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, part, stride, splits, out, per);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// column sums (bias gradients): out[n] = sum_m X[m*ld + n]; two deterministic stages
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, long long ld, int M, int N,
+                                                          int rows_per, float* __restrict__ part) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+    float a0 = 0.f, a1 = 0.f;
+    int m = m0;
+    for (; m + 1 < m1; m += 2) {
+        a0 += X[(long long)m * ld + n];
+        a1 += X[(long long)(m + 1) * ld + n];
+    }
+    if (m < m1) a0 += X[(long long)m * ld + n];
+    part[(long long)blockIdx.y * N + n] = a0 + a1;
+}
+
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, int Z, int N, float* __restrict__ out,
+                                                        float* __restrict__ out2) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float a = 0.f;
+    for (int z = 0; z < Z; ++z) a += part[(long long)z * N + n];
+    out[n] = a;
+    if (out2) out2[n] = a;
+}
+
+constexpr int kColZ = 64;
+
+static hipError_t colsum(const float* X, long long ld, int M, int N, float* part, float* out, float* out2, hipStream_t s) {
+    const int rows_per = (M + kColZ - 1) / kColZ;
+    const int Z = (M + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 255) / 256, Z), dim3(256), 0, s, X, ld, M, N, rows_per, part);
+    hipLaunchKernelGGL(colreduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, Z, N, out, out2);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm (torch LayerNorm: biased variance, eps 1e-5, affine): forward saving (mean, rstd); backward
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void tln_fwd_kernel(const float* __restrict__ z, const float* __restrict__ g,
+                                                      const float* __restrict__ be, float* __restrict__ x,
+                                                      float* __restrict__ stats, int M) {
+    constexpr int D = NV * 256;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* zr = z + (size_t)row * D;
+    float4 v[NV];
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const float4*>(zr + (i * 64 + lane) * 4);
+        sm += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum64(sm) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+        q += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum64(q) / (float)D + 1e-5f);
+    if (lane == 0) {
+        stats[(size_t)row * 2] = mean;
+        stats[(size_t)row * 2 + 1] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const float4 gg = *reinterpret_cast<const float4*>(g + c);
+        const float4 bb = *reinterpret_cast<const float4*>(be + c);
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * gg.x + bb.x;
+        o.y = (v[i].y - mean) * rstd * gg.y + bb.y;
+        o.z = (v[i].z - mean) * rstd * gg.z + bb.z;
+        o.w = (v[i].w - mean) * rstd * gg.w + bb.w;
+        *reinterpret_cast<float4*>(x + (size_t)row * D + c) = o;
+    }
+}
+
+constexpr int kLnRows = 64;   // rows per workgroup in the backward (16 per wave)
+
+// dz = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * gamma;  partial dgamma = sum dy * xhat, dbeta = sum dy.
+// Optionally also writes dzm = dz * keep(site, idx): the gradient that flows into the dropped branch of the residual.
+template <int NV>
+__global__ __launch_bounds__(256) void tln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                      const float* __restrict__ stats, const float* __restrict__ g,
+                                                      float* __restrict__ dz, float* __restrict__ dzm, Drop drop,
+                                                      float* __restrict__ part, int M) {
+    constexpr int D = NV * 256;
+    __shared__ float red[4][2][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 gg[NV], dg[NV], db[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        gg[i] = *reinterpret_cast<const float4*>(g + (i * 64 + lane) * 4);
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int r0 = blockIdx.x * kLnRows;
+    for (int rr = wave; rr < kLnRows; rr += 4) {
+        const int row = r0 + rr;
+        if (row >= M) break;
+        const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
+        float4 xh[NV], dyv[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const float4 zv = *reinterpret_cast<const float4*>(z + (size_t)row * D + c);
+            dyv[i] = *reinterpret_cast<const float4*>(dy + (size_t)row * D + c);
+            xh[i].x = (zv.x - mean) * rstd; xh[i].y = (zv.y - mean) * rstd;
+            xh[i].z = (zv.z - mean) * rstd; xh[i].w = (zv.w - mean) * rstd;
+            const float a = dyv[i].x * gg[i].x, b = dyv[i].y * gg[i].y, cc = dyv[i].z * gg[i].z, d = dyv[i].w * gg[i].w;
+            s1 += (a + b) + (cc + d);
+            s2 += (a * xh[i].x + b * xh[i].y) + (cc * xh[i].z + d * xh[i].w);
+            dg[i].x += dyv[i].x * xh[i].x; dg[i].y += dyv[i].y * xh[i].y; dg[i].z += dyv[i].z * xh[i].z; dg[i].w += dyv[i].w * xh[i].w;
+            db[i].x += dyv[i].x; db[i].y += dyv[i].y; db[i].z += dyv[i].z; db[i].w += dyv[i].w;
+        }
+        const float m1 = wave_sum64(s1) / (float)D, m2 = wave_sum64(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            float4 o;
+            o.x = rstd * (dyv[i].x * gg[i].x - m1 - xh[i].x * m2);
+            o.y = rstd * (dyv[i].y * gg[i].y - m1 - xh[i].y * m2);
+            o.z = rstd * (dyv[i].z * gg[i].z - m1 - xh[i].z * m2);
+            o.w = rstd * (dyv[i].w * gg[i].w - m1 - xh[i].w * m2);
+            *reinterpret_cast<float4*>(dz + (size_t)row * D + c) = o;
+            if (dzm) {
+                const unsigned long long idx = (unsigned long long)row * D + c;
+                float4 m;
+                m.x = o.x * drop_factor(drop, idx);
+                m.y = o.y * drop_factor(drop, idx + 1);
+                m.z = o.z * drop_factor(drop, idx + 2);
+                m.w = o.w * drop_factor(drop, idx + 3);
+                *reinterpret_cast<float4*>(dzm + (size_t)row * D + c) = m;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        *reinterpret_cast<float4*>(&red[wave][0][c]) = dg[i];
+        *reinterpret_cast<float4*>(&red[wave][1][c]) = db[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const int w = i / D, c = i - w * D;
+        part[(size_t)blockIdx.x * 2 * D + i] = (red[0][w][c] + red[1][w][c]) + (red[2][w][c] + red[3][w][c]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// causal multi-head attention, training forward and backward (torch functional.py scaled_dot_product_attention with the
+// additive mask of simple_transformer_with_state.py:56-58 and dropout on the probabilities).  One workgroup per
+// (window, head); thread i owns query row i in pass 1, key row j in pass 2.  T <= 128.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH>
+__device__ __forceinline__ float dot_dh(const float* a, const float* b) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int e = 0; e < DH; e += 4) {
+        s0 = fmaf(a[e], b[e], s0); s1 = fmaf(a[e + 1], b[e + 1], s1);
+        s2 = fmaf(a[e + 2], b[e + 2], s2); s3 = fmaf(a[e + 3], b[e + 3], s3);
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
+template <int DH>
+__global__ __launch_bounds__(128) void tattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ ast, int T, int H,
+                                 float q_scale, Drop drop) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;
+    float* Vs = smem + (size_t)T * DH;
+    const int D = H * DH, ld = 3 * D;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const float* base = qkv + (size_t)b * T * ld + h * DH;
+    for (int f = threadIdx.x; f < T * (DH / 4); f += blockDim.x) {
+        const int j = f / (DH / 4), e = (f % (DH / 4)) * 4;
+        *reinterpret_cast<float4*>(Ks + j * DH + e) = *reinterpret_cast<const float4*>(base + (size_t)j * ld + D + e);
+        *reinterpret_cast<float4*>(Vs + j * DH + e) = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * D + e);
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i >= T) return;
+    float q[DH], o[DH];
+#pragma unroll
+    for (int e = 0; e < DH; ++e) {
+        q[e] = base[(size_t)i * ld + e] * q_scale;
+        o[e] = 0.f;
+    }
+    float m = -INFINITY;
+    for (int j = 0; j <= i; ++j) m = fmaxf(m, dot_dh<DH>(q, Ks + j * DH));
+    float l = 0.f;
+    const unsigned long long pbase = ((unsigned long long)blockIdx.x * T + i) * T;
+    for (int j = 0; j <= i; ++j) {
+        const float e_ = expf(dot_dh<DH>(q, Ks + j * DH) - m);
+        l += e_;
+        const float pk = e_ * drop_factor(drop, pbase + j);
+        const float* vj = Vs + j * DH;
+#pragma unroll
+        for (int e = 0; e < DH; ++e) o[e] = fmaf(pk, vj[e], o[e]);
+    }
+    const float inv = 1.0f / l;
+    float* op = out + ((size_t)b * T + i) * D + h * DH;
+#pragma unroll
+    for (int e = 0; e < DH; ++e) op[e] = o[e] * inv;
+    ast[((size_t)blockIdx.x * T + i) * 2] = m;
+    ast[((size_t)blockIdx.x * T + i) * 2 + 1] = inv;
+}
+
+template <int DH>
+__global__ __launch_bounds__(128) void tattn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o_saved,
+                                 const float* __restrict__ ast, const float* __restrict__ d_o, float* __restrict__ dqkv, int T,
+                                 int H, float q_scale, Drop drop) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Qs = smem;                       // pre-scaled by q_scale, as in the forward
+    float* Ks = Qs + (size_t)T * DH;
+    float* Vs = Ks + (size_t)T * DH;
+    float* Gs = Vs + (size_t)T * DH;        // dO
+    float* Ms = Gs + (size_t)T * DH;        // row max
+    float* Ls = Ms + T;                     // 1 / row sum
+    float* Ds = Ls + T;                     // dO_i . O_i
+    const int D = H * DH, ld = 3 * D;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const float* base = qkv + (size_t)b * T * ld + h * DH;
+    for (int f = threadIdx.x; f < T * DH; f += blockDim.x) {
+        const int j = f / DH, e = f % DH;
+        Qs[f] = base[(size_t)j * ld + e] * q_scale;
+        Ks[f] = base[(size_t)j * ld + D + e];
+        Vs[f] = base[(size_t)j * ld + 2 * D + e];
+        Gs[f] = d_o[((size_t)b * T + j) * D + h * DH + e];
+    }
+    const int i = threadIdx.x;
+    if (i < T) {
+        Ms[i] = ast[((size_t)blockIdx.x * T + i) * 2];
+        Ls[i] = ast[((size_t)blockIdx.x * T + i) * 2 + 1];
+        const float* op = o_saved + ((size_t)b * T + i) * D + h * DH;
+        const float* gp = d_o + ((size_t)b * T + i) * D + h * DH;
+        float dd = 0.f;
+        for (int e = 0; e < DH; ++e) dd = fmaf(gp[e], op[e], dd);
+        Ds[i] = dd;
+    }
+    __syncthreads();
+    float* dq_out = dqkv + (size_t)b * T * ld + h * DH;
+    if (i < T) {
+        // pass 1: dq_i = q_scale * sum_{j<=i} ds_ij k_j
+        float q[DH], g[DH], dq[DH];
+#pragma unroll
+        for (int e = 0; e < DH; ++e) {
+            q[e] = Qs[i * DH + e];
+            g[e] = Gs[i * DH + e];
+            dq[e] = 0.f;
+        }
+        const float m = Ms[i], inv = Ls[i], dd = Ds[i];
+        const unsigned long long pbase = ((unsigned long long)blockIdx.x * T + i) * T;
+        for (int j = 0; j <= i; ++j) {
+            const float p = expf(dot_dh<DH>(q, Ks + j * DH) - m) * inv;
+            const float dp = dot_dh<DH>(g, Vs + j * DH) * drop_factor(drop, pbase + j);
+            const float ds = p * (dp - dd);
+            const float* kj = Ks + j * DH;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) dq[e] = fmaf(ds, kj[e], dq[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < DH; ++e) dq_out[(size_t)i * ld + e] = dq[e] * q_scale;
+        // pass 2: this thread is key row j = i
+        const int j = i;
+        float k[DH], v[DH], dk[DH], dv[DH];
+#pragma unroll
+        for (int e = 0; e < DH; ++e) {
+            k[e] = Ks[j * DH + e];
+            v[e] = Vs[j * DH + e];
+            dk[e] = 0.f;
+            dv[e] = 0.f;
+        }
+        for (int ii = j; ii < T; ++ii) {
+            const float* qi = Qs + ii * DH;
+            const float* gi = Gs + ii * DH;
+            const float p = expf(dot_dh<DH>(qi, k) - Ms[ii]) * Ls[ii];
+            const float kf = drop_factor(drop, ((unsigned long long)blockIdx.x * T + ii) * T + j);
+            const float dp = dot_dh<DH>(gi, v) * kf;
+            const float ds = p * (dp - Ds[ii]);
+            const float pk = p * kf;
+#pragma unroll
+            for (int e = 0; e < DH; ++e) {
+                dk[e] = fmaf(ds, qi[e], dk[e]);     // qi is already q * q_scale
+                dv[e] = fmaf(pk, gi[e], dv[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < DH; ++e) {
+            dq_out[(size_t)j * ld + D + e] = dk[e];
+            dq_out[(size_t)j * ld + 2 * D + e] = dv[e];
+        }
+    }
+}
+
+template <typename F>
+static hipError_t dispatch_dh(int dh, F&& f) {
+    switch (dh) {
+        case 16: return f(std::integral_constant<int, 16>());
+        case 32: return f(std::integral_constant<int, 32>());
+        case 64: return f(std::integral_constant<int, 64>());
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// small data-movement kernels
+// ---------------------------------------------------------------------------------------------------------------------
+// in_linear with the channel shuffle (:88-89) folded into its rows (new row a*H + b <- old row b*dh + a), K padded to InPad,
+// and the root-velocity zeroing (:75) folded into its columns
+__global__ __launch_bounds__(256) void prep_in_kernel(const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ Wp,
+                                                      float* __restrict__ bp, int D, int H, int In, int InPad, int z0, int z1) {
+    const int dh = D / H;
+    const int total = D * InPad;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int nn = i / InPad, c = i - nn * InPad;
+        const int old = (nn % H) * dh + nn / H;
+        Wp[i] = (c < In && !(c >= z0 && c < z1)) ? W[(size_t)old * In + c] : 0.f;   // root-velocity columns (:75) read as zero
+        if (c == 0) bp[nn] = bias[old];
+    }
+}
+
+// b_ih + b_hh; W_hh in 16x16x4 B-fragment order for the forward (h W_hh^T) and W_hh^T for the backward (delta W_hh)
+__global__ __launch_bounds__(256) void prep_rnn_kernel(const float* __restrict__ Whh, const float* __restrict__ bih,
+                                                       const float* __restrict__ bhh, float* __restrict__ ff, float* __restrict__ fb,
+                                                       float* __restrict__ bsum, int R) {
+    const int KB = R / 16;
+    const int total = R * R;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int sidx = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+        const int kb = blk % KB, nb = blk / KB;
+        const int n = nb * 16 + (lane & 15), k = kb * 16 + 4 * (lane >> 4) + sidx;
+        ff[i] = Whh[(size_t)n * R + k];
+        fb[i] = Whh[(size_t)k * R + n];
+        if (i < R) bsum[i] = bih[i] + bhh[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, int n, float* __restrict__ dst, int npad, long long rows) {
+    const long long total = rows * npad;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / npad;
+        const int c = (int)(i - r * npad);
+        dst[i] = c < n ? src[r * n + c] : 0.f;
+    }
+}
+
+// hprev[b,t] = h[b,t-1], h[b,-1] = 0
+__global__ __launch_bounds__(256) void shift_rows_kernel(const float* __restrict__ h, float* __restrict__ hp, int T, int R4, long long total4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long row = i / R4;
+        const int t = (int)(row % T);
+        reinterpret_cast<float4*>(hp)[i] = t ? reinterpret_cast<const float4*>(h)[i - R4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// dW_in in state-dict layout: undo the row shuffle, crop the K padding, zero the root-velocity columns (:75)
+__global__ __launch_bounds__(256) void finish_in_kernel(const float* __restrict__ dWp, const float* __restrict__ dbp, float* __restrict__ dW,
+                                                        float* __restrict__ db, int D, int H, int In, int InPad, int z0, int z1) {
+    const int dh = D / H;
+    const int total = D * In;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int old = i / In, c = i - old * In;
+        const int nn = (old % dh) * H + old / dh;
+        dW[i] = (c >= z0 && c < z1) ? 0.f : dWp[(size_t)nn * InPad + c];
+        if (c == 0) db[old] = dbp[nn];
+    }
+}
+
+static int grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// buffers
+// ---------------------------------------------------------------------------------------------------------------------
+struct TrainLayer {
+    size_t qkv, ast, att, z1, st1, x1, hid, z2, st2, xo;
+};
+struct TrainSaved {
+    size_t win_p, bin_p, bsum, whh_f, whh_b, U, x0, ih, hall, flags;
+    std::vector<TrainLayer> layers;
+    size_t total;
+};
+struct TrainScratch {
+    size_t dyp, dh, delta, hprev, ga, gb, gc, gbig, datt, part, colpart, dwin_p, dbin_p;
+    size_t part_floats;
+    size_t total;
+};
+
+static size_t take(size_t& off, size_t n) {
+    const size_t o = off;
+    off += (n + 63) / 64 * 64;
+    return o;
+}
+
+static TrainSaved saved_layout(const Dims& d, int B, int T) {
+    TrainSaved L;
+    const size_t M = (size_t)B * T;
+    size_t off = 0;
+    L.win_p = take(off, (size_t)d.D * d.InPad);
+    L.bin_p = take(off, d.D);
+    L.bsum = take(off, d.R);
+    L.whh_f = take(off, (size_t)d.R * d.R);
+    L.whh_b = take(off, (size_t)d.R * d.R);
+    L.U = take(off, M * d.InPad);
+    L.x0 = take(off, M * d.D);
+    for (int l = 0; l < d.L; ++l) {
+        TrainLayer t;
+        t.qkv = take(off, M * 3 * d.D);
+        t.ast = take(off, (size_t)B * d.H * T * 2);
+        t.att = take(off, M * d.D);
+        t.z1 = take(off, M * d.D);
+        t.st1 = take(off, M * 2);
+        t.x1 = take(off, M * d.D);
+        t.hid = take(off, M * d.F);
+        t.z2 = take(off, M * d.D);
+        t.st2 = take(off, M * 2);
+        t.xo = take(off, M * d.D);
+        L.layers.push_back(t);
+    }
+    L.ih = take(off, M * d.R);
+    L.hall = take(off, M * d.R);
+    L.flags = take(off, rnn_flag_words(B, T));
+    L.total = off;
+    return L;
+}
+
+static TrainScratch scratch_layout(const Dims& d, int B, int T) {
+    TrainScratch S;
+    const size_t M = (size_t)B * T;
+    const int Sp = round_up(d.S, 16);
+    size_t off = 0;
+    S.dyp = take(off, M * Sp);
+    S.dh = take(off, M * d.R);
+    S.delta = take(off, M * d.R);
+    S.hprev = take(off, M * d.R);
+    S.ga = take(off, M * d.D);
+    S.gb = take(off, M * d.D);
+    S.gc = take(off, M * d.D);
+    S.gbig = take(off, M * (size_t)(3 * d.D > d.F ? 3 * d.D : d.F));
+    S.datt = take(off, M * d.D);
+    size_t wmax = (size_t)d.F * d.D;
+    if ((size_t)3 * d.D * d.D > wmax) wmax = (size_t)3 * d.D * d.D;
+    if ((size_t)d.R * d.R > wmax) wmax = (size_t)d.R * d.R;
+    S.part_floats = wmax * 32;
+    S.part = take(off, S.part_floats);
+    const size_t ln_parts = (M + kLnRows - 1) / kLnRows * 2 * d.D;
+    size_t cmax = (size_t)kColZ * (size_t)(3 * d.D > d.F ? 3 * d.D : d.F);
+    if (ln_parts > cmax) cmax = ln_parts;
+    S.colpart = take(off, cmax);
+    S.dwin_p = take(off, (size_t)d.D * d.InPad);
+    S.dbin_p = take(off, d.D);
+    S.total = off;
+    return S;
+}
+
+static bool train_supported(const Dims& d, int B, int T) {
+    if (!d.with_rnn || d.R != 512) return false;
+    if (d.D % 256 != 0 || d.D > 1024 || (d.D / 256 == 3)) return false;
+    if (d.dh != 16 && d.dh != 32 && d.dh != 64) return false;
+    if (d.F % 4 != 0 || T < 1 || T > 128 || B < 1) return false;
+    if ((long long)B * T * 512 * 4 > 0x7fffffffLL) return false;
+    return true;
+}
+
+template <typename K>
+static hipError_t ln_dispatch(int D, K&& k) {
+    switch (D / 256) {
+        case 1: return k(std::integral_constant<int, 1>());
+        case 2: return k(std::integral_constant<int, 2>());
+        case 4: return k(std::integral_constant<int, 4>());
+        default: return hipErrorInvalidValue;
+    }
+}
+
+static int auto_cluster(int B, int num_cus) {
+    const int ntiles = (B + kRnnTile - 1) / kRnnTile;
+    int c = 16;
+    while (c > 4 && ntiles * c > num_cus) c >>= 1;
+    return c;   // the resident kernel exists for 4 / 8 / 16
+}
+
+}  // namespace tip
+
+using namespace tip;
+
+// state-dict order (simple_transformer_with_state.py:20-46)
+enum { P_IN_W = 0, P_IN_B = 1, P_LAYER0 = 2 };
+enum { PL_QKV_W = 0, PL_QKV_B, PL_OUT_W, PL_OUT_B, PL_L1_W, PL_L1_B, PL_L2_W, PL_L2_B, PL_N1_W, PL_N1_B, PL_N2_W, PL_N2_B, PL_COUNT };
+enum { PR_WIH = 0, PR_WHH, PR_BIH, PR_BHH, PR_LIN_W, PR_LIN_B };
+
+static int train_fail(tip_handle* h, hipError_t e, const char* what) {
+    h->last_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+    return TIP_ERR_HIP;
+}
+
+#define TT(expr, what)                                   \
+    do {                                                 \
+        hipError_t e_ = (expr);                          \
+        if (e_ != hipSuccess) return train_fail(h, e_, what); \
+    } while (0)
+
+extern "C" {
+
+int tip_train_bytes(const tip_handle* h, int B, int T, size_t* saved_bytes, size_t* scratch_bytes) {
+    if (!h || B < 0 || T < 0) return TIP_ERR_INVALID_ARG;
+    if (B == 0 || T == 0) {
+        if (saved_bytes) *saved_bytes = 256;
+        if (scratch_bytes) *scratch_bytes = 256;
+        return TIP_OK;
+    }
+    if (!train_supported(h->d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (saved_bytes) *saved_bytes = saved_layout(h->d, B, T).total * sizeof(float);
+    if (scratch_bytes) *scratch_bytes = scratch_layout(h->d, B, T).total * sizeof(float);
+    return TIP_OK;
+}
+
+int tip_train_saved_view(const tip_handle* h, int B, int T, int what, int layer, size_t* float_offset, size_t* floats) {
+    if (!h || !float_offset || !floats) return TIP_ERR_INVALID_ARG;
+    const Dims& d = h->d;
+    if (!train_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (layer < 0 || layer >= d.L) return TIP_ERR_INVALID_ARG;
+    const TrainSaved L = saved_layout(d, B, T);
+    const TrainLayer& t = L.layers[layer];
+    const size_t M = (size_t)B * T;
+    switch (what) {
+        case TIP_SAVED_QKV: *float_offset = t.qkv; *floats = M * 3 * d.D; break;
+        case TIP_SAVED_ATT: *float_offset = t.att; *floats = M * d.D; break;
+        case TIP_SAVED_X1: *float_offset = t.x1; *floats = M * d.D; break;
+        case TIP_SAVED_HID: *float_offset = t.hid; *floats = M * d.F; break;
+        case TIP_SAVED_XOUT: *float_offset = t.xo; *floats = M * d.D; break;
+        case TIP_SAVED_HALL: *float_offset = L.hall; *floats = M * d.R; break;
+        default: return TIP_ERR_INVALID_ARG;
+    }
+    return TIP_OK;
+}
+
+int tip_train_forward(tip_handle* h, const float* const* params, int n_params, const float* x_imu, const float* x_s,
+                      const float* keep_mask, float keep_scale, float p_drop, unsigned long long seed, float* y, void* saved,
+                      size_t saved_bytes, int B, int T, void* stream) {
+    if (!h || !params || !x_imu || !x_s || !y || !saved) return TIP_ERR_INVALID_ARG;
+    if (n_params != (int)h->tensor_names.size()) return TIP_ERR_INVALID_ARG;
+    if (p_drop < 0.f || p_drop >= 1.f) return TIP_ERR_INVALID_ARG;
+    const Dims& d = h->d;
+    if (!train_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    const TrainSaved L = saved_layout(d, B, T);
+    if (reinterpret_cast<uintptr_t>(saved) % 256 || saved_bytes < L.total * sizeof(float)) return TIP_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* W = static_cast<float*>(saved);
+    const int M = B * T;
+    const float* const* rp = params + P_LAYER0 + PL_COUNT * d.L;
+
+    hipLaunchKernelGGL(prep_in_kernel, dim3(grid_for((long long)d.D * d.InPad)), dim3(256), 0, s, params[P_IN_W], params[P_IN_B],
+                       W + L.win_p, W + L.bin_p, d.D, d.H, d.In, d.InPad, d.n_imu_total + d.rootv0, d.n_imu_total + d.rootv1);
+    hipLaunchKernelGGL(prep_rnn_kernel, dim3(grid_for((long long)d.R * d.R)), dim3(256), 0, s, rp[PR_WHH], rp[PR_BIH], rp[PR_BHH],
+                       W + L.whh_f, W + L.whh_b, W + L.bsum, d.R);
+    TT(hipGetLastError(), "train_prep");
+    TT(launch_prologue(d, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f, W + L.U, M, s), "train_prologue");
+    {
+        TG g = tg_base(W + L.U, d.InPad, W + L.win_p, d.InPad, W + L.x0, d.D, M, d.D, d.InPad);
+        g.bias = W + L.bin_p;
+        TT((tgemm_launch<0, 0>(g, 1, s)), "train_in_linear");
+    }
+    const float* x = W + L.x0;
+    for (int l = 0; l < d.L; ++l) {
+        const float* const* lp = params + P_LAYER0 + PL_COUNT * l;
+        const TrainLayer& t = L.layers[l];
+        {
+            TG g = tg_base(x, d.D, lp[PL_QKV_W], d.D, W + t.qkv, 3 * d.D, M, 3 * d.D, d.D);
+            g.bias = lp[PL_QKV_B];
+            TT((tgemm_launch<0, 0>(g, 1, s)), "train_qkv");
+        }
+        {
+            const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 0));
+            const int threads = round_up(T, 64);
+            const float qs = 1.0f / sqrtf((float)d.dh);
+            const float* qkv = W + t.qkv;
+            float* att = W + t.att;
+            float* ast = W + t.ast;
+            const int H = d.H;
+            TT(dispatch_dh(d.dh, [&](auto dh) {
+                   constexpr int DH = decltype(dh)::value;
+                   hipLaunchKernelGGL((tattn_fwd_kernel<DH>), dim3(B * H), dim3(threads), (size_t)2 * T * DH * sizeof(float), s, qkv,
+                                      att, ast, T, H, qs, dr);
+                   return hipGetLastError();
+               }), "train_attention");
+        }
+        {
+            TG g = tg_base(W + t.att, d.D, lp[PL_OUT_W], d.D, W + t.z1, d.D, M, d.D, d.D);
+            g.bias = lp[PL_OUT_B];
+            g.drop = make_drop(p_drop, seed, (unsigned)(l * 4 + 1));
+            g.res = x; g.ldres = d.D;
+            TT((tgemm_launch<0, 0>(g, 1, s)), "train_out_proj");
+        }
+        {
+            const float* z = W + t.z1;
+            float* xo = W + t.x1;
+            float* st = W + t.st1;
+            TT(ln_dispatch(d.D, [&](auto nv) {
+                   hipLaunchKernelGGL((tln_fwd_kernel<decltype(nv)::value>), dim3((M + 3) / 4), dim3(256), 0, s, z, lp[PL_N1_W],
+                                      lp[PL_N1_B], xo, st, M);
+                   return hipGetLastError();
+               }), "train_ln1");
+        }
+        {
+            TG g = tg_base(W + t.x1, d.D, lp[PL_L1_W], d.D, W + t.hid, d.F, M, d.F, d.D);
+            g.bias = lp[PL_L1_B];
+            g.relu = 1;
+            g.drop = make_drop(p_drop, seed, (unsigned)(l * 4 + 2));
+            TT((tgemm_launch<0, 0>(g, 1, s)), "train_ffn1");
+        }
+        {
+            TG g = tg_base(W + t.hid, d.F, lp[PL_L2_W], d.F, W + t.z2, d.D, M, d.D, d.F);
+            g.bias = lp[PL_L2_B];
+            g.drop = make_drop(p_drop, seed, (unsigned)(l * 4 + 3));
+            g.res = W + t.x1; g.ldres = d.D;
+            TT((tgemm_launch<0, 0>(g, 1, s)), "train_ffn2");
+        }
+        {
+            const float* z = W + t.z2;
+            float* xo = W + t.xo;
+            float* st = W + t.st2;
+            TT(ln_dispatch(d.D, [&](auto nv) {
+                   hipLaunchKernelGGL((tln_fwd_kernel<decltype(nv)::value>), dim3((M + 3) / 4), dim3(256), 0, s, z, lp[PL_N2_W],
+                                      lp[PL_N2_B], xo, st, M);
+                   return hipGetLastError();
+               }), "train_ln2");
+        }
+        x = W + t.xo;
+    }
+    {
+        TG g = tg_base(x, d.D, rp[PR_WIH], d.D, W + L.ih, d.R, M, d.R, d.D);
+        g.bias = W + L.bsum;
+        TT((tgemm_launch<0, 0>(g, 1, s)), "train_rnn_ih");
+    }
+    TT(launch_rnn(d, W + L.ih, W + L.whh_f, W + L.hall, reinterpret_cast<unsigned*>(W + L.flags), B, T, auto_cluster(B, h->num_cus),
+                  h->num_cus, false, s), "train_rnn");
+    {
+        TG g = tg_base(W + L.hall, d.R, rp[PR_LIN_W], d.R, y, d.S, M, d.S, d.R);
+        g.bias = rp[PR_LIN_B];
+        TT((tgemm_launch<0, 0>(g, 1, s)), "train_head");
+    }
+    h->forward_count++;
+    return TIP_OK;
+}
+
+int tip_train_backward(tip_handle* h, const float* const* params, int n_params, const float* dy, const void* saved,
+                       size_t saved_bytes, void* scratch, size_t scratch_bytes, float* grads, size_t grads_floats, float p_drop,
+                       unsigned long long seed, int B, int T, void* stream) {
+    if (!h || !params || !dy || !saved || !scratch || !grads) return TIP_ERR_INVALID_ARG;
+    if (n_params != (int)h->tensor_names.size()) return TIP_ERR_INVALID_ARG;
+    const Dims& d = h->d;
+    if (!train_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    const TrainSaved L = saved_layout(d, B, T);
+    const TrainScratch S = scratch_layout(d, B, T);
+    if (reinterpret_cast<uintptr_t>(saved) % 256 || saved_bytes < L.total * sizeof(float)) return TIP_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(scratch) % 256 || scratch_bytes < S.total * sizeof(float)) return TIP_ERR_WORKSPACE;
+    // gradient offsets in state-dict order
+    std::vector<size_t> goff(n_params);
+    size_t gtot = 0;
+    for (int i = 0; i < n_params; ++i) {
+        goff[i] = gtot;
+        const auto& sh = h->tensor_shapes[i];
+        gtot += (size_t)sh.first * (sh.second ? sh.second : 1);
+    }
+    if (grads_floats < gtot) return TIP_ERR_INVALID_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float* W = static_cast<const float*>(saved);
+    float* X = static_cast<float*>(scratch);
+    const int M = B * T;
+    const int Sp = round_up(d.S, 16);
+    const int ncu = h->num_cus;
+    const int rbase = P_LAYER0 + PL_COUNT * d.L;
+    const float* const* rp = params + rbase;
+    float* part = X + S.part;
+    float* colpart = X + S.colpart;
+
+    // ---- output projection (:102): y = h W_out^T + b ---------------------------------------------------------------
+    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for((long long)M * Sp)), dim3(256), 0, s, dy, d.S, X + S.dyp, Sp, (long long)M);
+    TT(hipGetLastError(), "bwd_pad_dy");
+    TT(colsum(dy, d.S, M, d.S, colpart, grads + goff[rbase + PR_LIN_B], nullptr, s), "bwd_db_out");
+    TT(grad_weight(X + S.dyp, Sp, Sp, d.S, W + L.hall, d.R, d.R, M, part, S.part_floats, grads + goff[rbase + PR_LIN_W], ncu, s),
+       "bwd_dW_out");
+    {
+        TG g = tg_base(X + S.dyp, Sp, rp[PR_LIN_W], d.R, X + S.dh, d.R, M, d.R, Sp);
+        g.kvb = d.S;
+        TT((tgemm_launch<0, 1>(g, 1, s)), "bwd_dH");
+    }
+    // ---- recurrence (:98-99), time reversed: delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2) -------------------------
+    TT(launch_rnn_bwd(d, X + S.dh, W + L.whh_b, W + L.hall, X + S.delta, reinterpret_cast<unsigned*>(const_cast<float*>(W + L.flags)),
+                      B, T, auto_cluster(B, ncu), ncu, s), "bwd_rnn");
+    hipLaunchKernelGGL(shift_rows_kernel, dim3(grid_for((long long)M * d.R / 4)), dim3(256), 0, s, W + L.hall, X + S.hprev, T,
+                       d.R / 4, (long long)M * d.R / 4);
+    TT(hipGetLastError(), "bwd_shift");
+    TT(colsum(X + S.delta, d.R, M, d.R, colpart, grads + goff[rbase + PR_BIH], grads + goff[rbase + PR_BHH], s), "bwd_db_rnn");
+    TT(grad_weight(X + S.delta, d.R, d.R, d.R, X + S.hprev, d.R, d.R, M, part, S.part_floats, grads + goff[rbase + PR_WHH], ncu, s),
+       "bwd_dW_hh");
+    const float* enc = W + L.layers[d.L - 1].xo;
+    TT(grad_weight(X + S.delta, d.R, d.R, d.R, enc, d.D, d.D, M, part, S.part_floats, grads + goff[rbase + PR_WIH], ncu, s),
+       "bwd_dW_ih");
+    float* gx = X + S.ga;     // gradient w.r.t. the current layer's output
+    float* galt = X + S.gb;
+    {
+        TG g = tg_base(X + S.delta, d.R, rp[PR_WIH], d.D, gx, d.D, M, d.D, d.R);
+        TT((tgemm_launch<0, 1>(g, 1, s)), "bwd_d_enc");
+    }
+    // ---- encoder layers, last to first -----------------------------------------------------------------------------------
+    for (int l = d.L - 1; l >= 0; --l) {
+        const int pb = P_LAYER0 + PL_COUNT * l;
+        const float* const* lp = params + pb;
+        const TrainLayer& t = L.layers[l];
+        const float* x_in = l ? W + L.layers[l - 1].xo : W + L.x0;
+        const int nln = (M + kLnRows - 1) / kLnRows;
+        // LN2: gx -> dz2 (galt), dff2 = dz2 * keep3 (gc)
+        {
+            const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 3));
+            const float* z = W + t.z2;
+            const float* st = W + t.st2;
+            float* dzm = X + S.gc;
+            TT(ln_dispatch(d.D, [&](auto nv) {
+                   hipLaunchKernelGGL((tln_bwd_kernel<decltype(nv)::value>), dim3(nln), dim3(256), 0, s, gx, z, st, lp[PL_N2_W], galt,
+                                      dzm, dr, colpart, M);
+                   return hipGetLastError();
+               }), "bwd_ln2");
+            hipLaunchKernelGGL(colreduce_kernel, dim3((2 * d.D + 255) / 256), dim3(256), 0, s, colpart, nln, 2 * d.D,
+                               grads + goff[pb + PL_N2_W], nullptr);
+            TT(hipGetLastError(), "bwd_ln2_params");
+        }
+        // norm weight and bias are consecutive tensors of D floats each: the reduce wrote [dgamma | dbeta] in one go
+        TT(colsum(X + S.gc, d.D, M, d.D, colpart, grads + goff[pb + PL_L2_B], nullptr, s), "bwd_db2");
+        TT(grad_weight(X + S.gc, d.D, d.D, d.D, W + t.hid, d.F, d.F, M, part, S.part_floats, grads + goff[pb + PL_L2_W], ncu, s),
+           "bwd_dW2");
+        {
+            // d(pre-ReLU) = (dff2 W2) * [hid > 0] / (1 - p)   (hid is saved AFTER ReLU and dropout)
+            TG g = tg_base(X + S.gc, d.D, lp[PL_L2_W], d.F, X + S.gbig, d.F, M, d.F, d.D);
+            g.gate = W + t.hid; g.ldgate = d.F;
+            g.gate_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.f;
+            TT((tgemm_launch<0, 1>(g, 1, s)), "bwd_dhid");
+        }
+        TT(colsum(X + S.gbig, d.F, M, d.F, colpart, grads + goff[pb + PL_L1_B], nullptr, s), "bwd_db1");
+        TT(grad_weight(X + S.gbig, d.F, d.F, d.F, W + t.x1, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_L1_W], ncu, s),
+           "bwd_dW1");
+        {
+            // dx1 = dz2 + dpre W1   -> gx
+            TG g = tg_base(X + S.gbig, d.F, lp[PL_L1_W], d.D, gx, d.D, M, d.D, d.F);
+            g.res = galt; g.ldres = d.D;
+            TT((tgemm_launch<0, 1>(g, 1, s)), "bwd_dx1");
+        }
+        // LN1: gx -> dz1 (galt), datt_o = dz1 * keep1 (gc)
+        {
+            const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 1));
+            const float* z = W + t.z1;
+            const float* st = W + t.st1;
+            float* dzm = X + S.gc;
+            TT(ln_dispatch(d.D, [&](auto nv) {
+                   hipLaunchKernelGGL((tln_bwd_kernel<decltype(nv)::value>), dim3(nln), dim3(256), 0, s, gx, z, st, lp[PL_N1_W], galt,
+                                      dzm, dr, colpart, M);
+                   return hipGetLastError();
+               }), "bwd_ln1");
+            hipLaunchKernelGGL(colreduce_kernel, dim3((2 * d.D + 255) / 256), dim3(256), 0, s, colpart, nln, 2 * d.D,
+                               grads + goff[pb + PL_N1_W], nullptr);
+            TT(hipGetLastError(), "bwd_ln1_params");
+        }
+        TT(colsum(X + S.gc, d.D, M, d.D, colpart, grads + goff[pb + PL_OUT_B], nullptr, s), "bwd_dbo");
+        TT(grad_weight(X + S.gc, d.D, d.D, d.D, W + t.att, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_OUT_W], ncu, s),
+           "bwd_dWo");
+        {
+            TG g = tg_base(X + S.gc, d.D, lp[PL_OUT_W], d.D, X + S.datt, d.D, M, d.D, d.D);
+            TT((tgemm_launch<0, 1>(g, 1, s)), "bwd_datt");
+        }
+        {
+            const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 0));
+            const int threads = round_up(T, 64);
+            const float qs = 1.0f / sqrtf((float)d.dh);
+            const float* qkv = W + t.qkv;
+            const float* att = W + t.att;
+            const float* ast = W + t.ast;
+            const float* datt = X + S.datt;
+            float* dqkv = X + S.gbig;
+            const int H = d.H;
+            TT(dispatch_dh(d.dh, [&](auto dh) {
+                   constexpr int DH = decltype(dh)::value;
+                   const size_t smem = ((size_t)4 * T * DH + 3 * T) * sizeof(float);
+                   hipLaunchKernelGGL((tattn_bwd_kernel<DH>), dim3(B * H), dim3(threads), smem, s, qkv, att, ast, datt, dqkv, T, H, qs, dr);
+                   return hipGetLastError();
+               }), "bwd_attention");
+        }
+        TT(colsum(X + S.gbig, 3 * d.D, M, 3 * d.D, colpart, grads + goff[pb + PL_QKV_B], nullptr, s), "bwd_dbqkv");
+        TT(grad_weight(X + S.gbig, 3 * d.D, 3 * d.D, 3 * d.D, x_in, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_QKV_W], ncu, s),
+           "bwd_dWqkv");
+        {
+            // dx_in = dz1 + dqkv W_qkv   -> gx
+            TG g = tg_base(X + S.gbig, 3 * d.D, lp[PL_QKV_W], d.D, gx, d.D, M, d.D, 3 * d.D);
+            g.res = galt; g.ldres = d.D;
+            TT((tgemm_launch<0, 1>(g, 1, s)), "bwd_dx_in");
+        }
+    }
+    // ---- in_linear (:79) ---------------------------------------------------------------------------------------------------
+    TT(colsum(gx, d.D, M, d.D, colpart, X + S.dbin_p, nullptr, s), "bwd_db_in");
+    TT(grad_weight(gx, d.D, d.D, d.D, W + L.U, d.InPad, d.InPad, M, part, S.part_floats, X + S.dwin_p, ncu, s), "bwd_dW_in");
+    hipLaunchKernelGGL(finish_in_kernel, dim3(grid_for((long long)d.D * d.In)), dim3(256), 0, s, X + S.dwin_p, X + S.dbin_p,
+                       grads + goff[P_IN_W], grads + goff[P_IN_B], d.D, d.H, d.In, d.InPad, d.n_imu_total + d.rootv0,
+                       d.n_imu_total + d.rootv1);
+    TT(hipGetLastError(), "bwd_finish_in");
+    return TIP_OK;
+}
+
+}  // extern "C"

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(CSRC, "libtip_hip.so")
 TIP_FWD_LAST_ROW_ONLY = 0x1
 TIP_FWD_KEEP_MASK = 0x2
 TIP_PLAN_AUTO, TIP_PLAN_GENERAL, TIP_PLAN_FUSED, TIP_PLAN_LATENCY, TIP_PLAN_FUSED2 = 0, 1, 2, 3, 4
+TIP_SAVED_QKV, TIP_SAVED_ATT, TIP_SAVED_X1, TIP_SAVED_HID, TIP_SAVED_XOUT, TIP_SAVED_HALL = range(6)
 TIP_OPT_PLAN, TIP_OPT_PROFILE, TIP_OPT_RNN_CLUSTER = 1, 2, 3
 
 # every symbol include/tip_hip.h declares (tests check the .so exports exactly these)
@@ -22,6 +23,7 @@ EXPORTS = (
     "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
     "tip_attach_packed", "tip_workspace_bytes", "tip_forward", "tip_forward_count", "tip_profile_read",
     "tip_spin_timeouts", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
+    "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward",
 )
 
 
@@ -97,6 +99,12 @@ def load() -> ctypes.CDLL:
     lib.tip_stream_window_len.argtypes = [i32]
     lib.tip_stream_ingest.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.tip_stream_consume.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    u64 = ctypes.c_ulonglong
+    f32 = ctypes.c_float
+    lib.tip_train_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.tip_train_saved_view.argtypes = [vp, i32, i32, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.tip_train_forward.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, vp, f32, f32, u64, vp, vp, sz, i32, i32, vp]
+    lib.tip_train_backward.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, sz, vp, sz, vp, sz, f32, u64, i32, i32, vp]
     for name in EXPORTS:
         if name not in ("tip_destroy", "tip_strerror", "tip_last_hip_error"):
             getattr(lib, name).restype = i32
@@ -166,6 +174,33 @@ class Handle:
                 keep_scale: float, workspace: int, workspace_bytes: int, stream: int):
         self._check(self.lib.tip_forward(self._h, x_imu, x_s, y, B, T, flags, keep_mask, keep_scale, workspace,
                                          workspace_bytes, stream))
+
+    # -- training step (train_model.py:171-196) -------------------------------------------------------
+    def train_bytes(self, B: int, T: int) -> Tuple[int, int]:
+        """(saved_bytes, scratch_bytes); raises TipStatusError(-4: unsupported config) when the HIP training path
+        does not cover this configuration."""
+        a, b = ctypes.c_size_t(), ctypes.c_size_t()
+        self._check(self.lib.tip_train_bytes(self._h, B, T, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def train_saved_view(self, B: int, T: int, what: int, layer: int) -> Tuple[int, int]:
+        """(float offset, float count) of one stashed activation inside the `saved` buffer of train_forward."""
+        a, b = ctypes.c_size_t(), ctypes.c_size_t()
+        self._check(self.lib.tip_train_saved_view(self._h, B, T, what, layer, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def train_forward(self, param_ptrs: List[int], x_imu: int, x_s: int, keep_mask: Optional[int], keep_scale: float,
+                      p_drop: float, seed: int, y: int, saved: int, saved_bytes: int, B: int, T: int, stream: int):
+        arr = (ctypes.c_void_p * len(param_ptrs))(*param_ptrs)
+        self._check(self.lib.tip_train_forward(self._h, arr, len(param_ptrs), x_imu, x_s, keep_mask, keep_scale, p_drop,
+                                               seed, y, saved, saved_bytes, B, T, stream))
+
+    def train_backward(self, param_ptrs: List[int], dy: int, saved: int, saved_bytes: int, scratch: int,
+                       scratch_bytes: int, grads: int, grads_floats: int, p_drop: float, seed: int, B: int, T: int,
+                       stream: int):
+        arr = (ctypes.c_void_p * len(param_ptrs))(*param_ptrs)
+        self._check(self.lib.tip_train_backward(self._h, arr, len(param_ptrs), dy, saved, saved_bytes, scratch,
+                                                scratch_bytes, grads, grads_floats, p_drop, seed, B, T, stream))
 
     def forward_count(self) -> int:
         n = ctypes.c_uint64()

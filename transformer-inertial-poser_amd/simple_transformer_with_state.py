@@ -112,6 +112,10 @@ class TF_RNN_Past_State(nn.Module):
         self._workspace: Optional[torch.Tensor] = None
         self._frozen = False
         self._warned_autograd = False
+        self._train_scratch: Optional[torch.Tensor] = None
+        self.use_hip_training = True     # .train() + autograd on the GPU -> tip_train_forward / tip_train_backward
+        self.keep_train_stash = False    # debugging/tests: keep the last activation stash (see train_activation())
+        self.last_train_stash = None
         self.t_max = 80
 
     # ------------------------------------------------------------------------------------------
@@ -156,6 +160,13 @@ class TF_RNN_Past_State(nn.Module):
     def _dispatch(self, x_imu, x_s, last_row_only: bool):
         needs_grad = torch.is_grad_enabled() and (x_imu.requires_grad or x_s.requires_grad or
                                                   any(p.requires_grad for p in self.parameters()))
+        if needs_grad and self.training and self._hip_train_ok(x_imu, x_s):
+            # train_model.py:171-196 on the HIP path: forward with saved activations + live encoder dropout, HIP backward
+            xi = F.dropout(x_imu, self.in_dropout, training=True) if self.in_dropout > 0.0 else x_imu   # :73
+            mask = self._draw_keep_mask(x_s)                                                            # :77
+            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())     # CPU generator: no device sync
+            y = _HipTrainFunction.apply(self, xi, x_s, mask, float(self.ENCODER_DROPOUT), seed, *self.parameters())
+            return y[:, -1] if last_row_only else y
         if needs_grad and (self.training or not x_imu.is_cuda):
             if not self._warned_autograd:
                 warnings.warn("tip_amd: autograd in .train() mode (or on CPU) — using the torch-op training composite "
@@ -170,6 +181,30 @@ class TF_RNN_Past_State(nn.Module):
         xi = F.dropout(x_imu, self.in_dropout, training=True) if self.in_dropout > 0.0 else x_imu   # :73
         mask = self._draw_keep_mask(x_s)
         return _HipForwardTorchBackward.apply(self, last_row_only, xi, x_s, mask, *self.parameters())
+
+    def _hip_train_ok(self, x_imu, x_s) -> bool:
+        """True when the HIP training step (libtip_hip tip_train_*) covers this call: fp32 CUDA tensors, gradients wanted
+        for parameters only, and a configuration the kernels support (TIP_ERR_UNSUPPORTED_CONFIG otherwise)."""
+        if not self.use_hip_training or not (x_imu.is_cuda and x_s.is_cuda):
+            return False
+        if x_imu.requires_grad or x_s.requires_grad or x_imu.dtype != torch.float32 or x_s.dtype != torch.float32:
+            return False
+        if x_imu.dim() != 3 or x_s.dim() != 3 or x_imu.shape[:2] != x_s.shape[:2]:
+            return False
+        if any(p.dtype != torch.float32 or not p.is_cuda for p in self.parameters()):
+            return False
+        try:
+            self._ensure_handle().train_bytes(int(x_imu.shape[0]), int(x_imu.shape[1]))
+        except _lib.TipStatusError:
+            return False
+        return True
+
+    def train_activation(self, what: int, layer: int = 0) -> torch.Tensor:
+        """One stashed activation of the last HIP training forward (needs keep_train_stash = True): `what` is one of
+        lib.TIP_SAVED_*; returns a [B*T, width] float32 view."""
+        saved, B, T = self.last_train_stash
+        off, n = self._ensure_handle().train_saved_view(B, T, what, layer)
+        return saved.view(torch.float32)[off:off + n].view(B * T, -1)
 
     def _draw_keep_mask(self, x_s):
         """Bernoulli keep-mask of the always-on past-state dropout (:77); None when p == 0."""
@@ -314,6 +349,68 @@ class TF_RNN_Past_State(nn.Module):
                 hs.append(hcur)
             z = torch.stack(hs, dim=1)
         return F.linear(z, self.linear.weight, self.linear.bias)
+
+
+class _HipTrainFunction(torch.autograd.Function):
+    """The model call of the reference training loop (train_model.py:175 forward, :192 backward) on the HIP kernels.
+    forward: tip_train_forward (activations stashed in `saved`, encoder dropout from a counter-based hash of `seed`);
+    backward: tip_train_backward -> gradients of the state-dict tensors, returned as views of one flat buffer."""
+
+    @staticmethod
+    def forward(ctx, module, x_imu, x_s, mask, p_drop, seed, *params):
+        h = module._ensure_handle()
+        dev = x_imu.device
+        B, T = int(x_imu.shape[0]), int(x_imu.shape[1])
+        n_imu = module.input_size_imu + (18 if module.with_acc_sum else 0)
+        if x_imu.shape[2] != n_imu or x_s.shape[2] != module.size_s:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied: got feature widths "
+                               f"{x_imu.shape[2]}+{x_s.shape[2]}, in_linear expects {n_imu}+{module.size_s}")
+        with torch.cuda.device(dev):
+            saved_bytes, _ = h.train_bytes(B, T)
+            saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+            xi, xs = x_imu.contiguous(), x_s.contiguous()
+            pc = [p.detach().contiguous() for p in params]
+            mask_ptr, scale = None, 1.0
+            if mask is not None:
+                pd = module.past_state_dropout
+                mask = mask.to(torch.float32).contiguous()
+                mask_ptr, scale = mask.data_ptr(), (1.0 / (1.0 - pd) if pd < 1.0 else 0.0)
+            y = torch.empty((B, T, module.size_s), dtype=torch.float32, device=dev)
+            h.train_forward([p.data_ptr() for p in pc], xi.data_ptr(), xs.data_ptr(), mask_ptr, scale, p_drop, seed,
+                            y.data_ptr(), saved.data_ptr(), saved.numel(), B, T, torch.cuda.current_stream(dev).cuda_stream)
+        ctx.module, ctx.dims, ctx.p_drop, ctx.seed = module, (B, T), p_drop, seed
+        ctx.saved_stash = saved
+        if module.keep_train_stash:
+            module.last_train_stash = (saved, B, T)
+        ctx.save_for_backward(*params)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        module, (B, T) = ctx.module, ctx.dims
+        params = ctx.saved_tensors          # raises if a parameter was modified in place since the forward
+        h = module._ensure_handle()
+        dev = gy.device
+        with torch.cuda.device(dev):
+            saved = ctx.saved_stash
+            _, scratch_bytes = h.train_bytes(B, T)
+            if module._train_scratch is None or module._train_scratch.device != dev or \
+                    module._train_scratch.numel() < scratch_bytes:
+                module._train_scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+            total = sum(p.numel() for p in params)
+            flat = torch.empty(total, dtype=torch.float32, device=dev)
+            pc = [p.detach().contiguous() for p in params]
+            g = gy.to(torch.float32).contiguous()
+            h.train_backward([p.data_ptr() for p in pc], g.data_ptr(), saved.data_ptr(), saved.numel(),
+                             module._train_scratch.data_ptr(), module._train_scratch.numel(), flat.data_ptr(), total,
+                             ctx.p_drop, ctx.seed, B, T, torch.cuda.current_stream(dev).cuda_stream)
+        ctx.saved_stash = None
+        out, off = [], 0
+        for i, p in enumerate(params):
+            n = p.numel()
+            out.append(flat[off:off + n].view(p.shape) if ctx.needs_input_grad[6 + i] else None)
+            off += n
+        return (None, None, None, None, None, None, *out)
 
 
 class _HipForwardTorchBackward(torch.autograd.Function):
