@@ -19,6 +19,7 @@
 // Dropout (encoder p = 0.1, torch default, live in train mode): masks are never stored.  keep(site, idx) is a pure
 // function of (seed, site, element index) — splitmix64 finaliser, documented in include/tip_hip.h — evaluated in the
 // forward epilogues and again in the backward.  Tests rebuild the same masks in numpy.
+#include <stdlib.h>
 #include <string.h>
 
 #include "tip_internal.h"
@@ -92,9 +93,9 @@ struct TG {
     const float* res; long long ldres;                       // v += res[i][j]
 };
 
-template <int MODE>
+template <int MODE, int ROWS>
 struct TileLoader {
-    static constexpr int LDT = MODE ? 132 : 130;
+    static constexpr int LDT = ROWS + (MODE ? 4 : 2);
     float4 r0, r1;
     __device__ __forceinline__ void load(const float* P, long long ld, int r_base, int rows, int k0, int kvalid, int tid) {
         // explicit branches: a `cond ? *p : zero` select makes the compiler pick between two ADDRESSES and park the zero
@@ -106,14 +107,14 @@ struct TileLoader {
             const int ra = r_base + lr, rb = ra + 64, k = k0 + lk;
             if (k < kvalid) {
                 if (ra < rows) r0 = *reinterpret_cast<const float4*>(P + (long long)ra * ld + k);
-                if (rb < rows) r1 = *reinterpret_cast<const float4*>(P + (long long)rb * ld + k);
+                if (ROWS == 128 && rb < rows) r1 = *reinterpret_cast<const float4*>(P + (long long)rb * ld + k);
             }
         } else {
             const int kr = tid >> 4, ic = (tid & 15) * 4;
             const int k = k0 + kr, ia = r_base + ic, ib = ia + 64;
             if (k < kvalid) {
                 if (ia < rows) r0 = *reinterpret_cast<const float4*>(P + (long long)k * ld + ia);
-                if (ib < rows) r1 = *reinterpret_cast<const float4*>(P + (long long)k * ld + ib);
+                if (ROWS == 128 && ib < rows) r1 = *reinterpret_cast<const float4*>(P + (long long)k * ld + ib);
             }
         }
     }
@@ -121,36 +122,42 @@ struct TileLoader {
         if (MODE == 0) {
             const int lr = tid >> 2, lk = (tid & 3) * 4;
             S[lk + 0][lr] = r0.x; S[lk + 1][lr] = r0.y; S[lk + 2][lr] = r0.z; S[lk + 3][lr] = r0.w;
-            S[lk + 0][lr + 64] = r1.x; S[lk + 1][lr + 64] = r1.y; S[lk + 2][lr + 64] = r1.z; S[lk + 3][lr + 64] = r1.w;
+            if (ROWS == 128) {
+                S[lk + 0][lr + 64] = r1.x; S[lk + 1][lr + 64] = r1.y; S[lk + 2][lr + 64] = r1.z; S[lk + 3][lr + 64] = r1.w;
+            }
         } else {
             const int kr = tid >> 4, ic = (tid & 15) * 4;
             *reinterpret_cast<float4*>(&S[kr][ic]) = r0;
-            *reinterpret_cast<float4*>(&S[kr][ic + 64]) = r1;
+            if (ROWS == 128) *reinterpret_cast<float4*>(&S[kr][ic + 64]) = r1;
         }
     }
 };
 
-template <int AM, int BM>
+// TI x TJ block tile (64 or 128 each), 4 waves as 2 x 2, each wave (TI/2) x (TJ/2) as 32x32 MFMA tiles.  The small tiles
+// exist for the many GEMMs here whose output is only 256 wide: 10 240 x 256 is 160 tiles of 128 x 128 — fewer than the
+// chip has CUs, and one 4-wave workgroup per CU cannot hide its own LDS/MFMA latency.
+template <int AM, int BM, int TI, int TJ>
 __global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
-    constexpr int LDA_T = TileLoader<AM>::LDT, LDB_T = TileLoader<BM>::LDT;
+    constexpr int LDA_T = TileLoader<AM, TI>::LDT, LDB_T = TileLoader<BM, TJ>::LDT;
+    constexpr int NI = TI / 64, NJ = TJ / 64;
     __shared__ __attribute__((aligned(16))) float As[2][16][LDA_T];
     __shared__ __attribute__((aligned(16))) float Bs[2][16][LDB_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    const int i0 = blockIdx.y * TI, j0 = blockIdx.x * TJ;
     const int kbeg = blockIdx.z * g.klen;
     const int kend = min(g.kk, kbeg + g.klen);
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    TileLoader<AM> la;
-    TileLoader<BM> lb;
+    TileLoader<AM, TI> la;
+    TileLoader<BM, TJ> lb;
     const int l31 = lane & 31, lhi = lane >> 5;
     if (kbeg < kend) {
         la.load(g.A, g.lda, i0, g.mm, kbeg, g.kva, tid);
@@ -168,15 +175,15 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const int k = kk * 2 + lhi;
-                float a[2], b[2];
-                a[0] = As[cur][k][wm * 64 + l31];
-                a[1] = As[cur][k][wm * 64 + 32 + l31];
-                b[0] = Bs[cur][k][wn * 64 + l31];
-                b[1] = Bs[cur][k][wn * 64 + 32 + l31];
+                float a[NI], b[NJ];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < NI; ++i) a[i] = As[cur][k][wm * (TI / 2) + i * 32 + l31];
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) b[j] = Bs[cur][k][wn * (TJ / 2) + j * 32 + l31];
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
             if (more) {
                 la.stage(As[cur ^ 1], tid);
@@ -190,15 +197,15 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
     float* C = g.C + (long long)blockIdx.z * g.c_zstride;
     const bool plain = gridDim.z > 1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = j0 + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < NJ; ++j) {
+            const int col = j0 + wn * (TJ / 2) + j * 32 + l31;
             if (col >= g.nn) continue;
             const float bv = (!plain && g.bias) ? g.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = i0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                const int row = i0 + wm * (TI / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (row >= g.c_rows) continue;
                 float v = acc[i][j][r];
                 if (!plain) {
@@ -209,6 +216,131 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
                     if (g.res) v += g.res[(long long)row * g.ldres + col];
                 }
                 C[(long long)row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tgemm16: the (0,0) orientation — both operands k-contiguous, i.e. every forward GEMM and (with the transposed weight
+// copies prep makes once per step) every dX GEMM — on v_mfma_f32_16x16x4_f32.  Both tiles go to LDS as they are in
+// memory ([row][32 k], straight 16-byte copies, no transposing scatter) and one ds_read_b128 feeds four MFMA k-steps:
+// lane (row l15, group lg) holds k = 4*lg .. 4*lg+3 of each 16-wide k-block for A and for B alike, so MFMA step j
+// multiplies matching k's and the sum over (lg, j) covers the block (same trick as the fused inference kernels).
+// TI x TJ block tile, 4 waves as 2 x 2, BK = 32.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TI, int TJ>
+__global__ __launch_bounds__(256) void tgemm16_kernel(TG g) {
+    constexpr int BK = 32, LDK = BK + 4;
+    constexpr int RI = TI / 32, RJ = TJ / 32;          // 16-row blocks per wave in i and j
+    __shared__ __attribute__((aligned(16))) float As[2][TI][LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TJ][LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int i0 = blockIdx.y * TI, j0 = blockIdx.x * TJ;
+    constexpr int NA = TI * (BK / 4) / 256, NB = TJ * (BK / 4) / 256;   // float4 slots per thread
+    // global -> register prefetch runs TWO k-tiles ahead (two register sets), registers -> LDS one tile ahead: a load
+    // has two tiles of MFMA work to land before anything waits on it (one tile is ~0.4 us, less than an L2 round trip
+    // under load).
+    float4 ra[2][NA], rb[2][NB];
+
+    auto fetch = [&](int k0, float4 (&xa)[NA], float4 (&xb)[NB]) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int f = tid + u * 256, r = f >> 3, k = k0 + (f & 7) * 4;
+            xa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 < g.kk && i0 + r < g.mm && k < g.kva) xa[u] = *reinterpret_cast<const float4*>(g.A + (long long)(i0 + r) * g.lda + k);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int f = tid + u * 256, r = f >> 3, k = k0 + (f & 7) * 4;
+            xb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k0 < g.kk && j0 + r < g.nn && k < g.kvb) xb[u] = *reinterpret_cast<const float4*>(g.B + (long long)(j0 + r) * g.ldb + k);
+        }
+    };
+    auto stage = [&](int buf, const float4 (&xa)[NA], const float4 (&xb)[NB]) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int f = tid + u * 256;
+            *reinterpret_cast<float4*>(&As[buf][f >> 3][(f & 7) * 4]) = xa[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int f = tid + u * 256;
+            *reinterpret_cast<float4*>(&Bs[buf][f >> 3][(f & 7) * 4]) = xb[u];
+        }
+    };
+
+    f32x4 acc[RI][RJ];
+#pragma unroll
+    for (int i = 0; i < RI; ++i)
+#pragma unroll
+        for (int j = 0; j < RJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int cur) {
+#pragma unroll
+        for (int kb = 0; kb < BK / 16; ++kb) {
+            float4 a[RI], b[RJ];
+#pragma unroll
+            for (int i = 0; i < RI; ++i) a[i] = *reinterpret_cast<const float4*>(&As[cur][wm * (TI / 2) + i * 16 + l15][kb * 16 + lg * 4]);
+#pragma unroll
+            for (int j = 0; j < RJ; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[cur][wn * (TJ / 2) + j * 16 + l15][kb * 16 + lg * 4]);
+#pragma unroll
+            for (int i = 0; i < RI; ++i)
+#pragma unroll
+                for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RI; ++i)
+#pragma unroll
+                for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RI; ++i)
+#pragma unroll
+                for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RI; ++i)
+#pragma unroll
+                for (int j = 0; j < RJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // tiles: 0 -> LDS[0]; 1 -> registers set 1; then per pair of iterations the two register sets alternate
+    fetch(0, ra[0], rb[0]);
+    fetch(BK, ra[1], rb[1]);
+    stage(0, ra[0], rb[0]);
+    __syncthreads();
+    for (int k0 = 0; k0 < g.kk; k0 += 2 * BK) {
+        // even tile k0 lives in LDS[0]; set 1 holds tile k0+BK (in flight); set 0 is free
+        fetch(k0 + 2 * BK, ra[0], rb[0]);
+        compute(0);
+        if (k0 + BK < g.kk) stage(1, ra[1], rb[1]);
+        __syncthreads();
+        if (k0 + BK >= g.kk) break;
+        // odd tile k0+BK lives in LDS[1]; set 0 holds tile k0+2BK (in flight); set 1 is free
+        fetch(k0 + 3 * BK, ra[1], rb[1]);
+        compute(1);
+        if (k0 + 2 * BK < g.kk) stage(0, ra[0], rb[0]);
+        __syncthreads();
+    }
+    // epilogue.  C/D layout of 16x16: col = lane&15, row = 4*(lane>>4) + r.
+#pragma unroll
+    for (int j = 0; j < RJ; ++j) {
+        const int col = j0 + wn * (TJ / 2) + j * 16 + l15;
+        if (col >= g.nn) continue;
+        const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < RI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wm * (TI / 2) + i * 16 + lg * 4 + r;
+                if (row >= g.c_rows) continue;
+                float v = acc[i][j][r] + bv;
+                if (g.relu) v = v > 0.f ? v : 0.f;
+                v *= drop_factor(g.drop, (unsigned long long)row * (unsigned)g.nn + (unsigned)col);
+                if (g.gate) v *= g.gate[(long long)row * g.ldgate + col] > 0.f ? g.gate_scale : 0.f;
+                if (g.res) v += g.res[(long long)row * g.ldres + col];
+                g.C[(long long)row * g.ldc + col] = v;
             }
         }
     }
@@ -227,33 +359,77 @@ static TG tg_base(const float* A, long long lda, const float* B, long long ldb, 
     return g;
 }
 
-template <int AM, int BM>
-static hipError_t tgemm_launch(const TG& g, int splits, hipStream_t s) {
-    dim3 grid((g.nn + 127) / 128, (g.mm + 127) / 128, splits);
-    hipLaunchKernelGGL((tgemm_kernel<AM, BM>), grid, dim3(256), 0, s, g);
+static int g_tgemm_cus = 256;   // set from the handle before the first launch of a pass
+
+// (0,0) orientation, no split: 16x16x4 kernel.  kk is padded to the 32-wide k tile (k beyond kva/kvb reads as zero).
+// Tile: 64 x 64 always — measured on MI355X at M = 10 240 it beats 64 x 128 and 128 x 128 for every shape of this model
+// (N = 256 .. 1024, K = 144 .. 1024): 640+ small workgroups, four resident per CU, hide each other's barrier and
+// LDS latency better than fewer big ones.  TIP_TGEMM16_TILE = 1 / 2 forces 128x128 / 64x128 for measurement.
+static hipError_t tgemm16_launch(TG g, hipStream_t s) {
+    g.kk = round_up(g.kk, 32);
+    static int force = -1;
+    if (force < 0) force = getenv("TIP_TGEMM16_TILE") ? atoi(getenv("TIP_TGEMM16_TILE")) : 0;
+    if (force == 1) {
+        hipLaunchKernelGGL((tgemm16_kernel<128, 128>), dim3((g.nn + 127) / 128, (g.mm + 127) / 128), dim3(256), 0, s, g);
+    } else if (force == 2) {
+        hipLaunchKernelGGL((tgemm16_kernel<64, 128>), dim3((g.nn + 127) / 128, (g.mm + 63) / 64), dim3(256), 0, s, g);
+    } else {
+        hipLaunchKernelGGL((tgemm16_kernel<64, 64>), dim3((g.nn + 63) / 64, (g.mm + 63) / 64), dim3(256), 0, s, g);
+    }
     return hipGetLastError();
 }
 
-// out[i] = sum_z part[z*stride + i]
+template <int AM, int BM>
+static hipError_t tgemm_launch(const TG& g, int splits, hipStream_t s) {
+    auto blocks = [&](int ti, int tj) { return (long long)((g.mm + ti - 1) / ti) * ((g.nn + tj - 1) / tj) * splits; };
+    const long long want = 2LL * g_tgemm_cus;
+    static int force = -1;   // measurement only: TIP_TGEMM_TILE = 1 (128x128) / 2 (64x128) / 3 (64x64)
+    if (force < 0) force = getenv("TIP_TGEMM_TILE") ? atoi(getenv("TIP_TGEMM_TILE")) : 0;
+    if (force == 1 || (force == 0 && blocks(128, 128) >= want)) {
+        hipLaunchKernelGGL((tgemm_kernel<AM, BM, 128, 128>), dim3((g.nn + 127) / 128, (g.mm + 127) / 128, splits), dim3(256), 0, s, g);
+    } else if (force == 2 || (force == 0 && blocks(64, 128) >= want)) {
+        hipLaunchKernelGGL((tgemm_kernel<AM, BM, 64, 128>), dim3((g.nn + 127) / 128, (g.mm + 63) / 64, splits), dim3(256), 0, s, g);
+    } else {
+        hipLaunchKernelGGL((tgemm_kernel<AM, BM, 64, 64>), dim3((g.nn + 63) / 64, (g.mm + 63) / 64, splits), dim3(256), 0, s, g);
+    }
+    return hipGetLastError();
+}
+
+// out[i] = sum_z part[z*stride + i]   (z summed in order; four partial chains only to keep loads in flight)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, long long stride, int Z,
                                                             float* __restrict__ out, long long n) {
     const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i4 >= n) return;
     if (i4 + 3 < n) {
-        float4 a = *reinterpret_cast<const float4*>(part + i4);
-        for (int z = 1; z < Z; ++z) {
-            const float4 b = *reinterpret_cast<const float4*>(part + z * stride + i4);
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        float4 a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int z = 0;
+        for (; z + 3 < Z; z += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 b = *reinterpret_cast<const float4*>(part + (z + u) * stride + i4);
+                a[u].x += b.x; a[u].y += b.y; a[u].z += b.z; a[u].w += b.w;
+            }
         }
+        for (; z < Z; ++z) {
+            const float4 b = *reinterpret_cast<const float4*>(part + z * stride + i4);
+            a[0].x += b.x; a[0].y += b.y; a[0].z += b.z; a[0].w += b.w;
+        }
+        float4 r;
+        r.x = (a[0].x + a[1].x) + (a[2].x + a[3].x);
+        r.y = (a[0].y + a[1].y) + (a[2].y + a[3].y);
+        r.z = (a[0].z + a[1].z) + (a[2].z + a[3].z);
+        r.w = (a[0].w + a[1].w) + (a[2].w + a[3].w);
         if ((reinterpret_cast<uintptr_t>(out + i4) & 15) == 0) {
-            *reinterpret_cast<float4*>(out + i4) = a;
+            *reinterpret_cast<float4*>(out + i4) = r;
         } else {
-            out[i4] = a.x; out[i4 + 1] = a.y; out[i4 + 2] = a.z; out[i4 + 3] = a.w;
+            out[i4] = r.x; out[i4 + 1] = r.y; out[i4 + 2] = r.z; out[i4 + 3] = r.w;
         }
     } else {
         for (long long i = i4; i < n; ++i) {
-            float a = part[i];
-            for (int z = 1; z < Z; ++z) a += part[z * stride + i];
+            float a = 0.f;
+            for (int z = 0; z < Z; ++z) a += part[z * stride + i];
             out[i] = a;
         }
     }
@@ -266,7 +442,7 @@ static hipError_t grad_weight(const float* dY, long long ldy, int n_rows_pad, in
     TG g = tg_base(dY, ldy, X, ldx, part, K, n_rows_pad, K, M);
     g.c_rows = n_store;
     const int tiles = ((K + 127) / 128) * ((n_rows_pad + 127) / 128);
-    int splits = (2 * num_cus + tiles - 1) / tiles;
+    int splits = (2 * num_cus + tiles - 1) / tiles;   // >= 2 x CUs blocks so that tgemm_launch keeps the 128 x 128 tile
     const long long per = (long long)n_store * K;
     const long long stride = (per + 3) / 4 * 4;
     if ((long long)splits * stride > (long long)part_floats) splits = (int)((long long)part_floats / stride);
@@ -290,29 +466,53 @@ static hipError_t grad_weight(const float* dY, long long ldy, int n_rows_pad, in
 // ---------------------------------------------------------------------------------------------------------------------
 // column sums (bias gradients): out[n] = sum_m X[m*ld + n]; two deterministic stages
 // ---------------------------------------------------------------------------------------------------------------------
+// block = 64 columns x 4 row lanes; grid (ceil(N/64), Z)
 __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, long long ld, int M, int N,
                                                           int rows_per, float* __restrict__ part) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
     const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
-    float a0 = 0.f, a1 = 0.f;
-    int m = m0;
-    for (; m + 1 < m1; m += 2) {
-        a0 += X[(long long)m * ld + n];
-        a1 += X[(long long)(m + 1) * ld + n];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (n < N) {
+        int m = m0 + rl;
+        for (; m + 12 < m1; m += 16) {
+            a0 += X[(long long)m * ld + n];
+            a1 += X[(long long)(m + 4) * ld + n];
+            a2 += X[(long long)(m + 8) * ld + n];
+            a3 += X[(long long)(m + 12) * ld + n];
+        }
+        for (; m < m1; m += 4) a0 += X[(long long)m * ld + n];
     }
-    if (m < m1) a0 += X[(long long)m * ld + n];
-    part[(long long)blockIdx.y * N + n] = a0 + a1;
+    red[rl][c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rl == 0 && n < N) part[(long long)blockIdx.y * N + n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
+// out[n] = sum_z part[z][n]; block = 64 columns x 4 z lanes
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, int Z, int N, float* __restrict__ out,
                                                         float* __restrict__ out2) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float a = 0.f;
-    for (int z = 0; z < Z; ++z) a += part[(long long)z * N + n];
-    out[n] = a;
-    if (out2) out2[n] = a;
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (n < N) {
+        int z = zl;
+        for (; z + 12 < Z; z += 16) {
+            a0 += part[(long long)z * N + n];
+            a1 += part[(long long)(z + 4) * N + n];
+            a2 += part[(long long)(z + 8) * N + n];
+            a3 += part[(long long)(z + 12) * N + n];
+        }
+        for (; z < Z; z += 4) a0 += part[(long long)z * N + n];
+    }
+    red[zl][c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (zl == 0 && n < N) {
+        const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        out[n] = v;
+        if (out2) out2[n] = v;
+    }
 }
 
 constexpr int kColZ = 64;
@@ -320,8 +520,8 @@ constexpr int kColZ = 64;
 static hipError_t colsum(const float* X, long long ld, int M, int N, float* part, float* out, float* out2, hipStream_t s) {
     const int rows_per = (M + kColZ - 1) / kColZ;
     const int Z = (M + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 255) / 256, Z), dim3(256), 0, s, X, ld, M, N, rows_per, part);
-    hipLaunchKernelGGL(colreduce_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, Z, N, out, out2);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, Z), dim3(256), 0, s, X, ld, M, N, rows_per, part);
+    hipLaunchKernelGGL(colreduce_kernel, dim3((N + 63) / 64), dim3(256), 0, s, part, Z, N, out, out2);
     return hipGetLastError();
 }
 
@@ -669,6 +869,45 @@ __global__ __launch_bounds__(256) void finish_in_kernel(const float* __restrict_
     }
 }
 
+// transposed weight copies for the dX GEMMs (dX = dY W reads W "the other way"): one launch for all of them.
+// dst[c][r] = src[r][c] for r < rows, 0 for rows <= r < ldd (k padding), dst row stride ldd.
+constexpr int kMaxTr = 64;
+struct TrDesc {
+    const float* src;
+    float* dst;
+    int rows, cols, ldd, tile0, tiles_c;
+};
+struct TrBatch {
+    TrDesc d[kMaxTr];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void transpose_batch_kernel(TrBatch tb) {
+    __shared__ float tile[32][33];
+    int di = 0;
+    while (di + 1 < tb.n && (int)blockIdx.x >= tb.d[di + 1].tile0) ++di;
+    const TrDesc& t = tb.d[di];
+    const int lt = blockIdx.x - t.tile0;
+    const int tr = lt / t.tiles_c, tc = lt % t.tiles_c;       // tile row (over padded rows) / tile col
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int y = ty; y < 32; y += 8) {
+        const int r = tr * 32 + y, c = tc * 32 + tx;
+        tile[y][tx] = (r < t.rows && c < t.cols) ? t.src[(size_t)r * t.cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int y = ty; y < 32; y += 8) {
+        const int c = tc * 32 + y, r = tr * 32 + tx;
+        if (c < t.cols && r < t.ldd) t.dst[(size_t)c * t.ldd + r] = tile[tx][y];
+    }
+}
+
+static void tr_add(TrBatch& tb, int& tiles, const float* src, float* dst, int rows, int cols, int ldd) {
+    TrDesc& t = tb.d[tb.n++];
+    t.src = src; t.dst = dst; t.rows = rows; t.cols = cols; t.ldd = ldd; t.tile0 = tiles;
+    t.tiles_c = (cols + 31) / 32;
+    tiles += ((ldd + 31) / 32) * t.tiles_c;
+}
+
 static int grid_for(long long n) {
     long long b = (n + 255) / 256;
     if (b > 4096) b = 4096;
@@ -681,9 +920,11 @@ static int grid_for(long long n) {
 // ---------------------------------------------------------------------------------------------------------------------
 struct TrainLayer {
     size_t qkv, ast, att, z1, st1, x1, hid, z2, st2, xo;
+    size_t wqkv_t, wo_t, w1_t, w2_t;   // transposed weight copies (prep) for the dX GEMMs
 };
 struct TrainSaved {
     size_t win_p, bin_p, bsum, whh_f, whh_b, U, x0, ih, hall, flags;
+    size_t wout_t, wih_t;
     std::vector<TrainLayer> layers;
     size_t total;
 };
@@ -708,6 +949,8 @@ static TrainSaved saved_layout(const Dims& d, int B, int T) {
     L.bsum = take(off, d.R);
     L.whh_f = take(off, (size_t)d.R * d.R);
     L.whh_b = take(off, (size_t)d.R * d.R);
+    L.wout_t = take(off, (size_t)d.R * round_up(d.S, 16));
+    L.wih_t = take(off, (size_t)d.D * d.R);
     L.U = take(off, M * d.InPad);
     L.x0 = take(off, M * d.D);
     for (int l = 0; l < d.L; ++l) {
@@ -722,6 +965,10 @@ static TrainSaved saved_layout(const Dims& d, int B, int T) {
         t.z2 = take(off, M * d.D);
         t.st2 = take(off, M * 2);
         t.xo = take(off, M * d.D);
+        t.wqkv_t = take(off, (size_t)3 * d.D * d.D);
+        t.wo_t = take(off, (size_t)d.D * d.D);
+        t.w1_t = take(off, (size_t)d.F * d.D);
+        t.w2_t = take(off, (size_t)d.F * d.D);
         L.layers.push_back(t);
     }
     L.ih = take(off, M * d.R);
@@ -764,7 +1011,7 @@ static bool train_supported(const Dims& d, int B, int T) {
     if (!d.with_rnn || d.R != 512) return false;
     if (d.D % 256 != 0 || d.D > 1024 || (d.D / 256 == 3)) return false;
     if (d.dh != 16 && d.dh != 32 && d.dh != 64) return false;
-    if (d.F % 4 != 0 || T < 1 || T > 128 || B < 1) return false;
+    if (d.F % 4 != 0 || T < 1 || T > 128 || B < 1 || 4 * d.L + 2 > kMaxTr) return false;
     if ((long long)B * T * 512 * 4 > 0x7fffffffLL) return false;
     return true;
 }
@@ -852,6 +1099,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     const TrainSaved L = saved_layout(d, B, T);
     if (reinterpret_cast<uintptr_t>(saved) % 256 || saved_bytes < L.total * sizeof(float)) return TIP_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    g_tgemm_cus = h->num_cus;
     float* W = static_cast<float*>(saved);
     const int M = B * T;
     const float* const* rp = params + P_LAYER0 + PL_COUNT * d.L;
@@ -860,12 +1108,28 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
                        W + L.win_p, W + L.bin_p, d.D, d.H, d.In, d.InPad, d.n_imu_total + d.rootv0, d.n_imu_total + d.rootv1);
     hipLaunchKernelGGL(prep_rnn_kernel, dim3(grid_for((long long)d.R * d.R)), dim3(256), 0, s, rp[PR_WHH], rp[PR_BIH], rp[PR_BHH],
                        W + L.whh_f, W + L.whh_b, W + L.bsum, d.R);
+    {
+        TrBatch tb;
+        tb.n = 0;
+        int tiles = 0;
+        tr_add(tb, tiles, rp[PR_LIN_W], W + L.wout_t, d.S, d.R, round_up(d.S, 16));
+        tr_add(tb, tiles, rp[PR_WIH], W + L.wih_t, d.R, d.D, d.R);
+        for (int l = 0; l < d.L; ++l) {
+            const float* const* lp = params + P_LAYER0 + PL_COUNT * l;
+            const TrainLayer& t = L.layers[l];
+            tr_add(tb, tiles, lp[PL_QKV_W], W + t.wqkv_t, 3 * d.D, d.D, 3 * d.D);
+            tr_add(tb, tiles, lp[PL_OUT_W], W + t.wo_t, d.D, d.D, d.D);
+            tr_add(tb, tiles, lp[PL_L1_W], W + t.w1_t, d.F, d.D, d.F);
+            tr_add(tb, tiles, lp[PL_L2_W], W + t.w2_t, d.D, d.F, d.D);
+        }
+        hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(256), 0, s, tb);
+    }
     TT(hipGetLastError(), "train_prep");
     TT(launch_prologue(d, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f, W + L.U, M, s), "train_prologue");
     {
         TG g = tg_base(W + L.U, d.InPad, W + L.win_p, d.InPad, W + L.x0, d.D, M, d.D, d.InPad);
         g.bias = W + L.bin_p;
-        TT((tgemm_launch<0, 0>(g, 1, s)), "train_in_linear");
+        TT(tgemm16_launch(g, s), "train_in_linear");
     }
     const float* x = W + L.x0;
     for (int l = 0; l < d.L; ++l) {
@@ -874,7 +1138,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         {
             TG g = tg_base(x, d.D, lp[PL_QKV_W], d.D, W + t.qkv, 3 * d.D, M, 3 * d.D, d.D);
             g.bias = lp[PL_QKV_B];
-            TT((tgemm_launch<0, 0>(g, 1, s)), "train_qkv");
+            TT(tgemm16_launch(g, s), "train_qkv");
         }
         {
             const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 0));
@@ -896,7 +1160,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
             g.bias = lp[PL_OUT_B];
             g.drop = make_drop(p_drop, seed, (unsigned)(l * 4 + 1));
             g.res = x; g.ldres = d.D;
-            TT((tgemm_launch<0, 0>(g, 1, s)), "train_out_proj");
+            TT(tgemm16_launch(g, s), "train_out_proj");
         }
         {
             const float* z = W + t.z1;
@@ -913,14 +1177,14 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
             g.bias = lp[PL_L1_B];
             g.relu = 1;
             g.drop = make_drop(p_drop, seed, (unsigned)(l * 4 + 2));
-            TT((tgemm_launch<0, 0>(g, 1, s)), "train_ffn1");
+            TT(tgemm16_launch(g, s), "train_ffn1");
         }
         {
             TG g = tg_base(W + t.hid, d.F, lp[PL_L2_W], d.F, W + t.z2, d.D, M, d.D, d.F);
             g.bias = lp[PL_L2_B];
             g.drop = make_drop(p_drop, seed, (unsigned)(l * 4 + 3));
             g.res = W + t.x1; g.ldres = d.D;
-            TT((tgemm_launch<0, 0>(g, 1, s)), "train_ffn2");
+            TT(tgemm16_launch(g, s), "train_ffn2");
         }
         {
             const float* z = W + t.z2;
@@ -937,14 +1201,14 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     {
         TG g = tg_base(x, d.D, rp[PR_WIH], d.D, W + L.ih, d.R, M, d.R, d.D);
         g.bias = W + L.bsum;
-        TT((tgemm_launch<0, 0>(g, 1, s)), "train_rnn_ih");
+        TT(tgemm16_launch(g, s), "train_rnn_ih");
     }
     TT(launch_rnn(d, W + L.ih, W + L.whh_f, W + L.hall, reinterpret_cast<unsigned*>(W + L.flags), B, T, auto_cluster(B, h->num_cus),
                   h->num_cus, false, s), "train_rnn");
     {
         TG g = tg_base(W + L.hall, d.R, rp[PR_LIN_W], d.R, y, d.S, M, d.S, d.R);
         g.bias = rp[PR_LIN_B];
-        TT((tgemm_launch<0, 0>(g, 1, s)), "train_head");
+        TT(tgemm16_launch(g, s), "train_head");
     }
     h->forward_count++;
     return TIP_OK;
@@ -971,13 +1235,13 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     }
     if (grads_floats < gtot) return TIP_ERR_INVALID_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    g_tgemm_cus = h->num_cus;
     const float* W = static_cast<const float*>(saved);
     float* X = static_cast<float*>(scratch);
     const int M = B * T;
     const int Sp = round_up(d.S, 16);
     const int ncu = h->num_cus;
     const int rbase = P_LAYER0 + PL_COUNT * d.L;
-    const float* const* rp = params + rbase;
     float* part = X + S.part;
     float* colpart = X + S.colpart;
 
@@ -988,9 +1252,8 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     TT(grad_weight(X + S.dyp, Sp, Sp, d.S, W + L.hall, d.R, d.R, M, part, S.part_floats, grads + goff[rbase + PR_LIN_W], ncu, s),
        "bwd_dW_out");
     {
-        TG g = tg_base(X + S.dyp, Sp, rp[PR_LIN_W], d.R, X + S.dh, d.R, M, d.R, Sp);
-        g.kvb = d.S;
-        TT((tgemm_launch<0, 1>(g, 1, s)), "bwd_dH");
+        TG g = tg_base(X + S.dyp, Sp, W + L.wout_t, Sp, X + S.dh, d.R, M, d.R, Sp);
+        TT(tgemm16_launch(g, s), "bwd_dH");
     }
     // ---- recurrence (:98-99), time reversed: delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2) -------------------------
     TT(launch_rnn_bwd(d, X + S.dh, W + L.whh_b, W + L.hall, X + S.delta, reinterpret_cast<unsigned*>(const_cast<float*>(W + L.flags)),
@@ -1007,8 +1270,8 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     float* gx = X + S.ga;     // gradient w.r.t. the current layer's output
     float* galt = X + S.gb;
     {
-        TG g = tg_base(X + S.delta, d.R, rp[PR_WIH], d.D, gx, d.D, M, d.D, d.R);
-        TT((tgemm_launch<0, 1>(g, 1, s)), "bwd_d_enc");
+        TG g = tg_base(X + S.delta, d.R, W + L.wih_t, d.R, gx, d.D, M, d.D, d.R);
+        TT(tgemm16_launch(g, s), "bwd_d_enc");
     }
     // ---- encoder layers, last to first -----------------------------------------------------------------------------------
     for (int l = d.L - 1; l >= 0; --l) {
@@ -1028,7 +1291,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
                                       dzm, dr, colpart, M);
                    return hipGetLastError();
                }), "bwd_ln2");
-            hipLaunchKernelGGL(colreduce_kernel, dim3((2 * d.D + 255) / 256), dim3(256), 0, s, colpart, nln, 2 * d.D,
+            hipLaunchKernelGGL(colreduce_kernel, dim3((2 * d.D + 63) / 64), dim3(256), 0, s, colpart, nln, 2 * d.D,
                                grads + goff[pb + PL_N2_W], nullptr);
             TT(hipGetLastError(), "bwd_ln2_params");
         }
@@ -1038,19 +1301,19 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
            "bwd_dW2");
         {
             // d(pre-ReLU) = (dff2 W2) * [hid > 0] / (1 - p)   (hid is saved AFTER ReLU and dropout)
-            TG g = tg_base(X + S.gc, d.D, lp[PL_L2_W], d.F, X + S.gbig, d.F, M, d.F, d.D);
+            TG g = tg_base(X + S.gc, d.D, W + t.w2_t, d.D, X + S.gbig, d.F, M, d.F, d.D);
             g.gate = W + t.hid; g.ldgate = d.F;
             g.gate_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.f;
-            TT((tgemm_launch<0, 1>(g, 1, s)), "bwd_dhid");
+            TT(tgemm16_launch(g, s), "bwd_dhid");
         }
         TT(colsum(X + S.gbig, d.F, M, d.F, colpart, grads + goff[pb + PL_L1_B], nullptr, s), "bwd_db1");
         TT(grad_weight(X + S.gbig, d.F, d.F, d.F, W + t.x1, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_L1_W], ncu, s),
            "bwd_dW1");
         {
             // dx1 = dz2 + dpre W1   -> gx
-            TG g = tg_base(X + S.gbig, d.F, lp[PL_L1_W], d.D, gx, d.D, M, d.D, d.F);
+            TG g = tg_base(X + S.gbig, d.F, W + t.w1_t, d.F, gx, d.D, M, d.D, d.F);
             g.res = galt; g.ldres = d.D;
-            TT((tgemm_launch<0, 1>(g, 1, s)), "bwd_dx1");
+            TT(tgemm16_launch(g, s), "bwd_dx1");
         }
         // LN1: gx -> dz1 (galt), datt_o = dz1 * keep1 (gc)
         {
@@ -1063,7 +1326,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
                                       dzm, dr, colpart, M);
                    return hipGetLastError();
                }), "bwd_ln1");
-            hipLaunchKernelGGL(colreduce_kernel, dim3((2 * d.D + 255) / 256), dim3(256), 0, s, colpart, nln, 2 * d.D,
+            hipLaunchKernelGGL(colreduce_kernel, dim3((2 * d.D + 63) / 64), dim3(256), 0, s, colpart, nln, 2 * d.D,
                                grads + goff[pb + PL_N1_W], nullptr);
             TT(hipGetLastError(), "bwd_ln1_params");
         }
@@ -1071,8 +1334,8 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
         TT(grad_weight(X + S.gc, d.D, d.D, d.D, W + t.att, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_OUT_W], ncu, s),
            "bwd_dWo");
         {
-            TG g = tg_base(X + S.gc, d.D, lp[PL_OUT_W], d.D, X + S.datt, d.D, M, d.D, d.D);
-            TT((tgemm_launch<0, 1>(g, 1, s)), "bwd_datt");
+            TG g = tg_base(X + S.gc, d.D, W + t.wo_t, d.D, X + S.datt, d.D, M, d.D, d.D);
+            TT(tgemm16_launch(g, s), "bwd_datt");
         }
         {
             const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 0));
@@ -1096,9 +1359,9 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
            "bwd_dWqkv");
         {
             // dx_in = dz1 + dqkv W_qkv   -> gx
-            TG g = tg_base(X + S.gbig, 3 * d.D, lp[PL_QKV_W], d.D, gx, d.D, M, d.D, 3 * d.D);
+            TG g = tg_base(X + S.gbig, 3 * d.D, W + t.wqkv_t, 3 * d.D, gx, d.D, M, d.D, 3 * d.D);
             g.res = galt; g.ldres = d.D;
-            TT((tgemm_launch<0, 1>(g, 1, s)), "bwd_dx_in");
+            TT(tgemm16_launch(g, s), "bwd_dx_in");
         }
     }
     // ---- in_linear (:79) ---------------------------------------------------------------------------------------------------
