@@ -158,3 +158,39 @@ def test_batch_256_step_runs_and_matches_composite_on_gpu():
         ref = p.grad.detach().cpu().numpy().astype(np.float64)
         err = np.linalg.norm(g[n] - ref) / (np.linalg.norm(ref) + 1e-30)
         assert err < 1e-3, (n, err)
+
+
+@pytest.mark.parametrize("name,over,B,T", [
+    ("scaled width, 2 layers, T=80", dict(tf_layers=2), 3, 80),                       # D=1024, dh=64, F=4096 (configs[4])
+    ("D=512, dh=32, no acc-sum", dict(tf_in_dim=512, tf_hid_size=768, tf_layers=1, with_acc_sum=False), 5, 33),
+])
+def test_other_configurations(name, over, B, T):
+    """The training kernels are not specialised to the paper configuration: wider models (BASELINE.json configs[4]) and
+    other head widths go through the same code with different template arguments."""
+    cfg = dict(synth.SCALED, **over)
+    m, w = _train_model(cfg, 4, 0.1)
+    seed = 42
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=17)
+    cot = synth.normal(11, "cot", B * T * cfg["size_s"]).reshape(B, T, -1).astype(np.float32)
+    y, g, _ = _hip_step(m, x_imu, x_s, cot, seed=seed)
+    yo, go = train_oracle.step(cfg, w, x_imu, x_s, cot, p_drop=0.1, seed=seed, relu_gates=_gates(m, cfg, B, T))
+    assert np.abs(y - yo).max() < 5e-5, np.abs(y - yo).max()
+    print(name, "worst tensor", _check_grads(g, go, rel=2e-5))
+
+
+def test_unsupported_configuration_falls_back_to_the_composite():
+    """rnn_hid_size != 512 is outside the HIP training path: the module differentiates its torch-op composite instead
+    (and says so), results still match the oracle."""
+    cfg = synth.TINY
+    m, w = _train_model(cfg, 0, 0.0)
+    x_imu, x_s = synth.make_inputs(cfg, 2, 12, seed=2)
+    cot = np.ones((2, 12, cfg["size_s"]), dtype=np.float32)
+    with pytest.warns(UserWarning, match="torch-op training composite"):
+        y = m(torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda())
+    assert not type(y.grad_fn).__name__.startswith("_HipTrainFunction")
+    (y * torch.tensor(cot).cuda()).sum().backward()
+    yo, go = train_oracle.step(cfg, w, x_imu, x_s, cot)
+    assert np.abs(y.detach().cpu().numpy() - yo).max() < 2e-5
+    for n, p in m.named_parameters():
+        err = np.linalg.norm(p.grad.cpu().numpy() - go[n]) / (np.linalg.norm(go[n]) + 1e-30)
+        assert err < 1e-3, (n, err)
