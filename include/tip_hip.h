@@ -163,6 +163,23 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
                        size_t saved_bytes, void* scratch, size_t scratch_bytes, float* grads, size_t grads_floats, float p_drop,
                        unsigned long long seed, int B, int T, tip_stream_t stream);
 
+/* ---- train-set combiner and window gather -------------------------------------------------
+ * tip_combine_sequence replaces the per-file body of store_imu_s_info (preprocess_and_combine_syn_amass.py:73-101):
+ *   imu [L_imu,72], s = nimble_qdq [L_s,114], c = constrs [>=min(L),20]: fp64 DEVICE arrays as unpickled; bias [18] = the
+ *   constant accelerometer bias the caller drew (:85); nan_root_vel = 1 for augmented-DIP files (:61-62).
+ *   Writes float32 rows imu_out [n,72], sum_out [n,18], s_out [n,131] and returns n = min(L_imu, L_s) - 8, or 0 when the
+ *   file is too short (min(L) <= 40, :68-70: nothing written), or a negative tip_status.
+ * tip_gather_windows replaces TrainSubDataset's window slicing (training_data_loader.py:53-58,72-86): for each sampled
+ *   end frame t_idx[i] (device int64, seq_length <= t < n_frames): x_imu[i] = [IMU[t-T:t] | SUM[t-T:t]] ([T,90]; [T,72]
+ *   when sum_c is NULL), x_s[i] = S[t-T:t], y[i] = S[t-T+1:t+1]. */
+int tip_combine_frames(int L_imu, int L_s);
+int tip_combine_scratch_bytes(int L_imu, int L_s, size_t* bytes);
+int tip_combine_sequence(const double* imu, const double* s, const double* c, int L_imu, int L_s, const double* bias,
+                         int nan_root_vel, float* imu_out, float* sum_out, float* s_out, void* scratch, size_t scratch_bytes,
+                         tip_stream_t stream);
+int tip_gather_windows(const float* imu_c, const float* sum_c, const float* s_c, long long n_frames, const long long* t_idx,
+                       int n, int T, float* x_imu, float* x_s, float* y, tip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@ EXPORTS = (
     "tip_attach_packed", "tip_workspace_bytes", "tip_forward", "tip_forward_count", "tip_profile_read",
     "tip_spin_timeouts", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
     "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward",
+    "tip_combine_frames", "tip_combine_scratch_bytes", "tip_combine_sequence", "tip_gather_windows",
 )
 
 
@@ -105,6 +106,10 @@ def load() -> ctypes.CDLL:
     lib.tip_train_saved_view.argtypes = [vp, i32, i32, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.tip_train_forward.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, vp, f32, f32, u64, vp, vp, sz, i32, i32, vp]
     lib.tip_train_backward.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, sz, vp, sz, vp, sz, f32, u64, i32, i32, vp]
+    lib.tip_combine_frames.argtypes = [i32, i32]
+    lib.tip_combine_scratch_bytes.argtypes = [i32, i32, ctypes.POINTER(sz)]
+    lib.tip_combine_sequence.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
+    lib.tip_gather_windows.argtypes = [vp, vp, vp, ctypes.c_longlong, vp, i32, i32, vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("tip_destroy", "tip_strerror", "tip_last_hip_error"):
             getattr(lib, name).restype = i32
