@@ -169,6 +169,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const float* __restrict__ A, 
 hipError_t launch_gemm(const float* A, int lda, const float* W, int Kpad, const float* bias, const float* res,
                        int ldres, float* C, int ldc, int M, int N, int Npad, int flags, hipStream_t s) {
     if (M <= 0) return hipSuccess;
+    // default: the 16x16x4 / 64x64-tile kernel of tip_train.hip (measured: paper B=256 general plan 1.27 vs 1.59 ms, scaled
+    // B=128 32.3 vs 35.5 ms, scaled B=512 equal); TIP_GENERAL_GEMM=32 selects the 128x128 32x32x2 kernel below
+    static int use16 = -1;
+    if (use16 < 0) use16 = (getenv("TIP_GENERAL_GEMM") && atoi(getenv("TIP_GENERAL_GEMM")) == 32) ? 0 : 1;
+    if (use16) return launch_gemm16(A, lda, W, Kpad, bias, res, ldres, C, ldc, M, N, Kpad, flags, s);
     dim3 grid(Npad / kGemmBN, (M + kGemmBM - 1) / kGemmBM);
     dim3 block(256);
     switch (flags & 3) {

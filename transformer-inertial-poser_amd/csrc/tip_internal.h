@@ -105,6 +105,9 @@ hipError_t launch_prologue(const Dims& d, const float* x_imu, const float* x_s, 
 // C[M,N] = epi(A[M,K(lda)] * W[Npad,Kpad]^T + bias (+ res)); flags: 1 = relu, 2 = residual
 hipError_t launch_gemm(const float* A, int lda, const float* W, int Kpad, const float* bias, const float* res,
                        int ldres, float* C, int ldc, int M, int N, int Npad, int flags, hipStream_t s);
+// same contract on the 16x16x4 / 64x64-tile kernel of tip_train.hip (K = reduction length, multiple of 4)
+hipError_t launch_gemm16(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldres,
+                         float* C, int ldc, int M, int N, int K, int flags, hipStream_t s);
 hipError_t launch_attention(const Dims& d, const float* qkv, float* out, int B, int T, hipStream_t s);
 hipError_t launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s);
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,

@@ -1026,6 +1026,21 @@ static hipError_t ln_dispatch(int D, K&& k) {
     }
 }
 
+// C[M,N] = epi(A[M,K(lda)] * W[N(+pad),K(ldw)]^T + bias (+ res)); flags: 1 = relu, 2 = residual — the general plan's GEMM
+// contract (tip_general.hip launch_gemm) on the 16x16x4 straight-copy kernel.
+hipError_t launch_gemm16(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldres,
+                         float* C, int ldc, int M, int N, int K, int flags, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    TG g = tg_base(A, lda, W, ldw, C, ldc, M, N, K);
+    g.bias = bias;
+    g.relu = flags & 1;
+    if (flags & 2) {
+        g.res = res;
+        g.ldres = ldres;
+    }
+    return tgemm16_launch(g, s);
+}
+
 static int auto_cluster(int B, int num_cus) {
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
     int c = 16;
