@@ -229,17 +229,18 @@ __global__ __launch_bounds__(256) void tgemm_kernel(TG g) {
 // multiplies matching k's and the sum over (lg, j) covers the block (same trick as the fused inference kernels).
 // TI x TJ block tile, 4 waves as 2 x 2, BK = 32.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TI, int TJ>
-__global__ __launch_bounds__(256) void tgemm16_kernel(TG g) {
+template <int TI, int TJ, int WI = 2, int WJ = 2>
+__global__ __launch_bounds__(64 * WI * WJ) void tgemm16_kernel(TG g) {
     constexpr int BK = 32, LDK = BK + 4;
-    constexpr int RI = TI / 32, RJ = TJ / 32;          // 16-row blocks per wave in i and j
+    constexpr int THREADS = 64 * WI * WJ;
+    constexpr int RI = TI / (16 * WI), RJ = TJ / (16 * WJ);   // 16-row blocks per wave in i and j
     __shared__ __attribute__((aligned(16))) float As[2][TI][LDK];
     __shared__ __attribute__((aligned(16))) float Bs[2][TJ][LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WJ, wn = wave % WJ;
     const int l15 = lane & 15, lg = lane >> 4;
     const int i0 = blockIdx.y * TI, j0 = blockIdx.x * TJ;
-    constexpr int NA = TI * (BK / 4) / 256, NB = TJ * (BK / 4) / 256;   // float4 slots per thread
+    constexpr int NA = TI * (BK / 4) / THREADS, NB = TJ * (BK / 4) / THREADS;   // float4 slots per thread
     // global -> register prefetch runs TWO k-tiles ahead (two register sets), registers -> LDS one tile ahead: a load
     // has two tiles of MFMA work to land before anything waits on it (one tile is ~0.4 us, less than an L2 round trip
     // under load).
@@ -248,13 +249,13 @@ __global__ __launch_bounds__(256) void tgemm16_kernel(TG g) {
     auto fetch = [&](int k0, float4 (&xa)[NA], float4 (&xb)[NB]) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const int f = tid + u * 256, r = f >> 3, k = k0 + (f & 7) * 4;
+            const int f = tid + u * THREADS, r = f >> 3, k = k0 + (f & 7) * 4;
             xa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k0 < g.kk && i0 + r < g.mm && k < g.kva) xa[u] = *reinterpret_cast<const float4*>(g.A + (long long)(i0 + r) * g.lda + k);
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const int f = tid + u * 256, r = f >> 3, k = k0 + (f & 7) * 4;
+            const int f = tid + u * THREADS, r = f >> 3, k = k0 + (f & 7) * 4;
             xb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (k0 < g.kk && j0 + r < g.nn && k < g.kvb) xb[u] = *reinterpret_cast<const float4*>(g.B + (long long)(j0 + r) * g.ldb + k);
         }
@@ -262,12 +263,12 @@ __global__ __launch_bounds__(256) void tgemm16_kernel(TG g) {
     auto stage = [&](int buf, const float4 (&xa)[NA], const float4 (&xb)[NB]) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const int f = tid + u * 256;
+            const int f = tid + u * THREADS;
             *reinterpret_cast<float4*>(&As[buf][f >> 3][(f & 7) * 4]) = xa[u];
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
-            const int f = tid + u * 256;
+            const int f = tid + u * THREADS;
             *reinterpret_cast<float4*>(&Bs[buf][f >> 3][(f & 7) * 4]) = xb[u];
         }
     };
@@ -283,9 +284,9 @@ __global__ __launch_bounds__(256) void tgemm16_kernel(TG g) {
         for (int kb = 0; kb < BK / 16; ++kb) {
             float4 a[RI], b[RJ];
 #pragma unroll
-            for (int i = 0; i < RI; ++i) a[i] = *reinterpret_cast<const float4*>(&As[cur][wm * (TI / 2) + i * 16 + l15][kb * 16 + lg * 4]);
+            for (int i = 0; i < RI; ++i) a[i] = *reinterpret_cast<const float4*>(&As[cur][wm * (TI / WI) + i * 16 + l15][kb * 16 + lg * 4]);
 #pragma unroll
-            for (int j = 0; j < RJ; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[cur][wn * (TJ / 2) + j * 16 + l15][kb * 16 + lg * 4]);
+            for (int j = 0; j < RJ; ++j) b[j] = *reinterpret_cast<const float4*>(&Bs[cur][wn * (TJ / WJ) + j * 16 + l15][kb * 16 + lg * 4]);
 #pragma unroll
             for (int i = 0; i < RI; ++i)
 #pragma unroll
@@ -326,14 +327,14 @@ __global__ __launch_bounds__(256) void tgemm16_kernel(TG g) {
     // epilogue.  C/D layout of 16x16: col = lane&15, row = 4*(lane>>4) + r.
 #pragma unroll
     for (int j = 0; j < RJ; ++j) {
-        const int col = j0 + wn * (TJ / 2) + j * 16 + l15;
+        const int col = j0 + wn * (TJ / WJ) + j * 16 + l15;
         if (col >= g.nn) continue;
         const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < RI; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = i0 + wm * (TI / 2) + i * 16 + lg * 4 + r;
+                const int row = i0 + wm * (TI / WI) + i * 16 + lg * 4 + r;
                 if (row >= g.c_rows) continue;
                 float v = acc[i][j][r] + bv;
                 if (g.relu) v = v > 0.f ? v : 0.f;
@@ -364,12 +365,15 @@ static int g_tgemm_cus = 256;   // set from the handle before the first launch o
 // (0,0) orientation, no split: 16x16x4 kernel.  kk is padded to the 32-wide k tile (k beyond kva/kvb reads as zero).
 // Tile: 64 x 64 always — measured on MI355X at M = 10 240 it beats 64 x 128 and 128 x 128 for every shape of this model
 // (N = 256 .. 1024, K = 144 .. 1024): 640+ small workgroups, four resident per CU, hide each other's barrier and
-// LDS latency better than fewer big ones.  TIP_TGEMM16_TILE = 1 / 2 forces 128x128 / 64x128 for measurement.
+// LDS latency better than fewer big ones.  TIP_TGEMM16_TILE = 1 / 2 / 3 forces 128x128 / 64x128 / 128x128 on 8 waves
+// for measurement.
 static hipError_t tgemm16_launch(TG g, hipStream_t s) {
     g.kk = round_up(g.kk, 32);
     static int force = -1;
     if (force < 0) force = getenv("TIP_TGEMM16_TILE") ? atoi(getenv("TIP_TGEMM16_TILE")) : 0;
-    if (force == 1) {
+    if (force == 3) {   // 8-wave 128 x 128 (measured: no gain over 64 x 64 even at N, K in the thousands: 112 vs 110 TFLOP/s)
+        hipLaunchKernelGGL((tgemm16_kernel<128, 128, 4, 2>), dim3((g.nn + 127) / 128, (g.mm + 127) / 128), dim3(512), 0, s, g);
+    } else if (force == 1) {
         hipLaunchKernelGGL((tgemm16_kernel<128, 128>), dim3((g.nn + 127) / 128, (g.mm + 127) / 128), dim3(256), 0, s, g);
     } else if (force == 2) {
         hipLaunchKernelGGL((tgemm16_kernel<64, 128>), dim3((g.nn + 127) / 128, (g.mm + 63) / 64), dim3(256), 0, s, g);
