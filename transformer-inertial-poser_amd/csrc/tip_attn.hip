@@ -1,0 +1,162 @@
+// tip_attn.hip — causal multi-head attention on the matrix cores for ANY configuration (general plan, training step):
+// torch scaled_dot_product_attention with the additive causal mask of simple_transformer_with_state.py:56-58, as called by
+// nn.TransformerEncoderLayer (:26-29,:91).  T <= 128, head width 16 / 32 / 64.
+//
+// One wave per (window, head), no LDS at all.  The trick that removes every re-layout: the score tile is computed
+// TRANSPOSED, S^T = K Q^T (A operand = K rows, B operand = Q rows — both are plain 16-byte loads of 4 consecutive channels
+// from the [M, 3D] QKV matrix).  Its accumulator layout — lane holds (keys 4*lg + r, query l15) — is exactly the A-operand
+// layout of the next product P V with the 4-k-step MFMA idiom (.x/.y/.z/.w = keys 4*lg + 0..3), so P feeds P V straight
+// from registers.  Softmax statistics of a query live in the 4 lanes that share l15: two xor-shuffles reduce them.
+// The fused inference kernels keep their own LDS-plane variant (tip_attention.h); this one serves everything else.
+#include "tip_internal.h"
+
+namespace tip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned attn_drop_hash(unsigned long long seed, unsigned site, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + ((unsigned long long)site << 40) + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32);
+}
+
+// NBMAX = ceil(T / 16) upper bound (3: T <= 48, 5: T <= 80, 8: T <= 128)
+template <int DH, int NBMAX>
+__global__ __launch_bounds__(256) void mattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                        float* __restrict__ ast, int B, int T, int H, float q_scale,
+                                                        AttnDrop drop) {
+    constexpr int KB = DH / 16;
+    const int lane = threadIdx.x & 63;
+    const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bh >= B * H) return;
+    const int b = bh / H, h = bh - b * H;
+    const int D = H * DH, ld = 3 * D;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const float* base = qkv + (size_t)b * T * ld + h * DH;
+    const int nb = (T + 15) >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int ib = 0; ib < nb; ++ib) {
+        const int q = ib * 16 + l15;                 // this lane's query (as B-operand row and as statistics owner)
+        f32x4 qf[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            qf[kb] = zero4;
+            if (q < T) qf[kb] = *reinterpret_cast<const f32x4*>(base + (size_t)q * ld + kb * 16 + lg * 4);
+        }
+        // ---- S^T tiles: element (key jb*16 + 4*lg + r, query q) ---------------------------------------------------------
+        f32x4 st[NBMAX];
+        float m = -INFINITY;
+#pragma unroll
+        for (int jb = 0; jb < NBMAX; ++jb) {
+            st[jb] = zero4;
+            if (jb <= ib) {
+                const int key = jb * 16 + l15;
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb) {
+                    f32x4 kf = zero4;
+                    if (key < T) kf = *reinterpret_cast<const f32x4*>(base + (size_t)key * ld + D + kb * 16 + lg * 4);
+                    st[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[kb].x, st[jb], 0, 0, 0);
+                    st[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[kb].y, st[jb], 0, 0, 0);
+                    st[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[kb].z, st[jb], 0, 0, 0);
+                    st[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[kb].w, st[jb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kk = jb * 16 + lg * 4 + r;
+                    const float sv = (kk <= q && kk < T) ? st[jb][r] * q_scale : -INFINITY;   // causal mask (:56-58)
+                    st[jb][r] = sv;
+                    m = fmaxf(m, sv);
+                }
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (q >= T) m = 0.f;                         // padded query rows: keep everything finite, nothing is stored
+        float l = 0.f;
+        const unsigned long long pbase = ((unsigned long long)bh * T + q) * T;
+#pragma unroll
+        for (int jb = 0; jb < NBMAX; ++jb) {
+            if (jb <= ib) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(st[jb][r] - m);      // exp(-inf) = 0 for masked keys
+                    l += p;
+                    float pk = p;
+                    if (drop.thresh) {
+                        const int kk = jb * 16 + lg * 4 + r;
+                        pk = attn_drop_hash(drop.seed, drop.site, pbase + kk) >= drop.thresh ? p * drop.scale : 0.f;
+                    }
+                    st[jb][r] = pk;
+                }
+            }
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = q < T ? 1.0f / l : 0.f;
+        if (ast && lg == 0 && q < T) {
+            ast[((size_t)bh * T + q) * 2] = m;
+            ast[((size_t)bh * T + q) * 2 + 1] = inv;
+        }
+        // ---- O = P V: A = P tiles straight from the accumulators, B = V gathered as (key 4*lg + e, channel l15) ------------
+        f32x4 o[KB];
+#pragma unroll
+        for (int cb = 0; cb < KB; ++cb) o[cb] = zero4;
+#pragma unroll
+        for (int jb = 0; jb < NBMAX; ++jb) {
+            if (jb <= ib) {
+                const int k0 = jb * 16 + lg * 4;
+#pragma unroll
+                for (int cb = 0; cb < KB; ++cb) {
+                    const float* vp = base + (size_t)k0 * ld + 2 * D + cb * 16 + l15;
+                    const float v0 = k0 + 0 < T ? vp[0] : 0.f;
+                    const float v1 = k0 + 1 < T ? vp[(size_t)ld] : 0.f;
+                    const float v2 = k0 + 2 < T ? vp[(size_t)2 * ld] : 0.f;
+                    const float v3 = k0 + 3 < T ? vp[(size_t)3 * ld] : 0.f;
+                    o[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jb][0], v0, o[cb], 0, 0, 0);
+                    o[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jb][1], v1, o[cb], 0, 0, 0);
+                    o[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jb][2], v2, o[cb], 0, 0, 0);
+                    o[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jb][3], v3, o[cb], 0, 0, 0);
+                }
+            }
+        }
+        // O layout: lane holds (queries 4*lg + r, channel l15): fetch 1/l of those queries from the lanes that own them
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ir = __shfl(inv, lg * 4 + r, 64);
+            const int qq = ib * 16 + lg * 4 + r;
+            if (qq < T) {
+                float* op = out + ((size_t)b * T + qq) * D + h * DH + l15;
+#pragma unroll
+                for (int cb = 0; cb < KB; ++cb) op[cb * 16] = o[cb][r] * ir;
+            }
+        }
+    }
+}
+
+bool mattn_supported(int dh, int T) { return (dh == 16 || dh == 32 || dh == 64) && T >= 1 && T <= 128; }
+
+template <int DH>
+static hipError_t mattn_fwd_dh(const float* qkv, float* out, float* ast, int B, int T, int H, float q_scale, AttnDrop drop,
+                               hipStream_t s) {
+    const dim3 grid((B * H + 3) / 4), block(256);
+    if (T <= 48) hipLaunchKernelGGL((mattn_fwd_kernel<DH, 3>), grid, block, 0, s, qkv, out, ast, B, T, H, q_scale, drop);
+    else if (T <= 80) hipLaunchKernelGGL((mattn_fwd_kernel<DH, 5>), grid, block, 0, s, qkv, out, ast, B, T, H, q_scale, drop);
+    else hipLaunchKernelGGL((mattn_fwd_kernel<DH, 8>), grid, block, 0, s, qkv, out, ast, B, T, H, q_scale, drop);
+    return hipGetLastError();
+}
+
+hipError_t launch_mattn_fwd(const float* qkv, float* out, float* ast, int B, int T, int H, int dh, float q_scale, AttnDrop drop,
+                            hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    switch (dh) {
+        case 16: return mattn_fwd_dh<16>(qkv, out, ast, B, T, H, q_scale, drop, s);
+        case 32: return mattn_fwd_dh<32>(qkv, out, ast, B, T, H, q_scale, drop, s);
+        case 64: return mattn_fwd_dh<64>(qkv, out, ast, B, T, H, q_scale, drop, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace tip

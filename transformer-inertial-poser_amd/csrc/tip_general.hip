@@ -365,6 +365,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 }
 
 hipError_t launch_attention(const Dims& d, const float* qkv, float* out, int B, int T, hipStream_t s) {
+    static int valu = -1;   // TIP_GENERAL_ATTN=valu keeps the one-thread-per-query kernel below (measurement / fallback)
+    if (valu < 0) valu = (getenv("TIP_GENERAL_ATTN") && getenv("TIP_GENERAL_ATTN")[0] == 'v') ? 1 : 0;
+    if (!valu && mattn_supported(d.dh, T)) {
+        Drop off;
+        off.seed = 0; off.site = 0; off.thresh = 0; off.scale = 1.f;
+        return launch_mattn_fwd(qkv, out, nullptr, B, T, d.H, d.dh, d.q_scale, off, s);
+    }
     const size_t per_wave = (size_t)2 * T * d.dh * sizeof(float);
     int waves = 4;
     while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;

@@ -19,6 +19,15 @@ __device__ __forceinline__ float tip_tanh(float x) {
     return copysignf(__fdividef(1.0f - e, 1.0f + e), x);
 }
 
+// one dropout site of the training step (tip_train.hip): keep(idx) = hash(seed, site, idx) >= thresh; thresh 0 = off
+struct Drop {
+    unsigned long long seed;
+    unsigned site;
+    unsigned thresh;
+    float scale;   // 1 / (1 - p)
+};
+typedef Drop AttnDrop;
+
 constexpr int kGemmBM = 128;   // general GEMM block tile (rows)
 constexpr int kGemmBN = 128;   // general GEMM block tile (cols); packed weights are padded to this
 constexpr int kGemmBK = 16;    // K tile; packed K is padded to this
@@ -109,6 +118,11 @@ hipError_t launch_gemm(const float* A, int lda, const float* W, int Kpad, const 
 hipError_t launch_gemm16(const float* A, int lda, const float* W, int ldw, const float* bias, const float* res, int ldres,
                          float* C, int ldc, int M, int N, int K, int flags, hipStream_t s);
 hipError_t launch_attention(const Dims& d, const float* qkv, float* out, int B, int T, hipStream_t s);
+// matrix-core attention for any configuration (tip_attn.hip): out [M,D] = softmax(causal(q k^T * q_scale)) v per head;
+// ast (nullable) receives (row max, 1 / row sum) per (window, head, query) for the training backward; drop = dropout on P
+bool mattn_supported(int dh, int T);
+hipError_t launch_mattn_fwd(const float* qkv, float* out, float* ast, int B, int T, int H, int dh, float q_scale, AttnDrop drop,
+                            hipStream_t s);
 hipError_t launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s);
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
                       int T, int cluster, int num_cus, bool hall_armed, hipStream_t s);

@@ -40,13 +40,6 @@ __device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned 
     return (unsigned)(z >> 32);
 }
 
-struct Drop {
-    unsigned long long seed;
-    unsigned site;
-    unsigned thresh;   // 0 => dropout off
-    float scale;       // 1 / (1 - p)
-};
-
 __device__ __forceinline__ float drop_factor(const Drop d, unsigned long long idx) {
     if (d.thresh == 0) return 1.f;
     return drop_hash(d.seed, d.site, idx) >= d.thresh ? d.scale : 0.f;
@@ -1161,18 +1154,12 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         }
         {
             const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 0));
-            const int threads = round_up(T, 64);
             const float qs = 1.0f / sqrtf((float)d.dh);
             const float* qkv = W + t.qkv;
             float* att = W + t.att;
             float* ast = W + t.ast;
             const int H = d.H;
-            TT(dispatch_dh(d.dh, [&](auto dh) {
-                   constexpr int DH = decltype(dh)::value;
-                   hipLaunchKernelGGL((tattn_fwd_kernel<DH>), dim3(B * H), dim3(threads), (size_t)2 * T * DH * sizeof(float), s, qkv,
-                                      att, ast, T, H, qs, dr);
-                   return hipGetLastError();
-               }), "train_attention");
+            TT(launch_mattn_fwd(qkv, att, ast, B, T, H, d.dh, qs, dr, s), "train_attention");
         }
         {
             TG g = tg_base(W + t.att, d.D, lp[PL_OUT_W], d.D, W + t.z1, d.D, M, d.D, d.D);
