@@ -123,6 +123,8 @@ hipError_t launch_attention(const Dims& d, const float* qkv, float* out, int B, 
 bool mattn_supported(int dh, int T);
 hipError_t launch_mattn_fwd(const float* qkv, float* out, float* ast, int B, int T, int H, int dh, float q_scale, AttnDrop drop,
                             hipStream_t s);
+hipError_t launch_mattn_bwd(const float* qkv, const float* o_saved, const float* ast, const float* d_o, float* dqkv, int B, int T,
+                            int H, int dh, float q_scale, AttnDrop drop, hipStream_t s);
 hipError_t launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s);
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
                       int T, int cluster, int num_cus, bool hall_armed, hipStream_t s);

@@ -647,162 +647,6 @@ __global__ __launch_bounds__(256) void tln_bwd_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// causal multi-head attention, training forward and backward (torch functional.py scaled_dot_product_attention with the
-// additive mask of simple_transformer_with_state.py:56-58 and dropout on the probabilities).  One workgroup per
-// (window, head); thread i owns query row i in pass 1, key row j in pass 2.  T <= 128.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int DH>
-__device__ __forceinline__ float dot_dh(const float* a, const float* b) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-    for (int e = 0; e < DH; e += 4) {
-        s0 = fmaf(a[e], b[e], s0); s1 = fmaf(a[e + 1], b[e + 1], s1);
-        s2 = fmaf(a[e + 2], b[e + 2], s2); s3 = fmaf(a[e + 3], b[e + 3], s3);
-    }
-    return (s0 + s1) + (s2 + s3);
-}
-
-template <int DH>
-__global__ __launch_bounds__(128) void tattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out, float* __restrict__ ast, int T, int H,
-                                 float q_scale, Drop drop) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;
-    float* Vs = smem + (size_t)T * DH;
-    const int D = H * DH, ld = 3 * D;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const float* base = qkv + (size_t)b * T * ld + h * DH;
-    for (int f = threadIdx.x; f < T * (DH / 4); f += blockDim.x) {
-        const int j = f / (DH / 4), e = (f % (DH / 4)) * 4;
-        *reinterpret_cast<float4*>(Ks + j * DH + e) = *reinterpret_cast<const float4*>(base + (size_t)j * ld + D + e);
-        *reinterpret_cast<float4*>(Vs + j * DH + e) = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * D + e);
-    }
-    __syncthreads();
-    const int i = threadIdx.x;
-    if (i >= T) return;
-    float q[DH], o[DH];
-#pragma unroll
-    for (int e = 0; e < DH; ++e) {
-        q[e] = base[(size_t)i * ld + e] * q_scale;
-        o[e] = 0.f;
-    }
-    float m = -INFINITY;
-    for (int j = 0; j <= i; ++j) m = fmaxf(m, dot_dh<DH>(q, Ks + j * DH));
-    float l = 0.f;
-    const unsigned long long pbase = ((unsigned long long)blockIdx.x * T + i) * T;
-    for (int j = 0; j <= i; ++j) {
-        const float e_ = expf(dot_dh<DH>(q, Ks + j * DH) - m);
-        l += e_;
-        const float pk = e_ * drop_factor(drop, pbase + j);
-        const float* vj = Vs + j * DH;
-#pragma unroll
-        for (int e = 0; e < DH; ++e) o[e] = fmaf(pk, vj[e], o[e]);
-    }
-    const float inv = 1.0f / l;
-    float* op = out + ((size_t)b * T + i) * D + h * DH;
-#pragma unroll
-    for (int e = 0; e < DH; ++e) op[e] = o[e] * inv;
-    ast[((size_t)blockIdx.x * T + i) * 2] = m;
-    ast[((size_t)blockIdx.x * T + i) * 2 + 1] = inv;
-}
-
-template <int DH>
-__global__ __launch_bounds__(128) void tattn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o_saved,
-                                 const float* __restrict__ ast, const float* __restrict__ d_o, float* __restrict__ dqkv, int T,
-                                 int H, float q_scale, Drop drop) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Qs = smem;                       // pre-scaled by q_scale, as in the forward
-    float* Ks = Qs + (size_t)T * DH;
-    float* Vs = Ks + (size_t)T * DH;
-    float* Gs = Vs + (size_t)T * DH;        // dO
-    float* Ms = Gs + (size_t)T * DH;        // row max
-    float* Ls = Ms + T;                     // 1 / row sum
-    float* Ds = Ls + T;                     // dO_i . O_i
-    const int D = H * DH, ld = 3 * D;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const float* base = qkv + (size_t)b * T * ld + h * DH;
-    for (int f = threadIdx.x; f < T * DH; f += blockDim.x) {
-        const int j = f / DH, e = f % DH;
-        Qs[f] = base[(size_t)j * ld + e] * q_scale;
-        Ks[f] = base[(size_t)j * ld + D + e];
-        Vs[f] = base[(size_t)j * ld + 2 * D + e];
-        Gs[f] = d_o[((size_t)b * T + j) * D + h * DH + e];
-    }
-    const int i = threadIdx.x;
-    if (i < T) {
-        Ms[i] = ast[((size_t)blockIdx.x * T + i) * 2];
-        Ls[i] = ast[((size_t)blockIdx.x * T + i) * 2 + 1];
-        const float* op = o_saved + ((size_t)b * T + i) * D + h * DH;
-        const float* gp = d_o + ((size_t)b * T + i) * D + h * DH;
-        float dd = 0.f;
-        for (int e = 0; e < DH; ++e) dd = fmaf(gp[e], op[e], dd);
-        Ds[i] = dd;
-    }
-    __syncthreads();
-    float* dq_out = dqkv + (size_t)b * T * ld + h * DH;
-    if (i < T) {
-        // pass 1: dq_i = q_scale * sum_{j<=i} ds_ij k_j
-        float q[DH], g[DH], dq[DH];
-#pragma unroll
-        for (int e = 0; e < DH; ++e) {
-            q[e] = Qs[i * DH + e];
-            g[e] = Gs[i * DH + e];
-            dq[e] = 0.f;
-        }
-        const float m = Ms[i], inv = Ls[i], dd = Ds[i];
-        const unsigned long long pbase = ((unsigned long long)blockIdx.x * T + i) * T;
-        for (int j = 0; j <= i; ++j) {
-            const float p = expf(dot_dh<DH>(q, Ks + j * DH) - m) * inv;
-            const float dp = dot_dh<DH>(g, Vs + j * DH) * drop_factor(drop, pbase + j);
-            const float ds = p * (dp - dd);
-            const float* kj = Ks + j * DH;
-#pragma unroll
-            for (int e = 0; e < DH; ++e) dq[e] = fmaf(ds, kj[e], dq[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < DH; ++e) dq_out[(size_t)i * ld + e] = dq[e] * q_scale;
-        // pass 2: this thread is key row j = i
-        const int j = i;
-        float k[DH], v[DH], dk[DH], dv[DH];
-#pragma unroll
-        for (int e = 0; e < DH; ++e) {
-            k[e] = Ks[j * DH + e];
-            v[e] = Vs[j * DH + e];
-            dk[e] = 0.f;
-            dv[e] = 0.f;
-        }
-        for (int ii = j; ii < T; ++ii) {
-            const float* qi = Qs + ii * DH;
-            const float* gi = Gs + ii * DH;
-            const float p = expf(dot_dh<DH>(qi, k) - Ms[ii]) * Ls[ii];
-            const float kf = drop_factor(drop, ((unsigned long long)blockIdx.x * T + ii) * T + j);
-            const float dp = dot_dh<DH>(gi, v) * kf;
-            const float ds = p * (dp - Ds[ii]);
-            const float pk = p * kf;
-#pragma unroll
-            for (int e = 0; e < DH; ++e) {
-                dk[e] = fmaf(ds, qi[e], dk[e]);     // qi is already q * q_scale
-                dv[e] = fmaf(pk, gi[e], dv[e]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < DH; ++e) {
-            dq_out[(size_t)j * ld + D + e] = dk[e];
-            dq_out[(size_t)j * ld + 2 * D + e] = dv[e];
-        }
-    }
-}
-
-template <typename F>
-static hipError_t dispatch_dh(int dh, F&& f) {
-    switch (dh) {
-        case 16: return f(std::integral_constant<int, 16>());
-        case 32: return f(std::integral_constant<int, 32>());
-        case 64: return f(std::integral_constant<int, 64>());
-        default: return hipErrorInvalidValue;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // small data-movement kernels
 // ---------------------------------------------------------------------------------------------------------------------
 // in_linear with the channel shuffle (:88-89) folded into its rows (new row a*H + b <- old row b*dh + a), K padded to InPad,
@@ -1345,7 +1189,6 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
         }
         {
             const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 0));
-            const int threads = round_up(T, 64);
             const float qs = 1.0f / sqrtf((float)d.dh);
             const float* qkv = W + t.qkv;
             const float* att = W + t.att;
@@ -1353,12 +1196,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             const float* datt = X + S.datt;
             float* dqkv = X + S.gbig;
             const int H = d.H;
-            TT(dispatch_dh(d.dh, [&](auto dh) {
-                   constexpr int DH = decltype(dh)::value;
-                   const size_t smem = ((size_t)4 * T * DH + 3 * T) * sizeof(float);
-                   hipLaunchKernelGGL((tattn_bwd_kernel<DH>), dim3(B * H), dim3(threads), smem, s, qkv, att, ast, datt, dqkv, T, H, qs, dr);
-                   return hipGetLastError();
-               }), "bwd_attention");
+            TT(launch_mattn_bwd(qkv, att, ast, datt, dqkv, B, T, H, d.dh, qs, dr, s), "bwd_attention");
         }
         TT(colsum(X + S.gbig, 3 * d.D, M, 3 * d.D, colpart, grads + goff[pb + PL_QKV_B], nullptr, s), "bwd_dbqkv");
         TT(grad_weight(X + S.gbig, 3 * d.D, 3 * d.D, 3 * d.D, x_in, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_QKV_W], ncu, s),
