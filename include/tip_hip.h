@@ -63,7 +63,7 @@ typedef enum tip_status {
 #define TIP_PLAN_FUSED2  4 /* two windows per workgroup (80 rows = 5 MFMA row blocks, no padding); AUTO picks it for
                               B >= 2 x CUs; bit-identical results to TIP_PLAN_FUSED */
 #define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);
-                              AUTO picks it for B <= 32 */
+                              AUTO picks it for B <= 64 */
 
 #define TIP_OPT_PLAN        1
 #define TIP_OPT_PROFILE     2 /* 0 off; 1: bracket every stage with a HIP event pair; 2: only the dominant stage

@@ -272,7 +272,7 @@ def test_eval_mode_with_autograd_uses_hip_forward_and_torch_backward():
 
 
 def test_latency_plan_is_deterministic_and_batch_independent():
-    """The latency plan (auto for B <= 32): run-to-run identical (granule hand-off has no race) and a stream's result
+    """The latency plan (auto for B <= 64): run-to-run identical (granule hand-off has no race) and a stream's result
     does not depend on its neighbours within the plan."""
     cfg = synth.PAPER
     m, w = _gpu_model(cfg, 0)

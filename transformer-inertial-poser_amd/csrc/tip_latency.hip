@@ -1,4 +1,4 @@
-// tip_latency.hip — "latency" execution plan for few concurrent streams (B <= 32), paper configuration.
+// tip_latency.hip — "latency" execution plan for few concurrent streams (B <= 64), paper configuration.
 //
 // The fused plan gives one window to one CU (0.75 ms): fine for throughput, 13x too slow for a single 60-Hz
 // stream.  Here ONE window is spread over up to 64 CUs per GEMM: every workgroup owns ONE 16-column block of the
