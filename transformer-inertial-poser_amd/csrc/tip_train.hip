@@ -487,8 +487,9 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
 }
 
 // out[n] = sum_z part[z][n]; block = 64 columns x 4 z lanes
+// columns n >= nsplit go to out_hi[n - nsplit] (nsplit = N: everything to out, and to out2 when given)
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, int Z, int N, float* __restrict__ out,
-                                                        float* __restrict__ out2) {
+                                                        float* __restrict__ out2, int nsplit, float* __restrict__ out_hi) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, zl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
@@ -507,8 +508,12 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     __syncthreads();
     if (zl == 0 && n < N) {
         const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-        out[n] = v;
-        if (out2) out2[n] = v;
+        if (n >= nsplit) {
+            out_hi[n - nsplit] = v;
+        } else {
+            out[n] = v;
+            if (out2) out2[n] = v;
+        }
     }
 }
 
@@ -518,7 +523,7 @@ static hipError_t colsum(const float* X, long long ld, int M, int N, float* part
     const int rows_per = (M + kColZ - 1) / kColZ;
     const int Z = (M + rows_per - 1) / rows_per;
     hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, Z), dim3(256), 0, s, X, ld, M, N, rows_per, part);
-    hipLaunchKernelGGL(colreduce_kernel, dim3((N + 63) / 64), dim3(256), 0, s, part, Z, N, out, out2);
+    hipLaunchKernelGGL(colreduce_kernel, dim3((N + 63) / 64), dim3(256), 0, s, part, Z, N, out, out2, N, nullptr);
     return hipGetLastError();
 }
 
@@ -573,24 +578,26 @@ __global__ __launch_bounds__(256) void tln_fwd_kernel(const float* __restrict__ 
     }
 }
 
-constexpr int kLnRows = 64;   // rows per workgroup in the backward (16 per wave)
+constexpr int kLnRows = 16;   // rows per workgroup in the backward (4 per wave): 640 workgroups at M = 10 240 keep every SIMD loaded
 
 // dz = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * gamma;  partial dgamma = sum dy * xhat, dbeta = sum dy.
-// Optionally also writes dzm = dz * keep(site, idx): the gradient that flows into the dropped branch of the residual.
+// Also writes dzm = dz * keep(site, idx), the gradient that flows into the dropped branch of the residual, and its column
+// sums (third partial): that IS the bias gradient of the linear layer feeding the branch (out_proj / linear2).
 template <int NV>
 __global__ __launch_bounds__(256) void tln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                       const float* __restrict__ stats, const float* __restrict__ g,
                                                       float* __restrict__ dz, float* __restrict__ dzm, Drop drop,
                                                       float* __restrict__ part, int M) {
     constexpr int D = NV * 256;
-    __shared__ float red[4][2][D];
+    __shared__ float red[4][3][D];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 gg[NV], dg[NV], db[NV];
+    float4 gg[NV], dg[NV], db[NV], dm[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         gg[i] = *reinterpret_cast<const float4*>(g + (i * 64 + lane) * 4);
         dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dm[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int r0 = blockIdx.x * kLnRows;
     for (int rr = wave; rr < kLnRows; rr += 4) {
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(256) void tln_bwd_kernel(const float* __restrict__ 
             o.z = rstd * (dyv[i].z * gg[i].z - m1 - xh[i].z * m2);
             o.w = rstd * (dyv[i].w * gg[i].w - m1 - xh[i].w * m2);
             *reinterpret_cast<float4*>(dz + (size_t)row * D + c) = o;
-            if (dzm) {
+            {
                 const unsigned long long idx = (unsigned long long)row * D + c;
                 float4 m;
                 m.x = o.x * drop_factor(drop, idx);
@@ -630,6 +637,7 @@ __global__ __launch_bounds__(256) void tln_bwd_kernel(const float* __restrict__ 
                 m.z = o.z * drop_factor(drop, idx + 2);
                 m.w = o.w * drop_factor(drop, idx + 3);
                 *reinterpret_cast<float4*>(dzm + (size_t)row * D + c) = m;
+                dm[i].x += m.x; dm[i].y += m.y; dm[i].z += m.z; dm[i].w += m.w;
             }
         }
     }
@@ -638,11 +646,12 @@ __global__ __launch_bounds__(256) void tln_bwd_kernel(const float* __restrict__ 
         const int c = (i * 64 + lane) * 4;
         *reinterpret_cast<float4*>(&red[wave][0][c]) = dg[i];
         *reinterpret_cast<float4*>(&red[wave][1][c]) = db[i];
+        *reinterpret_cast<float4*>(&red[wave][2][c]) = dm[i];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    for (int i = threadIdx.x; i < 3 * D; i += 256) {
         const int w = i / D, c = i - w * D;
-        part[(size_t)blockIdx.x * 2 * D + i] = (red[0][w][c] + red[1][w][c]) + (red[2][w][c] + red[3][w][c]);
+        part[(size_t)blockIdx.x * 3 * D + i] = (red[0][w][c] + red[1][w][c]) + (red[2][w][c] + red[3][w][c]);
     }
 }
 
@@ -838,7 +847,7 @@ static TrainScratch scratch_layout(const Dims& d, int B, int T) {
     if ((size_t)d.R * d.R > wmax) wmax = (size_t)d.R * d.R;
     S.part_floats = wmax * 32;
     S.part = take(off, S.part_floats);
-    const size_t ln_parts = (M + kLnRows - 1) / kLnRows * 2 * d.D;
+    const size_t ln_parts = (M + kLnRows - 1) / kLnRows * 3 * d.D;
     size_t cmax = (size_t)kColZ * (size_t)(3 * d.D > d.F ? 3 * d.D : d.F);
     if (ln_parts > cmax) cmax = ln_parts;
     S.colpart = take(off, cmax);
@@ -1141,12 +1150,12 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
                                       dzm, dr, colpart, M);
                    return hipGetLastError();
                }), "bwd_ln2");
-            hipLaunchKernelGGL(colreduce_kernel, dim3((2 * d.D + 63) / 64), dim3(256), 0, s, colpart, nln, 2 * d.D,
-                               grads + goff[pb + PL_N2_W], nullptr);
+            // norm weight and bias are consecutive tensors of D floats each: [dgamma | dbeta] land there in one go, the third
+            // section (column sums of the masked gradient) is linear2's bias gradient
+            hipLaunchKernelGGL(colreduce_kernel, dim3((3 * d.D + 63) / 64), dim3(256), 0, s, colpart, nln, 3 * d.D,
+                               grads + goff[pb + PL_N2_W], nullptr, 2 * d.D, grads + goff[pb + PL_L2_B]);
             TT(hipGetLastError(), "bwd_ln2_params");
         }
-        // norm weight and bias are consecutive tensors of D floats each: the reduce wrote [dgamma | dbeta] in one go
-        TT(colsum(X + S.gc, d.D, M, d.D, colpart, grads + goff[pb + PL_L2_B], nullptr, s), "bwd_db2");
         TT(grad_weight(X + S.gc, d.D, d.D, d.D, W + t.hid, d.F, d.F, M, part, S.part_floats, grads + goff[pb + PL_L2_W], ncu, s),
            "bwd_dW2");
         {
@@ -1176,11 +1185,10 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
                                       dzm, dr, colpart, M);
                    return hipGetLastError();
                }), "bwd_ln1");
-            hipLaunchKernelGGL(colreduce_kernel, dim3((2 * d.D + 63) / 64), dim3(256), 0, s, colpart, nln, 2 * d.D,
-                               grads + goff[pb + PL_N1_W], nullptr);
+            hipLaunchKernelGGL(colreduce_kernel, dim3((3 * d.D + 63) / 64), dim3(256), 0, s, colpart, nln, 3 * d.D,
+                               grads + goff[pb + PL_N1_W], nullptr, 2 * d.D, grads + goff[pb + PL_OUT_B]);
             TT(hipGetLastError(), "bwd_ln1_params");
         }
-        TT(colsum(X + S.gc, d.D, M, d.D, colpart, grads + goff[pb + PL_OUT_B], nullptr, s), "bwd_dbo");
         TT(grad_weight(X + S.gc, d.D, d.D, d.D, W + t.att, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_OUT_W], ncu, s),
            "bwd_dWo");
         {
