@@ -28,66 +28,130 @@ __device__ __forceinline__ void inv3(const double* m, double* o) {
     o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
 }
 
-// one thread per kept frame f (source frame f + 4): filtered + biased accelerations (:81-85), root-local rotations and
+// One thread per kept frame f (source frame f + 4): filtered + biased accelerations (:81-85), root-local rotations and
 // accelerations (:86, data_utils.py:190-219).  Writes the float32 IMU row and the fp64 local accelerations (scratch).
-__global__ __launch_bounds__(128) void combine_imu_kernel(const double* __restrict__ imu, const double* __restrict__ bias, int Lp,
-                                                          float* __restrict__ imu_out, double* __restrict__ loc_acc) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= Lp) return;
-    const double* row = imu + (size_t)(f + kTrim) * 72;
-    double R[9], inv[9];
+// A frame is a 576-byte fp64 row: read per thread that is a 576-byte lane stride.  So the block's 128 rows (+ the
+// accelerations of 5 halo rows each side for the 11-tap filter) are first copied to LDS with unit-stride loads, at odd row
+// strides so that the per-thread row reads spread over all banks; results go back through LDS the same way (unit-stride
+// stores).
+constexpr int kCombFrames = 128;
+constexpr int kCombRows = kCombFrames + 2 * kAccTaps;   // 138 rows of accelerations (with the filter halo)
+constexpr int kRotLd = 55, kAccLd = 19;                  // staged row strides in doubles (odd: bank-conflict free)
+constexpr int kCombLdsDoubles = kCombFrames * kRotLd + kCombRows * kAccLd;   // 9 662 doubles = 77.3 KB: two blocks per CU
+
+constexpr int kCombThreads = 256;   // all of them copy; the first 128 each own a frame
+
+__global__ __launch_bounds__(kCombThreads) void combine_imu_kernel(const double* __restrict__ imu, const double* __restrict__ bias, int Lp,
+                                                                  float* __restrict__ imu_out, double* __restrict__ loc_acc) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* rot = lds;                              // [128][55]: the six rotation matrices of each frame
+    double* accs = lds + kCombFrames * kRotLd;      // [138][19]: accelerations of frames f0-5 .. f0+132 (edge-replicated)
+    const int f0 = blockIdx.x * kCombFrames;
+    for (int i = threadIdx.x; i < kCombRows * 36; i += kCombThreads) {     // 16-byte loads: 36 double2 per row
+        const int r = i / 36, c = (i - r * 36) * 2;
+        const int fr = f0 + r - kAccTaps;
+        const int g = fr < 0 ? 0 : (fr > Lp - 1 ? Lp - 1 : fr);     // mode="nearest" inside the trimmed sequence
+        const bool body = r >= kAccTaps && r < kAccTaps + kCombFrames;
+        if (c >= 54 || body) {
+            const double2 v = *reinterpret_cast<const double2*>(imu + (size_t)(g + kTrim) * 72 + c);
+            if (c >= 54) {
+                accs[r * kAccLd + (c - 54)] = v.x;
+                accs[r * kAccLd + (c - 53)] = v.y;
+            } else {
+                rot[(r - kAccTaps) * kRotLd + c] = v.x;
+                rot[(r - kAccTaps) * kRotLd + c + 1] = v.y;
+            }
+        }
+    }
+    __syncthreads();
+    const int t = threadIdx.x & (kCombFrames - 1);       // threads 128..255 shadow a frame but never publish it
+    const bool owner = threadIdx.x < kCombFrames;
+    const double* row = rot + t * kRotLd;
+    double R[9], inv[9], la[18];
+    float o[72];
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = row[i];
     inv3(R, inv);
-    float* out = imu_out + (size_t)f * 72;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) out[i] = (float)R[i];
+    for (int i = 0; i < 9; ++i) o[i] = (float)R[i];
+#pragma unroll
     for (int sidx = 0; sidx < 5; ++sidx) {
-        const double* o = row + 9 + 9 * sidx;
+        double m[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) m[i] = row[9 + 9 * sidx + i];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                out[9 + 9 * sidx + 3 * i + k] = (float)(inv[3 * i] * o[k] + inv[3 * i + 1] * o[3 + k] + inv[3 * i + 2] * o[6 + k]);
+                o[9 + 9 * sidx + 3 * i + k] = (float)(inv[3 * i] * m[k] + inv[3 * i + 1] * m[3 + k] + inv[3 * i + 2] * m[6 + k]);
     }
     double acc[18];
 #pragma unroll
     for (int ch = 0; ch < 18; ++ch) acc[ch] = 0.0;
-    for (int k = -kAccTaps; k <= kAccTaps; ++k) {
-        int g = f + k;
-        g = g < 0 ? 0 : (g > Lp - 1 ? Lp - 1 : g);     // mode="nearest" inside the trimmed sequence
-        const double* a = imu + (size_t)(g + kTrim) * 72 + 54;
+    for (int k = 0; k <= 2 * kAccTaps; ++k) {
+        const double* a = accs + (t + k) * kAccLd;
 #pragma unroll
         for (int ch = 0; ch < 18; ++ch) acc[ch] += a[ch];
     }
 #pragma unroll
     for (int ch = 0; ch < 18; ++ch) acc[ch] = acc[ch] / (double)(2 * kAccTaps + 1) + bias[ch];
-    double* la = loc_acc + (size_t)f * 18;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         la[ch] = acc[ch];
-        out[54 + ch] = (float)acc[ch];
+        o[54 + ch] = (float)acc[ch];
     }
+#pragma unroll
     for (int sidx = 0; sidx < 5; ++sidx) {
-        const double* a = acc + 3 + 3 * sidx;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const double v = inv[3 * i] * a[0] + inv[3 * i + 1] * a[1] + inv[3 * i + 2] * a[2];
+            const double v = inv[3 * i] * acc[3 + 3 * sidx] + inv[3 * i + 1] * acc[4 + 3 * sidx] + inv[3 * i + 2] * acc[5 + 3 * sidx];
             la[3 + 3 * sidx + i] = v;
-            out[57 + 3 * sidx + i] = (float)v;
+            o[57 + 3 * sidx + i] = (float)v;
         }
+    }
+    __syncthreads();                                   // everyone is done with the staged inputs: reuse them for the outputs
+    float* so = reinterpret_cast<float*>(lds);                         // [128][73] floats (37.4 KB)
+    double* sl = lds + (kCombFrames * 73 + 1) / 2 + 1;                  // [128][19] doubles behind it
+    if (owner) {
+#pragma unroll
+        for (int i = 0; i < 72; ++i) so[t * 73 + i] = o[i];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) sl[t * kAccLd + i] = la[i];
+    }
+    __syncthreads();
+    const int nf = min(kCombFrames, Lp - f0);
+    for (int i = threadIdx.x; i < nf * 72; i += kCombThreads) {
+        const int r = i / 72, c = i - r * 72;
+        imu_out[(size_t)f0 * 72 + i] = so[r * 73 + c];
+    }
+    for (int i = threadIdx.x; i < nf * 18; i += kCombThreads) {
+        const int r = i / 18, c = i - r * 18;
+        loc_acc[(size_t)f0 * 18 + i] = sl[r * kAccLd + c];
     }
 }
 
-// running sum of the last <= 40 local accelerations / 15 (:90-93); one thread per (frame, channel)
+// running sum of the last <= 40 local accelerations / 15 (:90-93).  Block = 256 frames x 18 channels; the 295 rows the
+// block needs are staged in LDS once instead of being re-read 40 times from L2.
+constexpr int kSumFrames = 256;
+
 __global__ __launch_bounds__(256) void acc_sum_kernel(const double* __restrict__ loc_acc, int Lp, float* __restrict__ sum_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Lp * 18) return;
-    const int f = i / 18, ch = i - f * 18;
-    const int lo = f - (kSumWin - 1) < 0 ? 0 : f - (kSumWin - 1);
-    double a = 0.0;
-    for (int g = lo; g <= f; ++g) a += loc_acc[(size_t)g * 18 + ch];
-    sum_out[i] = (float)(a / kSumScale);
+    __shared__ double win[(kSumFrames + kSumWin - 1) * 18];
+    const int f0 = blockIdx.x * kSumFrames;
+    const int g0 = f0 - (kSumWin - 1);
+    const int nrows = min(kSumFrames, Lp - f0) + kSumWin - 1;
+    for (int i = threadIdx.x; i < nrows * 18; i += 256) {
+        const int g = g0 + i / 18;
+        win[i] = g >= 0 ? loc_acc[(long long)g0 * 18 + i] : 0.0;       // frames before the sequence start contribute nothing
+    }
+    __syncthreads();
+    const int nf = min(kSumFrames, Lp - f0);
+    for (int i = threadIdx.x; i < nf * 18; i += 256) {
+        const int r = i / 18, ch = i - r * 18;
+        double a = 0.0;
+        // ascending frame order, as np.cumsum accumulates
+        for (int k = 0; k < kSumWin; ++k) a += win[(r + k) * 18 + ch];
+        sum_out[(size_t)f0 * 18 + i] = (float)(a / kSumScale);
+    }
 }
 
 // S row (:96,:99-100,:127-128): 18 joints x first two columns of R(axis-angle) | root velocity | 20 SBP channels.
@@ -180,8 +244,17 @@ int tip_combine_sequence(const double* imu, const double* s, const double* c, in
     if (scratch_bytes < (size_t)Lp * 18 * sizeof(double) || reinterpret_cast<uintptr_t>(scratch) % 8) return TIP_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* la = static_cast<double*>(scratch);
-    hipLaunchKernelGGL(combine_imu_kernel, dim3((Lp + 127) / 128), dim3(128), 0, st, imu, bias, Lp, imu_out, la);
-    hipLaunchKernelGGL(acc_sum_kernel, dim3((Lp * 18 + 255) / 256), dim3(256), 0, st, la, Lp, sum_out);
+    constexpr size_t comb_lds = (size_t)kCombLdsDoubles * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(combine_imu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)comb_lds) != hipSuccess)
+            return TIP_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(combine_imu_kernel, dim3((Lp + kCombFrames - 1) / kCombFrames), dim3(kCombThreads), comb_lds, st, imu, bias, Lp,
+                       imu_out, la);
+    hipLaunchKernelGGL(acc_sum_kernel, dim3((Lp + kSumFrames - 1) / kSumFrames), dim3(256), 0, st, la, Lp, sum_out);
     hipLaunchKernelGGL(s_2axis_kernel, dim3((Lp * 19 + 255) / 256), dim3(256), 0, st, s, c, Lp, nan_root_vel, s_out);
     if (hipGetLastError() != hipSuccess) return TIP_ERR_HIP;
     return Lp;
