@@ -91,6 +91,10 @@ int tip_packed_bytes(const tip_handle* h, size_t* bytes);
 int tip_pack_weights(const tip_handle* h, const float* const* host_tensors, int n, void* packed_host_out, size_t bytes);
 /* device: point the handle at a packed image resident in HBM (caller-owned; e.g. the buffer every rank
  * receives from the one-time RCCL broadcast).  Must stay valid until the next attach / destroy. */
+/* tip_pack_weights on the GPU: `tensors` are DEVICE pointers (the live parameters), `packed_dev` a device buffer of
+ * tip_packed_bytes(); asynchronous on `stream`.  Bit-identical image; microseconds instead of a host pack + 27 MB upload. */
+int tip_pack_weights_device(const tip_handle* h, const float* const* tensors, int n, void* packed_dev, size_t bytes,
+                            tip_stream_t stream);
 int tip_attach_packed(tip_handle* h, const void* packed_device, size_t bytes);
 
 /* ---- forward: replaces TF_RNN_Past_State.forward(x_imu, x_s) (simple_transformer_with_state.py:60-102) ---- */

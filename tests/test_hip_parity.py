@@ -331,3 +331,24 @@ def test_general_plan_configuration_sweep(D, H, F, L, R, with_rnn, acc, B, T):
     assert y.shape == yo.shape and np.abs(y - yo).max() < TOL_TIGHT, np.abs(y - yo).max()
     yl = _run(m, x_imu, x_s, last=True)
     assert np.array_equal(yl, y[:, -1])
+
+
+@pytest.mark.parametrize("cfgname", ["paper", "tiny", "scaled2", "no_rnn"])
+def test_device_packer_builds_the_same_image_as_the_host_packer(cfgname):
+    """tip_pack_weights_device (descriptor-driven kernel) vs tip_pack_weights (host loops): two independent
+    implementations of the packed layout and its folds must agree bit for bit."""
+    cfg = {"paper": synth.PAPER, "tiny": synth.TINY, "scaled2": dict(synth.SCALED, tf_layers=2),
+           "no_rnn": dict(synth.PAPER, with_rnn=False)}[cfgname]
+    m, _ = _gpu_model(cfg, 3)
+    host = m.pack_host()
+    dev = m.pack_device().cpu()
+    assert host.numel() == dev.numel()
+    a, b = host.view(torch.float32), dev.view(torch.float32)
+    assert torch.equal(a, b), int((a != b).sum())
+    # and the module uses it: a parameter change reaches the kernels without a host pack
+    x_imu, x_s = synth.make_inputs(cfg, 2, 9, seed=1)
+    y0 = _run(m, x_imu, x_s)
+    with torch.no_grad():
+        m.linear.bias.add_(1.0)
+    y1 = _run(m, x_imu, x_s)
+    assert np.allclose(y1 - y0, 1.0, atol=1e-5)

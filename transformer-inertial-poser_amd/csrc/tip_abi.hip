@@ -380,6 +380,73 @@ int tip_pack_weights(const tip_handle* h, const float* const* t, int n, void* pa
     return TIP_OK;
 }
 
+// The same image built on the GPU from device tensors (tip_pack.hip); `packed_dev` is then ready for tip_attach_packed.
+int tip_pack_weights_device(const tip_handle* h, const float* const* t, int n, void* packed_dev, size_t bytes, void* stream) {
+    if (!h || !t || !packed_dev) return TIP_ERR_INVALID_ARG;
+    if (n != (int)h->tensor_names.size()) return TIP_ERR_INVALID_ARG;
+    if (bytes < h->lay.total_floats * sizeof(float)) return TIP_ERR_INVALID_ARG;
+    for (int i = 0; i < n; ++i)
+        if (!t[i]) return TIP_ERR_INVALID_ARG;
+    const Dims& d = h->d;
+    const PackedLayout& L = h->lay;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<PackOp> ops;
+    auto op = [](const float* src, size_t dst, int N, int K, int src_rows, int src_cols, int frag) {
+        PackOp o;
+        o.src = src; o.src2 = nullptr; o.dst_off = dst; o.N = N; o.K = K; o.src_rows = src_rows; o.src_cols = src_cols; o.frag = frag;
+        o.shuffle_h = 0; o.shuffle_dh = 0; o.z0 = 0; o.z1 = 0; o.scale_rows = 0; o.scale = 1.f;
+        return o;
+    };
+    auto linear = [&](const PackedLinear& p, const float* W, const float* b) {
+        ops.push_back(op(W, p.w_off, p.Npad, p.Kpad, p.N, p.K, 0));
+        ops.push_back(op(b, p.b_off, p.Npad, 1, p.N, 1, 0));
+    };
+    {
+        PackOp w = op(t[0], L.in_lin.w_off, L.in_lin.Npad, L.in_lin.Kpad, d.D, d.In, 0);
+        w.shuffle_h = d.H; w.shuffle_dh = d.dh;
+        w.z0 = d.n_imu_total + d.rootv0; w.z1 = d.n_imu_total + d.rootv1;
+        ops.push_back(w);
+        PackOp b = op(t[1], L.in_lin.b_off, L.in_lin.Npad, 1, d.D, 1, 0);
+        b.shuffle_h = d.H; b.shuffle_dh = d.dh;
+        ops.push_back(b);
+    }
+    for (int l = 0; l < d.L; ++l) {
+        const float* const* lw = t + 2 + 12 * l;
+        const PackedLayer& pl = L.layers[l];
+        linear(pl.qkv, lw[0], lw[1]);
+        if (d.fold_q_scale) {
+            const float sc = 1.0f / sqrtf((float)d.dh);
+            ops[ops.size() - 2].scale = sc; ops[ops.size() - 2].scale_rows = d.D;
+            ops[ops.size() - 1].scale = sc; ops[ops.size() - 1].scale_rows = d.D;
+        }
+        linear(pl.out, lw[2], lw[3]);
+        linear(pl.ff1, lw[4], lw[5]);
+        linear(pl.ff2, lw[6], lw[7]);
+        ops.push_back(op(lw[8], pl.g1_off, d.D, 1, d.D, 1, 0));
+        ops.push_back(op(lw[9], pl.be1_off, d.D, 1, d.D, 1, 0));
+        ops.push_back(op(lw[10], pl.g2_off, d.D, 1, d.D, 1, 0));
+        ops.push_back(op(lw[11], pl.be2_off, d.D, 1, d.D, 1, 0));
+    }
+    const float* const* tw = t + 2 + 12 * d.L;
+    const float* Wo;
+    int Ko;
+    if (d.with_rnn) {
+        linear(L.rnn_ih, tw[0], tw[2]);
+        ops.back().src2 = tw[3];                                           // b_ih + b_hh
+        ops.push_back(op(tw[1], L.whh_frag_off, d.R, d.R, d.R, d.R, 1));
+        linear(L.out_lin, tw[4], tw[5]);
+        Wo = tw[4]; Ko = d.R;
+    } else {
+        linear(L.out_lin, tw[0], tw[1]);
+        Wo = tw[0]; Ko = d.D;
+    }
+    ops.push_back(op(Wo, L.out_frag_off, round_up(d.S, 16), Ko, d.S, Ko, 1));
+    if (L.fused_floats) fused_pack_ops(d, t, L.fused_off, ops);
+    if (hipMemsetAsync(packed_dev, 0, L.total_floats * sizeof(float), s) != hipSuccess) return TIP_ERR_HIP;
+    if (run_pack_ops(ops, static_cast<float*>(packed_dev), s) != hipSuccess) return TIP_ERR_HIP;
+    return TIP_OK;
+}
+
 int tip_attach_packed(tip_handle* h, const void* packed_device, size_t bytes) {
     if (!h || !packed_device) return TIP_ERR_INVALID_ARG;
     if (bytes < h->lay.total_floats * sizeof(float)) return TIP_ERR_INVALID_ARG;

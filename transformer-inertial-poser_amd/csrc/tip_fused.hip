@@ -118,6 +118,55 @@ void fused_pack(const Dims& d, const float* const* t, float* dst) {
     }
 }
 
+static PackOp mk_op(const float* src, size_t dst, int N, int K, int src_rows, int src_cols, int frag) {
+    PackOp o;
+    o.src = src; o.src2 = nullptr; o.dst_off = dst; o.N = N; o.K = K; o.src_rows = src_rows; o.src_cols = src_cols; o.frag = frag;
+    o.shuffle_h = 0; o.shuffle_dh = 0; o.z0 = 0; o.z1 = 0; o.scale_rows = 0; o.scale = 1.f;
+    return o;
+}
+
+// the same image as fused_pack() above, as descriptors for the on-device packer
+void fused_pack_ops(const Dims& d, const float* const* t, size_t base, std::vector<PackOp>& ops) {
+    using namespace fz;
+    {
+        PackOp o = mk_op(t[0], base + IN_W, D, KIN, D, d.In, 1);
+        o.shuffle_h = H; o.shuffle_dh = DH;
+        o.z0 = d.n_imu_total + d.rootv0; o.z1 = d.n_imu_total + d.rootv1;
+        ops.push_back(o);
+        PackOp b = mk_op(t[1], base + IN_B, D, 1, D, 1, 0);
+        b.shuffle_h = H; b.shuffle_dh = DH;
+        ops.push_back(b);
+    }
+    for (int l = 0; l < d.L; ++l) {
+        const float* const* lw = t + 2 + 12 * l;
+        const size_t L = base + LAYER0 + (size_t)l * LAYER_FLOATS;
+        PackOp q = mk_op(lw[0], L + QKV_W, 3 * D, D, 3 * D, D, 1);
+        q.scale = 0.25f; q.scale_rows = D;
+        ops.push_back(q);
+        PackOp qb = mk_op(lw[1], L + QKV_B, 3 * D, 1, 3 * D, 1, 0);
+        qb.scale = 0.25f; qb.scale_rows = D;
+        ops.push_back(qb);
+        ops.push_back(mk_op(lw[2], L + WO_W, D, D, D, D, 1));
+        ops.push_back(mk_op(lw[3], L + WO_B, D, 1, D, 1, 0));
+        ops.push_back(mk_op(lw[4], L + W1_W, F, D, F, D, 1));
+        ops.push_back(mk_op(lw[5], L + W1_B, F, 1, F, 1, 0));
+        ops.push_back(mk_op(lw[6], L + W2_W, D, F, D, F, 1));
+        ops.push_back(mk_op(lw[7], L + W2_B, D, 1, D, 1, 0));
+        ops.push_back(mk_op(lw[8], L + G1, D, 1, D, 1, 0));
+        ops.push_back(mk_op(lw[9], L + BE1, D, 1, D, 1, 0));
+        ops.push_back(mk_op(lw[10], L + G2, D, 1, D, 1, 0));
+        ops.push_back(mk_op(lw[11], L + BE2, D, 1, D, 1, 0));
+    }
+    if (fused_has_rnn_ih(d)) {
+        const float* const* tw = t + 2 + 12 * d.L;
+        const size_t I = base + fused_ih_off(d);
+        ops.push_back(mk_op(tw[0], I, R, D, R, D, 1));
+        PackOp b = mk_op(tw[2], I + (size_t)R * D, R, 1, R, 1, 0);
+        b.src2 = tw[3];
+        ops.push_back(b);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // device pieces
 // ------------------------------------------------------------------------------------------------------------

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <algorithm>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -73,6 +74,26 @@ struct PackedLayout {
     size_t total_floats;
 };
 
+// One destination array of the packed image, as a function of one (or the sum of two) source tensors: used by the on-device
+// packer (tip_pack.hip).  dst element (n, k), n < N, k < K:  src[map(n)][k] (+ src2) for n < src_rows, k < src_cols and k
+// outside [z0, z1), times `scale` for n < scale_rows, else 0; stored row-major or in 16x16x4 B-fragment order.
+struct PackOp {
+    const float* src;
+    const float* src2;
+    unsigned long long dst_off;   // float offset into the image
+    int N, K;
+    int src_rows, src_cols;
+    int frag;                     // 0: [N][K] row-major, 1: [N/16][K/16][64 lanes][4]
+    int shuffle_h, shuffle_dh;    // 0 = identity, else dst row a*H + b <- src row b*dh + a (channel shuffle :88-89)
+    int z0, z1;
+    int scale_rows;
+    float scale;
+};
+constexpr int kPackBatch = 32;
+struct PackBatch {
+    PackOp ops[kPackBatch];
+};
+
 // Workspace carve-up for the general plan (float offsets), M = B*T rows.
 struct Workspace {
     size_t xa, xb, big, att, hall, flags, lat;  // float offsets
@@ -133,7 +154,12 @@ size_t rnn_flag_words(int B, int T);
 hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_frag, const float* h_fwd, float* delta,
                           unsigned* flags, int B, int T, int cluster, int num_cus, hipStream_t s);
 
+// ---- on-device packing (tip_pack.hip) ----
+hipError_t run_pack_ops(const std::vector<PackOp>& ops, float* img, hipStream_t s);
+
 // ---- fused plan (tip_fused.hip) ----
+// descriptors of the fused section for the on-device packer (t = 56 device pointers, base = float offset of the section)
+void fused_pack_ops(const Dims& d, const float* const* t, size_t base, std::vector<PackOp>& ops);
 bool fused_supported(const Dims& d, int T);
 size_t fused_packed_floats(const Dims& d);
 void fused_pack(const Dims& d, const float* const* tensors, float* dst);

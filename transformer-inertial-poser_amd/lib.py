@@ -21,7 +21,7 @@ TIP_OPT_PLAN, TIP_OPT_PROFILE, TIP_OPT_RNN_CLUSTER = 1, 2, 3
 EXPORTS = (
     "tip_abi_version", "tip_create", "tip_destroy", "tip_strerror", "tip_last_hip_error", "tip_set_option",
     "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
-    "tip_attach_packed", "tip_workspace_bytes", "tip_forward", "tip_forward_count", "tip_profile_read",
+    "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_forward", "tip_forward_count", "tip_profile_read",
     "tip_spin_timeouts", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
     "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward",
     "tip_combine_frames", "tip_combine_scratch_bytes", "tip_combine_sequence", "tip_gather_windows",
@@ -88,6 +88,7 @@ def load() -> ctypes.CDLL:
     lib.tip_tensor_info.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     lib.tip_packed_bytes.argtypes = [vp, ctypes.POINTER(sz)]
     lib.tip_pack_weights.argtypes = [vp, ctypes.POINTER(vp), i32, vp, sz]
+    lib.tip_pack_weights_device.argtypes = [vp, ctypes.POINTER(vp), i32, vp, sz, vp]
     lib.tip_attach_packed.argtypes = [vp, vp, sz]
     lib.tip_workspace_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
     lib.tip_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, ctypes.c_float, vp, sz, vp]
@@ -165,6 +166,11 @@ class Handle:
     def pack_weights(self, host_ptrs: List[int], out_ptr: int, out_bytes: int):
         arr = (ctypes.c_void_p * len(host_ptrs))(*host_ptrs)
         self._check(self.lib.tip_pack_weights(self._h, arr, len(host_ptrs), ctypes.c_void_p(out_ptr), out_bytes))
+
+    def pack_weights_device(self, dev_ptrs: List[int], out_dev_ptr: int, out_bytes: int, stream: int):
+        arr = (ctypes.c_void_p * len(dev_ptrs))(*dev_ptrs)
+        self._check(self.lib.tip_pack_weights_device(self._h, arr, len(dev_ptrs), ctypes.c_void_p(out_dev_ptr), out_bytes,
+                                                     stream))
 
     def attach_packed(self, dev_ptr: int, nbytes: int):
         self._check(self.lib.tip_attach_packed(self._h, ctypes.c_void_p(dev_ptr), nbytes))

@@ -245,9 +245,24 @@ class TF_RNN_Past_State(nn.Module):
         self._packed_dev = packed_dev
         self._packed_key = self._param_key(packed_dev.device)
 
+    def pack_device(self, device=None) -> torch.Tensor:
+        """Build the packed weight image ON the GPU from the live parameters (tip_pack_weights_device): same bytes as
+        pack_host(), no host round trip."""
+        h = self._ensure_handle()
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        tensors = [p.detach().to(device, torch.float32).contiguous() for p in self.state_dict().values()]
+        out = torch.empty(h.packed_bytes(), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            h.pack_weights_device([t.data_ptr() for t in tensors], out.data_ptr(), out.numel(),
+                                  torch.cuda.current_stream(device).cuda_stream)
+        return out
+
     def refresh_packed(self, device=None):
-        device = device if device is not None else next(self.parameters()).device
-        self.attach_packed(self.pack_host().to(device, non_blocking=False))
+        device = torch.device(device) if device is not None else next(self.parameters()).device
+        if device.type == "cuda" and all(p.is_cuda for p in self.parameters()):
+            self.attach_packed(self.pack_device(device))          # parameters already live on the GPU: pack there
+        else:
+            self.attach_packed(self.pack_host().to(device, non_blocking=False))
 
     def freeze_packed(self, frozen: bool = True):
         """Skip the per-call 'did the parameters change' check (streaming hot loop)."""
