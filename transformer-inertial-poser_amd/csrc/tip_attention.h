@@ -98,5 +98,80 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
     }
 }
 
+// The same attention with Q, K and V arriving IN REGISTERS, for a wave that has just projected its own head:
+//   qt[r], kt[r]  Q^T / K^T tiles of row block r: lane holds (channels 4*lg + e, row l15) — what the projection yields when
+//                 its MFMA operands are swapped (weights as A, activations as B);
+//   v[r]          V tile of row block r in the plain accumulator layout: (keys 4*lg + e, channel l15).
+// These are precisely the A/B fragments of S^T = K Q^T and the B fragments of P V, so the head goes from projection to
+// output without touching LDS and without a workgroup barrier in between.  O is written to the plane `Oc` (out-projection
+// A operand) at column c0.
+template <int LDC>
+__device__ __forceinline__ void attention_head_regs(const f32x4_att (&qt)[3], const f32x4_att (&kt)[3], const f32x4_att (&v)[3],
+                                                    float* Oc, int c0, int lane, int row_limit = 48) {
+    constexpr int RB = 3;
+    const int l15 = lane & 15, lg = lane >> 4;
+    f32x4_att S[RB][RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int cb = 0; cb <= r; ++cb) {
+            f32x4_att t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t = __builtin_amdgcn_mfma_f32_16x16x4f32(kt[cb][e], qt[r][e], t, 0, 0, 0);
+            S[r][cb] = t;
+        }
+    float mx[RB], rsum[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (lg * 4 + e <= l15) m = fmaxf(m, S[r][r][e]);
+#pragma unroll
+            for (int cb = 0; cb < r; ++cb) m = fmaxf(m, S[r][cb][e]);
+        }
+        mx[r] = m;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], 16, 64));
+#pragma unroll
+    for (int r = 0; r < RB; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], 32, 64));
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        float sm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int cb = 0; cb < r; ++cb) {
+                const float p = __expf(S[r][cb][e] - mx[r]);
+                S[r][cb][e] = p;
+                sm += p;
+            }
+            const float pd = (lg * 4 + e <= l15) ? __expf(S[r][r][e] - mx[r]) : 0.f;
+            S[r][r][e] = pd;
+            sm += pd;
+        }
+        rsum[r] = sm;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) rsum[r] += __shfl_xor(rsum[r], 16, 64);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) rsum[r] += __shfl_xor(rsum[r], 32, 64);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) rsum[r] = 1.0f / rsum[r];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        f32x4_att o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb <= r; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_16x16x4f32(S[r][kb][e], v[kb][e], o, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float inv = __shfl(rsum[r], lg * 4 + e, 64);
+            if (r * 16 + lg * 4 + e < row_limit) Oc[(r * 16 + lg * 4 + e) * LDC + c0 + l15] = o[e] * inv;
+        }
+    }
+}
 
 }  // namespace tip

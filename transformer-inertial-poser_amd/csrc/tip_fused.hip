@@ -176,24 +176,20 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
-template <int NBW>
+// acc[r][n] += A(rows of block r) x W(block n).  For the first SWAPN column blocks the MFMA operands are swapped (weights
+// as A, activations as B): the accumulator then holds the TRANSPOSED tile — (channels 4*lg + e, row l15) — which is the
+// fragment layout a following MFMA wants for Q and K (tip_attention.h, attention_head_regs).
+template <int NBW, int SWAPN = 0>
 __device__ __forceinline__ void mfma_block(f32x4 (&acc)[fz::RB][NBW], const float4 (&a)[fz::RB], const float4 (&w)[NBW]) {
-#pragma unroll
-    for (int r = 0; r < fz::RB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].x, w[n].x, acc[r][n], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < fz::RB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].y, w[n].y, acc[r][n], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < fz::RB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].z, w[n].z, acc[r][n], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < fz::RB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].w, w[n].w, acc[r][n], 0, 0, 0);
+#define TIP_MFMA_STEP(c)                                                                                             \
+    _Pragma("unroll") for (int r = 0; r < fz::RB; ++r) _Pragma("unroll") for (int n = 0; n < NBW; ++n)                \
+        acc[r][n] = n < SWAPN ? __builtin_amdgcn_mfma_f32_16x16x4f32(w[n].c, a[r].c, acc[r][n], 0, 0, 0)              \
+                              : __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].c, w[n].c, acc[r][n], 0, 0, 0);
+    TIP_MFMA_STEP(x)
+    TIP_MFMA_STEP(y)
+    TIP_MFMA_STEP(z)
+    TIP_MFMA_STEP(w)
+#undef TIP_MFMA_STEP
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -232,7 +228,7 @@ __device__ __forceinline__ void ring_prefetch(WRing<NBW>& g, __amdgpu_buffer_rsr
 //   loop => counted vmcnt waits); for the LAST pair it is redirected to k-blocks 0,1 of the NEXT phase
 //   (nsoff / nnstride_b), so on exit the ring is already primed for a following phase of the same width.
 //   Callers without such a successor pass their own soff (a harmless in-bounds reload).
-template <int NBW, int KB, bool NOMMA = false>
+template <int NBW, int KB, bool NOMMA = false, int SWAPN = 0>
 __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[fz::RB][NBW], const float* As, int lda, __amdgpu_buffer_rsrc_t rsrc,
                                            int voff, int soff, int nstride_b, WRing<NBW>& g, int nsoff, int nnstride_b) {
     static_assert(KB % 2 == 0, "k-blocks are processed in pairs");
@@ -248,13 +244,13 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[fz::RB][NBW], const floa
         const int st = last ? nnstride_b : nstride_b;
 #pragma unroll
         for (int r = 0; r < fz::RB; ++r) a1[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda + (kb + 1) * 16);
-        if (!NOMMA) mfma_block<NBW>(acc, a0, g.w0);
+        if (!NOMMA) mfma_block<NBW, SWAPN>(acc, a0, g.w0);
         else { asm volatile("" :: "v"(a0[0].x), "v"(g.w0[0].x)); }
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w0[n] = load_frag(rsrc, voff, o + n * st);
 #pragma unroll
         for (int r = 0; r < fz::RB; ++r) a0[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda + (kb + 2) * 16);
-        if (!NOMMA) mfma_block<NBW>(acc, a1, g.w1);
+        if (!NOMMA) mfma_block<NBW, SWAPN>(acc, a1, g.w1);
         else { asm volatile("" :: "v"(a1[0].x), "v"(g.w1[0].x)); }
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w1[n] = load_frag(rsrc, voff, o + n * st + 1024);
@@ -377,9 +373,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
         for (int layer = 0; layer < L; ++layer) {
             const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
             const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
-            float* Qc = C;
-            float* Kc = C + RP * LDC;
-            float* Vt = C + 2 * RP * LDC;   // V^T [128 channels][LDV]
+            float* Qc = C;   // attention output of one 8-head chunk [48 rows][128 channels]: the out-projection's A operand
             // ---- self-attention block: two chunks of 8 heads; wave w owns head 8c + w end to end -----------------
             f32x4 acc_o[RB][2];
             zero_acc<2>(acc_o);
@@ -393,28 +387,25 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     zero_acc<3>(acc);
                     // column blocks of this head in the packed [48 nb][16 kb] QKV matrix: Q = head, K = 16+head, V = 32+head
                     const int qsoff = lbase + (int)(QKV_W * 4) + head * 16 * 1024;
-                    const float bq = LW[QKV_B + head * 16 + l15];
-                    const float bk = LW[QKV_B + D + head * 16 + l15];
-                    const float bv = LW[QKV_B + 2 * D + head * 16 + l15];
-                    gemm_phase<3, 16, (ABL & 4) != 0>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, qsoff, 16 * 16 * 1024, g_qkv, qsoff,
-                                      16 * 16 * 1024);
-                    // out-projection fragments of this chunk fly during the epilogue, the barrier and the attention
+                    // Q and K are projected with swapped MFMA operands: their accumulators come out as (channels 4*lg + e,
+                    // row l15) — the fragments S^T = K Q^T wants — and V in the plain layout P V wants, so this wave's head
+                    // runs projection -> scores -> softmax -> P V entirely in registers: no Q/K/V planes, no barrier here.
+                    gemm_phase<3, 16, (ABL & 4) != 0, 2>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, qsoff, 16 * 16 * 1024, g_qkv,
+                                                         qsoff, 16 * 16 * 1024);
+                    // out-projection fragments of this chunk fly during the attention
                     ring_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + c * 8) * 1024, 16 * 1024);
-                    const int col = wave * 16 + l15;
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(LW + QKV_B + head * 16 + lg * 4);
+                    const f32x4 bk = *reinterpret_cast<const f32x4*>(LW + QKV_B + D + head * 16 + lg * 4);
+                    const float bv = LW[QKV_B + 2 * D + head * 16 + l15];
+                    f32x4 qt[RB], kt[RB], vv[RB];
 #pragma unroll
                     for (int r = 0; r < RB; ++r) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int row = r * 16 + lg * 4 + e;
-                            Qc[row * LDC + col] = acc[r][0][e] + bq;
-                            Kc[row * LDC + col] = acc[r][1][e] + bk;
-                        }
-                        // V transposed: this lane's 4 keys of channel `col` are contiguous -> one b128 store
-                        *reinterpret_cast<f32x4*>(Vt + col * LDV + r * 16 + lg * 4) = acc[r][2] + bv;
+                        qt[r] = acc[r][0] + bq;
+                        kt[r] = acc[r][1] + bk;
+                        vv[r] = acc[r][2] + bv;
                     }
+                    if (!(ABL & 1)) attention_head_regs<LDC>(qt, kt, vv, Qc, wave * 16, lane);
                 }
-                __syncthreads();
-                if (!(ABL & 1)) attention_head_mfma<LDC, LDV>(Qc, Kc, Vt, wave * 16, lane);
                 __syncthreads();
                 // the next consumer's fragments go out before this phase's MFMAs: chunk 1's QKV, or the first FFN chunk
                 if (c == 0)
