@@ -682,12 +682,16 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
     }
     const bool same_xcd = HANDOFF == 1 && s_same_xcd != 0;
 
-    // W_hh slice -> registers, once
+    // W_hh slice -> registers, once.  KSPLIT = 1 / 2: wave ks owns the contiguous k-blocks [ks*KBW, (ks+1)*KBW).
+    // KSPLIT = 4: wave ks owns ONE canonical chain — half ks>>1, parity ks&1: k-blocks (ks>>1)*16 + (ks&1) + 2i.
     float4 wreg[KBW];
     {
-        const float4* wf = reinterpret_cast<const float4*>(whh_frag) + ((size_t)nb * KB + ks * KBW) * 64 + lane;
+        const float4* wf = reinterpret_cast<const float4*>(whh_frag) + (size_t)nb * KB * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < KBW; ++k) wreg[k] = wf[(size_t)k * 64];
+        for (int k = 0; k < KBW; ++k) {
+            const int kblk = KSPLIT == 4 ? (ks >> 1) * (KB / 2) + (ks & 1) + 2 * k : ks * KBW + k;
+            wreg[k] = wf[(size_t)kblk * 64];
+        }
     }
 
     for (int tile = group; tile < ntiles; tile += ngroups) {
@@ -706,7 +710,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
             }
             // canonical accumulation (see rnn_kernel): chains {lower,upper half of K} x {even,odd k-block}
             constexpr int NH = KSPLIT == 1 ? 2 : 1;   // K halves handled by this wave
-            static_assert(KSPLIT == 1 || KSPLIT == 2, "canonical order is defined on two K halves");
+            static_assert(KSPLIT == 1 || KSPLIT == 2 || KSPLIT == 4, "canonical order: two K halves x two k-block parities");
             f32x4 chn[NH][2];
 #pragma unroll
             for (int hh = 0; hh < NH; ++hh) chn[hh][0] = chn[hh][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -768,6 +772,19 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                 }
                 __syncthreads();
                 if (TRACE && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 0] = __builtin_amdgcn_s_memtime();
+                if (KSPLIT == 4) {
+                    // one chain per wave: its 8 k-blocks in ascending order, all into chn[0][0]
+                    const float* ap4 = smem + l15 * LDH + ((ks >> 1) * (KB / 2) + (ks & 1)) * 16 + lg * 4;
+#pragma unroll
+                    for (int k = 0; k < KBW; ++k) {
+                        const float4 a0 = *reinterpret_cast<const float4*>(ap4 + k * 32);
+                        chn[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wreg[k].x, chn[0][0], 0, 0, 0);
+                        chn[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wreg[k].y, chn[0][0], 0, 0, 0);
+                        chn[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wreg[k].z, chn[0][0], 0, 0, 0);
+                        chn[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wreg[k].w, chn[0][0], 0, 0, 0);
+                    }
+                }
+                if (KSPLIT != 4) {
                 const float* ap = smem + l15 * LDH + ks * KBW * 16 + lg * 4;
 #pragma unroll
                 for (int hh = 0; hh < NH; ++hh) {
@@ -785,8 +802,9 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                         chn[hh][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wreg[k + 1].w, chn[hh][1], 0, 0, 0);
                     }
                 }
+                }
             }
-            f32x4 acc = chn[0][0] + chn[0][1];
+            f32x4 acc = KSPLIT == 4 ? chn[0][0] : chn[0][0] + chn[0][1];
             if (NH == 2) acc = acc + (chn[NH - 1][0] + chn[NH - 1][1]);
             if (TRACE && blockIdx.x == 0 && tid == 0 && t < 64) {
                 asm volatile("" :: "v"(acc[0]));
@@ -796,8 +814,15 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                 if (ks > 0) *reinterpret_cast<f32x4*>(red + (((ks - 1) * CBW + cb) * 64 + lane) * 4) = acc;
                 __syncthreads();
                 if (ks == 0) {
+                    if (KSPLIT == 4) {   // (c00 + c01) + (c10 + c11): the canonical combination of the four chains
+                        const f32x4 c01 = *reinterpret_cast<const f32x4*>(red + ((0 * CBW + cb) * 64 + lane) * 4);
+                        const f32x4 c10 = *reinterpret_cast<const f32x4*>(red + ((1 * CBW + cb) * 64 + lane) * 4);
+                        const f32x4 c11 = *reinterpret_cast<const f32x4*>(red + ((2 * CBW + cb) * 64 + lane) * 4);
+                        acc = (acc + c01) + (c10 + c11);
+                    } else {
 #pragma unroll
-                    for (int q = 1; q < KSPLIT; ++q) acc += *reinterpret_cast<const f32x4*>(red + (((q - 1) * CBW + cb) * 64 + lane) * 4);
+                        for (int q = 1; q < KSPLIT; ++q) acc += *reinterpret_cast<const f32x4*>(red + (((q - 1) * CBW + cb) * 64 + lane) * 4);
+                    }
                 }
             }
             if (ks == 0) {
@@ -896,7 +921,7 @@ hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_fra
     if (B <= 0) return hipSuccess;
     if (d.R != 512 || (long long)B * T * 512 * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
-    if (cluster >= 16) return launch_rnn_resident<4, 2>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, s, h_fwd);
+    if (cluster >= 16) return launch_rnn_resident<8, 4>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, s, h_fwd);
     if (cluster == 8) return launch_rnn_resident<4, 1>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, s, h_fwd);
     return launch_rnn_resident<8, 1>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, s, h_fwd);
 }
@@ -909,7 +934,12 @@ hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, flo
     if (cluster < 1) cluster = 1;
     if (R == 512 && (long long)B * T * 512 * 4 <= 0x7fffffffLL) {
         // register-resident clustered kernel: W_hh slice lives in VGPRs, 4/8/16 workgroups per window tile
-        if (cluster >= 16) return launch_rnn_resident<4, 2>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, s);
+        if (cluster >= 16) {
+            static int w8 = -1;   // TIP_RNN_C16=4 selects the 4-wave variant (measurement)
+            if (w8 < 0) w8 = (getenv("TIP_RNN_C16") && getenv("TIP_RNN_C16")[0] == '4') ? 0 : 1;
+            return w8 ? launch_rnn_resident<8, 4>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, s)
+                      : launch_rnn_resident<4, 2>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, s);
+        }
         if (cluster == 8) return launch_rnn_resident<4, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, s);
         if (cluster == 4) return launch_rnn_resident<8, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, s);
     }
