@@ -105,10 +105,21 @@ def cpu_baseline(cfg, B, T, budget_s=12.0):
             el = time.perf_counter() - t0
             if el > budget_s or n >= 40:
                 break
+        # the reference's own streaming setting: one stream, one thread (offline_testing_simple.py:34, real_time_runner_minimal.py:149)
+        torch.set_num_threads(1)
+        x1i, x1s = xi[:1].contiguous(), xs[:1].contiguous()
+        m._forward_torch_ops(x1i, x1s)
+        n1, t1 = 0, time.perf_counter()
+        while n1 < 30 and time.perf_counter() - t1 < 2.0:
+            m._forward_torch_ops(x1i, x1s)
+            n1 += 1
+        b1_ms = (time.perf_counter() - t1) / n1 * 1e3
         torch.set_num_threads(max_threads)
     out = {"value": B * n / el, "unit": "IMU frames/s", "cores": cores, "kind": "port",
            "sample": f"{n} forwards of B={B},T={T} (paper config) with the torch-op restatement of the reference CPU "
-                     f"path, best of 1/8/16/32/64/{max_threads} threads = {cores}, {el:.1f} s"}
+                     f"path, best of 1/8/16/32/64/{max_threads} threads = {cores}, {el:.1f} s",
+           "b1_one_thread": {"ms_per_window": b1_ms, "realtime_factor_60fps": (1000.0 / b1_ms) / 60.0,
+                             "sample": f"{n1} forwards of B=1,T={T}, torch.set_num_threads(1) as the reference's runner"}}
     # the C oracle (scalar port, OpenMP over windows), same workload, bounded
     try:
         from oracle import oracle
