@@ -105,9 +105,13 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
 // These are precisely the A/B fragments of S^T = K Q^T and the B fragments of P V, so the head goes from projection to
 // output without touching LDS and without a workgroup barrier in between.  O is written to the plane `Oc` (out-projection
 // A operand) at column c0.
-template <int LDC>
+// TRAIN: dropout on the probabilities (keep = hash(seed, site, (bh*T + query)*T + key) >= thresh) and the softmax statistics
+// (row max, 1 / row sum) of every real query written to ast[(bh*T + query)*2 ..] for the backward.
+template <int LDC, bool TRAIN = false>
 __device__ __forceinline__ void attention_head_regs(const f32x4_att (&qt)[3], const f32x4_att (&kt)[3], const f32x4_att (&v)[3],
-                                                    float* Oc, int c0, int lane, int row_limit = 48) {
+                                                    float* Oc, int c0, int lane, int row_limit = 48, float* ast = nullptr,
+                                                    unsigned long long bh = 0, int T = 0, unsigned long long seed = 0,
+                                                    unsigned site = 0, unsigned thresh = 0, float dscale = 1.f) {
     constexpr int RB = 3;
     const int l15 = lane & 15, lg = lane >> 4;
     f32x4_att S[RB][RB];
@@ -159,6 +163,26 @@ __device__ __forceinline__ void attention_head_regs(const f32x4_att (&qt)[3], co
     for (int r = 0; r < RB; ++r) rsum[r] += __shfl_xor(rsum[r], 32, 64);
 #pragma unroll
     for (int r = 0; r < RB; ++r) rsum[r] = 1.0f / rsum[r];
+    if (TRAIN) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int q = r * 16 + l15;
+            if (q < T) {
+                if (lg == 0) {
+                    ast[(bh * T + q) * 2] = mx[r];
+                    ast[(bh * T + q) * 2 + 1] = rsum[r];
+                }
+                if (thresh) {
+                    const unsigned long long pb = (bh * T + q) * T;
+#pragma unroll
+                    for (int cb = 0; cb <= r; ++cb)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            S[r][cb][e] = tip_drop_hash(seed, site, pb + cb * 16 + lg * 4 + e) >= thresh ? S[r][cb][e] * dscale : 0.f;
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         f32x4_att o = {0.f, 0.f, 0.f, 0.f};

@@ -267,8 +267,11 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[fz::RB][NBW]) {
 
 // LayerNorm over the 48 rows of X (eps 1e-5, biased variance): wave w owns rows w, w+8, ... (6 rows); the six row
 // reductions advance together through every shuffle step so their latencies overlap.
+// zs / sts / xs (training forward, all three or none): the pre-norm rows, their (mean, rstd) and the normalised rows are
+// also written to HBM for rows < T — each wave owns whole rows, so these are plain 1-KB row stores.
+template <bool SAVE = false>
 __device__ __forceinline__ void layernorm_rows(float* X, const float* __restrict__ g, const float* __restrict__ be, int wave,
-                                               int lane) {
+                                               int lane, float* zs = nullptr, float* sts = nullptr, float* xs = nullptr, int T = 0) {
     constexpr int NR = fz::RP / 8;
     const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
     const float4 bb = *reinterpret_cast<const float4*>(be + lane * 4);
@@ -278,6 +281,7 @@ __device__ __forceinline__ void layernorm_rows(float* X, const float* __restrict
     for (int i = 0; i < NR; ++i) {
         v[i] = *reinterpret_cast<const float4*>(X + (wave + 8 * i) * fz::LDX + lane * 4);
         mean[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        if (SAVE && wave + 8 * i < T) *reinterpret_cast<float4*>(zs + (size_t)(wave + 8 * i) * fz::D + lane * 4) = v[i];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
@@ -302,6 +306,22 @@ __device__ __forceinline__ void layernorm_rows(float* X, const float* __restrict
         o.z = v[i].z * rstd * gg.z + bb.z;
         o.w = v[i].w * rstd * gg.w + bb.w;
         *reinterpret_cast<float4*>(X + (wave + 8 * i) * fz::LDX + lane * 4) = o;
+        if (SAVE && wave + 8 * i < T) {
+            *reinterpret_cast<float4*>(xs + (size_t)(wave + 8 * i) * fz::D + lane * 4) = o;
+            if (lane == 0) {
+                sts[(wave + 8 * i) * 2] = mean[i];
+                sts[(wave + 8 * i) * 2 + 1] = rstd;
+            }
+        }
+    }
+}
+
+// rows 0..T-1 of an LDS tile [rows][ld] (cols floats wide) -> HBM rows of stride dst_ld, 16-byte stores
+__device__ __forceinline__ void rows_to_hbm(const float* lds, int ld, int cols, float* dst, int dst_ld, int T, int tid) {
+    const int c4n = cols >> 2;
+    for (int i = tid; i < T * c4n; i += fz::THREADS) {
+        const int r = i / c4n, c4 = i - r * c4n;
+        *reinterpret_cast<float4*>(dst + (size_t)r * dst_ld + c4 * 4) = *reinterpret_cast<const float4*>(lds + r * ld + c4 * 4);
     }
 }
 
@@ -311,8 +331,9 @@ template <int ABL>
 __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
     const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
     const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ xout, float* __restrict__ ih_out,
-    unsigned* __restrict__ hall_sentinel, int B, int T, int NI, int S, int L, int wbytes, int ih_off_b) {
+    unsigned* __restrict__ hall_sentinel, int B, int T, int NI, int S, int L, int wbytes, int ih_off_b, FusedTrain tr) {
     using namespace fz;
+    constexpr bool TR = (ABL & 8) != 0;   // training forward: stash activations, apply the encoder's dropout
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;
     float* C = smem + X_FLOATS;
@@ -368,11 +389,14 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
             }
         }
         __syncthreads();
+        const size_t grow0 = (size_t)win * T;           // first global row (b*T + t) of this window
+        if (TR) rows_to_hbm(X, LDX, D, tr.sv + tr.x0 + grow0 * D, D, T, tid);
 
 #pragma unroll 1
         for (int layer = 0; layer < L; ++layer) {
             const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
             const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
+            float* svl = TR ? tr.sv + (size_t)layer * tr.layer_stride : nullptr;   // this layer's stash
             float* Qc = C;   // attention output of one 8-head chunk [48 rows][128 channels]: the out-projection's A operand
             // ---- self-attention block: two chunks of 8 heads; wave w owns head 8c + w end to end -----------------
             f32x4 acc_o[RB][2];
@@ -404,9 +428,31 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                         kt[r] = acc[r][1] + bk;
                         vv[r] = acc[r][2] + bv;
                     }
-                    if (!(ABL & 1)) attention_head_regs<LDC>(qt, kt, vv, Qc, wave * 16, lane);
+                    if (TR) {
+                        // raw q (the packed W_q carries the 1/sqrt(d_head) fold: undo it exactly), k, v -> [M, 3D]
+                        float* qp = svl + tr.qkv + grow0 * (3 * D) + head * 16;
+#pragma unroll
+                        for (int r = 0; r < RB; ++r) {
+                            const int row = r * 16 + l15;
+                            if (row < T) {
+                                *reinterpret_cast<f32x4*>(qp + (size_t)row * (3 * D) + lg * 4) = qt[r] * 4.0f;
+                                *reinterpret_cast<f32x4*>(qp + (size_t)row * (3 * D) + D + lg * 4) = kt[r];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int vr = r * 16 + lg * 4 + e;
+                                if (vr < T) qp[(size_t)vr * (3 * D) + 2 * D + l15] = vv[r][e];
+                            }
+                        }
+                        attention_head_regs<LDC, true>(qt, kt, vv, Qc, wave * 16, lane, 48, svl + tr.ast,
+                                                       (unsigned long long)win * H + head, T, tr.seed, (unsigned)(layer * 4 + 0),
+                                                       tr.thresh, tr.scale);
+                    } else if (!(ABL & 1)) {
+                        attention_head_regs<LDC>(qt, kt, vv, Qc, wave * 16, lane);
+                    }
                 }
                 __syncthreads();
+                if (TR) rows_to_hbm(Qc, LDC, 128, svl + tr.att + grow0 * D + c * 128, D, T, tid);
                 // the next consumer's fragments go out before this phase's MFMAs: chunk 1's QKV, or the first FFN chunk
                 if (c == 0)
                     ring_prefetch<3>(g_qkv, rsrc, voff, lbase + (int)(QKV_W * 4) + (8 + wave) * 16 * 1024, 16 * 16 * 1024);
@@ -427,10 +473,19 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
 #pragma unroll
                 for (int r = 0; r < RB; ++r)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_o[r][n][e] + bv;
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc_o[r][n][e] + bv;
+                        if (TR && tr.thresh)
+                            v = tip_drop_hash(tr.seed, (unsigned)(layer * 4 + 1), (grow0 + r * 16 + lg * 4 + e) * D + col) >= tr.thresh
+                                    ? v * tr.scale : 0.f;
+                        X[(r * 16 + lg * 4 + e) * LDX + col] += v;
+                    }
             }
             __syncthreads();
-            if (!(ABL & 2)) layernorm_rows(X, LW + G1, LW + BE1, wave, lane);
+            if (TR)
+                layernorm_rows<true>(X, LW + G1, LW + BE1, wave, lane, svl + tr.z1 + grow0 * D, svl + tr.st1 + grow0 * 2,
+                                     svl + tr.x1 + grow0 * D, T);
+            else if (!(ABL & 2)) layernorm_rows(X, LW + G1, LW + BE1, wave, lane);
             __syncthreads();
             // ---- feed-forward block: hidden processed in 4 chunks of 256, second GEMM accumulates in registers -----
             float* Hc = C;
@@ -453,10 +508,17 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
 #pragma unroll
                         for (int r = 0; r < RB; ++r)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) Hc[(r * 16 + lg * 4 + e) * LDX + col] = fmaxf(acc[r][n][e] + bv, 0.f);
+                            for (int e = 0; e < 4; ++e) {
+                                float v = fmaxf(acc[r][n][e] + bv, 0.f);
+                                if (TR && tr.thresh)
+                                    v = tip_drop_hash(tr.seed, (unsigned)(layer * 4 + 2),
+                                                      (grow0 + r * 16 + lg * 4 + e) * F + f * 256 + col) >= tr.thresh ? v * tr.scale : 0.f;
+                                Hc[(r * 16 + lg * 4 + e) * LDX + col] = v;
+                            }
                     }
                 }
                 __syncthreads();
+                if (TR) rows_to_hbm(Hc, LDX, 256, svl + tr.hid + grow0 * F + f * 256, F, T, tid);
                 {
                     const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                     // ... and the tail of linear2(f) primes it with linear1(f+1)'s (its own again after the last chunk)
@@ -477,10 +539,19 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
 #pragma unroll
                 for (int r = 0; r < RB; ++r)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_f[r][n][e] + bv;
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc_f[r][n][e] + bv;
+                        if (TR && tr.thresh)
+                            v = tip_drop_hash(tr.seed, (unsigned)(layer * 4 + 3), (grow0 + r * 16 + lg * 4 + e) * D + col) >= tr.thresh
+                                    ? v * tr.scale : 0.f;
+                        X[(r * 16 + lg * 4 + e) * LDX + col] += v;
+                    }
             }
             __syncthreads();
-            if (!(ABL & 2)) layernorm_rows(X, LW + G2, LW + BE2, wave, lane);
+            if (TR)
+                layernorm_rows<true>(X, LW + G2, LW + BE2, wave, lane, svl + tr.z2 + grow0 * D, svl + tr.st2 + grow0 * 2,
+                                     svl + tr.xo + grow0 * D, T);
+            else if (!(ABL & 2)) layernorm_rows(X, LW + G2, LW + BE2, wave, lane);
             __syncthreads();
         }
         // ---- RNN input projection (:99, first half of nn.RNN): IH = X W_ih^T + (b_ih + b_hh), rows 0..T-1 -> HBM ----
@@ -546,7 +617,7 @@ hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float
         }                                                                                                                \
         hipLaunchKernelGGL(fused_encoder_kernel<A>, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, \
                            keep_mask, keep_scale, xout, iho, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L, wb, \
-                           iob);                    \
+                           iob, FusedTrain{});                    \
     }
     switch (abl) {
         case 0: TIP_FUSED_LAUNCH(0) break;
@@ -558,6 +629,25 @@ hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float
         default: return hipErrorInvalidValue;
     }
 #undef TIP_FUSED_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s, const float* keep_mask,
+                              float keep_scale, float* ih_out, float* hall_sentinel, const FusedTrain& tr, int B, int T,
+                              int num_cus, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (!fused_supported(d, T) || !fused_has_rnn_ih(d)) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_kernel<8>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = B < num_cus ? B : num_cus;
+    hipLaunchKernelGGL(fused_encoder_kernel<8>, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+                       keep_scale, (float*)nullptr, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,
+                       (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4), tr);
     return hipGetLastError();
 }
 

@@ -29,6 +29,25 @@ struct Drop {
 };
 typedef Drop AttnDrop;
 
+// keep(seed, site, idx): the counter-based dropout hash of the training step (include/tip_hip.h documents it)
+__device__ __forceinline__ unsigned tip_drop_hash(unsigned long long seed, unsigned site, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + ((unsigned long long)site << 40) + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (unsigned)(z >> 32);
+}
+
+// Where the fused encoder, run as the TRAINING forward, stashes its activations (float offsets into `sv`; the per-layer
+// arrays of layer l start `l * layer_stride` further on) and the encoder dropout it applies (site = 4*layer + k).
+struct FusedTrain {
+    float* sv;
+    unsigned long long x0, qkv, ast, att, z1, st1, x1, hid, z2, st2, xo, layer_stride;
+    unsigned long long seed;
+    unsigned thresh;   // 0 = dropout off
+    float scale;
+};
+
 constexpr int kGemmBM = 128;   // general GEMM block tile (rows)
 constexpr int kGemmBN = 128;   // general GEMM block tile (cols); packed weights are padded to this
 constexpr int kGemmBK = 16;    // K tile; packed K is padded to this
@@ -168,6 +187,10 @@ bool fused_has_rnn_ih(const Dims& d);
 hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                 const float* keep_mask, float keep_scale, float* xout, float* ih_out, float* hall_sentinel,
                                 int B, int T, int num_cus, hipStream_t s);
+// the same kernel as the training forward: activations stashed per `tr`, encoder dropout live (tip_train.hip)
+hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s, const float* keep_mask,
+                              float keep_scale, float* ih_out, float* hall_sentinel, const FusedTrain& tr, int B, int T,
+                              int num_cus, hipStream_t s);
 // true when launch_rnn(cluster) will run the sentinel-polling resident kernel (HALL must be pre-filled with all-ones;
 // the fused encoder can do that for its own rows, otherwise launch_rnn memsets)
 bool rnn_uses_sentinel(const Dims& d, int B, int T, int cluster);

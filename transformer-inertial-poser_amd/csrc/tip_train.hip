@@ -775,6 +775,7 @@ struct TrainLayer {
 struct TrainSaved {
     size_t win_p, bin_p, bsum, whh_f, whh_b, U, x0, ih, hall, flags;
     size_t wout_t, wih_t;
+    size_t fused_img;   // fused-plan weight image (fragment order), packed on the GPU every step; 0 floats when unsupported
     std::vector<TrainLayer> layers;
     size_t total;
 };
@@ -824,6 +825,7 @@ static TrainSaved saved_layout(const Dims& d, int B, int T) {
     L.ih = take(off, M * d.R);
     L.hall = take(off, M * d.R);
     L.flags = take(off, rnn_flag_words(B, T));
+    L.fused_img = take(off, fused_packed_floats(d));
     L.total = off;
     return L;
 }
@@ -991,6 +993,28 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     }
     TT(hipGetLastError(), "train_prep");
     TT(launch_prologue(d, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f, W + L.U, M, s), "train_prologue");
+    // Paper configuration: the encoder runs as ONE kernel — the fused inference kernel with its activations stashed and the
+    // dropout sites live (tip_fused.hip, fused_encoder_kernel<8>) — on a weight image packed on the GPU from the live
+    // parameters.  Any other supported configuration takes the layer-by-layer path below.
+    static int use_fused = -1;   // TIP_TRAIN_FUSED=0: layer-by-layer forward (measurement)
+    if (use_fused < 0) use_fused = (getenv("TIP_TRAIN_FUSED") && getenv("TIP_TRAIN_FUSED")[0] == '0') ? 0 : 1;
+    const bool fused = use_fused && fused_supported(d, T) && fused_has_rnn_ih(d) && fused_packed_floats(d) > 0;
+    if (fused) {
+        std::vector<PackOp> ops;
+        fused_pack_ops(d, params, 0, ops);
+        TT(hipMemsetAsync(W + L.fused_img, 0, fused_packed_floats(d) * sizeof(float), s), "train_fused_pack");
+        TT(run_pack_ops(ops, W + L.fused_img, s), "train_fused_pack");
+        FusedTrain tr;
+        tr.sv = W;
+        const TrainLayer& t0 = L.layers[0];
+        tr.x0 = L.x0; tr.qkv = t0.qkv; tr.ast = t0.ast; tr.att = t0.att; tr.z1 = t0.z1; tr.st1 = t0.st1; tr.x1 = t0.x1;
+        tr.hid = t0.hid; tr.z2 = t0.z2; tr.st2 = t0.st2; tr.xo = t0.xo;
+        tr.layer_stride = d.L > 1 ? L.layers[1].qkv - t0.qkv : 0;
+        const Drop dr = make_drop(p_drop, seed, 0);
+        tr.seed = seed; tr.thresh = dr.thresh; tr.scale = dr.scale;
+        TT(launch_fused_train(d, W + L.fused_img, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f, W + L.ih, nullptr, tr, B, T,
+                              h->num_cus, s), "train_fused_encoder");
+    } else {
     {
         TG g = tg_base(W + L.U, d.InPad, W + L.win_p, d.InPad, W + L.x0, d.D, M, d.D, d.InPad);
         g.bias = W + L.bin_p;
@@ -1062,6 +1086,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         g.bias = W + L.bsum;
         TT(tgemm16_launch(g, s), "train_rnn_ih");
     }
+    }   // layer-by-layer path
     TT(launch_rnn(d, W + L.ih, W + L.whh_f, W + L.hall, reinterpret_cast<unsigned*>(W + L.flags), B, T, auto_cluster(B, h->num_cus),
                   h->num_cus, false, s), "train_rnn");
     {
