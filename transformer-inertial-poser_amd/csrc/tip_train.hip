@@ -439,7 +439,9 @@ static hipError_t grad_weight(const float* dY, long long ldy, int n_rows_pad, in
     TG g = tg_base(dY, ldy, X, ldx, part, K, n_rows_pad, K, M);
     g.c_rows = n_store;
     const int tiles = ((K + 127) / 128) * ((n_rows_pad + 127) / 128);
-    int splits = (2 * num_cus + tiles - 1) / tiles;   // >= 2 x CUs blocks so that tgemm_launch keeps the 128 x 128 tile
+    static int sdiv = -1;   // TIP_DW_SPLITDIV: fewer splits (smaller partial volume), tgemm_launch then picks smaller tiles
+    if (sdiv < 0) sdiv = getenv("TIP_DW_SPLITDIV") ? atoi(getenv("TIP_DW_SPLITDIV")) : 2;   // measured: 2 is the sweet spot (1: more reduce traffic, 4+: tiles too small)
+    int splits = ((2 * num_cus + tiles - 1) / tiles + sdiv - 1) / sdiv;
     const long long per = (long long)n_store * K;
     const long long stride = (per + 3) / 4 * 4;
     if ((long long)splits * stride > (long long)part_floats) splits = (int)((long long)part_floats / stride);
