@@ -394,7 +394,7 @@ int tip_pack_weights_device(const tip_handle* h, const float* const* t, int n, v
     auto op = [](const float* src, size_t dst, int N, int K, int src_rows, int src_cols, int frag) {
         PackOp o;
         o.src = src; o.src2 = nullptr; o.dst_off = dst; o.N = N; o.K = K; o.src_rows = src_rows; o.src_cols = src_cols; o.frag = frag;
-        o.shuffle_h = 0; o.shuffle_dh = 0; o.z0 = 0; o.z1 = 0; o.scale_rows = 0; o.scale = 1.f;
+        o.shuffle_h = 0; o.shuffle_dh = 0; o.z0 = 0; o.z1 = 0; o.scale_rows = 0; o.scale = 1.f; o.transpose = 0;
         return o;
     };
     auto linear = [&](const PackedLinear& p, const float* W, const float* b) {

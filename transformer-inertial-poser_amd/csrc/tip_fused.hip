@@ -121,7 +121,7 @@ void fused_pack(const Dims& d, const float* const* t, float* dst) {
 static PackOp mk_op(const float* src, size_t dst, int N, int K, int src_rows, int src_cols, int frag) {
     PackOp o;
     o.src = src; o.src2 = nullptr; o.dst_off = dst; o.N = N; o.K = K; o.src_rows = src_rows; o.src_cols = src_cols; o.frag = frag;
-    o.shuffle_h = 0; o.shuffle_dh = 0; o.z0 = 0; o.z1 = 0; o.scale_rows = 0; o.scale = 1.f;
+    o.shuffle_h = 0; o.shuffle_dh = 0; o.z0 = 0; o.z1 = 0; o.scale_rows = 0; o.scale = 1.f; o.transpose = 0;
     return o;
 }
 
@@ -648,6 +648,189 @@ hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* 
     hipLaunchKernelGGL(fused_encoder_kernel<8>, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
                        keep_scale, (float*)nullptr, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,
                        (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4), tr);
+    return hipGetLastError();
+}
+
+// =====================================================================================================================
+// Training step, backward of one encoder layer's feed-forward block, fused per window.
+//   dy = dL/d(layer output)  ->  LayerNorm2 backward  ->  dz2 (kept: it is also the residual path into the block's input)
+//   dff2 = dz2 * keep3                      (gradient into linear2's output; also linear2's bias-gradient rows)
+//   dpre = (dff2 W2) * [hid > 0] / (1 - p)  (hid was saved AFTER ReLU and dropout: its sign is the gate)
+//   dx1  = dz2 + dpre W1
+// Same structure as the forward FFN phases of fused_encoder_kernel — activations [48 x 256] resident in LDS, the hidden
+// dimension walked in 4 chunks of 256, weight fragments of W2^T ([F][D]) and W1^T ([D][F]) streamed from the backward
+// image with the same ring/offset scheme as W1 / W2 in the forward — so the two 10 240-row GEMMs and the LayerNorm
+// kernel of the layer-by-layer backward (and the HBM round trips between them) become one launch.
+// dff2 and dpre still go to HBM: the weight-gradient GEMMs (reduction over all rows of the batch) read them.
+// =====================================================================================================================
+namespace fb {
+constexpr size_t W2T = 0;                                  // [F][D] fragments: B operand of dhid = dff2 W2
+constexpr size_t W1T = W2T + (size_t)fz::F * fz::D;        // [D][F] fragments: B operand of dx1 = dpre W1
+constexpr size_t LAYER_FLOATS = W1T + (size_t)fz::D * fz::F;
+}  // namespace fb
+
+size_t fused_bwd_image_floats(const Dims& d) {
+    if (fused_packed_floats(d) == 0) return 0;
+    return (size_t)d.L * fb::LAYER_FLOATS + fz::TAIL_PAD;
+}
+
+void fused_bwd_pack_ops(const Dims& d, const float* const* t, size_t base, std::vector<PackOp>& ops) {
+    using namespace fz;
+    for (int l = 0; l < d.L; ++l) {
+        const float* const* lw = t + 2 + 12 * l;
+        const size_t L = base + (size_t)l * fb::LAYER_FLOATS;
+        PackOp a = mk_op(lw[6], L + fb::W2T, F, D, F, D, 1);   // linear2.weight is [D][F]: logical W2^T [F][D]
+        a.transpose = 1;
+        ops.push_back(a);
+        PackOp b = mk_op(lw[4], L + fb::W1T, D, F, D, F, 1);   // linear1.weight is [F][D]: logical W1^T [D][F]
+        b.transpose = 1;
+        ops.push_back(b);
+    }
+}
+
+__global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int B, int T) {
+    using namespace fz;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* G = smem;                       // dy -> dz2 -> dx1
+    float* Mb = smem + RP * LDX;           // dff2 (masked dz2)
+    float* Hc = smem + 2 * RP * LDX;       // dpre chunk; scratch for the LayerNorm parameter partials before that
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wimg), 0, a.wbytes, 0x00020000);
+    const int voff = lane * 16;
+    const int lbase = (int)(((size_t)a.layer * fb::LAYER_FLOATS) * 4);
+    // the saved hidden activations through a buffer descriptor (byte offsets must fit 32 bits: checked by the launcher)
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.hid), 0, a.hid_bytes, 0x00020000);
+
+    for (int win = blockIdx.x; win < B; win += gridDim.x) {
+        const size_t grow0 = (size_t)win * T;
+        WRing<2> g_f;
+        ring_prefetch<2>(g_f, rsrc, voff, lbase + (int)(fb::W2T * 4) + (wave * 2) * 16 * 1024, 16 * 1024);
+        // ---- LayerNorm2 backward, one wave per row (rows w, w+8, ...) ------------------------------------------------------
+        {
+            const float4 gg = *reinterpret_cast<const float4*>(a.g2 + lane * 4);
+            float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg, dm = dg;
+#pragma unroll 2
+            for (int i = 0; i < RP / 8; ++i) {
+                const int r = wave + 8 * i;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f), m = o;
+                if (r < T) {
+                    const size_t gr = grow0 + r;
+                    const float4 zv = *reinterpret_cast<const float4*>(a.z2 + gr * D + lane * 4);
+                    const float4 dyv = *reinterpret_cast<const float4*>(a.dy + gr * D + lane * 4);
+                    const float mean = a.st2[gr * 2], rstd = a.st2[gr * 2 + 1];
+                    float4 xh;
+                    xh.x = (zv.x - mean) * rstd; xh.y = (zv.y - mean) * rstd; xh.z = (zv.z - mean) * rstd; xh.w = (zv.w - mean) * rstd;
+                    const float ax = dyv.x * gg.x, ay = dyv.y * gg.y, az = dyv.z * gg.z, aw = dyv.w * gg.w;
+                    const float m1 = wsum((ax + ay) + (az + aw)) * (1.f / D);
+                    const float m2 = wsum((ax * xh.x + ay * xh.y) + (az * xh.z + aw * xh.w)) * (1.f / D);
+                    dg.x += dyv.x * xh.x; dg.y += dyv.y * xh.y; dg.z += dyv.z * xh.z; dg.w += dyv.w * xh.w;
+                    db.x += dyv.x; db.y += dyv.y; db.z += dyv.z; db.w += dyv.w;
+                    o.x = rstd * (ax - m1 - xh.x * m2); o.y = rstd * (ay - m1 - xh.y * m2);
+                    o.z = rstd * (az - m1 - xh.z * m2); o.w = rstd * (aw - m1 - xh.w * m2);
+                    m = o;
+                    if (a.thresh) {
+                        const unsigned long long idx = gr * D + lane * 4;
+                        m.x = tip_drop_hash(a.seed, a.site, idx) >= a.thresh ? o.x * a.scale : 0.f;
+                        m.y = tip_drop_hash(a.seed, a.site, idx + 1) >= a.thresh ? o.y * a.scale : 0.f;
+                        m.z = tip_drop_hash(a.seed, a.site, idx + 2) >= a.thresh ? o.z * a.scale : 0.f;
+                        m.w = tip_drop_hash(a.seed, a.site, idx + 3) >= a.thresh ? o.w * a.scale : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(a.dff2 + gr * D + lane * 4) = m;
+                    dm.x += m.x; dm.y += m.y; dm.z += m.z; dm.w += m.w;
+                }
+                *reinterpret_cast<float4*>(G + r * LDX + lane * 4) = o;      // padded rows: zeros
+                *reinterpret_cast<float4*>(Mb + r * LDX + lane * 4) = m;
+            }
+            // per-window partials of dgamma2 | dbeta2 | d(linear2 bias): waves -> LDS -> one [3*D] row per window
+            float* red = Hc;   // [8 waves][3][D]
+            *reinterpret_cast<float4*>(red + (wave * 3 + 0) * D + lane * 4) = dg;
+            *reinterpret_cast<float4*>(red + (wave * 3 + 1) * D + lane * 4) = db;
+            *reinterpret_cast<float4*>(red + (wave * 3 + 2) * D + lane * 4) = dm;
+        }
+        __syncthreads();
+        for (int i = tid; i < 3 * D; i += THREADS) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += Hc[w * 3 * D + i];
+            a.lnpart[(size_t)win * 3 * D + i] = s;
+        }
+        __syncthreads();
+        // ---- hidden chunks ------------------------------------------------------------------------------------------------
+        f32x4 acc_x[RB][2];
+        zero_acc<2>(acc_x);
+#pragma unroll 1
+        for (int f = 0; f < 4; ++f) {
+            {
+                f32x4 acc[RB][2];
+                zero_acc<2>(acc);
+                const int w2off = lbase + (int)(fb::W2T * 4) + (f * 16 + wave * 2) * 16 * 1024;
+                const int w1off = lbase + (int)(fb::W1T * 4) + ((wave * 2) * 64 + f * 16) * 1024;
+                // The product is computed TRANSPOSED (weights as the A operand): a lane then holds 4 consecutive hidden
+                // channels of ONE row, so the ReLU/dropout gate is one 16-byte load of the saved hidden row and the chunk goes
+                // to LDS as one 16-byte store per tile.  The gate loads are issued before the MFMAs (buffer loads: opaque to the
+                // optimiser, so they stay here) and consumed after.
+                f32x4 gate[RB][2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        const int row = r * 16 + l15;
+                        const long long off = ((long long)(grow0 + (row < T ? row : 0)) * F + f * 256 + (wave * 2 + n) * 16 + lg * 4) * 4;
+                        gate[r][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, (int)off, 0, 0));
+                    }
+                // the tail of this phase primes the ring with the dx1 phase's first fragments
+                gemm_phase<2, 16, false, 2>(acc, Mb + l15 * LDX + lg * 4, LDX, rsrc, voff, w2off, 16 * 1024, g_f, w1off, 64 * 1024);
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        const int row = r * 16 + l15;
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = (row < T && gate[r][n][e] > 0.f) ? acc[r][n][e] * a.gate_scale : 0.f;
+                        *reinterpret_cast<f32x4*>(Hc + row * LDX + (wave * 2 + n) * 16 + lg * 4) = v;
+                    }
+            }
+            __syncthreads();
+            rows_to_hbm(Hc, LDX, 256, a.dpre + grow0 * F + f * 256, F, T, tid);
+            {
+                const int w1off = lbase + (int)(fb::W1T * 4) + ((wave * 2) * 64 + f * 16) * 1024;
+                const int nxt = f < 3 ? lbase + (int)(fb::W2T * 4) + ((f + 1) * 16 + wave * 2) * 16 * 1024 : w1off;
+                gemm_phase<2, 16>(acc_x, Hc + l15 * LDX + lg * 4, LDX, rsrc, voff, w1off, 64 * 1024, g_f, nxt,
+                                  f < 3 ? 16 * 1024 : 64 * 1024);
+            }
+            __syncthreads();
+        }
+        // ---- dx1 = dz2 + dpre W1 -------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = (wave * 2 + n) * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) G[(r * 16 + lg * 4 + e) * LDX + col] += acc_x[r][n][e];
+        }
+        __syncthreads();
+        rows_to_hbm(G, LDX, D, a.dx1 + grow0 * D, D, T, tid);
+        __syncthreads();
+    }
+}
+
+hipError_t launch_ffn_bwd(const Dims& d, const FfnBwdArgs& a, int B, int T, int num_cus, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (!fused_supported(d, T) || (long long)B * T * d.F * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
+    constexpr int lds = 3 * fz::RP * fz::LDX * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    FfnBwdArgs aa = a;
+    aa.hid_bytes = (int)((long long)B * T * d.F * 4);
+    hipLaunchKernelGGL(ffn_bwd_kernel, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
     return hipGetLastError();
 }
 

@@ -107,6 +107,7 @@ struct PackOp {
     int z0, z1;
     int scale_rows;
     float scale;
+    int transpose;                // 1: the source is stored [K][N] (src_rows = N, src_cols = K describe the LOGICAL matrix)
 };
 constexpr int kPackBatch = 32;
 struct PackBatch {
@@ -187,6 +188,29 @@ bool fused_has_rnn_ih(const Dims& d);
 hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                 const float* keep_mask, float keep_scale, float* xout, float* ih_out, float* hall_sentinel,
                                 int B, int T, int num_cus, hipStream_t s);
+// fused backward of one encoder layer's feed-forward block for the training step (tip_fused.hip): LayerNorm2 backward ->
+// d(hidden) -> d(LN1 output), one workgroup per window; weight fragments of W2^T / W1^T from the backward image
+size_t fused_bwd_image_floats(const Dims& d);
+void fused_bwd_pack_ops(const Dims& d, const float* const* t, size_t base, std::vector<PackOp>& ops);
+struct FfnBwdArgs {
+    const float* wimg;      // backward image
+    int wbytes, layer;
+    const float* dy;        // [M,D] gradient w.r.t. the layer output
+    const float* z2;        // [M,D] pre-LayerNorm2 rows, st2 [M,2]
+    const float* st2;
+    const float* g2;        // LayerNorm2 weight
+    const float* hid;       // [M,F] saved hidden (after ReLU and dropout)
+    int hid_bytes;          // (set by the launcher)
+    float gate_scale;       // 1 / (1 - p)
+    float* dff2;            // out [M,D]: gradient into linear2's output (dropout mask applied)
+    float* dpre;            // out [M,F]: gradient into linear1's pre-activation
+    float* dx1;             // out [M,D]: gradient w.r.t. the LayerNorm1 output
+    float* lnpart;          // out [B][3*D]: per-window (dgamma2 | dbeta2 | d bias of linear2) partial sums
+    unsigned long long seed;
+    unsigned site, thresh;
+    float scale;
+};
+hipError_t launch_ffn_bwd(const Dims& d, const FfnBwdArgs& a, int B, int T, int num_cus, hipStream_t s);
 // the same kernel as the training forward: activations stashed per `tr`, encoder dropout live (tip_train.hip)
 hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s, const float* keep_mask,
                               float keep_scale, float* ih_out, float* hall_sentinel, const FusedTrain& tr, int B, int T,

@@ -30,8 +30,9 @@ __global__ __launch_bounds__(256) void pack_ops_kernel(PackBatch pb, float* __re
         if (op.shuffle_h) src_row = (n % op.shuffle_h) * op.shuffle_dh + n / op.shuffle_h;   // dst row a*H + b <- src row b*dh + a
         float v = 0.f;
         if (n < op.src_rows && k < op.src_cols && !(k >= op.z0 && k < op.z1)) {
-            v = op.src[(size_t)src_row * op.src_cols + k];
-            if (op.src2) v += op.src2[(size_t)src_row * op.src_cols + k];
+            const size_t si = op.transpose ? (size_t)k * op.src_rows + src_row : (size_t)src_row * op.src_cols + k;
+            v = op.src[si];
+            if (op.src2) v += op.src2[si];
             if (n < op.scale_rows) v *= op.scale;
         }
         img[op.dst_off + i] = v;

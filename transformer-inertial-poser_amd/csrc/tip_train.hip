@@ -783,6 +783,7 @@ struct TrainSaved {
 };
 struct TrainScratch {
     size_t dyp, dh, delta, hprev, ga, gb, gc, gbig, datt, part, colpart, dwin_p, dbin_p;
+    size_t bwimg, lnwin;   // fused backward: transposed-weight fragment image, per-window LayerNorm partials [B][3D]
     size_t part_floats;
     size_t total;
 };
@@ -857,6 +858,8 @@ static TrainScratch scratch_layout(const Dims& d, int B, int T) {
     S.colpart = take(off, cmax);
     S.dwin_p = take(off, (size_t)d.D * d.InPad);
     S.dbin_p = take(off, d.D);
+    S.bwimg = take(off, fused_bwd_image_floats(d));
+    S.lnwin = take(off, (size_t)B * 3 * d.D);
     S.total = off;
     return S;
 }
@@ -1131,6 +1134,15 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     float* part = X + S.part;
     float* colpart = X + S.colpart;
 
+    // paper configuration: the feed-forward half of every layer's backward runs as one fused kernel per window
+    static int use_fbwd = -1;   // TIP_TRAIN_FUSED_BWD=0: layer-by-layer (measurement)
+    if (use_fbwd < 0) use_fbwd = (getenv("TIP_TRAIN_FUSED_BWD") && getenv("TIP_TRAIN_FUSED_BWD")[0] == '0') ? 0 : 1;
+    const bool fbwd = use_fbwd && fused_supported(d, T) && fused_bwd_image_floats(d) > 0;
+    if (fbwd) {
+        std::vector<PackOp> ops;
+        fused_bwd_pack_ops(d, params, 0, ops);
+        TT(run_pack_ops(ops, X + S.bwimg, s), "bwd_pack");
+    }
     // ---- output projection (:102): y = h W_out^T + b ---------------------------------------------------------------
     hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for((long long)M * Sp)), dim3(256), 0, s, dy, d.S, X + S.dyp, Sp, (long long)M);
     TT(hipGetLastError(), "bwd_pad_dy");
@@ -1166,6 +1178,25 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
         const TrainLayer& t = L.layers[l];
         const float* x_in = l ? W + L.layers[l - 1].xo : W + L.x0;
         const int nln = (M + kLnRows - 1) / kLnRows;
+        if (fbwd) {
+            // LayerNorm2 backward -> dff2 (gc) -> dpre (gbig) -> dx1 (gx, in place), fused per window
+            FfnBwdArgs fa;
+            fa.wimg = X + S.bwimg; fa.wbytes = (int)(fused_bwd_image_floats(d) * 4); fa.layer = l;
+            fa.dy = gx; fa.z2 = W + t.z2; fa.st2 = W + t.st2; fa.g2 = lp[PL_N2_W]; fa.hid = W + t.hid;
+            fa.gate_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.f;
+            fa.dff2 = X + S.gc; fa.dpre = X + S.gbig; fa.dx1 = gx; fa.lnpart = X + S.lnwin;
+            const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 3));
+            fa.seed = dr.seed; fa.site = dr.site; fa.thresh = dr.thresh; fa.scale = dr.scale;
+            TT(launch_ffn_bwd(d, fa, B, T, ncu, s), "bwd_ffn_fused");
+            hipLaunchKernelGGL(colreduce_kernel, dim3((3 * d.D + 63) / 64), dim3(256), 0, s, X + S.lnwin, B, 3 * d.D,
+                               grads + goff[pb + PL_N2_W], nullptr, 2 * d.D, grads + goff[pb + PL_L2_B]);
+            TT(hipGetLastError(), "bwd_ln2_params");
+            TT(grad_weight(X + S.gc, d.D, d.D, d.D, W + t.hid, d.F, d.F, M, part, S.part_floats, grads + goff[pb + PL_L2_W], ncu, s),
+               "bwd_dW2");
+            TT(colsum(X + S.gbig, d.F, M, d.F, colpart, grads + goff[pb + PL_L1_B], nullptr, s), "bwd_db1");
+            TT(grad_weight(X + S.gbig, d.F, d.F, d.F, W + t.x1, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_L1_W], ncu, s),
+               "bwd_dW1");
+        } else {
         // LN2: gx -> dz2 (galt), dff2 = dz2 * keep3 (gc)
         {
             const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 3));
@@ -1200,6 +1231,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             TG g = tg_base(X + S.gbig, d.F, W + t.w1_t, d.F, gx, d.D, M, d.D, d.F);
             g.res = galt; g.ldres = d.D;
             TT(tgemm16_launch(g, s), "bwd_dx1");
+        }
         }
         // LN1: gx -> dz1 (galt), datt_o = dz1 * keep1 (gc)
         {
