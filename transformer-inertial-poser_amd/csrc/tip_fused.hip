@@ -666,25 +666,34 @@ hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* 
 namespace fb {
 constexpr size_t W2T = 0;                                  // [F][D] fragments: B operand of dhid = dff2 W2
 constexpr size_t W1T = W2T + (size_t)fz::F * fz::D;        // [D][F] fragments: B operand of dx1 = dpre W1
-constexpr size_t LAYER_FLOATS = W1T + (size_t)fz::D * fz::F;
+constexpr size_t WOT = W1T + (size_t)fz::D * fz::F;        // [D][D]  fragments of Wo^T:   datt = datt_o Wo
+constexpr size_t WQT = WOT + (size_t)fz::D * fz::D;        // [D][3D] fragments of Wqkv^T: dx_in = dqkv Wqkv
+constexpr size_t LAYER_FLOATS2 = WQT + (size_t)fz::D * 3 * fz::D;   // per-layer stride of the backward image
+
 }  // namespace fb
 
 size_t fused_bwd_image_floats(const Dims& d) {
     if (fused_packed_floats(d) == 0) return 0;
-    return (size_t)d.L * fb::LAYER_FLOATS + fz::TAIL_PAD;
+    return (size_t)d.L * fb::LAYER_FLOATS2 + fz::TAIL_PAD;
 }
 
 void fused_bwd_pack_ops(const Dims& d, const float* const* t, size_t base, std::vector<PackOp>& ops) {
     using namespace fz;
     for (int l = 0; l < d.L; ++l) {
         const float* const* lw = t + 2 + 12 * l;
-        const size_t L = base + (size_t)l * fb::LAYER_FLOATS;
+        const size_t L = base + (size_t)l * fb::LAYER_FLOATS2;
         PackOp a = mk_op(lw[6], L + fb::W2T, F, D, F, D, 1);   // linear2.weight is [D][F]: logical W2^T [F][D]
         a.transpose = 1;
         ops.push_back(a);
         PackOp b = mk_op(lw[4], L + fb::W1T, D, F, D, F, 1);   // linear1.weight is [F][D]: logical W1^T [D][F]
         b.transpose = 1;
         ops.push_back(b);
+        PackOp o = mk_op(lw[2], L + fb::WOT, D, D, D, D, 1);         // out_proj.weight [D][D]: logical Wo^T
+        o.transpose = 1;
+        ops.push_back(o);
+        PackOp q = mk_op(lw[0], L + fb::WQT, D, 3 * D, D, 3 * D, 1);  // in_proj_weight [3D][D]: logical Wqkv^T [D][3D]
+        q.transpose = 1;
+        ops.push_back(q);
     }
 }
 
@@ -699,7 +708,7 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
     const int l15 = lane & 15, lg = lane >> 4;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wimg), 0, a.wbytes, 0x00020000);
     const int voff = lane * 16;
-    const int lbase = (int)(((size_t)a.layer * fb::LAYER_FLOATS) * 4);
+    const int lbase = (int)(((size_t)a.layer * fb::LAYER_FLOATS2) * 4);
     // the saved hidden activations through a buffer descriptor (byte offsets must fit 32 bits: checked by the launcher)
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.hid), 0, a.hid_bytes, 0x00020000);
 
@@ -831,6 +840,298 @@ hipError_t launch_ffn_bwd(const Dims& d, const FfnBwdArgs& a, int B, int T, int 
     FfnBwdArgs aa = a;
     aa.hid_bytes = (int)((long long)B * T * d.F * 4);
     hipLaunchKernelGGL(ffn_bwd_kernel, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
+    return hipGetLastError();
+}
+
+// =====================================================================================================================
+// Training step, backward of one encoder layer's ATTENTION block, fused per window:
+//   dx1 = dL/d(LayerNorm1 output)  ->  LayerNorm1 backward  ->  dz1 (to HBM: it is also the residual path)
+//   datt_o = dz1 * keep1 (gradient into out_proj's output)  ->  dO = datt_o Wo, per head, in registers, in BOTH layouts
+//   attention backward per head in registers (as tip_attn.hip, mattn_bwd_kernel) -> dq | dk | dv planes in LDS (+ HBM)
+//   dx_in = dz1 + [dq | dk | dv] W_qkv
+// One wave owns one head end to end; 2 chunks of 8 heads as in the forward.  datt_o and dqkv also go to HBM for the
+// weight-gradient GEMMs.
+// =====================================================================================================================
+
+__global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, int B, int T) {
+    using namespace fz;
+    constexpr int LDT = 20;                             // per-wave transposition tiles [48][16 + 4]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Mb = smem;                                   // datt_o [48][260]
+    float* Sc = smem + RP * LDX;                        // per-wave scratch: Q tile | K tile (LayerNorm partials before that)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wimg), 0, a.wbytes, 0x00020000);
+    const int voff = lane * 16;
+    const int lbase = (int)(((size_t)a.layer * fb::LAYER_FLOATS2) * 4);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float* Qs = Sc + wave * (3 * RP * LDT);             // this wave's head: Q rows [48][16] (row-major) ...
+    float* Ks = Qs + RP * LDT;                          // ... and K rows: read back as (row 4*lg + e, channel l15) B fragments
+    float* Gs = Ks + RP * LDT;                          // dO tile: written in the accumulator layout, read back as row fragments
+
+    for (int win = blockIdx.x; win < B; win += gridDim.x) {
+        const size_t grow0 = (size_t)win * T;
+        WRing<1> g_o;   // Wo^T fragments of head c*8 + wave
+        ring_prefetch<1>(g_o, rsrc, voff, lbase + (int)(fb::WOT * 4) + wave * 16 * 1024, 0);
+        // ---- LayerNorm1 backward --------------------------------------------------------------------------------------------
+        {
+            const float4 gg = *reinterpret_cast<const float4*>(a.g1 + lane * 4);
+            float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg, dm = dg;
+#pragma unroll 2
+            for (int i = 0; i < RP / 8; ++i) {
+                const int r = wave + 8 * i;
+                float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < T) {
+                    const size_t gr = grow0 + r;
+                    const float4 zv = *reinterpret_cast<const float4*>(a.z1 + gr * D + lane * 4);
+                    const float4 dyv = *reinterpret_cast<const float4*>(a.dx1 + gr * D + lane * 4);
+                    const float mean = a.st1[gr * 2], rstd = a.st1[gr * 2 + 1];
+                    float4 xh;
+                    xh.x = (zv.x - mean) * rstd; xh.y = (zv.y - mean) * rstd; xh.z = (zv.z - mean) * rstd; xh.w = (zv.w - mean) * rstd;
+                    const float ax = dyv.x * gg.x, ay = dyv.y * gg.y, az = dyv.z * gg.z, aw = dyv.w * gg.w;
+                    const float m1 = wsum((ax + ay) + (az + aw)) * (1.f / D);
+                    const float m2 = wsum((ax * xh.x + ay * xh.y) + (az * xh.z + aw * xh.w)) * (1.f / D);
+                    dg.x += dyv.x * xh.x; dg.y += dyv.y * xh.y; dg.z += dyv.z * xh.z; dg.w += dyv.w * xh.w;
+                    db.x += dyv.x; db.y += dyv.y; db.z += dyv.z; db.w += dyv.w;
+                    float4 o;
+                    o.x = rstd * (ax - m1 - xh.x * m2); o.y = rstd * (ay - m1 - xh.y * m2);
+                    o.z = rstd * (az - m1 - xh.z * m2); o.w = rstd * (aw - m1 - xh.w * m2);
+                    *reinterpret_cast<float4*>(a.dz1 + gr * D + lane * 4) = o;
+                    m = o;
+                    if (a.thresh) {
+                        const unsigned long long idx = gr * D + lane * 4;
+                        m.x = tip_drop_hash(a.seed, a.site1, idx) >= a.thresh ? o.x * a.scale : 0.f;
+                        m.y = tip_drop_hash(a.seed, a.site1, idx + 1) >= a.thresh ? o.y * a.scale : 0.f;
+                        m.z = tip_drop_hash(a.seed, a.site1, idx + 2) >= a.thresh ? o.z * a.scale : 0.f;
+                        m.w = tip_drop_hash(a.seed, a.site1, idx + 3) >= a.thresh ? o.w * a.scale : 0.f;
+                    }
+                    *reinterpret_cast<float4*>(a.datt_o + gr * D + lane * 4) = m;
+                    dm.x += m.x; dm.y += m.y; dm.z += m.z; dm.w += m.w;
+                }
+                *reinterpret_cast<float4*>(Mb + r * LDX + lane * 4) = m;      // padded rows: zeros
+            }
+            float* red = Sc;   // [8 waves][3][D] = 6144 floats
+            *reinterpret_cast<float4*>(red + (wave * 3 + 0) * D + lane * 4) = dg;
+            *reinterpret_cast<float4*>(red + (wave * 3 + 1) * D + lane * 4) = db;
+            *reinterpret_cast<float4*>(red + (wave * 3 + 2) * D + lane * 4) = dm;
+        }
+        __syncthreads();
+        for (int i = tid; i < 3 * D; i += THREADS) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += Sc[w * 3 * D + i];
+            a.lnpart[(size_t)win * 3 * D + i] = s;
+        }
+        __syncthreads();
+
+        // ---- per head (no workgroup barrier in here: a wave only touches Mb (read), its own scratch and its own HBM columns) ---
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            const int head = c * 8 + wave;
+            const unsigned long long bh = (unsigned long long)win * H + head;
+            const float* qb = a.qkv + grow0 * (3 * D) + head * 16;
+            // q, k, v, O row fragments and the softmax statistics are requested before the dO product
+            f32x4 qf[RB], kf[RB], vf[RB], of[RB];
+            float mq[RB], iq[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int row = r * 16 + l15;
+                qf[r] = kf[r] = vf[r] = of[r] = zero4;
+                mq[r] = 0.f; iq[r] = 0.f;
+                if (row < T) {
+                    qf[r] = *reinterpret_cast<const f32x4*>(qb + (size_t)row * (3 * D) + lg * 4);
+                    kf[r] = *reinterpret_cast<const f32x4*>(qb + (size_t)row * (3 * D) + D + lg * 4);
+                    vf[r] = *reinterpret_cast<const f32x4*>(qb + (size_t)row * (3 * D) + 2 * D + lg * 4);
+                    of[r] = *reinterpret_cast<const f32x4*>(a.att + (grow0 + row) * D + head * 16 + lg * 4);
+                    mq[r] = a.ast[(bh * T + row) * 2];
+                    iq[r] = a.ast[(bh * T + row) * 2 + 1];
+                }
+            }
+            // dO of this head: [48 x 16] = datt_o [48 x 256] * Wo^T(:, head): gp = accumulator layout (rows 4*lg + e, channel l15);
+            // gs = the same tile as row fragments (row l15, channels 4*lg + e), obtained through the wave's scratch
+            f32x4 gs[RB], gp[RB];
+            {
+                f32x4 acc[RB][1];
+                zero_acc<1>(acc);
+                const int osoff = lbase + (int)(fb::WOT * 4) + head * 16 * 1024;
+                const int nxt = c == 0 ? lbase + (int)(fb::WOT * 4) + (8 + wave) * 16 * 1024 : osoff;
+                gemm_phase<1, 16>(acc, Mb + l15 * LDX + lg * 4, LDX, rsrc, voff, osoff, 0, g_o, nxt, 0);
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    gp[r] = acc[r][0];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Gs[(r * 16 + lg * 4 + e) * LDT + l15] = gp[r][e];
+                }
+            }
+            // Q and K rows through the wave's scratch: written as row fragments, read back transposed (row 4*lg + e, channel l15)
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                *reinterpret_cast<f32x4*>(Qs + (r * 16 + l15) * LDT + lg * 4) = qf[r];
+                *reinterpret_cast<f32x4*>(Ks + (r * 16 + l15) * LDT + lg * 4) = kf[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < RB; ++r) gs[r] = *reinterpret_cast<const f32x4*>(Gs + (r * 16 + l15) * LDT + lg * 4);
+            float dd[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                float d_ = (gs[r][0] * of[r][0] + gs[r][1] * of[r][1]) + (gs[r][2] * of[r][2] + gs[r][3] * of[r][3]);
+                d_ += __shfl_xor(d_, 16, 64);
+                d_ += __shfl_xor(d_, 32, 64);
+                dd[r] = d_;
+            }
+            f32x4 dk[RB], dv[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) dk[r] = dv[r] = zero4;
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int q = r * 16 + l15;
+                float m2[4], i2[4], d2[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    m2[e] = __shfl(mq[r], lg * 4 + e, 64);
+                    i2[e] = __shfl(iq[r], lg * 4 + e, 64);
+                    d2[e] = __shfl(dd[r], lg * 4 + e, 64);
+                }
+                f32x4 dq = zero4;
+#pragma unroll
+                for (int cb = 0; cb <= r; ++cb) {
+                    // layout 1: (key 4*lg + e, query l15) -> dQ
+                    f32x4 s1 = zero4, p1 = zero4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[cb][e], qf[r][e], s1, 0, 0, 0);
+                        p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[cb][e], gs[r][e], p1, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kk = cb * 16 + lg * 4 + e;
+                        float v = 0.f;
+                        if (kk <= q && q < T) {
+                            const float p = __expf(s1[e] * a.q_scale - mq[r]) * iq[r];
+                            float kf_ = 1.f;
+                            if (a.thresh) kf_ = tip_drop_hash(a.seed, a.site0, (bh * T + q) * T + kk) >= a.thresh ? a.scale : 0.f;
+                            v = p * (p1[e] * kf_ - dd[r]);
+                        }
+                        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(v, Ks[(cb * 16 + lg * 4 + e) * LDT + l15], dq, 0, 0, 0);
+                    }
+                    // layout 2: (query 4*lg + e, key l15) -> dK, dV
+                    f32x4 s2 = zero4, p2 = zero4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[r][e], kf[cb][e], s2, 0, 0, 0);
+                        p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gs[r][e], vf[cb][e], p2, 0, 0, 0);
+                    }
+                    const int key = cb * 16 + l15;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int qq = r * 16 + lg * 4 + e;
+                        float dsv = 0.f, pdv = 0.f;
+                        if (key <= qq && qq < T) {
+                            const float p = __expf(s2[e] * a.q_scale - m2[e]) * i2[e];
+                            float kf_ = 1.f;
+                            if (a.thresh) kf_ = tip_drop_hash(a.seed, a.site0, (bh * T + qq) * T + key) >= a.thresh ? a.scale : 0.f;
+                            pdv = p * kf_;
+                            dsv = p * (p2[e] * kf_ - d2[e]);
+                        }
+                        dv[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pdv, gp[r][e], dv[cb], 0, 0, 0);
+                        dk[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsv, Qs[qq * LDT + l15], dk[cb], 0, 0, 0);
+                    }
+                }
+                // dQ rows of block r: (queries 4*lg + e, channel l15)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int qq = r * 16 + lg * 4 + e;
+                    if (qq < T) a.dqkv[(grow0 + qq) * (3 * D) + head * 16 + l15] = dq[e] * a.q_scale;
+                }
+            }
+#pragma unroll
+            for (int cb = 0; cb < RB; ++cb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = cb * 16 + lg * 4 + e;
+                    if (kk < T) {
+                        a.dqkv[(grow0 + kk) * (3 * D) + D + head * 16 + l15] = dk[cb][e] * a.q_scale;
+                        a.dqkv[(grow0 + kk) * (3 * D) + 2 * D + head * 16 + l15] = dv[cb][e];
+                    }
+                }
+            __builtin_amdgcn_wave_barrier();   // the scratch tiles are rewritten by the next head
+        }
+        __syncthreads();   // every head's dq | dk | dv rows of this window are in HBM/L2 (and visible to the other waves)
+        // ---- dx_in = dz1 + dqkv [48 x 768] * Wqkv^T: the A fragments come straight from the rows just written --------------------
+        {
+            f32x4 acc_i[RB][2];
+            zero_acc<2>(acc_i);
+            const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(a.dqkv, 0, a.dqkv_bytes, 0x00020000);
+            int aoff[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int row = r * 16 + l15;
+                aoff[r] = row < T ? (int)(((grow0 + row) * (3 * D) + lg * 4) * 4) : -1;
+            }
+            const int wq = lbase + (int)(fb::WQT * 4) + (wave * 2) * 48 * 1024;
+            constexpr int KBT = 3 * D / 16;   // 48 k-blocks
+            f32x4 a0[RB], a1[RB], w0[2], w1[2];
+            auto lda = [&](f32x4 (&x)[RB], int kb) {
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+                    x[r] = aoff[r] >= 0 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, aoff[r], kb * 64, 0)) : zero4;
+            };
+            auto ldw = [&](f32x4 (&x)[2], int kb) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    x[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, wq + (n * 48 + kb) * 1024, 0));
+            };
+            lda(a0, 0); ldw(w0, 0);
+#pragma unroll 1
+            for (int kb = 0; kb < KBT; kb += 2) {
+                lda(a1, kb + 1); ldw(w1, kb + 1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc_i[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r][e], w0[n][e], acc_i[r][n], 0, 0, 0);
+                if (kb + 2 < KBT) { lda(a0, kb + 2); ldw(w0, kb + 2); }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) acc_i[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r][e], w1[n][e], acc_i[r][n], 0, 0, 0);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = (wave * 2 + n) * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = r * 16 + lg * 4 + e;
+                        if (row < T) a.dx_in[(grow0 + row) * D + col] = a.dz1[(grow0 + row) * D + col] + acc_i[r][n][e];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_attn_bwd(const Dims& d, const AttnBwdArgs& a, int B, int T, int num_cus, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (!fused_supported(d, T)) return hipErrorInvalidValue;
+    constexpr int lds = (fz::RP * fz::LDX + 8 * 3 * fz::RP * 20) * 4;   // datt_o + per-wave Q / K / dO transposition tiles
+    static_assert(8 * 3 * fz::RP * 20 >= 8 * 3 * fz::D, "the LayerNorm partial scratch lives in the per-wave scratch region");
+    if ((long long)B * T * 3 * d.D * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    AttnBwdArgs aa = a;
+    aa.dqkv_bytes = (int)((long long)B * T * 3 * d.D * 4);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
     return hipGetLastError();
 }
 

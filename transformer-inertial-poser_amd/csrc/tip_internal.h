@@ -211,6 +211,29 @@ struct FfnBwdArgs {
     float scale;
 };
 hipError_t launch_ffn_bwd(const Dims& d, const FfnBwdArgs& a, int B, int T, int num_cus, hipStream_t s);
+// ... and of its attention block: LayerNorm1 backward -> d(attention output) -> attention backward -> d(layer input)
+struct AttnBwdArgs {
+    const float* wimg;
+    int wbytes, layer;
+    const float* dx1;       // [M,D] gradient w.r.t. the LayerNorm1 output
+    const float* z1;        // [M,D] pre-LayerNorm1 rows, st1 [M,2]
+    const float* st1;
+    const float* g1;
+    const float* qkv;       // [M,3D] saved in-projection output (raw q | k | v)
+    const float* att;       // [M,D] saved attention output
+    const float* ast;       // [B,H,T,2] softmax statistics
+    float q_scale;
+    float* dz1;             // out [M,D]: gradient w.r.t. the pre-LayerNorm1 sum (scratch; also the residual path)
+    float* datt_o;          // out [M,D]: gradient into out_proj's output (dropout mask applied)
+    float* dqkv;            // out [M,3D]
+    int dqkv_bytes;         // (set by the launcher)
+    float* dx_in;           // out [M,D]: gradient w.r.t. the layer input (may alias dx1)
+    float* lnpart;          // out [B][3*D]
+    unsigned long long seed;
+    unsigned site0, site1, thresh;   // dropout sites: attention probabilities, after out_proj
+    float scale;
+};
+hipError_t launch_attn_bwd(const Dims& d, const AttnBwdArgs& a, int B, int T, int num_cus, hipStream_t s);
 // the same kernel as the training forward: activations stashed per `tr`, encoder dropout live (tip_train.hip)
 hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s, const float* keep_mask,
                               float keep_scale, float* ih_out, float* hall_sentinel, const FusedTrain& tr, int B, int T,

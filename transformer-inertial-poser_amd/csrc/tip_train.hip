@@ -1233,6 +1233,25 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             TT(tgemm16_launch(g, s), "bwd_dx1");
         }
         }
+        if (fbwd) {
+            // LayerNorm1 backward -> datt_o (gc) -> per-head dO -> attention backward -> dqkv (gbig) -> dx_in (gx, in place)
+            AttnBwdArgs aa;
+            aa.wimg = X + S.bwimg; aa.wbytes = (int)(fused_bwd_image_floats(d) * 4); aa.layer = l;
+            aa.dx1 = gx; aa.z1 = W + t.z1; aa.st1 = W + t.st1; aa.g1 = lp[PL_N1_W];
+            aa.qkv = W + t.qkv; aa.att = W + t.att; aa.ast = W + t.ast; aa.q_scale = 1.0f / sqrtf((float)d.dh);
+            aa.dz1 = galt; aa.datt_o = X + S.gc; aa.dqkv = X + S.gbig; aa.dx_in = gx; aa.lnpart = X + S.lnwin;
+            const Drop dr = make_drop(p_drop, seed, 0);
+            aa.seed = dr.seed; aa.site0 = (unsigned)(l * 4 + 0); aa.site1 = (unsigned)(l * 4 + 1); aa.thresh = dr.thresh; aa.scale = dr.scale;
+            TT(launch_attn_bwd(d, aa, B, T, ncu, s), "bwd_attn_fused");
+            hipLaunchKernelGGL(colreduce_kernel, dim3((3 * d.D + 63) / 64), dim3(256), 0, s, X + S.lnwin, B, 3 * d.D,
+                               grads + goff[pb + PL_N1_W], nullptr, 2 * d.D, grads + goff[pb + PL_OUT_B]);
+            TT(hipGetLastError(), "bwd_ln1_params");
+            TT(grad_weight(X + S.gc, d.D, d.D, d.D, W + t.att, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_OUT_W], ncu, s),
+               "bwd_dWo");
+            TT(colsum(X + S.gbig, 3 * d.D, M, 3 * d.D, colpart, grads + goff[pb + PL_QKV_B], nullptr, s), "bwd_dbqkv");
+            TT(grad_weight(X + S.gbig, 3 * d.D, 3 * d.D, 3 * d.D, x_in, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_QKV_W], ncu, s),
+               "bwd_dWqkv");
+        } else {
         // LN1: gx -> dz1 (galt), datt_o = dz1 * keep1 (gc)
         {
             const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 1));
@@ -1273,6 +1292,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             TG g = tg_base(X + S.gbig, 3 * d.D, W + t.wqkv_t, 3 * d.D, gx, d.D, M, d.D, 3 * d.D);
             g.res = galt; g.ldres = d.D;
             TT(tgemm16_launch(g, s), "bwd_dx_in");
+        }
         }
     }
     // ---- in_linear (:79) ---------------------------------------------------------------------------------------------------
