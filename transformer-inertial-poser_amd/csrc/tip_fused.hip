@@ -763,7 +763,7 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) s += Hc[w * 3 * D + i];
-            a.lnpart[(size_t)win * 3 * D + i] = s;
+            a.lnpart[(size_t)win * (3 * D + F) + i] = s;
         }
         __syncthreads();
         // ---- hidden chunks ------------------------------------------------------------------------------------------------
@@ -804,6 +804,15 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
             }
             __syncthreads();
             rows_to_hbm(Hc, LDX, 256, a.dpre + grow0 * F + f * 256, F, T, tid);
+            if (tid < 256) {   // this window's share of linear1's bias gradient: column sums of the chunk
+                float s0 = 0.f, s1 = 0.f;
+                for (int r = 0; r + 1 < T; r += 2) {
+                    s0 += Hc[r * LDX + tid];
+                    s1 += Hc[(r + 1) * LDX + tid];
+                }
+                if (T & 1) s0 += Hc[(T - 1) * LDX + tid];
+                a.lnpart[(size_t)win * (3 * D + F) + 3 * D + f * 256 + tid] = s0 + s1;
+            }
             {
                 const int w1off = lbase + (int)(fb::W1T * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                 const int nxt = f < 3 ? lbase + (int)(fb::W2T * 4) + ((f + 1) * 16 + wave * 2) * 16 * 1024 : w1off;
@@ -921,7 +930,7 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < 8; ++w) s += Sc[w * 3 * D + i];
-            a.lnpart[(size_t)win * 3 * D + i] = s;
+            a.lnpart[(size_t)win * 6 * D + i] = s;
         }
         __syncthreads();
 
@@ -982,6 +991,7 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
                 dd[r] = d_;
             }
             f32x4 dk[RB], dv[RB];
+            float sq = 0.f;   // this lane's share of the in-projection bias gradient (column sums of dq)
 #pragma unroll
             for (int r = 0; r < RB; ++r) dk[r] = dv[r] = zero4;
 #pragma unroll
@@ -1044,8 +1054,10 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
                 for (int e = 0; e < 4; ++e) {
                     const int qq = r * 16 + lg * 4 + e;
                     if (qq < T) a.dqkv[(grow0 + qq) * (3 * D) + head * 16 + l15] = dq[e] * a.q_scale;
+                    sq += dq[e] * a.q_scale;   // rows >= T are exactly zero (their dS is masked)
                 }
             }
+            float sk = 0.f, sv = 0.f;
 #pragma unroll
             for (int cb = 0; cb < RB; ++cb)
 #pragma unroll
@@ -1055,7 +1067,18 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
                         a.dqkv[(grow0 + kk) * (3 * D) + D + head * 16 + l15] = dk[cb][e] * a.q_scale;
                         a.dqkv[(grow0 + kk) * (3 * D) + 2 * D + head * 16 + l15] = dv[cb][e];
                     }
+                    sk += dk[cb][e] * a.q_scale;
+                    sv += dv[cb][e];
                 }
+            sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
+            sk += __shfl_xor(sk, 16, 64); sk += __shfl_xor(sk, 32, 64);
+            sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
+            if (lg == 0) {
+                float* lp = a.lnpart + (size_t)win * 6 * D + 3 * D + head * 16 + l15;
+                lp[0] = sq;
+                lp[D] = sk;
+                lp[2 * D] = sv;
+            }
             __builtin_amdgcn_wave_barrier();   // the scratch tiles are rewritten by the next head
         }
         __syncthreads();   // every head's dq | dk | dv rows of this window are in HBM/L2 (and visible to the other waves)

@@ -205,7 +205,7 @@ struct FfnBwdArgs {
     float* dff2;            // out [M,D]: gradient into linear2's output (dropout mask applied)
     float* dpre;            // out [M,F]: gradient into linear1's pre-activation
     float* dx1;             // out [M,D]: gradient w.r.t. the LayerNorm1 output
-    float* lnpart;          // out [B][3*D]: per-window (dgamma2 | dbeta2 | d bias of linear2) partial sums
+    float* lnpart;          // out [B][3*D + F]: per-window (dgamma2 | dbeta2 | d bias of linear2 | d bias of linear1) partial sums
     unsigned long long seed;
     unsigned site, thresh;
     float scale;
@@ -228,7 +228,7 @@ struct AttnBwdArgs {
     float* dqkv;            // out [M,3D]
     int dqkv_bytes;         // (set by the launcher)
     float* dx_in;           // out [M,D]: gradient w.r.t. the layer input (may alias dx1)
-    float* lnpart;          // out [B][3*D]
+    float* lnpart;          // out [B][6*D]: per-window (dgamma1 | dbeta1 | d bias of out_proj | d bias of in_proj)
     unsigned long long seed;
     unsigned site0, site1, thresh;   // dropout sites: attention probabilities, after out_proj
     float scale;

@@ -489,9 +489,11 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
 }
 
 // out[n] = sum_z part[z][n]; block = 64 columns x 4 z lanes
-// columns n >= nsplit go to out_hi[n - nsplit] (nsplit = N: everything to out, and to out2 when given)
+// columns n >= nsplit go to out_hi[n - nsplit], columns n >= nsplit2 to out_hi2[n - nsplit2] (a split at N or beyond is
+// inactive); `out2` duplicates the low part when given
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, int Z, int N, float* __restrict__ out,
-                                                        float* __restrict__ out2, int nsplit, float* __restrict__ out_hi) {
+                                                        float* __restrict__ out2, int nsplit, float* __restrict__ out_hi,
+                                                        int nsplit2 = 0x7fffffff, float* __restrict__ out_hi2 = nullptr) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, zl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
@@ -510,7 +512,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     __syncthreads();
     if (zl == 0 && n < N) {
         const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-        if (n >= nsplit) {
+        if (n >= nsplit2) {
+            out_hi2[n - nsplit2] = v;
+        } else if (n >= nsplit) {
             out_hi[n - nsplit] = v;
         } else {
             out[n] = v;
@@ -859,7 +863,7 @@ static TrainScratch scratch_layout(const Dims& d, int B, int T) {
     S.dwin_p = take(off, (size_t)d.D * d.InPad);
     S.dbin_p = take(off, d.D);
     S.bwimg = take(off, fused_bwd_image_floats(d));
-    S.lnwin = take(off, (size_t)B * 3 * d.D);
+    S.lnwin = take(off, (size_t)B * (size_t)(6 * d.D > 3 * d.D + d.F ? 6 * d.D : 3 * d.D + d.F));
     S.total = off;
     return S;
 }
@@ -1188,12 +1192,13 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 3));
             fa.seed = dr.seed; fa.site = dr.site; fa.thresh = dr.thresh; fa.scale = dr.scale;
             TT(launch_ffn_bwd(d, fa, B, T, ncu, s), "bwd_ffn_fused");
-            hipLaunchKernelGGL(colreduce_kernel, dim3((3 * d.D + 63) / 64), dim3(256), 0, s, X + S.lnwin, B, 3 * d.D,
-                               grads + goff[pb + PL_N2_W], nullptr, 2 * d.D, grads + goff[pb + PL_L2_B]);
+            // per-window partials [dgamma2 | dbeta2 | d(linear2 bias) | d(linear1 bias)] -> the four gradient tensors
+            hipLaunchKernelGGL(colreduce_kernel, dim3((3 * d.D + d.F + 63) / 64), dim3(256), 0, s, X + S.lnwin, B, 3 * d.D + d.F,
+                               grads + goff[pb + PL_N2_W], nullptr, 2 * d.D, grads + goff[pb + PL_L2_B], 3 * d.D,
+                               grads + goff[pb + PL_L1_B]);
             TT(hipGetLastError(), "bwd_ln2_params");
             TT(grad_weight(X + S.gc, d.D, d.D, d.D, W + t.hid, d.F, d.F, M, part, S.part_floats, grads + goff[pb + PL_L2_W], ncu, s),
                "bwd_dW2");
-            TT(colsum(X + S.gbig, d.F, M, d.F, colpart, grads + goff[pb + PL_L1_B], nullptr, s), "bwd_db1");
             TT(grad_weight(X + S.gbig, d.F, d.F, d.F, W + t.x1, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_L1_W], ncu, s),
                "bwd_dW1");
         } else {
@@ -1243,12 +1248,13 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             const Drop dr = make_drop(p_drop, seed, 0);
             aa.seed = dr.seed; aa.site0 = (unsigned)(l * 4 + 0); aa.site1 = (unsigned)(l * 4 + 1); aa.thresh = dr.thresh; aa.scale = dr.scale;
             TT(launch_attn_bwd(d, aa, B, T, ncu, s), "bwd_attn_fused");
-            hipLaunchKernelGGL(colreduce_kernel, dim3((3 * d.D + 63) / 64), dim3(256), 0, s, X + S.lnwin, B, 3 * d.D,
-                               grads + goff[pb + PL_N1_W], nullptr, 2 * d.D, grads + goff[pb + PL_OUT_B]);
+            // per-window partials [dgamma1 | dbeta1 | d(out_proj bias) | d(in_proj bias)] -> the four gradient tensors
+            hipLaunchKernelGGL(colreduce_kernel, dim3((6 * d.D + 63) / 64), dim3(256), 0, s, X + S.lnwin, B, 6 * d.D,
+                               grads + goff[pb + PL_N1_W], nullptr, 2 * d.D, grads + goff[pb + PL_OUT_B], 3 * d.D,
+                               grads + goff[pb + PL_QKV_B]);
             TT(hipGetLastError(), "bwd_ln1_params");
             TT(grad_weight(X + S.gc, d.D, d.D, d.D, W + t.att, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_OUT_W], ncu, s),
                "bwd_dWo");
-            TT(colsum(X + S.gbig, 3 * d.D, M, 3 * d.D, colpart, grads + goff[pb + PL_QKV_B], nullptr, s), "bwd_dbqkv");
             TT(grad_weight(X + S.gbig, 3 * d.D, 3 * d.D, 3 * d.D, x_in, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_QKV_W], ncu, s),
                "bwd_dWqkv");
         } else {
