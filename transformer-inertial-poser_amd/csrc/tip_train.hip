@@ -1008,6 +1008,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     static int use_fused = -1;   // TIP_TRAIN_FUSED=0: layer-by-layer forward (measurement)
     if (use_fused < 0) use_fused = (getenv("TIP_TRAIN_FUSED") && getenv("TIP_TRAIN_FUSED")[0] == '0') ? 0 : 1;
     const bool fused = use_fused && fused_supported(d, T) && fused_has_rnn_ih(d) && fused_packed_floats(d) > 0;
+    bool hall_armed = false;
     if (fused) {
         std::vector<PackOp> ops;
         fused_pack_ops(d, params, 0, ops);
@@ -1021,8 +1022,10 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         tr.layer_stride = d.L > 1 ? L.layers[1].qkv - t0.qkv : 0;
         const Drop dr = make_drop(p_drop, seed, 0);
         tr.seed = seed; tr.thresh = dr.thresh; tr.scale = dr.scale;
-        TT(launch_fused_train(d, W + L.fused_img, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f, W + L.ih, nullptr, tr, B, T,
-                              h->num_cus, s), "train_fused_encoder");
+        // the encoder also pre-fills its windows' HALL rows with the recurrence's hand-off sentinel (saves a 21-MB memset)
+        hall_armed = rnn_uses_sentinel(d, B, T, auto_cluster(B, h->num_cus));
+        TT(launch_fused_train(d, W + L.fused_img, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f, W + L.ih,
+                              hall_armed ? W + L.hall : nullptr, tr, B, T, h->num_cus, s), "train_fused_encoder");
     } else {
     {
         TG g = tg_base(W + L.U, d.InPad, W + L.win_p, d.InPad, W + L.x0, d.D, M, d.D, d.InPad);
@@ -1097,7 +1100,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     }
     }   // layer-by-layer path
     TT(launch_rnn(d, W + L.ih, W + L.whh_f, W + L.hall, reinterpret_cast<unsigned*>(W + L.flags), B, T, auto_cluster(B, h->num_cus),
-                  h->num_cus, false, s), "train_rnn");
+                  h->num_cus, hall_armed, s), "train_rnn");
     {
         TG g = tg_base(W + L.hall, d.R, rp[PR_LIN_W], d.R, y, d.S, M, d.S, d.R);
         g.bias = rp[PR_LIN_B];
