@@ -28,11 +28,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--p-drop", type=float, default=0.1)
     ap.add_argument("--no-composite", action="store_true")
+    ap.add_argument("--config", default="paper", choices=["paper", "scaled"], help="scaled = BASELINE.json configs[4] (T=80)")
     a = ap.parse_args()
-    cfg = synth.PAPER
-    B, T = a.batch, 40
+    cfg = synth.PAPER if a.config == "paper" else synth.SCALED
+    B, T = a.batch, (40 if a.config == "paper" else 80)
     with contextlib.redirect_stdout(sys.stderr):
-        m = tip_amd.TF_RNN_Past_State(72, 131, rnn_hid_size=512, tf_hid_size=1024, tf_in_dim=256, n_heads=16, tf_layers=4,
+        m = tip_amd.TF_RNN_Past_State(72, 131, rnn_hid_size=cfg["rnn_hid_size"], tf_hid_size=cfg["tf_hid_size"],
+                                      tf_in_dim=cfg["tf_in_dim"], n_heads=cfg["n_heads"], tf_layers=cfg["tf_layers"],
                                       dropout=0.0, in_dropout=0.0, past_state_dropout=0.8, with_acc_sum=True)
     w = synth.make_weights(cfg, seed=0)
     m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
@@ -80,7 +82,7 @@ def main():
         return e0.elapsed_time(e1) / a.steps
 
     fl = synth.flops_per_window(cfg, T)
-    out = {"config": f"paper config, train mode, B={B} T={T}, encoder dropout p={a.p_drop}, past-state dropout 0.8, AdamW",
+    out = {"config": f"{a.config} config, train mode, B={B} T={T}, encoder dropout p={a.p_drop}, past-state dropout 0.8, AdamW",
            "flops_forward": B * fl, "flops_fwd_bwd": 3 * B * fl}
     for what in ("forward", "fwd_bwd", "step"):
         out["hip_ms_" + what] = run(True, what)
