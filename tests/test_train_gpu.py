@@ -194,3 +194,20 @@ def test_unsupported_configuration_falls_back_to_the_composite():
     for n, p in m.named_parameters():
         err = np.linalg.norm(p.grad.cpu().numpy() - go[n]) / (np.linalg.norm(go[n]) + 1e-30)
         assert err < 1e-3, (n, err)
+
+
+def test_train_mode_without_autograd_still_draws_encoder_dropout():
+    """The reference in .train() mode applies nn.TransformerEncoderLayer's dropout under torch.no_grad() too."""
+    cfg = synth.PAPER
+    m, _ = _train_model(cfg, 0, 0.1)
+    x_imu, x_s = synth.make_inputs(cfg, 4, 40, seed=3)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    with torch.no_grad():
+        y1, y2 = m(xi, xs), m(xi, xs)
+        assert (y1 - y2).abs().max() > 1e-3          # two draws differ
+        m.eval()
+        e1, e2 = m(xi, xs), m(xi, xs)
+        assert torch.equal(e1, e2)                   # .eval(): deterministic inference kernels
+        m.train()
+        m.ENCODER_DROPOUT = 0.0
+        assert (m(xi, xs) - e1).abs().max() < 2e-5   # p = 0: same function

@@ -160,7 +160,10 @@ class TF_RNN_Past_State(nn.Module):
     def _dispatch(self, x_imu, x_s, last_row_only: bool):
         needs_grad = torch.is_grad_enabled() and (x_imu.requires_grad or x_s.requires_grad or
                                                   any(p.requires_grad for p in self.parameters()))
-        if needs_grad and self.training and self._hip_train_ok(x_imu, x_s):
+        # .train() mode draws the encoder's dropout whether or not autograd records (nn.TransformerEncoderLayer p = 0.1): with
+        # gradients wanted, or with dropout to apply, the call goes to the training kernels; .train() + no_grad + p = 0 is the
+        # same function as .eval() and takes the inference kernels below
+        if self.training and (needs_grad or self.ENCODER_DROPOUT > 0.0) and self._hip_train_ok(x_imu, x_s):
             # train_model.py:171-196 on the HIP path: forward with saved activations + live encoder dropout, HIP backward
             xi = F.dropout(x_imu, self.in_dropout, training=True) if self.in_dropout > 0.0 else x_imu   # :73
             mask = self._draw_keep_mask(x_s)                                                            # :77
