@@ -61,6 +61,9 @@ void build_layout(tip_handle* h) {
         pl.be1_off = c.take(d.D);
         pl.g2_off = c.take(d.D);
         pl.be2_off = c.take(d.D);
+        // big linears also in MFMA fragment order for the panel GEMM (tip_fused2.hip, launch_pgemm)
+        for (PackedLinear* p : {&pl.qkv, &pl.out, &pl.ff1, &pl.ff2})
+            if (pgemm_ok(1 << 20, p->N, p->K)) p->f_off = c.take((size_t)p->N * p->K);
     }
     if (d.with_rnn) {
         L.rnn_ih = carve_linear(c, d.R, d.D);
@@ -185,6 +188,17 @@ struct StageScope {
 };
 
 }  // namespace
+
+// y = epi(x W^T + b (+ res)) for one packed linear of the general plan: the panel GEMM on the fragment copy when the layer
+// has one and the batch is big enough, else the LDS-tiled GEMM on the row-major copy
+static hipError_t linear_gemm(const float* P, const tip::PackedLinear& p, const float* A, int lda, const float* res, int ldres,
+                              float* C, int ldc, int M, int flags, hipStream_t s) {
+    static int use_pg = -1;   // TIP_GENERAL_PGEMM=0 keeps the LDS-tiled kernel (measurement)
+    if (use_pg < 0) use_pg = (getenv("TIP_GENERAL_PGEMM") && getenv("TIP_GENERAL_PGEMM")[0] == '0') ? 0 : 1;
+    if (use_pg && p.f_off && tip::pgemm_ok(M, p.N, p.K))
+        return tip::launch_pgemm(A, lda, P + p.f_off, (size_t)p.N * p.K, P + p.b_off, res, ldres, C, ldc, M, p.N, p.K, flags, s);
+    return tip::launch_gemm(A, lda, P + p.w_off, p.Kpad, P + p.b_off, res, ldres, C, ldc, M, p.N, p.Npad, flags, s);
+}
 
 extern "C" {
 
@@ -341,6 +355,19 @@ int tip_pack_weights(const tip_handle* h, const float* const* t, int n, void* pa
         pack_linear(img, pl.out, lw[2], lw[3]);
         pack_linear(img, pl.ff1, lw[4], lw[5]);
         pack_linear(img, pl.ff2, lw[6], lw[7]);
+        for (const PackedLinear* p : {&pl.qkv, &pl.out, &pl.ff1, &pl.ff2}) {
+            if (!p->f_off) continue;
+            // from the packed row-major copy (which already carries the folds) to [N/16][K/16][64 lanes][4]
+            const float* w = img + p->w_off;
+            float* f = img + p->f_off;
+            const int KBn = p->K / 16;
+            for (int nb = 0; nb < p->N / 16; ++nb)
+                for (int kb = 0; kb < KBn; ++kb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int s4 = 0; s4 < 4; ++s4)
+                            f[((size_t)(nb * KBn + kb) * 64 + lane) * 4 + s4] =
+                                w[(size_t)(nb * 16 + (lane & 15)) * p->Kpad + kb * 16 + 4 * (lane >> 4) + s4];
+        }
         memcpy(img + pl.g1_off, lw[8], sizeof(float) * d.D);
         memcpy(img + pl.be1_off, lw[9], sizeof(float) * d.D);
         memcpy(img + pl.g2_off, lw[10], sizeof(float) * d.D);
@@ -422,6 +449,19 @@ int tip_pack_weights_device(const tip_handle* h, const float* const* t, int n, v
         linear(pl.out, lw[2], lw[3]);
         linear(pl.ff1, lw[4], lw[5]);
         linear(pl.ff2, lw[6], lw[7]);
+        {
+            const PackedLinear* pls[4] = {&pl.qkv, &pl.out, &pl.ff1, &pl.ff2};
+            const float* src[4] = {lw[0], lw[2], lw[4], lw[6]};
+            for (int i = 0; i < 4; ++i) {
+                if (!pls[i]->f_off) continue;
+                PackOp f = op(src[i], pls[i]->f_off, pls[i]->N, pls[i]->K, pls[i]->N, pls[i]->K, 1);
+                if (i == 0 && d.fold_q_scale) {
+                    f.scale = 1.0f / sqrtf((float)d.dh);
+                    f.scale_rows = d.D;
+                }
+                ops.push_back(f);
+            }
+        }
         ops.push_back(op(lw[8], pl.g1_off, d.D, 1, d.D, 1, 0));
         ops.push_back(op(lw[9], pl.be1_off, d.D, 1, d.D, 1, 0));
         ops.push_back(op(lw[10], pl.g2_off, d.D, 1, d.D, 1, 0));
@@ -584,8 +624,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
             const PackedLayer& pl = L.layers[l];
             {
                 StageScope sc(h, s, "qkv_gemm");
-                TIP_TRY(launch_gemm(xa, d.D, P + pl.qkv.w_off, pl.qkv.Kpad, P + pl.qkv.b_off, nullptr, 0, big, 3 * d.D,
-                                    M, 3 * d.D, pl.qkv.Npad, 0, s), "qkv_gemm");
+                TIP_TRY(linear_gemm(P, pl.qkv, xa, d.D, nullptr, 0, big, 3 * d.D, M, 0, s), "qkv_gemm");
             }
             {
                 StageScope sc(h, s, "attention");
@@ -593,8 +632,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
             }
             {
                 StageScope sc(h, s, "out_proj_gemm");
-                TIP_TRY(launch_gemm(att, d.D, P + pl.out.w_off, pl.out.Kpad, P + pl.out.b_off, xa, d.D, xb, d.D, M, d.D,
-                                    pl.out.Npad, 2, s), "out_proj_gemm");
+                TIP_TRY(linear_gemm(P, pl.out, att, d.D, xa, d.D, xb, d.D, M, 2, s), "out_proj_gemm");
             }
             {
                 StageScope sc(h, s, "layernorm1");
@@ -602,13 +640,11 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
             }
             {
                 StageScope sc(h, s, "ffn1_gemm");
-                TIP_TRY(launch_gemm(xb, d.D, P + pl.ff1.w_off, pl.ff1.Kpad, P + pl.ff1.b_off, nullptr, 0, big, d.F, M,
-                                    d.F, pl.ff1.Npad, 1, s), "ffn1_gemm");
+                TIP_TRY(linear_gemm(P, pl.ff1, xb, d.D, nullptr, 0, big, d.F, M, 1, s), "ffn1_gemm");
             }
             {
                 StageScope sc(h, s, "ffn2_gemm");
-                TIP_TRY(launch_gemm(big, d.F, P + pl.ff2.w_off, pl.ff2.Kpad, P + pl.ff2.b_off, xb, d.D, xa, d.D, M, d.D,
-                                    pl.ff2.Npad, 2, s), "ffn2_gemm");
+                TIP_TRY(linear_gemm(P, pl.ff2, big, d.F, xb, d.D, xa, d.D, M, 2, s), "ffn2_gemm");
             }
             {
                 StageScope sc(h, s, "layernorm2");

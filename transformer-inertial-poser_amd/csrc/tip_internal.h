@@ -73,6 +73,7 @@ struct PackedLinear {
     size_t w_off;   // float offset into the packed image
     size_t b_off;
     int N, K, Npad, Kpad;
+    size_t f_off = 0;   // the same weight in 16x16x4 B-fragment order (+ tail padding) for launch_pgemm; 0 = not packed
 };
 
 struct PackedLayer {
@@ -173,6 +174,12 @@ size_t rnn_flag_words(int B, int T);
 // training step, backward recurrence: delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2) (tip_train.hip)
 hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_frag, const float* h_fwd, float* delta,
                           unsigned* flags, int B, int T, int cluster, int num_cus, hipStream_t s);
+
+// ---- panel GEMM with fragment-ordered weights for big linears (tip_fused2.hip) ----
+bool pgemm_ok(int M, int N, int K);
+// wfrag: W [N][K] in 16x16x4 B-fragment order [N/16][K/16][64][4], followed by >= 2 KiB of readable padding
+hipError_t launch_pgemm(const float* A, int lda, const float* wfrag, size_t wfrag_floats, const float* bias, const float* res, int ldres,
+                        float* C, int ldc, int M, int N, int K, int flags, hipStream_t s);
 
 // ---- on-device packing (tip_pack.hip) ----
 hipError_t run_pack_ops(const std::vector<PackOp>& ops, float* img, hipStream_t s);
