@@ -63,7 +63,7 @@ void build_layout(tip_handle* h) {
         pl.be2_off = c.take(d.D);
         // big linears also in MFMA fragment order for the panel GEMM (tip_fused2.hip, launch_pgemm)
         for (PackedLinear* p : {&pl.qkv, &pl.out, &pl.ff1, &pl.ff2})
-            if (pgemm_ok(1 << 20, p->N, p->K)) p->f_off = c.take((size_t)p->N * p->K);
+            if (pgemm_shape_ok(1 << 20, p->N, p->K)) p->f_off = c.take((size_t)p->N * p->K);
     }
     if (d.with_rnn) {
         L.rnn_ih = carve_linear(c, d.R, d.D);
@@ -195,7 +195,7 @@ static hipError_t linear_gemm(const float* P, const tip::PackedLinear& p, const 
                               float* C, int ldc, int M, int flags, hipStream_t s) {
     static int use_pg = -1;   // TIP_GENERAL_PGEMM=0 keeps the LDS-tiled kernel (measurement)
     if (use_pg < 0) use_pg = (getenv("TIP_GENERAL_PGEMM") && getenv("TIP_GENERAL_PGEMM")[0] == '0') ? 0 : 1;
-    if (use_pg && p.f_off && tip::pgemm_ok(M, p.N, p.K))
+    if (use_pg && p.f_off && tip::pgemm_shape_ok(M, p.N, p.K))
         return tip::launch_pgemm(A, lda, P + p.f_off, (size_t)p.N * p.K, P + p.b_off, res, ldres, C, ldc, M, p.N, p.K, flags, s);
     return tip::launch_gemm(A, lda, P + p.w_off, p.Kpad, P + p.b_off, res, ldres, C, ldc, M, p.N, p.Npad, flags, s);
 }

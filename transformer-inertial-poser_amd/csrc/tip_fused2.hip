@@ -16,10 +16,9 @@
 
 #include "tip_internal.h"
 #include "tip_attention.h"
+#include "tip_pgemm.h"
 
 namespace tip {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace f2 {
 constexpr int D = 256, F = 1024, R = 512, T = 40, ROWS = 80, RB = 5, KIN = 224;
@@ -40,45 +39,6 @@ constexpr size_t W1_W = WO_B + D, W1_B = W1_W + (size_t)F * D, W2_W = W1_B + F, 
 constexpr size_t G1 = W2_B + D, BE1 = G1 + D, G2 = BE1 + D, BE2 = G2 + D, LAYER_FLOATS = BE2 + D;
 static_assert(C_FLOATS >= ROWS * LDU && C_FLOATS >= ROWS * LDH, "chunk region must hold U and Hc");
 }  // namespace f2
-
-__device__ __forceinline__ float4 ldfrag2(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
-    const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
-    return make_float4(f.x, f.y, f.z, f.w);
-}
-
-template <int NBW>
-struct WRing2 {
-    float4 w0[NBW], w1[NBW];
-};
-
-template <int NBW>
-__device__ __forceinline__ void ring2_prefetch(WRing2<NBW>& g, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b) {
-#pragma unroll
-    for (int n = 0; n < NBW; ++n) {
-        g.w0[n] = ldfrag2(rsrc, voff, soff + n * nstride_b);
-        g.w1[n] = ldfrag2(rsrc, voff, soff + n * nstride_b + 1024);
-    }
-}
-
-template <int NRB, int NBW>
-__device__ __forceinline__ void mfma_block2(f32x4 (&acc)[NRB][NBW], const float4 (&a)[NRB], const float4 (&w)[NBW]) {
-#pragma unroll
-    for (int r = 0; r < NRB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].x, w[n].x, acc[r][n], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < NRB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].y, w[n].y, acc[r][n], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < NRB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].z, w[n].z, acc[r][n], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < NRB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].w, w[n].w, acc[r][n], 0, 0, 0);
-}
 
 // acc[r][n] += A(rows of block r) * Wblock(n, kb), kb in [0, KB).  lds + aoff[r]: this lane's LDS address of
 // (its row of row-block r, k-offset 4*(lane>>4)) — row blocks need not be equally spaced (remapped planes).
@@ -110,13 +70,6 @@ __device__ __forceinline__ void gemm_phase2(f32x4 (&acc)[NRB][NBW], const float*
     }
 }
 
-template <int NRB, int NBW>
-__device__ __forceinline__ void zero_acc2(f32x4 (&acc)[NRB][NBW]) {
-#pragma unroll
-    for (int r = 0; r < NRB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-}
 
 // LayerNorm over the 80 rows of X: wave w owns rows w, w+8, ... (10 rows), reductions interleaved.
 __device__ __forceinline__ void layernorm_rows2(float* X, const float* __restrict__ g, const float* __restrict__ be, int wave,
@@ -436,104 +389,30 @@ hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const floa
     return hipGetLastError();
 }
 
-// =====================================================================================================================
-// pgemm: the fused kernels' GEMM structure as a stand-alone kernel for BIG linears (the scaled configuration's d = 1024,
-// ffn = 4096): C[M,N] = epi(A[M,K] W^T + bias (+ res)).  An 80-row x 512-column panel per 512-thread workgroup; the A
-// panel goes through LDS in K-chunks of 128 (double-buffered, ONE barrier per chunk = per 640 MFMAs of a wave), the
-// weights never touch LDS: they are packed in 16x16x4 B-fragment order and each wave streams the fragments of its four
-// column blocks from L2 into a register ring.  Against the LDS-tiled tgemm16 (both operands staged, a barrier every 32
-// MFMAs, 16 flop per L2 byte) this reads 40 flop per L2 byte and keeps the matrix pipe fed between barriers.
-// =====================================================================================================================
-namespace pg {
-constexpr int ROWS = 80, RB = 5, NBW = 4, KC = 128, LDA = KC + 4, THREADS = 512, COLS = 8 * NBW * 16;   // 512
-constexpr int LDS_BYTES = 2 * ROWS * LDA * 4;                                                          // 84 480
-}  // namespace pg
-
+// general plan: bias (+ residual) (+ ReLU)
 template <int FLAGS>   // 1 = relu, 2 = residual
+struct PgEpi {
+    const float* bias;
+    const float* res;
+    float* C;
+    int ldres, ldc;
+    __device__ __forceinline__ void operator()(int row, int col, float v) const {
+        v += bias[col];
+        if (FLAGS & 2) v += res[(size_t)row * ldres + col];
+        if (FLAGS & 1) v = v > 0.f ? v : 0.f;
+        C[(size_t)row * ldc + col] = v;
+    }
+};
+
+template <int FLAGS>
 __global__ __launch_bounds__(pg::THREADS) void pgemm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ wfrag,
                                                             int wbytes, const float* __restrict__ bias, const float* __restrict__ res,
                                                             int ldres, float* __restrict__ C, int ldc, int M, int N, int K) {
-    using namespace pg;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, lg = lane >> 4;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wfrag), 0, wbytes, 0x00020000);
-    const int voff = lane * 16;
-    const int row0 = blockIdx.y * ROWS;
-    const int nb0 = blockIdx.x * (COLS / 16) + wave * NBW;          // first 16-column block of this wave
-    const int KB = K >> 4, nchunks = K / KC;
-    const int wsoff = nb0 * KB * 1024;                              // byte offset of (nb0, kb = 0); next nb: + KB*1024
-    // A staging: 80 x 128 floats = 2560 float4 = 5 per thread
-    float4 st[5];
-    auto fetch = [&](int c) {
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int f = tid + u * THREADS, r = f >> 5, k4 = f & 31;
-            st[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + r < M) st[u] = *reinterpret_cast<const float4*>(A + (size_t)(row0 + r) * lda + c * KC + k4 * 4);
-        }
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int f = tid + u * THREADS, r = f >> 5, k4 = f & 31;
-            *reinterpret_cast<float4*>(smem + (buf * ROWS + r) * LDA + k4 * 4) = st[u];
-        }
-    };
-    f32x4 acc[RB][NBW];
-    zero_acc2<RB, NBW>(acc);
-    WRing2<NBW> g;
-    ring2_prefetch<NBW>(g, rsrc, voff, wsoff, KB * 1024);
-    fetch(0);
-    stage(0);
-    __syncthreads();
-#pragma unroll 1
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) fetch(c + 1);
-        const float* As = smem + ((c & 1) * ROWS + l15) * LDA + lg * 4;
-        float4 a0[RB], a1[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) a0[r] = *reinterpret_cast<const float4*>(As + r * 16 * LDA);
-#pragma unroll 1
-        for (int kb = 0; kb < KC / 16; kb += 2) {
-            const int gkb = c * (KC / 16) + kb + 2;                 // the k-blocks the ring fetches next (may run past K: padded image)
-#pragma unroll
-            for (int r = 0; r < RB; ++r) a1[r] = *reinterpret_cast<const float4*>(As + r * 16 * LDA + (kb + 1) * 16);
-            mfma_block2<RB, NBW>(acc, a0, g.w0);
-#pragma unroll
-            for (int n = 0; n < NBW; ++n) g.w0[n] = ldfrag2(rsrc, voff, wsoff + (n * KB + gkb) * 1024);
-#pragma unroll
-            for (int r = 0; r < RB; ++r) a0[r] = *reinterpret_cast<const float4*>(As + r * 16 * LDA + ((kb + 2) & (KC / 16 - 1)) * 16);
-            mfma_block2<RB, NBW>(acc, a1, g.w1);
-#pragma unroll
-            for (int n = 0; n < NBW; ++n) g.w1[n] = ldfrag2(rsrc, voff, wsoff + (n * KB + gkb + 1) * 1024);
-        }
-        if (c + 1 < nchunks) stage((c + 1) & 1);
-        __syncthreads();
-    }
-    // epilogue.  C/D layout of 16x16: col = lane&15, row = 4*(lane>>4) + e.
-#pragma unroll
-    for (int n = 0; n < NBW; ++n) {
-        const int col = (nb0 + n) * 16 + l15;
-        if (col >= N) continue;
-        const float bv = bias[col];
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = row0 + r * 16 + lg * 4 + e;
-                if (row < M) {
-                    float v = acc[r][n][e] + bv;
-                    if (FLAGS & 2) v += res[(size_t)row * ldres + col];
-                    if (FLAGS & 1) v = v > 0.f ? v : 0.f;
-                    C[(size_t)row * ldc + col] = v;
-                }
-            }
-    }
+    const PgEpi<FLAGS> epi{bias, res, C, ldres, ldc};
+    pgemm_body(A, lda, wfrag, wbytes, M, N, K, epi);
 }
 
-bool pgemm_ok(int M, int N, int K) { return N % pg::COLS == 0 && K % pg::KC == 0 && M >= 4 * pg::ROWS; }
+bool pgemm_shape_ok(int M, int N, int K) { return pgemm_ok(M, N, K); }
 
 hipError_t launch_pgemm(const float* A, int lda, const float* wfrag, size_t wfrag_floats, const float* bias, const float* res, int ldres,
                         float* C, int ldc, int M, int N, int K, int flags, hipStream_t s) {

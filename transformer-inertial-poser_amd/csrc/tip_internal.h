@@ -176,7 +176,7 @@ hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_fra
                           unsigned* flags, int B, int T, int cluster, int num_cus, hipStream_t s);
 
 // ---- panel GEMM with fragment-ordered weights for big linears (tip_fused2.hip) ----
-bool pgemm_ok(int M, int N, int K);
+bool pgemm_shape_ok(int M, int N, int K);   // N % 512 == 0, K % 128 == 0, M >= 320
 // wfrag: W [N][K] in 16x16x4 B-fragment order [N/16][K/16][64][4], followed by >= 2 KiB of readable padding
 hipError_t launch_pgemm(const float* A, int lda, const float* wfrag, size_t wfrag_floats, const float* bias, const float* res, int ldres,
                         float* C, int ldc, int M, int N, int K, int flags, hipStream_t s);

@@ -23,10 +23,10 @@
 #include <string.h>
 
 #include "tip_internal.h"
+#include "tip_pgemm.h"
 
 namespace tip {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -373,6 +373,48 @@ static hipError_t tgemm16_launch(TG g, hipStream_t s) {
     } else {
         hipLaunchKernelGGL((tgemm16_kernel<64, 64>), dim3((g.nn + 63) / 64, (g.mm + 63) / 64), dim3(256), 0, s, g);
     }
+    return hipGetLastError();
+}
+
+// The same GEMM contract on the panel kernel (tip_pgemm.h) when the weight is available in fragment order and the shape
+// fits (N % 512 == 0, K % 128 == 0): the scaled configuration's linears, forward and dX alike.
+struct TgEpi {
+    TG g;
+    __device__ __forceinline__ void operator()(int row, int col, float v) const {
+        if (g.bias) v += g.bias[col];
+        if (g.relu) v = v > 0.f ? v : 0.f;
+        v *= drop_factor(g.drop, (unsigned long long)row * (unsigned)g.nn + (unsigned)col);
+        if (g.gate) v *= g.gate[(long long)row * g.ldgate + col] > 0.f ? g.gate_scale : 0.f;
+        if (g.res) v += g.res[(long long)row * g.ldres + col];
+        g.C[(long long)row * g.ldc + col] = v;
+    }
+};
+
+__global__ __launch_bounds__(pg::THREADS) void pgemm_tg_kernel(TG g, const float* __restrict__ wfrag, int wbytes) {
+    const TgEpi epi{g};
+    pgemm_body(g.A, (int)g.lda, wfrag, wbytes, g.mm, g.nn, g.kva, epi);
+}
+
+// shape fits AND the grid fills the chip: an 80 x 512 panel per workgroup needs M*N/40960 >= 2 x CUs of them to beat the
+// 64 x 64-tile kernel (scaled model: B >= 128 windows of 80 frames; measured B=64: slower, B=256: +6 %)
+static bool panel_ok(int M, int N, int K) {
+    return pgemm_ok(M, N, K) && (long long)(N / pg::COLS) * ((M + pg::ROWS - 1) / pg::ROWS) >= 2LL * g_tgemm_cus;
+}
+
+static hipError_t lin_launch(const TG& g, const float* wfrag, hipStream_t s) {
+    static int use_pg = -1;   // TIP_TRAIN_PGEMM=0: LDS-tiled kernel everywhere (measurement)
+    if (use_pg < 0) use_pg = (getenv("TIP_TRAIN_PGEMM") && getenv("TIP_TRAIN_PGEMM")[0] == '0') ? 0 : 1;
+    if (!use_pg || !wfrag || !panel_ok(g.mm, g.nn, g.kva) || g.kva != g.kvb || (long long)g.nn * g.kva * 4 > 0x7fffffffLL)
+        return tgemm16_launch(g, s);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pgemm_tg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           pg::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pgemm_tg_kernel, dim3(g.nn / pg::COLS, (g.mm + pg::ROWS - 1) / pg::ROWS), dim3(pg::THREADS), pg::LDS_BYTES, s, g,
+                       wfrag, (int)((long long)g.nn * g.kva * 4));
     return hipGetLastError();
 }
 
@@ -777,10 +819,13 @@ static int grid_for(long long n) {
 struct TrainLayer {
     size_t qkv, ast, att, z1, st1, x1, hid, z2, st2, xo;
     size_t wqkv_t, wo_t, w1_t, w2_t;   // transposed weight copies (prep) for the dX GEMMs
+    // fragment-order copies for the panel GEMM (0 = shape not eligible / fused path): forward W, and W^T for the dX products
+    size_t qkv_f = 0, wo_f = 0, w1_f = 0, w2_f = 0, qkv_tf = 0, wo_tf = 0, w1_tf = 0, w2_tf = 0;
 };
 struct TrainSaved {
     size_t win_p, bin_p, bsum, whh_f, whh_b, U, x0, ih, hall, flags;
     size_t wout_t, wih_t;
+    size_t wih_f = 0, wih_tf = 0;
     size_t fused_img;   // fused-plan weight image (fragment order), packed on the GPU every step; 0 floats when unsupported
     std::vector<TrainLayer> layers;
     size_t total;
@@ -811,6 +856,10 @@ static TrainSaved saved_layout(const Dims& d, int B, int T) {
     L.wih_t = take(off, (size_t)d.D * d.R);
     L.U = take(off, M * d.InPad);
     L.x0 = take(off, M * d.D);
+    // the panel GEMM serves the layer-by-layer path; the paper configuration's fused kernels have their own images
+    const bool frags = !(fused_supported(d, T) && fused_has_rnn_ih(d));
+    if (frags && panel_ok((int)M, d.R, d.D)) L.wih_f = take(off, (size_t)d.R * d.D);
+    if (frags && panel_ok((int)M, d.D, d.R)) L.wih_tf = take(off, (size_t)d.R * d.D);
     for (int l = 0; l < d.L; ++l) {
         TrainLayer t;
         t.qkv = take(off, M * 3 * d.D);
@@ -827,6 +876,16 @@ static TrainSaved saved_layout(const Dims& d, int B, int T) {
         t.wo_t = take(off, (size_t)d.D * d.D);
         t.w1_t = take(off, (size_t)d.F * d.D);
         t.w2_t = take(off, (size_t)d.F * d.D);
+        if (frags) {
+            if (panel_ok((int)M, 3 * d.D, d.D)) t.qkv_f = take(off, (size_t)3 * d.D * d.D);
+            if (panel_ok((int)M, d.D, d.D)) t.wo_f = take(off, (size_t)d.D * d.D);
+            if (panel_ok((int)M, d.F, d.D)) t.w1_f = take(off, (size_t)d.F * d.D);
+            if (panel_ok((int)M, d.D, d.F)) t.w2_f = take(off, (size_t)d.F * d.D);
+            if (panel_ok((int)M, d.D, 3 * d.D)) t.qkv_tf = take(off, (size_t)3 * d.D * d.D);   // dx_in = dqkv Wqkv: N = D, K = 3D
+            if (panel_ok((int)M, d.D, d.D)) t.wo_tf = take(off, (size_t)d.D * d.D);
+            if (panel_ok((int)M, d.D, d.F)) t.w1_tf = take(off, (size_t)d.F * d.D);            // dx1 = dpre W1:   N = D, K = F
+            if (panel_ok((int)M, d.F, d.D)) t.w2_tf = take(off, (size_t)d.F * d.D);            // dhid = dff2 W2:  N = F, K = D
+        }
         L.layers.push_back(t);
     }
     L.ih = take(off, M * d.R);
@@ -939,6 +998,7 @@ int tip_train_bytes(const tip_handle* h, int B, int T, size_t* saved_bytes, size
         return TIP_OK;
     }
     if (!train_supported(h->d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    g_tgemm_cus = h->num_cus;   // the layouts below depend on it (panel-GEMM eligibility)
     if (saved_bytes) *saved_bytes = saved_layout(h->d, B, T).total * sizeof(float);
     if (scratch_bytes) *scratch_bytes = scratch_layout(h->d, B, T).total * sizeof(float);
     return TIP_OK;
@@ -949,6 +1009,7 @@ int tip_train_saved_view(const tip_handle* h, int B, int T, int what, int layer,
     const Dims& d = h->d;
     if (!train_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (layer < 0 || layer >= d.L) return TIP_ERR_INVALID_ARG;
+    g_tgemm_cus = h->num_cus;
     const TrainSaved L = saved_layout(d, B, T);
     const TrainLayer& t = L.layers[layer];
     const size_t M = (size_t)B * T;
@@ -972,10 +1033,10 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     if (p_drop < 0.f || p_drop >= 1.f) return TIP_ERR_INVALID_ARG;
     const Dims& d = h->d;
     if (!train_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    g_tgemm_cus = h->num_cus;
     const TrainSaved L = saved_layout(d, B, T);
     if (reinterpret_cast<uintptr_t>(saved) % 256 || saved_bytes < L.total * sizeof(float)) return TIP_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    g_tgemm_cus = h->num_cus;
     float* W = static_cast<float*>(saved);
     const int M = B * T;
     const float* const* rp = params + P_LAYER0 + PL_COUNT * d.L;
@@ -1028,6 +1089,32 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
                               hall_armed ? W + L.hall : nullptr, tr, B, T, h->num_cus, s), "train_fused_encoder");
     } else {
     {
+        // fragment-order weight copies (forward and transposed) for the panel GEMM, packed from the live parameters
+        std::vector<PackOp> ops;
+        auto frag = [&](const float* src, size_t dst, int N, int K, bool tr) {
+            if (!dst) return;
+            PackOp o;
+            o.src = src; o.src2 = nullptr; o.dst_off = dst; o.N = N; o.K = K; o.src_rows = N; o.src_cols = K; o.frag = 1;
+            o.shuffle_h = 0; o.shuffle_dh = 0; o.z0 = 0; o.z1 = 0; o.scale_rows = 0; o.scale = 1.f; o.transpose = tr ? 1 : 0;
+            ops.push_back(o);
+        };
+        frag(rp[PR_WIH], L.wih_f, d.R, d.D, false);
+        frag(rp[PR_WIH], L.wih_tf, d.D, d.R, true);
+        for (int l = 0; l < d.L; ++l) {
+            const float* const* lp = params + P_LAYER0 + PL_COUNT * l;
+            const TrainLayer& t = L.layers[l];
+            frag(lp[PL_QKV_W], t.qkv_f, 3 * d.D, d.D, false);
+            frag(lp[PL_OUT_W], t.wo_f, d.D, d.D, false);
+            frag(lp[PL_L1_W], t.w1_f, d.F, d.D, false);
+            frag(lp[PL_L2_W], t.w2_f, d.D, d.F, false);
+            frag(lp[PL_QKV_W], t.qkv_tf, d.D, 3 * d.D, true);
+            frag(lp[PL_OUT_W], t.wo_tf, d.D, d.D, true);
+            frag(lp[PL_L1_W], t.w1_tf, d.D, d.F, true);
+            frag(lp[PL_L2_W], t.w2_tf, d.F, d.D, true);
+        }
+        if (!ops.empty()) TT(run_pack_ops(ops, W, s), "train_frag_pack");
+    }
+    {
         TG g = tg_base(W + L.U, d.InPad, W + L.win_p, d.InPad, W + L.x0, d.D, M, d.D, d.InPad);
         g.bias = W + L.bin_p;
         TT(tgemm16_launch(g, s), "train_in_linear");
@@ -1039,7 +1126,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         {
             TG g = tg_base(x, d.D, lp[PL_QKV_W], d.D, W + t.qkv, 3 * d.D, M, 3 * d.D, d.D);
             g.bias = lp[PL_QKV_B];
-            TT(tgemm16_launch(g, s), "train_qkv");
+            TT(lin_launch(g, t.qkv_f ? W + t.qkv_f : nullptr, s), "train_qkv");
         }
         {
             const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 0));
@@ -1055,7 +1142,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
             g.bias = lp[PL_OUT_B];
             g.drop = make_drop(p_drop, seed, (unsigned)(l * 4 + 1));
             g.res = x; g.ldres = d.D;
-            TT(tgemm16_launch(g, s), "train_out_proj");
+            TT(lin_launch(g, t.wo_f ? W + t.wo_f : nullptr, s), "train_out_proj");
         }
         {
             const float* z = W + t.z1;
@@ -1072,14 +1159,14 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
             g.bias = lp[PL_L1_B];
             g.relu = 1;
             g.drop = make_drop(p_drop, seed, (unsigned)(l * 4 + 2));
-            TT(tgemm16_launch(g, s), "train_ffn1");
+            TT(lin_launch(g, t.w1_f ? W + t.w1_f : nullptr, s), "train_ffn1");
         }
         {
             TG g = tg_base(W + t.hid, d.F, lp[PL_L2_W], d.F, W + t.z2, d.D, M, d.D, d.F);
             g.bias = lp[PL_L2_B];
             g.drop = make_drop(p_drop, seed, (unsigned)(l * 4 + 3));
             g.res = W + t.x1; g.ldres = d.D;
-            TT(tgemm16_launch(g, s), "train_ffn2");
+            TT(lin_launch(g, t.w2_f ? W + t.w2_f : nullptr, s), "train_ffn2");
         }
         {
             const float* z = W + t.z2;
@@ -1096,7 +1183,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     {
         TG g = tg_base(x, d.D, rp[PR_WIH], d.D, W + L.ih, d.R, M, d.R, d.D);
         g.bias = W + L.bsum;
-        TT(tgemm16_launch(g, s), "train_rnn_ih");
+        TT(lin_launch(g, L.wih_f ? W + L.wih_f : nullptr, s), "train_rnn_ih");
     }
     }   // layer-by-layer path
     TT(launch_rnn(d, W + L.ih, W + L.whh_f, W + L.hall, reinterpret_cast<unsigned*>(W + L.flags), B, T, auto_cluster(B, h->num_cus),
@@ -1117,6 +1204,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     if (n_params != (int)h->tensor_names.size()) return TIP_ERR_INVALID_ARG;
     const Dims& d = h->d;
     if (!train_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    g_tgemm_cus = h->num_cus;
     const TrainSaved L = saved_layout(d, B, T);
     const TrainScratch S = scratch_layout(d, B, T);
     if (reinterpret_cast<uintptr_t>(saved) % 256 || saved_bytes < L.total * sizeof(float)) return TIP_ERR_WORKSPACE;
@@ -1176,7 +1264,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     float* galt = X + S.gb;
     {
         TG g = tg_base(X + S.delta, d.R, W + L.wih_t, d.R, gx, d.D, M, d.D, d.R);
-        TT(tgemm16_launch(g, s), "bwd_d_enc");
+        TT(lin_launch(g, L.wih_tf ? W + L.wih_tf : nullptr, s), "bwd_d_enc");
     }
     // ---- encoder layers, last to first -----------------------------------------------------------------------------------
     for (int l = d.L - 1; l >= 0; --l) {
@@ -1229,7 +1317,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             TG g = tg_base(X + S.gc, d.D, W + t.w2_t, d.D, X + S.gbig, d.F, M, d.F, d.D);
             g.gate = W + t.hid; g.ldgate = d.F;
             g.gate_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.f;
-            TT(tgemm16_launch(g, s), "bwd_dhid");
+            TT(lin_launch(g, t.w2_tf ? W + t.w2_tf : nullptr, s), "bwd_dhid");
         }
         TT(colsum(X + S.gbig, d.F, M, d.F, colpart, grads + goff[pb + PL_L1_B], nullptr, s), "bwd_db1");
         TT(grad_weight(X + S.gbig, d.F, d.F, d.F, W + t.x1, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_L1_W], ncu, s),
@@ -1238,7 +1326,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             // dx1 = dz2 + dpre W1   -> gx
             TG g = tg_base(X + S.gbig, d.F, W + t.w1_t, d.F, gx, d.D, M, d.D, d.F);
             g.res = galt; g.ldres = d.D;
-            TT(tgemm16_launch(g, s), "bwd_dx1");
+            TT(lin_launch(g, t.w1_tf ? W + t.w1_tf : nullptr, s), "bwd_dx1");
         }
         }
         if (fbwd) {
@@ -1280,7 +1368,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
            "bwd_dWo");
         {
             TG g = tg_base(X + S.gc, d.D, W + t.wo_t, d.D, X + S.datt, d.D, M, d.D, d.D);
-            TT(tgemm16_launch(g, s), "bwd_datt");
+            TT(lin_launch(g, t.wo_tf ? W + t.wo_tf : nullptr, s), "bwd_datt");
         }
         {
             const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 0));
@@ -1300,7 +1388,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             // dx_in = dz1 + dqkv W_qkv   -> gx
             TG g = tg_base(X + S.gbig, 3 * d.D, W + t.wqkv_t, 3 * d.D, gx, d.D, M, d.D, 3 * d.D);
             g.res = galt; g.ldres = d.D;
-            TT(tgemm16_launch(g, s), "bwd_dx_in");
+            TT(lin_launch(g, t.qkv_tf ? W + t.qkv_tf : nullptr, s), "bwd_dx_in");
         }
         }
     }
