@@ -184,6 +184,28 @@ int tip_combine_sequence(const double* imu, const double* s, const double* c, in
 int tip_gather_windows(const float* imu_c, const float* sum_c, const float* s_c, long long n_frames, const long long* t_idx,
                        int n, int T, float* x_imu, float* x_s, float* y, tip_stream_t stream);
 
+/* ---- training losses and their gradient ---------------------------------------------------
+ * Replaces learning_utils.py:13-78 as train_model.py:177-189 combines them: loss = loss_constr_multi + loss_q_only_2axis +
+ * loss_jerk.  pred / gt: DEVICE fp32 rows [B*T, W], W = n_pose + n_vel + 4*n_sbp (reference: 108 + 3 + 20), row strides ld_*
+ * in floats (so the reference's column slices can be passed as they are); n_vel is 3 or 0.  `terms` selects which of the
+ * three functions are evaluated; a column group a term does not use may have width 0 (loss_jerk alone: n_vel = n_sbp = 0,
+ * gt may be NULL).  Masking as the reference: rows whose GT root x/y are NaN leave the root-velocity terms, rows with any
+ * NaN GT constraint leave the constraint terms; a mean over no rows is NaN.
+ *   tip_loss_forward   stats[0..3] = total, loss_q, loss_c, loss_j (0 for a term not selected); the rest of stats
+ *                      (TIP_LOSS_STATS floats, device) carries the normalisers the backward needs.
+ *   tip_loss_backward  dpred[B*T, W] = gout * d total / d pred (gout: DEVICE scalar, NULL = 1); every column is written.
+ * Deterministic: fixed-order fp64 reduction of per-workgroup partial sums. */
+#define TIP_LOSS_Q 1 /* loss_q_only_2axis (learning_utils.py:50-78) */
+#define TIP_LOSS_C 2 /* loss_constr_multi (learning_utils.py:13-35) */
+#define TIP_LOSS_J 4 /* loss_jerk         (learning_utils.py:38-47) */
+#define TIP_LOSS_STATS 16
+int tip_loss_ws_bytes(int B, int T, size_t* bytes);
+int tip_loss_forward(const float* pred, long long ld_pred, const float* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
+                     int n_sbp, int terms, float* stats, void* ws, size_t ws_bytes, tip_stream_t stream);
+int tip_loss_backward(const float* pred, long long ld_pred, const float* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
+                      int n_sbp, int terms, const float* stats, const float* gout, float* dpred, long long ld_dpred,
+                      tip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

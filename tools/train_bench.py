@@ -19,6 +19,43 @@ import tip_amd  # noqa: E402
 from tip_amd import synth  # noqa: E402
 
 PEAK = 157.3
+N_SBPS = 5
+
+
+def torch_losses(y_pred, y):
+    """Baseline only: the loss part of the reference loop (train_model.py:177-189) as the torch ops it issues — third
+    difference for the jerk term, boolean-mask row selection for the root-velocity and constraint terms, one BCE and one
+    squared error per constraint (learning_utils.py:13-78)."""
+    F = torch.nn.functional
+    W, nc = y_pred.shape[-1], 4 * N_SBPS
+    pose = y_pred[:, :, :W - nc - 3]
+    jit = pose[:, 3:] - 3 * pose[:, 2:-1] + 3 * pose[:, 1:-2] - pose[:, :-3]
+    l_j = (jit ** 2).mean() * 100.0
+    p2, g2 = y_pred.reshape(-1, W), y.reshape(-1, W)
+    pq, gq = p2[:, :W - nc].clone(), g2[:, :W - nc].clone()
+    l_q = ((pq[:, :-3] - gq[:, :-3]) ** 2).mean() * 100.0
+    keep = ~torch.any(gq[:, -3:-1].isnan(), dim=1)
+    l_q = l_q + ((gq[:, -3:-1][keep] - pq[:, -3:-1][keep]) ** 2).mean() * 6.0 + ((gq[:, -1:][keep] - pq[:, -1:][keep]) ** 2).mean() * 12.0
+    pc, gc = p2[:, W - nc:], g2[:, W - nc:]
+    keep = ~torch.any(gc.isnan(), dim=1)
+    pc, gc = pc[keep].clone(), gc[keep].clone()
+    l_c = 0.0
+    for i in range(N_SBPS):
+        l_c = l_c + F.binary_cross_entropy(torch.sigmoid(pc[:, 4 * i:4 * i + 1]), gc[:, 4 * i:4 * i + 1]) \
+            + ((pc[:, 4 * i + 1:4 * i + 4] - gc[:, 4 * i + 1:4 * i + 4] * 5.0) ** 2).mean() * 4.0
+    return l_c / N_SBPS * 2.5 + l_q + l_j
+
+
+def make_targets(B, T, W, seed=9):
+    """GT rows with the training set's NaN pattern: root velocity NaN on ~30 % of the rows, constraints on ~20 %."""
+    rng = np.random.RandomState(seed)
+    gt = (rng.standard_normal((B, T, W)) * 0.5).astype(np.float32)
+    c = gt[:, :, W - 4 * N_SBPS:].reshape(B, T, N_SBPS, 4)
+    c[..., 0] = rng.rand(B, T, N_SBPS) < 0.4
+    c[..., 1:] = rng.uniform(-0.25, 0.25, (B, T, N_SBPS, 3))
+    gt[rng.rand(B, T) < 0.3, W - 4 * N_SBPS - 3:W - 4 * N_SBPS] = np.nan
+    gt[rng.rand(B, T) < 0.2, W - 4 * N_SBPS:] = np.nan
+    return gt
 
 
 def main():
@@ -46,6 +83,7 @@ def main():
     xi = torch.tensor(np.tile(x_imu, (reps, 1, 1))[:B]).cuda()
     xs = torch.tensor(np.nan_to_num(np.tile(x_s, (reps, 1, 1))[:B])).cuda()
     tgt = torch.randn(B, T, cfg["size_s"], device="cuda")
+    gt = torch.tensor(make_targets(B, T, cfg["size_s"])).cuda()
 
     def run(hip, what):
         m.use_hip_training = hip
@@ -61,13 +99,28 @@ def main():
             torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
             opt.step()
 
+        def ref_step():
+            # the body of the reference's batch loop (train_model.py:171-198): noise, forward, three losses, backward, clip, AdamW
+            noise = (torch.rand(xs.size(), device="cuda") - 0.5) * 0.06
+            y_pred = m(xi, xs + noise)
+            loss = tip_amd.learning_utils.train_loss(y_pred, gt, N_SBPS) if hip else torch_losses(y_pred, gt)
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+            opt.step()
+
+        def loss_only():
+            yp = tgt.detach().requires_grad_(True)
+            loss = tip_amd.learning_utils.train_loss(yp, gt, N_SBPS) if hip else torch_losses(yp, gt)
+            loss.backward()
+
         def fb():
             for p in m.parameters():
                 p.grad = None
             y = fwd()
             y.backward(tgt)
 
-        fn = {"forward": fwd, "fwd_bwd": fb, "step": step}[what]
+        fn = {"forward": fwd, "fwd_bwd": fb, "step": step, "ref_step": ref_step, "loss_fwd_bwd": loss_only}[what]
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             for _ in range(a.warmup):
@@ -84,15 +137,17 @@ def main():
     fl = synth.flops_per_window(cfg, T)
     out = {"config": f"{a.config} config, train mode, B={B} T={T}, encoder dropout p={a.p_drop}, past-state dropout 0.8, AdamW",
            "flops_forward": B * fl, "flops_fwd_bwd": 3 * B * fl}
-    for what in ("forward", "fwd_bwd", "step"):
+    whats = ("forward", "fwd_bwd", "step", "loss_fwd_bwd", "ref_step")
+    for what in whats:
         out["hip_ms_" + what] = run(True, what)
     out["hip_fwd_bwd_tflops"] = 3 * B * fl / out["hip_ms_fwd_bwd"] / 1e9
     out["hip_fwd_bwd_frac_fp32_mfma_peak"] = out["hip_fwd_bwd_tflops"] / PEAK
     out["hip_windows_per_s_step"] = B / out["hip_ms_step"] * 1e3
     if not a.no_composite:
-        for what in ("forward", "fwd_bwd", "step"):
+        for what in whats:
             out["torch_ops_ms_" + what] = run(False, what)
         out["speedup_step_vs_torch_ops"] = out["torch_ops_ms_step"] / out["hip_ms_step"]
+        out["speedup_ref_step_vs_torch_ops"] = out["torch_ops_ms_ref_step"] / out["hip_ms_ref_step"]
     print(json.dumps(out))
 
 

@@ -18,7 +18,7 @@ def __getattr__(name):
     if name == "TF_RNN_Past_State":
         from .simple_transformer_with_state import TF_RNN_Past_State
         return TF_RNN_Past_State
-    if name in ("lib", "dist", "simple_transformer_with_state", "streaming", "data"):
+    if name in ("lib", "dist", "simple_transformer_with_state", "streaming", "data", "learning_utils"):
         import importlib
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

@@ -1,0 +1,270 @@
+// tip_loss.hip — the reference's training losses and their gradient w.r.t. the prediction (SURVEY.md section 8 row f-2:
+// learning_utils.py:13-78 as combined at train_model.py:177-189), fused into one reduction pass and one gradient pass over
+// the [B*T, W] prediction rows.  HBM-bound streaming work: 2 reads + 1 write of the rows, no matrix cores.
+//
+// Row layout (W = n_pose + n_vel + 4*n_sbp columns; the reference's is 108 + 3 + 20):
+//   [0, n_pose)            6-D joint rotations    loss_q_only_2axis :62 (mean sq. error * 100) and loss_jerk :38-47
+//   [n_pose, +n_vel)       root velocity x, y, z  loss_q_only_2axis :64-78 (rows whose GT x/y are NaN are dropped; *6 / *12)
+//   [n_pose + n_vel, W)    n_sbp x (flag, r.xyz)  loss_constr_multi :13-35 (rows with any NaN GT dropped; BCE on sigmoid(flag),
+//                                                  (pred - 5*gt)^2 * 4 on the offsets, sum / n_sbp * 2.5)
+// The separate reference functions are the same kernels with the other column groups given width 0.
+#include "tip_internal.h"
+
+namespace tip {
+namespace {
+
+constexpr int kLossRows = 16;        // prediction rows per workgroup
+constexpr int kLossThreads = 256;
+constexpr int kLossPart = 8;         // doubles per workgroup: S_pose, S_xy, S_z, N_vel, S_bce, S_off, N_sbp, S_jerk
+
+struct LossShape {
+    int B, T, n_pose, n_vel, n_sbp4, terms;
+};
+
+// stats[] slots (floats, TIP_LOSS_STATS of them)
+enum { ST_TOTAL = 0, ST_Q, ST_C, ST_J, ST_KPOSE, ST_KXY, ST_KZ, ST_KBCE, ST_KOFF, ST_KJ, ST_NVEL, ST_NSBP };
+
+// which rows of this workgroup's tile count for the masked terms (learning_utils.py:19, :67)
+__device__ __forceinline__ void row_masks(const float* __restrict__ gt, long long ldg, const LossShape& sh, int row0, int nrows,
+                                          unsigned char* vmask, unsigned char* cmask) {
+    const int tid = threadIdx.x;
+    if (tid < kLossRows) {
+        bool v = false, c = false;
+        if (tid < nrows && gt) {
+            const float* g = gt + (size_t)(row0 + tid) * ldg + sh.n_pose;
+            v = sh.n_vel > 0 && !(isnan(g[0]) || isnan(g[1]));
+            c = sh.n_sbp4 > 0;
+            for (int k = 0; k < sh.n_sbp4; ++k) c = c && !isnan(g[sh.n_vel + k]);
+        }
+        vmask[tid] = v;
+        cmask[tid] = c;
+    }
+    __syncthreads();
+}
+
+// binary_cross_entropy(sigmoid(x), t) as torch evaluates it in fp32: both logs clamped at -100
+__device__ __forceinline__ float bce_sigmoid(float x, float t) {
+    const float p = 1.0f / (1.0f + expf(-x));
+    return (t - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - t * fmaxf(logf(p), -100.0f);
+}
+
+// d/dx of the above through torch's two backward formulas (binary_cross_entropy_backward, eps 1e-12; sigmoid_backward):
+// equals p - t until the sigmoid saturates in fp32, exactly 0 after.
+__device__ __forceinline__ float bce_sigmoid_grad(float x, float t) {
+    const float p = 1.0f / (1.0f + expf(-x));
+    const float pq = (1.0f - p) * p;
+    return (p - t) / fmaxf(pq, 1e-12f) * pq;
+}
+
+__global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(const float* __restrict__ pred, long long ldp,
+                                                                    const float* __restrict__ gt, long long ldg, LossShape sh,
+                                                                    double* __restrict__ part) {
+    __shared__ unsigned char vmask[kLossRows], cmask[kLossRows];
+    __shared__ double red[kLossThreads / 64][kLossPart];
+    const int tid = threadIdx.x;
+    const int M = sh.B * sh.T;
+    const int row0 = blockIdx.x * kLossRows;
+    const int nrows = min(kLossRows, M - row0);
+    const int W = sh.n_pose + sh.n_vel + sh.n_sbp4;
+    row_masks(gt, ldg, sh, row0, nrows, vmask, cmask);
+    float s_pose = 0.f, s_xy = 0.f, s_z = 0.f, s_bce = 0.f, s_off = 0.f, s_j = 0.f;
+    for (int e = tid; e < nrows * W; e += kLossThreads) {
+        const int r = e / W, col = e - r * W;
+        const size_t row = (size_t)row0 + r;
+        const float p = pred[row * ldp + col];
+        if (col < sh.n_pose) {
+            if (sh.terms & TIP_LOSS_Q) {
+                const float d = p - gt[row * ldg + col];
+                s_pose += d * d;
+            }
+            if ((sh.terms & TIP_LOSS_J) && (int)(row % sh.T) + 3 < sh.T) {
+                const float j = pred[(row + 3) * ldp + col] - 3.0f * pred[(row + 2) * ldp + col] +
+                                3.0f * pred[(row + 1) * ldp + col] - p;
+                s_j += j * j;
+            }
+        } else if (col < sh.n_pose + sh.n_vel) {
+            if ((sh.terms & TIP_LOSS_Q) && vmask[r]) {
+                const float d = gt[row * ldg + col] - p;
+                if (col - sh.n_pose < 2) s_xy += d * d; else s_z += d * d;
+            }
+        } else if ((sh.terms & TIP_LOSS_C) && cmask[r]) {
+            const float g = gt[row * ldg + col];
+            if (((col - sh.n_pose - sh.n_vel) & 3) == 0) {
+                s_bce += bce_sigmoid(p, g);
+            } else {
+                const float d = p - g * 5.0f;
+                s_off += d * d;
+            }
+        }
+    }
+    double v[kLossPart] = {s_pose, s_xy, s_z, 0.0, s_bce, s_off, 0.0, s_j};
+    if (tid < nrows) {
+        v[3] = vmask[tid];
+        v[6] = cmask[tid];
+    }
+#pragma unroll
+    for (int i = 0; i < kLossPart; ++i)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v[i] += __shfl_xor(v[i], o, 64);
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int i = 0; i < kLossPart; ++i) red[tid >> 6][i] = v[i];
+    __syncthreads();
+    if (tid < kLossPart) part[(size_t)blockIdx.x * kLossPart + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// one workgroup: fixed-order sum of the partials, then the losses and the gradient coefficients
+__global__ __launch_bounds__(kLossThreads) void loss_final_kernel(const double* __restrict__ part, int nblocks, LossShape sh,
+                                                                  float* __restrict__ stats) {
+    __shared__ double red[kLossThreads][kLossPart];
+    const int tid = threadIdx.x;
+    double v[kLossPart] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = tid; b < nblocks; b += kLossThreads)
+#pragma unroll
+        for (int i = 0; i < kLossPart; ++i) v[i] += part[(size_t)b * kLossPart + i];
+#pragma unroll
+    for (int i = 0; i < kLossPart; ++i) red[tid][i] = v[i];
+    __syncthreads();
+    for (int s = kLossThreads / 2; s >= 1; s >>= 1) {
+        if (tid < s)
+#pragma unroll
+            for (int i = 0; i < kLossPart; ++i) red[tid][i] += red[tid + s][i];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double M = (double)sh.B * sh.T;
+        const double S_pose = red[0][0], S_xy = red[0][1], S_z = red[0][2], Nv = red[0][3];
+        const double S_bce = red[0][4], S_off = red[0][5], Nc = red[0][6], S_j = red[0][7];
+        const double n_c = sh.n_sbp4 / 4;
+        const double Nj = (double)sh.B * (sh.T > 3 ? sh.T - 3 : 0) * sh.n_pose;
+        double lq = 0.0, lc = 0.0, lj = 0.0;   // an empty mean is 0/0 = NaN, as torch's .mean() of an empty tensor
+        if (sh.terms & TIP_LOSS_Q) {
+            lq = S_pose / (M * sh.n_pose) * 100.0;
+            if (sh.n_vel) lq += S_xy / (2.0 * Nv) * 6.0 + S_z / Nv * 12.0;
+        }
+        if (sh.terms & TIP_LOSS_C) lc = (S_bce / Nc + S_off / (3.0 * Nc) * 4.0) / n_c * 2.5;
+        if (sh.terms & TIP_LOSS_J) lj = S_j / Nj * 100.0;
+        stats[ST_TOTAL] = (float)((lc + lq) + lj);      // train_model.py:187-189
+        stats[ST_Q] = (float)lq;
+        stats[ST_C] = (float)lc;
+        stats[ST_J] = (float)lj;
+        stats[ST_KPOSE] = (float)(200.0 / (M * sh.n_pose));
+        stats[ST_KXY] = (float)(6.0 / Nv);               // 2 * 6 / (2 Nv)
+        stats[ST_KZ] = (float)(24.0 / Nv);
+        stats[ST_KBCE] = (float)(2.5 / n_c / Nc);
+        stats[ST_KOFF] = (float)(2.5 / n_c * 8.0 / (3.0 * Nc));
+        stats[ST_KJ] = (float)(200.0 / Nj);
+        stats[ST_NVEL] = (float)Nv;
+        stats[ST_NSBP] = (float)Nc;
+        for (int i = ST_NSBP + 1; i < TIP_LOSS_STATS; ++i) stats[i] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(kLossThreads) void loss_grad_kernel(const float* __restrict__ pred, long long ldp,
+                                                                 const float* __restrict__ gt, long long ldg, LossShape sh,
+                                                                 const float* __restrict__ stats, const float* __restrict__ gout,
+                                                                 float* __restrict__ dy, long long ldd) {
+    __shared__ unsigned char vmask[kLossRows], cmask[kLossRows];
+    const int tid = threadIdx.x;
+    const int M = sh.B * sh.T;
+    const int row0 = blockIdx.x * kLossRows;
+    const int nrows = min(kLossRows, M - row0);
+    const int W = sh.n_pose + sh.n_vel + sh.n_sbp4;
+    row_masks(gt, ldg, sh, row0, nrows, vmask, cmask);
+    const float go = gout ? gout[0] : 1.0f;
+    const float k_pose = stats[ST_KPOSE], k_xy = stats[ST_KXY], k_z = stats[ST_KZ];
+    const float k_bce = stats[ST_KBCE], k_off = stats[ST_KOFF], k_j = stats[ST_KJ];
+    for (int e = tid; e < nrows * W; e += kLossThreads) {
+        const int r = e / W, col = e - r * W;
+        const size_t row = (size_t)row0 + r;
+        const float p = pred[row * ldp + col];
+        float g = 0.f;
+        if (col < sh.n_pose) {
+            if (sh.terms & TIP_LOSS_Q) g = k_pose * (p - gt[row * ldg + col]);
+            if ((sh.terms & TIP_LOSS_J) && sh.T > 3) {
+                // jitter[u] = y[u+3] - 3 y[u+2] + 3 y[u+1] - y[u], u in [0, T-4]; y[t] appears in u = t-3 .. t
+                const int t = (int)(row % sh.T);
+                float w[7];   // y[t-3 .. t+3], zero outside the window (never used there)
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    const int tt = t + i - 3;
+                    w[i] = (tt >= 0 && tt < sh.T) ? pred[(size_t)((long long)row + i - 3) * ldp + col] : 0.f;
+                }
+                const float cf[4] = {-1.0f, 3.0f, -3.0f, 1.0f};   // d jitter[u] / d y[u + k]
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int u = t - k;
+                    if (u >= 0 && u + 3 < sh.T) {
+                        const float* y = w + 3 - k;   // y[u]
+                        acc += cf[k] * (y[3] - 3.0f * y[2] + 3.0f * y[1] - y[0]);
+                    }
+                }
+                g += k_j * acc;   // (T <= 3: no jitter sample, loss_j is NaN, k_j not finite, nothing to add)
+            }
+        } else if (col < sh.n_pose + sh.n_vel) {
+            if ((sh.terms & TIP_LOSS_Q) && vmask[r]) g = (col - sh.n_pose < 2 ? k_xy : k_z) * (p - gt[row * ldg + col]);
+        } else if ((sh.terms & TIP_LOSS_C) && cmask[r]) {
+            const float t = gt[row * ldg + col];
+            g = ((col - sh.n_pose - sh.n_vel) & 3) == 0 ? k_bce * bce_sigmoid_grad(p, t) : k_off * (p - t * 5.0f);
+        }
+        dy[row * ldd + col] = g * go;
+    }
+}
+
+int check_shape(const float* pred, long long ldp, const float* gt, long long ldg, int B, int T, int n_pose, int n_vel, int n_sbp,
+                int terms, LossShape* sh) {
+    if (!pred || B < 0 || T < 0 || n_pose < 0 || n_sbp < 0 || (n_vel != 0 && n_vel != 3)) return TIP_ERR_INVALID_ARG;
+    if (!terms || (terms & ~(TIP_LOSS_Q | TIP_LOSS_C | TIP_LOSS_J))) return TIP_ERR_INVALID_ARG;
+    const long long W = (long long)n_pose + n_vel + 4LL * n_sbp;
+    if (W <= 0 || W > (1 << 20) || ldp < W || (long long)B * T > (1LL << 31) - 1 - kLossRows) return TIP_ERR_INVALID_ARG;
+    if ((terms & (TIP_LOSS_Q | TIP_LOSS_C)) && (!gt || ldg < W)) return TIP_ERR_INVALID_ARG;
+    if ((terms & TIP_LOSS_C) && n_sbp == 0) return TIP_ERR_INVALID_ARG;
+    *sh = LossShape{B, T, n_pose, n_vel, 4 * n_sbp, terms};
+    return TIP_OK;
+}
+
+inline int loss_blocks(int B, int T) { return (int)(((long long)B * T + kLossRows - 1) / kLossRows); }
+
+}  // namespace
+}  // namespace tip
+
+using namespace tip;
+
+extern "C" {
+
+int tip_loss_ws_bytes(int B, int T, size_t* bytes) {
+    if (!bytes || B < 0 || T < 0) return TIP_ERR_INVALID_ARG;
+    *bytes = (size_t)(loss_blocks(B, T) > 0 ? loss_blocks(B, T) : 1) * kLossPart * sizeof(double);
+    return TIP_OK;
+}
+
+int tip_loss_forward(const float* pred, long long ld_pred, const float* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
+                     int n_sbp, int terms, float* stats, void* ws, size_t ws_bytes, void* stream) {
+    LossShape sh;
+    const int rc = check_shape(pred, ld_pred, gt, ld_gt, B, T, n_pose, n_vel, n_sbp, terms, &sh);
+    if (rc != TIP_OK) return rc;
+    if (!stats || !ws) return TIP_ERR_INVALID_ARG;
+    const int nb = loss_blocks(B, T);
+    if (ws_bytes < (size_t)(nb > 0 ? nb : 1) * kLossPart * sizeof(double) || reinterpret_cast<uintptr_t>(ws) % 8) return TIP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* part = static_cast<double*>(ws);
+    if (nb > 0) hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(kLossThreads), 0, st, pred, ld_pred, gt, ld_gt, sh, part);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(kLossThreads), 0, st, part, nb, sh, stats);
+    return hipGetLastError() == hipSuccess ? TIP_OK : TIP_ERR_HIP;
+}
+
+int tip_loss_backward(const float* pred, long long ld_pred, const float* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
+                      int n_sbp, int terms, const float* stats, const float* gout, float* dpred, long long ld_dpred, void* stream) {
+    LossShape sh;
+    const int rc = check_shape(pred, ld_pred, gt, ld_gt, B, T, n_pose, n_vel, n_sbp, terms, &sh);
+    if (rc != TIP_OK) return rc;
+    if (!stats || !dpred || ld_dpred < sh.n_pose + sh.n_vel + sh.n_sbp4) return TIP_ERR_INVALID_ARG;
+    const int nb = loss_blocks(B, T);
+    if (nb == 0) return TIP_OK;
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(nb), dim3(kLossThreads), 0, static_cast<hipStream_t>(stream), pred, ld_pred, gt, ld_gt,
+                       sh, stats, gout, dpred, ld_dpred);
+    return hipGetLastError() == hipSuccess ? TIP_OK : TIP_ERR_HIP;
+}
+
+}  // extern "C"

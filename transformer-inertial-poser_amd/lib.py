@@ -16,6 +16,7 @@ TIP_FWD_KEEP_MASK = 0x2
 TIP_PLAN_AUTO, TIP_PLAN_GENERAL, TIP_PLAN_FUSED, TIP_PLAN_LATENCY, TIP_PLAN_FUSED2 = 0, 1, 2, 3, 4
 TIP_SAVED_QKV, TIP_SAVED_ATT, TIP_SAVED_X1, TIP_SAVED_HID, TIP_SAVED_XOUT, TIP_SAVED_HALL = range(6)
 TIP_OPT_PLAN, TIP_OPT_PROFILE, TIP_OPT_RNN_CLUSTER = 1, 2, 3
+TIP_LOSS_Q, TIP_LOSS_C, TIP_LOSS_J, TIP_LOSS_STATS = 1, 2, 4, 16
 
 # every symbol include/tip_hip.h declares (tests check the .so exports exactly these)
 EXPORTS = (
@@ -25,6 +26,7 @@ EXPORTS = (
     "tip_spin_timeouts", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
     "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward",
     "tip_combine_frames", "tip_combine_scratch_bytes", "tip_combine_sequence", "tip_gather_windows",
+    "tip_loss_ws_bytes", "tip_loss_forward", "tip_loss_backward",
 )
 
 
@@ -111,6 +113,10 @@ def load() -> ctypes.CDLL:
     lib.tip_combine_scratch_bytes.argtypes = [i32, i32, ctypes.POINTER(sz)]
     lib.tip_combine_sequence.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
     lib.tip_gather_windows.argtypes = [vp, vp, vp, ctypes.c_longlong, vp, i32, i32, vp, vp, vp, vp]
+    ll = ctypes.c_longlong
+    lib.tip_loss_ws_bytes.argtypes = [i32, i32, ctypes.POINTER(sz)]
+    lib.tip_loss_forward.argtypes = [vp, ll, vp, ll, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]
+    lib.tip_loss_backward.argtypes = [vp, ll, vp, ll, i32, i32, i32, i32, i32, i32, vp, vp, vp, ll, vp]
     for name in EXPORTS:
         if name not in ("tip_destroy", "tip_strerror", "tip_last_hip_error"):
             getattr(lib, name).restype = i32
