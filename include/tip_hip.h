@@ -194,7 +194,7 @@ int tip_gather_windows(const float* imu_c, const float* sum_c, const float* s_c,
  *   tip_loss_forward   stats[0..3] = total, loss_q, loss_c, loss_j (0 for a term not selected); the rest of stats
  *                      (TIP_LOSS_STATS floats, device) carries the normalisers the backward needs.
  *   tip_loss_backward  dpred[B*T, W] = gout * d total / d pred (gout: DEVICE scalar, NULL = 1); every column is written.
- * Deterministic: fixed-order fp64 reduction of per-workgroup partial sums. */
+ * Deterministic: fixed-order fp64 reduction of per-workgroup partial sums.  W <= 256 (else TIP_ERR_UNSUPPORTED_CONFIG). */
 #define TIP_LOSS_Q 1 /* loss_q_only_2axis (learning_utils.py:50-78) */
 #define TIP_LOSS_C 2 /* loss_constr_multi (learning_utils.py:13-35) */
 #define TIP_LOSS_J 4 /* loss_jerk         (learning_utils.py:38-47) */

@@ -15,6 +15,8 @@ namespace {
 
 constexpr int kLossRows = 16;        // prediction rows per workgroup
 constexpr int kLossThreads = 256;
+constexpr int kLossMaxW = 256;       // widest row the tiles are sized for (the reference's is 131)
+constexpr int kLossDepth = 10;       // loads a thread keeps in flight while staging a tile (19 x 131 / 256 = 9.7)
 constexpr int kLossPart = 8;         // doubles per workgroup: S_pose, S_xy, S_z, N_vel, S_bce, S_off, N_sbp, S_jerk
 
 struct LossShape {
@@ -24,22 +26,69 @@ struct LossShape {
 // stats[] slots (floats, TIP_LOSS_STATS of them)
 enum { ST_TOTAL = 0, ST_Q, ST_C, ST_J, ST_KPOSE, ST_KXY, ST_KZ, ST_KBCE, ST_KOFF, ST_KJ, ST_NVEL, ST_NSBP };
 
-// which rows of this workgroup's tile count for the masked terms (learning_utils.py:19, :67)
-__device__ __forceinline__ void row_masks(const float* __restrict__ gt, long long ldg, const LossShape& sh, int row0, int nrows,
+// Stage rows [first, first + n) of a [M, W] array (row stride ld) into an LDS tile [n][W], kLossDepth loads per thread in
+// flight before the first LDS store (this is latency-bound streaming: the bytes in flight set the rate); with ld == W the
+// span is contiguous.
+__device__ __forceinline__ void stage_rows(float* __restrict__ tile, const float* __restrict__ src, long long ld, long long first,
+                                           int n, int W) {
+    const int tid = threadIdx.x;
+    const int total = n * W;
+    const float* s = src + first * ld;
+    // loads are unconditional (index clamped) so that nothing but the address arithmetic sits between them
+    auto batch = [&](auto&& index) {
+        for (int e0 = tid; e0 < total; e0 += kLossThreads * kLossDepth) {
+            float v[kLossDepth];
+#pragma unroll
+            for (int u = 0; u < kLossDepth; ++u) v[u] = s[index(min(e0 + u * kLossThreads, total - 1))];
+#pragma unroll
+            for (int u = 0; u < kLossDepth; ++u)
+                if (e0 + u * kLossThreads < total) tile[e0 + u * kLossThreads] = v[u];
+        }
+    };
+    if (ld == W) {
+        batch([](int e) { return (long long)e; });
+    } else {
+        batch([&](int e) {
+            const int r = e / W;
+            return r * ld + (e - r * W);
+        });
+    }
+}
+
+// which rows of this workgroup's tile count for the masked terms (learning_utils.py:19, :67); gt tile already in LDS
+__device__ __forceinline__ void row_masks(const float* gtile, bool have_gt, const LossShape& sh, int nrows, int W,
                                           unsigned char* vmask, unsigned char* cmask) {
     const int tid = threadIdx.x;
     if (tid < kLossRows) {
-        bool v = false, c = false;
-        if (tid < nrows && gt) {
-            const float* g = gt + (size_t)(row0 + tid) * ldg + sh.n_pose;
-            v = sh.n_vel > 0 && !(isnan(g[0]) || isnan(g[1]));
-            c = sh.n_sbp4 > 0;
-            for (int k = 0; k < sh.n_sbp4; ++k) c = c && !isnan(g[sh.n_vel + k]);
-        }
-        vmask[tid] = v;
-        cmask[tid] = c;
+        vmask[tid] = tid < nrows && have_gt && sh.n_vel > 0;
+        cmask[tid] = tid < nrows && have_gt && sh.n_sbp4 > 0;
     }
     __syncthreads();
+    if (have_gt) {
+        // a NaN in the GT x / y of the root velocity, or in any constraint column, clears its row's flag (racing writers all
+        // store 0)
+        const int nxy = sh.n_vel ? 2 : 0, G = nxy + sh.n_sbp4;
+        for (int e = tid; e < nrows * G; e += kLossThreads) {
+            const int r = e / G, k = e - r * G;
+            if (isnan(gtile[r * W + sh.n_pose + (k < nxy ? k : k - nxy + sh.n_vel)])) {
+                if (k < nxy) vmask[r] = 0; else cmask[r] = 0;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// thread -> (column, rows [rbeg, rend)) of the tile: one column per thread, 256 / W blocks of consecutive rows side by side
+// (consecutive rows let the third difference slide through registers: one LDS read per row instead of four)
+struct ColWalk {
+    int col, rbeg, rend;
+};
+__device__ __forceinline__ ColWalk col_walk(int W, int nrows) {
+    const int tid = threadIdx.x;
+    const int rg = kLossThreads / W;     // >= 1 (W <= kLossMaxW)
+    const int chunk = (kLossRows + rg - 1) / rg;
+    const int b = tid / W;
+    return ColWalk{tid - b * W, min(b * chunk, nrows), b < rg ? min(b * chunk + chunk, nrows) : 0};
 }
 
 // binary_cross_entropy(sigmoid(x), t) as torch evaluates it in fp32: both logs clamped at -100
@@ -59,6 +108,7 @@ __device__ __forceinline__ float bce_sigmoid_grad(float x, float t) {
 __global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(const float* __restrict__ pred, long long ldp,
                                                                     const float* __restrict__ gt, long long ldg, LossShape sh,
                                                                     double* __restrict__ part) {
+    extern __shared__ float lds[];
     __shared__ unsigned char vmask[kLossRows], cmask[kLossRows];
     __shared__ double red[kLossThreads / 64][kLossPart];
     const int tid = threadIdx.x;
@@ -66,36 +116,57 @@ __global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(const float*
     const int row0 = blockIdx.x * kLossRows;
     const int nrows = min(kLossRows, M - row0);
     const int W = sh.n_pose + sh.n_vel + sh.n_sbp4;
-    row_masks(gt, ldg, sh, row0, nrows, vmask, cmask);
+    float* pt = lds;                                // prediction rows row0 .. row0 + nrows + 2 (3 more for the third difference)
+    float* gtl = lds + (kLossRows + 3) * W;         // GT rows row0 .. row0 + nrows - 1
+    stage_rows(pt, pred, ldp, row0, min(kLossRows + 3, M - row0), W);
+    if (gt) stage_rows(gtl, gt, ldg, row0, nrows, W);
+    __syncthreads();
+    row_masks(gtl, gt != nullptr, sh, nrows, W, vmask, cmask);
     float s_pose = 0.f, s_xy = 0.f, s_z = 0.f, s_bce = 0.f, s_off = 0.f, s_j = 0.f;
-    for (int e = tid; e < nrows * W; e += kLossThreads) {
-        const int r = e / W, col = e - r * W;
-        const size_t row = (size_t)row0 + r;
-        const float p = pred[row * ldp + col];
-        if (col < sh.n_pose) {
-            if (sh.terms & TIP_LOSS_Q) {
-                const float d = p - gt[row * ldg + col];
-                s_pose += d * d;
+    const ColWalk cw = col_walk(W, nrows);
+    if (cw.rbeg < cw.rend) {
+        const int col = cw.col;
+        const int kind = col < sh.n_pose ? 0 : col < sh.n_pose + sh.n_vel ? (col - sh.n_pose < 2 ? 1 : 2)
+                                         : (((col - sh.n_pose - sh.n_vel) & 3) == 0 ? 3 : 4);
+        if (kind == 0) {
+            const bool doq = sh.terms & TIP_LOSS_Q, doj = sh.terms & TIP_LOSS_J;
+            int t = (row0 + cw.rbeg) % sh.T;             // frame index inside the window
+            const int left = M - row0 - cw.rbeg;          // rows from rbeg to the end of the array (all staged up to +3)
+            float ya = pt[cw.rbeg * W + col];
+            float yb = left > 1 ? pt[(cw.rbeg + 1) * W + col] : 0.f;
+            float yc = left > 2 ? pt[(cw.rbeg + 2) * W + col] : 0.f;
+            for (int r = cw.rbeg; r < cw.rend; ++r) {
+                const float yn = row0 + r + 3 < M ? pt[(r + 3) * W + col] : 0.f;
+                if (doq) {
+                    const float d = ya - gtl[r * W + col];
+                    s_pose += d * d;
+                }
+                if (doj && t + 3 < sh.T) {
+                    const float j = yn - 3.0f * yc + 3.0f * yb - ya;
+                    s_j += j * j;
+                }
+                ya = yb, yb = yc, yc = yn;
+                if (++t == sh.T) t = 0;
             }
-            if ((sh.terms & TIP_LOSS_J) && (int)(row % sh.T) + 3 < sh.T) {
-                const float j = pred[(row + 3) * ldp + col] - 3.0f * pred[(row + 2) * ldp + col] +
-                                3.0f * pred[(row + 1) * ldp + col] - p;
-                s_j += j * j;
-            }
-        } else if (col < sh.n_pose + sh.n_vel) {
-            if ((sh.terms & TIP_LOSS_Q) && vmask[r]) {
-                const float d = gt[row * ldg + col] - p;
-                if (col - sh.n_pose < 2) s_xy += d * d; else s_z += d * d;
-            }
-        } else if ((sh.terms & TIP_LOSS_C) && cmask[r]) {
-            const float g = gt[row * ldg + col];
-            if (((col - sh.n_pose - sh.n_vel) & 3) == 0) {
-                s_bce += bce_sigmoid(p, g);
-            } else {
-                const float d = p - g * 5.0f;
-                s_off += d * d;
+        } else if (kind != 3) {
+            for (int r = cw.rbeg; r < cw.rend; ++r) {
+                const float p = pt[r * W + col];
+                if (kind <= 2) {
+                    if ((sh.terms & TIP_LOSS_Q) && vmask[r]) {
+                        const float d = gtl[r * W + col] - p;
+                        if (kind == 1) s_xy += d * d; else s_z += d * d;
+                    }
+                } else if ((sh.terms & TIP_LOSS_C) && cmask[r]) {
+                    const float d = p - gtl[r * W + col] * 5.0f;
+                    s_off += d * d;
+                }
             }
         }
+    }
+    // the flag columns (exp + two logs each) one per thread rather than a column's 16 rows in sequence
+    if ((sh.terms & TIP_LOSS_C) && tid < nrows * (sh.n_sbp4 >> 2)) {
+        const int nf = sh.n_sbp4 >> 2, r = tid / nf, col = sh.n_pose + sh.n_vel + 4 * (tid - r * nf);
+        if (cmask[r]) s_bce = bce_sigmoid(pt[r * W + col], gtl[r * W + col]);
     }
     double v[kLossPart] = {s_pose, s_xy, s_z, 0.0, s_bce, s_off, 0.0, s_j};
     if (tid < nrows) {
@@ -164,51 +235,83 @@ __global__ __launch_bounds__(kLossThreads) void loss_grad_kernel(const float* __
                                                                  const float* __restrict__ gt, long long ldg, LossShape sh,
                                                                  const float* __restrict__ stats, const float* __restrict__ gout,
                                                                  float* __restrict__ dy, long long ldd) {
+    extern __shared__ float lds[];
     __shared__ unsigned char vmask[kLossRows], cmask[kLossRows];
-    const int tid = threadIdx.x;
     const int M = sh.B * sh.T;
     const int row0 = blockIdx.x * kLossRows;
     const int nrows = min(kLossRows, M - row0);
     const int W = sh.n_pose + sh.n_vel + sh.n_sbp4;
-    row_masks(gt, ldg, sh, row0, nrows, vmask, cmask);
+    // prediction rows row0 - 3 .. row0 + nrows + 2: y[t] enters the third differences u = t-3 .. t, which reach y[t+3]
+    const int lead = min(3, row0);
+    float* pt = lds + (3 - lead) * W;               // pt[(r + 3) * W + c] = prediction row row0 + r
+    float* gtl = lds + (kLossRows + 6) * W;
+    stage_rows(pt, pred, ldp, row0 - lead, min(lead + kLossRows + 3, M - row0 + lead), W);
+    if (gt) stage_rows(gtl, gt, ldg, row0, nrows, W);
+    __syncthreads();
+    row_masks(gtl, gt != nullptr, sh, nrows, W, vmask, cmask);
     const float go = gout ? gout[0] : 1.0f;
     const float k_pose = stats[ST_KPOSE], k_xy = stats[ST_KXY], k_z = stats[ST_KZ];
     const float k_bce = stats[ST_KBCE], k_off = stats[ST_KOFF], k_j = stats[ST_KJ];
-    for (int e = tid; e < nrows * W; e += kLossThreads) {
-        const int r = e / W, col = e - r * W;
-        const size_t row = (size_t)row0 + r;
-        const float p = pred[row * ldp + col];
+    const int tid = threadIdx.x;
+    // the flag columns (exp, divide) one per thread rather than a column's 16 rows in sequence
+    if (tid < nrows * (sh.n_sbp4 >> 2)) {
+        const int nf = sh.n_sbp4 >> 2, r = tid / nf, col = sh.n_pose + sh.n_vel + 4 * (tid - r * nf);
         float g = 0.f;
-        if (col < sh.n_pose) {
-            if (sh.terms & TIP_LOSS_Q) g = k_pose * (p - gt[row * ldg + col]);
-            if ((sh.terms & TIP_LOSS_J) && sh.T > 3) {
-                // jitter[u] = y[u+3] - 3 y[u+2] + 3 y[u+1] - y[u], u in [0, T-4]; y[t] appears in u = t-3 .. t
-                const int t = (int)(row % sh.T);
-                float w[7];   // y[t-3 .. t+3], zero outside the window (never used there)
+        if ((sh.terms & TIP_LOSS_C) && cmask[r]) g = k_bce * bce_sigmoid_grad(lds[(3 + r) * W + col], gtl[r * W + col]);
+        dy[(size_t)(row0 + r) * ldd + col] = g * go;
+    }
+    const ColWalk cw = col_walk(W, nrows);
+    if (cw.rbeg >= cw.rend) return;
+    const int col = cw.col;
+    const int kind = col < sh.n_pose ? 0 : col < sh.n_pose + sh.n_vel ? (col - sh.n_pose < 2 ? 1 : 2)
+                                     : (((col - sh.n_pose - sh.n_vel) & 3) == 0 ? 3 : 4);
+    if (kind == 3) return;
+    const float* y0 = lds + 3 * W + col;   // y0[r * W] = prediction (row0 + r, col), r >= -3
+    if (kind == 0) {
+        // jitter[u] = y[u+3] - 3 y[u+2] + 3 y[u+1] - y[u] for frames u <= T-4 of a window (jv = 0 elsewhere);
+        // d loss_j / d y[q] = k_j * (-jv[q] + 3 jv[q-1] - 3 jv[q-2] + jv[q-3]).  jv and y slide through registers.
+        const bool doq = sh.terms & TIP_LOSS_Q, doj = (sh.terms & TIP_LOSS_J) && sh.T > 3;
+        float jm[3] = {0.f, 0.f, 0.f};     // jv[q-3], jv[q-2], jv[q-1]
+        if (doj) {
 #pragma unroll
-                for (int i = 0; i < 7; ++i) {
-                    const int tt = t + i - 3;
-                    w[i] = (tt >= 0 && tt < sh.T) ? pred[(size_t)((long long)row + i - 3) * ldp + col] : 0.f;
-                }
-                const float cf[4] = {-1.0f, 3.0f, -3.0f, 1.0f};   // d jitter[u] / d y[u + k]
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int u = t - k;
-                    if (u >= 0 && u + 3 < sh.T) {
-                        const float* y = w + 3 - k;   // y[u]
-                        acc += cf[k] * (y[3] - 3.0f * y[2] + 3.0f * y[1] - y[0]);
-                    }
-                }
-                g += k_j * acc;   // (T <= 3: no jitter sample, loss_j is NaN, k_j not finite, nothing to add)
+            for (int k = 3; k >= 1; --k) {
+                const int rr = cw.rbeg - k, qq = row0 + rr;
+                if (qq >= 0 && qq % sh.T + 3 < sh.T)
+                    jm[3 - k] = y0[(rr + 3) * W] - 3.0f * y0[(rr + 2) * W] + 3.0f * y0[(rr + 1) * W] - y0[rr * W];
             }
-        } else if (col < sh.n_pose + sh.n_vel) {
-            if ((sh.terms & TIP_LOSS_Q) && vmask[r]) g = (col - sh.n_pose < 2 ? k_xy : k_z) * (p - gt[row * ldg + col]);
-        } else if ((sh.terms & TIP_LOSS_C) && cmask[r]) {
-            const float t = gt[row * ldg + col];
-            g = ((col - sh.n_pose - sh.n_vel) & 3) == 0 ? k_bce * bce_sigmoid_grad(p, t) : k_off * (p - t * 5.0f);
         }
-        dy[row * ldd + col] = g * go;
+        int t = (row0 + cw.rbeg) % sh.T;
+        const int left = M - row0 - cw.rbeg;
+        float ya = y0[cw.rbeg * W];
+        float yb = left > 1 ? y0[(cw.rbeg + 1) * W] : 0.f;
+        float yc = left > 2 ? y0[(cw.rbeg + 2) * W] : 0.f;
+        for (int r = cw.rbeg; r < cw.rend; ++r) {
+            const float yn = row0 + r + 3 < M ? y0[(r + 3) * W] : 0.f;
+            float g = doq ? k_pose * (ya - gtl[r * W + col]) : 0.f;
+            if (doj) {
+                const float jn = t + 3 < sh.T ? yn - 3.0f * yc + 3.0f * yb - ya : 0.f;
+                float acc = -jn;
+                acc += 3.0f * jm[2];
+                acc += -3.0f * jm[1];
+                acc += jm[0];
+                g += k_j * acc;
+                jm[0] = jm[1], jm[1] = jm[2], jm[2] = jn;
+            }
+            dy[(size_t)(row0 + r) * ldd + col] = g * go;
+            ya = yb, yb = yc, yc = yn;
+            if (++t == sh.T) t = 0;
+        }
+        return;
+    }
+    for (int r = cw.rbeg; r < cw.rend; ++r) {
+        const float p = y0[r * W];
+        float g = 0.f;
+        if (kind <= 2) {
+            if ((sh.terms & TIP_LOSS_Q) && vmask[r]) g = (kind == 1 ? k_xy : k_z) * (p - gtl[r * W + col]);
+        } else if ((sh.terms & TIP_LOSS_C) && cmask[r]) {
+            g = k_off * (p - gtl[r * W + col] * 5.0f);
+        }
+        dy[(size_t)(row0 + r) * ldd + col] = g * go;
     }
 }
 
@@ -217,7 +320,8 @@ int check_shape(const float* pred, long long ldp, const float* gt, long long ldg
     if (!pred || B < 0 || T < 0 || n_pose < 0 || n_sbp < 0 || (n_vel != 0 && n_vel != 3)) return TIP_ERR_INVALID_ARG;
     if (!terms || (terms & ~(TIP_LOSS_Q | TIP_LOSS_C | TIP_LOSS_J))) return TIP_ERR_INVALID_ARG;
     const long long W = (long long)n_pose + n_vel + 4LL * n_sbp;
-    if (W <= 0 || W > (1 << 20) || ldp < W || (long long)B * T > (1LL << 31) - 1 - kLossRows) return TIP_ERR_INVALID_ARG;
+    if (W > kLossMaxW) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (W <= 0 || ldp < W || (long long)B * T > (1LL << 31) - 1 - kLossRows) return TIP_ERR_INVALID_ARG;
     if ((terms & (TIP_LOSS_Q | TIP_LOSS_C)) && (!gt || ldg < W)) return TIP_ERR_INVALID_ARG;
     if ((terms & TIP_LOSS_C) && n_sbp == 0) return TIP_ERR_INVALID_ARG;
     *sh = LossShape{B, T, n_pose, n_vel, 4 * n_sbp, terms};
@@ -249,7 +353,9 @@ int tip_loss_forward(const float* pred, long long ld_pred, const float* gt, long
     if (ws_bytes < (size_t)(nb > 0 ? nb : 1) * kLossPart * sizeof(double) || reinterpret_cast<uintptr_t>(ws) % 8) return TIP_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* part = static_cast<double*>(ws);
-    if (nb > 0) hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(kLossThreads), 0, st, pred, ld_pred, gt, ld_gt, sh, part);
+    const int W = sh.n_pose + sh.n_vel + sh.n_sbp4;
+    if (nb > 0)
+        hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(kLossThreads), (size_t)(2 * kLossRows + 3) * W * sizeof(float), st, pred, ld_pred, gt, ld_gt, sh, part);
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(kLossThreads), 0, st, part, nb, sh, stats);
     return hipGetLastError() == hipSuccess ? TIP_OK : TIP_ERR_HIP;
 }
@@ -262,7 +368,8 @@ int tip_loss_backward(const float* pred, long long ld_pred, const float* gt, lon
     if (!stats || !dpred || ld_dpred < sh.n_pose + sh.n_vel + sh.n_sbp4) return TIP_ERR_INVALID_ARG;
     const int nb = loss_blocks(B, T);
     if (nb == 0) return TIP_OK;
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(nb), dim3(kLossThreads), 0, static_cast<hipStream_t>(stream), pred, ld_pred, gt, ld_gt,
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(nb), dim3(kLossThreads),
+                       (size_t)(2 * kLossRows + 6) * (sh.n_pose + sh.n_vel + sh.n_sbp4) * sizeof(float), static_cast<hipStream_t>(stream), pred, ld_pred, gt, ld_gt,
                        sh, stats, gout, dpred, ld_dpred);
     return hipGetLastError() == hipSuccess ? TIP_OK : TIP_ERR_HIP;
 }
