@@ -474,10 +474,178 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dwgemm: dW[n][k] = sum_m dY[m][n] * X[m][k] straight from the two row-major activations, no LDS staging, no transposes.
+// The reduction index m is the ROW of both operands.  v_mfma_f32_16x16x4 takes from lane (l15, lg) the A element
+// (i = l15, kk = lg) and the B element (j = l15, kk = lg); which feature plays "i" (or "j") in which MFMA is ours to choose.
+// Lane (l15, lg) loads ONE float4 per operand from row m0 + lg: features 4*l15 .. 4*l15+3.  Component c of that float4 is
+// the operand of the "virtual tile" c, made of the features {4*i + c}: 4 interleaved 16-feature tiles per 64-feature block,
+// so a pair of 16-byte loads (4 rows x 256 contiguous bytes per wave instruction) feeds 16 MFMAs.  The accumulator of virtual
+// tiles (ca, cb) holds dW[64*ia + 4*(4*lg + e) + ca][4*l15 + cb]: the four cb tiles of a lane are 4 consecutive k -> 16-byte stores.
+// Per wave: 128 out-features x 64 in-features (3 loads, 32 MFMAs per 4 rows; 128 accumulator registers).  The 4 waves of a
+// workgroup share ONE output tile and take every 4th group of rows (in-workgroup split of the reduction, summed through LDS
+// in a fixed order), so the split-K partial volume that goes through HBM is a quarter of one-wave-per-tile's.
+// ---------------------------------------------------------------------------------------------------------------------
+struct DwArgs {
+    const float* dY; long long ldy;
+    const float* X; long long ldx;
+    float* out; long long zstride;     // partial z at out + z*zstride, [n_out][k_in]
+    int n_out, k_in, M, klen, splits;  // klen: rows per split, multiple of 16
+};
+
+constexpr int kDwDepth = 4;            // row groups in flight per wave (register stages)
+template <int NB> constexpr int dw_lds_bytes() { return 2 * 32 * NB * 64 * 4 * (int)sizeof(float); }   // two accumulator images
+
+// NB = 64-feature blocks of X per wave: 1 -> 128 x 64 per wave, 2 waves per SIMD; 2 -> 128 x 128 per wave (256 accumulator
+// registers, one wave per SIMD, 1.5x fewer operand bytes per MFMA)
+template <int NB>
+__global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void dwgemm_kernel(DwArgs g) {
+    extern __shared__ float dw_red[];
+    constexpr int NT = 32 * NB;        // 16x16 accumulator tiles per wave
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles_b = g.k_in / (64 * NB);
+    const int ta = blockIdx.x / tiles_b, tb = blockIdx.x - ta * tiles_b;
+    const int z = blockIdx.y;
+    const int kbeg = z * g.klen;
+    const int rows = min(g.klen, g.M - kbeg);
+    const int ns = ((rows >> 2) - wave + 3) >> 2;          // this wave's row groups: wave, wave + 4, ...
+    const float* pa = g.dY + (long long)(kbeg + 4 * wave + lg) * g.ldy + ta * 128 + 4 * l15;
+    const float* pb = g.X + (long long)(kbeg + 4 * wave + lg) * g.ldx + tb * (64 * NB) + 4 * l15;
+    const long long sa = 16 * g.ldy, sb = 16 * g.ldx;      // one own step = 16 rows further
+    f32x4 acc[2][4][NB][4];
+#pragma unroll
+    for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+        for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[ia][ca][ib][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 Av[kDwDepth][2], Bv[kDwDepth][NB];
+    auto fetch = [&](int d, int st) {
+#pragma unroll
+        for (int ia = 0; ia < 2; ++ia) Av[d][ia] = *reinterpret_cast<const float4*>(pa + st * sa + 64 * ia);
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) Bv[d][ib] = *reinterpret_cast<const float4*>(pb + st * sb + 64 * ib);
+    };
+    if (ns > 0) {
+#pragma unroll
+        for (int d = 0; d < kDwDepth; ++d) fetch(d, d < ns ? d : ns - 1);
+    }
+    for (int s0 = 0; s0 < ns; s0 += kDwDepth) {
+#pragma unroll
+        for (int d = 0; d < kDwDepth; ++d) {
+            if (s0 + d < ns) {
+                float av[2][4], bv[NB][4];
+#pragma unroll
+                for (int ia = 0; ia < 2; ++ia) av[ia][0] = Av[d][ia].x, av[ia][1] = Av[d][ia].y, av[ia][2] = Av[d][ia].z, av[ia][3] = Av[d][ia].w;
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib) bv[ib][0] = Bv[d][ib].x, bv[ib][1] = Bv[d][ib].y, bv[ib][2] = Bv[d][ib].z, bv[ib][3] = Bv[d][ib].w;
+                if (s0 + d + kDwDepth < ns) fetch(d, s0 + d + kDwDepth);
+#pragma unroll
+                for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+                    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+                        for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                            for (int cb = 0; cb < 4; ++cb)
+                                acc[ia][ca][ib][cb] =
+                                    __builtin_amdgcn_mfma_f32_16x16x4f32(av[ia][ca], bv[ib][cb], acc[ia][ca][ib][cb], 0, 0, 0);
+            }
+        }
+    }
+    // (w0 + w2) + (w1 + w3) through two accumulator images [tile][lane][4]
+    auto tile_of = [&](int t) -> f32x4& { return acc[t / (16 * NB)][(t / (4 * NB)) & 3][(t >> 2) % NB][t & 3]; };
+    auto put = [&](float* img) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4*>(img + (t * 64 + lane) * 4) = tile_of(t);
+    };
+    auto add = [&](const float* img) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tile_of(t) += *reinterpret_cast<const f32x4*>(img + (t * 64 + lane) * 4);
+    };
+    float* img0 = dw_red;
+    float* img1 = dw_red + NT * 64 * 4;
+    if (wave == 2) put(img0);
+    if (wave == 3) put(img1);
+    __syncthreads();
+    if (wave == 0) add(img0);
+    if (wave == 1) add(img1);
+    __syncthreads();
+    if (wave == 1) put(img0);
+    __syncthreads();
+    if (wave != 0) return;
+    add(img0);
+    float* o = g.out + (long long)z * g.zstride + (long long)(ta * 128) * g.k_in + tb * (64 * NB) + 4 * l15;
+#pragma unroll
+    for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+        for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = 64 * ia + 4 * (4 * lg + e) + ca;
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib)
+                    *reinterpret_cast<float4*>(o + (long long)n * g.k_in + 64 * ib) =
+                        make_float4(acc[ia][ca][ib][0][e], acc[ia][ca][ib][1][e], acc[ia][ca][ib][2][e], acc[ia][ca][ib][3][e]);
+            }
+}
+
+static bool dwgemm_ok(long long ldy, long long ldx, int n_rows_pad, int n_store, int K, int M) {
+    static int off = -1;   // TIP_DW_KERNEL=tgemm: the LDS-tiled 32x32x2 kernel for every shape (measurement)
+    if (off < 0) off = getenv("TIP_DW_KERNEL") && !strcmp(getenv("TIP_DW_KERNEL"), "tgemm");
+    return !off && n_store == n_rows_pad && n_store % 128 == 0 && K % 64 == 0 && M % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0;
+}
+
 // dW[N x K] = dY^T X with the reduction over the M rows split across the grid; deterministic two-stage sum.
 // A(i = n, k = m) = dY[m*ldy + n], B(j = k', k = m) = X[m*ldx + k'].
 static hipError_t grad_weight(const float* dY, long long ldy, int n_rows_pad, int n_store, const float* X, long long ldx, int K,
                               int M, float* part, size_t part_floats, float* out, int num_cus, hipStream_t s) {
+    if (dwgemm_ok(ldy, ldx, n_rows_pad, n_store, K, M)) {
+        static int nbsel = -1;   // TIP_DW_NB: 1 / 2 = X blocks per wave for every shape (measurement)
+        if (nbsel < 0) nbsel = getenv("TIP_DW_NB") ? atoi(getenv("TIP_DW_NB")) : 0;
+        // 128 x 128 per wave once such tiles alone fill the chip (big layers: operand traffic is what binds there, +7 %);
+        // 128 x 64 with two waves per SIMD otherwise (more, smaller workgroups; better at the paper model's shapes)
+        const bool big = K % 128 == 0 && (n_store / 128) * (K / 128) >= num_cus;
+        const int NB = nbsel ? ((nbsel == 2 && K % 128 == 0) ? 2 : 1) : (big ? 2 : 1);
+        const int tiles = (n_store / 128) * (K / (64 * NB));
+        const int slots = num_cus * (NB == 1 ? 2 : 1);       // workgroups resident at once
+        const long long per = (long long)n_store * K;       // multiple of 4
+        // split count: fewest rounds of resident workgroups times (rows per split + a fixed per-workgroup cost: pipeline fill,
+        // LDS reduction, 32-KB store ~ the time of 96 rows), plus the second-stage reduce when the reduction is split
+        int best = 1;
+        double best_cost = 1e30;
+        const int smax = (int)std::min<long long>(std::max(1, M / 128), (long long)part_floats / per);
+        for (int sp = 1; sp <= std::max(1, smax); ++sp) {
+            const int klen_s = round_up((M + sp - 1) / sp, 16);
+            const int sp_eff = (M + klen_s - 1) / klen_s;
+            const double rounds = (double)((tiles * sp_eff + slots - 1) / slots);
+            const double cost = rounds * (klen_s + 96.0) + (sp_eff > 1 ? 24.0 + 0.02 * sp_eff * (double)per / (128.0 * 64 * NB) : 0.0);
+            if (cost < best_cost - 1e-9) best_cost = cost, best = sp_eff;
+        }
+        int splits = best;
+        static int force = -1;   // TIP_DW_SPLITS: fixed split count (measurement)
+        if (force < 0) force = getenv("TIP_DW_SPLITS") ? atoi(getenv("TIP_DW_SPLITS")) : 0;
+        if (force > 0) splits = std::min(force, std::max(1, smax));
+        const int klen = round_up((M + splits - 1) / splits, 16);
+        splits = (M + klen - 1) / klen;
+        DwArgs a{dY, ldy, X, ldx, splits == 1 ? out : part, per, n_store, K, M, klen, splits};
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwgemm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<1>());
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwgemm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<2>());
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        if (NB == 1) hipLaunchKernelGGL(dwgemm_kernel<1>, dim3(tiles, splits), dim3(256), dw_lds_bytes<1>(), s, a);
+        else hipLaunchKernelGGL(dwgemm_kernel<2>, dim3(tiles, splits), dim3(256), dw_lds_bytes<2>(), s, a);
+        if (splits > 1)
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, s, part, per, splits, out, per);
+        return hipGetLastError();
+    }
     TG g = tg_base(dY, ldy, X, ldx, part, K, n_rows_pad, K, M);
     g.c_rows = n_store;
     const int tiles = ((K + 127) / 128) * ((n_rows_pad + 127) / 128);
