@@ -493,20 +493,19 @@ struct DwArgs {
     int n_out, k_in, M, klen, splits;  // klen: rows per split, multiple of 16
 };
 
-constexpr int kDwDepth = 4;            // row groups in flight per wave (register stages)
+constexpr int kDwDepth = 6;            // row groups in flight per wave (register stages)
 template <int NB> constexpr int dw_lds_bytes() { return 2 * 32 * NB * 64 * 4 * (int)sizeof(float); }   // two accumulator images
 
 // NB = 64-feature blocks of X per wave: 1 -> 128 x 64 per wave, 2 waves per SIMD; 2 -> 128 x 128 per wave (256 accumulator
 // registers, one wave per SIMD, 1.5x fewer operand bytes per MFMA)
 template <int NB>
-__global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void dwgemm_kernel(DwArgs g) {
+__device__ __forceinline__ void dwgemm_body(const DwArgs& g, int tile, int z) {
     extern __shared__ float dw_red[];
     constexpr int NT = 32 * NB;        // 16x16 accumulator tiles per wave
     const int lane = threadIdx.x & 63, l15 = lane & 15, lg = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tiles_b = g.k_in / (64 * NB);
-    const int ta = blockIdx.x / tiles_b, tb = blockIdx.x - ta * tiles_b;
-    const int z = blockIdx.y;
+    const int ta = tile / tiles_b, tb = tile - ta * tiles_b;
     const int kbeg = z * g.klen;
     const int rows = min(g.klen, g.M - kbeg);
     const int ns = ((rows >> 2) - wave + 3) >> 2;          // this wave's row groups: wave, wave + 4, ...
@@ -593,10 +592,164 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void dwgemm_kernel(DwArgs g) 
             }
 }
 
+// Workgroup -> (tile, split).  Hardware hands consecutive workgroup ids to the 8 XCDs round-robin; id L becomes virtual id
+// (L % 8) * ceil(total / 8) + L / 8, so each XCD works through one CONTIGUOUS run of (split, tile) pairs: neighbours in that
+// run share their dY / X row slabs, which then sit in that XCD's L2 instead of being fetched into all eight.
+__device__ __forceinline__ bool dw_work(int tiles, int splits, int* tile, int* z) {
+    const int total = tiles * splits, per_xcd = (total + 7) >> 3;
+    const int v = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || v >= total) return false;
+    *z = v / tiles;
+    *tile = v - *z * tiles;
+    return true;
+}
+static unsigned dw_grid(int tiles, int splits) { return (unsigned)((tiles * splits + 7) / 8 * 8); }
+
+template <int NB>
+__global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void dwgemm_kernel(DwArgs g) {
+    int tile, z;
+    if (!dw_work((g.n_out >> 7) * (g.k_in / (64 * NB)), g.splits, &tile, &z)) return;
+    dwgemm_body<NB>(g, tile, z);
+}
+
+// several weight gradients that reduce over the same rows in ONE launch (the four of an encoder layer): their tiles fill the
+// chip together, so each workgroup walks 4x more rows than it would in four launches of their own — the pipeline fill, the
+// LDS reduction and the tail are paid once, and the split-K partial volume per gradient shrinks accordingly
+constexpr int kDwBatchMax = 4;
+struct DwBatch {
+    DwArgs p[kDwBatchMax];
+    int tile0[kDwBatchMax + 1];
+    int n;
+};
+__global__ __launch_bounds__(256, 2) void dwgemm_batch_kernel(DwBatch b) {
+    int tile, z;
+    if (!dw_work(b.tile0[b.n], b.p[0].splits, &tile, &z)) return;
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < kDwBatchMax; ++i)
+        if (i < b.n && tile >= b.tile0[i]) q = i;
+    // select by value (uniform branch) rather than by pointer into the kernel argument: keeps the descriptor in SGPRs
+    if (q == 0) dwgemm_body<1>(b.p[0], tile - b.tile0[0], z);
+    else if (q == 1) dwgemm_body<1>(b.p[1], tile - b.tile0[1], z);
+    else if (q == 2) dwgemm_body<1>(b.p[2], tile - b.tile0[2], z);
+    else dwgemm_body<1>(b.p[3], tile - b.tile0[3], z);
+}
+
+struct ReduceBatch {
+    const float* part[kDwBatchMax];
+    float* out[kDwBatchMax];
+    long long per[kDwBatchMax];
+    int splits;
+};
+// out_q[i] = sum_z part_q[z*per_q + i], z in order; blockIdx.y = q
+__global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(ReduceBatch r) {
+    const int q = blockIdx.y;
+    const long long i4 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long long per = r.per[q];
+    if (i4 >= per) return;
+    const float* p = r.part[q] + i4;
+    float4 a = *reinterpret_cast<const float4*>(p), b = make_float4(0.f, 0.f, 0.f, 0.f);
+    int z = 1;
+    for (; z + 1 < r.splits; z += 2) {   // two chains only to keep loads in flight; fixed order
+        const float4 u = *reinterpret_cast<const float4*>(p + z * per);
+        const float4 v = *reinterpret_cast<const float4*>(p + (z + 1) * per);
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    if (z < r.splits) {
+        const float4 u = *reinterpret_cast<const float4*>(p + z * per);
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+    }
+    float* o = r.out[q] + i4;
+    const float4 t = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    if ((reinterpret_cast<uintptr_t>(o) & 15) == 0) {
+        *reinterpret_cast<float4*>(o) = t;
+    } else {
+        o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+    }
+}
+
 static bool dwgemm_ok(long long ldy, long long ldx, int n_rows_pad, int n_store, int K, int M) {
     static int off = -1;   // TIP_DW_KERNEL=tgemm: the LDS-tiled 32x32x2 kernel for every shape (measurement)
     if (off < 0) off = getenv("TIP_DW_KERNEL") && !strcmp(getenv("TIP_DW_KERNEL"), "tgemm");
     return !off && n_store == n_rows_pad && n_store % 128 == 0 && K % 64 == 0 && M % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0;
+}
+
+// split count of a dwgemm launch: fewest rounds of resident workgroups times (rows per split + a fixed per-workgroup cost —
+// pipeline fill, LDS reduction, 32-KB store ~ the time of 96 rows), plus the second-stage reduce when the reduction is split
+static int dw_choose_splits(int tiles, int slots, int M, long long per_total, size_t part_floats, int tile_floats) {
+    static int force = -1;   // TIP_DW_SPLITS: fixed split count (measurement)
+    if (force < 0) force = getenv("TIP_DW_SPLITS") ? atoi(getenv("TIP_DW_SPLITS")) : 0;
+    const int smax = std::max(1, (int)std::min<long long>(std::max(1, M / 128), (long long)part_floats / per_total));
+    if (force > 0) return std::min(force, smax);
+    int best = 1;
+    double best_cost = 1e30;
+    for (int sp = 1; sp <= smax; ++sp) {
+        const int klen_s = round_up((M + sp - 1) / sp, 16);
+        const int sp_eff = (M + klen_s - 1) / klen_s;
+        const double rounds = (double)((tiles * sp_eff + slots - 1) / slots);
+        const double cost = rounds * (klen_s + 96.0) + (sp_eff > 1 ? 24.0 + 0.02 * sp_eff * (double)per_total / tile_floats : 0.0);
+        if (cost < best_cost - 1e-9) best_cost = cost, best = sp_eff;
+    }
+    return best;
+}
+
+static hipError_t dw_set_attrs() {
+    static bool done = false;
+    if (done) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwgemm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<1>());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwgemm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<2>());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwgemm_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<1>());
+    done = e == hipSuccess;
+    return e;
+}
+
+struct DwProb {
+    const float* dY; long long ldy; int n_out;
+    const float* X; long long ldx; int K;
+    float* out;
+};
+
+// n <= 4 weight gradients over the same M rows in one dwgemm launch + one reduce launch.  False when a shape is not
+// eligible (caller then issues them one by one).
+static bool grad_weight_batch(const DwProb* pr, int n, int M, float* part, size_t part_floats, int num_cus, hipStream_t s, hipError_t* err) {
+    static int on = -1;   // TIP_DW_GROUP=0: one launch per gradient (measurement)
+    if (on < 0) on = !(getenv("TIP_DW_GROUP") && atoi(getenv("TIP_DW_GROUP")) == 0);
+    if (!on || n < 1 || n > kDwBatchMax) return false;
+    long long per_total = 0;
+    DwBatch b;
+    b.n = n;
+    b.tile0[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!dwgemm_ok(pr[i].ldy, pr[i].ldx, pr[i].n_out, pr[i].n_out, pr[i].K, M)) return false;
+        b.tile0[i + 1] = b.tile0[i] + (pr[i].n_out / 128) * (pr[i].K / 64);
+        per_total += (long long)pr[i].n_out * pr[i].K;
+    }
+    for (int i = n; i < kDwBatchMax; ++i) b.tile0[i + 1] = b.tile0[n], b.p[i] = DwArgs{};
+    const int tiles = b.tile0[n];
+    int splits = dw_choose_splits(tiles, 2 * num_cus, M, per_total, part_floats, 128 * 64);
+    const int klen = round_up((M + splits - 1) / splits, 16);
+    splits = (M + klen - 1) / klen;
+    ReduceBatch r;
+    r.splits = splits;
+    long long off = 0, per_max = 0;
+    for (int i = 0; i < kDwBatchMax; ++i) r.part[i] = nullptr, r.out[i] = nullptr, r.per[i] = 0;
+    for (int i = 0; i < n; ++i) {
+        const long long per = (long long)pr[i].n_out * pr[i].K;
+        b.p[i] = DwArgs{pr[i].dY, pr[i].ldy, pr[i].X, pr[i].ldx, splits == 1 ? pr[i].out : part + off, per, pr[i].n_out, pr[i].K, M, klen, splits};
+        r.part[i] = part + off; r.out[i] = pr[i].out; r.per[i] = per;
+        off += (long long)splits * per;
+        per_max = std::max(per_max, per);
+    }
+    *err = dw_set_attrs();
+    if (*err != hipSuccess) return true;
+    hipLaunchKernelGGL(dwgemm_batch_kernel, dim3(dw_grid(tiles, splits)), dim3(256), dw_lds_bytes<1>(), s, b);
+    if (splits > 1)
+        hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3((unsigned)((per_max / 4 + 255) / 256), n), dim3(256), 0, s, r);
+    *err = hipGetLastError();
+    return true;
 }
 
 // dW[N x K] = dY^T X with the reduction over the M rows split across the grid; deterministic two-stage sum.
@@ -613,35 +766,14 @@ static hipError_t grad_weight(const float* dY, long long ldy, int n_rows_pad, in
         const int tiles = (n_store / 128) * (K / (64 * NB));
         const int slots = num_cus * (NB == 1 ? 2 : 1);       // workgroups resident at once
         const long long per = (long long)n_store * K;       // multiple of 4
-        // split count: fewest rounds of resident workgroups times (rows per split + a fixed per-workgroup cost: pipeline fill,
-        // LDS reduction, 32-KB store ~ the time of 96 rows), plus the second-stage reduce when the reduction is split
-        int best = 1;
-        double best_cost = 1e30;
-        const int smax = (int)std::min<long long>(std::max(1, M / 128), (long long)part_floats / per);
-        for (int sp = 1; sp <= std::max(1, smax); ++sp) {
-            const int klen_s = round_up((M + sp - 1) / sp, 16);
-            const int sp_eff = (M + klen_s - 1) / klen_s;
-            const double rounds = (double)((tiles * sp_eff + slots - 1) / slots);
-            const double cost = rounds * (klen_s + 96.0) + (sp_eff > 1 ? 24.0 + 0.02 * sp_eff * (double)per / (128.0 * 64 * NB) : 0.0);
-            if (cost < best_cost - 1e-9) best_cost = cost, best = sp_eff;
-        }
-        int splits = best;
-        static int force = -1;   // TIP_DW_SPLITS: fixed split count (measurement)
-        if (force < 0) force = getenv("TIP_DW_SPLITS") ? atoi(getenv("TIP_DW_SPLITS")) : 0;
-        if (force > 0) splits = std::min(force, std::max(1, smax));
+        int splits = dw_choose_splits(tiles, slots, M, per, part_floats, 128 * 64 * NB);
         const int klen = round_up((M + splits - 1) / splits, 16);
         splits = (M + klen - 1) / klen;
         DwArgs a{dY, ldy, X, ldx, splits == 1 ? out : part, per, n_store, K, M, klen, splits};
-        static bool attr = false;
-        if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwgemm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<1>());
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwgemm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<2>());
-            if (e != hipSuccess) return e;
-            attr = true;
-        }
-        if (NB == 1) hipLaunchKernelGGL(dwgemm_kernel<1>, dim3(tiles, splits), dim3(256), dw_lds_bytes<1>(), s, a);
-        else hipLaunchKernelGGL(dwgemm_kernel<2>, dim3(tiles, splits), dim3(256), dw_lds_bytes<2>(), s, a);
+        hipError_t e = dw_set_attrs();
+        if (e != hipSuccess) return e;
+        if (NB == 1) hipLaunchKernelGGL(dwgemm_kernel<1>, dim3(dw_grid(tiles, splits)), dim3(256), dw_lds_bytes<1>(), s, a);
+        else hipLaunchKernelGGL(dwgemm_kernel<2>, dim3(dw_grid(tiles, splits)), dim3(256), dw_lds_bytes<2>(), s, a);
         if (splits > 1)
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((per / 4 + 255) / 256)), dim3(256), 0, s, part, per, splits, out, per);
         return hipGetLastError();
@@ -1000,6 +1132,7 @@ struct TrainSaved {
 };
 struct TrainScratch {
     size_t dyp, dh, delta, hprev, ga, gb, gc, gbig, datt, part, colpart, dwin_p, dbin_p;
+    size_t gbig2;          // fused backward: dqkv of the attention half (dff2 / dpre of the FFN half stay alive for the layer's one dW launch)
     size_t bwimg, lnwin;   // fused backward: transposed-weight fragment image, per-window LayerNorm partials [B][3D]
     size_t part_floats;
     size_t total;
@@ -1078,6 +1211,7 @@ static TrainScratch scratch_layout(const Dims& d, int B, int T) {
     S.gc = take(off, M * d.D);
     S.gbig = take(off, M * (size_t)(3 * d.D > d.F ? 3 * d.D : d.F));
     S.datt = take(off, M * d.D);
+    S.gbig2 = take(off, M * 3 * d.D);
     size_t wmax = (size_t)d.F * d.D;
     if ((size_t)3 * d.D * d.D > wmax) wmax = (size_t)3 * d.D * d.D;
     if ((size_t)d.R * d.R > wmax) wmax = (size_t)d.R * d.R;
@@ -1423,11 +1557,21 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
                        d.R / 4, (long long)M * d.R / 4);
     TT(hipGetLastError(), "bwd_shift");
     TT(colsum(X + S.delta, d.R, M, d.R, colpart, grads + goff[rbase + PR_BIH], grads + goff[rbase + PR_BHH], s), "bwd_db_rnn");
-    TT(grad_weight(X + S.delta, d.R, d.R, d.R, X + S.hprev, d.R, d.R, M, part, S.part_floats, grads + goff[rbase + PR_WHH], ncu, s),
-       "bwd_dW_hh");
     const float* enc = W + L.layers[d.L - 1].xo;
-    TT(grad_weight(X + S.delta, d.R, d.R, d.R, enc, d.D, d.D, M, part, S.part_floats, grads + goff[rbase + PR_WIH], ncu, s),
-       "bwd_dW_ih");
+    {
+        // dW_hh = delta^T h_prev and dW_ih = delta^T x share delta and the row range: one launch
+        const DwProb pr[2] = {{X + S.delta, d.R, d.R, X + S.hprev, d.R, d.R, grads + goff[rbase + PR_WHH]},
+                              {X + S.delta, d.R, d.R, enc, d.D, d.D, grads + goff[rbase + PR_WIH]}};
+        hipError_t be = hipSuccess;
+        // (the big-tile variant of the single launch serves the large configurations better than a two-problem batch)
+        const bool big = (d.R / 128) * (d.D / 128) >= ncu;
+        if (!big && grad_weight_batch(pr, 2, M, part, S.part_floats, ncu, s, &be)) {
+            TT(be, "bwd_dW_rnn");
+        } else {
+            TT(grad_weight(pr[0].dY, d.R, d.R, d.R, pr[0].X, d.R, d.R, M, part, S.part_floats, pr[0].out, ncu, s), "bwd_dW_hh");
+            TT(grad_weight(pr[1].dY, d.R, d.R, d.R, pr[1].X, d.D, d.D, M, part, S.part_floats, pr[1].out, ncu, s), "bwd_dW_ih");
+        }
+    }
     float* gx = X + S.ga;     // gradient w.r.t. the current layer's output
     float* galt = X + S.gb;
     {
@@ -1456,10 +1600,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
                                grads + goff[pb + PL_N2_W], nullptr, 2 * d.D, grads + goff[pb + PL_L2_B], 3 * d.D,
                                grads + goff[pb + PL_L1_B]);
             TT(hipGetLastError(), "bwd_ln2_params");
-            TT(grad_weight(X + S.gc, d.D, d.D, d.D, W + t.hid, d.F, d.F, M, part, S.part_floats, grads + goff[pb + PL_L2_W], ncu, s),
-               "bwd_dW2");
-            TT(grad_weight(X + S.gbig, d.F, d.F, d.F, W + t.x1, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_L1_W], ncu, s),
-               "bwd_dW1");
+            // dW2 / dW1 wait for the attention half: the layer's four weight gradients go out in one launch below
         } else {
         // LN2: gx -> dz2 (galt), dff2 = dz2 * keep3 (gc)
         {
@@ -1503,7 +1644,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             aa.wimg = X + S.bwimg; aa.wbytes = (int)(fused_bwd_image_floats(d) * 4); aa.layer = l;
             aa.dx1 = gx; aa.z1 = W + t.z1; aa.st1 = W + t.st1; aa.g1 = lp[PL_N1_W];
             aa.qkv = W + t.qkv; aa.att = W + t.att; aa.ast = W + t.ast; aa.q_scale = 1.0f / sqrtf((float)d.dh);
-            aa.dz1 = galt; aa.datt_o = X + S.gc; aa.dqkv = X + S.gbig; aa.dx_in = gx; aa.lnpart = X + S.lnwin;
+            aa.dz1 = galt; aa.datt_o = X + S.datt; aa.dqkv = X + S.gbig2; aa.dx_in = gx; aa.lnpart = X + S.lnwin;
             const Drop dr = make_drop(p_drop, seed, 0);
             aa.seed = dr.seed; aa.site0 = (unsigned)(l * 4 + 0); aa.site1 = (unsigned)(l * 4 + 1); aa.thresh = dr.thresh; aa.scale = dr.scale;
             TT(launch_attn_bwd(d, aa, B, T, ncu, s), "bwd_attn_fused");
@@ -1512,10 +1653,18 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
                                grads + goff[pb + PL_N1_W], nullptr, 2 * d.D, grads + goff[pb + PL_OUT_B], 3 * d.D,
                                grads + goff[pb + PL_QKV_B]);
             TT(hipGetLastError(), "bwd_ln1_params");
-            TT(grad_weight(X + S.gc, d.D, d.D, d.D, W + t.att, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_OUT_W], ncu, s),
-               "bwd_dWo");
-            TT(grad_weight(X + S.gbig, 3 * d.D, 3 * d.D, 3 * d.D, x_in, d.D, d.D, M, part, S.part_floats, grads + goff[pb + PL_QKV_W], ncu, s),
-               "bwd_dWqkv");
+            const DwProb pr[4] = {{X + S.gc, d.D, d.D, W + t.hid, d.F, d.F, grads + goff[pb + PL_L2_W]},
+                                  {X + S.gbig, d.F, d.F, W + t.x1, d.D, d.D, grads + goff[pb + PL_L1_W]},
+                                  {X + S.datt, d.D, d.D, W + t.att, d.D, d.D, grads + goff[pb + PL_OUT_W]},
+                                  {X + S.gbig2, 3 * d.D, 3 * d.D, x_in, d.D, d.D, grads + goff[pb + PL_QKV_W]}};
+            hipError_t be = hipSuccess;
+            if (grad_weight_batch(pr, 4, M, part, S.part_floats, ncu, s, &be)) {
+                TT(be, "bwd_dW_layer");
+            } else {
+                for (int i = 0; i < 4; ++i)
+                    TT(grad_weight(pr[i].dY, pr[i].ldy, pr[i].n_out, pr[i].n_out, pr[i].X, pr[i].ldx, pr[i].K, M, part, S.part_floats,
+                                   pr[i].out, ncu, s), "bwd_dW");
+            }
         } else {
         // LN1: gx -> dz1 (galt), datt_o = dz1 * keep1 (gc)
         {
