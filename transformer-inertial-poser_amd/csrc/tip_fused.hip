@@ -697,6 +697,14 @@ void fused_bwd_pack_ops(const Dims& d, const float* const* t, size_t base, std::
     }
 }
 
+// measurement only (TIP_BWD_TRACE=1): s_memtime stamps of workgroup 0 / thread 0 at the phase boundaries of the two fused
+// backward kernels ([0..7] ffn_bwd, [8..15] attn_bwd), read back with tip_debug_read_bwd_trace() (tools/bwd_trace.py)
+__device__ unsigned long long g_bwd_trace[16];
+__device__ __forceinline__ void bwd_stamp(int on, int slot) {
+    if (on && blockIdx.x == 0 && threadIdx.x == 0) g_bwd_trace[slot] = __builtin_amdgcn_s_memtime();
+}
+
+
 __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int B, int T) {
     using namespace fz;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -714,6 +722,7 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
 
     for (int win = blockIdx.x; win < B; win += gridDim.x) {
         const size_t grow0 = (size_t)win * T;
+        bwd_stamp(a.trace, 0);
         WRing<2> g_f;
         ring_prefetch<2>(g_f, rsrc, voff, lbase + (int)(fb::W2T * 4) + (wave * 2) * 16 * 1024, 16 * 1024);
         // ---- LayerNorm2 backward, one wave per row (rows w, w+8, ...) ------------------------------------------------------
@@ -766,6 +775,7 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
             a.lnpart[(size_t)win * (3 * D + F) + i] = s;
         }
         __syncthreads();
+        bwd_stamp(a.trace, 1);
         // ---- hidden chunks ------------------------------------------------------------------------------------------------
         f32x4 acc_x[RB][2];
         zero_acc<2>(acc_x);
@@ -802,7 +812,9 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
                         *reinterpret_cast<f32x4*>(Hc + row * LDX + (wave * 2 + n) * 16 + lg * 4) = v;
                     }
             }
+            if (f == 0) bwd_stamp(a.trace, 2);     // first chunk: d(hidden) product done
             __syncthreads();
+            if (f == 0) bwd_stamp(a.trace, 3);
             rows_to_hbm(Hc, LDX, 256, a.dpre + grow0 * F + f * 256, F, T, tid);
             if (tid < 256) {   // this window's share of linear1's bias gradient: column sums of the chunk
                 float s0 = 0.f, s1 = 0.f;
@@ -816,11 +828,14 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
             {
                 const int w1off = lbase + (int)(fb::W1T * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                 const int nxt = f < 3 ? lbase + (int)(fb::W2T * 4) + ((f + 1) * 16 + wave * 2) * 16 * 1024 : w1off;
+                if (f == 0) bwd_stamp(a.trace, 4);     // first chunk: rows + bias partials out
                 gemm_phase<2, 16>(acc_x, Hc + l15 * LDX + lg * 4, LDX, rsrc, voff, w1off, 64 * 1024, g_f, nxt,
                                   f < 3 ? 16 * 1024 : 64 * 1024);
+                if (f == 0) bwd_stamp(a.trace, 5);     // first chunk: dx1 partial product done
             }
             __syncthreads();
         }
+        bwd_stamp(a.trace, 6);
         // ---- dx1 = dz2 + dpre W1 -------------------------------------------------------------------------------------------
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
@@ -832,6 +847,7 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
         }
         __syncthreads();
         rows_to_hbm(G, LDX, D, a.dx1 + grow0 * D, D, T, tid);
+        bwd_stamp(a.trace, 7);
         __syncthreads();
     }
 }
@@ -848,6 +864,9 @@ hipError_t launch_ffn_bwd(const Dims& d, const FfnBwdArgs& a, int B, int T, int 
     }
     FfnBwdArgs aa = a;
     aa.hid_bytes = (int)((long long)B * T * d.F * 4);
+    static int trace = -1;
+    if (trace < 0) trace = getenv("TIP_BWD_TRACE") ? 1 : 0;
+    aa.trace = trace;
     hipLaunchKernelGGL(ffn_bwd_kernel, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
     return hipGetLastError();
 }
@@ -881,6 +900,7 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
 
     for (int win = blockIdx.x; win < B; win += gridDim.x) {
         const size_t grow0 = (size_t)win * T;
+        bwd_stamp(a.trace, 8);
         WRing<1> g_o;   // Wo^T fragments of head c*8 + wave
         ring_prefetch<1>(g_o, rsrc, voff, lbase + (int)(fb::WOT * 4) + wave * 16 * 1024, 0);
         // ---- LayerNorm1 backward --------------------------------------------------------------------------------------------
@@ -934,9 +954,11 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
         }
         __syncthreads();
 
+        bwd_stamp(a.trace, 9);
         // ---- per head (no workgroup barrier in here: a wave only touches Mb (read), its own scratch and its own HBM columns) ---
 #pragma unroll 1
         for (int c = 0; c < 2; ++c) {
+            bwd_stamp(a.trace, 10 + c);
             const int head = c * 8 + wave;
             const unsigned long long bh = (unsigned long long)win * H + head;
             const float* qb = a.qkv + grow0 * (3 * D) + head * 16;
@@ -1081,48 +1103,49 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
             }
             __builtin_amdgcn_wave_barrier();   // the scratch tiles are rewritten by the next head
         }
+        bwd_stamp(a.trace, 12);
         __syncthreads();   // every head's dq | dk | dv rows of this window are in HBM/L2 (and visible to the other waves)
-        // ---- dx_in = dz1 + dqkv [48 x 768] * Wqkv^T: the A fragments come straight from the rows just written --------------------
+        bwd_stamp(a.trace, 13);
+        // ---- dx_in = dz1 + dqkv [48 x 768] * Wqkv^T -------------------------------------------------------------------------------
+        // The dq | dk | dv rows just written (L2) are staged through LDS in 6 chunks of 128 columns, double-buffered in the
+        // per-wave scratch region (free by now): coalesced 512-byte row segments once per workgroup instead of every wave
+        // gathering 64-byte pieces of all 48 rows per k-block (that form ran this product at 55 % of its MFMA time).
         {
+            constexpr int KC = 128, LDA = 132, NCH = 3 * D / KC;
+            static_assert(2 * RP * LDA <= 8 * 3 * RP * 20, "chunk buffers fit the scratch region");
             f32x4 acc_i[RB][2];
             zero_acc<2>(acc_i);
-            const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(a.dqkv, 0, a.dqkv_bytes, 0x00020000);
-            int aoff[RB];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                const int row = r * 16 + l15;
-                aoff[r] = row < T ? (int)(((grow0 + row) * (3 * D) + lg * 4) * 4) : -1;
-            }
+            float* Ab = Sc;
             const int wq = lbase + (int)(fb::WQT * 4) + (wave * 2) * 48 * 1024;
-            constexpr int KBT = 3 * D / 16;   // 48 k-blocks
-            f32x4 a0[RB], a1[RB], w0[2], w1[2];
-            auto lda = [&](f32x4 (&x)[RB], int kb) {
+            WRing<2> g_q;
+            ring_prefetch<2>(g_q, rsrc, voff, wq, 48 * 1024);
+            f32x4 st[3];   // this thread's 3 float4 of a chunk: element i = tid + 512 j -> row i / 32, columns 4 (i % 32) ..
+            auto fetch = [&](int ch) {
 #pragma unroll
-                for (int r = 0; r < RB; ++r)
-                    x[r] = aoff[r] >= 0 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ars, aoff[r], kb * 64, 0)) : zero4;
+                for (int j = 0; j < 3; ++j) {
+                    const int i = tid + THREADS * j, row = i >> 5, c4 = i & 31;
+                    st[j] = zero4;
+                    if (row < T) st[j] = *reinterpret_cast<const f32x4*>(a.dqkv + (grow0 + row) * (3 * D) + ch * KC + c4 * 4);
+                }
             };
-            auto ldw = [&](f32x4 (&x)[2], int kb) {
+            auto stash = [&](float* buf) {
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    x[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, wq + (n * 48 + kb) * 1024, 0));
+                for (int j = 0; j < 3; ++j) {
+                    const int i = tid + THREADS * j, row = i >> 5, c4 = i & 31;
+                    *reinterpret_cast<f32x4*>(buf + row * LDA + c4 * 4) = st[j];
+                }
             };
-            lda(a0, 0); ldw(w0, 0);
+            fetch(0);
+            stash(Ab);
+            __syncthreads();
 #pragma unroll 1
-            for (int kb = 0; kb < KBT; kb += 2) {
-                lda(a1, kb + 1); ldw(w1, kb + 1);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int r = 0; r < RB; ++r)
-#pragma unroll
-                        for (int n = 0; n < 2; ++n) acc_i[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r][e], w0[n][e], acc_i[r][n], 0, 0, 0);
-                if (kb + 2 < KBT) { lda(a0, kb + 2); ldw(w0, kb + 2); }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int r = 0; r < RB; ++r)
-#pragma unroll
-                        for (int n = 0; n < 2; ++n) acc_i[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[r][e], w1[n][e], acc_i[r][n], 0, 0, 0);
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (ch + 1 < NCH) fetch(ch + 1);           // in flight during this chunk's MFMAs
+                const int nx = ch + 1 < NCH ? wq + (ch + 1) * (KC / 16) * 1024 : wq;
+                gemm_phase<2, KC / 16>(acc_i, Ab + (ch & 1) * RP * LDA + l15 * LDA + lg * 4, LDA, rsrc, voff, wq + ch * (KC / 16) * 1024,
+                                       48 * 1024, g_q, nx, 48 * 1024);
+                if (ch + 1 < NCH) stash(Ab + ((ch + 1) & 1) * RP * LDA);
+                __syncthreads();
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
@@ -1136,6 +1159,7 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
                     }
             }
         }
+        bwd_stamp(a.trace, 14);
         __syncthreads();
     }
 }
@@ -1154,8 +1178,16 @@ hipError_t launch_attn_bwd(const Dims& d, const AttnBwdArgs& a, int B, int T, in
     }
     AttnBwdArgs aa = a;
     aa.dqkv_bytes = (int)((long long)B * T * 3 * d.D * 4);
+    static int trace = -1;
+    if (trace < 0) trace = getenv("TIP_BWD_TRACE") ? 1 : 0;
+    aa.trace = trace;
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
     return hipGetLastError();
 }
 
 }  // namespace tip
+
+extern "C" int tip_debug_read_bwd_trace(unsigned long long* out, int n) {
+    if (!out || n < 0 || n > 16) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tip::g_bwd_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
+}

@@ -208,6 +208,7 @@ struct FfnBwdArgs {
     const float* g2;        // LayerNorm2 weight
     const float* hid;       // [M,F] saved hidden (after ReLU and dropout)
     int hid_bytes;          // (set by the launcher)
+    int trace;              // (set by the launcher) TIP_BWD_TRACE=1: phase stamps of workgroup 0 (measurement)
     float gate_scale;       // 1 / (1 - p)
     float* dff2;            // out [M,D]: gradient into linear2's output (dropout mask applied)
     float* dpre;            // out [M,F]: gradient into linear1's pre-activation
@@ -234,6 +235,7 @@ struct AttnBwdArgs {
     float* datt_o;          // out [M,D]: gradient into out_proj's output (dropout mask applied)
     float* dqkv;            // out [M,3D]
     int dqkv_bytes;         // (set by the launcher)
+    int trace;              // (set by the launcher) TIP_BWD_TRACE=1: phase stamps of workgroup 0 (measurement)
     float* dx_in;           // out [M,D]: gradient w.r.t. the layer input (may alias dx1)
     float* lnpart;          // out [B][6*D]: per-window (dgamma1 | dbeta1 | d bias of out_proj | d bias of in_proj)
     unsigned long long seed;
