@@ -802,7 +802,8 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
                 // the tail of this phase primes the ring with the dx1 phase's first fragments
                 gemm_phase<2, 16, false, 2>(acc, Mb + l15 * LDX + lg * 4, LDX, rsrc, voff, w2off, 16 * 1024, g_f, w1off, 64 * 1024);
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < 2; ++n) {
+                    f32x4 bs = {0.f, 0.f, 0.f, 0.f};   // this window's share of linear1's bias gradient: column sums of the chunk
 #pragma unroll
                     for (int r = 0; r < RB; ++r) {
                         const int row = r * 16 + l15;
@@ -810,21 +811,27 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = (row < T && gate[r][n][e] > 0.f) ? acc[r][n][e] * a.gate_scale : 0.f;
                         *reinterpret_cast<f32x4*>(Hc + row * LDX + (wave * 2 + n) * 16 + lg * 4) = v;
+                        bs += v;
                     }
+                    // the lane holds 4 consecutive hidden channels of rows l15, 16 + l15, 32 + l15: the sum over rows is a butterfly
+                    // over the 16 lanes that share lg, straight from the registers
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = bs[e];
+                        x += __shfl_xor(x, 1, 64);
+                        x += __shfl_xor(x, 2, 64);
+                        x += __shfl_xor(x, 4, 64);
+                        x += __shfl_xor(x, 8, 64);
+                        bs[e] = x;
+                    }
+                    if (l15 == 0)
+                        *reinterpret_cast<f32x4*>(a.lnpart + (size_t)win * (3 * D + F) + 3 * D + f * 256 + (wave * 2 + n) * 16 + lg * 4) = bs;
+                }
             }
             if (f == 0) bwd_stamp(a.trace, 2);     // first chunk: d(hidden) product done
             __syncthreads();
             if (f == 0) bwd_stamp(a.trace, 3);
             rows_to_hbm(Hc, LDX, 256, a.dpre + grow0 * F + f * 256, F, T, tid);
-            if (tid < 256) {   // this window's share of linear1's bias gradient: column sums of the chunk
-                float s0 = 0.f, s1 = 0.f;
-                for (int r = 0; r + 1 < T; r += 2) {
-                    s0 += Hc[r * LDX + tid];
-                    s1 += Hc[(r + 1) * LDX + tid];
-                }
-                if (T & 1) s0 += Hc[(T - 1) * LDX + tid];
-                a.lnpart[(size_t)win * (3 * D + F) + 3 * D + f * 256 + tid] = s0 + s1;
-            }
             {
                 const int w1off = lbase + (int)(fb::W1T * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                 const int nxt = f < 3 ? lbase + (int)(fb::W2T * 4) + ((f + 1) * 16 + wave * 2) * 16 * 1024 : w1off;
