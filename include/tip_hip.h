@@ -143,9 +143,11 @@ int tip_stream_consume(void* state, const float* y_last, int n_streams, int call
  *             applied by the caller to x_imu (no gradient flows to the inputs)
  *   p_drop, seed  dropout of the four nn.TransformerEncoderLayer sites (attention probabilities, after out_proj, after
  *             ReLU, after linear2; torch default p = 0.1, simple_transformer_with_state.py:26-29).  A mask is never
- *             stored: element idx of site s is kept iff  hi32(splitmix64_mix(seed + GOLDEN*(idx + (s<<40) + 1))) >=
- *             floor(p * 2^32), GOLDEN = 0x9E3779B97F4A7C15, mix = the splitmix64 finaliser; site s = 4*layer + {0 attention
- *             P [B,H,T,T], 1 out_proj [M,D], 2 ffn hidden [M,F], 3 linear2 [M,D]}, idx = row-major element index.
+ *             stored: element idx of site s is kept iff  lowbias32((idx mod 2^32) * 0x9E3779B1 + key(seed, s)) >=
+ *             floor(p * 2^32), where key = hi32(splitmix64_mix(seed + 0x9E3779B97F4A7C15 * (s + 1))) (once per site) and
+ *             lowbias32(z): z ^= z>>16; z *= 0x7FEB352D; z ^= z>>15; z *= 0x846CA68B; z ^= z>>16 (all mod 2^32);
+ *             site s = 4*layer + {0 attention P [B,H,T,T], 1 out_proj [M,D], 2 ffn hidden [M,F], 3 linear2 [M,D]},
+ *             idx = row-major element index.
  *             Kept values are scaled by 1/(1-p).  p_drop = 0 switches it off.
  *   saved     activation stash written by the forward and read by the backward (tip_train_bytes: saved_bytes)
  *   scratch   backward workspace (scratch_bytes); grads = one flat buffer, tensors in tip_tensor_info() order.

@@ -22,20 +22,31 @@ M1 = np.uint64(0xBF58476D1CE4E5B9)
 M2 = np.uint64(0x94D049BB133111EB)
 
 
-def drop_scale(seed: int, site: int, n: int, p: float) -> np.ndarray:
-    """keep/(1-p) factor of the n elements of dropout site `site` (include/tip_hip.h, tip_train_forward)."""
-    if p <= 0.0:
-        return np.ones(n, dtype=np.float32)
+def drop_key(seed: int, site: int) -> np.uint32:
+    """32-bit key of one dropout site: hi32 of the splitmix64 mix of seed + GOLDEN * (site + 1)."""
     with np.errstate(over="ignore"):
-        idx = np.arange(n, dtype=np.uint64)
-        z = np.uint64(seed) + GOLDEN * (idx + (np.uint64(site) << np.uint64(40)) + np.uint64(1))
+        z = np.uint64(seed) + GOLDEN * (np.uint64(site) + np.uint64(1))
         z = (z ^ (z >> np.uint64(30))) * M1
         z = (z ^ (z >> np.uint64(27))) * M2
         z = z ^ (z >> np.uint64(31))
-    hi = (z >> np.uint64(32)).astype(np.uint64)
+    return np.uint32(z >> np.uint64(32))
+
+
+def drop_scale(seed: int, site: int, n: int, p: float) -> np.ndarray:
+    """keep/(1-p) factor of the n elements of dropout site `site` (include/tip_hip.h, tip_train_forward):
+    keep(idx) = lowbias32((idx mod 2^32) * 0x9E3779B1 + key(seed, site)) >= floor(p * 2^32)."""
+    if p <= 0.0:
+        return np.ones(n, dtype=np.float32)
+    with np.errstate(over="ignore"):
+        z = np.arange(n, dtype=np.uint64).astype(np.uint32) * np.uint32(0x9E3779B1) + drop_key(seed, site)
+        z ^= z >> np.uint32(16)
+        z *= np.uint32(0x7FEB352D)
+        z ^= z >> np.uint32(15)
+        z *= np.uint32(0x846CA68B)
+        z ^= z >> np.uint32(16)
     thresh = min(int(p * 4294967296.0), 4294967295)
     thresh = max(thresh, 1)
-    keep = hi >= np.uint64(thresh)
+    keep = z.astype(np.uint64) >= np.uint64(thresh)
     return (keep.astype(np.float32) * np.float32(1.0 / (1.0 - np.float32(p)))).astype(np.float32)
 
 

@@ -164,6 +164,7 @@ __device__ __forceinline__ void attention_head_regs(const f32x4_att (&qt)[3], co
 #pragma unroll
     for (int r = 0; r < RB; ++r) rsum[r] = 1.0f / rsum[r];
     if (TRAIN) {
+        const unsigned dkey = tip_drop_key_s(seed, site);
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int q = r * 16 + l15;
@@ -178,7 +179,7 @@ __device__ __forceinline__ void attention_head_regs(const f32x4_att (&qt)[3], co
                     for (int cb = 0; cb <= r; ++cb)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            S[r][cb][e] = tip_drop_hash(seed, site, pb + cb * 16 + lg * 4 + e) >= thresh ? S[r][cb][e] * dscale : 0.f;
+                            S[r][cb][e] = tip_drop_hash_k(dkey, pb + cb * 16 + lg * 4 + e) >= thresh ? S[r][cb][e] * dscale : 0.f;
                 }
             }
         }

@@ -14,14 +14,6 @@ namespace tip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned attn_drop_hash(unsigned long long seed, unsigned site, unsigned long long idx) {
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + ((unsigned long long)site << 40) + 1ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (unsigned)(z >> 32);
-}
-
 // NBMAX = ceil(T / 16) upper bound (3: T <= 48, 5: T <= 80, 8: T <= 128)
 template <int DH, int NBMAX>
 __global__ __launch_bounds__(256) void mattn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
@@ -87,7 +79,7 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(const float* __restrict_
                     float pk = p;
                     if (drop.thresh) {
                         const int kk = jb * 16 + lg * 4 + r;
-                        pk = attn_drop_hash(drop.seed, drop.site, pbase + kk) >= drop.thresh ? p * drop.scale : 0.f;
+                        pk = tip_drop_hash_k(drop.key, pbase + kk) >= drop.thresh ? p * drop.scale : 0.f;
                     }
                     st[jb][r] = pk;
                 }
@@ -258,7 +250,7 @@ __global__ __launch_bounds__(64) void mattn_bwd_kernel(const float* __restrict__
                         const float p = __expf(s1[r] * q_scale - mq) * iq;
                         float kf_ = 1.f;
                         if (drop.thresh)
-                            kf_ = attn_drop_hash(drop.seed, drop.site, ((unsigned long long)bh * T + q) * T + kk) >= drop.thresh ? drop.scale : 0.f;
+                            kf_ = tip_drop_hash_k(drop.key, ((unsigned long long)bh * T + q) * T + kk) >= drop.thresh ? drop.scale : 0.f;
                         v = p * (p1[r] * kf_ - dd);
                     }
                     ds1[r] = v;
@@ -300,7 +292,7 @@ __global__ __launch_bounds__(64) void mattn_bwd_kernel(const float* __restrict__
                         const float p = __expf(s2[r] * q_scale - m2[r]) * i2[r];
                         float kf_ = 1.f;
                         if (drop.thresh)
-                            kf_ = attn_drop_hash(drop.seed, drop.site, ((unsigned long long)bh * T + qq) * T + key) >= drop.thresh ? drop.scale : 0.f;
+                            kf_ = tip_drop_hash_k(drop.key, ((unsigned long long)bh * T + qq) * T + key) >= drop.thresh ? drop.scale : 0.f;
                         pdv = p * kf_;
                         dsv = p * (p2[r] * kf_ - d2[r]);
                     }

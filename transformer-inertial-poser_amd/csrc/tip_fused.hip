@@ -397,6 +397,10 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
             const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
             const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
             float* svl = TR ? tr.sv + (size_t)layer * tr.layer_stride : nullptr;   // this layer's stash
+            // dropout keys of this layer's sites 1..3 (site 0, the attention probabilities, is keyed inside attention_head_regs)
+            const unsigned dk1 = TR ? tip_drop_key_s(tr.seed, (unsigned)(layer * 4 + 1)) : 0u;
+            const unsigned dk2 = TR ? tip_drop_key_s(tr.seed, (unsigned)(layer * 4 + 2)) : 0u;
+            const unsigned dk3 = TR ? tip_drop_key_s(tr.seed, (unsigned)(layer * 4 + 3)) : 0u;
             float* Qc = C;   // attention output of one 8-head chunk [48 rows][128 channels]: the out-projection's A operand
             // ---- self-attention block: two chunks of 8 heads; wave w owns head 8c + w end to end -----------------
             f32x4 acc_o[RB][2];
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     for (int e = 0; e < 4; ++e) {
                         float v = acc_o[r][n][e] + bv;
                         if (TR && tr.thresh)
-                            v = tip_drop_hash(tr.seed, (unsigned)(layer * 4 + 1), (grow0 + r * 16 + lg * 4 + e) * D + col) >= tr.thresh
+                            v = tip_drop_hash_k(dk1, (grow0 + r * 16 + lg * 4 + e) * D + col) >= tr.thresh
                                     ? v * tr.scale : 0.f;
                         X[(r * 16 + lg * 4 + e) * LDX + col] += v;
                     }
@@ -511,8 +515,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                             for (int e = 0; e < 4; ++e) {
                                 float v = fmaxf(acc[r][n][e] + bv, 0.f);
                                 if (TR && tr.thresh)
-                                    v = tip_drop_hash(tr.seed, (unsigned)(layer * 4 + 2),
-                                                      (grow0 + r * 16 + lg * 4 + e) * F + f * 256 + col) >= tr.thresh ? v * tr.scale : 0.f;
+                                    v = tip_drop_hash_k(dk2, (grow0 + r * 16 + lg * 4 + e) * F + f * 256 + col) >= tr.thresh ? v * tr.scale : 0.f;
                                 Hc[(r * 16 + lg * 4 + e) * LDX + col] = v;
                             }
                     }
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     for (int e = 0; e < 4; ++e) {
                         float v = acc_f[r][n][e] + bv;
                         if (TR && tr.thresh)
-                            v = tip_drop_hash(tr.seed, (unsigned)(layer * 4 + 3), (grow0 + r * 16 + lg * 4 + e) * D + col) >= tr.thresh
+                            v = tip_drop_hash_k(dk3, (grow0 + r * 16 + lg * 4 + e) * D + col) >= tr.thresh
                                     ? v * tr.scale : 0.f;
                         X[(r * 16 + lg * 4 + e) * LDX + col] += v;
                     }
@@ -720,6 +723,7 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
     // the saved hidden activations through a buffer descriptor (byte offsets must fit 32 bits: checked by the launcher)
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.hid), 0, a.hid_bytes, 0x00020000);
 
+    const unsigned dkey = tip_drop_key_s(a.seed, a.site);
     for (int win = blockIdx.x; win < B; win += gridDim.x) {
         const size_t grow0 = (size_t)win * T;
         bwd_stamp(a.trace, 0);
@@ -750,10 +754,10 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
                     m = o;
                     if (a.thresh) {
                         const unsigned long long idx = gr * D + lane * 4;
-                        m.x = tip_drop_hash(a.seed, a.site, idx) >= a.thresh ? o.x * a.scale : 0.f;
-                        m.y = tip_drop_hash(a.seed, a.site, idx + 1) >= a.thresh ? o.y * a.scale : 0.f;
-                        m.z = tip_drop_hash(a.seed, a.site, idx + 2) >= a.thresh ? o.z * a.scale : 0.f;
-                        m.w = tip_drop_hash(a.seed, a.site, idx + 3) >= a.thresh ? o.w * a.scale : 0.f;
+                        m.x = tip_drop_hash_k(dkey, idx) >= a.thresh ? o.x * a.scale : 0.f;
+                        m.y = tip_drop_hash_k(dkey, idx + 1) >= a.thresh ? o.y * a.scale : 0.f;
+                        m.z = tip_drop_hash_k(dkey, idx + 2) >= a.thresh ? o.z * a.scale : 0.f;
+                        m.w = tip_drop_hash_k(dkey, idx + 3) >= a.thresh ? o.w * a.scale : 0.f;
                     }
                     *reinterpret_cast<float4*>(a.dff2 + gr * D + lane * 4) = m;
                     dm.x += m.x; dm.y += m.y; dm.z += m.z; dm.w += m.w;
@@ -904,6 +908,7 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
     float* Qs = Sc + wave * (3 * RP * LDT);             // this wave's head: Q rows [48][16] (row-major) ...
     float* Ks = Qs + RP * LDT;                          // ... and K rows: read back as (row 4*lg + e, channel l15) B fragments
     float* Gs = Ks + RP * LDT;                          // dO tile: written in the accumulator layout, read back as row fragments
+    const unsigned dkey0 = tip_drop_key_s(a.seed, a.site0), dkey1 = tip_drop_key_s(a.seed, a.site1);
 
     for (int win = blockIdx.x; win < B; win += gridDim.x) {
         const size_t grow0 = (size_t)win * T;
@@ -937,10 +942,10 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
                     m = o;
                     if (a.thresh) {
                         const unsigned long long idx = gr * D + lane * 4;
-                        m.x = tip_drop_hash(a.seed, a.site1, idx) >= a.thresh ? o.x * a.scale : 0.f;
-                        m.y = tip_drop_hash(a.seed, a.site1, idx + 1) >= a.thresh ? o.y * a.scale : 0.f;
-                        m.z = tip_drop_hash(a.seed, a.site1, idx + 2) >= a.thresh ? o.z * a.scale : 0.f;
-                        m.w = tip_drop_hash(a.seed, a.site1, idx + 3) >= a.thresh ? o.w * a.scale : 0.f;
+                        m.x = tip_drop_hash_k(dkey1, idx) >= a.thresh ? o.x * a.scale : 0.f;
+                        m.y = tip_drop_hash_k(dkey1, idx + 1) >= a.thresh ? o.y * a.scale : 0.f;
+                        m.z = tip_drop_hash_k(dkey1, idx + 2) >= a.thresh ? o.z * a.scale : 0.f;
+                        m.w = tip_drop_hash_k(dkey1, idx + 3) >= a.thresh ? o.w * a.scale : 0.f;
                     }
                     *reinterpret_cast<float4*>(a.datt_o + gr * D + lane * 4) = m;
                     dm.x += m.x; dm.y += m.y; dm.z += m.z; dm.w += m.w;
@@ -1050,7 +1055,7 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
                         if (kk <= q && q < T) {
                             const float p = __expf(s1[e] * a.q_scale - mq[r]) * iq[r];
                             float kf_ = 1.f;
-                            if (a.thresh) kf_ = tip_drop_hash(a.seed, a.site0, (bh * T + q) * T + kk) >= a.thresh ? a.scale : 0.f;
+                            if (a.thresh) kf_ = tip_drop_hash_k(dkey0, (bh * T + q) * T + kk) >= a.thresh ? a.scale : 0.f;
                             v = p * (p1[e] * kf_ - dd[r]);
                         }
                         dq = __builtin_amdgcn_mfma_f32_16x16x4f32(v, Ks[(cb * 16 + lg * 4 + e) * LDT + l15], dq, 0, 0, 0);
@@ -1070,7 +1075,7 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
                         if (key <= qq && qq < T) {
                             const float p = __expf(s2[e] * a.q_scale - m2[e]) * i2[e];
                             float kf_ = 1.f;
-                            if (a.thresh) kf_ = tip_drop_hash(a.seed, a.site0, (bh * T + qq) * T + key) >= a.thresh ? a.scale : 0.f;
+                            if (a.thresh) kf_ = tip_drop_hash_k(dkey0, (bh * T + qq) * T + key) >= a.thresh ? a.scale : 0.f;
                             pdv = p * kf_;
                             dsv = p * (p2[e] * kf_ - d2[e]);
                         }

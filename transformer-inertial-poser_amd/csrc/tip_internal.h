@@ -26,16 +26,35 @@ struct Drop {
     unsigned site;
     unsigned thresh;
     float scale;   // 1 / (1 - p)
+    unsigned key;  // tip_drop_key(seed, site), filled in by make_drop on the host
 };
 typedef Drop AttnDrop;
 
-// keep(seed, site, idx): the counter-based dropout hash of the training step (include/tip_hip.h documents it)
-__device__ __forceinline__ unsigned tip_drop_hash(unsigned long long seed, unsigned site, unsigned long long idx) {
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + ((unsigned long long)site << 40) + 1ull);
+// keep(seed, site, idx): the counter-based dropout hash of the training step (include/tip_hip.h documents it).
+// key = hi32(splitmix64-mix(seed + GOLDEN * (site + 1))) is wave-uniform (scalar unit, once per site); per element only
+// 32-bit arithmetic remains: the 64-bit splitmix per ELEMENT of the first version cost a dozen quarter-rate multiplies.
+__host__ __device__ __forceinline__ unsigned tip_drop_key(unsigned long long seed, unsigned site) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)site + 1ull);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
     return (unsigned)(z >> 32);
+}
+// kernels compute the key ONCE (wave-uniform, forced into an SGPR) and hash elements with tip_drop_hash_k
+__device__ __forceinline__ unsigned tip_drop_key_s(unsigned long long seed, unsigned site) {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)tip_drop_key(seed, site));
+}
+__device__ __forceinline__ unsigned tip_drop_hash_k(unsigned key, unsigned idx) {   // idx: element index mod 2^32
+    unsigned z = idx * 0x9E3779B1u + key;
+    z ^= z >> 16;
+    z *= 0x7FEB352Du;
+    z ^= z >> 15;
+    z *= 0x846CA68Bu;
+    z ^= z >> 16;
+    return z;
+}
+__device__ __forceinline__ unsigned tip_drop_hash(unsigned long long seed, unsigned site, unsigned long long idx) {
+    return tip_drop_hash_k(tip_drop_key(seed, site), (unsigned)idx);
 }
 
 // Where the fused encoder, run as the TRAINING forward, stashes its activations (float offsets into `sv`; the per-layer

@@ -32,23 +32,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------------------------------------------------
 // dropout: keep(seed, site, idx) = hash >= thresh, thresh = floor(p * 2^32)
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned drop_hash(unsigned long long seed, unsigned site, unsigned long long idx) {
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + ((unsigned long long)site << 40) + 1ull);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (unsigned)(z >> 32);
-}
-
 __device__ __forceinline__ float drop_factor(const Drop d, unsigned long long idx) {
     if (d.thresh == 0) return 1.f;
-    return drop_hash(d.seed, d.site, idx) >= d.thresh ? d.scale : 0.f;
+    return tip_drop_hash_k(d.key, idx) >= d.thresh ? d.scale : 0.f;
 }
 
 static Drop make_drop(float p, unsigned long long seed, unsigned site) {
     Drop d;
     d.seed = seed;
     d.site = site;
+    d.key = tip_drop_key(seed, site);
     if (p <= 0.f) {
         d.thresh = 0;
         d.scale = 1.f;
