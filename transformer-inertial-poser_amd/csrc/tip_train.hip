@@ -858,6 +858,49 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     }
 }
 
+// the same reduction for several partial arrays in one launch (blockIdx.y = source): the fused backward leaves every layer's
+// per-window partials in place and reduces them all at the end instead of with two small launches per layer
+constexpr int kColMulti = 16;
+struct ColSrc {
+    const float* part;   // [Z][N]
+    float* out;          // columns [0, nsplit)
+    float* out_hi;       // columns [nsplit, nsplit2)
+    float* out_hi2;      // columns [nsplit2, N)
+    int N, nsplit, nsplit2;
+};
+struct ColMulti {
+    ColSrc src[kColMulti];
+    int Z;
+};
+__global__ __launch_bounds__(256) void colreduce_multi_kernel(ColMulti m) {
+    __shared__ float red[4][64];
+    const ColSrc& q = m.src[blockIdx.y];
+    const int N = q.N, Z = m.Z;
+    if ((int)blockIdx.x * 64 >= N) return;
+    const float* __restrict__ part = q.part;
+    const int c = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (n < N) {
+        int z = zl;
+        for (; z + 12 < Z; z += 16) {
+            a0 += part[(long long)z * N + n];
+            a1 += part[(long long)(z + 4) * N + n];
+            a2 += part[(long long)(z + 8) * N + n];
+            a3 += part[(long long)(z + 12) * N + n];
+        }
+        for (; z < Z; z += 4) a0 += part[(long long)z * N + n];
+    }
+    red[zl][c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (zl == 0 && n < N) {
+        const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+        if (n >= q.nsplit2) q.out_hi2[n - q.nsplit2] = v;
+        else if (n >= q.nsplit) q.out_hi[n - q.nsplit] = v;
+        else q.out[n] = v;
+    }
+}
+
 constexpr int kColZ = 64;
 
 static hipError_t colsum(const float* X, long long ld, int M, int N, float* part, float* out, float* out2, hipStream_t s) {
@@ -1217,7 +1260,8 @@ static TrainScratch scratch_layout(const Dims& d, int B, int T) {
     S.dwin_p = take(off, (size_t)d.D * d.InPad);
     S.dbin_p = take(off, d.D);
     S.bwimg = take(off, fused_bwd_image_floats(d));
-    S.lnwin = take(off, (size_t)B * (size_t)(6 * d.D > 3 * d.D + d.F ? 6 * d.D : 3 * d.D + d.F));
+    // per layer: [B][3D + F] of the FFN half, then [B][6D] of the attention half (reduced by one launch after the last layer)
+    S.lnwin = take(off, (size_t)d.L * B * (size_t)(9 * d.D + d.F));
     S.total = off;
     return S;
 }
@@ -1572,6 +1616,12 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
         TT(lin_launch(g, L.wih_tf ? W + L.wih_tf : nullptr, s), "bwd_d_enc");
     }
     // ---- encoder layers, last to first -----------------------------------------------------------------------------------
+    // fused backward: the per-window LayerNorm / bias partials of every layer stay in place and are reduced by ONE launch after
+    // the loop (two small launches per layer otherwise)
+    const bool col_multi = fbwd && 2 * d.L <= kColMulti;
+    ColMulti cm;
+    cm.Z = B;
+    for (int i = 0; i < kColMulti; ++i) cm.src[i] = ColSrc{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     for (int l = d.L - 1; l >= 0; --l) {
         const int pb = P_LAYER0 + PL_COUNT * l;
         const float* const* lp = params + pb;
@@ -1584,15 +1634,24 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             fa.wimg = X + S.bwimg; fa.wbytes = (int)(fused_bwd_image_floats(d) * 4); fa.layer = l;
             fa.dy = gx; fa.z2 = W + t.z2; fa.st2 = W + t.st2; fa.g2 = lp[PL_N2_W]; fa.hid = W + t.hid;
             fa.gate_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.f;
-            fa.dff2 = X + S.gc; fa.dpre = X + S.gbig; fa.dx1 = gx; fa.lnpart = X + S.lnwin;
+            float* lnw_f = X + S.lnwin + (size_t)l * B * (9 * d.D + d.F);        // this layer's FFN-half partials
+            float* lnw_a = lnw_f + (size_t)B * (3 * d.D + d.F);                   // ... and attention-half partials
+            fa.dff2 = X + S.gc; fa.dpre = X + S.gbig; fa.dx1 = gx; fa.lnpart = lnw_f;
             const Drop dr = make_drop(p_drop, seed, (unsigned)(l * 4 + 3));
             fa.seed = dr.seed; fa.site = dr.site; fa.thresh = dr.thresh; fa.scale = dr.scale;
             TT(launch_ffn_bwd(d, fa, B, T, ncu, s), "bwd_ffn_fused");
             // per-window partials [dgamma2 | dbeta2 | d(linear2 bias) | d(linear1 bias)] -> the four gradient tensors
-            hipLaunchKernelGGL(colreduce_kernel, dim3((3 * d.D + d.F + 63) / 64), dim3(256), 0, s, X + S.lnwin, B, 3 * d.D + d.F,
-                               grads + goff[pb + PL_N2_W], nullptr, 2 * d.D, grads + goff[pb + PL_L2_B], 3 * d.D,
-                               grads + goff[pb + PL_L1_B]);
-            TT(hipGetLastError(), "bwd_ln2_params");
+            if (!col_multi) {
+                hipLaunchKernelGGL(colreduce_kernel, dim3((3 * d.D + d.F + 63) / 64), dim3(256), 0, s, lnw_f, B, 3 * d.D + d.F,
+                                   grads + goff[pb + PL_N2_W], nullptr, 2 * d.D, grads + goff[pb + PL_L2_B], 3 * d.D,
+                                   grads + goff[pb + PL_L1_B]);
+                TT(hipGetLastError(), "bwd_ln2_params");
+            } else {
+                cm.src[2 * l] = ColSrc{lnw_f, grads + goff[pb + PL_N2_W], grads + goff[pb + PL_L2_B], grads + goff[pb + PL_L1_B],
+                                       3 * d.D + d.F, 2 * d.D, 3 * d.D};
+                cm.src[2 * l + 1] = ColSrc{lnw_a, grads + goff[pb + PL_N1_W], grads + goff[pb + PL_OUT_B], grads + goff[pb + PL_QKV_B],
+                                           6 * d.D, 2 * d.D, 3 * d.D};
+            }
             // dW2 / dW1 wait for the attention half: the layer's four weight gradients go out in one launch below
         } else {
         // LN2: gx -> dz2 (galt), dff2 = dz2 * keep3 (gc)
@@ -1637,15 +1696,18 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             aa.wimg = X + S.bwimg; aa.wbytes = (int)(fused_bwd_image_floats(d) * 4); aa.layer = l;
             aa.dx1 = gx; aa.z1 = W + t.z1; aa.st1 = W + t.st1; aa.g1 = lp[PL_N1_W];
             aa.qkv = W + t.qkv; aa.att = W + t.att; aa.ast = W + t.ast; aa.q_scale = 1.0f / sqrtf((float)d.dh);
-            aa.dz1 = galt; aa.datt_o = X + S.datt; aa.dqkv = X + S.gbig2; aa.dx_in = gx; aa.lnpart = X + S.lnwin;
+            float* lnw_a = X + S.lnwin + (size_t)l * B * (9 * d.D + d.F) + (size_t)B * (3 * d.D + d.F);
+            aa.dz1 = galt; aa.datt_o = X + S.datt; aa.dqkv = X + S.gbig2; aa.dx_in = gx; aa.lnpart = lnw_a;
             const Drop dr = make_drop(p_drop, seed, 0);
             aa.seed = dr.seed; aa.site0 = (unsigned)(l * 4 + 0); aa.site1 = (unsigned)(l * 4 + 1); aa.thresh = dr.thresh; aa.scale = dr.scale;
             TT(launch_attn_bwd(d, aa, B, T, ncu, s), "bwd_attn_fused");
             // per-window partials [dgamma1 | dbeta1 | d(out_proj bias) | d(in_proj bias)] -> the four gradient tensors
-            hipLaunchKernelGGL(colreduce_kernel, dim3((6 * d.D + 63) / 64), dim3(256), 0, s, X + S.lnwin, B, 6 * d.D,
-                               grads + goff[pb + PL_N1_W], nullptr, 2 * d.D, grads + goff[pb + PL_OUT_B], 3 * d.D,
-                               grads + goff[pb + PL_QKV_B]);
-            TT(hipGetLastError(), "bwd_ln1_params");
+            if (!col_multi) {
+                hipLaunchKernelGGL(colreduce_kernel, dim3((6 * d.D + 63) / 64), dim3(256), 0, s, lnw_a, B, 6 * d.D,
+                                   grads + goff[pb + PL_N1_W], nullptr, 2 * d.D, grads + goff[pb + PL_OUT_B], 3 * d.D,
+                                   grads + goff[pb + PL_QKV_B]);
+                TT(hipGetLastError(), "bwd_ln1_params");
+            }
             const DwProb pr[4] = {{X + S.gc, d.D, d.D, W + t.hid, d.F, d.F, grads + goff[pb + PL_L2_W]},
                                   {X + S.gbig, d.F, d.F, W + t.x1, d.D, d.D, grads + goff[pb + PL_L1_W]},
                                   {X + S.datt, d.D, d.D, W + t.att, d.D, d.D, grads + goff[pb + PL_OUT_W]},
@@ -1701,6 +1763,11 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             TT(lin_launch(g, t.qkv_tf ? W + t.qkv_tf : nullptr, s), "bwd_dx_in");
         }
         }
+    }
+    if (col_multi) {
+        hipLaunchKernelGGL(colreduce_multi_kernel, dim3((3 * d.D + d.F + 63) / 64 > (6 * d.D + 63) / 64 ? (3 * d.D + d.F + 63) / 64 : (6 * d.D + 63) / 64, 2 * d.L),
+                           dim3(256), 0, s, cm);
+        TT(hipGetLastError(), "bwd_ln_params");
     }
     // ---- in_linear (:79) ---------------------------------------------------------------------------------------------------
     TT(colsum(gx, d.D, M, d.D, colpart, X + S.dbin_p, nullptr, s), "bwd_db_in");
