@@ -352,3 +352,18 @@ def test_device_packer_builds_the_same_image_as_the_host_packer(cfgname):
         m.linear.bias.add_(1.0)
     y1 = _run(m, x_imu, x_s)
     assert np.allclose(y1 - y0, 1.0, atol=1e-5)
+
+
+def test_empty_and_oversized_inputs_raise_like_the_reference():
+    """The reference raises RuntimeError on an empty batch or an empty window (its head-interleave reshape fails,
+    simple_transformer_with_state.py:88); so does the drop-in.  A window longer than the handle's t_max is refused too."""
+    cfg = synth.PAPER
+    m, _ = _gpu_model(cfg, 0)
+    with torch.no_grad():
+        for B, T in ((0, 40), (2, 0)):
+            with pytest.raises(RuntimeError):
+                m(torch.zeros(B, T, 90).cuda(), torch.zeros(B, T, 131).cuda())
+        with pytest.raises(RuntimeError):
+            m(torch.zeros(1, 4096, 90).cuda(), torch.zeros(1, 4096, 131).cuda())
+        y = m(torch.zeros(2, 41, 90).cuda(), torch.zeros(2, 41, 131).cuda())     # past the paper's 40 frames: general plan
+        assert y.shape == (2, 41, 131) and torch.isfinite(y).all()
