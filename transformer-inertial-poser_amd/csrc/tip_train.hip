@@ -521,32 +521,43 @@ __device__ __forceinline__ void dwgemm_body(const DwArgs& g, int tile, int z) {
 #pragma unroll
         for (int ib = 0; ib < NB; ++ib) Bv[d][ib] = *reinterpret_cast<const float4*>(pb + st * sb + 64 * ib);
     };
+    auto mfmas = [&](int d) {
+        float av[2][4], bv[NB][4];
+#pragma unroll
+        for (int ia = 0; ia < 2; ++ia) av[ia][0] = Av[d][ia].x, av[ia][1] = Av[d][ia].y, av[ia][2] = Av[d][ia].z, av[ia][3] = Av[d][ia].w;
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib) bv[ib][0] = Bv[d][ib].x, bv[ib][1] = Bv[d][ib].y, bv[ib][2] = Bv[d][ib].z, bv[ib][3] = Bv[d][ib].w;
+#pragma unroll
+        for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+            for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        acc[ia][ca][ib][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ia][ca], bv[ib][cb], acc[ia][ca][ib][cb], 0, 0, 0);
+    };
     if (ns > 0) {
+        // The steady-state loop is branch-free: stage d is consumed, then refilled with row group s0 + d + kDwDepth (index
+        // clamped to the last group: a harmless reload near the end).  With per-stage `if (step < ns)` guards the compiler
+        // shuffled the ring through register copies and waited for each freshly issued load — the prefetch was void.
 #pragma unroll
         for (int d = 0; d < kDwDepth; ++d) fetch(d, d < ns ? d : ns - 1);
-    }
-    for (int s0 = 0; s0 < ns; s0 += kDwDepth) {
+        int s0 = 0;
+        for (; s0 + kDwDepth <= ns; s0 += kDwDepth) {
 #pragma unroll
-        for (int d = 0; d < kDwDepth; ++d) {
-            if (s0 + d < ns) {
-                float av[2][4], bv[NB][4];
-#pragma unroll
-                for (int ia = 0; ia < 2; ++ia) av[ia][0] = Av[d][ia].x, av[ia][1] = Av[d][ia].y, av[ia][2] = Av[d][ia].z, av[ia][3] = Av[d][ia].w;
-#pragma unroll
-                for (int ib = 0; ib < NB; ++ib) bv[ib][0] = Bv[d][ib].x, bv[ib][1] = Bv[d][ib].y, bv[ib][2] = Bv[d][ib].z, bv[ib][3] = Bv[d][ib].w;
-                if (s0 + d + kDwDepth < ns) fetch(d, s0 + d + kDwDepth);
-#pragma unroll
-                for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-                    for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-                        for (int ib = 0; ib < NB; ++ib)
-#pragma unroll
-                            for (int cb = 0; cb < 4; ++cb)
-                                acc[ia][ca][ib][cb] =
-                                    __builtin_amdgcn_mfma_f32_16x16x4f32(av[ia][ca], bv[ib][cb], acc[ia][ca][ib][cb], 0, 0, 0);
+            for (int d = 0; d < kDwDepth; ++d) {
+                mfmas(d);
+                const int nx = s0 + d + kDwDepth;
+                fetch(d, nx < ns ? nx : ns - 1);
+                __builtin_amdgcn_sched_barrier(0);   // keep each refill where it is (the scheduler otherwise sinks all of them
+                                                     // to the end of the body: stage 0 would wait a full memory round trip)
             }
         }
+        // remaining ns - s0 (< kDwDepth) row groups are already in stages 0 .. ns - s0 - 1
+#pragma unroll
+        for (int d = 0; d < kDwDepth - 1; ++d)
+            if (s0 + d < ns) mfmas(d);
     }
     // (w0 + w2) + (w1 + w3) through two accumulator images [tile][lane][4]
     auto tile_of = [&](int t) -> f32x4& { return acc[t / (16 * NB)][(t / (4 * NB)) & 3][(t >> 2) % NB][t & 3]; };
@@ -614,7 +625,8 @@ struct DwBatch {
     int tile0[kDwBatchMax + 1];
     int n;
 };
-__global__ __launch_bounds__(256, 2) void dwgemm_batch_kernel(DwBatch b) {
+template <int NB>
+__global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void dwgemm_batch_kernel(DwBatch b) {
     int tile, z;
     if (!dw_work(b.tile0[b.n], b.p[0].splits, &tile, &z)) return;
     int q = 0;
@@ -622,10 +634,10 @@ __global__ __launch_bounds__(256, 2) void dwgemm_batch_kernel(DwBatch b) {
     for (int i = 1; i < kDwBatchMax; ++i)
         if (i < b.n && tile >= b.tile0[i]) q = i;
     // select by value (uniform branch) rather than by pointer into the kernel argument: keeps the descriptor in SGPRs
-    if (q == 0) dwgemm_body<1>(b.p[0], tile - b.tile0[0], z);
-    else if (q == 1) dwgemm_body<1>(b.p[1], tile - b.tile0[1], z);
-    else if (q == 2) dwgemm_body<1>(b.p[2], tile - b.tile0[2], z);
-    else dwgemm_body<1>(b.p[3], tile - b.tile0[3], z);
+    if (q == 0) dwgemm_body<NB>(b.p[0], tile - b.tile0[0], z);
+    else if (q == 1) dwgemm_body<NB>(b.p[1], tile - b.tile0[1], z);
+    else if (q == 2) dwgemm_body<NB>(b.p[2], tile - b.tile0[2], z);
+    else dwgemm_body<NB>(b.p[3], tile - b.tile0[3], z);
 }
 
 struct ReduceBatch {
@@ -694,7 +706,9 @@ static hipError_t dw_set_attrs() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwgemm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<2>());
     if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwgemm_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<1>());
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwgemm_batch_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<1>());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwgemm_batch_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<2>());
     done = e == hipSuccess;
     return e;
 }
@@ -715,14 +729,20 @@ static bool grad_weight_batch(const DwProb* pr, int n, int M, float* part, size_
     DwBatch b;
     b.n = n;
     b.tile0[0] = 0;
+    static int nbsel = -1;   // TIP_DW_NB=2: 128 x 128 per wave in the batched launch too (measurement)
+    if (nbsel < 0) nbsel = getenv("TIP_DW_NB") ? atoi(getenv("TIP_DW_NB")) : 0;
+    int NB = nbsel == 2 ? 2 : 1;
     for (int i = 0; i < n; ++i) {
         if (!dwgemm_ok(pr[i].ldy, pr[i].ldx, pr[i].n_out, pr[i].n_out, pr[i].K, M)) return false;
-        b.tile0[i + 1] = b.tile0[i] + (pr[i].n_out / 128) * (pr[i].K / 64);
+        if (pr[i].K % 128) NB = 1;
+    }
+    for (int i = 0; i < n; ++i) {
+        b.tile0[i + 1] = b.tile0[i] + (pr[i].n_out / 128) * (pr[i].K / (64 * NB));
         per_total += (long long)pr[i].n_out * pr[i].K;
     }
     for (int i = n; i < kDwBatchMax; ++i) b.tile0[i + 1] = b.tile0[n], b.p[i] = DwArgs{};
     const int tiles = b.tile0[n];
-    int splits = dw_choose_splits(tiles, 2 * num_cus, M, per_total, part_floats, 128 * 64);
+    int splits = dw_choose_splits(tiles, (NB == 1 ? 2 : 1) * num_cus, M, per_total, part_floats, 128 * 64 * NB);
     const int klen = round_up((M + splits - 1) / splits, 16);
     splits = (M + klen - 1) / klen;
     ReduceBatch r;
@@ -738,7 +758,8 @@ static bool grad_weight_batch(const DwProb* pr, int n, int M, float* part, size_
     }
     *err = dw_set_attrs();
     if (*err != hipSuccess) return true;
-    hipLaunchKernelGGL(dwgemm_batch_kernel, dim3(dw_grid(tiles, splits)), dim3(256), dw_lds_bytes<1>(), s, b);
+    if (NB == 1) hipLaunchKernelGGL(dwgemm_batch_kernel<1>, dim3(dw_grid(tiles, splits)), dim3(256), dw_lds_bytes<1>(), s, b);
+    else hipLaunchKernelGGL(dwgemm_batch_kernel<2>, dim3(dw_grid(tiles, splits)), dim3(256), dw_lds_bytes<2>(), s, b);
     if (splits > 1)
         hipLaunchKernelGGL(splitk_reduce_batch_kernel, dim3((unsigned)((per_max / 4 + 255) / 256), n), dim3(256), 0, s, r);
     *err = hipGetLastError();
