@@ -212,6 +212,43 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const float* __restrict_
     f32x4 acc[NBO];
 #pragma unroll
     for (int n = 0; n < NBO; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (KB % 8 == 0) {
+        // Steady state without a branch: a ring of 4 k-blocks of weight fragments (L2) and 8 of A rows (HBM: HALL has just
+        // been written by the RNN); stage j is consumed, THEN refilled (index clamped at the end: a harmless reload), and a
+        // scheduling barrier pins each refill where it stands.  The first version guarded every stage with `if (kb < KB)` and
+        // rotated wc <- wn by copies: the compiler answered with `s_waitcnt vmcnt(0)` right after each load, i.e. no
+        // prefetch at all — a full memory round trip per k-block (23 us for a 10-us product).
+        f32x4 wr[4][NBO];
+        float4 ar[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int n = 0; n < NBO; ++n) wr[j][n] = ldw(n, j);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ar[j] = *reinterpret_cast<const float4*>(ap + j * 16);
+        auto body = [&](int kb0, int KBc) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 a = ar[j];
+#pragma unroll
+                for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wr[j & 3][n].x, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wr[j & 3][n].y, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wr[j & 3][n].z, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NBO; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wr[j & 3][n].w, acc[n], 0, 0, 0);
+                const int kw = kb0 + j + 4 < KBc ? kb0 + j + 4 : KBc - 1;
+                const int ka = kb0 + j + 8 < KBc ? kb0 + j + 8 : KBc - 1;
+#pragma unroll
+                for (int n = 0; n < NBO; ++n) wr[j & 3][n] = ldw(n, kw);
+                ar[j] = *reinterpret_cast<const float4*>(ap + ka * 16);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+#pragma unroll 1
+        for (int kb0 = 0; kb0 < KB; kb0 += 8) body(kb0, KB);   // (fully unrolling K = 512 measured no better)
+    } else {
     f32x4 wc[NBO], wn[NBO];
 #pragma unroll
     for (int n = 0; n < NBO; ++n) wc[n] = ldw(n, 0);
@@ -244,6 +281,7 @@ __global__ __launch_bounds__(256) void head_gemm_kernel(const float* __restrict_
                 for (int n = 0; n < NBO; ++n) wc[n] = wn[n];
             }
         }
+    }
     }
 #pragma unroll
     for (int n = 0; n < NBO; ++n) {
