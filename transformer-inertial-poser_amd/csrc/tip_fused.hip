@@ -390,13 +390,13 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
         }
         __syncthreads();
         const size_t grow0 = (size_t)win * T;           // first global row (b*T + t) of this window
-        if (TR) rows_to_hbm(X, LDX, D, tr.sv + tr.x0 + grow0 * D, D, T, tid);
+        if (TR) rows_to_hbm(X, LDX, D, tr.sv + (size_t)tr.x0 * 64 + grow0 * D, D, T, tid);
 
 #pragma unroll 1
         for (int layer = 0; layer < L; ++layer) {
             const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
             const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
-            float* svl = TR ? tr.sv + (size_t)layer * tr.layer_stride : nullptr;   // this layer's stash
+            float* svl = TR ? tr.sv + (size_t)layer * tr.layer_stride * 64 : nullptr;   // this layer's stash
             // dropout keys of this layer's sites 1..3 (site 0, the attention probabilities, is keyed inside attention_head_regs)
             const unsigned dk1 = TR ? tip_drop_key_s(tr.seed, (unsigned)(layer * 4 + 1)) : 0u;
             const unsigned dk2 = TR ? tip_drop_key_s(tr.seed, (unsigned)(layer * 4 + 2)) : 0u;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     }
                     if (TR) {
                         // raw q (the packed W_q carries the 1/sqrt(d_head) fold: undo it exactly), k, v -> [M, 3D]
-                        float* qp = svl + tr.qkv + grow0 * (3 * D) + head * 16;
+                        float* qp = svl + (size_t)tr.qkv * 64 + grow0 * (3 * D) + head * 16;
 #pragma unroll
                         for (int r = 0; r < RB; ++r) {
                             const int row = r * 16 + l15;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                                 if (vr < T) qp[(size_t)vr * (3 * D) + 2 * D + l15] = vv[r][e];
                             }
                         }
-                        attention_head_regs<LDC, true>(qt, kt, vv, Qc, wave * 16, lane, 48, svl + tr.ast,
+                        attention_head_regs<LDC, true>(qt, kt, vv, Qc, wave * 16, lane, 48, svl + (size_t)tr.ast * 64,
                                                        (unsigned long long)win * H + head, T, tr.seed, (unsigned)(layer * 4 + 0),
                                                        tr.thresh, tr.scale);
                     } else if (!(ABL & 1)) {
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     }
                 }
                 __syncthreads();
-                if (TR) rows_to_hbm(Qc, LDC, 128, svl + tr.att + grow0 * D + c * 128, D, T, tid);
+                if (TR) rows_to_hbm(Qc, LDC, 128, svl + (size_t)tr.att * 64 + grow0 * D + c * 128, D, T, tid);
                 // the next consumer's fragments go out before this phase's MFMAs: chunk 1's QKV, or the first FFN chunk
                 if (c == 0)
                     ring_prefetch<3>(g_qkv, rsrc, voff, lbase + (int)(QKV_W * 4) + (8 + wave) * 16 * 1024, 16 * 16 * 1024);
@@ -487,8 +487,8 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
             }
             __syncthreads();
             if (TR)
-                layernorm_rows<true>(X, LW + G1, LW + BE1, wave, lane, svl + tr.z1 + grow0 * D, svl + tr.st1 + grow0 * 2,
-                                     svl + tr.x1 + grow0 * D, T);
+                layernorm_rows<true>(X, LW + G1, LW + BE1, wave, lane, svl + (size_t)tr.z1 * 64 + grow0 * D, svl + (size_t)tr.st1 * 64 + grow0 * 2,
+                                     svl + (size_t)tr.x1 * 64 + grow0 * D, T);
             else if (!(ABL & 2)) layernorm_rows(X, LW + G1, LW + BE1, wave, lane);
             __syncthreads();
             // ---- feed-forward block: hidden processed in 4 chunks of 256, second GEMM accumulates in registers -----
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     }
                 }
                 __syncthreads();
-                if (TR) rows_to_hbm(Hc, LDX, 256, svl + tr.hid + grow0 * F + f * 256, F, T, tid);
+                if (TR) rows_to_hbm(Hc, LDX, 256, svl + (size_t)tr.hid * 64 + grow0 * F + f * 256, F, T, tid);
                 {
                     const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                     // ... and the tail of linear2(f) primes it with linear1(f+1)'s (its own again after the last chunk)
@@ -552,8 +552,8 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
             }
             __syncthreads();
             if (TR)
-                layernorm_rows<true>(X, LW + G2, LW + BE2, wave, lane, svl + tr.z2 + grow0 * D, svl + tr.st2 + grow0 * 2,
-                                     svl + tr.xo + grow0 * D, T);
+                layernorm_rows<true>(X, LW + G2, LW + BE2, wave, lane, svl + (size_t)tr.z2 * 64 + grow0 * D, svl + (size_t)tr.st2 * 64 + grow0 * 2,
+                                     svl + (size_t)tr.xo * 64 + grow0 * D, T);
             else if (!(ABL & 2)) layernorm_rows(X, LW + G2, LW + BE2, wave, lane);
             __syncthreads();
         }

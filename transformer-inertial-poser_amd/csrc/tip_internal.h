@@ -61,7 +61,9 @@ __device__ __forceinline__ unsigned tip_drop_hash(unsigned long long seed, unsig
 // arrays of layer l start `l * layer_stride` further on) and the encoder dropout it applies (site = 4*layer + k).
 struct FusedTrain {
     float* sv;
-    unsigned long long x0, qkv, ast, att, z1, st1, x1, hid, z2, st2, xo, layer_stride;
+    // float offsets into `sv` in units of 64 floats (every stash array is 64-float aligned): 32-bit, because this struct
+    // lives in SGPRs for the whole kernel and the training forward is short of them
+    unsigned x0, qkv, ast, att, z1, st1, x1, hid, z2, st2, xo, layer_stride;
     unsigned long long seed;
     unsigned thresh;   // 0 = dropout off
     float scale;

@@ -1438,9 +1438,10 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         FusedTrain tr;
         tr.sv = W;
         const TrainLayer& t0 = L.layers[0];
-        tr.x0 = L.x0; tr.qkv = t0.qkv; tr.ast = t0.ast; tr.att = t0.att; tr.z1 = t0.z1; tr.st1 = t0.st1; tr.x1 = t0.x1;
-        tr.hid = t0.hid; tr.z2 = t0.z2; tr.st2 = t0.st2; tr.xo = t0.xo;
-        tr.layer_stride = d.L > 1 ? L.layers[1].qkv - t0.qkv : 0;
+        auto u64 = [](size_t off) { return (unsigned)(off / 64); };   // take() aligns every array to 64 floats
+        tr.x0 = u64(L.x0); tr.qkv = u64(t0.qkv); tr.ast = u64(t0.ast); tr.att = u64(t0.att); tr.z1 = u64(t0.z1);
+        tr.st1 = u64(t0.st1); tr.x1 = u64(t0.x1); tr.hid = u64(t0.hid); tr.z2 = u64(t0.z2); tr.st2 = u64(t0.st2); tr.xo = u64(t0.xo);
+        tr.layer_stride = d.L > 1 ? u64(L.layers[1].qkv - t0.qkv) : 0;
         const Drop dr = make_drop(p_drop, seed, 0);
         tr.seed = seed; tr.thresh = dr.thresh; tr.scale = dr.scale;
         // the encoder also pre-fills its windows' HALL rows with the recurrence's hand-off sentinel (saves a 21-MB memset)
