@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="windows (IMU streams) per GPU")
     ap.add_argument("--seq-len", type=int, default=40)
-    ap.add_argument("--plan", default="auto", choices=["auto", "general", "fused", "latency", "fused2"])
+    ap.add_argument("--plan", default="auto", choices=["auto", "general", "fused", "latency", "fused2", "fused2s"])
     ap.add_argument("--rnn-cluster", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")

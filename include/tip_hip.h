@@ -62,6 +62,9 @@ typedef enum tip_status {
 #define TIP_PLAN_FUSED   2 /* one workgroup = one window through all encoder layers (paper configuration) */
 #define TIP_PLAN_FUSED2  4 /* two windows per workgroup (80 rows = 5 MFMA row blocks, no padding); AUTO picks it for
                               B >= 2 x CUs; bit-identical results to TIP_PLAN_FUSED */
+#define TIP_PLAN_FUSED2S 5 /* pair-split: a window pair on TWO co-resident workgroups, columns split, partial sums exchanged
+                              twice per layer (80 rows x half the columns per CU: no row padding at B <= #CUs);
+                              needs 2*ceil(B/2) <= #CUs */
 #define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);
                               AUTO picks it for B <= 64 */
 

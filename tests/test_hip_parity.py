@@ -367,3 +367,55 @@ def test_empty_and_oversized_inputs_raise_like_the_reference():
             m(torch.zeros(1, 4096, 90).cuda(), torch.zeros(1, 4096, 131).cuda())
         y = m(torch.zeros(2, 41, 90).cuda(), torch.zeros(2, 41, 131).cuda())     # past the paper's 40 frames: general plan
         assert y.shape == (2, 41, 131) and torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize("B", [1, 2, 7, 65, 128, 255, 256])
+def test_pair_split_plan(B):
+    """"fused2s": a window pair on two co-resident workgroups, columns split, partial sums exchanged twice per layer.
+    Sums are formed in a different order than in the one-window plan (half 0's heads / hidden units + half 1's), so the
+    comparison with it is by tolerance; within the plan a window's result is bit-identical whatever shares the launch, and
+    run to run (the hand-offs are counted, bounded spins: no time-out may be recorded)."""
+    cfg = synth.PAPER
+    m, w = _gpu_model(cfg, 1)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    if 2 * ((B + 1) // 2) > ncu:
+        pytest.skip("needs every workgroup resident")
+    x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=900 + B, nan_frac=0.01)
+    t0 = tip_amd.lib.spin_timeouts()
+    m.set_plan("fused2s")
+    y = _run(m, x_imu, x_s)
+    for _ in range(3):
+        assert np.array_equal(y, _run(m, x_imu, x_s)), "hand-off race: run-to-run difference"
+    m.set_plan("fused")
+    yf = _run(m, x_imu, x_s)
+    assert np.abs(y - yf).max() < 5e-6
+    if B <= 7:
+        yo = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
+        assert np.abs(y - yo).max() < TOL_TIGHT
+    if B >= 65:
+        # batch independence inside the plan: a sub-batch (different pairing, different partner CUs) gives the same bits
+        sel = np.array([0, 1, 2, B // 2, B - 2, B - 1])
+        sub = np.concatenate([sel, np.arange(3, min(B - 3, 3 + 64))])   # a different pairing of the same windows
+        m.set_plan("fused2s")
+        ysub = _run(m, x_imu[sub], x_s[sub])
+        assert np.array_equal(ysub[:len(sel)], y[sel])
+        # and AUTO picks this plan for 64 < B <= #CUs
+        m.set_plan("auto")
+        assert np.array_equal(_run(m, x_imu, x_s), y)
+        yl = _run(m, x_imu, x_s, last=True)
+        assert np.array_equal(yl, y[:, -1])
+    assert tip_amd.lib.spin_timeouts() == t0
+
+
+def test_pair_split_plan_refuses_what_it_cannot_hold():
+    cfg = synth.PAPER
+    m, _ = _gpu_model(cfg, 0)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    m.set_plan("fused2s")
+    B = ncu + 2                      # more workgroups than CUs: partners could wait for a workgroup that is not resident
+    x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=3)
+    with pytest.raises(RuntimeError):
+        _run(m, x_imu, x_s)
+    with pytest.raises(RuntimeError):   # T != 40
+        with torch.no_grad():
+            m(torch.tensor(x_imu[:4, :17]).cuda(), torch.tensor(x_s[:4, :17]).cuda())

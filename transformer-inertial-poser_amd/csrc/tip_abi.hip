@@ -142,6 +142,8 @@ Workspace carve_workspace(const Dims& d, int B, int T) {
     w.hall = take(Mp * (d.with_rnn ? d.R : 1));
     w.flags = take(rnn_flag_words(B, T) + 64);
     w.lat = take(latency_supported(d, B, T) ? latency_workspace_floats(B, T) : 0);
+    // pair-split plan: partial-sum images two partner workgroups exchange (only batches that can be co-resident use it)
+    w.xchg = take(fused2_supported(d, T) && B <= 1024 ? fused2s_xchg_floats(B) : 0);
     w.total_bytes = off * sizeof(float);
     return w;
 }
@@ -274,7 +276,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
     if (!h) return TIP_ERR_INVALID_ARG;
     switch (option) {
         case TIP_OPT_PLAN:
-            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED2) return TIP_ERR_INVALID_ARG;
+            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED2S) return TIP_ERR_INVALID_ARG;
             h->plan = value;
             return TIP_OK;
         case TIP_OPT_PROFILE:
@@ -531,9 +533,11 @@ int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches
 
 int tip_spin_timeouts(unsigned* count) {
     if (!count) return TIP_ERR_INVALID_ARG;
-    unsigned a = 0, b = 0;
-    if (read_spin_timeouts_general(&a) != hipSuccess || read_spin_timeouts_latency(&b) != hipSuccess) return TIP_ERR_HIP;
-    *count = a + b;
+    unsigned a = 0, b = 0, c = 0;
+    if (read_spin_timeouts_general(&a) != hipSuccess || read_spin_timeouts_latency(&b) != hipSuccess ||
+        read_spin_timeouts_fused2(&c) != hipSuccess)
+        return TIP_ERR_HIP;
+    *count = a + b + c;
     return TIP_OK;
 }
 
@@ -577,8 +581,11 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     }
     if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO && fused2_supported(d, T) && B >= 2 * h->num_cus)
         plan = TIP_PLAN_FUSED2;   // two windows per workgroup once every CU has at least two to chew on
+    else if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO && fused2_supported(d, T) && fused2s_fits(B, h->num_cus))
+        plan = TIP_PLAN_FUSED2S;  // at most one window per CU: window pairs on CU pairs, columns split (no row padding; 3-4 % faster)
     if (plan == TIP_PLAN_FUSED && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (plan == TIP_PLAN_FUSED2S && !(fused2_supported(d, T) && fused2s_fits(B, h->num_cus) && B <= 1024)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
 
     float* enc_out = xa;  // encoder output [M, D]
@@ -597,6 +604,12 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         TIP_TRY(launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall,
                                     B, T, s), "latency_chain");
         rnn_done = true;
+    } else if (plan == TIP_PLAN_FUSED2S) {
+        StageScope sc(h, s, "fused_encoder");
+        ih_done = true;
+        hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
+        TIP_TRY(launch_fused_encoder2s(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr,
+                                       W0 + ws.xchg, B, h->num_cus, s), "fused_encoder2s");
     } else if (plan == TIP_PLAN_FUSED2) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = true;

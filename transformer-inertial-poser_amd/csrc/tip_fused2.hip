@@ -367,6 +367,358 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pair-split plan ("fused2s"): the same two-window workgroup, but a window PAIR is shared by TWO workgroups on two CUs of
+// one XCD, split by COLUMNS.  Why: with one window per CU (B = #CUs) the 40 rows pad to 3 MFMA row blocks, and no
+// assignment of whole row blocks to CUs can do better (10 240 rows = 640 blocks on 256 CUs is 2.5 each).  Here every CU
+// carries 80 rows (5 blocks, no padding) of HALF the columns: 2.5 block-columns instead of 3.
+//   half h owns heads 8h .. 8h+7 (Q|K|V projection, attention), the K-half of the out-projection that those heads feed,
+//   FFN hidden units 512h .. 512h+511 (linear1 chunks, and the K-half of linear2 they feed), columns 256h .. of the
+//   RNN input projection.  in_linear, the residual stream and both LayerNorms are carried in full by both (identical bits).
+// Two hand-offs per layer: the [80 x 256] partial sums of the out-projection and of linear2 are exchanged as register
+// images ([wave][tile][lane] float4: the partner has the same thread -> element mapping) through a 2-slot buffer in
+// HBM/L2, and both sides add them in the same order (half 0 + half 1).  Protocol per hand-off k: image stores ->
+// s_waitcnt vmcnt(0) -> flag[h] = k + 1 (agent scope); poll flag[1 - h] >= k + 1 (bounded) -> sc1 (L1-bypassing) loads.
+// Slot k & 1 is free again when the partner's flag k has been seen (it read slot k - 1's predecessor before producing k).
+// The partners' XCC ids are compared at run time: same XCD -> plain stores (shared L2); otherwise agent-scope stores.
+// All 2 * ceil(B / 2) workgroups must be co-resident (the launcher checks grid <= #CUs; one workgroup per CU by LDS size).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ unsigned g_spin_timeouts_fused2;
+__device__ unsigned g_f2s_cross_xcd;
+__device__ unsigned long long g_f2s_trace[32];   // measurement: s_memtime stamps of workgroup 0 around its hand-offs
+__device__ __forceinline__ void note_spin_timeout() { atomicAdd(&g_spin_timeouts_fused2, 1u); }
+hipError_t read_spin_timeouts_fused2(unsigned* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spin_timeouts_fused2), sizeof(unsigned));
+}
+
+namespace f2 {
+constexpr int IMG_FLOATS = ROWS * D;                 // one partial-sum image: 8 waves x 10 tiles x 64 lanes x 4
+constexpr int PAIR_IMG_FLOATS = 4 * IMG_FLOATS;      // per pair: [slot 2][half 2] images
+constexpr int PAIR_FLAG_WORDS = 32;                  // per pair, behind ALL images: [0..1] hand-off counters, [16..17] XCC id + 1
+}
+size_t fused2s_xchg_floats(int B) { return (size_t)((B + 1) / 2) * (f2::PAIR_IMG_FLOATS + f2::PAIR_FLAG_WORDS); }
+
+__global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
+    const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
+    const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ ih_out, unsigned* __restrict__ hall_sentinel,
+    float* __restrict__ xchg, int xchg_bytes, int B, int NI, int S, int L, int wbytes, int ih_off_b) {
+    using namespace f2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int s_same_xcd;
+    float* X = smem;
+    float* C = smem + X_FLOATS;
+    float* Qp = C;
+    float* Kp = C + PROWS * LDQ;
+    float* Vt = C + 2 * PROWS * LDQ;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xchg, 0, xchg_bytes, 0x00020000);
+    const int voff = lane * 16;
+    const int npairs = (B + 1) / 2;
+    // workgroup -> (pair, half): the two halves of a pair are 8 workgroup ids apart, i.e. on the same XCD when ids go
+    // round-robin over the 8 XCDs (checked below, never assumed)
+    const int xslot = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int half = jj & 1;
+    const int pair = (jj >> 1) * 8 + xslot;
+    if (pair >= npairs) return;                           // (both halves of a surplus pair leave together)
+    float* px = xchg + (size_t)pair * PAIR_IMG_FLOATS;
+    unsigned* pflag = reinterpret_cast<unsigned*>(xchg + (size_t)npairs * PAIR_IMG_FLOATS) + pair * PAIR_FLAG_WORDS;
+    const int px_off_b = (int)((size_t)pair * PAIR_IMG_FLOATS * 4);
+
+    auto rows_off = [&](int (&off)[RB], int base, int ld) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) off[r] = base + (r * 16 + l15) * ld + lg * 4;
+    };
+    if (tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_store(pflag + 16 + half, (xcc & 0xf) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_same_xcd = -1;                                  // decided at the first hand-off
+    }
+    for (int i = tid; i < C_FLOATS; i += THREADS) C[i] = 0.f;
+    __syncthreads();
+
+    const int win0 = pair * 2;
+    const int nwin = (win0 + 1 < B) ? 2 : 1;
+    int handoff = 0;                                      // hand-offs done so far (uniform)
+
+    // X[:, all columns] += (partial of half 0 + partial of half 1) + bias: acc holds THIS half's partial.
+    // (A wave-to-wave variant — every wave publishing its own 10 tiles under its own counter and waiting only for its twin,
+    // no workgroup barrier inside the hand-off — measured SLOWER: 0.787 vs 0.768 ms per step.)
+    auto exchange_add = [&](f32x4 (&acc)[RB][2], const float* bias) {
+        if (tid == 0 && s_same_xcd < 0) {                  // first hand-off: are the partners on one XCD?
+            unsigned mine = 0, theirs = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(mine));
+            mine = (mine & 0xf) + 1u;
+            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                theirs = __hip_atomic_load(pflag + 16 + (1 - half), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (theirs) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!theirs) note_spin_timeout();
+            if (theirs != mine) atomicAdd(&g_f2s_cross_xcd, 1u);   // (measurement: pairs that straddle XCDs)
+            s_same_xcd = theirs == mine ? 1 : 0;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && tid == 0 && handoff < 8) g_f2s_trace[handoff * 4 + 0] = __builtin_amdgcn_s_memtime();
+        const bool same = s_same_xcd == 1;
+        const int slot = handoff & 1;
+        float* mine_img = px + (size_t)(slot * 2 + half) * IMG_FLOATS;
+        const int their_off_b = px_off_b + (slot * 2 + (1 - half)) * IMG_FLOATS * 4;
+        // image: [wave][r * 2 + n][lane] float4
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float* dst = mine_img + ((wave * (RB * 2) + r * 2 + n) * 64 + lane) * 4;
+                if (same) {
+                    *reinterpret_cast<f32x4*>(dst) = acc[r][n];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) __hip_atomic_store(dst + e, acc[r][n][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's image stores are acknowledged ...
+        __syncthreads();                                   // ... before the one counter store that publishes them
+        if (blockIdx.x == 0 && tid == 0 && handoff < 8) g_f2s_trace[handoff * 4 + 1] = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            __hip_atomic_store(pflag + half, (unsigned)(handoff + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            for (; spins < (1u << 22); ++spins) {
+                if (__hip_atomic_load(pflag + (1 - half), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(handoff + 1)) break;
+                if (!same) __builtin_amdgcn_s_sleep(1);
+            }
+            if (spins == (1u << 22)) note_spin_timeout();
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && tid == 0 && handoff < 8) g_f2s_trace[handoff * 4 + 2] = __builtin_amdgcn_s_memtime();
+        f32x4 other[RB][2];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+                other[r][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                  xrs, lane * 16, their_off_b + (wave * (RB * 2) + r * 2 + n) * 1024, 16));   // sc1: not from L1
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = (wave * 2 + n) * 16 + l15;
+            const float bv = bias[col];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float p0 = half == 0 ? acc[r][n][e] : other[r][n][e];
+                    const float p1 = half == 0 ? other[r][n][e] : acc[r][n][e];
+                    X[(r * 16 + lg * 4 + e) * LDX + col] += (p0 + p1) + bv;
+                }
+        }
+        if (blockIdx.x == 0 && tid == 0 && handoff < 8) g_f2s_trace[handoff * 4 + 3] = __builtin_amdgcn_s_memtime();
+        ++handoff;
+    };
+
+    {
+        const int in_soff = (int)(IN_W * 4) + (wave * 2) * (KIN / 16) * 1024;
+        WRing2<2> g_in;
+        ring2_prefetch<2>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
+        // ---- prologue (:63-78) for both windows (carried by both halves) -------------------------------------------------
+        float* U = C;
+        for (int i = tid; i < ROWS * LDU; i += THREADS) U[i] = 0.f;
+        __syncthreads();
+        for (int w = 0; w < nwin; ++w) {
+            const float* xi = x_imu + (size_t)(win0 + w) * T * NI;
+            for (int i = tid; i < T * NI; i += THREADS) {
+                const int r = i / NI, c = i - r * NI;
+                U[(w * T + r) * LDU + c] = xi[i];
+            }
+            const float* xs = x_s + (size_t)(win0 + w) * T * S;
+            const float* km = keep_mask ? keep_mask + (size_t)(win0 + w) * T * S : nullptr;
+            for (int i = tid; i < T * S; i += THREADS) {
+                const int r = i / S, c = i - r * S;
+                float v = xs[i];
+                if (v != v) v = 0.f;                  // :65
+                if (km) v = v * km[i] * keep_scale;   // :77
+                U[(w * T + r) * LDU + NI + c] = v;
+            }
+        }
+        __syncthreads();
+        // ---- in_linear (:79) + channel shuffle (folded), all 256 columns on both halves ----------------------------------
+        f32x4 acc[RB][2];
+        zero_acc2<RB, 2>(acc);
+        int au[RB];
+        rows_off(au, X_FLOATS, LDU);
+        gemm_phase2<RB, 2, KIN / 16>(acc, smem, au, rsrc, voff, in_soff, (KIN / 16) * 1024, g_in, in_soff, (KIN / 16) * 1024);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = (wave * 2 + n) * 16 + l15;
+            const float bv = wts[IN_B + col];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] = acc[r][n][e] + bv;
+        }
+    }
+    __syncthreads();
+
+    WRing2<1> g_q;   // Q|K projection ring of the next quad: primed one phase ahead (here for layer 0, quad 2 * half)
+    ring2_prefetch<1>(g_q, rsrc, voff, (int)(LAYER0 * 4) + (int)(QKV_W * 4) + ((wave >> 2) * 16 + half * 8 + (wave & 3)) * 16 * 1024, 0);
+#pragma unroll 1
+    for (int layer = 0; layer < L; ++layer) {
+        const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
+        const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
+        f32x4 acc_o[RB][2];
+        zero_acc2<RB, 2>(acc_o);
+        WRing2<2> g_o, g_f2r;
+        WRing2<1> g_v, g_f1;
+#pragma unroll 1
+        for (int qq = 0; qq < 2; ++qq) {
+            const int q = half * 2 + qq;              // this half's quads
+            const int hl = wave & 3;
+            const int head = q * 4 + hl;
+            {
+                const int isk = wave >> 2;            // 0: Q, 1: K
+                f32x4 acc[RB][1];
+                zero_acc2<RB, 1>(acc);
+                const int soff = lbase + (int)(QKV_W * 4) + (isk * 16 + head) * 16 * 1024;
+                int ax[RB];
+                rows_off(ax, 0, LDX);
+                gemm_phase2<RB, 1, 16>(acc, smem, ax, rsrc, voff, soff, 0, g_q, soff, 0);
+                const int vsoff = lbase + (int)(QKV_W * 4) + (32 + head) * 16 * 1024;
+                ring2_prefetch<1>(g_v, rsrc, voff, vsoff, 0);
+                const float bv = LW[QKV_B + isk * D + head * 16 + l15];
+                float* plane = isk ? Kp : Qp;
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        plane[prow(r * 16 + lg * 4 + e) * LDQ + hl * 16 + l15] = acc[r][0][e] + bv;
+                const float bvv = LW[QKV_B + 2 * D + head * 16 + l15];
+                if (wave < 4) {
+                    f32x4 av[3][1];
+                    zero_acc2<3, 1>(av);
+                    const int ar[3] = {ax[0], ax[1], ax[2]};
+                    gemm_phase2<3, 1, 16>(av, smem, ar, rsrc, voff, vsoff, 0, g_v, vsoff, 0);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            Vt[(hl * 16 + l15) * LDV + prow(r * 16 + lg * 4 + e)] = av[r][0][e] + bvv;
+                } else {
+                    f32x4 av[2][1];
+                    zero_acc2<2, 1>(av);
+                    const int ar[2] = {ax[3], ax[4]};
+                    gemm_phase2<2, 1, 16>(av, smem, ar, rsrc, voff, vsoff, 0, g_v, vsoff, 0);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            Vt[(hl * 16 + l15) * LDV + prow((r + 3) * 16 + lg * 4 + e)] = av[r][0][e] + bvv;
+                }
+                for (int i = tid; i < 64 * 16; i += THREADS) {
+                    const int ch = i >> 4, k = i & 15;
+                    Vt[ch * LDV + (k < 8 ? T + k : 48 + T + (k - 8))] = 0.f;
+                }
+                ring2_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + q * 4) * 1024, 16 * 1024);
+            }
+            __syncthreads();
+            {
+                const int w = wave >> 2;
+                if (w < nwin)
+                    attention_head_mfma<LDQ, LDV>(Qp + w * 48 * LDQ, Kp + w * 48 * LDQ, Vt + w * 48, hl * 16, lane, T);
+            }
+            __syncthreads();
+            if (qq == 0)
+                ring2_prefetch<1>(g_q, rsrc, voff,
+                                  lbase + (int)(QKV_W * 4) + ((wave >> 2) * 16 + (q + 1) * 4 + (wave & 3)) * 16 * 1024, 0);
+            else
+                ring2_prefetch<1>(g_f1, rsrc, voff, lbase + (int)(W1_W * 4) + (half * 32 + wave) * 16 * 1024, 0);
+            {
+                const int osoff = lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + q * 4) * 1024;
+                int ao[RB];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) ao[r] = X_FLOATS + prow(r * 16 + l15) * LDQ + lg * 4;
+                gemm_phase2<RB, 2, 4>(acc_o, smem, ao, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
+            }
+            __syncthreads();
+        }
+        exchange_add(acc_o, LW + WO_B);               // X += out-projection (both halves' heads) + bias
+        __syncthreads();
+        layernorm_rows2(X, LW + G1, LW + BE1, wave, lane);
+        __syncthreads();
+        // ---- feed-forward: this half's 4 hidden chunks of 128; its K-half of linear2 accumulates in registers ---------------
+        float* Hc = C;
+        f32x4 acc_f[RB][2];
+        zero_acc2<RB, 2>(acc_f);
+#pragma unroll 1
+        for (int ff = 0; ff < 4; ++ff) {
+            const int f = half * 4 + ff;
+            {
+                f32x4 acc[RB][1];
+                zero_acc2<RB, 1>(acc);
+                const int w1off = lbase + (int)(W1_W * 4) + (f * 8 + wave) * 16 * 1024;
+                int ax[RB];
+                rows_off(ax, 0, LDX);
+                gemm_phase2<RB, 1, 16>(acc, smem, ax, rsrc, voff, w1off, 0, g_f1, w1off, 0);
+                ring2_prefetch<2>(g_f2r, rsrc, voff, lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 8) * 1024, 64 * 1024);
+                const int col = wave * 16 + l15;
+                const float bv = LW[W1_B + f * 128 + col];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) Hc[(r * 16 + lg * 4 + e) * LDH + col] = fmaxf(acc[r][0][e] + bv, 0.f);
+            }
+            __syncthreads();
+            {
+                if (ff < 3) ring2_prefetch<1>(g_f1, rsrc, voff, lbase + (int)(W1_W * 4) + ((f + 1) * 8 + wave) * 16 * 1024, 0);
+                const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 8) * 1024;
+                int ah[RB];
+                rows_off(ah, X_FLOATS, LDH);
+                gemm_phase2<RB, 2, 8>(acc_f, smem, ah, rsrc, voff, w2off, 64 * 1024, g_f2r, w2off, 64 * 1024);
+            }
+            __syncthreads();
+        }
+        if (layer + 1 < L)                              // next layer's first Q|K ring flies during the hand-off and LayerNorm2
+            ring2_prefetch<1>(g_q, rsrc, voff, lbase + (int)(LAYER_FLOATS * 4) + (int)(QKV_W * 4) +
+                                                   ((wave >> 2) * 16 + half * 8 + (wave & 3)) * 16 * 1024, 0);
+        exchange_add(acc_f, LW + W2_B);               // X += linear2 (both halves' hidden units) + bias
+        __syncthreads();
+        layernorm_rows2(X, LW + G2, LW + BE2, wave, lane);
+        __syncthreads();
+    }
+    // ---- RNN input projection, columns 256 * half ..: IH = X W_ih^T + (b_ih + b_hh) -> HBM ------------------------------------
+    {
+        f32x4 acc[RB][2];
+        zero_acc2<RB, 2>(acc);
+        const int isoff = ih_off_b + (half * 16 + wave * 2) * 16 * 1024;
+        WRing2<2> g_ih;
+        ring2_prefetch<2>(g_ih, rsrc, voff, isoff, 16 * 1024);
+        int ax[RB];
+        rows_off(ax, 0, LDX);
+        gemm_phase2<RB, 2, 16>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
+        float* io = ih_out + (size_t)win0 * T * R;
+        const int nrows = nwin * T;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = (half * 16 + wave * 2 + n) * 16 + l15;
+            const float bv = wts[ih_off_b / 4 + R * D + col];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = r * 16 + lg * 4 + e;
+                    if (row < nrows) io[(size_t)row * R + col] = acc[r][n][e] + bv;
+                }
+        }
+    }
+    if (hall_sentinel) {   // each half arms half of the pair's HALL rows
+        uint4* hp = reinterpret_cast<uint4*>(hall_sentinel + (size_t)win0 * T * R);
+        const int n4 = nwin * T * (R / 4), h0 = half * (n4 / 2), h1 = half ? n4 : n4 / 2;
+        for (int i = h0 + tid; i < h1; i += THREADS) hp[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
+}
+
 bool fused2_supported(const Dims& d, int T) { return fused_supported(d, T) && fused_has_rnn_ih(d) && T == f2::T; }
 
 hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
@@ -385,6 +737,34 @@ hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const floa
     const size_t ih_off = f2::LAYER0 + (size_t)d.L * f2::LAYER_FLOATS;
     hipLaunchKernelGGL(fused_encoder2_kernel, dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
                        keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, d.n_imu_total, d.S, d.L,
+                       (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4));
+    return hipGetLastError();
+}
+
+bool fused2s_fits(int B, int num_cus) { return B >= 1 && 2 * ((B + 1) / 2) <= num_cus; }
+
+hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
+                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
+                                  int B, int num_cus, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (!fused2s_fits(B, num_cus)) return hipErrorInvalidValue;       // every workgroup must be resident: partners wait for each other
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder2s_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, f2::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int npairs = (B + 1) / 2;
+    const size_t xbytes = fused2s_xchg_floats(B) * sizeof(float);
+    if (xbytes > 0x7fffffffull) return hipErrorInvalidValue;
+    // hand-off counters and XCC words (behind all images) start from zero every forward
+    hipError_t e = hipMemsetAsync(xchg + (size_t)npairs * f2::PAIR_IMG_FLOATS, 0, (size_t)npairs * f2::PAIR_FLAG_WORDS * 4, s);
+    if (e != hipSuccess) return e;
+    const int grid = (2 * npairs + 15) / 16 * 16;                      // whole (xcd, j) blocks of the id -> (pair, half) map
+    const size_t ih_off = f2::LAYER0 + (size_t)d.L * f2::LAYER_FLOATS;
+    hipLaunchKernelGGL(fused_encoder2s_kernel, dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+                       keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), xchg, (int)xbytes, B, d.n_imu_total, d.S, d.L,
                        (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4));
     return hipGetLastError();
 }
@@ -439,3 +819,12 @@ hipError_t launch_pgemm(const float* A, int lda, const float* wfrag, size_t wfra
 }
 
 }  // namespace tip
+
+extern "C" int tip_debug_read_f2s_cross_xcd(unsigned* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tip::g_f2s_cross_xcd), sizeof(unsigned)) == hipSuccess ? 0 : -5;
+}
+
+extern "C" int tip_debug_read_f2s_trace(unsigned long long* out, int n) {
+    if (!out || n < 0 || n > 32) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tip::g_f2s_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
+}

@@ -138,7 +138,7 @@ struct PackBatch {
 
 // Workspace carve-up for the general plan (float offsets), M = B*T rows.
 struct Workspace {
-    size_t xa, xb, big, att, hall, flags, lat;  // float offsets
+    size_t xa, xb, big, att, hall, flags, lat, xchg;  // float offsets
     size_t total_bytes;
 };
 
@@ -287,9 +287,16 @@ hipError_t launch_latency_head(const float* A, long long lda, const float* wfrag
 
 hipError_t read_spin_timeouts_general(unsigned* out);
 hipError_t read_spin_timeouts_latency(unsigned* out);
+hipError_t read_spin_timeouts_fused2(unsigned* out);
 
 // ---- two-window fused encoder (tip_fused2.hip): 80 rows = 5 MFMA row blocks, no padding; for >= 2 windows per CU ----
 bool fused2_supported(const Dims& d, int T);
+// pair-split form: a window pair on two co-resident workgroups (columns split), for B <= #CUs (tip_fused2.hip)
+bool fused2s_fits(int B, int num_cus);
+size_t fused2s_xchg_floats(int B);
+hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
+                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
+                                  int B, int num_cus, hipStream_t s);
 hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, int B,
                                  int num_cus, hipStream_t s);
