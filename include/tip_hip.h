@@ -64,7 +64,7 @@ typedef enum tip_status {
                               B >= 2 x CUs; bit-identical results to TIP_PLAN_FUSED */
 #define TIP_PLAN_FUSED2S 5 /* pair-split: a window pair on TWO co-resident workgroups, columns split, partial sums exchanged
                               twice per layer (80 rows x half the columns per CU: no row padding at B <= #CUs);
-                              needs 2*ceil(B/2) <= #CUs */
+                              needs 2*ceil(B/2) <= #CUs; AUTO picks it for 64 < B <= #CUs */
 #define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);
                               AUTO picks it for B <= 64 */
 
