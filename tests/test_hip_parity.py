@@ -45,7 +45,7 @@ PLANS = ["general", "fused"]
 ALL_PLANS = ["general", "fused", "latency"]
 
 
-@pytest.mark.parametrize("plan", ALL_PLANS)
+@pytest.mark.parametrize("plan", ALL_PLANS + ["fused2s"])
 def test_golden_vectors(golden, plan):
     _dev()
     models = {}
@@ -56,6 +56,8 @@ def test_golden_vectors(golden, plan):
         key = (tag.split("_B")[0])
         if plan != "general" and not tag.startswith("paper"):
             continue   # fused / latency plans specialise the paper configuration; other configs take the general plan
+        if plan == "fused2s" and case["x_imu"].shape[1] != 40:
+            continue   # the two-window kernels are built for T = 40
         if key not in models:
             models[key] = _gpu_model(cfg, seed_for_tag(tag))[0]
             models[key].set_plan(plan)
@@ -179,10 +181,14 @@ def test_keep_mask_semantics(golden):
     p = float(case["p"][0])
     y = torch.empty(2, 40, 131, device="cuda")
     ws = torch.empty(h.workspace_bytes(2, 40), dtype=torch.uint8, device="cuda")
-    h.forward(xi.data_ptr(), xs.data_ptr(), y.data_ptr(), 2, 40, tlib.TIP_FWD_KEEP_MASK, mask.data_ptr(),
-              1.0 / (1.0 - p), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    assert np.abs(y.cpu().numpy() - case["y64"]).max() < TOL_TIGHT
+    for plan in (tlib.TIP_PLAN_AUTO, tlib.TIP_PLAN_FUSED, tlib.TIP_PLAN_FUSED2, tlib.TIP_PLAN_FUSED2S):
+        h.set_option(tlib.TIP_OPT_PLAN, plan)
+        y.zero_()
+        h.forward(xi.data_ptr(), xs.data_ptr(), y.data_ptr(), 2, 40, tlib.TIP_FWD_KEEP_MASK, mask.data_ptr(),
+                  1.0 / (1.0 - p), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.abs(y.cpu().numpy() - case["y64"]).max() < TOL_TIGHT, plan
+    h.set_option(tlib.TIP_OPT_PLAN, tlib.TIP_PLAN_AUTO)
 
 
 def test_past_state_dropout_is_live_in_eval():
