@@ -62,11 +62,15 @@ __device__ __forceinline__ void gemm_phase2(f32x4 (&acc)[NRB][NBW], const float*
         mfma_block2<NRB, NBW>(acc, a0, g.w0);
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w0[n] = ldfrag2(rsrc, voff, o + n * st);
+        // pin the refill here: left alone, the scheduler sinks it behind the second MFMA block, next to its use at the top of the
+        // next trip — the two-k-block prefetch then covers two MFMAs instead of forty
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < NRB; ++r) a0[r] = *reinterpret_cast<const float4*>(lds + aoff[r] + (kb + 2) * 16);
         mfma_block2<NRB, NBW>(acc, a1, g.w1);
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w1[n] = ldfrag2(rsrc, voff, o + n * st + 1024);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
