@@ -228,7 +228,7 @@ __device__ __forceinline__ void ring_prefetch(WRing<NBW>& g, __amdgpu_buffer_rsr
 //   loop => counted vmcnt waits); for the LAST pair it is redirected to k-blocks 0,1 of the NEXT phase
 //   (nsoff / nnstride_b), so on exit the ring is already primed for a following phase of the same width.
 //   Callers without such a successor pass their own soff (a harmless in-bounds reload).
-template <int NBW, int KB, bool NOMMA = false, int SWAPN = 0>
+template <int NBW, int KB, bool NOMMA = false, int SWAPN = 0, bool PIN = true>
 __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[fz::RB][NBW], const float* As, int lda, __amdgpu_buffer_rsrc_t rsrc,
                                            int voff, int soff, int nstride_b, WRing<NBW>& g, int nsoff, int nnstride_b) {
     static_assert(KB % 2 == 0, "k-blocks are processed in pairs");
@@ -248,12 +248,16 @@ __device__ __forceinline__ void gemm_phase(f32x4 (&acc)[fz::RB][NBW], const floa
         else { asm volatile("" :: "v"(a0[0].x), "v"(g.w0[0].x)); }
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w0[n] = load_frag(rsrc, voff, o + n * st);
+        // PIN: keep the refill here (the scheduler may sink it towards its use).  Measured: helps the training forward and the
+        // backward kernels by ~1 %, costs the stash-free inference kernel 0.7 % — which therefore opts out
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < fz::RB; ++r) a0[r] = *reinterpret_cast<const float4*>(As + r * 16 * lda + (kb + 2) * 16);
         if (!NOMMA) mfma_block<NBW, SWAPN>(acc, a1, g.w1);
         else { asm volatile("" :: "v"(a1[0].x), "v"(g.w1[0].x)); }
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w1[n] = load_frag(rsrc, voff, o + n * st + 1024);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
         {
             f32x4 acc[RB][2];
             zero_acc<2>(acc);
-            gemm_phase<2, KIN / 16, (ABL & 4) != 0>(acc, U + l15 * LDU + lg * 4, LDU, rsrc, voff, in_soff, (KIN / 16) * 1024, g_in, in_soff,
+            gemm_phase<2, KIN / 16, (ABL & 4) != 0, 0, TR>(acc, U + l15 * LDU + lg * 4, LDU, rsrc, voff, in_soff, (KIN / 16) * 1024, g_in, in_soff,
                                     (KIN / 16) * 1024);
             // layer 0, chunk 0 QKV fragments fly during the epilogue + barrier
             ring_prefetch<3>(g_qkv, rsrc, voff, (int)(LAYER0 * 4) + (int)(QKV_W * 4) + wave * 16 * 1024, 16 * 16 * 1024);
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     // Q and K are projected with swapped MFMA operands: their accumulators come out as (channels 4*lg + e,
                     // row l15) — the fragments S^T = K Q^T wants — and V in the plain layout P V wants, so this wave's head
                     // runs projection -> scores -> softmax -> P V entirely in registers: no Q/K/V planes, no barrier here.
-                    gemm_phase<3, 16, (ABL & 4) != 0, 2>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, qsoff, 16 * 16 * 1024, g_qkv,
+                    gemm_phase<3, 16, (ABL & 4) != 0, 2, TR>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, qsoff, 16 * 16 * 1024, g_qkv,
                                                          qsoff, 16 * 16 * 1024);
                     // out-projection fragments of this chunk fly during the attention
                     ring_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + c * 8) * 1024, 16 * 1024);
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                 // out-projection partial: acc_o += O_chunk[48 x 128] * Wo[:, 128c .. 128c+127]^T
                 {
                     const int osoff = lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + c * 8) * 1024;
-                    gemm_phase<2, 8, (ABL & 4) != 0>(acc_o, Qc + l15 * LDC + lg * 4, LDC, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
+                    gemm_phase<2, 8, (ABL & 4) != 0, 0, TR>(acc_o, Qc + l15 * LDC + lg * 4, LDC, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
                 }
                 __syncthreads();
             }
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     const int w1off = lbase + (int)(W1_W * 4) + nb0 * 16 * 1024;
                     const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                     // chained: the tail of linear1(f) primes the ring with linear2(f)'s first fragments
-                    gemm_phase<2, 16, (ABL & 4) != 0>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, w1off, 16 * 1024, g_f, w2off, 64 * 1024);
+                    gemm_phase<2, 16, (ABL & 4) != 0, 0, TR>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, w1off, 16 * 1024, g_f, w2off, 64 * 1024);
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         const int col = (wave * 2 + n) * 16 + l15;
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                     // ... and the tail of linear2(f) primes it with linear1(f+1)'s (its own again after the last chunk)
                     const int nxt = f < 3 ? lbase + (int)(W1_W * 4) + ((f + 1) * 16 + wave * 2) * 16 * 1024 : w2off;
-                    gemm_phase<2, 16, (ABL & 4) != 0>(acc_f, Hc + l15 * LDX + lg * 4, LDX, rsrc, voff, w2off, 64 * 1024, g_f, nxt,
+                    gemm_phase<2, 16, (ABL & 4) != 0, 0, TR>(acc_f, Hc + l15 * LDX + lg * 4, LDX, rsrc, voff, w2off, 64 * 1024, g_f, nxt,
                                       f < 3 ? 16 * 1024 : 64 * 1024);
                 }
                 __syncthreads();
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
             WRing<4> g_ih;   // once per window: primed in place (one exposed L2 round trip per window)
             ring_prefetch<4>(g_ih, rsrc, voff, isoff, 16 * 1024);
 
-            gemm_phase<4, 16, (ABL & 4) != 0>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
+            gemm_phase<4, 16, (ABL & 4) != 0, 0, TR>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
             float* io = ih_out + (size_t)win * T * R;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
