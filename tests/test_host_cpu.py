@@ -169,3 +169,47 @@ def test_zero_edit_drop_in_import_path():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd="/tmp")
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip().splitlines()[-1] == "20 True"
+
+
+def test_stock_nn_composite_matches_golden(golden):
+    """oracle/torch_stock.py (stock nn.Linear / nn.TransformerEncoder / nn.RNN, the CPU dispatch the reference takes and the
+    bench's cpu_baseline) against the vectors captured from the reference: same modules, same kernels -> same bits."""
+    from oracle import torch_stock
+    for tag, case in golden.items():
+        cfg = cfg_for_tag(tag)
+        m = torch_stock.build(cfg, synth.make_weights(cfg, seed=seed_for_tag(tag)))
+        km = torch.tensor(case["mask"]) if "mask" in tag else None
+        ks = 1.0 / (1.0 - float(case["p"][0])) if "mask" in tag else 1.0
+        with torch.no_grad():
+            y = m(torch.tensor(case["x_imu"]), torch.tensor(case["x_s"]), km, ks).numpy()
+        if km is None:
+            assert np.array_equal(y, case["y32"]), (tag, np.abs(y - case["y32"]).max())
+        else:
+            assert np.abs(y - case["y32"]).max() < 2e-6, tag     # x * mask * 1.25 vs torch's fused dropout scaling
+
+
+@pytest.mark.parametrize("cfg", [synth.PAPER, dict(synth.TINY, with_rnn=False)])
+def test_reset_parameters_matches_torch_initialisers(cfg):
+    """Training from scratch under train_model.py depends on the initial distributions: every tensor of the drop-in must be
+    drawn like the stock module's (nn.Linear kaiming-uniform(a=sqrt 5) = U(+-1/sqrt(fan_in)) for weight and bias,
+    nn.MultiheadAttention xavier-uniform in_proj + zero biases, nn.LayerNorm ones/zeros, nn.RNN U(+-1/sqrt(hidden)))."""
+    from oracle import torch_stock
+    torch.manual_seed(7)
+    ours = make_model(cfg)
+    theirs = torch_stock.StockTIP(cfg)
+    sd_o, sd_t = ours.state_dict(), theirs.state_dict()
+    assert list(sd_o.keys()) == list(sd_t.keys())
+    for k in sd_o:
+        a, b = sd_o[k].double(), sd_t[k].double()
+        assert a.shape == b.shape, k
+        if float(b.abs().max()) == 0.0 or float((b - 1.0).abs().max()) == 0.0:
+            assert torch.equal(a, b), k                      # constants: zeros (attention biases, LN beta) / ones (LN gamma)
+            continue
+        # uniform on [-bound, bound]: torch's own draw estimates the bound; ours must fill the same interval
+        n = a.numel()
+        bound = float(b.abs().max()) * (n + 1) / n           # unbiased max estimate of a uniform
+        assert float(a.abs().max()) <= bound * (1.0 + 8.0 / n) + 1e-12, k
+        assert float(a.abs().max()) >= bound * (1.0 - 8.0 / n) - 1e-12 or n < 64, k
+        tol = 4.0 / np.sqrt(n)                               # ~4 sigma of the sample statistics of a uniform
+        assert abs(float(a.mean())) <= bound * tol, k
+        assert abs(float(a.std()) / (bound / np.sqrt(3.0)) - 1.0) <= 1.5 * tol + 0.01, k

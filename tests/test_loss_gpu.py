@@ -153,3 +153,23 @@ def test_loud_failures_and_argument_checks():
     assert lib.tip_loss_ws_bytes(2, 5, ctypes.byref(nb)) == 0 and nb.value == 64
     assert lib.tip_loss_forward(p.data_ptr(), 100, g.data_ptr(), 131, 2, 5, 108, 3, 5, 7, stats.data_ptr(), ws.data_ptr(), 512, None) == -1
     assert lib.tip_loss_forward(p.data_ptr(), 131, None, 0, 2, 5, 108, 3, 5, 7, stats.data_ptr(), ws.data_ptr(), 512, None) == -1
+
+
+@pytest.mark.parametrize("tag", ["c17", "c24", "c64"])
+def test_constraint_loss_with_more_than_16_constraints_per_row(tag):
+    """loss_constr_multi accepts any (bs, 4*N) (learning_utils.py:13-35); the flag columns of N > 16 constraints span more
+    than one sweep of the workgroup's threads over a 16-row tile: every BCE term and every gradient entry must be there.
+    Golden = the REAL reference function (make_loss_golden.py WIDE_CASES)."""
+    from make_loss_golden import WIDE_CASES, make_constr_case
+    z = np.load(GOLD)
+    gt, pred = make_constr_case(*WIDE_CASES[tag])
+    rb = torch.tensor(pred).cuda().requires_grad_(True)
+    loss = tip_amd.learning_utils.loss_constr_multi(torch.tensor(gt).cuda(), rb)
+    loss.backward(inputs=[rb])
+    assert close([float(loss)], z[tag + "/loss"], REL), (float(loss), z[tag + "/loss"])
+    g, gr = rb.grad.cpu().numpy(), z[tag + "/grad"]
+    assert np.isfinite(g).all() and np.all(g[7] == 0.0)
+    assert np.abs(g - gr).max() <= REL * max(1.0, np.abs(gr).max())
+    o_loss, o_grad = loss_oracle.loss_constr_multi(gt, pred)
+    assert abs(float(loss) - o_loss) <= 2e-6 * abs(o_loss), (float(loss), o_loss)
+    assert np.abs(g - o_grad).max() <= 2e-6 * np.abs(o_grad).max()

@@ -77,3 +77,18 @@ def test_separate_functions_match_reference():
         full[sl] = g
         ref = z[f"mix_{name}/grad"]
         assert np.abs(full - ref).max() <= REL * max(1.0, np.abs(ref).max()), name
+
+
+def test_constraint_loss_with_many_constraints_matches_reference():
+    """loss_constr_multi for N = 17 / 24 / 64 constraints per row (the model emits 5): reference-generated golden."""
+    from make_loss_golden import WIDE_CASES, make_constr_case
+    z = np.load(GOLD)
+    for tag, args in WIDE_CASES.items():
+        gt, pred = make_constr_case(*args)
+        chk = np.array([pred.astype(np.float64).sum(), np.nansum(gt.astype(np.float64)), np.isnan(gt).sum()])
+        assert np.allclose(chk, z[tag + "/insum"], rtol=0, atol=1e-9)
+        l, g = loss_oracle.loss_constr_multi(gt, pred)
+        assert close([l], z[tag + "/loss"]), tag
+        ref = z[tag + "/grad"]
+        assert np.abs(g - ref).max() <= REL * max(1.0, np.abs(ref).max()), tag
+        assert np.all(g[7] == 0.0) and np.all(ref[7] == 0.0)

@@ -798,10 +798,13 @@ __global__ __launch_bounds__(pg::THREADS) void pgemm_kernel(const float* __restr
 
 bool pgemm_shape_ok(int M, int N, int K) { return pgemm_ok(M, N, K); }
 
+static unsigned long long g_pgemm_launches = 0;   // host-side count (tests prove which GEMM kernel a configuration took)
+
 hipError_t launch_pgemm(const float* A, int lda, const float* wfrag, size_t wfrag_floats, const float* bias, const float* res, int ldres,
                         float* C, int ldc, int M, int N, int K, int flags, hipStream_t s) {
     if (M <= 0) return hipSuccess;
     if (!pgemm_ok(M, N, K) || wfrag_floats * 4 > 0x7fffffffULL) return hipErrorInvalidValue;
+    ++g_pgemm_launches;
     static bool attr_set = false;
     if (!attr_set) {
         for (const void* f : {reinterpret_cast<const void*>(pgemm_kernel<0>), reinterpret_cast<const void*>(pgemm_kernel<1>),
@@ -823,6 +826,12 @@ hipError_t launch_pgemm(const float* A, int lda, const float* wfrag, size_t wfra
 }
 
 }  // namespace tip
+
+extern "C" int tip_debug_pgemm_launches(unsigned long long* out) {
+    if (!out) return -1;
+    *out = tip::g_pgemm_launches;
+    return 0;
+}
 
 extern "C" int tip_debug_read_f2s_cross_xcd(unsigned* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(tip::g_f2s_cross_xcd), sizeof(unsigned)) == hipSuccess ? 0 : -5;

@@ -164,9 +164,13 @@ __global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(const float*
         }
     }
     // the flag columns (exp + two logs each) one per thread rather than a column's 16 rows in sequence
-    if ((sh.terms & TIP_LOSS_C) && tid < nrows * (sh.n_sbp4 >> 2)) {
-        const int nf = sh.n_sbp4 >> 2, r = tid / nf, col = sh.n_pose + sh.n_vel + 4 * (tid - r * nf);
-        if (cmask[r]) s_bce = bce_sigmoid(pt[r * W + col], gtl[r * W + col]);
+    // (more than kLossThreads / kLossRows = 16 constraints per row: a thread takes several elements)
+    if (sh.terms & TIP_LOSS_C) {
+        const int nf = sh.n_sbp4 >> 2;
+        for (int e = tid; e < nrows * nf; e += kLossThreads) {
+            const int r = e / nf, col = sh.n_pose + sh.n_vel + 4 * (e - r * nf);
+            if (cmask[r]) s_bce += bce_sigmoid(pt[r * W + col], gtl[r * W + col]);
+        }
     }
     double v[kLossPart] = {s_pose, s_xy, s_z, 0.0, s_bce, s_off, 0.0, s_j};
     if (tid < nrows) {
@@ -254,8 +258,8 @@ __global__ __launch_bounds__(kLossThreads) void loss_grad_kernel(const float* __
     const float k_bce = stats[ST_KBCE], k_off = stats[ST_KOFF], k_j = stats[ST_KJ];
     const int tid = threadIdx.x;
     // the flag columns (exp, divide) one per thread rather than a column's 16 rows in sequence
-    if (tid < nrows * (sh.n_sbp4 >> 2)) {
-        const int nf = sh.n_sbp4 >> 2, r = tid / nf, col = sh.n_pose + sh.n_vel + 4 * (tid - r * nf);
+    for (int e = tid, nf = sh.n_sbp4 >> 2; e < nrows * nf; e += kLossThreads) {
+        const int r = e / nf, col = sh.n_pose + sh.n_vel + 4 * (e - r * nf);
         float g = 0.f;
         if ((sh.terms & TIP_LOSS_C) && cmask[r]) g = k_bce * bce_sigmoid_grad(lds[(3 + r) * W + col], gtl[r * W + col]);
         dy[(size_t)(row0 + r) * ldd + col] = g * go;

@@ -346,7 +346,7 @@ static TG tg_base(const float* A, long long lda, const float* B, long long ldb, 
     return g;
 }
 
-static int g_tgemm_cus = 256;   // set from the handle before the first launch of a pass
+static thread_local int g_tgemm_cus = 256;   // set from the handle at every entry point (per thread: handles of GPUs with different CU counts may run on different threads)
 
 // (0,0) orientation, no split: 16x16x4 kernel.  kk is padded to the 32-wide k tile (k beyond kva/kvb reads as zero).
 // Tile: 64 x 64 always — measured on MI355X at M = 10 240 it beats 64 x 128 and 128 x 128 for every shape of this model

@@ -6,19 +6,23 @@ Mirrors the reference's module surface (/root/reference/simple_transformer_with_
   * forward(x_imu [B,T,72(+18)], x_s [B,T,size_s]) -> [B,T,size_s], inputs untouched, NaNs in x_s scrubbed (:60-102)
   * nn.Module services the callers use: .cuda(), .eval()/.train(), .parameters(), load_state_dict, torch.save
 
-Execution (ROCm tensors, fp32):
-  * forward values ALWAYS come from the hand-written HIP kernels through the C-ABI (csrc/libtip_hip.so,
-    include/tip_hip.h) unless encoder dropout has to be drawn (next bullet).  No fallback: a missing library, a CPU
-    tensor under no_grad or an fp64 tensor raises.
-  * module in .train() mode AND autograd needed (train_model.py:132,175,192): the reference's encoder layers carry
-    torch's default dropout p=0.1 (nn.TransformerEncoderLayer default; the constructor's `dropout` argument only
-    reaches nn.RNN, where it is a no-op for one layer), live in train mode.  The HIP kernels do not draw it, so this
-    case runs a torch-op composite with that dropout — the training path, not the accelerated one.
-  * .eval() mode with autograd on (the runners never call no_grad): HIP forward wrapped in an autograd.Function
-    whose backward recomputes the torch-op composite, so .backward() still works.
-  NOTE the reference's inference scripts never call .eval() (offline_testing_simple.py:98 is commented out), i.e.
-  they run with encoder dropout accidentally live.  Under torch.no_grad() this module treats a .train()-mode call
-  as inference and does NOT replicate those stochastic encoder-dropout draws.
+Execution (ROCm tensors, fp32) — what `_dispatch` does:
+  * .eval() (or .train() with encoder dropout 0) and no gradient wanted: `tip_forward`, the inference plans
+    (csrc/libtip_hip.so, include/tip_hip.h).  No fallback: a missing library, a CPU tensor under no_grad or an fp64
+    tensor raises.
+  * .train(): the reference's encoder layers carry torch's default dropout p=0.1 (nn.TransformerEncoderLayer default;
+    the constructor's `dropout` argument only reaches nn.RNN, where it is a no-op for one layer), live in train mode
+    WHETHER OR NOT autograd records.  Such a call — with gradients (train_model.py:132,175,192) or under
+    torch.no_grad() (the reference's inference scripts never call .eval(): offline_testing_simple.py:98 is commented
+    out, so they run with that dropout accidentally live) — goes to the HIP training step `tip_train_forward` /
+    `tip_train_backward` (`_HipTrainFunction`): dropout drawn from a counter-based hash, activations stashed, every row
+    computed.  Call .eval() for deterministic, stash-free inference (StreamingEngine warns when it is handed a
+    .train()-mode model).  Configurations the training kernels do not cover (rnn_hid_size != 512, CPU tensors, fp64,
+    gradients w.r.t. the inputs) run the torch-op composite with the same dropout, with a warning — never the
+    dropout-free inference kernels, so the behaviour does not depend on the configuration.
+  * .eval() with autograd on (the runners never enter no_grad): HIP forward wrapped in an autograd.Function whose
+    backward, if ever called, recomputes the torch-op composite, so .backward() still works.
+  The handle's workspace / backward scratch are per (device, stream); one module may be driven from several streams.
 
 Dropout semantics kept from the reference: `nn.Dropout(p)(x)` is constructed inside forward (:73,:77), i.e. it is
 always in training mode, so past_state_dropout / in_dropout are live even under .eval().  The HIP path draws the
@@ -109,10 +113,10 @@ class TF_RNN_Past_State(nn.Module):
         self._handle: Optional[_lib.Handle] = None
         self._packed_dev: Optional[torch.Tensor] = None
         self._packed_key = None
-        self._workspace: Optional[torch.Tensor] = None
+        self._workspace = {}             # (device index, stream handle) -> uint8 tensor: calls on different streams never share one
         self._frozen = False
         self._warned_autograd = False
-        self._train_scratch: Optional[torch.Tensor] = None
+        self._train_scratch = {}         # same keying for the backward scratch
         self.use_hip_training = True     # .train() + autograd on the GPU -> tip_train_forward / tip_train_backward
         self.keep_train_stash = False    # debugging/tests: keep the last activation stash (see train_activation())
         self.last_train_stash = None
@@ -170,11 +174,13 @@ class TF_RNN_Past_State(nn.Module):
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())     # CPU generator: no device sync
             y = _HipTrainFunction.apply(self, xi, x_s, mask, float(self.ENCODER_DROPOUT), seed, *self.parameters())
             return y[:, -1] if last_row_only else y
-        if needs_grad and (self.training or not x_imu.is_cuda):
+        if (needs_grad and (self.training or not x_imu.is_cuda)) or (self.training and self.ENCODER_DROPOUT > 0.0 and x_imu.is_cuda):
+            # not covered by the HIP training step: the torch-op composite, with the encoder dropout .train() implies
             if not self._warned_autograd:
-                warnings.warn("tip_amd: autograd in .train() mode (or on CPU) — using the torch-op training composite "
-                              "(encoder dropout p=0.1 live, as in the reference); the HIP kernels serve .eval() / "
-                              "torch.no_grad() forwards")
+                warnings.warn("tip_amd: .train()-mode call (or autograd on CPU) that the HIP training kernels do not cover "
+                              "(rnn_hid_size != 512, fp64, CPU tensors or gradients w.r.t. the inputs) — using the torch-op "
+                              "composite with encoder dropout p=0.1 live, as in the reference; call .eval() for the "
+                              "inference kernels")
                 self._warned_autograd = True
             y = self._forward_torch_ops(x_imu, x_s)
             return y[:, -1] if last_row_only else y
@@ -283,6 +289,17 @@ class TF_RNN_Past_State(nn.Module):
     def hip_forward_count(self) -> int:
         return self._handle.forward_count() if self._handle is not None else 0
 
+    @staticmethod
+    def _stream_buffer(table: dict, dev, stream: int, nbytes: int) -> torch.Tensor:
+        """The scratch buffer of (device, stream): grown on demand, never shared between streams (two forwards in flight on
+        two streams would otherwise race on it)."""
+        key = (dev.index, int(stream))
+        buf = table.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            table[key] = buf
+        return buf
+
     def _forward_hip(self, x_imu, x_s, last_row_only: bool, keep_mask="draw", apply_in_dropout=True):
         if not (x_imu.is_cuda and x_s.is_cuda):
             raise RuntimeError("tip_amd.TF_RNN_Past_State: the inference forward runs on an MI355X through "
@@ -324,11 +341,10 @@ class TF_RNN_Past_State(nn.Module):
             else:
                 y = torch.empty((B, T, self.size_s), dtype=torch.float32, device=dev)
             need = h.workspace_bytes(B, T)
-            if self._workspace is None or self._workspace.device != dev or self._workspace.numel() < need:
-                self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
+            ws = self._stream_buffer(self._workspace, dev, stream, need)
             h.forward(x_imu_c.data_ptr(), x_s_c.data_ptr(), y.data_ptr(), B, T, flags, mask_ptr, scale,
-                      self._workspace.data_ptr(), self._workspace.numel(), stream)
+                      ws.data_ptr(), ws.numel(), stream)
         return y
 
     # -- torch-op composite (autograd / training) -----------------------------------------------
@@ -336,7 +352,7 @@ class TF_RNN_Past_State(nn.Module):
         B, T = x_imu.shape[0], x_imu.shape[1]
         D, H = self.tf_in_dim, self.n_heads
         dh = D // H
-        s = torch.nan_to_num(x_s, nan=0.0) if not x_s.requires_grad else torch.where(x_s.isnan(), torch.zeros_like(x_s), x_s)
+        s = torch.where(x_s.isnan(), torch.zeros_like(x_s), x_s)          # :65 — NaN only: +/-inf stay, as in the reference
         keep = torch.ones(self.size_s, dtype=s.dtype, device=s.device)
         keep[18 * 6: 18 * 6 + 3] = 0.0                                  # :75
         s = s * keep
@@ -411,17 +427,20 @@ class _HipTrainFunction(torch.autograd.Function):
         dev = gy.device
         with torch.cuda.device(dev):
             saved = ctx.saved_stash
+            if saved is None:
+                raise RuntimeError("tip_amd: backward through the HIP training step a second time — the activation stash "
+                                   "is released after the first backward (retain_graph=True is not supported; run the "
+                                   "forward again)")
             _, scratch_bytes = h.train_bytes(B, T)
-            if module._train_scratch is None or module._train_scratch.device != dev or \
-                    module._train_scratch.numel() < scratch_bytes:
-                module._train_scratch = torch.empty(scratch_bytes, dtype=torch.uint8, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            scratch = module._stream_buffer(module._train_scratch, dev, stream, scratch_bytes)
             total = sum(p.numel() for p in params)
             flat = torch.empty(total, dtype=torch.float32, device=dev)
             pc = [p.detach().contiguous() for p in params]
             g = gy.to(torch.float32).contiguous()
             h.train_backward([p.data_ptr() for p in pc], g.data_ptr(), saved.data_ptr(), saved.numel(),
-                             module._train_scratch.data_ptr(), module._train_scratch.numel(), flat.data_ptr(), total,
-                             ctx.p_drop, ctx.seed, B, T, torch.cuda.current_stream(dev).cuda_stream)
+                             scratch.data_ptr(), scratch.numel(), flat.data_ptr(), total,
+                             ctx.p_drop, ctx.seed, B, T, stream)
         ctx.saved_stash = None
         out, off = [], 0
         for i, p in enumerate(params):

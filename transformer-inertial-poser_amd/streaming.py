@@ -32,6 +32,11 @@ class StreamingEngine:
         self.device = next(model.parameters()).device
         if self.device.type != "cuda":
             raise RuntimeError("tip_amd.StreamingEngine runs on an MI355X: move the model to the GPU first")
+        if model.training:
+            import warnings
+            warnings.warn("tip_amd.StreamingEngine: the model is in .train() mode — like the reference's runner without "
+                          ".eval() (offline_testing_simple.py:98) every frame then draws the encoder's dropout, here through "
+                          "the HIP TRAINING kernels (all rows, activation stash); call model.eval() for the inference plans")
         self.n = int(s_init.shape[0])
         nbytes = ctypes.c_size_t()
         self._check(self.lib.tip_stream_state_bytes(self.n, ctypes.byref(nbytes)))
