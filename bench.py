@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
 """bench.py — IMU frames/s of the TIP forward pass on N MI355X GPUs (BASELINE.json metric).
 
-One "step" = one forward of TF_RNN_Past_State over a batch of B synthetic 40-frame IMU windows per GPU
-(BASELINE.json configs[1]: batch=256, seq_len=40, 4 layers / 16 heads / d=256 / ffn=1024 / rnn=512), inputs
-resident in HBM, full [B,T,131] output.  In streaming, one window forward consumes one new IMU frame per stream,
-so frames/s == windows/s.  Streams shard on the batch axis (weak scaling, no data-path
-collective; one RCCL weight broadcast before the timed region).
+One "step" = one forward of TF_RNN_Past_State over a batch of B synthetic IMU windows per GPU, inputs resident in HBM.
+In streaming, one window forward consumes one new IMU frame per stream, so frames/s == windows/s.
+Streams shard on the batch axis (weak scaling, no data-path collective; one RCCL weight broadcast before the timed
+region).  --config selects which BASELINE.json configuration is the headline of the run:
+
+    paper256     configs[1]: batch 256 / GPU, seq_len 40, paper model, full [B,T,131] output           (default)
+    streams1024  configs[2]/[3]: 1024 concurrent streams / GPU, seq_len 40, last-row output (what RTRunnerMin.step consumes)
+    scaled512    configs[4]: 12 layers, d=1024, ffn=4096, seq_len 80, batch 512 / GPU (4096 over 8 GPUs), full output
 
     python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config streams1024]
+
+At N = 1 the default run also puts every other BASELINE configuration on the same clock (`extra.configs`: B=1 latency with
+and without the PCIe hops, 1024 closed-loop streams, B=1024 last-row, B=8192, the scaled model) and holds the headline step
+for >= 3 s (`extra.sustained`) so that the clock actually held is known.
 """
 import argparse
 import contextlib
+import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,21 +37,34 @@ import torch.distributed as dist  # noqa: E402
 import tip_amd  # noqa: E402
 from tip_amd import synth  # noqa: E402
 from tip_amd import dist as tdist  # noqa: E402
+from tip_amd import lib as tlib  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense, 2.4 GHz
+PEAK_CLOCK_GHZ = 2.4
 PEAK_HBM_GBS = 8000.0
+
+CONFIGS = {
+    "paper256": dict(cfg=synth.PAPER, B=256, T=40, last=False,
+                     metric="IMU frames/sec (whole node), seq_len=40 batch=256/GPU",
+                     workload="TIP paper config (4 layers, 16 heads, d=256, ffn=1024, rnn=512), {B} windows/GPU x {T} frames, "
+                              "full [B,T,131] output, inputs resident in HBM"),
+    "streams1024": dict(cfg=synth.PAPER, B=1024, T=40, last=True,
+                        metric="IMU frames/sec (whole node), 1024 concurrent streams/GPU, seq_len=40, last-row output",
+                        workload="TIP paper config, {B} concurrent streams/GPU x {T}-frame sliding window, row T-1 only "
+                                 "([B,131]: what RTRunnerMin.step consumes), inputs resident in HBM"),
+    "scaled512": dict(cfg=synth.SCALED, B=512, T=80, last=False,
+                      metric="IMU frames/sec (whole node), scaled model, seq_len=80 batch=512/GPU",
+                      workload="scaled config (12 layers, 16 heads, d=1024, ffn=4096, rnn=512), {B} windows/GPU x {T} frames, "
+                               "full [B,T,131] output, random-init weights, inputs resident in HBM"),
+}
 
 
 def build_model(cfg, seed, load):
     with contextlib.redirect_stdout(sys.stderr):   # the reference's constructor prints; stdout carries ONE JSON line
-        return _build_model(cfg, seed, load)
-
-
-def _build_model(cfg, seed, load):
-    m = tip_amd.TF_RNN_Past_State(
-        cfg["input_size_imu"], cfg["size_s"], rnn_hid_size=cfg["rnn_hid_size"], tf_hid_size=cfg["tf_hid_size"],
-        tf_in_dim=cfg["tf_in_dim"], n_heads=cfg["n_heads"], tf_layers=cfg["tf_layers"], dropout=0.0, in_dropout=0.0,
-        past_state_dropout=0.0, with_rnn=cfg.get("with_rnn", True), with_acc_sum=cfg.get("with_acc_sum", False))
+        m = tip_amd.TF_RNN_Past_State(
+            cfg["input_size_imu"], cfg["size_s"], rnn_hid_size=cfg["rnn_hid_size"], tf_hid_size=cfg["tf_hid_size"],
+            tf_in_dim=cfg["tf_in_dim"], n_heads=cfg["n_heads"], tf_layers=cfg["tf_layers"], dropout=0.0, in_dropout=0.0,
+            past_state_dropout=0.0, with_rnn=cfg.get("with_rnn", True), with_acc_sum=cfg.get("with_acc_sum", False))
     if load:
         w = synth.make_weights(cfg, seed=seed)
         m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
@@ -63,69 +85,98 @@ def stage_flops(cfg, name, B, T):
     return None
 
 
-def p50_latency_ms(model, xi, xs, iters, last=False):
+def timed_loop(fn, iters):
+    """ms per call over `iters` back-to-back calls (device time, events on the current stream)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def p50_latency_ms(fn, iters):
     ts = []
-    fn = model.forward_last if last else model
     for _ in range(iters):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        fn(xi, xs)
+        fn()
         e1.record()
         e1.synchronize()
         ts.append(e0.elapsed_time(e1))
     return float(np.median(ts))
 
 
-def cpu_baseline(cfg, B, T, budget_s=12.0):
-    """The reference's CPU path restated with the same torch ops (validated against the golden vectors in
-    tests/test_host_cpu.py), timed on this box's host cores on a bounded sample of the bench workload."""
-    m = build_model(cfg, 0, True).eval()
+def frac_of_peak(cfg, T, windows_per_s, n_gpus=1):
+    return windows_per_s * synth.flops_per_window(cfg, T) / 1e12 / (PEAK_FP32_MFMA_TFLOPS * n_gpus)
+
+
+def cpu_baseline(cfg, B, T, budget_s=10.0):
+    """The reference's CPU path on this box's host cores, bounded sample of the bench workload: the model built from STOCK
+    torch.nn modules (oracle/torch_stock.py: nn.Linear / nn.TransformerEncoder / nn.RNN — the dispatch the reference takes;
+    bit-identical to the reference's outputs on the golden vectors, tests/test_host_cpu.py).  Second figures: the module's
+    torch-op restatement and the scalar C oracle."""
+    from oracle import torch_stock
+    w = synth.make_weights(cfg, seed=0)
+    with contextlib.redirect_stdout(sys.stderr):
+        stock = torch_stock.build(cfg, w)
     x_imu, x_s = synth.make_inputs(cfg, B, T, seed=1234)
     xi, xs = torch.tensor(x_imu), torch.tensor(x_s)
     max_threads = torch.get_num_threads()
-    with torch.no_grad():
-        # pick the thread count that serves this workload best (the reference's own evaluation uses 1,
-        # offline_testing_simple.py:34; small GEMMs oversubscribe badly on a 128-thread host)
+
+    def best_threads(fn):
         best, cores = None, 1
         for nt in sorted({1, 8, 16, 32, 64, max_threads}):
             if nt > max_threads:
                 continue
             torch.set_num_threads(nt)
-            m._forward_torch_ops(xi, xs)  # warm-up
+            fn()
             t0 = time.perf_counter()
-            m._forward_torch_ops(xi, xs)
+            fn()
             dt = time.perf_counter() - t0
             if best is None or dt < best:
                 best, cores = dt, nt
         torch.set_num_threads(cores)
+        return cores
+
+    def run_for(fn, budget, cap):
         n, t0 = 0, time.perf_counter()
         while True:
-            m._forward_torch_ops(xi, xs)
+            fn()
             n += 1
             el = time.perf_counter() - t0
-            if el > budget_s or n >= 40:
-                break
+            if el > budget or n >= cap:
+                return n, el
+
+    with torch.no_grad():
+        f_stock = lambda: stock(xi, xs)   # noqa: E731
+        cores = best_threads(f_stock)
+        n, el = run_for(f_stock, budget_s, 40)
+        out = {"value": B * n / el, "unit": "IMU frames/s", "cores": cores, "kind": "port",
+               "sample": f"{n} forwards of B={B},T={T} (paper config) through stock torch.nn modules (nn.Linear, "
+                         f"nn.TransformerEncoder, nn.RNN: the reference's CPU dispatch), best of 1/8/16/32/64/{max_threads} "
+                         f"threads = {cores}, {el:.1f} s"}
         # the reference's own streaming setting: one stream, one thread (offline_testing_simple.py:34, real_time_runner_minimal.py:149)
         torch.set_num_threads(1)
         x1i, x1s = xi[:1].contiguous(), xs[:1].contiguous()
-        m._forward_torch_ops(x1i, x1s)
-        n1, t1 = 0, time.perf_counter()
-        while n1 < 30 and time.perf_counter() - t1 < 2.0:
-            m._forward_torch_ops(x1i, x1s)
-            n1 += 1
-        b1_ms = (time.perf_counter() - t1) / n1 * 1e3
+        stock(x1i, x1s)
+        n1, el1 = run_for(lambda: stock(x1i, x1s), 2.0, 30)
+        b1_ms = el1 / n1 * 1e3
+        out["b1_one_thread"] = {"ms_per_window": b1_ms, "realtime_factor_60fps": (1000.0 / b1_ms) / 60.0,
+                                "sample": f"{n1} forwards of B=1,T={T}, torch.set_num_threads(1) as the reference's runner"}
+        # second figure: the module's own torch-op restatement (SDPA + explicit recurrence loop)
+        m = build_model(cfg, 0, True).eval()
+        torch.set_num_threads(cores)
+        m._forward_torch_ops(xi, xs)
+        n2, el2 = run_for(lambda: m._forward_torch_ops(xi, xs), 3.0, 12)
+        out["torch_ops_composite"] = {"value": B * n2 / el2, "unit": "IMU frames/s", "cores": cores,
+                                      "sample": f"{n2} forwards, same inputs, {el2:.1f} s"}
         torch.set_num_threads(max_threads)
-    out = {"value": B * n / el, "unit": "IMU frames/s", "cores": cores, "kind": "port",
-           "sample": f"{n} forwards of B={B},T={T} (paper config) with the torch-op restatement of the reference CPU "
-                     f"path, best of 1/8/16/32/64/{max_threads} threads = {cores}, {el:.1f} s",
-           "b1_one_thread": {"ms_per_window": b1_ms, "realtime_factor_60fps": (1000.0 / b1_ms) / 60.0,
-                             "sample": f"{n1} forwards of B=1,T={T}, torch.set_num_threads(1) as the reference's runner"}}
-    # the C oracle (scalar port, OpenMP over windows), same workload, bounded
-    try:
+    try:   # the C oracle (scalar port, OpenMP over windows), same workload, bounded
         from oracle import oracle
-        w = synth.make_weights(cfg, seed=0)
         nt = oracle.max_threads()
-        nb = max(4 * nt, 32)
+        nb = min(B, max(4 * nt, 32))
         t0 = time.perf_counter()
         oracle.forward(cfg, w, x_imu[:nb], x_s[:nb], dtype=np.float32, nthreads=nt)
         el = time.perf_counter() - t0
@@ -136,17 +187,148 @@ def cpu_baseline(cfg, B, T, budget_s=12.0):
     return out
 
 
+def clock_probe(buf):
+    st = tlib.load().tip_debug_clock_probe(ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+
+
+def smi_sclk_mhz():
+    """Current shader clock as rocm-smi reports it (sampled while the GPU is busy); None when unavailable."""
+    try:
+        out = subprocess.run(["rocm-smi", "-d", str(torch.cuda.current_device()), "--showclocks", "--json"],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        for k, v in card.items():
+            if "sclk" in k.lower() and "mhz" in str(v).lower():
+                return float(str(v).lower().replace("(", "").replace(")", "").replace("mhz", "").strip())
+    except Exception:
+        return None
+    return None
+
+
+def sustained_pass(step, ms_est, seconds):
+    """Hold the headline step for `seconds`: sustained ms/step, the shader clock held (s_memtime ticks over wall_clock64's
+    100 MHz, both read on the device right before and after), rocm-smi's clock sampled mid-run."""
+    n = max(50, int(seconds * 1e3 / ms_est))
+    probes = torch.zeros(8, dtype=torch.int64, device="cuda")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    clock_probe(probes[0:4])
+    e0.record()
+    for _ in range(n):
+        step()
+    e1.record()
+    clock_probe(probes[4:8])
+    smi = smi_sclk_mhz()                  # the queue is still draining while this runs
+    e1.synchronize()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    p = probes.cpu().numpy().astype(np.float64)
+    ticks, wall_s = p[4] - p[0], (p[5] - p[1]) / 100e6
+    ghz = ticks / wall_s / 1e9 if wall_s > 0 else None
+    return {"steps": n, "seconds": ms * 1e-3, "sustained_ms_per_step": ms / n,
+            "sclk_ghz_s_memtime": ghz, "probe_xcc": [int(p[2]), int(p[6])], "sclk_mhz_rocm_smi": smi}
+
+
+def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
+    """Every other BASELINE.json configuration on this run's clock (N = 1).  A few seconds each."""
+    out = {}
+    T = xi.shape[1]
+    fpw = synth.flops_per_window(cfg, T)
+    model.set_plan("auto")
+    # -- configs[0]/north_star B=1: device-resident p50, and the per-frame protocol of real_time_runner_minimal.py:146-150
+    #    (host window -> H2D -> forward -> D2H of the consumed row)
+    x1i, x1s = xi[:1].contiguous(), xs[:1].contiguous()
+    for _ in range(10):
+        model.forward_last(x1i, x1s)
+    lat_full = p50_latency_ms(lambda: model(x1i, x1s), 200)
+    lat_last = p50_latency_ms(lambda: model.forward_last(x1i, x1s), 200)
+    h_i, h_s = x1i.cpu().pin_memory(), x1s.cpu().pin_memory()
+    ts = []
+    for _ in range(220):
+        t0 = time.perf_counter()
+        y = model.forward_last(h_i.to(dev, non_blocking=True), h_s.to(dev, non_blocking=True)).cpu()   # .cpu() synchronises
+        ts.append((time.perf_counter() - t0) * 1e3)
+    lat_pcie = float(np.median(ts[20:]))
+    out["b1_latency"] = {"p50_forward_ms": lat_full, "p50_forward_last_row_ms": lat_last,
+                         "realtime_factor_60fps": (1000.0 / lat_full) / 60.0,
+                         "p50_ms_with_h2d_window_and_d2h_last_row": lat_pcie,
+                         "realtime_factor_60fps_with_pcie": (1000.0 / lat_pcie) / 60.0,
+                         "hbm_gbs_weights_plus_io": (14709260 + 56320) / (lat_full * 1e-3) / 1e9,
+                         "note": "latency-bound: far below either roofline (weights 14.7 MB + 56 KB I/O per forward)"}
+    del y
+    # -- configs[3] share / B=1024 last-row, and B=8192 on one GPU (north_star sweep point), full output
+    for tag, Bx, last in (("b1024_last_row", 1024, True), ("b8192_full", 8192, False)):
+        reps = Bx // xi.shape[0]
+        bi, bs = xi.repeat(reps, 1, 1), xs.repeat(reps, 1, 1)
+        fn = (lambda: model.forward_last(bi, bs)) if last else (lambda: model(bi, bs))
+        for _ in range(3):
+            fn()
+        ms = timed_loop(fn, 12 if Bx <= 1024 else 5)
+        out[tag] = {"batch": Bx, "T": T, "ms_per_step": ms, "frames_per_s": Bx / (ms * 1e-3),
+                    "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(cfg, T, Bx / (ms * 1e-3)),
+                    "headroom_vs_60fps": (1000.0 / ms) / 60.0}
+        del bi, bs
+    # -- configs[2]: 1024 closed-loop streams through the on-device streaming engine (ingest -> forward(last row) -> consume)
+    try:
+        from scipy.spatial.transform import Rotation
+        n = 1024
+        rng = np.random.RandomState(n)
+        base = Rotation.random(n * 6, random_state=n).as_matrix().reshape(n, 54).astype(np.float32)
+        s_init = (rng.randn(n, 114) * 0.2).astype(np.float32)
+        model.freeze_packed(True)
+        eng = tip_amd.streaming.StreamingEngine(model, s_init)
+        frames = [torch.tensor(np.concatenate([base, rng.randn(n, 18).astype(np.float32)], axis=1)).to(dev) for _ in range(8)]
+        for f in range(60):                      # prime the smoother and fill the 40-frame windows
+            eng.step(frames[f % 8])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in range(60):
+            eng.step(frames[f % 8])
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 60 * 1e3
+        out["streams1024_closed_loop"] = {"streams": n, "ms_per_frame": ms, "stream_frames_per_s": n / (ms * 1e-3),
+                                          "headroom_vs_60fps_budget_16.7ms": (1000.0 / 60.0) / ms,
+                                          "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(cfg, T, n / (ms * 1e-3))}
+        del eng, frames
+    except Exception as e:   # the extras must never take the headline line down
+        out["streams1024_closed_loop"] = {"error": f"{type(e).__name__}: {e}"}
+    # -- configs[4] share: scaled model, B=512, T=80 (random-init weights on the device)
+    try:
+        sc = synth.SCALED
+        torch.manual_seed(0)
+        ms_model = build_model(sc, 0, load=False).to(dev).eval()
+        Bs, Ts = 512, 80
+        s_imu, s_s = synth.make_inputs(sc, 64, Ts, seed=99)
+        si = torch.tensor(s_imu).to(dev).repeat(Bs // 64, 1, 1)
+        ss = torch.tensor(s_s).to(dev).repeat(Bs // 64, 1, 1)
+        ms_model(si, ss)
+        ms_model(si, ss)
+        ms = timed_loop(lambda: ms_model(si, ss), 3)
+        out["scaled_b512_t80"] = {"batch": Bs, "T": Ts, "ms_per_step": ms, "frames_per_s": Bs / (ms * 1e-3),
+                                  "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(sc, Ts, Bs / (ms * 1e-3)),
+                                  "tflops": Bs / (ms * 1e-3) * synth.flops_per_window(sc, Ts) / 1e12}
+        del ms_model, si, ss
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["scaled_b512_t80"] = {"error": f"{type(e).__name__}: {e}"}
+    del fpw
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="windows (IMU streams) per GPU")
-    ap.add_argument("--seq-len", type=int, default=40)
+    ap.add_argument("--config", default="paper256", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="windows (IMU streams) per GPU; 0 = the configuration's own")
+    ap.add_argument("--seq-len", type=int, default=0)
     ap.add_argument("--plan", default="auto", choices=["auto", "general", "fused", "latency", "fused2", "fused2s"])
     ap.add_argument("--rnn-cluster", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra.configs / extra.sustained (headline line only)")
+    ap.add_argument("--sustain-s", type=float, default=3.0)
     ap.add_argument("--profile-all", action="store_true", help="print a per-stage time table (separate pass)")
     args = ap.parse_args()
 
@@ -159,17 +341,33 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    cfg = synth.PAPER
-    B, T = args.batch, args.seq_len
-    model = build_model(cfg, 0, load=(rank == 0)).to(dev).eval()
+    spec = CONFIGS[args.config]
+    cfg = spec["cfg"]
+    B, T = args.batch or spec["B"], args.seq_len or spec["T"]
+    last = spec["last"]
+    synth_weights = args.config != "scaled512"     # 152 M parameters: the module's own random init, drawn on rank 0's GPU
+    torch.manual_seed(0)
+    model = build_model(cfg, 0, load=(rank == 0 and synth_weights))
+    model = model.to(dev).eval()
     t_b0 = time.perf_counter()
-    tdist.broadcast_packed(model, src=0, device=dev)      # one-time RCCL broadcast (no-op collective at N=1)
+    packed = tdist.broadcast_packed(model, src=0, device=dev)      # one-time RCCL broadcast (no-op collective at N=1)
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t_b0) * 1e3
+    # every rank must hold rank 0's image, bit for bit
+    csum = packed.view(torch.int32).to(torch.int64).sum().reshape(1)
+    sums = [csum.clone() for _ in range(world)]
+    if use_pg and world > 1:
+        dist.all_gather(sums, csum)
+    image_equal = all(int(s.item()) == int(sums[0].item()) for s in sums)
+    assert image_equal, "a rank's packed weight image differs from rank 0's after the broadcast"
     model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=0)
 
-    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=1234 + rank)
+    x_imu, x_s = synth.make_inputs(cfg, min(B, 256), T, seed=1234 + rank)
     xi, xs = torch.tensor(x_imu).to(dev), torch.tensor(x_s).to(dev)
+    if B > xi.shape[0]:
+        reps = (B + xi.shape[0] - 1) // xi.shape[0]
+        xi, xs = xi.repeat(reps, 1, 1)[:B].contiguous(), xs.repeat(reps, 1, 1)[:B].contiguous()
+    step = (lambda: model.forward_last(xi, xs)) if last else (lambda: model(xi, xs))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -179,21 +377,26 @@ def main():
 
     with torch.no_grad():
         for _ in range(args.warmup):
-            y = model(xi, xs)
+            y = step()
         model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=2)   # event pair around the dominant kernel
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            y = model(xi, xs)
+            y = step()
         sync_all()
         elapsed = time.perf_counter() - t0
         prof = model.profile_read()
         model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=0)
     assert torch.isfinite(y).all()
+    model.check_handoffs()                 # a lost inter-workgroup hand-off is an error, not a number
+    my_ms = elapsed / args.steps * 1e3
+    rank_ms = [my_ms]
     if use_pg:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        all_t = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(all_t, t)
+        rank_ms = [float(v.item()) / args.steps * 1e3 for v in all_t]
+        elapsed = max(float(v.item()) for v in all_t)
 
     global_b = B * world
     value = global_b * args.steps / elapsed
@@ -218,50 +421,56 @@ def main():
 
     extra = {}
     with torch.no_grad():
-        if not args.no_latency and rank == 0:
-            extra["p50_forward_ms_batch"] = p50_latency_ms(model, xi, xs, 40)
-            x1i, x1s = xi[:1].contiguous(), xs[:1].contiguous()
-            for _ in range(5):
-                model(x1i, x1s)
-            lat1 = p50_latency_ms(model, x1i, x1s, 200)
-            extra["p50_forward_ms_b1"] = lat1
-            extra["p50_forward_last_row_ms_b1"] = p50_latency_ms(model, x1i, x1s, 200, last=True)
-            extra["b1_realtime_factor_60fps"] = (1000.0 / lat1) / 60.0
+        if rank == 0 and world == 1 and not args.no_extra:
+            extra["sustained"] = sustained_pass(step, my_ms, args.sustain_s)
+            sus = extra["sustained"]
+            if sus.get("sclk_ghz_s_memtime"):
+                wps = B / (sus["sustained_ms_per_step"] * 1e-3)
+                sus["whole_forward_frac_of_peak_at_2.4GHz"] = frac_of_peak(cfg, T, wps)
+                sus["whole_forward_frac_of_peak_at_held_clock"] = frac_of_peak(cfg, T, wps) * PEAK_CLOCK_GHZ / sus["sclk_ghz_s_memtime"]
+            extra["p50_forward_ms_batch"] = p50_latency_ms(step, 40)
+            if args.config == "paper256":
+                extra["configs"] = extra_configs(model, cfg, xi, xs, dev)
+                model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=0)
         if args.profile_all and rank == 0:
             model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=1)
             for _ in range(5):
-                model(xi, xs)
+                step()
             torch.cuda.synchronize()
             table = {}
             for n, ms, k in model.profile_read():
                 table[n] = {"ms_per_forward": ms / 5, "launches_per_forward": k / 5}
             extra["stage_ms"] = table
             model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=0)
+    model.check_handoffs()
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, B, T)
+    if rank == 0 and not args.no_cpu_baseline:     # off the timed path; other ranks wait at the final barrier
+        cpu = cpu_baseline(synth.PAPER, 256, 40, budget_s=10.0 if world == 1 else 6.0)
 
     if rank == 0:
         fpw = synth.flops_per_window(cfg, T)
         line = {
-            "metric": "IMU frames/sec (whole node), seq_len=40 batch=256/GPU",
+            "metric": spec["metric"],
             "value": value, "unit": "IMU frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"TIP paper config (4 layers, 16 heads, d=256, ffn=1024, rnn=512), "
-                                   f"{B} windows/GPU x {T} frames, full [B,T,131] output, inputs resident in HBM",
+            "config": {"workload": spec["workload"].format(B=B, T=T), "name": args.config,
                        "global_batch": global_b, "seq_len": T, "plan": args.plan,
                        "parallelism": f"batch-sharded x{world}, one-time RCCL weight broadcast, no per-step collective"},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "whole_forward_tflops": value * fpw / 1e12,
             "whole_forward_frac_of_fp32_mfma_peak": value * fpw / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
+            "world_size": world, "backend": "nccl (RCCL)" if use_pg else "single process",
+            "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
+            "packed_image_identical_on_all_ranks": image_equal,
             "weight_broadcast_ms": bcast_ms,
             "extra": extra,
         }
         print(json.dumps(line))
     if use_pg:
+        dist.barrier()
         dist.destroy_process_group()
 
 

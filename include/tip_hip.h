@@ -8,7 +8,9 @@
  * Conventions: plain C, no torch types, no exceptions; every function returns 0 or a negative
  * tip_status; device pointers are caller-owned, contiguous, row-major fp32; tip_forward is asynchronous on
  * the caller's HIP stream; one handle per GPU, used from one thread at a time; the library allocates no
- * device memory (packed weights and workspace are caller-provided buffers).
+ * device memory (packed weights and workspace are caller-provided buffers; the one allocation is a 64-byte pinned HOST
+ * block per handle, the hand-off error word of tip_check).  Arithmetic is fp32 only: the reference's `--double` switch
+ * (train_model.py:84-85) has no counterpart here — an fp64 tensor is refused by the Python host, not converted.
  */
 #ifndef TIP_HIP_H
 #define TIP_HIP_H
@@ -47,7 +49,8 @@ typedef enum tip_status {
     TIP_ERR_WORKSPACE = -4,      /* workspace too small / misaligned */
     TIP_ERR_HIP = -5,            /* a HIP runtime call failed; see tip_last_hip_error */
     TIP_ERR_NO_DEVICE = -6,
-    TIP_ERR_ALLOC = -7
+    TIP_ERR_ALLOC = -7,
+    TIP_ERR_HANDOFF = -8         /* an inter-workgroup hand-off wait of an EARLIER launch gave up (see tip_check) */
 } tip_status;
 
 /* tip_forward flags */
@@ -72,6 +75,10 @@ typedef enum tip_status {
 #define TIP_OPT_PROFILE     2 /* 0 off; 1: bracket every stage with a HIP event pair; 2: only the dominant stage
                                  (cheap enough for a timed region).  Setting it resets the accumulated times. */
 #define TIP_OPT_RNN_CLUSTER 3 /* workgroups cooperating on one RNN window-tile (1,2,4,8,16); 0 = auto */
+#define TIP_OPT_FAULT_INJECT 4 /* TESTS ONLY.  Bit 0: the pair-split encoder drops one workgroup of pair 0; bit 1: the clustered
+                                 RNN drops member 1 of its first cluster; bit 2: the latency plan's GEMV RNN drops member 1 of
+                                 stream 0.  The partners' waits then MUST give up (after a shortened spin): the error path of
+                                 tip_check is exercised deterministically.  0 = off (default). */
 
 /* ---- lifetime: replaces TF_RNN_Past_State.__init__ (simple_transformer_with_state.py:9-54) ---------------- */
 int tip_abi_version(void);
@@ -119,6 +126,17 @@ int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches
  * The cooperating kernels (RNN clusters) never spin forever; if a peer does not arrive within ~1 s they continue
  * and bump this counter: non-zero => the outputs of that launch are invalid.  Must be 0 in a healthy process. */
 int tip_spin_timeouts(unsigned* count);
+/* Hand-off failures are ERRORS, not numbers.  The cooperating plans (pair-split encoder, clustered / GEMV RNN) rely on
+ * all their workgroups being resident at once: the launchers refuse a grid the runtime's occupancy query says cannot be
+ * (hipErrorCooperativeLaunchTooLarge -> TIP_ERR_HIP), but another process or stream holding CUs can still starve a
+ * partner.  A wait that gives up (bounded spin, ~1 s) (a) makes that workgroup produce NaN from there on, which the rest of
+ * the forward propagates into the affected output rows — never finite-but-wrong values; (b) sets a sticky word in the
+ * handle's pinned host block.  While it is set, tip_forward / tip_train_forward / tip_train_backward return
+ * TIP_ERR_HANDOFF at entry, i.e. the call AFTER the failed launch completed reports it.  tip_check(h, 0) returns
+ * TIP_ERR_HANDOFF or TIP_OK without synchronising (synchronise the stream first for a definitive answer about launches in
+ * flight); tip_check(h, 1) also clears the word.  The GPU must be exclusively this process's for the cooperating plans to
+ * run at speed; TIP_PLAN_FUSED / TIP_PLAN_GENERAL with TIP_OPT_RNN_CLUSTER = 1 need no co-residency at all. */
+int tip_check(tip_handle* h, int clear);
 
 /* ---- streaming front/back-end: the model-facing half of RTRunnerMin.step
  *      (real_time_runner_minimal.py:59-85 record_raw_imu / record_state_aa_and_c, :87-112 smooth_and_split_s_c,

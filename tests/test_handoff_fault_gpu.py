@@ -1,0 +1,151 @@
+"""GPU: a hand-off wait that gives up is an ERROR, never a number.
+
+The cooperating plans (pair-split encoder, clustered / GEMV RNN) wait for partner workgroups with bounded spins.  When a
+partner never arrives — simulated deterministically with TIP_OPT_FAULT_INJECT, which drops one cooperating workgroup at kernel
+entry — the launch must (a) leave NaN, not stale finite values, in every output row the missing data could have reached and
+bit-exact values everywhere else, and (b) make the NEXT call raise TipHandoffError (sticky until cleared).  A CU-masked stream
+(the co-tenant case) must give either bit-exact results or that error."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import tip_amd
+from tip_amd import synth
+from tip_amd import lib as tlib
+from test_host_cpu import make_model, load_synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _model():
+    m = make_model(synth.PAPER)
+    load_synth(m, synth.PAPER, 0)
+    return m.cuda().eval()
+
+
+def _fault(m, bits):
+    m._ensure_handle().set_option(tlib.TIP_OPT_FAULT_INJECT, bits)
+
+
+@pytest.mark.handoff_fault
+@pytest.mark.parametrize("plan,B,bits,hit", [
+    ("fused2s", 64, 1, "pair0"),      # pair-split encoder: workgroup (pair 0, half 1) never arrives
+    ("fused", 40, 2, "tile0"),        # 16-workgroup RNN clusters (sentinel hand-off): member 1 of cluster 0 never arrives
+    ("general", 37, 2, "tile0"),      # same through the general plan
+    ("latency", 3, 4, "win0"),        # GEMV RNN of the latency plan: member 1 of stream 0 never arrives
+])
+def test_lost_handoff_poisons_and_raises(plan, B, bits, hit):
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    if plan == "fused2s" and 2 * ((B + 1) // 2) > ncu:
+        pytest.skip("needs every workgroup resident")
+    m = _model()
+    m.set_plan(plan)
+    x_imu, x_s = synth.make_inputs(synth.PAPER, B, 40, seed=5)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    with torch.no_grad():
+        ref = m(xi, xs).cpu().numpy()
+        m.check_handoffs()                                   # healthy so far
+        t0 = tlib.spin_timeouts()
+        _fault(m, bits)
+        y = m(xi, xs)                                        # this launch loses a hand-off: the call itself returns normally
+        torch.cuda.synchronize()
+        y = y.cpu().numpy()
+        _fault(m, 0)
+        assert tlib.spin_timeouts() > t0, "the injected fault did not make any wait give up"
+        # never finite-but-wrong: every element is either NaN or exactly the healthy value
+        bad = np.isnan(y)
+        assert bad.any(), "a lost hand-off left no trace in the output"
+        assert np.array_equal(y[~bad], ref[~bad])
+        if hit == "pair0":
+            assert bad[0].all() and bad[1].all() and not bad[2:].any()      # both windows of pair 0, nothing else
+        elif hit == "tile0":
+            nt = min(16, B)
+            assert bad[:nt].all()                                            # the whole tile (row 0 too: the slice of h_0 that never came)
+            assert not bad[nt:].any()                                        # other window tiles are untouched
+        else:
+            assert bad[0].all() and not bad[1:].any()
+        # the NEXT call reports it, and keeps reporting it until cleared
+        with pytest.raises(tlib.TipHandoffError):
+            m(xi, xs)
+        with pytest.raises(tlib.TipHandoffError):
+            m.check_handoffs()
+        try:
+            m._ensure_handle().check(clear=True)
+        except tlib.TipHandoffError:
+            pass
+        m.check_handoffs()                                   # cleared
+        y2 = m(xi, xs).cpu().numpy()                          # and the handle works again
+        assert np.array_equal(y2, ref)
+
+
+@pytest.mark.handoff_fault
+def test_training_step_reports_a_lost_handoff():
+    """tip_train_forward shares the clustered RNN: a lost hand-off there poisons y and makes the next step raise."""
+    m = _model().train()
+    x_imu, x_s = synth.make_inputs(synth.PAPER, 32, 40, seed=6)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    _fault(m, 2)
+    y = m(xi, xs)
+    torch.cuda.synchronize()
+    _fault(m, 0)
+    assert torch.isnan(y[:16, 1:]).all() and torch.isfinite(y[16:]).all()
+    with pytest.raises(tlib.TipHandoffError):
+        m(xi, xs)
+    try:
+        m._ensure_handle().check(clear=True)
+    except tlib.TipHandoffError:
+        pass
+    y = m(xi, xs)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()
+
+
+@pytest.mark.handoff_fault
+@pytest.mark.parametrize("ncus_enabled", [200, 64])
+def test_cu_masked_stream_is_exact_or_an_error(ncus_enabled):
+    """The co-tenant case: the forward runs on a stream that may use only some of the CUs, so the 256 cooperating workgroups of
+    the AUTO plan at B = 256 cannot all be resident.  Allowed outcomes: bit-exact results (partners dispatched late but
+    dispatched), or NaN rows + TipHandoffError.  Not allowed: finite values that differ."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    if ncu < 256:
+        pytest.skip("written for the 256-CU part")
+    mask = (ctypes.c_uint32 * 8)()
+    per_xcd = ncus_enabled // 8                                # CU bit i -> (XCD i % 8, CU i / 8): keep the XCDs balanced
+    for i in range(256):
+        if (i // 8) < per_xcd:
+            mask[i // 32] |= 1 << (i % 32)
+    stream = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), 8, mask)
+    if rc != 0:
+        pytest.skip(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    try:
+        m = _model()
+        m.set_plan("auto")
+        B = 256
+        x_imu, x_s = synth.make_inputs(synth.PAPER, B, 40, seed=8)
+        xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+        with torch.no_grad():
+            ref = m(xi, xs)
+            torch.cuda.synchronize()
+            ext = torch.cuda.ExternalStream(stream.value)
+            with torch.cuda.stream(ext):
+                y = m(xi, xs)
+            ext.synchronize()
+            y, ref = y.cpu().numpy(), ref.cpu().numpy()
+            bad = np.isnan(y)
+            assert np.array_equal(y[~bad], ref[~bad]), "finite-but-wrong values under a CU mask"
+            if bad.any():
+                with pytest.raises(tlib.TipHandoffError):
+                    m.check_handoffs()
+                try:
+                    m._ensure_handle().check(clear=True)
+                except tlib.TipHandoffError:
+                    pass
+            else:
+                m.check_handoffs()
+    finally:
+        torch.cuda.synchronize()
+        hip.hipStreamDestroy(stream)

@@ -20,6 +20,7 @@ const char* kStatusText[] = {
     "HIP runtime error",
     "no HIP device",
     "allocation failure",
+    "an inter-workgroup hand-off wait gave up in an earlier launch (outputs of that launch are NaN-poisoned); tip_check(h, 1) clears",
 };
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -253,6 +254,19 @@ int tip_create(const tip_config* cfg, tip_handle** out) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
             h->num_cus = prop.multiProcessorCount;
+        // the hand-off error word: pinned host memory the kernels can store to and the host can read without a sync
+        void* hp = nullptr;
+        if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess && hp) {
+            memset(hp, 0, 64);
+            void* dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess && dp) {
+                h->err_host = static_cast<unsigned*>(hp);
+                h->err_dev = static_cast<unsigned*>(dp);
+            } else {
+                (void)hipHostFree(hp);
+            }
+        }
+        (void)hipGetLastError();
     } else {
         (void)hipGetLastError();
     }
@@ -267,6 +281,7 @@ void tip_destroy(tip_handle* h) {
             (void)hipEventDestroy(pr.first);
             (void)hipEventDestroy(pr.second);
         }
+    if (h->err_host) (void)hipHostFree(h->err_host);
     delete h;
 }
 
@@ -288,8 +303,20 @@ int tip_set_option(tip_handle* h, int option, int value) {
             if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) return TIP_ERR_INVALID_ARG;
             h->rnn_cluster = value;
             return TIP_OK;
+        case TIP_OPT_FAULT_INJECT:
+            if (value < 0 || value > 7) return TIP_ERR_INVALID_ARG;
+            h->fault_inject = value;
+            return TIP_OK;
         default: return TIP_ERR_INVALID_ARG;
     }
+}
+
+int tip_check(tip_handle* h, int clear) {
+    if (!h) return TIP_ERR_INVALID_ARG;
+    if (!h->err_host) return TIP_OK;
+    const unsigned v = *const_cast<volatile unsigned*>(h->err_host);
+    if (clear) *const_cast<volatile unsigned*>(h->err_host) = 0u;
+    return v ? TIP_ERR_HANDOFF : TIP_OK;
 }
 
 int tip_get_option(const tip_handle* h, int option, int* value) {
@@ -298,6 +325,7 @@ int tip_get_option(const tip_handle* h, int option, int* value) {
         case TIP_OPT_PLAN: *value = h->plan; return TIP_OK;
         case TIP_OPT_PROFILE: *value = h->profile; return TIP_OK;
         case TIP_OPT_RNN_CLUSTER: *value = h->rnn_cluster; return TIP_OK;
+        case TIP_OPT_FAULT_INJECT: *value = h->fault_inject; return TIP_OK;
         default: return TIP_ERR_INVALID_ARG;
     }
 }
@@ -548,9 +576,11 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if (T > h->d.t_max) return TIP_ERR_INVALID_ARG;
     if ((flags & TIP_FWD_KEEP_MASK) && !keep_mask) return TIP_ERR_INVALID_ARG;
     if (!h->packed_dev) return TIP_ERR_NOT_READY;
+    if (tip_check(h, 0) != TIP_OK) return TIP_ERR_HANDOFF;   // sticky: an earlier launch lost a hand-off (tip_check(h, 1) clears)
     if (B == 0) return TIP_OK;
     const Dims& d = h->d;
     const Workspace ws = carve_workspace(d, B, T);
+    const Guard gd = h->guard();
     if (!workspace || reinterpret_cast<uintptr_t>(workspace) % 256 || workspace_bytes < ws.total_bytes)
         return TIP_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -602,14 +632,14 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if (plan == TIP_PLAN_LATENCY) {
         StageScope sc(h, s, "latency_chain");
         TIP_TRY(launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall,
-                                    B, T, s), "latency_chain");
+                                    B, T, h->num_cus, gd, s), "latency_chain");
         rnn_done = true;
     } else if (plan == TIP_PLAN_FUSED2S) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = true;
         hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
         TIP_TRY(launch_fused_encoder2s(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr,
-                                       W0 + ws.xchg, B, h->num_cus, s), "fused_encoder2s");
+                                       W0 + ws.xchg, B, h->num_cus, gd, s), "fused_encoder2s");
     } else if (plan == TIP_PLAN_FUSED2) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = true;
@@ -680,7 +710,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         }
         {
             StageScope sc(h, s, "rnn_recurrence");
-            TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, rnn_cluster, h->num_cus, hall_armed, s),
+            TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, rnn_cluster, h->num_cus, hall_armed, gd, s),
                     "rnn_recurrence");
         }
         head_in = hall;

@@ -391,7 +391,10 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
 __device__ unsigned g_spin_timeouts_fused2;
 __device__ unsigned g_f2s_cross_xcd;
 __device__ unsigned long long g_f2s_trace[32];   // measurement: s_memtime stamps of workgroup 0 around its hand-offs
-__device__ __forceinline__ void note_spin_timeout() { atomicAdd(&g_spin_timeouts_fused2, 1u); }
+__device__ __forceinline__ void note_spin_timeout(unsigned* err) {
+    atomicAdd(&g_spin_timeouts_fused2, 1u);
+    guard_report(err);
+}
 hipError_t read_spin_timeouts_fused2(unsigned* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_spin_timeouts_fused2), sizeof(unsigned));
 }
@@ -406,10 +409,11 @@ size_t fused2s_xchg_floats(int B) { return (size_t)((B + 1) / 2) * (f2::PAIR_IMG
 __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
     const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ ih_out, unsigned* __restrict__ hall_sentinel,
-    float* __restrict__ xchg, int xchg_bytes, int B, int NI, int S, int L, int wbytes, int ih_off_b) {
+    float* __restrict__ xchg, int xchg_bytes, int B, int NI, int S, int L, int wbytes, int ih_off_b, Guard gd) {
     using namespace f2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int s_same_xcd;
+    __shared__ int s_poison;   // a hand-off wait gave up: the partner's partial sums count as NaN from here on (and no wait spins again)
     float* X = smem;
     float* C = smem + X_FLOATS;
     float* Qp = C;
@@ -428,6 +432,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     const int half = jj & 1;
     const int pair = (jj >> 1) * 8 + xslot;
     if (pair >= npairs) return;                           // (both halves of a surplus pair leave together)
+    if ((gd.fault & 1) && pair == 0 && half == 1) return; // TIP_OPT_FAULT_INJECT: this partner never arrives
     float* px = xchg + (size_t)pair * PAIR_IMG_FLOATS;
     unsigned* pflag = reinterpret_cast<unsigned*>(xchg + (size_t)npairs * PAIR_IMG_FLOATS) + pair * PAIR_FLAG_WORDS;
     const int px_off_b = (int)((size_t)pair * PAIR_IMG_FLOATS * 4);
@@ -441,6 +446,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         __hip_atomic_store(pflag + 16 + half, (xcc & 0xf) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_same_xcd = -1;                                  // decided at the first hand-off
+        s_poison = 0;
     }
     for (int i = tid; i < C_FLOATS; i += THREADS) C[i] = 0.f;
     __syncthreads();
@@ -457,12 +463,16 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
             unsigned mine = 0, theirs = 0;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(mine));
             mine = (mine & 0xf) + 1u;
-            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+            const unsigned lim0 = guard_spin_limit(gd.fault, 1u << 22);
+            for (unsigned spins = 0; spins < lim0; ++spins) {
                 theirs = __hip_atomic_load(pflag + 16 + (1 - half), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (theirs) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (!theirs) note_spin_timeout();
+            if (!theirs) {                                 // the partner is not there at all: poison now, never wait again
+                note_spin_timeout(gd.err);
+                s_poison = 1;
+            }
             if (theirs != mine) atomicAdd(&g_f2s_cross_xcd, 1u);   // (measurement: pairs that straddle XCDs)
             s_same_xcd = theirs == mine ? 1 : 0;
         }
@@ -490,14 +500,21 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         if (blockIdx.x == 0 && tid == 0 && handoff < 8) g_f2s_trace[handoff * 4 + 1] = __builtin_amdgcn_s_memtime();
         if (tid == 0) {
             __hip_atomic_store(pflag + half, (unsigned)(handoff + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned spins = 0;
-            for (; spins < (1u << 22); ++spins) {
-                if (__hip_atomic_load(pflag + (1 - half), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(handoff + 1)) break;
-                if (!same) __builtin_amdgcn_s_sleep(1);
+            if (!s_poison) {
+                const unsigned lim = guard_spin_limit(gd.fault, 1u << 22);
+                unsigned spins = 0;
+                for (; spins < lim; ++spins) {
+                    if (__hip_atomic_load(pflag + (1 - half), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(handoff + 1)) break;
+                    if (!same) __builtin_amdgcn_s_sleep(1);
+                }
+                if (spins == lim) {
+                    note_spin_timeout(gd.err);
+                    s_poison = 1;
+                }
             }
-            if (spins == (1u << 22)) note_spin_timeout();
         }
         __syncthreads();
+        const bool poisoned = s_poison != 0;
         if (blockIdx.x == 0 && tid == 0 && handoff < 8) g_f2s_trace[handoff * 4 + 2] = __builtin_amdgcn_s_memtime();
         f32x4 other[RB][2];
 #pragma unroll
@@ -514,8 +531,9 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
             for (int r = 0; r < RB; ++r)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float p0 = half == 0 ? acc[r][n][e] : other[r][n][e];
-                    const float p1 = half == 0 ? other[r][n][e] : acc[r][n][e];
+                    const float oth = poisoned ? __uint_as_float(kPoisonBits) : other[r][n][e];
+                    const float p0 = half == 0 ? acc[r][n][e] : oth;
+                    const float p1 = half == 0 ? oth : acc[r][n][e];
                     X[(r * 16 + lg * 4 + e) * LDX + col] += (p0 + p1) + bv;
                 }
         }
@@ -749,7 +767,7 @@ bool fused2s_fits(int B, int num_cus) { return B >= 1 && 2 * ((B + 1) / 2) <= nu
 
 hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                   const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
-                                  int B, int num_cus, hipStream_t s) {
+                                  int B, int num_cus, const Guard& gd, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (!fused2s_fits(B, num_cus)) return hipErrorInvalidValue;       // every workgroup must be resident: partners wait for each other
     static bool attr_set = false;
@@ -766,10 +784,17 @@ hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const flo
     hipError_t e = hipMemsetAsync(xchg + (size_t)npairs * f2::PAIR_IMG_FLOATS, 0, (size_t)npairs * f2::PAIR_FLAG_WORDS * 4, s);
     if (e != hipSuccess) return e;
     const int grid = (2 * npairs + 15) / 16 * 16;                      // whole (xcd, j) blocks of the id -> (pair, half) map
+    {
+        // the runtime's own answer to "how many of these workgroups fit on a CU" (what a cooperative launch would check): the
+        // 2 * npairs working ones must all be resident (surplus ids leave at once)
+        static int occ = -1;
+        hipError_t ce = check_coresident(fused_encoder2s_kernel, f2::THREADS, (size_t)f2::LDS_BYTES, 2 * npairs, num_cus, &occ);
+        if (ce != hipSuccess) return ce;
+    }
     const size_t ih_off = f2::LAYER0 + (size_t)d.L * f2::LAYER_FLOATS;
     hipLaunchKernelGGL(fused_encoder2s_kernel, dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
                        keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), xchg, (int)xbytes, B, d.n_imu_total, d.S, d.L,
-                       (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4));
+                       (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4), gd);
     return hipGetLastError();
 }
 

@@ -25,7 +25,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // every bounded hand-off spin that gives up bumps this counter (read with tip_spin_timeouts()): a non-zero value
 // means a cluster member never arrived and the outputs of that launch are invalid.
 __device__ unsigned g_spin_timeouts_general;
-__device__ __forceinline__ void note_spin_timeout() { atomicAdd(&g_spin_timeouts_general, 1u); }
+__device__ __forceinline__ void note_spin_timeout(unsigned* err) {
+    atomicAdd(&g_spin_timeouts_general, 1u);
+    guard_report(err);
+}
 
 // ------------------------------------------------------------------------------------------------
 // prologue: U[row][0:InPad] = [x_imu | scrub(x_s) * mask * scale | 0-pad]
@@ -501,8 +504,11 @@ hipError_t launch_layernorm(float* x, const float* g, const float* b, int M, int
 template <int NBW>  // 16-column blocks per wave: R / (16 * 4 * cluster)
 __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, const float* __restrict__ whh_frag,
                                                   float* __restrict__ hall, unsigned* __restrict__ flags, int B, int T,
-                                                  int R, int cluster, int ntiles) {
+                                                  int R, int cluster, int ntiles, Guard gd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // h tile [16][R+4]
+    __shared__ int s_poison;   // a hand-off wait of this workgroup gave up: everything it produces from here on is NaN
+    if (threadIdx.x == 0) s_poison = 0;
+    if ((gd.fault & 2) && cluster > 1 && blockIdx.x == 1) return;   // TIP_OPT_FAULT_INJECT: this member never arrives
     const int LDH = R + 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -534,17 +540,32 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
                 }
             if (t > 0 && cluster > 1) {
                 // wait for every member's slice of h_{t-1}, then pull the full [16][R] tile from HALL
-                if (tid == 0) {
+                if (tid == 0 && !s_poison) {
                     unsigned* f = flags + (size_t)tile * T + (t - 1);
+                    const unsigned lim = guard_spin_limit(gd.fault, 1u << 22);
                     unsigned spins = 0;
-                    for (; spins < (1u << 22); ++spins) {  // bounded: never hang the GPU
+                    for (; spins < lim; ++spins) {  // bounded: never hang the GPU
                         if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)cluster) break;
                         __builtin_amdgcn_s_sleep(1);
                     }
-                    if (spins == (1u << 22)) note_spin_timeout();
+                    if (spins == lim) {
+                        note_spin_timeout(gd.err);
+                        s_poison = t;                      // (t >= 1 here: the step whose wait gave up)
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
                 __syncthreads();
+                if (s_poison == t) {
+                    // h_{t-1} is incomplete (the missing member's slice of HALL holds stale memory): this member's slice of that
+                    // row turns NaN too, so the output row t-1 cannot come out finite
+#pragma unroll
+                    for (int n = 0; n < NBW; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int bb = b0 + lg * 4 + r;
+                            if (bb < B) hall[((size_t)bb * T + (t - 1)) * R + (nb0 + n) * 16 + l15] = __uint_as_float(kPoisonBits);
+                        }
+                }
                 for (int i = tid; i < kRnnTile * (R / 4); i += 256) {
                     const int m = i / (R / 4), c = (i % (R / 4)) * 4;
                     const int bb = b0 + m;
@@ -609,7 +630,8 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
 #pragma unroll
             for (int n = 0; n < NBW; ++n)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hvv[n][r] = (b0 + lg * 4 + r < B) ? tip_tanh(acc[n][r] + ihv[n][r]) : 0.f;
+                for (int r = 0; r < 4; ++r)
+                    hvv[n][r] = (b0 + lg * 4 + r < B) ? (s_poison ? __uint_as_float(kPoisonBits) : tip_tanh(acc[n][r] + ihv[n][r])) : 0.f;
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
                 const int col = (nb0 + n) * 16 + l15;
@@ -664,7 +686,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                                                                    const float* __restrict__ whh_frag,
                                                                    float* __restrict__ hall, unsigned* __restrict__ flags,
                                                                    int B, int T, int ntiles, int hall_bytes,
-                                                                   const float* __restrict__ gate) {
+                                                                   const float* __restrict__ gate, Guard gd) {
     constexpr int R = 512, KB = R / 16, KBW = KB / KSPLIT;      // k-blocks per wave
     constexpr int CBW = WAVES / KSPLIT;                          // 16-column blocks per workgroup
     constexpr int CLUSTER = KB / CBW;
@@ -690,6 +712,13 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
     const int l15 = lane & 15, lg = lane >> 4;
     const int nb = cid * CBW + cb;                                // global 16-column block of this wave
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hall, 0, hall_bytes, 0x00020000);
+    if ((gd.fault & 2) && group == 0 && cid == 1) return;         // TIP_OPT_FAULT_INJECT: this member never arrives
+    // A wait that gives up poisons: the waiter's words become canonical NaNs (never the sentinel: peers must not wait on
+    // them), every h it produces from then on is NaN, and it never spins again (one load pass per step).
+    bool poisoned = false;
+    __shared__ int s_poison0;                                     // HANDOFF == 0: the counter wait is lane 0's
+    if (HANDOFF == 0 && tid == 0) s_poison0 = 0;
+    const unsigned spin_big = guard_spin_limit(gd.fault, 1u << 22), spin_pull = guard_spin_limit(gd.fault, 1u << 20);
 
     // Same-XCD fast path, VERIFIED at run time (placement is never assumed): every member publishes the XCC id it
     // really runs on (agent-scope), reads the others', and only if all 16 agree do producers use plain stores — which
@@ -706,12 +735,12 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
             bool same = true;
             for (int m = 0; m < CLUSTER; ++m) {
                 unsigned v = 0;
-                for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                for (unsigned spins = 0; spins < spin_big; ++spins) {
                     v = __hip_atomic_load(flags + group * CLUSTER + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (v) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (!v) note_spin_timeout();
+                if (!v) note_spin_timeout(gd.err);   // (the step loop below will time out on this member too, and poison)
                 same &= (v == xcc + 1u);
             }
             s_same_xcd = same ? 1 : 0;
@@ -755,18 +784,28 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
             if (t > 0) {
                 constexpr int NLD = kRnnTile * (R / 4) / THREADS;   // float4 slots of the h tile per thread
                 if (HANDOFF == 0) {
-                    if (tid == 0) {
-                        // bounded spin: a cluster member that never arrives must not hang the GPU (result is then
-                        // wrong, which the parity tests catch)
+                    if (tid == 0 && !s_poison0) {
+                        // bounded spin: a cluster member that never arrives must not hang the GPU; giving up poisons
                         const unsigned* f = flags + (size_t)tile * T + (t - 1);
                         unsigned spins = 0;
-                        for (; spins < (1u << 22); ++spins) {
+                        for (; spins < spin_big; ++spins) {
                             if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)CLUSTER) break;
                             __builtin_amdgcn_s_sleep(1);
                         }
-                        if (spins == (1u << 22)) note_spin_timeout();
+                        if (spins == spin_big) {
+                            note_spin_timeout(gd.err);
+                            s_poison0 = t;                 // t >= 1
+                        }
                     }
                     __syncthreads();
+                    poisoned = s_poison0 != 0;
+                    if (s_poison0 == t && ks == 0) {       // the consumed row is incomplete: this member's slice of it turns NaN too
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int bb = b0 + lg * 4 + r;
+                            if (bb < B) hall[((size_t)bb * T + tp) * R + nb * 16 + l15] = __uint_as_float(kPoisonBits);
+                        }
+                    }
                 }
                 // pull h_{t-1} [16][512] with sc1 loads (aux = 16): bypass this CU's L1, coherent at agent scope
                 u32x4 v[NLD];
@@ -778,7 +817,8 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                     v[j] = (u32x4){0u, 0u, 0u, 0u};
                 }
                 bool gave_up = true;
-                for (unsigned spins = 0; spins < (1u << 20); ++spins) {
+                const unsigned pull_lim = poisoned ? 1u : spin_pull;
+                for (unsigned spins = 0; spins < pull_lim; ++spins) {
                     bool any = false;
 #pragma unroll
                     for (int j = 0; j < NLD; ++j) {
@@ -801,11 +841,23 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                     if (!any) { gave_up = false; break; }
                     if (!same_xcd) __builtin_amdgcn_s_sleep(2);   // cross-XCD polls travel the fabric: pace them
                 }
-                if (gave_up) note_spin_timeout();
+                if (gave_up && HANDOFF == 1) {
+                    if (!poisoned) note_spin_timeout(gd.err);
+                    poisoned = true;
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j)   // what never arrived becomes NaN, not the sentinel
+                        if (need[j]) {
+                            if (v[j].x == kRnnSentinel) v[j].x = kPoisonBits;
+                            if (v[j].y == kRnnSentinel) v[j].y = kPoisonBits;
+                            if (v[j].z == kRnnSentinel) v[j].z = kPoisonBits;
+                            if (v[j].w == kRnnSentinel) v[j].w = kPoisonBits;
+                        }
+                }
 #pragma unroll
                 for (int j = 0; j < NLD; ++j) {
                     const int i = tid + j * THREADS;
                     const int m = i / (R / 4), c = (i % (R / 4)) * 4;
+                    if (HANDOFF == 0 && poisoned) v[j] = (u32x4){kPoisonBits, kPoisonBits, kPoisonBits, kPoisonBits};
                     *reinterpret_cast<u32x4*>(smem + m * LDH + c) = v[j];
                 }
                 __syncthreads();
@@ -869,7 +921,10 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                 // store between two uses of the prefetched `ihv` makes the compiler wait for its write-through ack.
                 float hv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) hv[r] = BWD ? (acc[r] + ihv[r]) * (1.0f - gv[r] * gv[r]) : tip_tanh(acc[r] + ihv[r]);
+                for (int r = 0; r < 4; ++r) {
+                    hv[r] = BWD ? (acc[r] + ihv[r]) * (1.0f - gv[r] * gv[r]) : tip_tanh(acc[r] + ihv[r]);
+                    if (hv[r] != hv[r]) hv[r] = __uint_as_float(kPoisonBits);   // poison travels as the canonical NaN, never as the sentinel
+                }
                 // pin the four values here (the optimiser otherwise sinks each tanh back into its store's branch)
                 asm volatile("" : "+v"(hv[0]), "+v"(hv[1]), "+v"(hv[2]), "+v"(hv[3]));
 #pragma unroll
@@ -913,13 +968,20 @@ bool rnn_uses_sentinel(const Dims& d, int B, int T, int cluster) {
 
 template <int WAVES, int KSPLIT>
 static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T,
-                                      int ntiles, int num_cus, bool hall_armed, hipStream_t s, const float* gate = nullptr) {
+                                      int ntiles, int num_cus, bool hall_armed, const Guard& gd, hipStream_t s,
+                                      const float* gate = nullptr) {
     constexpr int CLUSTER = (512 / 16) / (WAVES / KSPLIT);
     int groups = ntiles;
     const int maxg = num_cus / CLUSTER > 0 ? num_cus / CLUSTER : 1;   // keep every cluster co-resident
     if (groups > maxg) groups = maxg;
     const int handoff = rnn_handoff_mode();
     const size_t smem = ((size_t)kRnnTile * (512 + 4) + (size_t)(KSPLIT - 1) * (WAVES / KSPLIT) * 256) * sizeof(float);
+    {
+        // every member of a cluster must be resident while its partners wait for it: ask the runtime, do not assume
+        static int occ = -1;
+        hipError_t ce = check_coresident(rnn_resident_kernel<WAVES, KSPLIT, 1>, WAVES * 64, smem, groups * CLUSTER, num_cus, &occ);
+        if (ce != hipSuccess) return ce;
+    }
     const long long hb = (long long)B * T * 512 * 4;
     if (hb > 0x7fffffffLL) return hipErrorInvalidValue;
     if (handoff == 0) {
@@ -927,10 +989,10 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
         if (e != hipSuccess) return e;
         if (gate)
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 0, false, true>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem,
-                               s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate);
+                               s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd);
         else
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 0>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
-                               whh_frag, hall, flags, B, T, ntiles, (int)hb, gate);
+                               whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd);
     } else {
         if (!hall_armed) {
             hipError_t e = hipMemsetAsync(hall, 0xFF, (size_t)hb, s);   // every word = kRnnSentinel
@@ -942,30 +1004,30 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
         if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
         if (gate)
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1, false, true>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem,
-                               s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate);
+                               s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd);
         else if (trace)
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1, true>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s,
-                               ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate);
+                               ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd);
         else
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
-                               whh_frag, hall, flags, B, T, ntiles, (int)hb, gate);
+                               whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd);
     }
     return hipGetLastError();
 }
 
 // backward recurrence of the training step (R = 512, cluster 4 / 8 / 16 only); see rnn_resident_kernel<.., BWD>
 hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_frag, const float* h_fwd, float* delta,
-                          unsigned* flags, int B, int T, int cluster, int num_cus, hipStream_t s) {
+                          unsigned* flags, int B, int T, int cluster, int num_cus, const Guard& gd, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (d.R != 512 || (long long)B * T * 512 * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
-    if (cluster >= 16) return launch_rnn_resident<8, 4>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, s, h_fwd);
-    if (cluster == 8) return launch_rnn_resident<4, 1>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, s, h_fwd);
-    return launch_rnn_resident<8, 1>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, s, h_fwd);
+    if (cluster >= 16) return launch_rnn_resident<8, 4>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, gd, s, h_fwd);
+    if (cluster == 8) return launch_rnn_resident<4, 1>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, gd, s, h_fwd);
+    return launch_rnn_resident<8, 1>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, gd, s, h_fwd);
 }
 
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
-                      int T, int cluster, int num_cus, bool hall_armed, hipStream_t s) {
+                      int T, int cluster, int num_cus, bool hall_armed, const Guard& gd, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     const int R = d.R;
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
@@ -975,11 +1037,11 @@ hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, flo
         if (cluster >= 16) {
             static int w8 = -1;   // TIP_RNN_C16=4 selects the 4-wave variant (measurement)
             if (w8 < 0) w8 = (getenv("TIP_RNN_C16") && getenv("TIP_RNN_C16")[0] == '4') ? 0 : 1;
-            return w8 ? launch_rnn_resident<8, 4>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, s)
-                      : launch_rnn_resident<4, 2>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, s);
+            return w8 ? launch_rnn_resident<8, 4>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, gd, s)
+                      : launch_rnn_resident<4, 2>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, gd, s);
         }
-        if (cluster == 8) return launch_rnn_resident<4, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, s);
-        if (cluster == 4) return launch_rnn_resident<8, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, s);
+        if (cluster == 8) return launch_rnn_resident<4, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, gd, s);
+        if (cluster == 4) return launch_rnn_resident<8, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, gd, s);
     }
     if (cluster > 8) cluster = 8;
     const int KB = R / 16;
@@ -997,7 +1059,7 @@ hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, flo
     const size_t smem = (size_t)kRnnTile * (R + 4) * sizeof(float);
     const dim3 grid(groups * cluster), block(256);
 #define TIP_RNN_CASE(N) \
-    case N: hipLaunchKernelGGL(rnn_kernel<N>, grid, block, smem, s, ih, whh_frag, hall, flags, B, T, R, cluster, ntiles); break;
+    case N: hipLaunchKernelGGL(rnn_kernel<N>, grid, block, smem, s, ih, whh_frag, hall, flags, B, T, R, cluster, ntiles, gd); break;
     switch (nbw) {
         TIP_RNN_CASE(1) TIP_RNN_CASE(2) TIP_RNN_CASE(3) TIP_RNN_CASE(4) TIP_RNN_CASE(5) TIP_RNN_CASE(6)
         TIP_RNN_CASE(7) TIP_RNN_CASE(8)
@@ -1018,4 +1080,22 @@ hipError_t read_spin_timeouts_general(unsigned* out) {
 extern "C" int tip_debug_read_rnn_trace(unsigned long long* out, int n) {
     if (!out || n < 0 || n > 64 * 4) return -1;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(tip::g_rnn_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
+}
+
+// measurement only: one lane writes {s_memtime (shader-clock ticks), wall_clock64 (constant 100 MHz), XCC id}.  Two probes
+// bracketing a stretch of work on the same stream give the shader clock actually held over it (bench.py, sustained pass).
+namespace tip {
+__global__ void clock_probe_kernel(unsigned long long* out) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    out[0] = __builtin_amdgcn_s_memtime();
+    out[1] = wall_clock64();
+    out[2] = xcc & 0xf;
+}
+}  // namespace tip
+
+extern "C" int tip_debug_clock_probe(unsigned long long* dev_out, void* stream) {
+    if (!dev_out) return -1;
+    hipLaunchKernelGGL(tip::clock_probe_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), dev_out);
+    return hipGetLastError() == hipSuccess ? 0 : -5;
 }

@@ -149,6 +149,37 @@ struct StageTimer {
 };
 constexpr size_t kMaxTimerPairs = 1 << 16;
 
+// What every kernel with an inter-workgroup hand-off is given: where to report a wait that gave up, and (tests only) which
+// cooperating workgroup to drop so that a wait MUST give up.
+//   err   device-visible pointer to the handle's pinned host word (null = no reporting): a give-up stores 1 there (system
+//         scope); tip_forward / tip_train_* / tip_check return TIP_ERR_HANDOFF while it is set.  The kernel that gave up
+//         also POISONS what it produces from then on (canonical NaN), so the launch's outputs are NaN, never finite-but-wrong.
+//   fault TIP_OPT_FAULT_INJECT bits: 1 = pair-split encoder, workgroup (pair 0, half 1) exits at entry; 2 = clustered RNN,
+//         member 1 of group 0 exits at entry; 4 = GEMV RNN (latency plan), member 1 of stream 0 exits at entry.  With any bit
+//         set the spin bounds shrink (2^14 polls) so the give-up takes milliseconds, not seconds.
+struct Guard {
+    unsigned* err = nullptr;
+    int fault = 0;
+};
+constexpr unsigned kPoisonBits = 0x7FC00000u;   // canonical quiet NaN (NOT the all-ones RNN sentinel)
+__device__ __forceinline__ unsigned guard_spin_limit(int fault, unsigned normal) { return fault ? (1u << 14) : normal; }
+__device__ __forceinline__ void guard_report(unsigned* err) {
+    if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// cooperating kernels need `grid` workgroups resident at once: checked against the runtime's own occupancy answer for THIS
+// kernel / block size / dynamic LDS (what hipLaunchCooperativeKernel checks, without its 15-19 us per launch); cached.
+template <typename K>
+inline hipError_t check_coresident(K kernel, int threads, size_t smem, int grid, int num_cus, int* cache) {
+    if (*cache < 0) {
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, smem);
+        if (e != hipSuccess) return e;
+        *cache = nb;
+    }
+    return (long long)grid <= (long long)*cache * num_cus ? hipSuccess : hipErrorCooperativeLaunchTooLarge;
+}
+
 }  // namespace tip
 
 struct tip_handle {
@@ -167,6 +198,10 @@ struct tip_handle {
     std::string last_hip_error;
     std::vector<tip::StageTimer> timers;
     int cur_timer = -1;
+    unsigned* err_host = nullptr;   // 64-byte pinned, device-mapped host block: word 0 = "a hand-off wait gave up" (sticky)
+    unsigned* err_dev = nullptr;    // the device's address of it
+    int fault_inject = 0;           // TIP_OPT_FAULT_INJECT (tests)
+    tip::Guard guard() const { return tip::Guard{err_dev, fault_inject}; }
 };
 
 namespace tip {
@@ -190,11 +225,11 @@ hipError_t launch_mattn_bwd(const float* qkv, const float* o_saved, const float*
                             int H, int dh, float q_scale, AttnDrop drop, hipStream_t s);
 hipError_t launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s);
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
-                      int T, int cluster, int num_cus, bool hall_armed, hipStream_t s);
+                      int T, int cluster, int num_cus, bool hall_armed, const Guard& gd, hipStream_t s);
 size_t rnn_flag_words(int B, int T);
 // training step, backward recurrence: delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2) (tip_train.hip)
 hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_frag, const float* h_fwd, float* delta,
-                          unsigned* flags, int B, int T, int cluster, int num_cus, hipStream_t s);
+                          unsigned* flags, int B, int T, int cluster, int num_cus, const Guard& gd, hipStream_t s);
 
 // ---- panel GEMM with fragment-ordered weights for big linears (tip_fused2.hip) ----
 bool pgemm_shape_ok(int M, int N, int K);   // N % 512 == 0, K % 128 == 0, M >= 320
@@ -280,7 +315,7 @@ bool latency_supported(const Dims& d, int B, int T);
 size_t latency_workspace_floats(int B, int T);
 hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float* whh_frag, const float* x_imu,
                                const float* x_s, const float* keep_mask, float keep_scale, float* ws, float* hall, int B,
-                               int T, hipStream_t s);
+                               int T, int num_cus, const Guard& gd, hipStream_t s);
 
 hipError_t launch_latency_head(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy,
                                int M, int N, hipStream_t s);
@@ -296,7 +331,7 @@ bool fused2s_fits(int B, int num_cus);
 size_t fused2s_xchg_floats(int B);
 hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                   const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
-                                  int B, int num_cus, hipStream_t s);
+                                  int B, int num_cus, const Guard& gd, hipStream_t s);
 hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, int B,
                                  int num_cus, hipStream_t s);

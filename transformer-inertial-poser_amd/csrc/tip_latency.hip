@@ -447,7 +447,7 @@ typedef unsigned long long u64;
 __device__ unsigned g_spin_timeouts_latency;   // see tip_spin_timeouts()
 __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__ ih, const float* __restrict__ whh_frag,
                                                        float* __restrict__ hall, u64* __restrict__ hb,
-                                                       unsigned* __restrict__ xcc_words, int B, int T) {
+                                                       unsigned* __restrict__ xcc_words, int B, int T, Guard gd) {
     using namespace lz;
     __shared__ __attribute__((aligned(16))) float hs[4 * 132];   // 4 K-quarters of 128, padded: distinct banks per quarter
     const int tid = threadIdx.x, lane = tid & 63;
@@ -456,6 +456,9 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
     // the 4 members of a stream's cluster are taken 8 blocks apart: observed to share an XCD (verified below)
     const int wg = (blockIdx.x >> 3) & 3, win = (blockIdx.x & 7) + 8 * (blockIdx.x >> 5);
     if (win >= B) return;
+    if ((gd.fault & 4) && win == 0 && wg == 1) return;   // TIP_OPT_FAULT_INJECT: this member never arrives
+    const unsigned spin_lim = guard_spin_limit(gd.fault, 1u << 22);
+    bool poisoned = false;   // a granule wait gave up: this thread's h words are NaN from here on and it never spins again
     const int row = wg * 128 + wave * 16 + l15;
     // run-time check that all 4 members really sit on one XCD: only then may granules be published with plain 8-byte
     // stores (they stay in the shared L2, where the peers' L1-bypassing loads see them after ~0.4 us); otherwise the
@@ -469,12 +472,15 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
         bool same = true;
         for (int m = 0; m < 4; ++m) {
             unsigned v = 0;
-            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+            for (unsigned spins = 0; spins < spin_lim; ++spins) {
                 v = __hip_atomic_load(xcc_words + win * 4 + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (v) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (!v) atomicAdd(&g_spin_timeouts_latency, 1u);
+            if (!v) {
+                atomicAdd(&g_spin_timeouts_latency, 1u);
+                guard_report(gd.err);
+            }
             same &= (v == xcc + 1u);
         }
         s_same_xcd = same ? 1 : 0;
@@ -501,11 +507,21 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
             // gather h_{t-1}: thread i polls granule i until its tag says "step t" (bounded: never hang the GPU)
             const u64* gp = hbw + (size_t)((t - 1) & 1) * R + tid;
             u64 v = 0;
-            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+            const unsigned lim = poisoned ? 1u : spin_lim;
+            for (unsigned spins = 0; spins < lim; ++spins) {
                 v = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(v >> 32) == (unsigned)t) break;
             }
-            if ((unsigned)(v >> 32) != (unsigned)t) atomicAdd(&g_spin_timeouts_latency, 1u);
+            if ((unsigned)(v >> 32) != (unsigned)t) {
+                if (!poisoned) {
+                    atomicAdd(&g_spin_timeouts_latency, 1u);
+                    guard_report(gd.err);
+                }
+                if (!poisoned && lg == 0)   // row t-1 is incomplete (the missing slice holds stale memory): no finite y row may come of it
+                    hw[(size_t)(t - 1) * R + row] = __uint_as_float(kPoisonBits);
+                poisoned = true;
+                v = (u64)kPoisonBits;   // the word that never came is NaN: every hidden unit that reads it follows
+            }
             hs[(tid >> 7) * 132 + (tid & 127)] = __uint_as_float((unsigned)v);
             __syncthreads();
             const float* hq = hs + lg * 132;
@@ -552,7 +568,7 @@ size_t latency_workspace_floats(int B, int T) {
 
 hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float* whh_frag, const float* x_imu,
                                const float* x_s, const float* keep_mask, float keep_scale, float* ws, float* hall, int B,
-                               int T, hipStream_t s) {
+                               int T, int num_cus, const Guard& gd, hipStream_t s) {
     using namespace lz;
     const size_t bt = (size_t)B * T;
     float* xa = ws;
@@ -593,7 +609,12 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
     const size_t ih_off = LAYER0 + (size_t)d.L * LAYER_FLOATS;
     hipLaunchKernelGGL((lat_ln_gemm_kernel<false, false>), dim3(32, B), dim3(256), 0, s, fused_w, wbytes, xa, pg, pb, (int)(ih_off * 4),
                        (int)(ih_off + (size_t)R * D), ihb, R, (float*)nullptr, T);
-    hipLaunchKernelGGL(rnn_gemv_kernel, dim3(32 * ((B + 7) / 8)), dim3(512), 0, s, ihb, whh_frag, hall, gran, xccw, B, T);
+    {
+        static int occ = -1;   // the 4 workgroups of every stream's cluster must be resident together
+        hipError_t ce = check_coresident(rnn_gemv_kernel, 512, (size_t)0, 4 * B, num_cus, &occ);
+        if (ce != hipSuccess) return ce;
+    }
+    hipLaunchKernelGGL(rnn_gemv_kernel, dim3(32 * ((B + 7) / 8)), dim3(512), 0, s, ihb, whh_frag, hall, gran, xccw, B, T, gd);
     return hipGetLastError();
 }
 

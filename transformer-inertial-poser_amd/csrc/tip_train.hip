@@ -1389,6 +1389,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
                       const float* keep_mask, float keep_scale, float p_drop, unsigned long long seed, float* y, void* saved,
                       size_t saved_bytes, int B, int T, void* stream) {
     if (!h || !params || !x_imu || !x_s || !y || !saved) return TIP_ERR_INVALID_ARG;
+    if (tip_check(h, 0) != TIP_OK) return TIP_ERR_HANDOFF;   // an earlier launch lost a hand-off (sticky; tip_check(h, 1) clears)
     if (n_params != (int)h->tensor_names.size()) return TIP_ERR_INVALID_ARG;
     if (p_drop < 0.f || p_drop >= 1.f) return TIP_ERR_INVALID_ARG;
     const Dims& d = h->d;
@@ -1548,7 +1549,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     }
     }   // layer-by-layer path
     TT(launch_rnn(d, W + L.ih, W + L.whh_f, W + L.hall, reinterpret_cast<unsigned*>(W + L.flags), B, T, auto_cluster(B, h->num_cus),
-                  h->num_cus, hall_armed, s), "train_rnn");
+                  h->num_cus, hall_armed, h->guard(), s), "train_rnn");
     {
         TG g = tg_base(W + L.hall, d.R, rp[PR_LIN_W], d.R, y, d.S, M, d.S, d.R);
         g.bias = rp[PR_LIN_B];
@@ -1562,6 +1563,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
                        size_t saved_bytes, void* scratch, size_t scratch_bytes, float* grads, size_t grads_floats, float p_drop,
                        unsigned long long seed, int B, int T, void* stream) {
     if (!h || !params || !dy || !saved || !scratch || !grads) return TIP_ERR_INVALID_ARG;
+    if (tip_check(h, 0) != TIP_OK) return TIP_ERR_HANDOFF;
     if (n_params != (int)h->tensor_names.size()) return TIP_ERR_INVALID_ARG;
     const Dims& d = h->d;
     if (!train_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
@@ -1611,7 +1613,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     }
     // ---- recurrence (:98-99), time reversed: delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2) -------------------------
     TT(launch_rnn_bwd(d, X + S.dh, W + L.whh_b, W + L.hall, X + S.delta, reinterpret_cast<unsigned*>(const_cast<float*>(W + L.flags)),
-                      B, T, auto_cluster(B, ncu), ncu, s), "bwd_rnn");
+                      B, T, auto_cluster(B, ncu), ncu, h->guard(), s), "bwd_rnn");
     hipLaunchKernelGGL(shift_rows_kernel, dim3(grid_for((long long)M * d.R / 4)), dim3(256), 0, s, W + L.hall, X + S.hprev, T,
                        d.R / 4, (long long)M * d.R / 4);
     TT(hipGetLastError(), "bwd_shift");

@@ -33,7 +33,9 @@ def broadcast_packed(model, src: int = 0, device=None) -> torch.Tensor:
     device = torch.device(device)
     nbytes = model._ensure_handle().packed_bytes()
     if rank == src:
-        packed = model.pack_host().to(device)
+        # parameters already on this GPU: pack there (bit-identical image, no host loops — matters for the 609-MB scaled model)
+        on_dev = device.type == "cuda" and all(p.is_cuda and p.device == device for p in model.parameters())
+        packed = model.pack_device(device) if on_dev else model.pack_host().to(device)
     else:
         packed = torch.empty(nbytes, dtype=torch.uint8, device=device)
     if world > 1:

@@ -15,7 +15,8 @@ TIP_FWD_LAST_ROW_ONLY = 0x1
 TIP_FWD_KEEP_MASK = 0x2
 TIP_PLAN_AUTO, TIP_PLAN_GENERAL, TIP_PLAN_FUSED, TIP_PLAN_LATENCY, TIP_PLAN_FUSED2, TIP_PLAN_FUSED2S = 0, 1, 2, 3, 4, 5
 TIP_SAVED_QKV, TIP_SAVED_ATT, TIP_SAVED_X1, TIP_SAVED_HID, TIP_SAVED_XOUT, TIP_SAVED_HALL = range(6)
-TIP_OPT_PLAN, TIP_OPT_PROFILE, TIP_OPT_RNN_CLUSTER = 1, 2, 3
+TIP_OPT_PLAN, TIP_OPT_PROFILE, TIP_OPT_RNN_CLUSTER, TIP_OPT_FAULT_INJECT = 1, 2, 3, 4
+TIP_ERR_HANDOFF = -8
 TIP_LOSS_Q, TIP_LOSS_C, TIP_LOSS_J, TIP_LOSS_STATS = 1, 2, 4, 16
 
 # every symbol include/tip_hip.h declares (tests check the .so exports exactly these)
@@ -23,7 +24,7 @@ EXPORTS = (
     "tip_abi_version", "tip_create", "tip_destroy", "tip_strerror", "tip_last_hip_error", "tip_set_option",
     "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
     "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_forward", "tip_forward_count", "tip_profile_read",
-    "tip_spin_timeouts", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
+    "tip_spin_timeouts", "tip_check", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
     "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward",
     "tip_combine_frames", "tip_combine_scratch_bytes", "tip_combine_sequence", "tip_gather_windows",
     "tip_loss_ws_bytes", "tip_loss_forward", "tip_loss_backward",
@@ -38,6 +39,11 @@ class TipStatusError(RuntimeError):
     def __init__(self, status: int, text: str):
         super().__init__(f"libtip_hip: {text} (status {status})")
         self.status = status
+
+
+class TipHandoffError(TipStatusError):
+    """An inter-workgroup hand-off wait of an EARLIER launch gave up (a co-tenant held CUs, or a partner workgroup never
+    became resident): the outputs of that launch are NaN-poisoned.  Sticky until Handle.check(clear=True)."""
 
 
 class TipConfig(ctypes.Structure):
@@ -98,6 +104,7 @@ def load() -> ctypes.CDLL:
     lib.tip_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
                                      ctypes.POINTER(i32), i32]
     lib.tip_spin_timeouts.argtypes = [ctypes.POINTER(ctypes.c_uint)]
+    lib.tip_check.argtypes = [vp, i32]
     lib.tip_stream_state_bytes.argtypes = [i32, ctypes.POINTER(sz)]
     lib.tip_stream_reset.argtypes = [vp, vp, i32, vp]
     lib.tip_stream_window_len.argtypes = [i32]
@@ -140,6 +147,8 @@ class Handle:
             text = self.lib.tip_strerror(status).decode()
             if status == -5 and self._h:
                 text += " — " + self.lib.tip_last_hip_error(self._h).decode()
+            if status == TIP_ERR_HANDOFF:
+                raise TipHandoffError(status, text)
             raise TipStatusError(status, text)
         return status
 
@@ -218,6 +227,11 @@ class Handle:
         arr = (ctypes.c_void_p * len(param_ptrs))(*param_ptrs)
         self._check(self.lib.tip_train_backward(self._h, arr, len(param_ptrs), dy, saved, saved_bytes, scratch,
                                                 scratch_bytes, grads, grads_floats, p_drop, seed, B, T, stream))
+
+    def check(self, clear: bool = False):
+        """Raise TipHandoffError if a hand-off wait of a completed launch gave up (no device sync: synchronise the stream first
+        for a definitive answer about launches in flight).  clear=True also resets the sticky word."""
+        self._check(self.lib.tip_check(self._h, 1 if clear else 0))
 
     def forward_count(self) -> int:
         n = ctypes.c_uint64()

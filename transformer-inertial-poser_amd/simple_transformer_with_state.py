@@ -178,7 +178,7 @@ class TF_RNN_Past_State(nn.Module):
             # not covered by the HIP training step: the torch-op composite, with the encoder dropout .train() implies
             if not self._warned_autograd:
                 warnings.warn("tip_amd: .train()-mode call (or autograd on CPU) that the HIP training kernels do not cover "
-                              "(rnn_hid_size != 512, fp64, CPU tensors or gradients w.r.t. the inputs) — using the torch-op "
+                              "(rnn_hid_size != 512, fp64, CPU tensors or gradients w.r.t. the inputs) — using the torch-op training "
                               "composite with encoder dropout p=0.1 live, as in the reference; call .eval() for the "
                               "inference kernels")
                 self._warned_autograd = True
@@ -282,6 +282,23 @@ class TF_RNN_Past_State(nn.Module):
         h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fused2s": 5}[plan])
         h.set_option(_lib.TIP_OPT_RNN_CLUSTER, int(rnn_cluster))
         h.set_option(_lib.TIP_OPT_PROFILE, int(profile))
+
+    def check_handoffs(self, synchronize: bool = True, clear: bool = False):
+        """Raise lib.TipHandoffError if any launch so far lost an inter-workgroup hand-off (its outputs are NaN-poisoned, never
+        finite-but-wrong).  The cooperating plans need the GPU to themselves: a co-tenant holding CUs can starve a partner
+        workgroup.  Without this call the NEXT forward raises the same error (the flag is sticky until clear=True)."""
+        if self._handle is None:
+            return
+        if synchronize and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        try:
+            self._handle.check(clear=False)
+        finally:
+            if clear:
+                try:
+                    self._handle.check(clear=True)
+                except _lib.TipHandoffError:
+                    pass
 
     def profile_read(self):
         return self._ensure_handle().profile_read()
