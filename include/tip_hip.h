@@ -68,6 +68,9 @@ typedef enum tip_status {
 #define TIP_PLAN_FUSED2S 5 /* pair-split: a window pair on TWO co-resident workgroups, columns split, partial sums exchanged
                               twice per layer (80 rows x half the columns per CU: no row padding at B <= #CUs);
                               needs 2*ceil(B/2) <= #CUs; AUTO picks it for 64 < B <= #CUs */
+#define TIP_PLAN_FUSEDH  6 /* TIP_PLAN_FUSED with a hybrid row tiling: rows 0-31 on 16x16x4 MFMAs, rows 32-39 on 4x4x1 MFMAs fed by the
+                              same weight fragments — no matrix-core work on the pad rows 40-47 outside the QKV projection.  No
+                              inter-workgroup hand-off in the encoder.  Rows 0-31 bit-identical to TIP_PLAN_FUSED. */
 #define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);
                               AUTO picks it for B <= 64 */
 

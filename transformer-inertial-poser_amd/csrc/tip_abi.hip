@@ -291,7 +291,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
     if (!h) return TIP_ERR_INVALID_ARG;
     switch (option) {
         case TIP_OPT_PLAN:
-            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED2S) return TIP_ERR_INVALID_ARG;
+            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSEDH) return TIP_ERR_INVALID_ARG;
             h->plan = value;
             return TIP_OK;
         case TIP_OPT_PROFILE:
@@ -300,7 +300,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
             for (auto& t : h->timers) t.used = 0;  // reset the accumulators
             return TIP_OK;
         case TIP_OPT_RNN_CLUSTER:
-            if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) return TIP_ERR_INVALID_ARG;
+            if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32)) return TIP_ERR_INVALID_ARG;
             h->rnn_cluster = value;
             return TIP_OK;
         case TIP_OPT_FAULT_INJECT:
@@ -609,11 +609,16 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         if (latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;   // <= 64 streams: spread each window over many CUs (0.65 vs 0.86 ms at B = 64)
         else plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
     }
-    if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO && fused2_supported(d, T) && B >= 2 * h->num_cus)
-        plan = TIP_PLAN_FUSED2;   // two windows per workgroup once every CU has at least two to chew on
-    else if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO && fused2_supported(d, T) && fused2s_fits(B, h->num_cus))
-        plan = TIP_PLAN_FUSED2S;  // at most one window per CU: window pairs on CU pairs, columns split (no row padding; 3-4 % faster)
-    if (plan == TIP_PLAN_FUSED && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO) {
+        // One window per workgroup with the hybrid row tiling (no hand-offs, 0.59 ms per round of #CUs windows at T = 40), or
+        // two windows per workgroup (80 rows = 5 full MFMA row blocks, 1.10 ms per round of 2 x #CUs windows): whichever
+        // needs less time for this batch.  (The pair-split plan, 0.63 ms per round with 8 hand-offs per pair, lost its
+        // place to the hybrid kernel and stays selectable for measurement.)
+        const long long cus = h->num_cus;
+        const long long rounds_h = (B + cus - 1) / cus, rounds_2 = ((B + 1) / 2 + cus - 1) / cus;
+        plan = (fused2_supported(d, T) && rounds_2 * 1100 < rounds_h * 593) ? TIP_PLAN_FUSED2 : TIP_PLAN_FUSEDH;
+    }
+    if ((plan == TIP_PLAN_FUSED || plan == TIP_PLAN_FUSEDH) && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2S && !(fused2_supported(d, T) && fused2s_fits(B, h->num_cus) && B <= 1024)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
@@ -646,6 +651,13 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
         TIP_TRY(launch_fused_encoder2(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr, B,
                                       h->num_cus, s), "fused_encoder2");
+    } else if (plan == TIP_PLAN_FUSEDH) {
+        StageScope sc(h, s, "fused_encoder");
+        ih_done = fused_has_rnn_ih(d);
+        hall_armed = ih_done && rnn_uses_sentinel(d, B, T, rnn_cluster);
+        TIP_TRY(launch_fused_encoder_h(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, ih_done ? nullptr : xa,
+                                       ih_done ? big : nullptr, hall_armed ? hall : nullptr, B, T, h->num_cus, s),
+                "fused_encoder_h");
     } else if (plan == TIP_PLAN_FUSED) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = fused_has_rnn_ih(d);

@@ -659,6 +659,348 @@ hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* 
 }
 
 // =====================================================================================================================
+// "fusedh": the one-window kernel with a HYBRID row tiling — no padded matrix-core work outside the QKV projection.
+//
+// T = 40 rows do not fill three 16-row MFMA blocks: in fused_encoder_kernel every weight fragment multiplies rows 0-15,
+// 16-31 and 32-47, and a third of that last block's cycles (17 % of all MFMA issue time) is spent on the eight zero rows
+// 40-47.  Here rows 0-31 keep v_mfma_f32_16x16x4_f32 (two row blocks), and rows 32-39 go through
+// v_mfma_f32_4x4x1_16b_f32 — sixteen independent 4x4x1 blocks per instruction, 512 FLOP in 2 passes (measured 8.4-9 cycles
+// per instruction against 32 for a 16x16x4: tools/probes/mfma4x4_probe.hip) — fed by THE SAME B-fragment registers:
+//   the 16x16x4 weight fragment has lane (l15, lg) = W[col 16 nb + l15][k = 16 kb + 4 lg + s] in component s.  Read as the
+//   B operand of a 4x4x1, lane 4 b + j is column j of block b: block b = 4 lg + (l15 >> 2), j = l15 & 3, i.e. block
+//   (lg, cb) multiplies columns 4 cb .. 4 cb + 3 at k = 16 kb + 4 lg + s.  Its A operand (lane 4 b + i = row i of block b)
+//   is X[row0 + i][16 kb + 4 lg + s]: one ds_read_b128 per (4-row block, k-block), lanes that differ only in cb reading the
+//   same address (LDS broadcast).  The accumulator of lane (lg, cb, j) then holds, in register i, the partial sum over the
+//   k == 4 lg .. 4 lg + 3 (mod 16) of output (row0 + i, column 16 nb + 4 cb + j): four k-partials per output, one per lg,
+//   combined once per phase by a two-step exchange (xor 32, xor 16) that leaves row row0 + lg in lane (lg, l15).
+// Per (16-column block, k-block): 8 big + 8 small MFMAs = 8 x 32 + 8 x 9 = 328 issue cycles instead of 12 x 32 = 384.
+// The QKV projection keeps the three padded 16-row blocks: its accumulators ARE the attention's register fragments
+// (attention_head_regs), which a 4x4x1 tail cannot produce without a cross-lane transpose per head.
+// Rows 40-47 of X are zeroed once and only ever pass through LayerNorm (-> beta): finite pad keys/values for the attention.
+// Numerics: rows 0-31 are bit-identical to TIP_PLAN_FUSED (same instructions; causality keeps rows >= 32 out of them);
+// rows 32-39 differ in summation order only (four k-chains per output instead of one).
+// =====================================================================================================================
+namespace fzh {
+constexpr int RBM = 2;    // 16-row MFMA blocks (rows 0-31)
+constexpr int RBT = 2;    // 4-row blocks of the tail (rows 32-35, 36-39)
+constexpr int TAIL0 = 32;
+}  // namespace fzh
+
+template <int NBW>
+__device__ __forceinline__ void mfma_block_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 (&acct)[fzh::RBT][NBW], const float4 (&a)[fzh::RBM],
+                                             const float4 (&at)[fzh::RBT], const float4 (&w)[NBW]) {
+#define TIP_MFMA_STEP_H(c)                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < fzh::RBM; ++r) _Pragma("unroll") for (int n = 0; n < NBW; ++n)               \
+        acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].c, w[n].c, acc[r][n], 0, 0, 0);                         \
+    _Pragma("unroll") for (int r = 0; r < fzh::RBT; ++r) _Pragma("unroll") for (int n = 0; n < NBW; ++n)               \
+        acct[r][n] = __builtin_amdgcn_mfma_f32_4x4x1f32(at[r].c, w[n].c, acct[r][n], 0, 0, 0);
+    TIP_MFMA_STEP_H(x)
+    TIP_MFMA_STEP_H(y)
+    TIP_MFMA_STEP_H(z)
+    TIP_MFMA_STEP_H(w)
+#undef TIP_MFMA_STEP_H
+}
+
+// acc  [r][n] += A[rows 16 r .. 16 r + 15] x Wblock(n, kb)      (r = 0, 1)
+// acct [r][n] += A[rows 32 + 4 r .. + 3]  x Wblock(n, kb), per-lg k-partials (see above)
+//   Am: this lane's LDS address for the 16-row blocks (base + l15 * lda + lg * 4);  At: for the tail (base + (32 + (lane & 3)) *
+//   lda + lg * 4).  Weight ring semantics exactly as gemm_phase.
+template <int NBW, int KB>
+__device__ __forceinline__ void gemm_phase_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 (&acct)[fzh::RBT][NBW], const float* Am, const float* At,
+                                             int lda, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b, WRing<NBW>& g,
+                                             int nsoff, int nnstride_b) {
+    static_assert(KB % 2 == 0, "k-blocks are processed in pairs");
+    float4 a0[fzh::RBM], a1[fzh::RBM], t0[fzh::RBT], t1[fzh::RBT];
+#pragma unroll
+    for (int r = 0; r < fzh::RBM; ++r) a0[r] = *reinterpret_cast<const float4*>(Am + r * 16 * lda);
+#pragma unroll
+    for (int r = 0; r < fzh::RBT; ++r) t0[r] = *reinterpret_cast<const float4*>(At + r * 4 * lda);
+#pragma unroll 1
+    for (int kb = 0; kb < KB; kb += 2) {
+        const bool last = kb + 2 >= KB;
+        const int o = last ? nsoff : soff + (kb + 2) * 1024;
+        const int st = last ? nnstride_b : nstride_b;
+#pragma unroll
+        for (int r = 0; r < fzh::RBM; ++r) a1[r] = *reinterpret_cast<const float4*>(Am + r * 16 * lda + (kb + 1) * 16);
+#pragma unroll
+        for (int r = 0; r < fzh::RBT; ++r) t1[r] = *reinterpret_cast<const float4*>(At + r * 4 * lda + (kb + 1) * 16);
+        mfma_block_h<NBW>(acc, acct, a0, t0, g.w0);
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) g.w0[n] = load_frag(rsrc, voff, o + n * st);
+#pragma unroll
+        for (int r = 0; r < fzh::RBM; ++r) a0[r] = *reinterpret_cast<const float4*>(Am + r * 16 * lda + (kb + 2) * 16);
+#pragma unroll
+        for (int r = 0; r < fzh::RBT; ++r) t0[r] = *reinterpret_cast<const float4*>(At + r * 4 * lda + (kb + 2) * 16);
+        mfma_block_h<NBW>(acc, acct, a1, t1, g.w1);
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) g.w1[n] = load_frag(rsrc, voff, o + n * st + 1024);
+    }
+}
+
+template <int NBW>
+__device__ __forceinline__ void zero_acc_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 (&acct)[fzh::RBT][NBW]) {
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+#pragma unroll
+        for (int r = 0; r < fzh::RBM; ++r) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < fzh::RBT; ++r) acct[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// Combine the four k-partials of a tail accumulator (registers = rows row0 .. row0 + 3, one partial per lg): two exchange
+// steps, after which lane (lg, l15) holds the finished sum of row row0 + lg, column l15 of the block.  Every row is summed
+// as (p[lg] + p[lg ^ 2]) + (p[lg ^ 1] + p[lg ^ 3]) — the same pairing for all four rows.
+__device__ __forceinline__ float tail_reduce(const f32x4& v, int lg) {
+    const bool hi = (lg & 2) != 0, odd = (lg & 1) != 0;
+    const float s0 = hi ? v[0] : v[2], s1 = hi ? v[1] : v[3];      // the two rows this lane gives away
+    const float k0 = (hi ? v[2] : v[0]) + __shfl_xor(s0, 32, 64);  // rows {0,1} stay with lg in {0,1}, rows {2,3} with {2,3}
+    const float k1 = (hi ? v[3] : v[1]) + __shfl_xor(s1, 32, 64);
+    const float give = odd ? k0 : k1;
+    return (odd ? k1 : k0) + __shfl_xor(give, 16, 64);             // row 2 * (lg >> 1) + (lg & 1) = lg
+}
+
+__global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
+    const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
+    const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ xout, float* __restrict__ ih_out,
+    unsigned* __restrict__ hall_sentinel, int B, int T, int NI, int S, int L, int wbytes, int ih_off_b) {
+    using namespace fz;
+    using namespace fzh;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;
+    float* C = smem + X_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, wbytes, 0x00020000);
+    const int voff = lane * 16;
+    // this lane's LDS offsets (floats) inside a [rows][ld] operand: 16-row blocks / tail blocks
+    auto am = [&](int ld) { return l15 * ld + lg * 4; };
+    auto at = [&](int ld) { return (TAIL0 + (lane & 3)) * ld + lg * 4; };
+
+    // rows 40..47 of the residual stream: zero once; afterwards only LayerNorm touches them (-> beta, finite pad keys/values)
+    for (int i = tid; i < 8 * LDX; i += THREADS) X[TMAX * LDX + i] = 0.f;
+
+    for (int win = blockIdx.x; win < B; win += gridDim.x) {
+        const int in_soff = (int)(IN_W * 4) + (wave * 2) * (KIN / 16) * 1024;
+        WRing<2> g_in;
+        ring_prefetch<2>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
+        WRing<3> g_qkv;
+        // ---- P0 prologue (:63-78) ------------------------------------------------------------------------------------
+        float* U = C;
+        for (int i = tid; i < RP * LDU; i += THREADS) U[i] = 0.f;
+        __syncthreads();
+        {
+            const float* xi = x_imu + (size_t)win * T * NI;
+            for (int i = tid; i < T * NI; i += THREADS) {
+                const int r = i / NI, c = i - r * NI;
+                U[r * LDU + c] = xi[i];
+            }
+            const float* xs = x_s + (size_t)win * T * S;
+            const float* km = keep_mask ? keep_mask + (size_t)win * T * S : nullptr;
+            for (int i = tid; i < T * S; i += THREADS) {
+                const int r = i / S, c = i - r * S;
+                float v = xs[i];
+                if (v != v) v = 0.f;                  // :65
+                if (km) v = v * km[i] * keep_scale;   // :77 with an explicit keep-mask
+                U[r * LDU + NI + c] = v;
+            }
+        }
+        __syncthreads();
+        // ---- P1 in_linear (:79) + channel shuffle (folded) -------------------------------------------------------------
+        {
+            f32x4 acc[RBM][2], acct[RBT][2];
+            zero_acc_h<2>(acc, acct);
+            gemm_phase_h<2, KIN / 16>(acc, acct, U + am(LDU), U + at(LDU), LDU, rsrc, voff, in_soff, (KIN / 16) * 1024, g_in, in_soff,
+                                      (KIN / 16) * 1024);
+            ring_prefetch<3>(g_qkv, rsrc, voff, (int)(LAYER0 * 4) + (int)(QKV_W * 4) + wave * 16 * 1024, 16 * 16 * 1024);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = (wave * 2 + n) * 16 + l15;
+                const float bv = wts[IN_B + col];
+#pragma unroll
+                for (int r = 0; r < RBM; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] = acc[r][n][e] + bv;
+#pragma unroll
+                for (int r = 0; r < RBT; ++r) X[(TAIL0 + 4 * r + lg) * LDX + col] = tail_reduce(acct[r][n], lg) + bv;
+            }
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int layer = 0; layer < L; ++layer) {
+            const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
+            const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
+            float* Qc = C;
+            f32x4 acc_o[RBM][2], acc_ot[RBT][2];
+            zero_acc_h<2>(acc_o, acc_ot);
+            WRing<2> g_o, g_f;
+#pragma unroll 1
+            for (int c = 0; c < 2; ++c) {
+                {
+                    // QKV projection of head 8c + wave on the three padded 16-row blocks + attention in registers (as in the
+                    // one-window kernel: the accumulators are the attention's fragments)
+                    const int head = c * 8 + wave;
+                    f32x4 acc[RB][3];
+                    zero_acc<3>(acc);
+                    const int qsoff = lbase + (int)(QKV_W * 4) + head * 16 * 1024;
+                    gemm_phase<3, 16, false, 2, false>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, qsoff, 16 * 16 * 1024, g_qkv, qsoff,
+                                                       16 * 16 * 1024);
+                    ring_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + c * 8) * 1024, 16 * 1024);
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(LW + QKV_B + head * 16 + lg * 4);
+                    const f32x4 bk = *reinterpret_cast<const f32x4*>(LW + QKV_B + D + head * 16 + lg * 4);
+                    const float bv = LW[QKV_B + 2 * D + head * 16 + l15];
+                    f32x4 qt[RB], kt[RB], vv[RB];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        qt[r] = acc[r][0] + bq;
+                        kt[r] = acc[r][1] + bk;
+                        vv[r] = acc[r][2] + bv;
+                    }
+                    attention_head_regs<LDC>(qt, kt, vv, Qc, wave * 16, lane, TMAX);   // rows 40..47 of the O plane are never read
+                }
+                __syncthreads();
+                if (c == 0)
+                    ring_prefetch<3>(g_qkv, rsrc, voff, lbase + (int)(QKV_W * 4) + (8 + wave) * 16 * 1024, 16 * 16 * 1024);
+                else
+                    ring_prefetch<2>(g_f, rsrc, voff, lbase + (int)(W1_W * 4) + (wave * 2) * 16 * 1024, 16 * 1024);
+                {
+                    const int osoff = lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + c * 8) * 1024;
+                    gemm_phase_h<2, 8>(acc_o, acc_ot, Qc + am(LDC), Qc + at(LDC), LDC, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
+                }
+                __syncthreads();
+            }
+            // residual + bias, then LayerNorm1
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = (wave * 2 + n) * 16 + l15;
+                const float bv = LW[WO_B + col];
+#pragma unroll
+                for (int r = 0; r < RBM; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_o[r][n][e] + bv;
+#pragma unroll
+                for (int r = 0; r < RBT; ++r) X[(TAIL0 + 4 * r + lg) * LDX + col] += tail_reduce(acc_ot[r][n], lg) + bv;
+            }
+            __syncthreads();
+            layernorm_rows(X, LW + G1, LW + BE1, wave, lane);
+            __syncthreads();
+            // ---- feed-forward block: hidden in 4 chunks of 256, linear2 accumulates in registers -------------------------
+            float* Hc = C;
+            f32x4 acc_f[RBM][2], acc_ft[RBT][2];
+            zero_acc_h<2>(acc_f, acc_ft);
+#pragma unroll 1
+            for (int f = 0; f < 4; ++f) {
+                {
+                    f32x4 acc[RBM][2], acct[RBT][2];
+                    zero_acc_h<2>(acc, acct);
+                    const int nb0 = f * 16 + wave * 2;
+                    const int w1off = lbase + (int)(W1_W * 4) + nb0 * 16 * 1024;
+                    const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
+                    gemm_phase_h<2, 16>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, w1off, 16 * 1024, g_f, w2off, 64 * 1024);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int col = (wave * 2 + n) * 16 + l15;
+                        const float bv = LW[W1_B + f * 256 + col];
+#pragma unroll
+                        for (int r = 0; r < RBM; ++r)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) Hc[(r * 16 + lg * 4 + e) * LDX + col] = fmaxf(acc[r][n][e] + bv, 0.f);
+#pragma unroll
+                        for (int r = 0; r < RBT; ++r)
+                            Hc[(TAIL0 + 4 * r + lg) * LDX + col] = fmaxf(tail_reduce(acct[r][n], lg) + bv, 0.f);
+                    }
+                }
+                __syncthreads();
+                {
+                    const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
+                    const int nxt = f < 3 ? lbase + (int)(W1_W * 4) + ((f + 1) * 16 + wave * 2) * 16 * 1024 : w2off;
+                    gemm_phase_h<2, 16>(acc_f, acc_ft, Hc + am(LDX), Hc + at(LDX), LDX, rsrc, voff, w2off, 64 * 1024, g_f, nxt,
+                                        f < 3 ? 16 * 1024 : 64 * 1024);
+                }
+                __syncthreads();
+            }
+            if (layer + 1 < L)
+                ring_prefetch<3>(g_qkv, rsrc, voff, lbase + (int)(LAYER_FLOATS * 4) + (int)(QKV_W * 4) + wave * 16 * 1024, 16 * 16 * 1024);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = (wave * 2 + n) * 16 + l15;
+                const float bv = LW[W2_B + col];
+#pragma unroll
+                for (int r = 0; r < RBM; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_f[r][n][e] + bv;
+#pragma unroll
+                for (int r = 0; r < RBT; ++r) X[(TAIL0 + 4 * r + lg) * LDX + col] += tail_reduce(acc_ft[r][n], lg) + bv;
+            }
+            __syncthreads();
+            layernorm_rows(X, LW + G2, LW + BE2, wave, lane);
+            __syncthreads();
+        }
+        // ---- RNN input projection: IH = X W_ih^T + (b_ih + b_hh), rows 0..T-1 -> HBM -------------------------------------
+        if (ih_out) {
+            f32x4 acc[RBM][4], acct[RBT][4];
+            zero_acc_h<4>(acc, acct);
+            const int isoff = ih_off_b + (wave * 4) * 16 * 1024;
+            WRing<4> g_ih;
+            ring_prefetch<4>(g_ih, rsrc, voff, isoff, 16 * 1024);
+            gemm_phase_h<4, 16>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
+            float* io = ih_out + (size_t)win * T * R;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int col = (wave * 4 + n) * 16 + l15;
+                const float bv = wts[ih_off_b / 4 + R * D + col];
+#pragma unroll
+                for (int r = 0; r < RBM; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = r * 16 + lg * 4 + e;
+                        if (row < T) io[(size_t)row * R + col] = acc[r][n][e] + bv;
+                    }
+#pragma unroll
+                for (int r = 0; r < RBT; ++r) {
+                    const float v = tail_reduce(acct[r][n], lg) + bv;
+                    const int row = TAIL0 + 4 * r + lg;
+                    if (row < T) io[(size_t)row * R + col] = v;
+                }
+            }
+        }
+        if (hall_sentinel) {
+            uint4* hp = reinterpret_cast<uint4*>(hall_sentinel + (size_t)win * T * R);
+            for (int i = tid; i < T * (R / 4); i += THREADS) hp[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        }
+        if (xout) {
+            float* out = xout + (size_t)win * T * D;
+            for (int i = tid; i < T * (D / 4); i += THREADS) {
+                const int r = i / (D / 4), c4 = i - r * (D / 4);
+                *reinterpret_cast<float4*>(out + (size_t)r * D + c4 * 4) = *reinterpret_cast<const float4*>(X + r * LDX + c4 * 4);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_fused_encoder_h(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
+                                  const float* keep_mask, float keep_scale, float* xout, float* ih_out, float* hall_sentinel,
+                                  int B, int T, int num_cus, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_h_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = B < num_cus ? B : num_cus;
+    float* iho = fused_has_rnn_ih(d) ? ih_out : nullptr;
+    hipLaunchKernelGGL(fused_encoder_h_kernel, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+                       keep_scale, xout, iho, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,
+                       (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4));
+    return hipGetLastError();
+}
+
+// =====================================================================================================================
 // Training step, backward of one encoder layer's feed-forward block, fused per window.
 //   dy = dL/d(layer output)  ->  LayerNorm2 backward  ->  dz2 (kept: it is also the residual path into the block's input)
 //   dff2 = dz2 * keep3                      (gradient into linear2's output; also linear2's bias-gradient rows)

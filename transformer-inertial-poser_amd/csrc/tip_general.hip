@@ -969,10 +969,10 @@ bool rnn_uses_sentinel(const Dims& d, int B, int T, int cluster) {
 template <int WAVES, int KSPLIT>
 static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T,
                                       int ntiles, int num_cus, bool hall_armed, const Guard& gd, hipStream_t s,
-                                      const float* gate = nullptr) {
+                                      const float* gate = nullptr, int wg_per_cu = 1) {
     constexpr int CLUSTER = (512 / 16) / (WAVES / KSPLIT);
     int groups = ntiles;
-    const int maxg = num_cus / CLUSTER > 0 ? num_cus / CLUSTER : 1;   // keep every cluster co-resident
+    const int maxg = num_cus * wg_per_cu / CLUSTER > 0 ? num_cus * wg_per_cu / CLUSTER : 1;   // keep every cluster co-resident
     if (groups > maxg) groups = maxg;
     const int handoff = rnn_handoff_mode();
     const size_t smem = ((size_t)kRnnTile * (512 + 4) + (size_t)(KSPLIT - 1) * (WAVES / KSPLIT) * 256) * sizeof(float);
@@ -1034,6 +1034,8 @@ hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, flo
     if (cluster < 1) cluster = 1;
     if (R == 512 && (long long)B * T * 512 * 4 <= 0x7fffffffLL) {
         // register-resident clustered kernel: W_hh slice lives in VGPRs, 4/8/16 workgroups per window tile
+        if (cluster >= 32)   // two 4-wave workgroups per CU, each one column block of a tile: one computes while the other waits
+            return launch_rnn_resident<4, 4>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, gd, s, nullptr, 2);
         if (cluster >= 16) {
             static int w8 = -1;   // TIP_RNN_C16=4 selects the 4-wave variant (measurement)
             if (w8 < 0) w8 = (getenv("TIP_RNN_C16") && getenv("TIP_RNN_C16")[0] == '4') ? 0 : 1;

@@ -251,6 +251,10 @@ bool fused_has_rnn_ih(const Dims& d);
 hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                 const float* keep_mask, float keep_scale, float* xout, float* ih_out, float* hall_sentinel,
                                 int B, int T, int num_cus, hipStream_t s);
+// hybrid row tiling (rows 0-31 on 16x16x4, rows 32-39 on 4x4x1 MFMAs: no padded rows outside the QKV projection); same contract
+hipError_t launch_fused_encoder_h(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
+                                  const float* keep_mask, float keep_scale, float* xout, float* ih_out, float* hall_sentinel,
+                                  int B, int T, int num_cus, hipStream_t s);
 // fused backward of one encoder layer's feed-forward block for the training step (tip_fused.hip): LayerNorm2 backward ->
 // d(hidden) -> d(LN1 output), one workgroup per window; weight fragments of W2^T / W1^T from the backward image
 size_t fused_bwd_image_floats(const Dims& d);

@@ -279,7 +279,7 @@ class TF_RNN_Past_State(nn.Module):
 
     def set_plan(self, plan: str = "auto", rnn_cluster: int = 0, profile: int = 0):
         h = self._ensure_handle()
-        h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fused2s": 5}[plan])
+        h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fused2s": 5, "fusedh": 6}[plan])
         h.set_option(_lib.TIP_OPT_RNN_CLUSTER, int(rnn_cluster))
         h.set_option(_lib.TIP_OPT_PROFILE, int(profile))
 
