@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Measurement only: phase timeline of the hybrid one-window encoder (workgroup 0, layer 1) from s_memtime stamps.
+usage: TIP_FUSEDH_TRACE=1 python tools/fh_trace.py"""
+import contextlib, ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import tip_amd
+from tip_amd import synth, lib as tlib
+cfg = synth.PAPER
+with contextlib.redirect_stdout(sys.stderr):
+    m = tip_amd.TF_RNN_Past_State(72, 131, rnn_hid_size=512, tf_hid_size=1024, tf_in_dim=256, n_heads=16, tf_layers=4,
+                                  dropout=0.0, in_dropout=0.0, past_state_dropout=0.0, with_acc_sum=True)
+m.load_state_dict({k: torch.tensor(v) for k, v in synth.make_weights(cfg, seed=0).items()})
+m = m.cuda().eval()
+m.set_plan("fusedh")
+x_imu, x_s = synth.make_inputs(cfg, 256, 40)
+xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+with torch.no_grad():
+    for _ in range(5):
+        m(xi, xs)
+    torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 64)()
+assert tlib.load().tip_debug_read_fh_trace(buf, 64) == 0
+t = np.array(buf[:], dtype=np.float64)
+GHZ = 2.4
+def d(a, b): return (t[b] - t[a])
+def row(name, cyc, mfma16=0, mfma4=0):
+    ideal = mfma16 * 32 + mfma4 * 8          # issue cycles of this wave's MFMAs x 2 waves per SIMD
+    print(f"  {name:44s} {cyc:8.0f} cyc = {cyc / GHZ / 1e3:6.2f} us" + (f"   MFMA issue (2 waves/SIMD) {2 * ideal:6.0f} cyc = {200 * ideal / cyc:5.1f} %" if ideal else ""))
+print("window: prologue (input staging)", d(0, 1)); print("        in_linear + epilogue + barrier", d(1, 2))
+print("layer 1:")
+for c in range(2):
+    base = 8 if c == 0 else 12
+    row(f"chunk {c}: QKV projection (3 padded blocks)", d(base if c == 0 else 12, 9 + 4 * c), mfma16=3 * 3 * 16 * 4)
+    row(f"chunk {c}: attention (registers)", d(9 + 4 * c, 10 + 4 * c), mfma16=48)
+    row(f"chunk {c}: barrier", d(10 + 4 * c, 11 + 4 * c))
+    row(f"chunk {c}: out-projection partial + barrier", d(11 + 4 * c, 12 + 4 * c), mfma16=2 * 2 * 8 * 4, mfma4=2 * 2 * 8 * 4)
+row("residual epilogue + barrier", d(16, 17))
+row("LayerNorm1 + barrier", d(17, 18))
+for f in range(4):
+    prev = 18 if f == 0 else 21 + 3 * (f - 1)
+    row(f"FFN chunk {f}: linear1 + ReLU epilogue", d(prev, 19 + 3 * f), mfma16=2 * 2 * 16 * 4, mfma4=2 * 2 * 16 * 4)
+    row(f"FFN chunk {f}: barrier", d(19 + 3 * f, 20 + 3 * f))
+    row(f"FFN chunk {f}: linear2 partial + barrier", d(20 + 3 * f, 21 + 3 * f), mfma16=2 * 2 * 16 * 4, mfma4=2 * 2 * 16 * 4)
+row("residual epilogue + barrier", d(30, 31))
+row("LayerNorm2 + barrier", d(31, 32))
+row("whole layer 1", d(8, 32))
+print("tail: RNN input projection + stores + sentinel", d(40, 41), "cyc =", d(40, 41) / GHZ / 1e3, "us")
+print("whole window (prologue .. end):", d(0, 41), "cyc =", d(0, 41) / GHZ / 1e3, "us")

@@ -21,9 +21,9 @@ with torch.no_grad():
     for _ in range(5):
         m(xi, xs)
     torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 160)()
+buf = (ctypes.c_ulonglong * 256)()
 lib = tlib.load()
-assert lib.tip_debug_read_rnn_trace(buf, 160) == 0
+assert lib.tip_debug_read_rnn_trace(buf, 256) == 0
 t = np.array(buf[:160], dtype=np.float64).reshape(40, 4)
 ghz = 0.1  # s_memtime ticks at 100 MHz on this part if constant-rate; printed raw and as deltas
 pull, mma, done = t[1:, 0], t[1:, 1], t[1:, 2]
@@ -31,4 +31,15 @@ print("ticks per step (median):", np.median(np.diff(t[1:, 0])))
 print("pull-done -> mfma-done  :", np.median(mma - pull))
 print("mfma-done -> stores-out :", np.median(done - mma))
 print("stores-out -> next pull :", np.median(pull[1:] - done[:-1]))
+probe = t[1:, 3]
+if probe.max() > 0:
+    print("stores-out -> arrival probe passes :", np.median(probe[1:] - done[:-1]))
+    print("probe passes -> tile pulled + in LDS:", np.median(pull - probe))
+x = np.array(buf[160:252], dtype=np.float64).reshape(23, 4)     # steps 1..23: first round done, loop exit, LDS written, rounds
+if x[:, 0].max() > 0:
+    pr = t[1:24, 3]
+    print("probe passes -> first pull round checked:", np.median(x[:, 0] - pr))
+    print("first round -> pull loop exit            :", np.median(x[:, 1] - x[:, 0]), " rounds (thread 0):", np.median(x[:, 3]), x[:, 3].max())
+    print("loop exit -> own LDS writes done         :", np.median(x[:, 2] - x[:, 1]))
+    print("LDS written -> barrier passed            :", np.median(t[1:24, 0] - x[:, 2]))
 print("first rows:", t[:4])

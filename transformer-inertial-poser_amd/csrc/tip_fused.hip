@@ -760,6 +760,11 @@ __device__ __forceinline__ float tail_reduce(const f32x4& v, int lg) {
     return (odd ? k1 : k0) + __shfl_xor(give, 16, 64);             // row 2 * (lg >> 1) + (lg & 1) = lg
 }
 
+// measurement only (TIP_FUSEDH_TRACE=1): s_memtime stamps of workgroup 0 / thread 0 at the phase boundaries of layer 1
+__device__ unsigned long long g_fh_trace[64];
+#define FH_STAMP(slot) do { if (TRACE && blockIdx.x == 0 && tid == 0 && (layer == 1 || (slot) < 4 || (slot) >= 40)) g_fh_trace[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+
+template <bool TRACE>
 __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
     const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
     const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ xout, float* __restrict__ ih_out,
@@ -782,10 +787,13 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
     for (int i = tid; i < 8 * LDX; i += THREADS) X[TMAX * LDX + i] = 0.f;
 
     for (int win = blockIdx.x; win < B; win += gridDim.x) {
+        WRing<3> g_qkv;
+        {
+        const int layer = -1;
+        FH_STAMP(0);
         const int in_soff = (int)(IN_W * 4) + (wave * 2) * (KIN / 16) * 1024;
         WRing<2> g_in;
         ring_prefetch<2>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
-        WRing<3> g_qkv;
         // ---- P0 prologue (:63-78) ------------------------------------------------------------------------------------
         float* U = C;
         for (int i = tid; i < RP * LDU; i += THREADS) U[i] = 0.f;
@@ -807,6 +815,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             }
         }
         __syncthreads();
+        FH_STAMP(1);
         // ---- P1 in_linear (:79) + channel shuffle (folded) -------------------------------------------------------------
         {
             f32x4 acc[RBM][2], acct[RBT][2];
@@ -827,9 +836,11 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             }
         }
         __syncthreads();
-
+        FH_STAMP(2);
+        }
 #pragma unroll 1
         for (int layer = 0; layer < L; ++layer) {
+            FH_STAMP(8);
             const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
             const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
             float* Qc = C;
@@ -858,9 +869,12 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                         kt[r] = acc[r][1] + bk;
                         vv[r] = acc[r][2] + bv;
                     }
+                    FH_STAMP(9 + 4 * c);    // QKV projection issued and its results consumed
                     attention_head_regs<LDC>(qt, kt, vv, Qc, wave * 16, lane, TMAX);   // rows 40..47 of the O plane are never read
+                    FH_STAMP(10 + 4 * c);
                 }
                 __syncthreads();
+                FH_STAMP(11 + 4 * c);
                 if (c == 0)
                     ring_prefetch<3>(g_qkv, rsrc, voff, lbase + (int)(QKV_W * 4) + (8 + wave) * 16 * 1024, 16 * 16 * 1024);
                 else
@@ -870,6 +884,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                     gemm_phase_h<2, 8>(acc_o, acc_ot, Qc + am(LDC), Qc + at(LDC), LDC, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
                 }
                 __syncthreads();
+                FH_STAMP(12 + 4 * c);
             }
             // residual + bias, then LayerNorm1
 #pragma unroll
@@ -884,8 +899,10 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                 for (int r = 0; r < RBT; ++r) X[(TAIL0 + 4 * r + lg) * LDX + col] += tail_reduce(acc_ot[r][n], lg) + bv;
             }
             __syncthreads();
+            FH_STAMP(17);
             layernorm_rows(X, LW + G1, LW + BE1, wave, lane);
             __syncthreads();
+            FH_STAMP(18);
             // ---- feed-forward block: hidden in 4 chunks of 256, linear2 accumulates in registers -------------------------
             float* Hc = C;
             f32x4 acc_f[RBM][2], acc_ft[RBT][2];
@@ -912,7 +929,9 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                             Hc[(TAIL0 + 4 * r + lg) * LDX + col] = fmaxf(tail_reduce(acct[r][n], lg) + bv, 0.f);
                     }
                 }
+                FH_STAMP(19 + 3 * f);
                 __syncthreads();
+                FH_STAMP(20 + 3 * f);
                 {
                     const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                     const int nxt = f < 3 ? lbase + (int)(W1_W * 4) + ((f + 1) * 16 + wave * 2) * 16 * 1024 : w2off;
@@ -920,6 +939,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                                         f < 3 ? 16 * 1024 : 64 * 1024);
                 }
                 __syncthreads();
+                FH_STAMP(21 + 3 * f);
             }
             if (layer + 1 < L)
                 ring_prefetch<3>(g_qkv, rsrc, voff, lbase + (int)(LAYER_FLOATS * 4) + (int)(QKV_W * 4) + wave * 16 * 1024, 16 * 16 * 1024);
@@ -935,9 +955,12 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                 for (int r = 0; r < RBT; ++r) X[(TAIL0 + 4 * r + lg) * LDX + col] += tail_reduce(acc_ft[r][n], lg) + bv;
             }
             __syncthreads();
+            FH_STAMP(31);
             layernorm_rows(X, LW + G2, LW + BE2, wave, lane);
             __syncthreads();
+            FH_STAMP(32);
         }
+        { const int layer = -1; FH_STAMP(40); }
         // ---- RNN input projection: IH = X W_ih^T + (b_ih + b_hh), rows 0..T-1 -> HBM -------------------------------------
         if (ih_out) {
             f32x4 acc[RBM][4], acct[RBT][4];
@@ -978,8 +1001,10 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             }
         }
         __syncthreads();
+        { const int layer = -1; FH_STAMP(41); }
     }
 }
+#undef FH_STAMP
 
 hipError_t launch_fused_encoder_h(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                   const float* keep_mask, float keep_scale, float* xout, float* ih_out, float* hall_sentinel,
@@ -987,19 +1012,33 @@ hipError_t launch_fused_encoder_h(const Dims& d, const float* fused_w, const flo
     if (B <= 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_h_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
-        if (e != hipSuccess) return e;
+        for (const void* f : {reinterpret_cast<const void*>(fused_encoder_h_kernel<false>), reinterpret_cast<const void*>(fused_encoder_h_kernel<true>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
+    static int trace = -1;
+    if (trace < 0) trace = getenv("TIP_FUSEDH_TRACE") ? 1 : 0;
     const int grid = B < num_cus ? B : num_cus;
     float* iho = fused_has_rnn_ih(d) ? ih_out : nullptr;
-    hipLaunchKernelGGL(fused_encoder_h_kernel, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
-                       keep_scale, xout, iho, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,
-                       (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4));
+    if (trace)
+        hipLaunchKernelGGL(fused_encoder_h_kernel<true>, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+                           keep_scale, xout, iho, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,
+                           (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4));
+    else
+        hipLaunchKernelGGL(fused_encoder_h_kernel<false>, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+                           keep_scale, xout, iho, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,
+                           (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4));
     return hipGetLastError();
 }
 
+}  // namespace tip
+extern "C" int tip_debug_read_fh_trace(unsigned long long* out, int n) {
+    if (!out || n < 0 || n > 64) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tip::g_fh_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
+}
+namespace tip {
 // =====================================================================================================================
 // Training step, backward of one encoder layer's feed-forward block, fused per window.
 //   dy = dL/d(layer output)  ->  LayerNorm2 backward  ->  dz2 (kept: it is also the residual path into the block's input)

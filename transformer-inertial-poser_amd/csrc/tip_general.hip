@@ -686,7 +686,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                                                                    const float* __restrict__ whh_frag,
                                                                    float* __restrict__ hall, unsigned* __restrict__ flags,
                                                                    int B, int T, int ntiles, int hall_bytes,
-                                                                   const float* __restrict__ gate, Guard gd) {
+                                                                   const float* __restrict__ gate, Guard gd, int prepoll) {
     constexpr int R = 512, KB = R / 16, KBW = KB / KSPLIT;      // k-blocks per wave
     constexpr int CBW = WAVES / KSPLIT;                          // 16-column blocks per workgroup
     constexpr int CLUSTER = KB / CBW;
@@ -719,6 +719,9 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
     __shared__ int s_poison0;                                     // HANDOFF == 0: the counter wait is lane 0's
     if (HANDOFF == 0 && tid == 0) s_poison0 = 0;
     const unsigned spin_big = guard_spin_limit(gd.fault, 1u << 22), spin_pull = guard_spin_limit(gd.fault, 1u << 20);
+    // Every member pulls the same 32-KB tile at the same moment: started at the same row they would queue behind each other at
+    // every L2 line.  Member cid starts its sweep at row cid (TIP_RNN_ROTATE=0 switches it off for measurement).
+    const int rot = prepoll & 2 ? cid : 0;
 
     // Same-XCD fast path, VERIFIED at run time (placement is never assumed): every member publishes the XCC id it
     // really runs on (agent-scope), reads the others', and only if all 16 agree do producers use plain stores — which
@@ -807,13 +810,33 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                         }
                     }
                 }
+                if (HANDOFF == 1 && (prepoll & 1)) {   // (workgroup-uniform condition: there is a barrier inside)
+                    // Cheap arrival probe before the 32-KB pull.  Sixteen workgroups re-pulling whole tiles until the last
+                    // sentinel is gone keep the XCD's L2 at its bandwidth limit, so every poll round takes ~700 cycles; here ONE
+                    // wave watches 1 KB — a 16-byte piece of the LAST row group each producer wave stores (rows 4 lg + 3 of its 16
+                    // columns) — and the full pull starts when none of them holds a sentinel.  A hint only: stores of one wave
+                    // may become visible out of order, so the pull below still checks every word and re-asks for stragglers.
+                    if (wave == 0) {
+                        const int nrows = min(kRnnTile, B - b0);
+                        const int prow = min(((lane & 1) ? 15 : 7), nrows - 1);          // rows 7 / 15: last store of lg = 1 / 3
+                        const int poff = (int)((((size_t)(b0 + prow) * T + tp) * R + (lane >> 1) * 16 + 12) * 4);
+                        const unsigned plim = poisoned ? 1u : spin_pull;   // a poisoned lane never waits again
+                        for (unsigned spins = 0; spins < plim; ++spins) {
+                            const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(hrs, poff, 0, 16);
+                            const bool pend = pv.x == kRnnSentinel || pv.y == kRnnSentinel || pv.z == kRnnSentinel || pv.w == kRnnSentinel;
+                            if (__builtin_amdgcn_ballot_w64(pend) == 0) break;
+                        }
+                        if (TRACE && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 3] = __builtin_amdgcn_s_memtime();
+                    }
+                    __syncthreads();
+                }
                 // pull h_{t-1} [16][512] with sc1 loads (aux = 16): bypass this CU's L1, coherent at agent scope
                 u32x4 v[NLD];
                 bool need[NLD];
 #pragma unroll
                 for (int j = 0; j < NLD; ++j) {
                     const int i = tid + j * THREADS;
-                    need[j] = b0 + i / (R / 4) < B;
+                    need[j] = b0 + ((i / (R / 4) + rot) & (kRnnTile - 1)) < B;
                     v[j] = (u32x4){0u, 0u, 0u, 0u};
                 }
                 bool gave_up = true;
@@ -824,7 +847,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                     for (int j = 0; j < NLD; ++j) {
                         if (need[j]) {
                             const int i = tid + j * THREADS;
-                            const int m = i / (R / 4), c = (i % (R / 4)) * 4;
+                            const int m = (i / (R / 4) + rot) & (kRnnTile - 1), c = (i % (R / 4)) * 4;
                             v[j] = __builtin_amdgcn_raw_buffer_load_b128(hrs, (int)((((size_t)(b0 + m) * T + tp) * R + c) * 4), 0, 16);
                         }
                     }
@@ -838,9 +861,12 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                             any |= pend;
                         }
                     }
+                    if (TRACE && blockIdx.x == 0 && tid == 0 && t < 24 && spins == 0) g_rnn_trace[160 + (t - 1) * 4 + 0] = __builtin_amdgcn_s_memtime();
+                    if (TRACE && blockIdx.x == 0 && tid == 0 && t < 24) g_rnn_trace[160 + (t - 1) * 4 + 3] = spins + 1;
                     if (!any) { gave_up = false; break; }
                     if (!same_xcd) __builtin_amdgcn_s_sleep(2);   // cross-XCD polls travel the fabric: pace them
                 }
+                if (TRACE && blockIdx.x == 0 && tid == 0 && t < 24) g_rnn_trace[160 + (t - 1) * 4 + 1] = __builtin_amdgcn_s_memtime();
                 if (gave_up && HANDOFF == 1) {
                     if (!poisoned) note_spin_timeout(gd.err);
                     poisoned = true;
@@ -856,9 +882,13 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
 #pragma unroll
                 for (int j = 0; j < NLD; ++j) {
                     const int i = tid + j * THREADS;
-                    const int m = i / (R / 4), c = (i % (R / 4)) * 4;
+                    const int m = (i / (R / 4) + rot) & (kRnnTile - 1), c = (i % (R / 4)) * 4;
                     if (HANDOFF == 0 && poisoned) v[j] = (u32x4){kPoisonBits, kPoisonBits, kPoisonBits, kPoisonBits};
                     *reinterpret_cast<u32x4*>(smem + m * LDH + c) = v[j];
+                }
+                if (TRACE && blockIdx.x == 0 && tid == 0 && t < 24) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    g_rnn_trace[160 + (t - 1) * 4 + 2] = __builtin_amdgcn_s_memtime();
                 }
                 __syncthreads();
                 if (TRACE && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 0] = __builtin_amdgcn_s_memtime();
@@ -985,14 +1015,15 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
     const long long hb = (long long)B * T * 512 * 4;
     if (hb > 0x7fffffffLL) return hipErrorInvalidValue;
     if (handoff == 0) {
+        const int prepoll = 0;
         hipError_t e = hipMemsetAsync(flags, 0, (size_t)ntiles * T * sizeof(unsigned), s);
         if (e != hipSuccess) return e;
         if (gate)
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 0, false, true>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem,
-                               s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd);
+                               s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, prepoll);
         else
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 0>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
-                               whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd);
+                               whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, prepoll);
     } else {
         if (!hall_armed) {
             hipError_t e = hipMemsetAsync(hall, 0xFF, (size_t)hb, s);   // every word = kRnnSentinel
@@ -1002,15 +1033,20 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
         if (e2 != hipSuccess) return e2;
         static int trace = -1;
         if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
+        static int prepoll_env = -1;   // TIP_RNN_PREPOLL=0: no arrival probe before the tile pull (measurement)
+        if (prepoll_env < 0) prepoll_env = (getenv("TIP_RNN_PREPOLL") && getenv("TIP_RNN_PREPOLL")[0] == '0') ? 0 : 1;
+        static int rot_env = -1;       // TIP_RNN_ROTATE=0: every member sweeps the tile from row 0 (measurement)
+        if (rot_env < 0) rot_env = (getenv("TIP_RNN_ROTATE") && getenv("TIP_RNN_ROTATE")[0] == '0') ? 0 : 2;
+        const int prepoll = prepoll_env | rot_env;
         if (gate)
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1, false, true>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem,
-                               s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd);
+                               s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, prepoll);
         else if (trace)
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1, true>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s,
-                               ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd);
+                               ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, prepoll);
         else
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem, s, ih,
-                               whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd);
+                               whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, prepoll);
     }
     return hipGetLastError();
 }
