@@ -38,7 +38,9 @@ typedef struct tip_config {
     int32_t tf_layers;       /* 4 */
     int32_t with_rnn;        /* :15 */
     int32_t with_acc_sum;    /* :16  (+18 input columns, :20-22) */
-    int32_t t_max;           /* longest window the handle must serve (40; 80 for the scaled config) */
+    int32_t t_max;           /* typical longest window (40; 80 for the scaled config): a sizing hint only — tip_forward serves any
+                                T >= 1 (the reference builds its causal mask for any length, :56-58,85); T > 128 takes the key-tiled
+                                attention of the general plan */
 } tip_config;
 
 typedef enum tip_status {

@@ -573,7 +573,10 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
                 const float* keep_mask, float keep_scale, void* workspace, size_t workspace_bytes,
                 tip_stream_t stream) {
     if (!h || !x_imu || !x_s || !y || B < 0 || T < 1) return TIP_ERR_INVALID_ARG;
-    if (T > h->d.t_max) return TIP_ERR_INVALID_ARG;
+    // (cfg.t_max is a sizing hint, not a limit: the reference builds its causal mask for any window length, :56-58,85; what
+    // bounds B * T here are the 32-bit byte offsets of the buffer descriptors)
+    if ((long long)B * T * (long long)std::max(std::max(3 * h->d.D, h->d.F), std::max(h->d.R, h->d.InPad)) * 4 > 0x7fffffffLL)
+        return TIP_ERR_UNSUPPORTED_CONFIG;
     if ((flags & TIP_FWD_KEEP_MASK) && !keep_mask) return TIP_ERR_INVALID_ARG;
     if (!h->packed_dev) return TIP_ERR_NOT_READY;
     if (tip_check(h, 0) != TIP_OK) return TIP_ERR_HANDOFF;   // sticky: an earlier launch lost a hand-off (tip_check(h, 1) clears)

@@ -328,34 +328,27 @@ hipError_t launch_head_gemm(const float* A, long long lda, const float* wfrag, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// attention: one wave per (window, head).  K and V of the head are staged in LDS; lane i owns query row i
-// (and i+64 when T > 64): q and the output accumulator live in registers, scores never leave the lane
-// (online softmax), so the row reductions need no cross-lane traffic at all.
+// attention for ANY window length (the matrix-core kernels of tip_attn.hip serve T <= 128; the reference builds its mask for
+// any T, simple_transformer_with_state.py:56-58,85): one wave per (window, head), lane i owns query row r0 + i of a 64-query
+// chunk — q and the output accumulator in registers, online softmax, so the row reductions need no cross-lane traffic — and
+// the keys/values stream through a wave-private LDS tile of TK keys at a time (key-tiled: LDS use does not grow with T).
+// A wave's LDS operations complete in program order: refilling its own tile needs no workgroup barrier.
 // ------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B,
-                                                        int T, int H, float q_scale) {
+                                                        int T, int H, float q_scale, int TK) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int waves = blockDim.x >> 6;
     const int D = H * DH;
     const int ld = 3 * D;
     const int bh = blockIdx.x * waves + wave;
-    float* Ks = smem + (size_t)wave * 2 * T * DH;
-    float* Vs = Ks + (size_t)T * DH;
-    const bool active = bh < B * H;
-    const int b = active ? bh / H : 0, h = active ? bh % H : 0;
+    float* Ks = smem + (size_t)wave * 2 * TK * DH;
+    float* Vs = Ks + (size_t)TK * DH;
+    if (bh >= B * H) return;
+    const int b = bh / H, h = bh % H;
     const float* base = qkv + (size_t)b * T * ld + h * DH;
-    if (active) {
-        constexpr int V4 = DH / 4;
-        for (int f = lane; f < T * V4; f += 64) {
-            const int j = f / V4, e = (f % V4) * 4;
-            *reinterpret_cast<float4*>(Ks + j * DH + e) = *reinterpret_cast<const float4*>(base + (size_t)j * ld + D + e);
-            *reinterpret_cast<float4*>(Vs + j * DH + e) = *reinterpret_cast<const float4*>(base + (size_t)j * ld + 2 * D + e);
-        }
-    }
-    __syncthreads();
-    if (!active) return;
+    constexpr int V4 = DH / 4;
     for (int r0 = 0; r0 < T; r0 += 64) {
         const int i = r0 + lane;
         const bool rv = i < T;
@@ -370,29 +363,42 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         for (int e = 0; e < DH; ++e) o[e] = 0.f;
         float m = -INFINITY, l = 0.f;
         const int jmax = min(T, r0 + 64);  // keys needed by the last row of this chunk
-        for (int j = 0; j < jmax; ++j) {
-            const float* kj = Ks + j * DH;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-            for (int e = 0; e < DH; e += 4) {
-                const float4 kv = *reinterpret_cast<const float4*>(kj + e);
-                s0 = fmaf(q[e], kv.x, s0); s1 = fmaf(q[e + 1], kv.y, s1);
-                s2 = fmaf(q[e + 2], kv.z, s2); s3 = fmaf(q[e + 3], kv.w, s3);
+        for (int k0 = 0; k0 < jmax; k0 += TK) {
+            const int kn = min(TK, jmax - k0);
+            __builtin_amdgcn_wave_barrier();   // (the previous tile's reads are issued before it is overwritten)
+            for (int f = lane; f < kn * V4; f += 64) {
+                const int j = f / V4, e = (f % V4) * 4;
+                *reinterpret_cast<float4*>(Ks + j * DH + e) = *reinterpret_cast<const float4*>(base + (size_t)(k0 + j) * ld + D + e);
+                *reinterpret_cast<float4*>(Vs + j * DH + e) = *reinterpret_cast<const float4*>(base + (size_t)(k0 + j) * ld + 2 * D + e);
             }
-            const float sc = (s0 + s1) + (s2 + s3);
-            if (j <= i) {  // causal mask (:56-58): key j visible to query i iff j <= i
-                const float mn = fmaxf(m, sc);
-                const float corr = expf(m - mn);   // exp(-inf) = 0 on the first key
-                const float p = expf(sc - mn);
-                l = l * corr + p;
-                const float* vj = Vs + j * DH;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int jj = 0; jj < kn; ++jj) {
+                const int j = k0 + jj;
+                const float* kj = Ks + jj * DH;
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
                 for (int e = 0; e < DH; e += 4) {
-                    const float4 vv = *reinterpret_cast<const float4*>(vj + e);
-                    o[e] = fmaf(o[e], corr, p * vv.x); o[e + 1] = fmaf(o[e + 1], corr, p * vv.y);
-                    o[e + 2] = fmaf(o[e + 2], corr, p * vv.z); o[e + 3] = fmaf(o[e + 3], corr, p * vv.w);
+                    const float4 kv = *reinterpret_cast<const float4*>(kj + e);
+                    s0 = fmaf(q[e], kv.x, s0); s1 = fmaf(q[e + 1], kv.y, s1);
+                    s2 = fmaf(q[e + 2], kv.z, s2); s3 = fmaf(q[e + 3], kv.w, s3);
                 }
-                m = mn;
+                const float sc = (s0 + s1) + (s2 + s3);
+                if (j <= i) {  // causal mask (:56-58): key j visible to query i iff j <= i
+                    const float mn = fmaxf(m, sc);
+                    const float corr = expf(m - mn);   // exp(-inf) = 0 on the first key
+                    const float p = expf(sc - mn);
+                    l = l * corr + p;
+                    const float* vj = Vs + jj * DH;
+#pragma unroll
+                    for (int e = 0; e < DH; e += 4) {
+                        const float4 vv = *reinterpret_cast<const float4*>(vj + e);
+                        o[e] = fmaf(o[e], corr, p * vv.x); o[e + 1] = fmaf(o[e + 1], corr, p * vv.y);
+                        o[e + 2] = fmaf(o[e + 2], corr, p * vv.z); o[e + 3] = fmaf(o[e + 3], corr, p * vv.w);
+                    }
+                    m = mn;
+                }
             }
         }
         if (rv) {
@@ -413,17 +419,18 @@ hipError_t launch_attention(const Dims& d, const float* qkv, float* out, int B, 
         off.seed = 0; off.site = 0; off.thresh = 0; off.scale = 1.f;
         return launch_mattn_fwd(qkv, out, nullptr, B, T, d.H, d.dh, d.q_scale, off, s);
     }
-    const size_t per_wave = (size_t)2 * T * d.dh * sizeof(float);
-    int waves = 4;
-    while (waves > 1 && per_wave * waves > 64 * 1024) waves >>= 1;
+    // key tile per wave: the whole window when it fits 16 KB per wave (4 waves = 64 KB, no opt-in needed), else 16 KB worth of keys
+    const int waves = 4;
+    int TK = (16 * 1024) / (2 * d.dh * (int)sizeof(float));
+    if (TK > T) TK = T;
     const int nbh = B * d.H;
     dim3 grid((nbh + waves - 1) / waves), block(64 * waves);
-    const size_t smem = per_wave * waves;
+    const size_t smem = (size_t)waves * 2 * TK * d.dh * sizeof(float);
     switch (d.dh) {
-        case 8: hipLaunchKernelGGL(attention_kernel<8>, grid, block, smem, s, qkv, out, B, T, d.H, d.q_scale); break;
-        case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, block, smem, s, qkv, out, B, T, d.H, d.q_scale); break;
-        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, block, smem, s, qkv, out, B, T, d.H, d.q_scale); break;
-        case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, block, smem, s, qkv, out, B, T, d.H, d.q_scale); break;
+        case 8: hipLaunchKernelGGL(attention_kernel<8>, grid, block, smem, s, qkv, out, B, T, d.H, d.q_scale, TK); break;
+        case 16: hipLaunchKernelGGL(attention_kernel<16>, grid, block, smem, s, qkv, out, B, T, d.H, d.q_scale, TK); break;
+        case 32: hipLaunchKernelGGL(attention_kernel<32>, grid, block, smem, s, qkv, out, B, T, d.H, d.q_scale, TK); break;
+        case 64: hipLaunchKernelGGL(attention_kernel<64>, grid, block, smem, s, qkv, out, B, T, d.H, d.q_scale, TK); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

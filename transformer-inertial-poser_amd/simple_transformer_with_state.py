@@ -120,7 +120,7 @@ class TF_RNN_Past_State(nn.Module):
         self.use_hip_training = True     # .train() + autograd on the GPU -> tip_train_forward / tip_train_backward
         self.keep_train_stash = False    # debugging/tests: keep the last activation stash (see train_activation())
         self.last_train_stash = None
-        self.t_max = 80
+        self.t_max = 80                  # sizing hint handed to the handle; any window length is served (general plan beyond T = 40)
 
     # ------------------------------------------------------------------------------------------
     # initialisation: same distributions torch's nn.Linear / nn.MultiheadAttention / nn.LayerNorm / nn.RNN use
@@ -333,8 +333,6 @@ class TF_RNN_Past_State(nn.Module):
         if x_imu.shape[2] != n_imu or x_s.shape[2] != self.size_s:
             raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied: got feature widths "
                                f"{x_imu.shape[2]}+{x_s.shape[2]}, in_linear expects {n_imu}+{self.size_s}")
-        if T > self.t_max:
-            raise RuntimeError(f"window length {T} exceeds t_max={self.t_max}")
         h = self._ensure_handle()
         with torch.cuda.device(dev):
             if self._packed_dev is None or self._packed_dev.device != dev or \
