@@ -16,6 +16,7 @@
 
 #include "tip_internal.h"
 #include "tip_attention.h"
+#include "tip_layernorm.h"
 
 namespace tip {
 
@@ -269,57 +270,8 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[fz::RB][NBW]) {
         for (int n = 0; n < NBW; ++n) acc[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// LayerNorm over the 48 rows of X (eps 1e-5, biased variance): wave w owns rows w, w+8, ... (6 rows); the six row
-// reductions advance together through every shuffle step so their latencies overlap.
-// zs / sts / xs (training forward, all three or none): the pre-norm rows, their (mean, rstd) and the normalised rows are
-// also written to HBM for rows < T — each wave owns whole rows, so these are plain 1-KB row stores.
-template <bool SAVE = false>
-__device__ __forceinline__ void layernorm_rows(float* X, const float* __restrict__ g, const float* __restrict__ be, int wave,
-                                               int lane, float* zs = nullptr, float* sts = nullptr, float* xs = nullptr, int T = 0) {
-    constexpr int NR = fz::RP / 8;
-    const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
-    const float4 bb = *reinterpret_cast<const float4*>(be + lane * 4);
-    float4 v[NR];
-    float mean[NR], var[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        v[i] = *reinterpret_cast<const float4*>(X + (wave + 8 * i) * fz::LDX + lane * 4);
-        mean[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        if (SAVE && wave + 8 * i < T) *reinterpret_cast<float4*>(zs + (size_t)(wave + 8 * i) * fz::D + lane * 4) = v[i];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int i = 0; i < NR; ++i) mean[i] += __shfl_xor(mean[i], off, 64);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        mean[i] *= (1.f / fz::D);
-        v[i].x -= mean[i]; v[i].y -= mean[i]; v[i].z -= mean[i]; v[i].w -= mean[i];
-        var[i] = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int i = 0; i < NR; ++i) var[i] += __shfl_xor(var[i], off, 64);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const float rstd = 1.0f / sqrtf(var[i] * (1.f / fz::D) + 1e-5f);
-        float4 o;
-        o.x = v[i].x * rstd * gg.x + bb.x;
-        o.y = v[i].y * rstd * gg.y + bb.y;
-        o.z = v[i].z * rstd * gg.z + bb.z;
-        o.w = v[i].w * rstd * gg.w + bb.w;
-        *reinterpret_cast<float4*>(X + (wave + 8 * i) * fz::LDX + lane * 4) = o;
-        if (SAVE && wave + 8 * i < T) {
-            *reinterpret_cast<float4*>(xs + (size_t)(wave + 8 * i) * fz::D + lane * 4) = o;
-            if (lane == 0) {
-                sts[(wave + 8 * i) * 2] = mean[i];
-                sts[(wave + 8 * i) * 2 + 1] = rstd;
-            }
-        }
-    }
-}
-
+// LayerNorm of the residual stream: tip_layernorm.h (16 lanes per row, DPP reductions), all 48 rows here — the pad rows of the
+// padded kernels evolve like real ones and must stay finite.
 // rows 0..T-1 of an LDS tile [rows][ld] (cols floats wide) -> HBM rows of stride dst_ld, 16-byte stores
 __device__ __forceinline__ void rows_to_hbm(const float* lds, int ld, int cols, float* dst, int dst_ld, int T, int tid) {
     const int c4n = cols >> 2;
@@ -491,9 +443,9 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
             }
             __syncthreads();
             if (TR)
-                layernorm_rows<true>(X, LW + G1, LW + BE1, wave, lane, svl + (size_t)tr.z1 * 64 + grow0 * D, svl + (size_t)tr.st1 * 64 + grow0 * 2,
+                layernorm_rows16<fz::RP, fz::LDX, true>(X, LW + G1, LW + BE1, wave, lane, svl + (size_t)tr.z1 * 64 + grow0 * D, svl + (size_t)tr.st1 * 64 + grow0 * 2,
                                      svl + (size_t)tr.x1 * 64 + grow0 * D, T);
-            else if (!(ABL & 2)) layernorm_rows(X, LW + G1, LW + BE1, wave, lane);
+            else if (!(ABL & 2)) layernorm_rows16<fz::RP, fz::LDX>(X, LW + G1, LW + BE1, wave, lane);
             __syncthreads();
             // ---- feed-forward block: hidden processed in 4 chunks of 256, second GEMM accumulates in registers -----
             float* Hc = C;
@@ -556,9 +508,9 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
             }
             __syncthreads();
             if (TR)
-                layernorm_rows<true>(X, LW + G2, LW + BE2, wave, lane, svl + (size_t)tr.z2 * 64 + grow0 * D, svl + (size_t)tr.st2 * 64 + grow0 * 2,
+                layernorm_rows16<fz::RP, fz::LDX, true>(X, LW + G2, LW + BE2, wave, lane, svl + (size_t)tr.z2 * 64 + grow0 * D, svl + (size_t)tr.st2 * 64 + grow0 * 2,
                                      svl + (size_t)tr.xo * 64 + grow0 * D, T);
-            else if (!(ABL & 2)) layernorm_rows(X, LW + G2, LW + BE2, wave, lane);
+            else if (!(ABL & 2)) layernorm_rows16<fz::RP, fz::LDX>(X, LW + G2, LW + BE2, wave, lane);
             __syncthreads();
         }
         // ---- RNN input projection (:99, first half of nn.RNN): IH = X W_ih^T + (b_ih + b_hh), rows 0..T-1 -> HBM ----
@@ -676,7 +628,7 @@ hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* 
 // Per (16-column block, k-block): 8 big + 8 small MFMAs = 8 x 32 + 8 x 9 = 328 issue cycles instead of 12 x 32 = 384.
 // The QKV projection keeps the three padded 16-row blocks: its accumulators ARE the attention's register fragments
 // (attention_head_regs), which a 4x4x1 tail cannot produce without a cross-lane transpose per head.
-// Rows 40-47 of X are zeroed once and only ever pass through LayerNorm (-> beta): finite pad keys/values for the attention.
+// Rows 40-47 of X are zeroed once and never written again (LayerNorm covers rows 0-39): finite pad keys/values for the attention.
 // Numerics: rows 0-31 are bit-identical to TIP_PLAN_FUSED (same instructions; causality keeps rows >= 32 out of them);
 // rows 32-39 differ in summation order only (four k-chains per output instead of one).
 // =====================================================================================================================
@@ -783,7 +735,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
     auto am = [&](int ld) { return l15 * ld + lg * 4; };
     auto at = [&](int ld) { return (TAIL0 + (lane & 3)) * ld + lg * 4; };
 
-    // rows 40..47 of the residual stream: zero once; afterwards only LayerNorm touches them (-> beta, finite pad keys/values)
+    // rows 40..47 of the residual stream: zero once, never written again (finite pad keys / values for the attention)
     for (int i = tid; i < 8 * LDX; i += THREADS) X[TMAX * LDX + i] = 0.f;
 
     for (int win = blockIdx.x; win < B; win += gridDim.x) {
@@ -900,7 +852,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             }
             __syncthreads();
             FH_STAMP(17);
-            layernorm_rows(X, LW + G1, LW + BE1, wave, lane);
+            layernorm_rows16<fz::TMAX, fz::LDX>(X, LW + G1, LW + BE1, wave, lane);   // rows 40..47 stay zero
             __syncthreads();
             FH_STAMP(18);
             // ---- feed-forward block: hidden in 4 chunks of 256, linear2 accumulates in registers -------------------------
@@ -956,7 +908,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             }
             __syncthreads();
             FH_STAMP(31);
-            layernorm_rows(X, LW + G2, LW + BE2, wave, lane);
+            layernorm_rows16<fz::TMAX, fz::LDX>(X, LW + G2, LW + BE2, wave, lane);
             __syncthreads();
             FH_STAMP(32);
         }

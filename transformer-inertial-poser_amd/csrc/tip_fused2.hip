@@ -16,6 +16,7 @@
 
 #include "tip_internal.h"
 #include "tip_attention.h"
+#include "tip_layernorm.h"
 #include "tip_pgemm.h"
 
 namespace tip {
@@ -74,45 +75,6 @@ __device__ __forceinline__ void gemm_phase2(f32x4 (&acc)[NRB][NBW], const float*
     }
 }
 
-
-// LayerNorm over the 80 rows of X: wave w owns rows w, w+8, ... (10 rows), reductions interleaved.
-__device__ __forceinline__ void layernorm_rows2(float* X, const float* __restrict__ g, const float* __restrict__ be, int wave,
-                                                int lane) {
-    constexpr int NR = f2::ROWS / 8;
-    const float4 gg = *reinterpret_cast<const float4*>(g + lane * 4);
-    const float4 bb = *reinterpret_cast<const float4*>(be + lane * 4);
-    float4 v[NR];
-    float mean[NR], var[NR];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        v[i] = *reinterpret_cast<const float4*>(X + (wave + 8 * i) * f2::LDX + lane * 4);
-        mean[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int i = 0; i < NR; ++i) mean[i] += __shfl_xor(mean[i], off, 64);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        mean[i] *= (1.f / f2::D);
-        v[i].x -= mean[i]; v[i].y -= mean[i]; v[i].z -= mean[i]; v[i].w -= mean[i];
-        var[i] = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int i = 0; i < NR; ++i) var[i] += __shfl_xor(var[i], off, 64);
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const float rstd = 1.0f / sqrtf(var[i] * (1.f / f2::D) + 1e-5f);
-        float4 o;
-        o.x = v[i].x * rstd * gg.x + bb.x;
-        o.y = v[i].y * rstd * gg.y + bb.y;
-        o.z = v[i].z * rstd * gg.z + bb.z;
-        o.w = v[i].w * rstd * gg.w + bb.w;
-        *reinterpret_cast<float4*>(X + (wave + 8 * i) * f2::LDX + lane * 4) = o;
-    }
-}
 
 // plane row of X row r: window 1 (rows 40..79) starts at plane row 48
 __device__ __forceinline__ int prow(int r) { return r + (r >= f2::T ? 8 : 0); }
@@ -289,7 +251,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                     for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_o[r][n][e] + bv;
             }
             __syncthreads();
-            layernorm_rows2(X, LW + G1, LW + BE1, wave, lane);
+            layernorm_rows16<f2::ROWS, f2::LDX>(X, LW + G1, LW + BE1, wave, lane);
             __syncthreads();
             // ---- feed-forward: 8 hidden chunks of 128; linear2 accumulates in registers ------------------------------------
             float* Hc = C;
@@ -335,7 +297,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                     for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_f[r][n][e] + bv;
             }
             __syncthreads();
-            layernorm_rows2(X, LW + G2, LW + BE2, wave, lane);
+            layernorm_rows16<f2::ROWS, f2::LDX>(X, LW + G2, LW + BE2, wave, lane);
             __syncthreads();
         }
         // ---- RNN input projection: IH = X W_ih^T + (b_ih + b_hh) for both windows -> HBM -------------------------------------
@@ -667,7 +629,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         }
         exchange_add(acc_o, LW + WO_B);               // X += out-projection (both halves' heads) + bias
         __syncthreads();
-        layernorm_rows2(X, LW + G1, LW + BE1, wave, lane);
+        layernorm_rows16<f2::ROWS, f2::LDX>(X, LW + G1, LW + BE1, wave, lane);
         __syncthreads();
         // ---- feed-forward: this half's 4 hidden chunks of 128; its K-half of linear2 accumulates in registers ---------------
         float* Hc = C;
@@ -706,7 +668,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
                                                    ((wave >> 2) * 16 + half * 8 + (wave & 3)) * 16 * 1024, 0);
         exchange_add(acc_f, LW + W2_B);               // X += linear2 (both halves' hidden units) + bias
         __syncthreads();
-        layernorm_rows2(X, LW + G2, LW + BE2, wave, lane);
+        layernorm_rows16<f2::ROWS, f2::LDX>(X, LW + G2, LW + BE2, wave, lane);
         __syncthreads();
     }
     // ---- RNN input projection, columns 256 * half ..: IH = X W_ih^T + (b_ih + b_hh) -> HBM ------------------------------------

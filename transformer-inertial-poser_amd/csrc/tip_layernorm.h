@@ -1,0 +1,80 @@
+// tip_layernorm.h — LayerNorm over the rows of an LDS-resident activation tile, shared by the fused encoder kernels (so that the
+// one-window, two-window and hybrid plans normalise every row with the same instructions: their bit-identity tests rely on it).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tip {
+
+// v + (v of another lane of the same 16-lane row), by a DPP modifier on the add's operand: no LDS crossbar trip.
+// hipcc lowers every __shfl_xor to ds_bpermute_b32 (an LDS round trip, ~100 cycles of latency each); a 64-lane row reduction
+// was 6 of them per statistic, 72 per wave and LayerNorm — 3.4 us per LayerNorm, 5 % of the encoder.
+template <int CTRL>
+__device__ __forceinline__ float dpp_peer(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a DPP row; every lane ends with the same bits (each step adds a value to its mirror image)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_peer<0xB1>(v);    // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_peer<0x4E>(v);    // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_peer<0x141>(v);   // row_half_mirror: the other quad of this half
+    v += dpp_peer<0x140>(v);   // row_mirror: the other half of the row
+    return v;
+}
+
+// LayerNorm (eps 1e-5, biased variance, affine) over rows 0 .. ROWS-1 of X [rows][LD] (256 columns).  SIXTEEN lanes per row —
+// a wave normalises four rows at a time, lane (sub = lane >> 4, q = lane & 15) holding columns 4 (q + 16 j) .. + 3, j = 0..3 of
+// row 32 p + 4 wave + sub — so both row statistics are a 16-value local sum plus row16_sum: four DPP adds instead of six LDS
+// round trips.  SAVE (training forward): the pre-norm rows, (mean, rstd) and the normalised rows also go to HBM for rows < T.
+template <int ROWS, int LD, bool SAVE = false>
+__device__ __forceinline__ void layernorm_rows16(float* X, const float* __restrict__ g, const float* __restrict__ be, int wave,
+                                                 int lane, float* zs = nullptr, float* sts = nullptr, float* xs = nullptr, int T = 0) {
+    constexpr int DCOLS = 256, NPASS = (ROWS + 31) / 32;
+    const int q = lane & 15, sub = lane >> 4;
+    float4 gg[4], bb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        gg[j] = *reinterpret_cast<const float4*>(g + (q + 16 * j) * 4);
+        bb[j] = *reinterpret_cast<const float4*>(be + (q + 16 * j) * 4);
+    }
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        if (p * 32 + wave * 4 < ROWS) {                     // wave-uniform (ROWS is a multiple of 4 x the waves that take part)
+            const int row = p * 32 + wave * 4 + sub;
+            float* xr = X + row * LD + q * 4;
+            float4 v[4];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = *reinterpret_cast<const float4*>(xr + j * 64);
+                if (SAVE && row < T) *reinterpret_cast<float4*>(zs + (size_t)row * DCOLS + (q + 16 * j) * 4) = v[j];
+            }
+            s = ((v[0].x + v[0].y) + (v[0].z + v[0].w)) + ((v[1].x + v[1].y) + (v[1].z + v[1].w));
+            s += ((v[2].x + v[2].y) + (v[2].z + v[2].w)) + ((v[3].x + v[3].y) + (v[3].z + v[3].w));
+            const float mean = row16_sum(s) * (1.f / DCOLS);
+            float qs[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+                qs[j] = (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+            }
+            const float var = row16_sum((qs[0] + qs[1]) + (qs[2] + qs[3])) * (1.f / DCOLS);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 o;
+                o.x = v[j].x * rstd * gg[j].x + bb[j].x;
+                o.y = v[j].y * rstd * gg[j].y + bb[j].y;
+                o.z = v[j].z * rstd * gg[j].z + bb[j].z;
+                o.w = v[j].w * rstd * gg[j].w + bb[j].w;
+                *reinterpret_cast<float4*>(xr + j * 64) = o;
+                if (SAVE && row < T) *reinterpret_cast<float4*>(xs + (size_t)row * DCOLS + (q + 16 * j) * 4) = o;
+            }
+            if (SAVE && row < T && q == 0) {
+                sts[row * 2] = mean;
+                sts[row * 2 + 1] = rstd;
+            }
+        }
+    }
+}
+
+}  // namespace tip
