@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "tip_layernorm.h"   // lg4_sum / lg4_max: lane ^ 16, lane ^ 32 reductions on permlane swaps
+
 namespace tip {
 
 typedef float f32x4_att __attribute__((ext_vector_type(4)));
@@ -52,9 +54,7 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
         mx[r] = m;
     }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], 16, 64));
-#pragma unroll
-    for (int r = 0; r < RB; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], 32, 64));
+    for (int r = 0; r < RB; ++r) mx[r] = lg4_max(mx[r]);
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         float sm = 0.f;
@@ -73,9 +73,7 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
         rsum[r] = sm;
     }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) rsum[r] += __shfl_xor(rsum[r], 16, 64);
-#pragma unroll
-    for (int r = 0; r < RB; ++r) rsum[r] += __shfl_xor(rsum[r], 32, 64);
+    for (int r = 0; r < RB; ++r) rsum[r] = lg4_sum(rsum[r]);
 #pragma unroll
     for (int r = 0; r < RB; ++r) rsum[r] = 1.0f / rsum[r];
     // P V per query block: A = P tiles from registers, B = V^T fragments
@@ -137,9 +135,7 @@ __device__ __forceinline__ void attention_head_regs(const f32x4_att (&qt)[3], co
         mx[r] = m;
     }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], 16, 64));
-#pragma unroll
-    for (int r = 0; r < RB; ++r) mx[r] = fmaxf(mx[r], __shfl_xor(mx[r], 32, 64));
+    for (int r = 0; r < RB; ++r) mx[r] = lg4_max(mx[r]);
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         float sm = 0.f;
@@ -158,9 +154,7 @@ __device__ __forceinline__ void attention_head_regs(const f32x4_att (&qt)[3], co
         rsum[r] = sm;
     }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) rsum[r] += __shfl_xor(rsum[r], 16, 64);
-#pragma unroll
-    for (int r = 0; r < RB; ++r) rsum[r] += __shfl_xor(rsum[r], 32, 64);
+    for (int r = 0; r < RB; ++r) rsum[r] = lg4_sum(rsum[r]);
 #pragma unroll
     for (int r = 0; r < RB; ++r) rsum[r] = 1.0f / rsum[r];
     if (TRAIN) {

@@ -703,13 +703,18 @@ __device__ __forceinline__ void zero_acc_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 (&
 // Combine the four k-partials of a tail accumulator (registers = rows row0 .. row0 + 3, one partial per lg): two exchange
 // steps, after which lane (lg, l15) holds the finished sum of row row0 + lg, column l15 of the block.  Every row is summed
 // as (p[lg] + p[lg ^ 2]) + (p[lg ^ 1] + p[lg ^ 3]) — the same pairing for all four rows.
+// Three permlane swaps (tip_layernorm.h), no LDS crossbar: swap32(v0, v2) leaves {v0.lo, v2.lo} and {v0.hi, v2.hi}, whose sum is
+// row 0 in lanes 0-31 and row 2 in lanes 32-63 — exactly what "keep one row, hand the other to lane ^ 32" produces.
 __device__ __forceinline__ float tail_reduce(const f32x4& v, int lg) {
-    const bool hi = (lg & 2) != 0, odd = (lg & 1) != 0;
-    const float s0 = hi ? v[0] : v[2], s1 = hi ? v[1] : v[3];      // the two rows this lane gives away
-    const float k0 = (hi ? v[2] : v[0]) + __shfl_xor(s0, 32, 64);  // rows {0,1} stay with lg in {0,1}, rows {2,3} with {2,3}
-    const float k1 = (hi ? v[3] : v[1]) + __shfl_xor(s1, 32, 64);
-    const float give = odd ? k0 : k1;
-    return (odd ? k1 : k0) + __shfl_xor(give, 16, 64);             // row 2 * (lg >> 1) + (lg & 1) = lg
+    (void)lg;
+    float a = v[0], b = v[2];
+    swap32(a, b);
+    float k0 = a + b;              // rows {0,1} live on with lg in {0,1}, rows {2,3} with lg in {2,3}
+    a = v[1], b = v[3];
+    swap32(a, b);
+    float k1 = a + b;
+    swap16(k0, k1);
+    return k0 + k1;                // row 2 * (lg >> 1) + (lg & 1) = lg
 }
 
 // measurement only (TIP_FUSEDH_TRACE=1): s_memtime stamps of workgroup 0 / thread 0 at the phase boundaries of layer 1

@@ -21,6 +21,37 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Cross-ROW exchanges (lane ^ 16, lane ^ 32) without the LDS crossbar: gfx950's v_permlane16_swap_b32 / v_permlane32_swap_b32.
+//   swap16(a, b): a' = [a.row0, b.row0, a.row2, b.row2], b' = [a.row1, b.row1, a.row3, b.row3]      (rows of 16 lanes)
+//   swap32(a, b): a' = [a.lanes 0-31, b.lanes 0-31],     b' = [a.lanes 32-63, b.lanes 32-63]
+// (semantics measured: tools/probes/permlane_probe.hip).  Through inline asm: hipcc's __builtin_amdgcn_permlane{16,32}_swap hands
+// back vdst' in BOTH elements of its result (ROCm 7.2).  The s_nops cover the VALU-write -> permlane-read wait states that the
+// compiler inserts around its own permlane instructions but not inside an asm statement.
+__device__ __forceinline__ void swap16(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+// v (op) v-of-lane^16, then (op) lane^32: the four lanes that share lane & 15 all end with the combination of their four
+// values — same pairing and (commutative) operand order as x = op(x, shfl_xor(x, 16)); x = op(x, shfl_xor(x, 32)), same bits.
+__device__ __forceinline__ float lg4_sum(float v) {
+    float w = v;
+    swap16(v, w);
+    v += w;
+    w = v;
+    swap32(v, w);
+    return v + w;
+}
+__device__ __forceinline__ float lg4_max(float v) {
+    float w = v;
+    swap16(v, w);
+    v = fmaxf(v, w);
+    w = v;
+    swap32(v, w);
+    return fmaxf(v, w);
+}
+
 // LayerNorm (eps 1e-5, biased variance, affine) over rows 0 .. ROWS-1 of X [rows][LD] (256 columns).  SIXTEEN lanes per row —
 // a wave normalises four rows at a time, lane (sub = lane >> 4, q = lane & 15) holding columns 4 (q + 16 j) .. + 3, j = 0..3 of
 // row 32 p + 4 wave + sub — so both row statistics are a 16-value local sum plus row16_sum: four DPP adds instead of six LDS
