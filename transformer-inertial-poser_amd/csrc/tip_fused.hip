@@ -611,7 +611,7 @@ hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* 
 }
 
 // =====================================================================================================================
-// "fusedh": the one-window kernel with a HYBRID row tiling — no padded matrix-core work outside the QKV projection.
+// "fusedh": the one-window kernel with a HYBRID row tiling — no matrix-core work on padded rows.
 //
 // T = 40 rows do not fill three 16-row MFMA blocks: in fused_encoder_kernel every weight fragment multiplies rows 0-15,
 // 16-31 and 32-47, and a third of that last block's cycles (17 % of all MFMA issue time) is spent on the eight zero rows
@@ -626,8 +626,8 @@ hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* 
 //   k == 4 lg .. 4 lg + 3 (mod 16) of output (row0 + i, column 16 nb + 4 cb + j): four k-partials per output, one per lg,
 //   combined once per phase by a two-step exchange (xor 32, xor 16) that leaves row row0 + lg in lane (lg, l15).
 // Per (16-column block, k-block): 8 big + 8 small MFMAs = 8 x 32 + 8 x 9 = 328 issue cycles instead of 12 x 32 = 384.
-// The QKV projection keeps the three padded 16-row blocks: its accumulators ARE the attention's register fragments
-// (attention_head_regs), which a 4x4x1 tail cannot produce without a cross-lane transpose per head.
+// The QKV projection does the same; its rows 32..39 reach the attention's register fragments (attention_head_regs: Q^T / K^T
+// tiles with the row in the lane index) through a 1.3-KB per-wave LDS patch that transposes the tail's (row, channel) result.
 // Rows 40-47 of X are zeroed once and never written again (LayerNorm covers rows 0-39): finite pad keys/values for the attention.
 // Numerics: rows 0-31 are bit-identical to TIP_PLAN_FUSED (same instructions; causality keeps rows >= 32 out of them);
 // rows 32-39 differ in summation order only (four k-chains per output instead of one).
@@ -638,12 +638,14 @@ constexpr int RBT = 2;    // 4-row blocks of the tail (rows 32-35, 36-39)
 constexpr int TAIL0 = 32;
 }  // namespace fzh
 
-template <int NBW>
+// (the first SWAPN column blocks of the 16-row part with swapped operands, as in mfma_block: transposed accumulators)
+template <int NBW, int SWAPN = 0>
 __device__ __forceinline__ void mfma_block_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 (&acct)[fzh::RBT][NBW], const float4 (&a)[fzh::RBM],
                                              const float4 (&at)[fzh::RBT], const float4 (&w)[NBW]) {
 #define TIP_MFMA_STEP_H(c)                                                                                            \
     _Pragma("unroll") for (int r = 0; r < fzh::RBM; ++r) _Pragma("unroll") for (int n = 0; n < NBW; ++n)               \
-        acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].c, w[n].c, acc[r][n], 0, 0, 0);                         \
+        acc[r][n] = n < SWAPN ? __builtin_amdgcn_mfma_f32_16x16x4f32(w[n].c, a[r].c, acc[r][n], 0, 0, 0)              \
+                              : __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].c, w[n].c, acc[r][n], 0, 0, 0);             \
     _Pragma("unroll") for (int r = 0; r < fzh::RBT; ++r) _Pragma("unroll") for (int n = 0; n < NBW; ++n)               \
         acct[r][n] = __builtin_amdgcn_mfma_f32_4x4x1f32(at[r].c, w[n].c, acct[r][n], 0, 0, 0);
     TIP_MFMA_STEP_H(x)
@@ -657,7 +659,7 @@ __device__ __forceinline__ void mfma_block_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 
 // acct [r][n] += A[rows 32 + 4 r .. + 3]  x Wblock(n, kb), per-lg k-partials (see above)
 //   Am: this lane's LDS address for the 16-row blocks (base + l15 * lda + lg * 4);  At: for the tail (base + (32 + (lane & 3)) *
 //   lda + lg * 4).  Weight ring semantics exactly as gemm_phase.
-template <int NBW, int KB>
+template <int NBW, int KB, int SWAPN = 0>
 __device__ __forceinline__ void gemm_phase_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 (&acct)[fzh::RBT][NBW], const float* Am, const float* At,
                                              int lda, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b, WRing<NBW>& g,
                                              int nsoff, int nnstride_b) {
@@ -676,14 +678,14 @@ __device__ __forceinline__ void gemm_phase_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 
         for (int r = 0; r < fzh::RBM; ++r) a1[r] = *reinterpret_cast<const float4*>(Am + r * 16 * lda + (kb + 1) * 16);
 #pragma unroll
         for (int r = 0; r < fzh::RBT; ++r) t1[r] = *reinterpret_cast<const float4*>(At + r * 4 * lda + (kb + 1) * 16);
-        mfma_block_h<NBW>(acc, acct, a0, t0, g.w0);
+        mfma_block_h<NBW, SWAPN>(acc, acct, a0, t0, g.w0);
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w0[n] = load_frag(rsrc, voff, o + n * st);
 #pragma unroll
         for (int r = 0; r < fzh::RBM; ++r) a0[r] = *reinterpret_cast<const float4*>(Am + r * 16 * lda + (kb + 2) * 16);
 #pragma unroll
         for (int r = 0; r < fzh::RBT; ++r) t0[r] = *reinterpret_cast<const float4*>(At + r * 4 * lda + (kb + 2) * 16);
-        mfma_block_h<NBW>(acc, acct, a1, t1, g.w1);
+        mfma_block_h<NBW, SWAPN>(acc, acct, a1, t1, g.w1);
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w1[n] = load_frag(rsrc, voff, o + n * st + 1024);
     }
@@ -715,6 +717,24 @@ __device__ __forceinline__ float tail_reduce(const f32x4& v, int lg) {
     float k1 = a + b;
     swap16(k0, k1);
     return k0 + k1;                // row 2 * (lg >> 1) + (lg & 1) = lg
+}
+
+// The V tile of rows 32..47 in the plain accumulator layout (lane (l15, lg) = rows 32 + 4 lg + e, channel l15) from the two tail
+// accumulators (a0: rows 32..35, a1: rows 36..39; four k-partials each, one per lg): all four rows of block lg must end up in
+// ONE lane — an all-reduce over lg rather than tail_reduce's reduce-scatter.  swap16(a0, a1) pairs lg with lg ^ 1 and parks
+// block 0 in the even, block 1 in the odd lane groups; swap32 of the sums finishes both.  Lanes lg = 2, 3 (pad rows 40..47,
+// multiplied by P = 0 in the attention) get zeros.
+__device__ __forceinline__ f32x4 tail_gather_v(const f32x4& a0, const f32x4& a1, int lg) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = a0[e], y = a1[e];
+        swap16(x, y);
+        float s = x + y, t = s;
+        swap32(s, t);
+        o[e] = s + t;
+    }
+    return lg < 2 ? o : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
 // measurement only (TIP_FUSEDH_TRACE=1): s_memtime stamps of workgroup 0 / thread 0 at the phase boundaries of layer 1
@@ -810,21 +830,45 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                     // QKV projection of head 8c + wave on the three padded 16-row blocks + attention in registers (as in the
                     // one-window kernel: the accumulators are the attention's fragments)
                     const int head = c * 8 + wave;
-                    f32x4 acc[RB][3];
-                    zero_acc<3>(acc);
+                    f32x4 acc[RBM][3], acct[RBT][3];
+                    zero_acc_h<3>(acc, acct);
                     const int qsoff = lbase + (int)(QKV_W * 4) + head * 16 * 1024;
-                    gemm_phase<3, 16, false, 2, false>(acc, X + l15 * LDX + lg * 4, LDX, rsrc, voff, qsoff, 16 * 16 * 1024, g_qkv, qsoff,
-                                                       16 * 16 * 1024);
+                    // rows 0..31: Q and K with swapped operands (their accumulators are the attention's transposed fragments), V plain;
+                    // rows 32..39: all three through the 4x4x1 tail in the plain orientation
+                    gemm_phase_h<3, 16, 2>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, qsoff, 16 * 16 * 1024, g_qkv, qsoff,
+                                           16 * 16 * 1024);
                     ring_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + c * 8) * 1024, 16 * 1024);
                     const f32x4 bq = *reinterpret_cast<const f32x4*>(LW + QKV_B + head * 16 + lg * 4);
                     const f32x4 bk = *reinterpret_cast<const f32x4*>(LW + QKV_B + D + head * 16 + lg * 4);
                     const float bv = LW[QKV_B + 2 * D + head * 16 + l15];
                     f32x4 qt[RB], kt[RB], vv[RB];
 #pragma unroll
-                    for (int r = 0; r < RB; ++r) {
+                    for (int r = 0; r < RBM; ++r) {
                         qt[r] = acc[r][0] + bq;
                         kt[r] = acc[r][1] + bk;
                         vv[r] = acc[r][2] + bv;
+                    }
+                    // Third row block (rows 32..47, eight of them real).  V: gather the tail into the plain layout.  Q, K: the tail
+                    // yields (row 4 rb + lg, channel l15) per lane; the attention wants (row l15, channels 4 lg ..): a 1.3-KB per-wave
+                    // LDS patch does the transpose (the K / V^T plane region of C is idle in this kernel), no workgroup barrier —
+                    // a wave's LDS operations complete in program order.
+                    vv[2] = tail_gather_v(acct[0][2], acct[1][2], lg);
+                    if (lg < 2) vv[2] += bv;
+                    {
+                        constexpr int SLD = 20;                                   // 16 channels + 4: b128 reads of 8 rows conflict-free
+                        float* scr = C + RP * LDC + wave * (2 * 8 * SLD);
+                        const float bqp = LW[QKV_B + head * 16 + l15], bkp = LW[QKV_B + D + head * 16 + l15];
+#pragma unroll
+                        for (int rb = 0; rb < RBT; ++rb) {
+                            scr[(4 * rb + lg) * SLD + l15] = tail_reduce(acct[rb][0], lg) + bqp;
+                            scr[8 * SLD + (4 * rb + lg) * SLD + l15] = tail_reduce(acct[rb][1], lg) + bkp;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        qt[2] = l15 < 8 ? *reinterpret_cast<const f32x4*>(scr + l15 * SLD + lg * 4) : z;
+                        kt[2] = l15 < 8 ? *reinterpret_cast<const f32x4*>(scr + 8 * SLD + l15 * SLD + lg * 4) : z;
                     }
                     FH_STAMP(9 + 4 * c);    // QKV projection issued and its results consumed
                     attention_head_regs<LDC>(qt, kt, vv, Qc, wave * 16, lane, TMAX);   // rows 40..47 of the O plane are never read
