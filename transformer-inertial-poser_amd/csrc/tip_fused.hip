@@ -821,6 +821,12 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
             const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
             float* Qc = C;
+            float bvo[2], bv2[2];   // out-projection / linear2 biases of this wave's columns: requested a phase (or eight) ahead of their use
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                bvo[n] = LW[WO_B + (wave * 2 + n) * 16 + l15];
+                bv2[n] = LW[W2_B + (wave * 2 + n) * 16 + l15];
+            }
             f32x4 acc_o[RBM][2], acc_ot[RBT][2];
             zero_acc_h<2>(acc_o, acc_ot);
             WRing<2> g_o, g_f;
@@ -891,7 +897,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int col = (wave * 2 + n) * 16 + l15;
-                const float bv = LW[WO_B + col];
+                const float bv = bvo[n];
 #pragma unroll
                 for (int r = 0; r < RBM; ++r)
 #pragma unroll
@@ -916,11 +922,15 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                     const int nb0 = f * 16 + wave * 2;
                     const int w1off = lbase + (int)(W1_W * 4) + nb0 * 16 * 1024;
                     const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
+                    // (the epilogue's bias is requested BEFORE the product: after it, the L2 round trip would be exposed 16 times a layer)
+                    float bv1[2];
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) bv1[n] = LW[W1_B + f * 256 + (wave * 2 + n) * 16 + l15];
                     gemm_phase_h<2, 16>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, w1off, 16 * 1024, g_f, w2off, 64 * 1024);
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         const int col = (wave * 2 + n) * 16 + l15;
-                        const float bv = LW[W1_B + f * 256 + col];
+                        const float bv = bv1[n];
 #pragma unroll
                         for (int r = 0; r < RBM; ++r)
 #pragma unroll
@@ -947,7 +957,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int col = (wave * 2 + n) * 16 + l15;
-                const float bv = LW[W2_B + col];
+                const float bv = bv2[n];
 #pragma unroll
                 for (int r = 0; r < RBM; ++r)
 #pragma unroll
