@@ -31,11 +31,10 @@ def row(name, cyc, mfma16=0, mfma4=0):
 print("window: prologue (input staging)", d(0, 1)); print("        in_linear + epilogue + barrier", d(1, 2))
 print("layer 1:")
 for c in range(2):
-    base = 8 if c == 0 else 12
-    row(f"chunk {c}: QKV projection (3 padded blocks)", d(base if c == 0 else 12, 9 + 4 * c), mfma16=3 * 3 * 16 * 4)
-    row(f"chunk {c}: attention (registers)", d(9 + 4 * c, 10 + 4 * c), mfma16=48)
-    row(f"chunk {c}: barrier", d(10 + 4 * c, 11 + 4 * c))
-    row(f"chunk {c}: out-projection partial + barrier", d(11 + 4 * c, 12 + 4 * c), mfma16=2 * 2 * 8 * 4, mfma4=2 * 2 * 8 * 4)
+    row(f"head {c}: QKV projection (2 blocks + tail)", d(8 if c == 0 else 10, 9 + 4 * c), mfma16=2 * 3 * 16 * 4, mfma4=2 * 3 * 16 * 4)
+    row(f"head {c}: attention (registers)", d(9 + 4 * c, 10 + 4 * c), mfma16=48)
+row("barrier", d(14, 15))
+row("out-projection (K = 256) + barrier", d(15, 16), mfma16=2 * 2 * 16 * 4, mfma4=2 * 2 * 16 * 4)
 row("residual epilogue + barrier", d(16, 17))
 row("LayerNorm1 + barrier", d(17, 18))
 for f in range(4):

@@ -820,79 +820,80 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             FH_STAMP(8);
             const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
             const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
-            float* Qc = C;
             float bvo[2], bv2[2];   // out-projection / linear2 biases of this wave's columns: requested a phase (or eight) ahead of their use
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 bvo[n] = LW[WO_B + (wave * 2 + n) * 16 + l15];
                 bv2[n] = LW[W2_B + (wave * 2 + n) * 16 + l15];
             }
-            f32x4 acc_o[RBM][2], acc_ot[RBT][2];
-            zero_acc_h<2>(acc_o, acc_ot);
             WRing<2> g_o, g_f;
+            // ---- self-attention block.  Wave w owns heads w and 8 + w END TO END and runs them back to back with no workgroup
+            // barrier in between: projection -> attention -> projection -> attention.  The two waves that share a SIMD drift apart
+            // in this stretch, so one's softmax (VALU, LDS) runs under the other's projection MFMAs instead of both idling the
+            // matrix pipe at the same time in front of a barrier; then ONE out-projection over all 16 heads (K = 256).
+            float* Oc = C;   // attention output of all heads [48 rows][256 channels], leading dimension LDX: the out-projection's A operand
 #pragma unroll 1
             for (int c = 0; c < 2; ++c) {
-                {
-                    // QKV projection of head 8c + wave on the three padded 16-row blocks + attention in registers (as in the
-                    // one-window kernel: the accumulators are the attention's fragments)
-                    const int head = c * 8 + wave;
-                    f32x4 acc[RBM][3], acct[RBT][3];
-                    zero_acc_h<3>(acc, acct);
-                    const int qsoff = lbase + (int)(QKV_W * 4) + head * 16 * 1024;
-                    // rows 0..31: Q and K with swapped operands (their accumulators are the attention's transposed fragments), V plain;
-                    // rows 32..39: all three through the 4x4x1 tail in the plain orientation
-                    gemm_phase_h<3, 16, 2>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, qsoff, 16 * 16 * 1024, g_qkv, qsoff,
-                                           16 * 16 * 1024);
-                    ring_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + c * 8) * 1024, 16 * 1024);
-                    const f32x4 bq = *reinterpret_cast<const f32x4*>(LW + QKV_B + head * 16 + lg * 4);
-                    const f32x4 bk = *reinterpret_cast<const f32x4*>(LW + QKV_B + D + head * 16 + lg * 4);
-                    const float bv = LW[QKV_B + 2 * D + head * 16 + l15];
-                    f32x4 qt[RB], kt[RB], vv[RB];
+                const int head = c * 8 + wave;
+                f32x4 acc[RBM][3], acct[RBT][3];
+                zero_acc_h<3>(acc, acct);
+                const int qsoff = lbase + (int)(QKV_W * 4) + head * 16 * 1024;
+                // rows 0..31: Q and K with swapped operands (their accumulators are the attention's transposed fragments), V plain;
+                // rows 32..39: all three through the 4x4x1 tail in the plain orientation.  The tail of head w's product primes
+                // the ring with head 8 + w's first fragments (they fly during head w's attention).
+                const int nxt = c == 0 ? qsoff + 8 * 16 * 1024 : qsoff;
+                gemm_phase_h<3, 16, 2>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, qsoff, 16 * 16 * 1024, g_qkv, nxt,
+                                       16 * 16 * 1024);
+                if (c == 1)   // out-projection fragments fly during the second attention and the barrier
+                    ring_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + (wave * 2) * 16 * 1024, 16 * 1024);
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(LW + QKV_B + head * 16 + lg * 4);
+                const f32x4 bk = *reinterpret_cast<const f32x4*>(LW + QKV_B + D + head * 16 + lg * 4);
+                const float bv = LW[QKV_B + 2 * D + head * 16 + l15];
+                f32x4 qt[RB], kt[RB], vv[RB];
 #pragma unroll
-                    for (int r = 0; r < RBM; ++r) {
-                        qt[r] = acc[r][0] + bq;
-                        kt[r] = acc[r][1] + bk;
-                        vv[r] = acc[r][2] + bv;
-                    }
-                    // Third row block (rows 32..47, eight of them real).  V: gather the tail into the plain layout.  Q, K: the tail
-                    // yields (row 4 rb + lg, channel l15) per lane; the attention wants (row l15, channels 4 lg ..): a 1.3-KB per-wave
-                    // LDS patch does the transpose (the K / V^T plane region of C is idle in this kernel), no workgroup barrier —
-                    // a wave's LDS operations complete in program order.
-                    vv[2] = tail_gather_v(acct[0][2], acct[1][2], lg);
-                    if (lg < 2) vv[2] += bv;
-                    {
-                        constexpr int SLD = 20;                                   // 16 channels + 4: b128 reads of 8 rows conflict-free
-                        float* scr = C + RP * LDC + wave * (2 * 8 * SLD);
-                        const float bqp = LW[QKV_B + head * 16 + l15], bkp = LW[QKV_B + D + head * 16 + l15];
-#pragma unroll
-                        for (int rb = 0; rb < RBT; ++rb) {
-                            scr[(4 * rb + lg) * SLD + l15] = tail_reduce(acct[rb][0], lg) + bqp;
-                            scr[8 * SLD + (4 * rb + lg) * SLD + l15] = tail_reduce(acct[rb][1], lg) + bkp;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                        qt[2] = l15 < 8 ? *reinterpret_cast<const f32x4*>(scr + l15 * SLD + lg * 4) : z;
-                        kt[2] = l15 < 8 ? *reinterpret_cast<const f32x4*>(scr + 8 * SLD + l15 * SLD + lg * 4) : z;
-                    }
-                    FH_STAMP(9 + 4 * c);    // QKV projection issued and its results consumed
-                    attention_head_regs<LDC>(qt, kt, vv, Qc, wave * 16, lane, TMAX);   // rows 40..47 of the O plane are never read
-                    FH_STAMP(10 + 4 * c);
+                for (int r = 0; r < RBM; ++r) {
+                    qt[r] = acc[r][0] + bq;
+                    kt[r] = acc[r][1] + bk;
+                    vv[r] = acc[r][2] + bv;
                 }
-                __syncthreads();
-                FH_STAMP(11 + 4 * c);
-                if (c == 0)
-                    ring_prefetch<3>(g_qkv, rsrc, voff, lbase + (int)(QKV_W * 4) + (8 + wave) * 16 * 1024, 16 * 16 * 1024);
-                else
-                    ring_prefetch<2>(g_f, rsrc, voff, lbase + (int)(W1_W * 4) + (wave * 2) * 16 * 1024, 16 * 1024);
+                // Third row block (rows 32..47, eight of them real).  V: gather the tail into the plain layout.  Q, K: the tail
+                // yields (row 4 rb + lg, channel l15) per lane; the attention wants (row l15, channels 4 lg ..): a 1.3-KB per-wave
+                // LDS patch behind the O plane does the transpose, no workgroup barrier — a wave's LDS operations complete in
+                // program order.
+                vv[2] = tail_gather_v(acct[0][2], acct[1][2], lg);
+                if (lg < 2) vv[2] += bv;
                 {
-                    const int osoff = lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + c * 8) * 1024;
-                    gemm_phase_h<2, 8>(acc_o, acc_ot, Qc + am(LDC), Qc + at(LDC), LDC, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
+                    constexpr int SLD = 20;                                   // 16 channels + 4: b128 reads of 8 rows conflict-free
+                    float* scr = C + RP * LDX + wave * (2 * 8 * SLD);
+                    const float bqp = LW[QKV_B + head * 16 + l15], bkp = LW[QKV_B + D + head * 16 + l15];
+#pragma unroll
+                    for (int rb = 0; rb < RBT; ++rb) {
+                        scr[(4 * rb + lg) * SLD + l15] = tail_reduce(acct[rb][0], lg) + bqp;
+                        scr[8 * SLD + (4 * rb + lg) * SLD + l15] = tail_reduce(acct[rb][1], lg) + bkp;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    qt[2] = l15 < 8 ? *reinterpret_cast<const f32x4*>(scr + l15 * SLD + lg * 4) : z;
+                    kt[2] = l15 < 8 ? *reinterpret_cast<const f32x4*>(scr + 8 * SLD + l15 * SLD + lg * 4) : z;
+                    __builtin_amdgcn_wave_barrier();                          // (the patch is rewritten by this wave's next head)
                 }
-                __syncthreads();
-                FH_STAMP(12 + 4 * c);
+                FH_STAMP(9 + 4 * c);    // QKV projection issued and its results consumed
+                attention_head_regs<LDX>(qt, kt, vv, Oc, head * 16, lane, TMAX);   // rows 40..47 of the O plane are never read
+                FH_STAMP(10 + 4 * c);
             }
+            __syncthreads();
+            FH_STAMP(15);
+            ring_prefetch<2>(g_f, rsrc, voff, lbase + (int)(W1_W * 4) + (wave * 2) * 16 * 1024, 16 * 1024);
+            f32x4 acc_o[RBM][2], acc_ot[RBT][2];
+            zero_acc_h<2>(acc_o, acc_ot);
+            {
+                const int osoff = lbase + (int)(WO_W * 4) + (wave * 2) * 16 * 1024;
+                gemm_phase_h<2, 16>(acc_o, acc_ot, Oc + am(LDX), Oc + at(LDX), LDX, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
+            }
+            __syncthreads();
+            FH_STAMP(16);
             // residual + bias, then LayerNorm1
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
