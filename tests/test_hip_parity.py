@@ -135,8 +135,8 @@ def test_two_window_plan_golden_and_auto_selection(golden):
             models[key].set_plan("fused2")
         y = _run(models[key], case["x_imu"], case["x_s"])
         assert np.abs(y - case["y64"]).max() < TOL_TIGHT, tag
-    # AUTO weighs rounds of the two-window kernel (2 x #CUs windows each, 1.10 ms) against rounds of the hybrid one-window
-    # kernel (#CUs windows, 0.59 ms): the result is bit-identical to the explicit plan it picked
+    # AUTO weighs rounds of the two-window kernel (2 x #CUs windows each, 1.065 ms) against rounds of the hybrid one-window
+    # kernel (#CUs windows, 0.553 ms): the result is bit-identical to the explicit plan it picked
     m, _ = _gpu_model(cfg, 0)
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     for B, picked in ((ncu + 3, "fused2"), (2 * ncu + 3, "fusedh"), (3 * ncu + 5, "fused2"), (ncu - 1, "fusedh"), (65, "fusedh")):

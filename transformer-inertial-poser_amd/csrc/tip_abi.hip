@@ -613,13 +613,13 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         else plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
     }
     if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO) {
-        // One window per workgroup with the hybrid row tiling (no hand-offs, 0.59 ms per round of #CUs windows at T = 40), or
-        // two windows per workgroup (80 rows = 5 full MFMA row blocks, 1.10 ms per round of 2 x #CUs windows): whichever
-        // needs less time for this batch.  (The pair-split plan, 0.63 ms per round with 8 hand-offs per pair, lost its
+        // One window per workgroup with the hybrid row tiling (no hand-offs, 0.553 ms per round of #CUs windows at T = 40), or
+        // two windows per workgroup (80 rows = 5 full MFMA row blocks, 1.065 ms per round of 2 x #CUs windows): whichever
+        // needs less time for this batch.  (The pair-split plan, 0.605 ms per round with 8 hand-offs per pair, lost its
         // place to the hybrid kernel and stays selectable for measurement.)
         const long long cus = h->num_cus;
         const long long rounds_h = (B + cus - 1) / cus, rounds_2 = ((B + 1) / 2 + cus - 1) / cus;
-        plan = (fused2_supported(d, T) && rounds_2 * 1100 < rounds_h * 593) ? TIP_PLAN_FUSED2 : TIP_PLAN_FUSEDH;
+        plan = (fused2_supported(d, T) && rounds_2 * 1065 < rounds_h * 553) ? TIP_PLAN_FUSED2 : TIP_PLAN_FUSEDH;
     }
     if ((plan == TIP_PLAN_FUSED || plan == TIP_PLAN_FUSEDH) && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
