@@ -329,6 +329,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.configs / extra.sustained (headline line only)")
     ap.add_argument("--sustain-s", type=float, default=3.0)
+    ap.add_argument("--prewarm-s", type=float, default=0.5, help="untimed seconds of the same step before the warm-up (clock ramp)")
     ap.add_argument("--profile-all", action="store_true", help="print a per-stage time table (separate pass)")
     args = ap.parse_args()
 
@@ -376,6 +377,14 @@ def main():
             torch.cuda.synchronize()
 
     with torch.no_grad():
+        # Bring the GPU from its idle power state to its operating clocks before the W warm-up steps (part of the set-up, like
+        # the weight broadcast: a 10-step warm-up is 7 ms, the clock ramp is longer, and the first timed steps would otherwise be
+        # measured on a GPU that is still clocking up: 0.704 vs 0.685 ms per step in profiles/r02).  Disclosed as `prewarm_s`.
+        t_pw = time.perf_counter()
+        while time.perf_counter() - t_pw < args.prewarm_s:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             y = step()
         model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=2)   # event pair around the dominant kernel
@@ -465,7 +474,7 @@ def main():
             "world_size": world, "backend": "nccl (RCCL)" if use_pg else "single process",
             "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
             "packed_image_identical_on_all_ranks": image_equal,
-            "weight_broadcast_ms": bcast_ms,
+            "weight_broadcast_ms": bcast_ms, "prewarm_s": args.prewarm_s,
             "extra": extra,
         }
         print(json.dumps(line))

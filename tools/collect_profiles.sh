@@ -1,14 +1,14 @@
 #!/bin/bash
 # Collect the round's measurement artefacts on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
 # Everything lands in gpurun_out/<round>/; copy what should be judged into profiles/<round>/ afterwards.
 # PMC passes are run separately from each other and with --kernel-trace only (no sys/hip/hsa trace domains).
 set -u
-ROUND=${1:-r01}
+ROUND=${1:-r02}
 OUT=$PWD/gpurun_out/$ROUND
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline"
+BENCH="python $PWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra"
 
 # 1. the default bench line (with cpu_baseline) and the same command under rocprofv3 --kernel-trace --stats
 timeout 600 python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
@@ -63,4 +63,15 @@ done
 # 3. sweeps
 timeout 900 python tools/sweep.py > "$OUT/sweep_n1.jsonl" 2> /dev/null
 timeout 600 python tools/stream_bench.py > "$OUT/stream_bench_n1.jsonl" 2> /dev/null
+ls -la "$OUT"
+
+# 4. the other rows' benches and the phase / step timelines of the two cooperating kernels
+timeout 600 python tools/train_bench.py > "$OUT/train_bench_n1.json" 2> /dev/null
+timeout 300 python tools/loss_bench.py > "$OUT/loss_bench_n1.json" 2> /dev/null
+timeout 300 python tools/data_bench.py > "$OUT/data_bench_n1.json" 2> /dev/null
+TIP_FUSEDH_TRACE=1 timeout 300 python tools/fh_trace.py 2> /dev/null | grep -v "^model\|^number" > "$OUT/fh_trace_B256.txt"
+TIP_RNN_TRACE=1 timeout 300 python tools/rnn_trace.py 2> /dev/null | grep -v "^model\|^number" > "$OUT/rnn_trace_B256.txt"
+timeout 300 python tools/rnn_variants.py 256 1024 2> /dev/null | grep "^B=" > "$OUT/rnn_variants.txt"
+timeout 300 python tools/plan_bench.py 256 300 512 1024 2> /dev/null | grep "^B=" > "$OUT/plan_bench.txt"
+for p in mfma4x4_probe hop_probe permlane_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
 ls -la "$OUT"
