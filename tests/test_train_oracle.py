@@ -12,7 +12,29 @@ from oracle import train_oracle
 from test_host_cpu import make_model, load_synth
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "tip_train_golden.npz")
-CASES = {"train_s0_B2_T40": 0, "train_s1_B3_T17": 1}
+CASES = {"train_s0_B2_T40": 0, "train_s1_B3_T17": 1, "train_s2_B12_T40": 2}   # tag -> weight / input seed
+
+
+def case_inputs(z, tag):
+    """(x_imu, x_s, cot) of a golden case: stored for the small ones, regenerated from the generator's seeds (and checked
+    against its checksum) for the larger one."""
+    if tag + "/x_imu" in z.files:
+        return z[tag + "/x_imu"], z[tag + "/x_s"], z[tag + "/cot"]
+    cfg = synth.PAPER
+    seed = CASES[tag]
+    B, T = int(tag.split("_B")[1].split("_")[0]), int(tag.split("_T")[1])
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=500 + seed)
+    cot = synth.normal(900 + seed, "train/cot", B * T * cfg["size_s"]).reshape(B, T, cfg["size_s"]).astype(np.float32)
+    chk = np.array([x_imu.astype(np.float64).sum(), np.nansum(x_s.astype(np.float64)), cot.astype(np.float64).sum()])
+    assert np.allclose(chk, z[tag + "/insum"], rtol=0, atol=1e-6), "synthetic inputs drifted from the golden run"
+    return x_imu, x_s, cot
+
+
+def check_y(z, tag, y, tol):
+    if tag + "/y" in z.files:
+        assert np.abs(y - z[tag + "/y"]).max() < tol
+    else:
+        assert np.abs(y[-1] - z[tag + "/y_last_window"]).max() < tol
 
 
 def digest_close(name, got, want, rtol=2e-4):
@@ -30,8 +52,9 @@ def test_oracle_matches_reference_gradients(tag):
     z = np.load(GOLD)
     cfg = synth.PAPER
     w = synth.make_weights(cfg, seed=CASES[tag])
-    y, grads = train_oracle.step(cfg, w, z[tag + "/x_imu"], z[tag + "/x_s"], z[tag + "/cot"])
-    assert np.abs(y - z[tag + "/y"]).max() < 5e-6
+    x_imu, x_s, cot = case_inputs(z, tag)
+    y, grads = train_oracle.step(cfg, w, x_imu, x_s, cot)
+    check_y(z, tag, y, 5e-6)
     names = list(w.keys())
     gn = np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in grads.values()))
     assert abs(gn - z[tag + "/gnorm"][0]) < 1e-4 * gn
