@@ -16,7 +16,7 @@ from test_host_cpu import make_model, load_synth
 pytestmark = pytest.mark.gpu
 RUNNER_GOLDEN = os.path.join(ROOT, "tests", "golden", "tip_runner_golden.npz")
 TOL_IO = 1e-4      # fp32 device arithmetic (rotation log/exp chain) vs the reference's float64 numpy, teacher-forced
-TOL_LOOP = 2e-3    # closed loop over 65 model calls (fp32 feedback through the network)
+TOL_LOOP = 5e-4    # closed loop over 65 model calls (fp32 feedback through the network); measured worst 6e-5
 
 
 @pytest.fixture(scope="module")
@@ -127,3 +127,86 @@ def test_many_streams_are_independent():
         if o is None:
             continue
         assert torch.equal(o["s_rest"][sel], o1["s_rest"]) and torch.equal(o["c_t"][sel], o1["c_t"])
+
+
+def test_rotation_branches_against_scipy_conventions():
+    """The 6D -> rotation -> axis-angle -> (averaging) -> 6D chain of the back-end at the hard spots of the conversions, teacher
+    forced: identity and 1e-4-rad rotations (small-angle branch), rotations within 1e-2 / 1e-3 rad of pi (where the axis-angle
+    sign convention decides the averaged pose), un-orthogonal and badly scaled 6D inputs (scipy's from_matrix projects to the
+    nearest rotation).  fairmotion's fork is not vendored: the conventions pinned here are scipy's, which fairmotion wraps —
+    the same stand-in the reference-runner golden uses ("parity unpinned" for the fork itself)."""
+    from scipy.spatial.transform import Rotation
+    from oracle.streaming_oracle import StreamOracle
+    lib = tlib.load()
+    n, frames = 6, 14
+    rng = np.random.RandomState(42)
+
+    def six_d(R):                      # first two columns, (3x2) row-major per joint
+        return R[:, :, :2].reshape(-1)
+
+    def crafted(kind, f):
+        axes = rng.randn(18, 3)
+        axes /= np.linalg.norm(axes, axis=1, keepdims=True)
+        if kind == 0:
+            ang = np.zeros(18)                                        # identity
+        elif kind == 1:
+            ang = np.full(18, 1e-4) * (1 + f)                         # small-angle branch
+        elif kind == 2:
+            ang = np.pi - 1e-2 * (1 + 0.1 * rng.rand(18))             # near pi
+        elif kind == 3:
+            ang = np.pi - 1e-3 * (1 + rng.rand(18))                   # nearer pi, axis flips from frame to frame
+            axes *= np.where(rng.rand(18, 1) < 0.5, -1.0, 1.0)
+        else:
+            ang = rng.uniform(0.2, 2.8, 18)
+        R = Rotation.from_rotvec(axes * ang[:, None]).as_matrix()
+        y = np.zeros(131, dtype=np.float64)
+        d6 = six_d(R)
+        if kind == 4:                                                 # un-orthogonal / badly scaled columns
+            d6 = d6.reshape(18, 3, 2) * np.array([3.0, 0.2]) + 0.15 * rng.randn(18, 3, 2)
+            d6 = d6.reshape(-1)
+        y[:108] = d6
+        y[108:111] = rng.randn(3) * 0.3
+        y[111:] = rng.randn(20)
+        return y.astype(np.float32)
+
+    kinds = [0, 1, 2, 3, 4, 5]
+    s_init = (rng.randn(n, 114) * 0.3).astype(np.float32)
+    base = Rotation.random(6 * n, random_state=7).as_matrix().reshape(n, 54)
+    oracles = [StreamOracle(s_init[b].astype(np.float64)) for b in range(n)]
+    nb = ctypes.c_size_t()
+    assert lib.tip_stream_state_bytes(n, ctypes.byref(nb)) == 0
+    state = torch.empty(nb.value, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.tip_stream_reset(state.data_ptr(), torch.tensor(s_init).cuda().data_ptr(), n, st) == 0
+    x_imu = torch.empty(n, 40, 90, device="cuda")
+    x_s = torch.empty(n, 40, 131, device="cuda")
+    s_rest = torch.empty(n, 111, device="cuda")
+    c_t = torch.empty(n, 20, device="cuda")
+    k, worst = 0, 0.0
+    for f in range(frames):
+        raw = np.concatenate([base, rng.randn(n, 18)], axis=1).astype(np.float32)
+        rd = torch.tensor(raw).cuda()
+        T = lib.tip_stream_window_len(f)
+        assert lib.tip_stream_ingest(state.data_ptr(), rd.data_ptr(), n, f, x_imu.data_ptr(), x_s.data_ptr(), st) == 0
+        ready = [o.ingest(raw[b].astype(np.float64)) for b, o in enumerate(oracles)]
+        if T == 0:
+            assert not any(ready)
+            continue
+        torch.cuda.synchronize()
+        xs = x_s.view(-1)[: n * T * 131].view(n, T, 131).cpu().numpy()
+        y = np.stack([crafted(kinds[b], f) for b in range(n)])
+        yd = torch.tensor(y).cuda()
+        assert lib.tip_stream_consume(state.data_ptr(), yd.data_ptr(), n, k, s_rest.data_ptr(), c_t.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        for b, o in enumerate(oracles):
+            _, xs_o = o.build_inputs()
+            # the history row fed back last frame (axis-angle -> 6D after the averaging): smooth in the rotation, tight tolerance
+            assert np.abs(xs[b, -1] - xs_o[-1]).max() < 2e-5, (f, b, kinds[b])
+            sr, ct = o.consume(y[b])
+            e = np.abs(s_rest[b].cpu().numpy() - sr).max()
+            worst = max(worst, e)
+            assert e < 1e-4, (f, b, kinds[b], e)       # axis-angle itself: the sign convention near pi must agree
+            assert np.array_equal(c_t[b].cpu().numpy()[0::4], ct[0::4])
+        k += 1
+    assert k == frames - 5
+    print("rotation-branch worst |axis-angle - scipy| =", worst)
