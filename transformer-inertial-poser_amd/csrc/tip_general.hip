@@ -14,6 +14,9 @@
 //   rnn_kernel          :98-99   h_t = tanh(ih_t + W_hh h_{t-1}), h_0 = 0
 #include <stdlib.h>
 
+#include <atomic>
+#include <random>
+
 #include "tip_internal.h"
 
 namespace tip {
@@ -741,17 +744,23 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             xcc &= 0xf;
-            __hip_atomic_store(flags + group * CLUSTER + cid, xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the exchange words carry this LAUNCH's tag (23 bits, a process-wide counter from a random start) above the XCC id:
+            // what an earlier launch left there never matches, so the words need no memset (a 4.7-us fill kernel plus its
+            // boundary in front of every recurrence)
+            const unsigned etag = (unsigned)prepoll >> 8, mine = (etag << 5) | (xcc + 1u);   // etag < 2^23
+            __hip_atomic_store(flags + group * CLUSTER + cid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool same = true;
             for (int m = 0; m < CLUSTER; ++m) {
                 unsigned v = 0;
+                bool here = false;
                 for (unsigned spins = 0; spins < spin_big; ++spins) {
                     v = __hip_atomic_load(flags + group * CLUSTER + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v) break;
+                    here = (v >> 5) == etag && (v & 31u) != 0u;
+                    if (here) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
-                if (!v) note_spin_timeout(gd.err);   // (the step loop below will time out on this member too, and poison)
-                same &= (v == xcc + 1u);
+                if (!here) note_spin_timeout(gd.err);   // (the step loop below will time out on this member too, and poison)
+                same &= (v == mine);
             }
             s_same_xcd = same ? 1 : 0;
         }
@@ -1036,15 +1045,16 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
             hipError_t e = hipMemsetAsync(hall, 0xFF, (size_t)hb, s);   // every word = kRnnSentinel
             if (e != hipSuccess) return e;
         }
-        hipError_t e2 = hipMemsetAsync(flags, 0, (size_t)groups * CLUSTER * sizeof(unsigned), s);   // XCC-id exchange words
-        if (e2 != hipSuccess) return e2;
+        // XCC-id exchange words: tagged with a per-launch number instead of being zeroed (see the kernel)
+        static std::atomic<unsigned> launch_tag{[] { std::random_device rd; return (unsigned)rd(); }()};
+        const unsigned etag = launch_tag.fetch_add(1u) & 0x7FFFFFu;   // 23 bits: fits the int kernel argument above the option bits
         static int trace = -1;
         if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
         static int prepoll_env = -1;   // TIP_RNN_PREPOLL=0: no arrival probe before the tile pull (measurement)
         if (prepoll_env < 0) prepoll_env = (getenv("TIP_RNN_PREPOLL") && getenv("TIP_RNN_PREPOLL")[0] == '0') ? 0 : 1;
         static int rot_env = -1;       // TIP_RNN_ROTATE=0: every member sweeps the tile from row 0 (measurement)
         if (rot_env < 0) rot_env = (getenv("TIP_RNN_ROTATE") && getenv("TIP_RNN_ROTATE")[0] == '0') ? 0 : 2;
-        const int prepoll = prepoll_env | rot_env;
+        const int prepoll = prepoll_env | rot_env | (int)(etag << 8);
         if (gate)
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1, false, true>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem,
                                s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, prepoll);
