@@ -23,6 +23,7 @@
 // Weights: the fused plan's fragment-ordered image (tip_fused.hip) — nothing is packed twice.
 #include "tip_internal.h"
 #include "tip_attention.h"
+#include "tip_layernorm.h"
 
 namespace tip {
 
@@ -43,57 +44,63 @@ __device__ __forceinline__ f32x4 ldfrag(__amdgpu_buffer_rsrc_t rsrc, int voff, i
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
 }
 
-// Stage a [T x 256] activation into LDS [48][260] (rows >= T zero) and optionally LayerNorm it in place
+// Stage a [T x 256] activation into LDS [48][260] (rows >= T zero) and optionally LayerNorm it on the way
 // (eps 1e-5, biased variance).  Row statistics go to `stats_out` ([48][2] = mean, rstd) when non-null.
+// Sixteen lanes per row (a wave takes four rows per pass, each lane 16 columns): the two statistics are a local sum plus four
+// DPP adds each (tip_layernorm.h) instead of six ds_bpermute round trips per statistic and row.
 template <int THREADS>
 __device__ __forceinline__ void stage_rows_ln(float* Xs, const float* __restrict__ src, int T, const float* __restrict__ g,
                                               const float* __restrict__ be, float* __restrict__ stats_out) {
     using namespace lz;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = THREADS / 64, RPW = RP / NW;   // rows per wave
-    // all of this wave's rows are requested before the first reduction: one L2 round trip, not RPW of them
-    float4 v[RPW];
+    constexpr int NW = THREADS / 64, NPASS = (RP + 4 * NW - 1) / (4 * NW);
+    const int q = lane & 15, sub = lane >> 4;
+    // all of this wave's rows are requested before the first reduction: one L2 round trip, not NPASS of them
+    float4 v[NPASS][4];
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int row = wave + i * NW;
-        v[i] = row < T ? *reinterpret_cast<const float4*>(src + (size_t)row * D + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float4 gg = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g) {
-        gg = *reinterpret_cast<const float4*>(g + lane * 4);
-        bb = *reinterpret_cast<const float4*>(be + lane * 4);
+    for (int p = 0; p < NPASS; ++p) {
+        const int row = (p * NW + wave) * 4 + sub;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v[p][j] = row < T ? *reinterpret_cast<const float4*>(src + (size_t)row * D + (q + 16 * j) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (g) {
-        // the RPW row reductions advance together through every shuffle step (independent chains interleave)
-        float mean[RPW], var[RPW];
+        float4 gg[4], bb[4];
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) mean[i] = (v[i].x + v[i].y) + (v[i].z + v[i].w);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) mean[i] += __shfl_xor(mean[i], off, 64);
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            mean[i] *= (1.f / D);
-            v[i].x -= mean[i]; v[i].y -= mean[i]; v[i].z -= mean[i]; v[i].w -= mean[i];
-            var[i] = (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        for (int j = 0; j < 4; ++j) {
+            gg[j] = *reinterpret_cast<const float4*>(g + (q + 16 * j) * 4);
+            bb[j] = *reinterpret_cast<const float4*>(be + (q + 16 * j) * 4);
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
+        for (int p = 0; p < NPASS; ++p) {
+            const int row = (p * NW + wave) * 4 + sub;
+            float s = ((v[p][0].x + v[p][0].y) + (v[p][0].z + v[p][0].w)) + ((v[p][1].x + v[p][1].y) + (v[p][1].z + v[p][1].w));
+            s += ((v[p][2].x + v[p][2].y) + (v[p][2].z + v[p][2].w)) + ((v[p][3].x + v[p][3].y) + (v[p][3].z + v[p][3].w));
+            const float mean = row16_sum(s) * (1.f / D);
+            float qs[4];
 #pragma unroll
-            for (int i = 0; i < RPW; ++i) var[i] += __shfl_xor(var[i], off, 64);
+            for (int j = 0; j < 4; ++j) {
+                v[p][j].x -= mean; v[p][j].y -= mean; v[p][j].z -= mean; v[p][j].w -= mean;
+                qs[j] = (v[p][j].x * v[p][j].x + v[p][j].y * v[p][j].y) + (v[p][j].z * v[p][j].z + v[p][j].w * v[p][j].w);
+            }
+            const float var = row16_sum((qs[0] + qs[1]) + (qs[2] + qs[3])) * (1.f / D);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int row = wave + i * NW;
-            const float rstd = 1.0f / sqrtf(var[i] * (1.f / D) + 1e-5f);
-            v[i].x = v[i].x * rstd * gg.x + bb.x; v[i].y = v[i].y * rstd * gg.y + bb.y;
-            v[i].z = v[i].z * rstd * gg.z + bb.z; v[i].w = v[i].w * rstd * gg.w + bb.w;
-            if (row >= T) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (stats_out && lane == 0 && row < T) { stats_out[row * 2] = mean[i]; stats_out[row * 2 + 1] = rstd; }
+            for (int j = 0; j < 4; ++j) {
+                v[p][j].x = v[p][j].x * rstd * gg[j].x + bb[j].x; v[p][j].y = v[p][j].y * rstd * gg[j].y + bb[j].y;
+                v[p][j].z = v[p][j].z * rstd * gg[j].z + bb[j].z; v[p][j].w = v[p][j].w * rstd * gg[j].w + bb[j].w;
+                if (row >= T) v[p][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (stats_out && q == 0 && row < T) { stats_out[row * 2] = mean; stats_out[row * 2 + 1] = rstd; }
         }
     }
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) *reinterpret_cast<float4*>(Xs + (wave + i * NW) * LDX + lane * 4) = v[i];
+    for (int p = 0; p < NPASS; ++p) {
+        const int row = (p * NW + wave) * 4 + sub;
+        if (row < RP)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(Xs + row * LDX + (q + 16 * j) * 4) = v[p][j];
+    }
 }
 
 // This wave's K slice (k-blocks kb0 .. kb0+nkb) of ONE 16-column block: weights first (they do not depend on the
@@ -533,8 +540,7 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
                 a2 = fmaf(w[j].z, hv.z, a2); a3 = fmaf(w[j].w, hv.w, a3);
             }
             acc = (a0 + a1) + (a2 + a3);
-            acc += __shfl_xor(acc, 16, 64);
-            acc += __shfl_xor(acc, 32, 64);
+            acc = lg4_sum(acc);   // the four K quarters (lane ^ 16, lane ^ 32) on permlane swaps: no LDS round trips on the serial chain
             __syncthreads();   // hs is rewritten next step
         }
         if (lg == 0) {
