@@ -9,6 +9,7 @@
 // from registers.  Softmax statistics of a query live in the 4 lanes that share l15: two xor-shuffles reduce them.
 // The fused inference kernels keep their own LDS-plane variant (tip_attention.h); this one serves everything else.
 #include "tip_internal.h"
+#include "tip_layernorm.h"
 
 namespace tip {
 
@@ -64,8 +65,7 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(const float* __restrict_
                 }
             }
         }
-        m = fmaxf(m, __shfl_xor(m, 16, 64));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = lg4_max(m);
         if (q >= T) m = 0.f;                         // padded query rows: keep everything finite, nothing is stored
         float l = 0.f;
         const unsigned long long pbase = ((unsigned long long)bh * T + q) * T;
@@ -85,8 +85,7 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(const float* __restrict_
                 }
             }
         }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = lg4_sum(l);
         const float inv = q < T ? 1.0f / l : 0.f;
         if (ast && lg == 0 && q < T) {
             ast[((size_t)bh * T + q) * 2] = m;
@@ -200,8 +199,7 @@ __global__ __launch_bounds__(64) void mattn_bwd_kernel(const float* __restrict__
                 dd += (gf[kb].x * of.x + gf[kb].y * of.y) + (gf[kb].z * of.z + gf[kb].w * of.w);
             }
         }
-        dd += __shfl_xor(dd, 16, 64);
-        dd += __shfl_xor(dd, 32, 64);
+        dd = lg4_sum(dd);
         const float mq = q < T ? ast[((size_t)bh * T + q) * 2] : 0.f;
         const float iq = q < T ? ast[((size_t)bh * T + q) * 2 + 1] : 0.f;
         float m2[4], i2[4], d2[4];      // the same statistics for queries 4*lg + r (second layout)

@@ -171,11 +171,7 @@ void fused_pack_ops(const Dims& d, const float* const* t, size_t base, std::vect
 // ------------------------------------------------------------------------------------------------------------
 // device pieces
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float wsum(float v) { return wave64_sum(v); }   // DPP + permlane swaps, no LDS round trips
 
 // acc[r][n] += A(rows of block r) x W(block n).  For the first SWAPN column blocks the MFMA operands are swapped (weights
 // as A, activations as B): the accumulator then holds the TRANSPOSED tile — (channels 4*lg + e, row l15) — which is the
@@ -1219,10 +1215,7 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float x = bs[e];
-                        x += __shfl_xor(x, 1, 64);
-                        x += __shfl_xor(x, 2, 64);
-                        x += __shfl_xor(x, 4, 64);
-                        x += __shfl_xor(x, 8, 64);
+                        x = row16_sum(x);
                         bs[e] = x;
                     }
                     if (l15 == 0)
@@ -1417,8 +1410,7 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 float d_ = (gs[r][0] * of[r][0] + gs[r][1] * of[r][1]) + (gs[r][2] * of[r][2] + gs[r][3] * of[r][3]);
-                d_ += __shfl_xor(d_, 16, 64);
-                d_ += __shfl_xor(d_, 32, 64);
+                d_ = lg4_sum(d_);
                 dd[r] = d_;
             }
             f32x4 dk[RB], dv[RB];
@@ -1501,9 +1493,9 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
                     sk += dk[cb][e] * a.q_scale;
                     sv += dv[cb][e];
                 }
-            sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
-            sk += __shfl_xor(sk, 16, 64); sk += __shfl_xor(sk, 32, 64);
-            sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
+            sq = lg4_sum(sq);
+            sk = lg4_sum(sk);
+            sv = lg4_sum(sv);
             if (lg == 0) {
                 float* lp = a.lnpart + (size_t)win * 6 * D + 3 * D + head * 16 + l15;
                 lp[0] = sq;

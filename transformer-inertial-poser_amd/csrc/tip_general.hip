@@ -18,6 +18,7 @@
 #include <random>
 
 #include "tip_internal.h"
+#include "tip_layernorm.h"
 
 namespace tip {
 
@@ -442,11 +443,7 @@ hipError_t launch_attention(const Dims& d, const float* qkv, float* out, int B, 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm (in place): one wave per row, two-pass in registers, wave-shuffle reductions.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave64_sum(v); }   // DPP + permlane swaps (tip_layernorm.h)
 
 template <int NV>  // float4 per lane: D <= NV*256
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, const float* __restrict__ g,

@@ -34,11 +34,7 @@ constexpr int D = 256, DH = 16, F = 1024, R = 512, RP = 48, RB = 3, TMAX = 40, K
 constexpr int LDX = D + 4, LDU = KIN + 4;
 }  // namespace lz
 
-__device__ __forceinline__ float wsum64(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float wsum64(float v) { return wave64_sum(v); }
 
 __device__ __forceinline__ f32x4 ldfrag(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));

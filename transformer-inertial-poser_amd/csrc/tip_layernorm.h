@@ -52,6 +52,10 @@ __device__ __forceinline__ float lg4_max(float v) {
     return fmaxf(v, w);
 }
 
+// sum over all 64 lanes, every lane gets it: four DPP adds inside each 16-lane row, then the four rows by two permlane swaps —
+// six VALU instructions where the __shfl_xor butterfly is six LDS round trips
+__device__ __forceinline__ float wave64_sum(float v) { return lg4_sum(row16_sum(v)); }
+
 // LayerNorm (eps 1e-5, biased variance, affine) over rows 0 .. ROWS-1 of X [rows][LD] (256 columns).  SIXTEEN lanes per row —
 // a wave normalises four rows at a time, lane (sub = lane >> 4, q = lane & 15) holding columns 4 (q + 16 j) .. + 3, j = 0..3 of
 // row 32 p + 4 wave + sub — so both row statistics are a 16-value local sum plus row16_sum: four DPP adds instead of six LDS

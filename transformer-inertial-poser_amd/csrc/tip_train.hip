@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include "tip_internal.h"
+#include "tip_layernorm.h"
 #include "tip_pgemm.h"
 
 namespace tip {
@@ -935,11 +936,7 @@ static hipError_t colsum(const float* X, long long ld, int M, int N, float* part
 // ---------------------------------------------------------------------------------------------------------------------
 // LayerNorm (torch LayerNorm: biased variance, eps 1e-5, affine): forward saving (mean, rstd); backward
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum64(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum64(float v) { return wave64_sum(v); }   // DPP + permlane swaps (tip_layernorm.h)
 
 template <int NV>
 __global__ __launch_bounds__(256) void tln_fwd_kernel(const float* __restrict__ z, const float* __restrict__ g,
