@@ -79,6 +79,11 @@ __device__ __forceinline__ void gemm_phase2(f32x4 (&acc)[NRB][NBW], const float*
 // plane row of X row r: window 1 (rows 40..79) starts at plane row 48
 __device__ __forceinline__ int prow(int r) { return r + (r >= f2::T ? 8 : 0); }
 
+// measurement only (TIP_FUSED2_TRACE=1): s_memtime stamps of workgroup 0 / thread 0 at the phase boundaries of layer 1
+__device__ unsigned long long g_f2_trace[64];
+#define F2_STAMP(slot) do { if (TRACE && blockIdx.x == 0 && tid == 0 && pair == (int)blockIdx.x && layer == 1) g_f2_trace[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+
+template <bool TRACE>
 __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
     const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
     const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ ih_out, unsigned* __restrict__ hall_sentinel,
@@ -217,14 +222,18 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                     // out-projection fragments of this quad fly during the barrier and the attention
                     ring2_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + q * 4) * 1024, 16 * 1024);
                 }
+                F2_STAMP(1 + 5 * q);
                 __syncthreads();
+                F2_STAMP(2 + 5 * q);
                 // ---- attention: wave = (head hl, window wave>>2); window w lives at plane rows 48w .. -------------------
                 {
                     const int w = wave >> 2;
                     if (w < nwin)
                         attention_head_mfma<LDQ, LDV>(Qp + w * 48 * LDQ, Kp + w * 48 * LDQ, Vt + w * 48, hl * 16, lane, T);
                 }
+                F2_STAMP(3 + 5 * q);
                 __syncthreads();
+                F2_STAMP(4 + 5 * q);
                 // next Q|K ring (next quad of this layer) goes out before the out-projection MFMAs
                 if (q < 3)
                     ring2_prefetch<1>(g_q, rsrc, voff,
@@ -240,6 +249,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                     gemm_phase2<RB, 2, 4>(acc_o, smem, ao, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
                 }
                 __syncthreads();
+                F2_STAMP(5 + 5 * q);
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
@@ -251,8 +261,10 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                     for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_o[r][n][e] + bv;
             }
             __syncthreads();
+            F2_STAMP(21);
             layernorm_rows16<f2::ROWS, f2::LDX>(X, LW + G1, LW + BE1, wave, lane);
             __syncthreads();
+            F2_STAMP(22);
             // ---- feed-forward: 8 hidden chunks of 128; linear2 accumulates in registers ------------------------------------
             float* Hc = C;
             f32x4 acc_f[RB][2];
@@ -275,6 +287,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                         for (int e = 0; e < 4; ++e) Hc[(r * 16 + lg * 4 + e) * LDH + col] = fmaxf(acc[r][0][e] + bv, 0.f);
                 }
                 __syncthreads();
+                F2_STAMP(23 + 2 * f);
                 {
                     if (f < 7) ring2_prefetch<1>(g_f1, rsrc, voff, lbase + (int)(W1_W * 4) + ((f + 1) * 8 + wave) * 16 * 1024, 0);
                     const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 8) * 1024;
@@ -283,6 +296,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                     gemm_phase2<RB, 2, 8>(acc_f, smem, ah, rsrc, voff, w2off, 64 * 1024, g_f2r, w2off, 64 * 1024);
                 }
                 __syncthreads();
+                F2_STAMP(24 + 2 * f);
             }
             if (layer + 1 < L)
                 ring2_prefetch<1>(g_q, rsrc, voff,
@@ -297,8 +311,10 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                     for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_f[r][n][e] + bv;
             }
             __syncthreads();
+            F2_STAMP(40);
             layernorm_rows16<f2::ROWS, f2::LDX>(X, LW + G2, LW + BE2, wave, lane);
             __syncthreads();
+            F2_STAMP(41);
         }
         // ---- RNN input projection: IH = X W_ih^T + (b_ih + b_hh) for both windows -> HBM -------------------------------------
         {
@@ -335,6 +351,9 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+#undef F2_STAMP
+
+
 // Pair-split plan ("fused2s"): the same two-window workgroup, but a window PAIR is shared by TWO workgroups on two CUs of
 // one XCD, split by COLUMNS.  Why: with one window per CU (B = #CUs) the 40 rows pad to 3 MFMA row blocks, and no
 // assignment of whole row blocks to CUs can do better (10 240 rows = 640 blocks on 256 CUs is 2.5 each).  Here every CU
@@ -711,17 +730,25 @@ hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const floa
     if (B <= 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder2_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, f2::LDS_BYTES);
-        if (e != hipSuccess) return e;
+        for (const void* f : {reinterpret_cast<const void*>(fused_encoder2_kernel<false>), reinterpret_cast<const void*>(fused_encoder2_kernel<true>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, f2::LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
+    static int trace = -1;
+    if (trace < 0) trace = getenv("TIP_FUSED2_TRACE") ? 1 : 0;
     const int npairs = (B + 1) / 2;
     const int grid = npairs < num_cus ? npairs : num_cus;
     const size_t ih_off = f2::LAYER0 + (size_t)d.L * f2::LAYER_FLOATS;
-    hipLaunchKernelGGL(fused_encoder2_kernel, dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
-                       keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, d.n_imu_total, d.S, d.L,
-                       (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4));
+    if (trace)
+        hipLaunchKernelGGL(fused_encoder2_kernel<true>, dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+                           keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, d.n_imu_total, d.S, d.L,
+                           (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4));
+    else
+        hipLaunchKernelGGL(fused_encoder2_kernel<false>, dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+                           keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, d.n_imu_total, d.S, d.L,
+                           (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4));
     return hipGetLastError();
 }
 
@@ -822,6 +849,11 @@ extern "C" int tip_debug_pgemm_launches(unsigned long long* out) {
 
 extern "C" int tip_debug_read_f2s_cross_xcd(unsigned* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(tip::g_f2s_cross_xcd), sizeof(unsigned)) == hipSuccess ? 0 : -5;
+}
+
+extern "C" int tip_debug_read_f2_trace(unsigned long long* out, int n) {
+    if (!out || n < 0 || n > 64) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tip::g_f2_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
 }
 
 extern "C" int tip_debug_read_f2s_trace(unsigned long long* out, int n) {
