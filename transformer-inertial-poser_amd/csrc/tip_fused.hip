@@ -268,6 +268,14 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[fz::RB][NBW]) {
 
 // LayerNorm of the residual stream: tip_layernorm.h (16 lanes per row, DPP reductions), all 48 rows here — the pad rows of the
 // padded kernels evolve like real ones and must stay finite.
+// The training forward's stash stores have per-thread row / column offsets that are loop invariant; hoisted out of the layer
+// loop they cost ~50 VGPRs for the whole kernel (hundreds of bytes of scratch per lane).  An opaque copy of the thread index at
+// each use keeps them where they are consumed: a dozen VALU instructions per store loop.
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // rows 0..T-1 of an LDS tile [rows][ld] (cols floats wide) -> HBM rows of stride dst_ld, 16-byte stores
 __device__ __forceinline__ void rows_to_hbm(const float* lds, int ld, int cols, float* dst, int dst_ld, int T, int tid) {
     const int c4n = cols >> 2;
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     }
                 }
                 __syncthreads();
-                if (TR) rows_to_hbm(Hc, LDX, 256, svl + (size_t)tr.hid * 64 + grow0 * F + f * 256, F, T, tid);
+                if (TR) rows_to_hbm(Hc, LDX, 256, svl + (size_t)tr.hid * 64 + grow0 * F + f * 256, F, T, opaque(tid));
                 {
                     const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                     // ... and the tail of linear2(f) primes it with linear1(f+1)'s (its own again after the last chunk)
@@ -655,7 +663,7 @@ __device__ __forceinline__ void mfma_block_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 
 // acct [r][n] += A[rows 32 + 4 r .. + 3]  x Wblock(n, kb), per-lg k-partials (see above)
 //   Am: this lane's LDS address for the 16-row blocks (base + l15 * lda + lg * 4);  At: for the tail (base + (32 + (lane & 3)) *
 //   lda + lg * 4).  Weight ring semantics exactly as gemm_phase.
-template <int NBW, int KB, int SWAPN = 0>
+template <int NBW, int KB, int SWAPN = 0, bool PIN = false>
 __device__ __forceinline__ void gemm_phase_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 (&acct)[fzh::RBT][NBW], const float* Am, const float* At,
                                              int lda, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b, WRing<NBW>& g,
                                              int nsoff, int nnstride_b) {
@@ -677,6 +685,7 @@ __device__ __forceinline__ void gemm_phase_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 
         mfma_block_h<NBW, SWAPN>(acc, acct, a0, t0, g.w0);
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w0[n] = load_frag(rsrc, voff, o + n * st);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);   // (as in gemm_phase: keeps the refill ahead of the second half's MFMAs)
 #pragma unroll
         for (int r = 0; r < fzh::RBM; ++r) a0[r] = *reinterpret_cast<const float4*>(Am + r * 16 * lda + (kb + 2) * 16);
 #pragma unroll
@@ -684,6 +693,7 @@ __device__ __forceinline__ void gemm_phase_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 
         mfma_block_h<NBW, SWAPN>(acc, acct, a1, t1, g.w1);
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w1[n] = load_frag(rsrc, voff, o + n * st + 1024);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -737,11 +747,13 @@ __device__ __forceinline__ f32x4 tail_gather_v(const f32x4& a0, const f32x4& a1,
 __device__ unsigned long long g_fh_trace[64];
 #define FH_STAMP(slot) do { if (TRACE && blockIdx.x == 0 && tid == 0 && (layer == 1 || (slot) < 4 || (slot) >= 40)) g_fh_trace[slot] = __builtin_amdgcn_s_memtime(); } while (0)
 
-template <bool TRACE>
+// TR: training forward (tip_train_forward) — the encoder's four dropout sites and the activation stash of the backward, exactly
+// as fused_encoder_kernel<8> writes them (same arrays, same per-element dropout keys: the masks do not depend on the tiling).
+template <bool TRACE, bool TR>
 __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
     const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
     const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ xout, float* __restrict__ ih_out,
-    unsigned* __restrict__ hall_sentinel, int B, int T, int NI, int S, int L, int wbytes, int ih_off_b) {
+    unsigned* __restrict__ hall_sentinel, int B, int T, int NI, int S, int L, int wbytes, int ih_off_b, FusedTrain tr) {
     using namespace fz;
     using namespace fzh;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -793,7 +805,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
         {
             f32x4 acc[RBM][2], acct[RBT][2];
             zero_acc_h<2>(acc, acct);
-            gemm_phase_h<2, KIN / 16>(acc, acct, U + am(LDU), U + at(LDU), LDU, rsrc, voff, in_soff, (KIN / 16) * 1024, g_in, in_soff,
+            gemm_phase_h<2, KIN / 16, 0, TR>(acc, acct, U + am(LDU), U + at(LDU), LDU, rsrc, voff, in_soff, (KIN / 16) * 1024, g_in, in_soff,
                                       (KIN / 16) * 1024);
             ring_prefetch<3>(g_qkv, rsrc, voff, (int)(LAYER0 * 4) + (int)(QKV_W * 4) + wave * 16 * 1024, 16 * 16 * 1024);
 #pragma unroll
@@ -811,11 +823,17 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
         __syncthreads();
         FH_STAMP(2);
         }
+        const size_t grow0 = (size_t)win * T;           // first global row (b*T + t) of this window
+        if (TR) rows_to_hbm(X, LDX, D, tr.sv + (size_t)tr.x0 * 64 + grow0 * D, D, T, tid);
 #pragma unroll 1
         for (int layer = 0; layer < L; ++layer) {
             FH_STAMP(8);
             const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
             const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
+            float* svl = TR ? tr.sv + (size_t)layer * tr.layer_stride * 64 : nullptr;   // this layer's stash
+            const unsigned dk1 = TR ? tip_drop_key_s(tr.seed, (unsigned)(layer * 4 + 1)) : 0u;
+            const unsigned dk2 = TR ? tip_drop_key_s(tr.seed, (unsigned)(layer * 4 + 2)) : 0u;
+            const unsigned dk3 = TR ? tip_drop_key_s(tr.seed, (unsigned)(layer * 4 + 3)) : 0u;
             float bvo[2], bv2[2];   // out-projection / linear2 biases of this wave's columns: requested a phase (or eight) ahead of their use
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
@@ -838,7 +856,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                 // rows 32..39: all three through the 4x4x1 tail in the plain orientation.  The tail of head w's product primes
                 // the ring with head 8 + w's first fragments (they fly during head w's attention).
                 const int nxt = c == 0 ? qsoff + 8 * 16 * 1024 : qsoff;
-                gemm_phase_h<3, 16, 2>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, qsoff, 16 * 16 * 1024, g_qkv, nxt,
+                gemm_phase_h<3, 16, 2, TR>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, qsoff, 16 * 16 * 1024, g_qkv, nxt,
                                        16 * 16 * 1024);
                 if (c == 1)   // out-projection fragments fly during the second attention and the barrier
                     ring_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + (wave * 2) * 16 * 1024, 16 * 1024);
@@ -876,17 +894,41 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                     __builtin_amdgcn_wave_barrier();                          // (the patch is rewritten by this wave's next head)
                 }
                 FH_STAMP(9 + 4 * c);    // QKV projection issued and its results consumed
-                attention_head_regs<LDX>(qt, kt, vv, Oc, head * 16, lane, TMAX);   // rows 40..47 of the O plane are never read
+                if (TR) {
+                    // raw q (the packed W_q carries the 1/sqrt(d_head) fold: undo it exactly), k, v -> [M, 3D]; the third block has
+                    // the same fragment layout as the padded kernel's (rows 32 + l15 / rows 32 + 4 lg + e), pad rows masked by T
+                    float* qp = svl + (size_t)tr.qkv * 64 + grow0 * (3 * D) + head * 16;
+                    const int lo = opaque(lane), l15o = lo & 15, lgo = lo >> 4;
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) {
+                        const int row = r * 16 + l15o;
+                        if (row < T) {
+                            *reinterpret_cast<f32x4*>(qp + row * (3 * D) + lgo * 4) = qt[r] * 4.0f;
+                            *reinterpret_cast<f32x4*>(qp + row * (3 * D) + D + lgo * 4) = kt[r];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int vr = r * 16 + lgo * 4 + e;
+                            if (vr < T) qp[vr * (3 * D) + 2 * D + l15o] = vv[r][e];
+                        }
+                    }
+                    attention_head_regs<LDX, true>(qt, kt, vv, Oc, head * 16, lo, TMAX, svl + (size_t)tr.ast * 64,
+                                                   (unsigned long long)win * H + head, T, tr.seed, (unsigned)(layer * 4 + 0), tr.thresh,
+                                                   tr.scale);
+                } else {
+                    attention_head_regs<LDX>(qt, kt, vv, Oc, head * 16, lane, TMAX);   // rows 40..47 of the O plane are never read
+                }
                 FH_STAMP(10 + 4 * c);
             }
             __syncthreads();
             FH_STAMP(15);
+            if (TR) rows_to_hbm(Oc, LDX, D, svl + (size_t)tr.att * 64 + grow0 * D, D, T, opaque(tid));
             ring_prefetch<2>(g_f, rsrc, voff, lbase + (int)(W1_W * 4) + (wave * 2) * 16 * 1024, 16 * 1024);
             f32x4 acc_o[RBM][2], acc_ot[RBT][2];
             zero_acc_h<2>(acc_o, acc_ot);
             {
                 const int osoff = lbase + (int)(WO_W * 4) + (wave * 2) * 16 * 1024;
-                gemm_phase_h<2, 16>(acc_o, acc_ot, Oc + am(LDX), Oc + at(LDX), LDX, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
+                gemm_phase_h<2, 16, 0, TR>(acc_o, acc_ot, Oc + am(LDX), Oc + at(LDX), LDX, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
             }
             __syncthreads();
             FH_STAMP(16);
@@ -898,13 +940,27 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
 #pragma unroll
                 for (int r = 0; r < RBM; ++r)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_o[r][n][e] + bv;
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc_o[r][n][e] + bv;
+                        if (TR && tr.thresh)
+                            v = tip_drop_hash_k(dk1, (grow0 + r * 16 + lg * 4 + e) * D + col) >= tr.thresh ? v * tr.scale : 0.f;
+                        X[(r * 16 + lg * 4 + e) * LDX + col] += v;
+                    }
 #pragma unroll
-                for (int r = 0; r < RBT; ++r) X[(TAIL0 + 4 * r + lg) * LDX + col] += tail_reduce(acc_ot[r][n], lg) + bv;
+                for (int r = 0; r < RBT; ++r) {
+                    float v = tail_reduce(acc_ot[r][n], lg) + bv;
+                    if (TR && tr.thresh)
+                        v = tip_drop_hash_k(dk1, (grow0 + TAIL0 + 4 * r + lg) * D + col) >= tr.thresh ? v * tr.scale : 0.f;
+                    X[(TAIL0 + 4 * r + lg) * LDX + col] += v;
+                }
             }
             __syncthreads();
             FH_STAMP(17);
-            layernorm_rows16<fz::TMAX, fz::LDX>(X, LW + G1, LW + BE1, wave, lane);   // rows 40..47 stay zero
+            if (TR)
+                layernorm_rows16<fz::TMAX, fz::LDX, true>(X, LW + G1, LW + BE1, wave, opaque(lane), svl + (size_t)tr.z1 * 64 + grow0 * D,
+                                                          svl + (size_t)tr.st1 * 64 + grow0 * 2, svl + (size_t)tr.x1 * 64 + grow0 * D, T);
+            else
+                layernorm_rows16<fz::TMAX, fz::LDX>(X, LW + G1, LW + BE1, wave, lane);   // rows 40..47 stay zero
             __syncthreads();
             FH_STAMP(18);
             // ---- feed-forward block: hidden in 4 chunks of 256, linear2 accumulates in registers -------------------------
@@ -923,7 +979,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                     float bv1[2];
 #pragma unroll
                     for (int n = 0; n < 2; ++n) bv1[n] = LW[W1_B + f * 256 + (wave * 2 + n) * 16 + l15];
-                    gemm_phase_h<2, 16>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, w1off, 16 * 1024, g_f, w2off, 64 * 1024);
+                    gemm_phase_h<2, 16, 0, TR>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, w1off, 16 * 1024, g_f, w2off, 64 * 1024);
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         const int col = (wave * 2 + n) * 16 + l15;
@@ -931,19 +987,29 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
 #pragma unroll
                         for (int r = 0; r < RBM; ++r)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) Hc[(r * 16 + lg * 4 + e) * LDX + col] = fmaxf(acc[r][n][e] + bv, 0.f);
+                            for (int e = 0; e < 4; ++e) {
+                                float v = fmaxf(acc[r][n][e] + bv, 0.f);
+                                if (TR && tr.thresh)
+                                    v = tip_drop_hash_k(dk2, (grow0 + r * 16 + lg * 4 + e) * F + f * 256 + col) >= tr.thresh ? v * tr.scale : 0.f;
+                                Hc[(r * 16 + lg * 4 + e) * LDX + col] = v;
+                            }
 #pragma unroll
-                        for (int r = 0; r < RBT; ++r)
-                            Hc[(TAIL0 + 4 * r + lg) * LDX + col] = fmaxf(tail_reduce(acct[r][n], lg) + bv, 0.f);
+                        for (int r = 0; r < RBT; ++r) {
+                            float v = fmaxf(tail_reduce(acct[r][n], lg) + bv, 0.f);
+                            if (TR && tr.thresh)
+                                v = tip_drop_hash_k(dk2, (grow0 + TAIL0 + 4 * r + lg) * F + f * 256 + col) >= tr.thresh ? v * tr.scale : 0.f;
+                            Hc[(TAIL0 + 4 * r + lg) * LDX + col] = v;
+                        }
                     }
                 }
                 FH_STAMP(19 + 3 * f);
                 __syncthreads();
                 FH_STAMP(20 + 3 * f);
+                if (TR) rows_to_hbm(Hc, LDX, 256, svl + (size_t)tr.hid * 64 + grow0 * F + f * 256, F, T, opaque(tid));
                 {
                     const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                     const int nxt = f < 3 ? lbase + (int)(W1_W * 4) + ((f + 1) * 16 + wave * 2) * 16 * 1024 : w2off;
-                    gemm_phase_h<2, 16>(acc_f, acc_ft, Hc + am(LDX), Hc + at(LDX), LDX, rsrc, voff, w2off, 64 * 1024, g_f, nxt,
+                    gemm_phase_h<2, 16, 0, TR>(acc_f, acc_ft, Hc + am(LDX), Hc + at(LDX), LDX, rsrc, voff, w2off, 64 * 1024, g_f, nxt,
                                         f < 3 ? 16 * 1024 : 64 * 1024);
                 }
                 __syncthreads();
@@ -958,13 +1024,27 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
 #pragma unroll
                 for (int r = 0; r < RBM; ++r)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_f[r][n][e] + bv;
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc_f[r][n][e] + bv;
+                        if (TR && tr.thresh)
+                            v = tip_drop_hash_k(dk3, (grow0 + r * 16 + lg * 4 + e) * D + col) >= tr.thresh ? v * tr.scale : 0.f;
+                        X[(r * 16 + lg * 4 + e) * LDX + col] += v;
+                    }
 #pragma unroll
-                for (int r = 0; r < RBT; ++r) X[(TAIL0 + 4 * r + lg) * LDX + col] += tail_reduce(acc_ft[r][n], lg) + bv;
+                for (int r = 0; r < RBT; ++r) {
+                    float v = tail_reduce(acc_ft[r][n], lg) + bv;
+                    if (TR && tr.thresh)
+                        v = tip_drop_hash_k(dk3, (grow0 + TAIL0 + 4 * r + lg) * D + col) >= tr.thresh ? v * tr.scale : 0.f;
+                    X[(TAIL0 + 4 * r + lg) * LDX + col] += v;
+                }
             }
             __syncthreads();
             FH_STAMP(31);
-            layernorm_rows16<fz::TMAX, fz::LDX>(X, LW + G2, LW + BE2, wave, lane);
+            if (TR)
+                layernorm_rows16<fz::TMAX, fz::LDX, true>(X, LW + G2, LW + BE2, wave, opaque(lane), svl + (size_t)tr.z2 * 64 + grow0 * D,
+                                                          svl + (size_t)tr.st2 * 64 + grow0 * 2, svl + (size_t)tr.xo * 64 + grow0 * D, T);
+            else
+                layernorm_rows16<fz::TMAX, fz::LDX>(X, LW + G2, LW + BE2, wave, lane);
             __syncthreads();
             FH_STAMP(32);
         }
@@ -976,7 +1056,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             const int isoff = ih_off_b + (wave * 4) * 16 * 1024;
             WRing<4> g_ih;
             ring_prefetch<4>(g_ih, rsrc, voff, isoff, 16 * 1024);
-            gemm_phase_h<4, 16>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
+            gemm_phase_h<4, 16, 0, TR>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
             float* io = ih_out + (size_t)win * T * R;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
@@ -1020,7 +1100,7 @@ hipError_t launch_fused_encoder_h(const Dims& d, const float* fused_w, const flo
     if (B <= 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
-        for (const void* f : {reinterpret_cast<const void*>(fused_encoder_h_kernel<false>), reinterpret_cast<const void*>(fused_encoder_h_kernel<true>)}) {
+        for (const void* f : {reinterpret_cast<const void*>(fused_encoder_h_kernel<false, false>), reinterpret_cast<const void*>(fused_encoder_h_kernel<true, false>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
             if (e != hipSuccess) return e;
         }
@@ -1031,13 +1111,33 @@ hipError_t launch_fused_encoder_h(const Dims& d, const float* fused_w, const flo
     const int grid = B < num_cus ? B : num_cus;
     float* iho = fused_has_rnn_ih(d) ? ih_out : nullptr;
     if (trace)
-        hipLaunchKernelGGL(fused_encoder_h_kernel<true>, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+        hipLaunchKernelGGL((fused_encoder_h_kernel<true, false>), dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
                            keep_scale, xout, iho, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,
-                           (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4));
+                           (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4), FusedTrain{});
     else
-        hipLaunchKernelGGL(fused_encoder_h_kernel<false>, dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+        hipLaunchKernelGGL((fused_encoder_h_kernel<false, false>), dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
                            keep_scale, xout, iho, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,
-                           (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4));
+                           (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4), FusedTrain{});
+    return hipGetLastError();
+}
+
+// training forward on the hybrid tiling (TIP_TRAIN_FWD_PADDED=1 selects fused_encoder_kernel<8>, the 48-row kernel, for A/B runs)
+hipError_t launch_fused_train_h(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s, const float* keep_mask,
+                                float keep_scale, float* ih_out, float* hall_sentinel, const FusedTrain& tr, int B, int T,
+                                int num_cus, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (!fused_supported(d, T) || !fused_has_rnn_ih(d)) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_h_kernel<false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = B < num_cus ? B : num_cus;
+    hipLaunchKernelGGL((fused_encoder_h_kernel<false, true>), dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s,
+                       keep_mask, keep_scale, (float*)nullptr, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total,
+                       d.S, d.L, (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4), tr);
     return hipGetLastError();
 }
 

@@ -307,6 +307,10 @@ hipError_t launch_attn_bwd(const Dims& d, const AttnBwdArgs& a, int B, int T, in
 hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s, const float* keep_mask,
                               float keep_scale, float* ih_out, float* hall_sentinel, const FusedTrain& tr, int B, int T,
                               int num_cus, hipStream_t s);
+// ... on the hybrid row tiling (rows 0-31 on 16x16x4, rows 32-39 on 4x4x1 MFMAs: no matrix-core work on the pad rows)
+hipError_t launch_fused_train_h(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s, const float* keep_mask,
+                                float keep_scale, float* ih_out, float* hall_sentinel, const FusedTrain& tr, int B, int T,
+                                int num_cus, hipStream_t s);
 // true when launch_rnn(cluster) will run the sentinel-polling resident kernel (HALL must be pre-filled with all-ones;
 // the fused encoder can do that for its own rows, otherwise launch_rnn memsets)
 bool rnn_uses_sentinel(const Dims& d, int B, int T, int cluster);

@@ -1444,8 +1444,10 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         tr.seed = seed; tr.thresh = dr.thresh; tr.scale = dr.scale;
         // the encoder also pre-fills its windows' HALL rows with the recurrence's hand-off sentinel (saves a 21-MB memset)
         hall_armed = rnn_uses_sentinel(d, B, T, auto_cluster(B, h->num_cus));
-        TT(launch_fused_train(d, W + L.fused_img, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f, W + L.ih,
-                              hall_armed ? W + L.hall : nullptr, tr, B, T, h->num_cus, s), "train_fused_encoder");
+        static const bool padded = getenv("TIP_TRAIN_FWD_PADDED") != nullptr;   // A/B runs only (tools/train_bench.py)
+        TT((padded ? launch_fused_train : launch_fused_train_h)(d, W + L.fused_img, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f,
+                                                                 W + L.ih, hall_armed ? W + L.hall : nullptr, tr, B, T, h->num_cus, s),
+           "train_fused_encoder");
     } else {
     {
         // fragment-order weight copies (forward and transposed) for the panel GEMM, packed from the live parameters
