@@ -281,7 +281,8 @@ __device__ __forceinline__ void rows_to_hbm(const float* lds, int ld, int cols, 
     const int c4n = cols >> 2;
     for (int i = tid; i < T * c4n; i += fz::THREADS) {
         const int r = i / c4n, c4 = i - r * c4n;
-        *reinterpret_cast<float4*>(dst + (size_t)r * dst_ld + c4 * 4) = *reinterpret_cast<const float4*>(lds + r * ld + c4 * 4);
+        // streaming stores: the stash (2 MB per window) is read next by the backward, the weights it would push out of L2 in 0.1 us
+        __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(lds + r * ld + c4 * 4), reinterpret_cast<f32x4*>(dst + (size_t)r * dst_ld + c4 * 4));
     }
 }
 
@@ -399,13 +400,13 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                         for (int r = 0; r < RB; ++r) {
                             const int row = r * 16 + l15;
                             if (row < T) {
-                                *reinterpret_cast<f32x4*>(qp + (size_t)row * (3 * D) + lg * 4) = qt[r] * 4.0f;
-                                *reinterpret_cast<f32x4*>(qp + (size_t)row * (3 * D) + D + lg * 4) = kt[r];
+                                __builtin_nontemporal_store(qt[r] * 4.0f, reinterpret_cast<f32x4*>(qp + (size_t)row * (3 * D) + lg * 4));
+                                __builtin_nontemporal_store(kt[r], reinterpret_cast<f32x4*>(qp + (size_t)row * (3 * D) + D + lg * 4));
                             }
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int vr = r * 16 + lg * 4 + e;
-                                if (vr < T) qp[(size_t)vr * (3 * D) + 2 * D + l15] = vv[r][e];
+                                if (vr < T) __builtin_nontemporal_store(vv[r][e], qp + (size_t)vr * (3 * D) + 2 * D + l15);
                             }
                         }
                         attention_head_regs<LDC, true>(qt, kt, vv, Qc, wave * 16, lane, 48, svl + (size_t)tr.ast * 64,
@@ -903,13 +904,13 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                     for (int r = 0; r < RB; ++r) {
                         const int row = r * 16 + l15o;
                         if (row < T) {
-                            *reinterpret_cast<f32x4*>(qp + row * (3 * D) + lgo * 4) = qt[r] * 4.0f;
-                            *reinterpret_cast<f32x4*>(qp + row * (3 * D) + D + lgo * 4) = kt[r];
+                            __builtin_nontemporal_store(qt[r] * 4.0f, reinterpret_cast<f32x4*>(qp + row * (3 * D) + lgo * 4));
+                            __builtin_nontemporal_store(kt[r], reinterpret_cast<f32x4*>(qp + row * (3 * D) + D + lgo * 4));
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int vr = r * 16 + lgo * 4 + e;
-                            if (vr < T) qp[vr * (3 * D) + 2 * D + l15o] = vv[r][e];
+                            if (vr < T) __builtin_nontemporal_store(vv[r][e], qp + vr * (3 * D) + 2 * D + l15o);
                         }
                     }
                     attention_head_regs<LDX, true>(qt, kt, vv, Oc, head * 16, lo, TMAX, svl + (size_t)tr.ast * 64,

@@ -60,6 +60,7 @@ __device__ __forceinline__ float wave64_sum(float v) { return lg4_sum(row16_sum(
 // a wave normalises four rows at a time, lane (sub = lane >> 4, q = lane & 15) holding columns 4 (q + 16 j) .. + 3, j = 0..3 of
 // row 32 p + 4 wave + sub — so both row statistics are a 16-value local sum plus row16_sum: four DPP adds instead of six LDS
 // round trips.  SAVE (training forward): the pre-norm rows, (mean, rstd) and the normalised rows also go to HBM for rows < T.
+typedef float ln_f32x4 __attribute__((ext_vector_type(4)));
 template <int ROWS, int LD, bool SAVE = false>
 __device__ __forceinline__ void layernorm_rows16(float* X, const float* __restrict__ g, const float* __restrict__ be, int wave,
                                                  int lane, float* zs = nullptr, float* sts = nullptr, float* xs = nullptr, int T = 0) {
@@ -81,7 +82,7 @@ __device__ __forceinline__ void layernorm_rows16(float* X, const float* __restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 v[j] = *reinterpret_cast<const float4*>(xr + j * 64);
-                if (SAVE && row < T) *reinterpret_cast<float4*>(zs + (size_t)row * DCOLS + (q + 16 * j) * 4) = v[j];
+                if (SAVE && row < T) __builtin_nontemporal_store(__builtin_bit_cast(ln_f32x4, v[j]), reinterpret_cast<ln_f32x4*>(zs + (size_t)row * DCOLS + (q + 16 * j) * 4));
             }
             s = ((v[0].x + v[0].y) + (v[0].z + v[0].w)) + ((v[1].x + v[1].y) + (v[1].z + v[1].w));
             s += ((v[2].x + v[2].y) + (v[2].z + v[2].w)) + ((v[3].x + v[3].y) + (v[3].z + v[3].w));
@@ -102,7 +103,7 @@ __device__ __forceinline__ void layernorm_rows16(float* X, const float* __restri
                 o.z = v[j].z * rstd * gg[j].z + bb[j].z;
                 o.w = v[j].w * rstd * gg[j].w + bb[j].w;
                 *reinterpret_cast<float4*>(xr + j * 64) = o;
-                if (SAVE && row < T) *reinterpret_cast<float4*>(xs + (size_t)row * DCOLS + (q + 16 * j) * 4) = o;
+                if (SAVE && row < T) __builtin_nontemporal_store(__builtin_bit_cast(ln_f32x4, o), reinterpret_cast<ln_f32x4*>(xs + (size_t)row * DCOLS + (q + 16 * j) * 4));
             }
             if (SAVE && row < T && q == 0) {
                 sts[row * 2] = mean;
