@@ -30,18 +30,20 @@ def _fault(m, bits):
 
 
 @pytest.mark.handoff_fault
-@pytest.mark.parametrize("plan,B,bits,hit", [
-    ("fused2s", 64, 1, "pair0"),      # pair-split encoder: workgroup (pair 0, half 1) never arrives
-    ("fused", 40, 2, "tile0"),        # 16-workgroup RNN clusters (sentinel hand-off): member 1 of cluster 0 never arrives
-    ("general", 37, 2, "tile0"),      # same through the general plan
-    ("latency", 3, 4, "win0"),        # GEMV RNN of the latency plan: member 1 of stream 0 never arrives
+@pytest.mark.parametrize("plan,B,bits,hit,cluster", [
+    ("fused2s", 64, 1, "pair0", 0),     # pair-split encoder: workgroup (pair 0, half 1) never arrives
+    ("fused", 40, 2, "tile0", 0),       # RNN clusters (AUTO: 4 workgroups per 4-window tile): member 1 of cluster 0 never arrives
+    ("fusedh", 40, 2, "tile0", 16),     # the 16-workgroup clusters on 16-window tiles (sentinel hand-off)
+    ("general", 37, 2, "tile0", 0),     # AUTO through the general plan
+    ("general", 37, 2, "tile0", 8),     # 8-workgroup clusters
+    ("latency", 3, 4, "win0", 0),       # GEMV RNN of the latency plan: member 1 of stream 0 never arrives
 ])
-def test_lost_handoff_poisons_and_raises(plan, B, bits, hit):
+def test_lost_handoff_poisons_and_raises(plan, B, bits, hit, cluster):
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     if plan == "fused2s" and 2 * ((B + 1) // 2) > ncu:
         pytest.skip("needs every workgroup resident")
     m = _model()
-    m.set_plan(plan)
+    m.set_plan(plan, rnn_cluster=cluster)
     x_imu, x_s = synth.make_inputs(synth.PAPER, B, 40, seed=5)
     xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
     with torch.no_grad():
@@ -61,7 +63,7 @@ def test_lost_handoff_poisons_and_raises(plan, B, bits, hit):
         if hit == "pair0":
             assert bad[0].all() and bad[1].all() and not bad[2:].any()      # both windows of pair 0, nothing else
         elif hit == "tile0":
-            nt = min(16, B)
+            nt = min(4 if cluster == 0 else 16, B)                            # windows per RNN tile (tip_general.hip: rnn_rows4_kernel / rnn_resident_kernel)
             assert bad[:nt].all()                                            # the whole tile (row 0 too: the slice of h_0 that never came)
             assert not bad[nt:].any()                                        # other window tiles are untouched
         else:
@@ -90,7 +92,7 @@ def test_training_step_reports_a_lost_handoff():
     y = m(xi, xs)
     torch.cuda.synchronize()
     _fault(m, 0)
-    assert torch.isnan(y[:16, 1:]).all() and torch.isfinite(y[16:]).all()
+    assert torch.isnan(y[:4, 1:]).all() and torch.isfinite(y[4:]).all()      # the 4-window tile of the cluster that lost a member
     with pytest.raises(tlib.TipHandoffError):
         m(xi, xs)
     try:

@@ -27,7 +27,7 @@ assert lib.tip_debug_read_rnn_trace(buf, 256) == 0
 t = np.array(buf[:160], dtype=np.float64).reshape(40, 4)
 ghz = 0.1  # s_memtime ticks at 100 MHz on this part if constant-rate; printed raw and as deltas
 pull, mma, done = t[1:, 0], t[1:, 1], t[1:, 2]
-print("ticks per step (median):", np.median(np.diff(t[1:, 0])))
+print("ticks per step (median):", np.median(np.diff(t[1:, 0])), " by the stores-out stamps:", np.median(np.diff(t[1:, 2])))
 print("pull-done -> mfma-done  :", np.median(mma - pull))
 print("mfma-done -> stores-out :", np.median(done - mma))
 print("stores-out -> next pull :", np.median(pull[1:] - done[:-1]))
@@ -36,7 +36,17 @@ if probe.max() > 0:
     print("stores-out -> arrival probe passes :", np.median(probe[1:] - done[:-1]))
     print("probe passes -> tile pulled + in LDS:", np.median(pull - probe))
 x = np.array(buf[160:252], dtype=np.float64).reshape(23, 4)     # steps 1..23: first round done, loop exit, LDS written, rounds
-if x[:, 0].max() > 0:
+if t[0, 3] > 0 and t[1, 3] > t[0, 3]:   # rows4 kernel: slots [0][3] = kernel entry, [2][3] = XCC exchange done, [1][3] = weights in registers
+    print("entry -> XCC exchange done:", t[2, 3] - t[0, 3], " -> weights loaded:", t[1, 3] - t[2, 3], " -> step 0 stores out:", t[0, 2] - t[1, 3],
+          " | entry -> last step done:", t[39, 2] - t[0, 3])
+    probe = probe * 0
+if x[:, 0].max() > 0 and probe.max() == 0:   # rows4 kernel: no arrival probe; times relative to the previous step's stores
+    d = done[:23]
+    print("stores-out -> first pull round checked   :", np.median(x[1:, 0] - d[:-1]))
+    print("first round -> pull loop exit            :", np.median(x[:, 1] - x[:, 0]), " rounds (thread 0):", np.median(x[:, 3]), x[:, 3].max())
+    print("loop exit -> own LDS writes done         :", np.median(x[:, 2] - x[:, 1]))
+    print("LDS written -> barrier passed            :", np.median(t[1:24, 0] - x[:, 2]))
+elif x[:, 0].max() > 0:
     pr = t[1:24, 3]
     print("probe passes -> first pull round checked:", np.median(x[:, 0] - pr))
     print("first round -> pull loop exit            :", np.median(x[:, 1] - x[:, 0]), " rounds (thread 0):", np.median(x[:, 3]), x[:, 3].max())

@@ -300,7 +300,8 @@ int tip_set_option(tip_handle* h, int option, int value) {
             for (auto& t : h->timers) t.used = 0;  // reset the accumulators
             return TIP_OK;
         case TIP_OPT_RNN_CLUSTER:
-            if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32)) return TIP_ERR_INVALID_ARG;
+            if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == TIP_RNN_CLUSTER_ROWS4))
+                return TIP_ERR_INVALID_ARG;
             h->rnn_cluster = value;
             return TIP_OK;
         case TIP_OPT_FAULT_INJECT:
@@ -636,6 +637,10 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         const int ntiles = (B + kRnnTile - 1) / kRnnTile;
         rnn_cluster = 16;
         while (rnn_cluster > 1 && ntiles * rnn_cluster > h->num_cus) rnn_cluster >>= 1;
+        // rnn_hidden 512: four-row tiles on 4-workgroup clusters at every batch size (76 us at B = 256 against 114 for the best
+        // 16-row variant; tools/rnn_variants2.py).  TIP_RNN_ROWS4=0 keeps the 16-row kernels (measurement).
+        static const bool rows4 = !(getenv("TIP_RNN_ROWS4") && getenv("TIP_RNN_ROWS4")[0] == '0');
+        if (rows4 && d.R == 512) rnn_cluster = kRnnRows4;
     }
     if (plan == TIP_PLAN_LATENCY) {
         StageScope sc(h, s, "latency_chain");
@@ -750,3 +755,4 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
 }
 
 }  // extern "C"
+static_assert(tip::kRnnRows4 == TIP_RNN_CLUSTER_ROWS4, "option value");

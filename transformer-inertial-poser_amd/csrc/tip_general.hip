@@ -994,6 +994,251 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// RNN recurrence on FOUR-ROW tiles (R = 512): 4-workgroup clusters, v_mfma_f32_4x4x1_16b_f32.
+//
+// The 16-row kernel above is bound by its hand-off, not by arithmetic: per step 16 workgroups all-gather a 32-KB tile from 16
+// producers through one L2 (1 750 cycles), four waves' k-partials meet in LDS behind a barrier (2 100 with tanh and stores),
+// against 2 300 cycles of MFMA.  Here a tile is FOUR windows and a cluster FOUR workgroups: each workgroup owns 128 columns of
+// W_hh, each of its 8 waves 16 columns x all 512 k — 128 VGPRs, the same fragment registers as the <8, 1> variant — and
+// multiplies with the 4x4x1 MFMA exactly as the hybrid encoder's tail does (tip_fused.hip): lane (l15, lg) of a 16x16x4
+// B fragment is column l15 at k = 16 kb + 4 lg + s, block (lg, l15 >> 2) of the 4x4x1; the A operand is h[row lane & 3] at
+// the same k (one ds_read_b128 per k-block, conflict-free with a row stride of 528 floats).  So
+//   * the tile a member pulls per step is 8 KB from 4 producers — ONE 16-byte load per thread — instead of 32 KB from 16;
+//   * a wave owns its 16 columns for every k: the four k-partials of an output sit in the four lane groups of ONE accumulator
+//     and meet through three permlane swaps — no LDS reduction, no second barrier;
+//   * the matrix-pipe time is unchanged (1 024 4x4x1 MFMAs per workgroup and step at 8+ cycles = 16x16x4's FLOP rate) and
+//     nothing is computed on pad rows.
+// A cluster serves up to kQ4Tiles tiles at once (their hops overlap; the MFMA phases run back to back) and further tiles in
+// sequence.  Hand-off protocol, XCD verification, sentinel, poison and fault injection: exactly rnn_resident_kernel's.
+// Numerics: k is summed in four chains per lane group (s = 0..3 of every k-block) — (c0 + c1) + (c2 + c3), then
+// (p[lg] + p[lg ^ 2]) + (p[lg ^ 1] + p[lg ^ 3]) — for every batch size; it differs from the 16-row kernels in summation
+// order only (they are bit-identical among themselves, this one with itself).
+// ------------------------------------------------------------------------------------------------
+constexpr int kQ4Rows = 4, kQ4Cluster = 4, kQ4Tiles = 4, kQ4LD = 512 + 16;
+
+// NT = tiles a cluster advances together (1, 2 or 4).  The step loop is straight-line code: a wave issues one VALU instruction
+// per 4 cycles and pays ~16 for every taken branch, and with two waves per SIMD a few hundred of either per step cost as much
+// as the MFMAs (the first version of this kernel spent 1 500 cycles per step outside MFMAs and memory).  Hence
+//   * every memory access of a batch is a buffer instruction: a per-lane byte offset fixed for the batch plus a SCALAR offset
+//     time * R * 4 — no per-step address arithmetic on the vector ALU;
+//   * no predication: rows past the end of the batch (and whole tiles past it, in a ragged last batch) have a per-lane offset
+//     >= hall_bytes, so the descriptor's range check returns zeros for their loads and drops their stores (the scalar offset is
+//     not part of that check: the row term alone decides); such tiles multiply zeros;
+//   * the poll loop is per WAVE: all its lanes re-ask until none of them sees a sentinel.
+template <int NT, bool TRACE, bool BWD>
+__global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict__ ih, const float* __restrict__ whh_frag,
+                                                        float* __restrict__ hall, unsigned* __restrict__ flags, int B, int T,
+                                                        int ntiles, int hall_bytes, const float* __restrict__ gate, Guard gd,
+                                                        unsigned etag, int abl, int ngroups) {
+    // abl: MEASUREMENT-ONLY ablations (wrong results), TIP_RNN_ABLATE: 1 = polls never wait, 2 = no MFMAs
+    constexpr int R = 512, KB = R / 16, CLUSTER = kQ4Cluster, LD = kQ4LD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2 buffers][NT tiles][4 rows][LD]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    if (TRACE && blockIdx.x == 0 && tid == 0) g_rnn_trace[3] = __builtin_amdgcn_s_memtime();   // kernel entry
+    // cluster membership: members are 8 workgroup ids apart — one XCD as workgroups are observed to be dealt (verified below,
+    // never assumed); the grid is whole rounds of 8 clusters, the clusters past `ngroups` have nothing to do
+    const int cid = (blockIdx.x >> 3) % CLUSTER, group = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / CLUSTER);
+    if (group >= ngroups) return;
+    const int nb = cid * 8 + wave;                                // global 16-column block of this wave
+    const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hall, 0, hall_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ih), 0, hall_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BWD ? gate : ih), 0, hall_bytes, 0x00020000);
+    if ((gd.fault & 2) && group == 0 && cid == 1) return;         // TIP_OPT_FAULT_INJECT: this member never arrives
+    const unsigned spin_big = guard_spin_limit(gd.fault, 1u << 22), spin_pull = guard_spin_limit(gd.fault, 1u << 20);
+
+    // W_hh slice -> registers, once: all 32 k-blocks of this wave's 16 columns (in flight during the exchange below)
+    float4 wreg[KB];
+    {
+        const float4* wf = reinterpret_cast<const float4*>(whh_frag) + (size_t)nb * KB * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) wreg[k] = wf[(size_t)k * 64];
+    }
+    // same-XCD fast path, verified at run time through launch-tagged exchange words (see rnn_resident_kernel)
+    __shared__ int s_same_xcd;
+    if (tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xf;
+        const unsigned mine = (etag << 5) | (xcc + 1u);
+        __hip_atomic_store(flags + group * CLUSTER + cid, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool same = true;
+        for (int m = 0; m < CLUSTER; ++m) {
+            unsigned v = 0;
+            bool here = false;
+            for (unsigned spins = 0; spins < spin_big; ++spins) {
+                v = __hip_atomic_load(flags + group * CLUSTER + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                here = (v >> 5) == etag && (v & 31u) != 0u;
+                if (here) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!here) note_spin_timeout(gd.err);
+            same &= (v == mine);
+        }
+        s_same_xcd = same ? 1 : 0;
+    }
+    __syncthreads();
+    const bool same_xcd = s_same_xcd != 0;
+    if (TRACE && blockIdx.x == 0 && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        g_rnn_trace[7] = __builtin_amdgcn_s_memtime();   // XCC exchange done, W_hh slice in registers
+    }
+    const int prow = tid >> 7, pcol = (tid & 127) * 4;            // this thread's 16 bytes of a pulled tile: row, first column
+    const int aoff = (lane & 3) * LD + lg * 4;                    // this lane's A operand: row lane & 3, k = 16 kb + 4 lg ..
+    const int lds_w = prow * LD + pcol;                            // where this thread's 16 bytes of a pulled tile go
+    bool poisoned = false;                                         // (wave-uniform)
+
+    const int tpg = (ntiles + ngroups - 1) / ngroups;             // tiles per cluster
+    const unsigned rowbytes = (unsigned)T * R * 4;
+    for (int q0 = 0; q0 < tpg; q0 += NT) {
+        int vpull[NT], vout[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            int tile = group + ngroups * (q0 + n);
+            if (q0 + n >= tpg || tile >= ntiles) tile = ntiles;   // past the batch: rows >= B, out of the descriptor's range
+            vpull[n] = (int)((unsigned)(tile * kQ4Rows + prow) * rowbytes + (unsigned)pcol * 4u);
+            vout[n] = (int)((unsigned)(tile * kQ4Rows + lg) * rowbytes + (unsigned)(nb * 16 + l15) * 4u);
+        }
+        // The input term (and the backward's gate) of step t + 1 is requested during step t's MFMA phase, AFTER its pull: vector
+        // memory returns in order, so an HBM-latency load issued in front of the poll loads would hold every one of them back.
+        float ihn[NT], gn[NT];
+        auto request_inputs = [&](int te_) {
+            const int so = te_ * (R * 4);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                ihn[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, vout[n], so, 0));
+                gn[n] = BWD ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, vout[n], so, 0)) : 0.f;
+            }
+        };
+        // The rows the producers are about to write sit in HBM / Infinity Cache (the encoder armed them with the sentinel long
+        // ago): a 64-byte store then allocates a PARTIALLY valid line in L2, and the first poll of that line waits for its fill
+        // from memory.  Each member therefore touches (one 16-byte load per thread and tile, result unused) the rows of step
+        // t + 2 during step t: the producers' stores then hit valid lines and the polls are plain L2 hits.
+        u32x4 pfv[NT];
+        auto touch_rows = [&](int te_) {
+            const int so = te_ * (R * 4);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) pfv[n] = __builtin_amdgcn_raw_buffer_load_b128(hrs, vpull[n], so, 16);
+        };
+        auto retire_touch = [&]() {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) asm volatile("" :: "v"(pfv[n]));
+        };
+        request_inputs(BWD ? T - 1 : 0);
+        touch_rows(BWD ? T - 1 : 0);
+        retire_touch();
+        if (T > 1) touch_rows(BWD ? T - 2 : 1);
+#pragma unroll 1
+        for (int t = 0; t < T; ++t) {
+            const int te = BWD ? T - 1 - t : t;        // time index this step produces
+            const int tp = BWD ? te + 1 : te - 1;      // time index of the state it consumes
+            float ihv[NT], gv[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) ihv[n] = ihn[n], gv[n] = gn[n];
+            float* buf = smem + (t & 1) * (NT * kQ4Rows * LD);
+            if (t > 0) {
+                // pull h_{t-1}: 16 bytes per thread and tile, sc1 loads (agent-scope coherent); the wave re-asks while any of
+                // its lanes still sees a sentinel word
+                const int so = tp * (R * 4);
+                u32x4 v[NT];
+                bool gave_up = true;
+                const unsigned pull_lim = poisoned ? 1u : spin_pull;
+                {   // measurement: delay before the first poll (abl bits 8..11 = s_sleep count)
+                    const int dl = (abl >> 8) & 15;
+                    for (int i = 0; i < dl; ++i) __builtin_amdgcn_s_sleep(1);
+                }
+                for (unsigned spins = 0; spins < pull_lim; ++spins) {
+                    bool pend = false;
+                    asm volatile("" ::: "memory");   // the addresses are loop invariant: without this the optimiser polls a register
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) v[n] = __builtin_amdgcn_raw_buffer_load_b128(hrs, vpull[n], so, 16);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        pend |= v[n].x == kRnnSentinel || v[n].y == kRnnSentinel || v[n].z == kRnnSentinel || v[n].w == kRnnSentinel;
+                    if (TRACE && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 24) {
+                        if (spins == 0) g_rnn_trace[160 + (t - 1) * 4 + 0] = __builtin_amdgcn_s_memtime();
+                        g_rnn_trace[160 + (t - 1) * 4 + 3] = spins + 1;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(pend) == 0 || (abl & 1)) { gave_up = false; break; }
+                    if (!same_xcd) __builtin_amdgcn_s_sleep(2);   // cross-XCD polls travel the fabric: pace them
+                }
+                if (TRACE && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 24) g_rnn_trace[160 + (t - 1) * 4 + 1] = __builtin_amdgcn_s_memtime();
+                if (gave_up) {   // (wave-uniform)
+                    if (!poisoned && lane == 0) note_spin_timeout(gd.err);
+                    poisoned = true;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {   // what never arrived becomes NaN, not the sentinel
+                        if (v[n].x == kRnnSentinel) v[n].x = kPoisonBits;
+                        if (v[n].y == kRnnSentinel) v[n].y = kPoisonBits;
+                        if (v[n].z == kRnnSentinel) v[n].z = kPoisonBits;
+                        if (v[n].w == kRnnSentinel) v[n].w = kPoisonBits;
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) *reinterpret_cast<u32x4*>(buf + n * kQ4Rows * LD + lds_w) = v[n];
+                if (TRACE && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 24) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    g_rnn_trace[160 + (t - 1) * 4 + 2] = __builtin_amdgcn_s_memtime();
+                }
+                __syncthreads();   // the only barrier of a step: the tile buffers alternate, so nobody overwrites what a slow wave still reads
+            }
+            if (TRACE && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 0] = __builtin_amdgcn_s_memtime();
+            retire_touch();
+            {   // (clamped to the last step instead of skipped: branch-free; the extra loads hit rows this launch owns)
+                const int tn = t + 1 < T ? t + 1 : t, tn2 = t + 2 < T ? t + 2 : t;
+                request_inputs(BWD ? T - 1 - tn : tn);
+                if (!(abl & 4)) touch_rows(BWD ? T - 1 - tn2 : tn2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int so_out = te * (R * 4);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+                if (t > 0 && !(abl & 2)) {
+                    // A fragments four k-blocks ahead of their MFMAs (LDS latency is 2-4 k-blocks of 4x4x1 issue time)
+                    const float* ap = buf + n * kQ4Rows * LD + aoff;
+                    float4 a[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[k] = *reinterpret_cast<const float4*>(ap + k * 16);
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) {
+                        const float4 ak = a[k & 3];
+                        if (k + 4 < KB) a[k & 3] = *reinterpret_cast<const float4*>(ap + (k + 4) * 16);
+                        c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.x, wreg[k].x, c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.y, wreg[k].y, c1, 0, 0, 0);
+                        c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.z, wreg[k].z, c2, 0, 0, 0);
+                        c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.w, wreg[k].w, c3, 0, 0, 0);
+                    }
+                }
+                const f32x4 p = (c0 + c1) + (c2 + c3);   // registers = rows 0..3, one k-partial per lane group
+                // reduce-scatter over the lane groups: lane (lg, l15) ends with row lg (as tip_fused.hip's tail_reduce)
+                float a0 = p[0], a2 = p[2];
+                swap32(a0, a2);
+                float k0 = a0 + a2;
+                float a1 = p[1], a3 = p[3];
+                swap32(a1, a3);
+                float k1 = a1 + a3;
+                swap16(k0, k1);
+                const float acc = k0 + k1;
+                if (TRACE && !(abl & 128) && n == 0 && blockIdx.x == 0 && tid == 0 && t < 64) {
+                    asm volatile("" :: "v"(acc));
+                    g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
+                }
+                float hv = BWD ? (acc + ihv[n]) * (1.0f - gv[n] * gv[n]) : tip_tanh(acc + ihv[n]);
+                if (hv != hv) hv = __uint_as_float(kPoisonBits);   // poison travels as the canonical NaN, never as the sentinel
+                // same XCD (verified): a plain store lands in the shared L2 (L1 is write-through); otherwise sc1 = write-through
+                if (same_xcd) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), hrs, vout[n], so_out, 0);
+                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), hrs, vout[n], so_out, 16);
+            }
+            if (TRACE && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 2] = __builtin_amdgcn_s_memtime();
+        }
+        retire_touch();
+        __syncthreads();   // the next batch's second step rewrites the buffer the last step of this one may still be reading
+    }
+}
+
 size_t rnn_flag_words(int B, int T) { return (size_t)((B + kRnnTile - 1) / kRnnTile) * (size_t)T + 1024; }
 
 static int rnn_handoff_mode() {
@@ -1065,12 +1310,69 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
     return hipGetLastError();
 }
 
+// four-row tiles on 4-workgroup clusters (rnn_rows4_kernel); sentinel hand-off only
+template <int NT>
+static hipError_t launch_rnn_rows4_nt(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T, int ntiles,
+                                      int groups, long long hb, const Guard& gd, hipStream_t s, const float* gate, unsigned etag, int num_cus) {
+    constexpr int smem = 2 * NT * kQ4Rows * kQ4LD * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        for (const void* f : {reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, false>), reinterpret_cast<const void*>(rnn_rows4_kernel<NT, true, false>),
+                              reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, true>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return e;
+        }
+        attr_set = true;
+    }
+    static int occ = -1;   // every member of a cluster must be resident while its partners wait for it: ask the runtime
+    hipError_t ce = check_coresident(rnn_rows4_kernel<NT, false, false>, 512, smem, groups * kQ4Cluster, num_cus, &occ);
+    if (ce != hipSuccess) return ce;
+    static int trace = -1, abl = -1;
+    if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
+    if (abl < 0) abl = getenv("TIP_RNN_ABLATE") ? atoi(getenv("TIP_RNN_ABLATE")) : 0;   // measurement only (profiles/): never set in production
+    // Members of a cluster are taken 8 workgroup ids apart (one XCD); that needs a grid of whole rounds of 8 clusters.  The
+    // workgroups of the clusters that pad the last round exit at once (they hold no resources anybody waits for).
+    const dim3 grid((groups + 7) / 8 * 8 * kQ4Cluster), block(512);
+    if (gate)
+        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, true>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups);
+    else if (trace)
+        hipLaunchKernelGGL((rnn_rows4_kernel<NT, true, false>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups);
+    else
+        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, false>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups);
+    return hipGetLastError();
+}
+
+static hipError_t launch_rnn_rows4(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T, int num_cus,
+                                   bool hall_armed, const Guard& gd, hipStream_t s, const float* gate = nullptr) {
+    const int ntiles = (B + kQ4Rows - 1) / kQ4Rows;
+    int groups = ntiles;
+    const int maxg = num_cus / kQ4Cluster > 0 ? num_cus / kQ4Cluster : 1;   // keep every cluster co-resident
+    if (groups > maxg) groups = maxg;
+    const int tpg = (ntiles + groups - 1) / groups;                          // tiles per cluster
+    const long long hb = (long long)B * T * 512 * 4;
+    if (hb > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (!hall_armed) {
+        hipError_t e = hipMemsetAsync(hall, 0xFF, (size_t)hb, s);   // every word = kRnnSentinel
+        if (e != hipSuccess) return e;
+    }
+    static std::atomic<unsigned> launch_tag{[] { std::random_device rd; return (unsigned)rd(); }()};
+    const unsigned etag = launch_tag.fetch_add(1u) & 0x7FFFFFu;
+    // tiles a cluster advances together: as many as it owns, up to kQ4Tiles (3 -> 4: the pad tile is out of range and multiplies zeros)
+    if (tpg <= 1) return launch_rnn_rows4_nt<1>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
+    if (tpg == 2) return launch_rnn_rows4_nt<2>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
+    return launch_rnn_rows4_nt<kQ4Tiles>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
+}
+
 // backward recurrence of the training step (R = 512, cluster 4 / 8 / 16 only); see rnn_resident_kernel<.., BWD>
 hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_frag, const float* h_fwd, float* delta,
                           unsigned* flags, int B, int T, int cluster, int num_cus, const Guard& gd, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (d.R != 512 || (long long)B * T * 512 * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
+    if (cluster == kRnnRows4) {
+        if (rnn_handoff_mode() == 1) return launch_rnn_rows4(dH, whh_t_frag, delta, flags, B, T, num_cus, false, gd, s, h_fwd);
+        cluster = 16;
+    }
     if (cluster >= 16) return launch_rnn_resident<8, 4>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, gd, s, h_fwd);
     if (cluster == 8) return launch_rnn_resident<4, 1>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, gd, s, h_fwd);
     return launch_rnn_resident<8, 1>(dH, whh_t_frag, delta, flags, B, T, ntiles, num_cus, false, gd, s, h_fwd);
@@ -1083,6 +1385,10 @@ hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, flo
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
     if (cluster < 1) cluster = 1;
     if (R == 512 && (long long)B * T * 512 * 4 <= 0x7fffffffLL) {
+        if (cluster == kRnnRows4) {
+            if (rnn_handoff_mode() == 1) return launch_rnn_rows4(ih, whh_frag, hall, flags, B, T, num_cus, hall_armed, gd, s);
+            cluster = 16;   // (TIP_RNN_HANDOFF=0, measurement: the counter protocol exists for the 16-row kernels only)
+        }
         // register-resident clustered kernel: W_hh slice lives in VGPRs, 4/8/16 workgroups per window tile
         if (cluster >= 32)   // two 4-wave workgroups per CU, each one column block of a tile: one computes while the other waits
             return launch_rnn_resident<4, 4>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, gd, s, nullptr, 2);

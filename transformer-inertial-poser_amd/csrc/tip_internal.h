@@ -73,6 +73,7 @@ constexpr int kGemmBM = 128;   // general GEMM block tile (rows)
 constexpr int kGemmBN = 128;   // general GEMM block tile (cols); packed weights are padded to this
 constexpr int kGemmBK = 16;    // K tile; packed K is padded to this
 constexpr int kRnnTile = 16;   // windows per RNN tile (= MFMA 16x16x4 row count)
+constexpr int kRnnRows4 = 0x44;  // TIP_OPT_RNN_CLUSTER value: 4-window tiles on 4-workgroup clusters, 4x4x1 MFMAs (rnn_rows4_kernel)
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 

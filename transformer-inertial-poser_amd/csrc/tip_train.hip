@@ -1319,6 +1319,8 @@ hipError_t launch_gemm16(const float* A, int lda, const float* W, int ldw, const
 }
 
 static int auto_cluster(int B, int num_cus) {
+    static const bool rows4 = !(getenv("TIP_RNN_ROWS4") && getenv("TIP_RNN_ROWS4")[0] == '0');
+    if (rows4) return kRnnRows4;   // (training needs rnn_hidden 512 anyway)
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
     int c = 16;
     while (c > 4 && ntiles * c > num_cus) c >>= 1;
