@@ -71,7 +71,9 @@ timeout 300 python tools/loss_bench.py > "$OUT/loss_bench_n1.json" 2> /dev/null
 timeout 300 python tools/data_bench.py > "$OUT/data_bench_n1.json" 2> /dev/null
 TIP_FUSEDH_TRACE=1 timeout 300 python tools/fh_trace.py 2> /dev/null | grep -v "^model\|^number" > "$OUT/fh_trace_B256.txt"
 TIP_RNN_TRACE=1 timeout 300 python tools/rnn_trace.py 2> /dev/null | grep -v "^model\|^number" > "$OUT/rnn_trace_B256.txt"
-timeout 300 python tools/rnn_variants.py 256 1024 2> /dev/null | grep "^B=" > "$OUT/rnn_variants.txt"
+TIP_RNN_TRACE=1 timeout 300 python tools/rnn_trace.py --cluster 16 2> /dev/null | grep -v "^model\|^number" > "$OUT/rnn_trace_B256_cluster16.txt"
+timeout 300 python tools/rnn_variants2.py 2> /dev/null | grep "^B=" > "$OUT/rnn_variants.txt"
+{ for a in 0 2; do echo "TIP_RNN_ABLATE=$a"; TIP_RNN_ABLATE=$a timeout 120 python tools/rnn_tsweep.py 256 2> /dev/null | grep "^B=\|^fit"; done; } > "$OUT/rnn_tsweep_B256.txt"
 timeout 300 python tools/plan_bench.py 256 300 512 1024 2> /dev/null | grep "^B=" > "$OUT/plan_bench.txt"
 for p in mfma4x4_probe hop_probe permlane_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
 ls -la "$OUT"

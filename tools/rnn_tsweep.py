@@ -17,7 +17,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 B = int(args[0]) if args else 256
 cl = int(sys.argv[sys.argv.index("--cluster") + 1], 0) if "--cluster" in sys.argv else 0
 res = []
-for T in (8, 16, 24, 32, 40):
+for T in (40, 16, 24, 32, 40):   # (the first pass warms up and is dropped)
     x_imu, x_s = synth.make_inputs(cfg, min(B, 256), T)
     xi = torch.tensor(np.tile(x_imu, ((B + 255) // 256, 1, 1))[:B]).cuda()
     xs = torch.tensor(np.tile(x_s, ((B + 255) // 256, 1, 1))[:B]).cuda()
@@ -29,6 +29,6 @@ for T in (8, 16, 24, 32, 40):
     st = {n: ms / k for n, ms, k in m.profile_read()}
     res.append((T, st["rnn_recurrence"] * 1e3))
     print(f"B={B} T={T:2d}: rnn {res[-1][1]:6.1f} us   " + " ".join(f"{k} {v*1e3:.1f}" for k, v in st.items()), flush=True)
-ts, us = np.array([r[0] for r in res], float), np.array([r[1] for r in res])
+ts, us = np.array([r[0] for r in res[1:]], float), np.array([r[1] for r in res[1:]])
 p, s0 = np.polyfit(ts, us, 1)
 print(f"fit: start-up {s0:.1f} us + {p:.3f} us per step")
