@@ -88,6 +88,35 @@ def test_rnn_cluster_variants(cluster):
     assert np.abs(yc - yo).max() < TOL_TIGHT
 
 
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 40), (5, 12), (37, 40), (256, 40), (300, 40), (1030, 40), (2100, 8)])
+def test_rnn_four_window_tiles(B, T):
+    """AUTO's recurrence for rnn_hidden 512 (rnn_rows4_kernel: 4-window tiles on 4-workgroup clusters, 4x4x1 MFMAs) against the
+    16-window kernels, which are pinned to the oracle above: same numbers up to summation order, for ragged tile counts (rows
+    and whole tiles past the batch end are range-checked buffer accesses), 1 / 2 / 4 tiles per cluster and several rounds of
+    them; a stream's result must not depend on its batch neighbours (bit-exact), nor on the run."""
+    cfg = synth.PAPER
+    m, w = _gpu_model(cfg, 0)
+    x_imu, x_s = synth.make_inputs(cfg, min(B, 300), T, seed=21)
+    reps = (B + x_imu.shape[0] - 1) // x_imu.shape[0]
+    x_imu, x_s = np.tile(x_imu, (reps, 1, 1))[:B], np.tile(x_s, (reps, 1, 1))[:B]
+    plan = "fusedh"
+    m.set_plan(plan, rnn_cluster=16)
+    y16 = _run(m, x_imu, x_s)
+    m.set_plan(plan, rnn_cluster=tlib.TIP_RNN_CLUSTER_ROWS4)
+    y4 = _run(m, x_imu, x_s)
+    assert np.isfinite(y4).all()
+    assert np.abs(y4 - y16).max() < 5e-6, np.abs(y4 - y16).max()
+    m.set_plan(plan, rnn_cluster=0)                                   # AUTO picks the same kernel
+    assert np.array_equal(y4, _run(m, x_imu, x_s))
+    for _ in range(3):
+        assert np.array_equal(y4, _run(m, x_imu, x_s)), "hand-off race: run-to-run difference"
+    if B > 8:                                                         # batch neighbours: the last 5 streams alone
+        assert np.array_equal(y4[-5:], _run(m, x_imu[-5:], x_s[-5:]))
+    if B <= 64:
+        yo = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
+        assert np.abs(y4 - yo).max() < TOL_TIGHT
+
+
 @pytest.mark.parametrize("plan", ALL_PLANS)
 @pytest.mark.parametrize("B,T", [(1, 1), (1, 40), (3, 2), (17, 39), (64, 40), (130, 7), (300, 33)])
 def test_vs_oracle_shapes(B, T, plan):

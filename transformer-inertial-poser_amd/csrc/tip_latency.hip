@@ -503,9 +503,11 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
     u64* hbw = hb + (size_t)win * 2 * R;
     const float* ihw = ih + (size_t)win * T * R;
     float* hw = hall + (size_t)win * T * R;
+    float ih_next = ihw[row];
     for (int t = 0; t < T; ++t) {
-        const float ihv = ihw[(size_t)t * R + row];
+        const float ihv = ih_next;
         float acc = 0.f;
+        if (t == 0 && T > 1) ih_next = ihw[(size_t)R + row];
         if (t > 0) {
             // gather h_{t-1}: thread i polls granule i until its tag says "step t" (bounded: never hang the GPU)
             const u64* gp = hbw + (size_t)((t - 1) & 1) * R + tid;
@@ -527,6 +529,9 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
             }
             hs[(tid >> 7) * 132 + (tid & 127)] = __uint_as_float((unsigned)v);
             __syncthreads();
+            // the next step's input term is requested AFTER this step's polls (vector memory returns in order: issued in front
+            // of them it would hold every poll back by its own round trip) and flies during the dot products
+            if (t + 1 < T) ih_next = ihw[(size_t)(t + 1) * R + row];
             const float* hq = hs + lg * 132;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
@@ -541,11 +546,11 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
         }
         if (lg == 0) {
             const float hv = tip_tanh(acc + ihv);
-            hw[(size_t)t * R + row] = hv;
             const u64 gran = ((u64)(unsigned)(t + 1) << 32) | (u64)__float_as_uint(hv);
             u64* gdst = hbw + (size_t)(t & 1) * R + row;
             if (same_xcd) *gdst = gran;   // one aligned 8-byte store: single-copy atomic, lands in the shared L2
             else __hip_atomic_store(gdst, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hw[(size_t)t * R + row] = hv;   // (after the granule: the partners wait for that one)
         }
     }
 }

@@ -278,6 +278,10 @@ class TF_RNN_Past_State(nn.Module):
         self._frozen = bool(frozen)
 
     def set_plan(self, plan: str = "auto", rnn_cluster: int = 0, profile: int = 0):
+        """Execution plan of the forward (measurement / deployment knob; AUTO is right for production).  rnn_cluster: 0 = auto
+        (four-window tiles on 4-workgroup clusters, lib.TIP_RNN_CLUSTER_ROWS4, when rnn_hidden is 512), 1 / 2 / 4 / 8 / 16 =
+        workgroups per 16-window tile (1: no inter-workgroup hand-off in the recurrence).  profile: 1 = per-stage timers
+        (profile_read())."""
         h = self._ensure_handle()
         h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fused2s": 5, "fusedh": 6}[plan])
         h.set_option(_lib.TIP_OPT_RNN_CLUSTER, int(rnn_cluster))
