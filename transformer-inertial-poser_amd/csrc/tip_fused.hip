@@ -1204,6 +1204,7 @@ __device__ __forceinline__ void bwd_stamp(int on, int slot) {
 
 __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int B, int T) {
     using namespace fz;
+    using namespace fzh;   // hybrid row tiling as in fused_encoder_h_kernel: rows 0-31 on 16x16x4, rows 32-39 on 4x4x1 MFMAs, nothing on pad rows
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* G = smem;                       // dy -> dz2 -> dx1
     float* Mb = smem + RP * LDX;           // dff2 (masked dz2)
@@ -1214,6 +1215,8 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wimg), 0, a.wbytes, 0x00020000);
     const int voff = lane * 16;
     const int lbase = (int)(((size_t)a.layer * fb::LAYER_FLOATS2) * 4);
+    auto am = [&](int ld) { return l15 * ld + lg * 4; };                       // this lane's LDS offsets: 16-row blocks / tail blocks
+    auto at = [&](int ld) { return (TAIL0 + (lane & 3)) * ld + lg * 4; };
     // the saved hidden activations through a buffer descriptor (byte offsets must fit 32 bits: checked by the launcher)
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.hid), 0, a.hid_bytes, 0x00020000);
 
@@ -1275,35 +1278,43 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
         __syncthreads();
         bwd_stamp(a.trace, 1);
         // ---- hidden chunks ------------------------------------------------------------------------------------------------
-        f32x4 acc_x[RB][2];
-        zero_acc<2>(acc_x);
+        f32x4 acc_x[RBM][2], acc_xt[RBT][2];
+        zero_acc_h<2>(acc_x, acc_xt);
 #pragma unroll 1
         for (int f = 0; f < 4; ++f) {
             {
-                f32x4 acc[RB][2];
-                zero_acc<2>(acc);
+                f32x4 acc[RBM][2], acct[RBT][2];
+                zero_acc_h<2>(acc, acct);
                 const int w2off = lbase + (int)(fb::W2T * 4) + (f * 16 + wave * 2) * 16 * 1024;
                 const int w1off = lbase + (int)(fb::W1T * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                 // The product is computed TRANSPOSED (weights as the A operand): a lane then holds 4 consecutive hidden
                 // channels of ONE row, so the ReLU/dropout gate is one 16-byte load of the saved hidden row and the chunk goes
                 // to LDS as one 16-byte store per tile.  The gate loads are issued before the MFMAs (buffer loads: opaque to the
                 // optimiser, so they stay here) and consumed after.
-                f32x4 gate[RB][2];
+                f32x4 gate[RBM][2];
+                float gatet[RBT][2];   // the tail comes out in the plain orientation: lane (lg, l15) = row 32 + 4 rb + lg, channel l15
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < 2; ++n) {
 #pragma unroll
-                    for (int r = 0; r < RB; ++r) {
+                    for (int r = 0; r < RBM; ++r) {
                         const int row = r * 16 + l15;
                         const long long off = ((long long)(grow0 + (row < T ? row : 0)) * F + f * 256 + (wave * 2 + n) * 16 + lg * 4) * 4;
                         gate[r][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(hrs, (int)off, 0, 0));
                     }
+#pragma unroll
+                    for (int rb = 0; rb < RBT; ++rb) {
+                        const int row = TAIL0 + 4 * rb + lg;
+                        const long long off = ((long long)(grow0 + (row < T ? row : 0)) * F + f * 256 + (wave * 2 + n) * 16 + l15) * 4;
+                        gatet[rb][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hrs, (int)off, 0, 0));
+                    }
+                }
                 // the tail of this phase primes the ring with the dx1 phase's first fragments
-                gemm_phase<2, 16, false, 2>(acc, Mb + l15 * LDX + lg * 4, LDX, rsrc, voff, w2off, 16 * 1024, g_f, w1off, 64 * 1024);
+                gemm_phase_h<2, 16, 2, true>(acc, acct, Mb + am(LDX), Mb + at(LDX), LDX, rsrc, voff, w2off, 16 * 1024, g_f, w1off, 64 * 1024);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     f32x4 bs = {0.f, 0.f, 0.f, 0.f};   // this window's share of linear1's bias gradient: column sums of the chunk
 #pragma unroll
-                    for (int r = 0; r < RB; ++r) {
+                    for (int r = 0; r < RBM; ++r) {
                         const int row = r * 16 + l15;
                         f32x4 v;
 #pragma unroll
@@ -1311,13 +1322,23 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
                         *reinterpret_cast<f32x4*>(Hc + row * LDX + (wave * 2 + n) * 16 + lg * 4) = v;
                         bs += v;
                     }
-                    // the lane holds 4 consecutive hidden channels of rows l15, 16 + l15, 32 + l15: the sum over rows is a butterfly
-                    // over the 16 lanes that share lg, straight from the registers
+                    float ts = 0.f;   // rows 32..39: lane (lg, l15) = (row 32 + 4 rb + lg, channel l15) after the tail's reduce-scatter
+#pragma unroll
+                    for (int rb = 0; rb < RBT; ++rb) {
+                        const int row = TAIL0 + 4 * rb + lg;
+                        const float x = tail_reduce(acct[rb][n], lg);
+                        const float v = (row < T && gatet[rb][n] > 0.f) ? x * a.gate_scale : 0.f;
+                        Hc[row * LDX + (wave * 2 + n) * 16 + l15] = v;
+                        ts += v;
+                    }
+                    ts = lg4_sum(ts);   // every lane (any lg, l15): the tail rows' sum of channel l15
+                    // the lane holds 4 consecutive hidden channels of rows l15 and 16 + l15: the sum over rows is a butterfly over the 16
+                    // lanes that share lg, straight from the registers; the tail's share of channel 4 lg + e sits in lane l15 = 4 lg + e
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float x = bs[e];
                         x = row16_sum(x);
-                        bs[e] = x;
+                        bs[e] = x + __shfl(ts, (lane & 48) | (lg * 4 + e), 64);
                     }
                     if (l15 == 0)
                         *reinterpret_cast<f32x4*>(a.lnpart + (size_t)win * (3 * D + F) + 3 * D + f * 256 + (wave * 2 + n) * 16 + lg * 4) = bs;
@@ -1331,8 +1352,8 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
                 const int w1off = lbase + (int)(fb::W1T * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                 const int nxt = f < 3 ? lbase + (int)(fb::W2T * 4) + ((f + 1) * 16 + wave * 2) * 16 * 1024 : w1off;
                 if (f == 0) bwd_stamp(a.trace, 4);     // first chunk: rows + bias partials out
-                gemm_phase<2, 16>(acc_x, Hc + l15 * LDX + lg * 4, LDX, rsrc, voff, w1off, 64 * 1024, g_f, nxt,
-                                  f < 3 ? 16 * 1024 : 64 * 1024);
+                gemm_phase_h<2, 16, 0, true>(acc_x, acc_xt, Hc + am(LDX), Hc + at(LDX), LDX, rsrc, voff, w1off, 64 * 1024, g_f, nxt,
+                                             f < 3 ? 16 * 1024 : 64 * 1024);
                 if (f == 0) bwd_stamp(a.trace, 5);     // first chunk: dx1 partial product done
             }
             __syncthreads();
@@ -1343,9 +1364,11 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
         for (int n = 0; n < 2; ++n) {
             const int col = (wave * 2 + n) * 16 + l15;
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
+            for (int r = 0; r < RBM; ++r)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) G[(r * 16 + lg * 4 + e) * LDX + col] += acc_x[r][n][e];
+#pragma unroll
+            for (int rb = 0; rb < RBT; ++rb) G[(TAIL0 + 4 * rb + lg) * LDX + col] += tail_reduce(acc_xt[rb][n], lg);
         }
         __syncthreads();
         rows_to_hbm(G, LDX, D, a.dx1 + grow0 * D, D, T, tid);
