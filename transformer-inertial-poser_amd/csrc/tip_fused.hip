@@ -1638,8 +1638,10 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
         {
             constexpr int KC = 128, LDA = 132, NCH = 3 * D / KC;
             static_assert(2 * RP * LDA <= 8 * 3 * RP * 20, "chunk buffers fit the scratch region");
-            f32x4 acc_i[RB][2];
-            zero_acc<2>(acc_i);
+            // hybrid row tiling (fused_encoder_h_kernel): rows 0-31 on 16x16x4, rows 32-39 on 4x4x1 MFMAs, nothing on the pad rows
+            using namespace fzh;
+            f32x4 acc_i[RBM][2], acc_it[RBT][2];
+            zero_acc_h<2>(acc_i, acc_it);
             float* Ab = Sc;
             const int wq = lbase + (int)(fb::WQT * 4) + (wave * 2) * 48 * 1024;
             WRing<2> g_q;
@@ -1667,8 +1669,9 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
             for (int ch = 0; ch < NCH; ++ch) {
                 if (ch + 1 < NCH) fetch(ch + 1);           // in flight during this chunk's MFMAs
                 const int nx = ch + 1 < NCH ? wq + (ch + 1) * (KC / 16) * 1024 : wq;
-                gemm_phase<2, KC / 16>(acc_i, Ab + (ch & 1) * RP * LDA + l15 * LDA + lg * 4, LDA, rsrc, voff, wq + ch * (KC / 16) * 1024,
-                                       48 * 1024, g_q, nx, 48 * 1024);
+                const float* Ac = Ab + (ch & 1) * RP * LDA;
+                gemm_phase_h<2, KC / 16, 0, true>(acc_i, acc_it, Ac + l15 * LDA + lg * 4, Ac + (TAIL0 + (lane & 3)) * LDA + lg * 4, LDA, rsrc, voff,
+                                                  wq + ch * (KC / 16) * 1024, 48 * 1024, g_q, nx, 48 * 1024);
                 if (ch + 1 < NCH) stash(Ab + ((ch + 1) & 1) * RP * LDA);
                 __syncthreads();
             }
@@ -1676,12 +1679,18 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
             for (int n = 0; n < 2; ++n) {
                 const int col = (wave * 2 + n) * 16 + l15;
 #pragma unroll
-                for (int r = 0; r < RB; ++r)
+                for (int r = 0; r < RBM; ++r)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int row = r * 16 + lg * 4 + e;
                         if (row < T) a.dx_in[(grow0 + row) * D + col] = a.dz1[(grow0 + row) * D + col] + acc_i[r][n][e];
                     }
+#pragma unroll
+                for (int rb = 0; rb < RBT; ++rb) {
+                    const int row = TAIL0 + 4 * rb + lg;
+                    const float v = tail_reduce(acc_it[rb][n], lg);
+                    if (row < T) a.dx_in[(grow0 + row) * D + col] = a.dz1[(grow0 + row) * D + col] + v;
+                }
             }
         }
         bwd_stamp(a.trace, 14);
