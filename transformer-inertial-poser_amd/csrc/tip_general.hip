@@ -1145,10 +1145,6 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
                 u32x4 v[NT];
                 bool gave_up = true;
                 const unsigned pull_lim = poisoned ? 1u : spin_pull;
-                {   // measurement: delay before the first poll (abl bits 8..11 = s_sleep count)
-                    const int dl = (abl >> 8) & 15;
-                    for (int i = 0; i < dl; ++i) __builtin_amdgcn_s_sleep(1);
-                }
                 for (unsigned spins = 0; spins < pull_lim; ++spins) {
                     bool pend = false;
                     asm volatile("" ::: "memory");   // the addresses are loop invariant: without this the optimiser polls a register
