@@ -74,6 +74,7 @@ TIP_RNN_TRACE=1 timeout 300 python tools/rnn_trace.py 2> /dev/null | grep -v "^m
 TIP_RNN_TRACE=1 timeout 300 python tools/rnn_trace.py --cluster 16 2> /dev/null | grep -v "^model\|^number" > "$OUT/rnn_trace_B256_cluster16.txt"
 timeout 300 python tools/rnn_variants2.py 2> /dev/null | grep "^B=" > "$OUT/rnn_variants.txt"
 { for a in 0 2; do echo "TIP_RNN_ABLATE=$a"; TIP_RNN_ABLATE=$a timeout 120 python tools/rnn_tsweep.py 256 2> /dev/null | grep "^B=\|^fit"; done; } > "$OUT/rnn_tsweep_B256.txt"
+timeout 600 python tools/rnn_soak.py 300 2> /dev/null | grep -v "^model\|^number" > "$OUT/rnn_soak.txt"
 timeout 300 python tools/plan_bench.py 256 300 512 1024 2> /dev/null | grep "^B=" > "$OUT/plan_bench.txt"
 for p in mfma4x4_probe hop_probe permlane_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
 ls -la "$OUT"
