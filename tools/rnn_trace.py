@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Measurement only: per-step timeline of the clustered RNN kernel (workgroup 0) from s_memtime stamps.
-usage: TIP_RNN_TRACE=1 python tools/rnn_trace.py [--cluster C]     (C = 0 / 0x44: four-window tiles; 16: the 16-window kernel)"""
+usage: TIP_RNN_TRACE=1 python tools/rnn_trace.py [--cluster C]     (C = 0 / 0x44: four-window tiles; 16: the 16-window kernel)
+TIP_RNN_ABLATE=128+256*k with k = 1 (barrier passed) / 2 (MFMAs done) / 3 (poll loop left): two stamps per step only — the
+stores-out stamp and point k — for phase lengths with little instrumentation in the way (TWO-STAMP line)."""
 import contextlib, ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -30,6 +32,7 @@ pull, mma, done = t[1:, 0], t[1:, 1], t[1:, 2]
 rows4 = cl in (0, 0x44) and t[0, 3] > 0 and t[1, 3] > t[0, 3]   # rnn_rows4_kernel: slots [0][3] = kernel entry, [1][3] = weights in registers
 print("kernel:", "rnn_rows4_kernel (4-window tiles, 4-workgroup clusters)" if rows4 else "rnn_resident_kernel (16-window tiles)")
 print("ticks per step (median):", np.median(np.diff(done)))
+print("TWO-STAMP: previous stores-out -> selected point:", float(np.median(mma[1:] - done[:-1])), "  selected point -> stores-out:", float(np.median(done - mma)))
 print("pull-done (barrier passed) -> mfma-done  :", np.median(mma - pull))
 print("mfma-done -> stores-out                  :", np.median(done - mma))
 print("stores-out -> next pull-done             :", np.median(pull[1:] - done[:-1]))

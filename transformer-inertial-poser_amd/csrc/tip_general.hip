@@ -1161,6 +1161,7 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
                     if (!same_xcd) __builtin_amdgcn_s_sleep(2);   // cross-XCD polls travel the fabric: pace them
                 }
                 if (TRACE && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 24) g_rnn_trace[160 + (t - 1) * 4 + 1] = __builtin_amdgcn_s_memtime();
+                if (TRACE && (abl & 128) && ((abl >> 8) & 7) == 3 && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
                 if (gave_up) {   // (wave-uniform)
                     if (!poisoned && lane == 0) note_spin_timeout(gd.err);
                     poisoned = true;
@@ -1181,6 +1182,7 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
                 __syncthreads();   // the only barrier of a step: the tile buffers alternate, so nobody overwrites what a slow wave still reads
             }
             if (TRACE && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 0] = __builtin_amdgcn_s_memtime();
+            if (TRACE && (abl & 128) && ((abl >> 8) & 7) == 1 && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
             retire_touch();
             {   // (clamped to the last step instead of skipped: branch-free; the extra loads hit rows this launch owns)
                 const int tn = t + 1 < T ? t + 1 : t, tn2 = t + 2 < T ? t + 2 : t;
@@ -1220,6 +1222,10 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
                 const float acc = k0 + k1;
                 if (TRACE && !(abl & 128) && n == 0 && blockIdx.x == 0 && tid == 0 && t < 64) {
                     asm volatile("" :: "v"(acc));
+                    g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
+                }
+                if (TRACE && (abl & 128) && ((abl >> 8) & 7) == 2 && n == 0 && blockIdx.x == 0 && tid == 0 && t < 64) {
+                    asm volatile("" :: "v"(c0[0]), "v"(c1[0]), "v"(c2[0]), "v"(c3[0]));   // MFMAs of tile 0 done, before the reduction
                     g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
                 }
                 float hv = BWD ? (acc + ihv[n]) * (1.0f - gv[n] * gv[n]) : tip_tanh(acc + ihv[n]);
