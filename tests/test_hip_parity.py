@@ -117,6 +117,33 @@ def test_rnn_four_window_tiles(B, T):
         assert np.abs(y4 - yo).max() < TOL_TIGHT
 
 
+def test_random_shapes_and_nan_patterns_auto_plan():
+    """Randomised sweep of the AUTO plan (whatever kernels it picks per shape) against the fp64 oracle: 24 seeded draws of
+    (B <= 72, T <= 40) with NaNs scattered through x_s (the reference scrubs them, :65) — a few per window, whole rows, whole
+    windows — and, through forward_last, the row the runner consumes."""
+    cfg = synth.PAPER
+    m, w = _gpu_model(cfg, 3)
+    m.set_plan("auto")
+    rng = np.random.RandomState(2026)
+    for draw in range(24):
+        B = int(rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 55, 65, 72]))
+        T = int(rng.randint(1, 41))
+        x_imu, x_s = synth.make_inputs(cfg, B, T, seed=1000 + draw)
+        mode = draw % 4
+        if mode == 1:
+            x_s[rng.rand(*x_s.shape) < 0.05] = np.nan
+        elif mode == 2:
+            x_s[rng.randint(B), rng.randint(T), :] = np.nan
+        elif mode == 3:
+            x_s[rng.randint(B)] = np.nan
+        y = _run(m, x_imu, x_s)
+        yo = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
+        assert np.isfinite(y).all(), (draw, B, T)
+        assert np.abs(y - yo).max() < TOL_TIGHT, (draw, B, T, mode, np.abs(y - yo).max())
+        yl = _run(m, x_imu, x_s, last=True)
+        assert np.abs(yl.reshape(B, -1) - yo[:, -1]).max() < TOL_TIGHT, (draw, B, T, "last row")
+
+
 @pytest.mark.parametrize("plan", ALL_PLANS)
 @pytest.mark.parametrize("B,T", [(1, 1), (1, 40), (3, 2), (17, 39), (64, 40), (130, 7), (300, 33)])
 def test_vs_oracle_shapes(B, T, plan):
