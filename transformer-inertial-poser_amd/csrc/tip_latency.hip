@@ -452,7 +452,8 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
                                                        float* __restrict__ hall, u64* __restrict__ hb,
                                                        unsigned* __restrict__ xcc_words, int B, int T, Guard gd) {
     using namespace lz;
-    __shared__ __attribute__((aligned(16))) float hs[4 * 132];   // 4 K-quarters of 128, padded: distinct banks per quarter
+    __shared__ __attribute__((aligned(16))) float hs2[2][4 * 132];   // 4 K-quarters of 128, padded: distinct banks per quarter; two buffers
+                                                                     // alternate, so one barrier per step suffices
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
                 poisoned = true;
                 v = (u64)kPoisonBits;   // the word that never came is NaN: every hidden unit that reads it follows
             }
+            float* hs = hs2[t & 1];
             hs[(tid >> 7) * 132 + (tid & 127)] = __uint_as_float((unsigned)v);
             __syncthreads();
             // the next step's input term is requested AFTER this step's polls (vector memory returns in order: issued in front
@@ -542,7 +544,6 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
             }
             acc = (a0 + a1) + (a2 + a3);
             acc = lg4_sum(acc);   // the four K quarters (lane ^ 16, lane ^ 32) on permlane swaps: no LDS round trips on the serial chain
-            __syncthreads();   // hs is rewritten next step
         }
         if (lg == 0) {
             const float hv = tip_tanh(acc + ihv);
