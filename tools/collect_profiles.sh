@@ -67,6 +67,7 @@ ls -la "$OUT"
 
 # 4. the other rows' benches and the phase / step timelines of the two cooperating kernels
 timeout 600 python tools/train_bench.py > "$OUT/train_bench_n1.json" 2> /dev/null
+timeout 600 bash tools/train_profile.sh $ROUND > "$OUT/kernel_avgs_train_B256_T40.txt" 2> /dev/null   # + kernel_stats_train_*.csv, timeline_train_step.txt
 timeout 300 python tools/loss_bench.py > "$OUT/loss_bench_n1.json" 2> /dev/null
 timeout 300 python tools/data_bench.py > "$OUT/data_bench_n1.json" 2> /dev/null
 TIP_FUSEDH_TRACE=1 timeout 300 python tools/fh_trace.py 2> /dev/null | grep -v "^model\|^number" > "$OUT/fh_trace_B256.txt"

@@ -2,11 +2,12 @@
 # kernel breakdown of the training step under rocprofv3 (run on the GPU box from the repo root)
 export TMPDIR=/tmp
 R=$PWD
+ROUND=${1:-r02}
 rm -rf /tmp/tp
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tp -- python $R/tools/train_bench.py --no-composite --steps 10 > /dev/null 2>&1)
 f=$(find /tmp/tp -name "*kernel_stats.csv" | head -1)
-mkdir -p $R/gpurun_out/r01
-cp $f $R/gpurun_out/r01/kernel_stats_train_B256_T40.csv
+mkdir -p $R/gpurun_out/$ROUND
+cp $f $R/gpurun_out/$ROUND/kernel_stats_train_B256_T40.csv
 python - "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
@@ -15,7 +16,7 @@ for r in csv.DictReader(open(sys.argv[1])):
         print(f"{n:56s} calls {int(r['Calls']):5d} avg {float(r['AverageNs'])/1e3:9.1f} us  total {float(r['TotalDurationNs'])/1e6:8.2f} ms")
 PY
 t=$(find /tmp/tp -name "*kernel_trace.csv" | head -1)
-python - "$t" > $R/gpurun_out/r01/timeline_train_step.txt <<'PY'
+python - "$t" > $R/gpurun_out/$ROUND/timeline_train_step.txt <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'tip::' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
@@ -30,4 +31,4 @@ for r in rows[a:b]:
     print(f"{s/1000:9.1f} dur {(e-s)/1000:7.1f} gap {gap:6.1f} grid {g:>16s}  {r['Kernel_Name'].split('(')[0].replace('void ','')[:60]}")
     prev = e
 PY
-tail -130 $R/gpurun_out/r01/timeline_train_step.txt
+tail -130 $R/gpurun_out/$ROUND/timeline_train_step.txt
