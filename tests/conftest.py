@@ -26,6 +26,25 @@ def golden():
     return cases
 
 
+COND_GOLDEN = os.path.join(ROOT, "tests", "golden", "tip_cond_golden.npz")
+
+
+@pytest.fixture(scope="session")
+def cond_golden():
+    """Conditioning sweep (tests/golden/make_golden.py --cond): {"x_imu", "x_s", "cases": {tag: {y32, y32_alt, y64, wsum,
+    gain_ln, noise}}}; `noise` = the reference's own fp32 rounding noise max(|y32 - y64|, |y32_alt - y64|)."""
+    z = np.load(COND_GOLDEN)
+    cases = {}
+    for k in z.files:
+        if "/" not in k:
+            continue
+        tag, name = k.split("/")
+        cases.setdefault(tag, {})[name] = z[k]
+    for c in cases.values():
+        c["noise"] = max(float(np.abs(c["y32"] - c["y64"]).max()), float(np.abs(c["y32_alt"] - c["y64"]).max()))
+    return {"x_imu": z["x_imu"], "x_s": z["x_s"], "cases": cases}
+
+
 def cfg_for_tag(tag):
     import tip_amd
     s = tip_amd.synth

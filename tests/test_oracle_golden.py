@@ -50,6 +50,28 @@ def test_oracle_f32_matches_reference_f32(golden):
         assert err < 5e-6 and err64 < 5e-6, (tag, err, err64)
 
 
+def test_oracle_conditioning_sweep(cond_golden):
+    """Outside the random-init regime (gain up to 4, LayerNorm gamma x3: the reference's own fp32-vs-fp64 difference grows
+    from 6e-7 to 1e-2) the fp64 oracle still reproduces the fp64 reference to rounding amplified by the same factor, and
+    the fp32 oracle stays inside a small multiple of the reference's own fp32 noise."""
+    cfg = synth.PAPER
+    x_imu, x_s = synth.make_inputs(cfg, 2, 40, seed=1234)
+    assert np.array_equal(x_imu, cond_golden["x_imu"]) and np.array_equal(x_s, cond_golden["x_s"], equal_nan=True)
+    assert len(cond_golden["cases"]) == 9
+    for tag, c in cond_golden["cases"].items():
+        g, lg = (float(v) for v in c["gain_ln"])
+        w = synth.make_weights(cfg, seed=0, gain=g, ln_gamma=lg)
+        s = sum(float(v.astype(np.float64).sum()) for v in w.values())
+        s2 = sum(float((v.astype(np.float64) ** 2).sum()) for v in w.values())
+        np.testing.assert_allclose([s, s2], c["wsum"], rtol=1e-12)
+        y64 = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
+        y32 = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float32)
+        e64, e32 = np.abs(y64 - c["y64"]).max(), np.abs(y32 - c["y64"]).max()
+        # fp64 rounding (1e-16) is amplified like fp32 rounding (6e-8): noise * 2^-29 * margin
+        assert e64 < max(1e-12, c["noise"] * 1e-7), (tag, e64, c["noise"])
+        assert e32 < max(5e-6, 3.0 * c["noise"]), (tag, e32, c["noise"])
+
+
 def test_oracle_taps_match_reference_hooks(golden):
     for tag, case in golden.items():
         if "tap_layer0" not in case:

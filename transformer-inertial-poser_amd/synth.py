@@ -120,15 +120,16 @@ def state_dict_layout(cfg: dict) -> "OrderedDict[str, tuple]":
     return lay
 
 
-def make_weights(cfg: dict, seed: int = 0, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
-    """fp32 weights: U(-g/sqrt(fan_in), g/sqrt(fan_in)) matrices and biases; LayerNorm gamma = 1 + 0.1 U(-1,1),
-    beta = 0.1 U(-1,1) so the affine part is exercised."""
+def make_weights(cfg: dict, seed: int = 0, gain: float = 1.0, ln_gamma: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """fp32 weights: U(-g/sqrt(fan_in), g/sqrt(fan_in)) matrices and biases; LayerNorm gamma = ln_gamma (1 + 0.1 U(-1,1)),
+    beta = 0.1 U(-1,1) so the affine part is exercised.  `gain` > 1 and `ln_gamma` > 1 leave the benign random-init regime
+    (larger attention logits, saturating tanh recurrence): the conditioning sweep of tests/golden/make_golden.py."""
     out: "OrderedDict[str, np.ndarray]" = OrderedDict()
     for name, shape in state_dict_layout(cfg).items():
         n = int(np.prod(shape))
         u = uniform01(seed, "w/" + name, n) * 2.0 - 1.0
         if ".norm" in name:
-            v = (1.0 + 0.1 * u) if name.endswith("weight") else 0.1 * u
+            v = ln_gamma * (1.0 + 0.1 * u) if name.endswith("weight") else 0.1 * u
         else:
             if len(shape) == 2:
                 fan_in = shape[1]
