@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Measurement only: tile timeline of the register-resident output projection (tip_head.hip) from s_memtime stamps.
+usage: TIP_HEAD_TRACE=1 python tools/head_trace.py [B]"""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np, torch
+from tip_amd import synth, lib as tlib
+from sweep import model_for
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+m = model_for(synth.PAPER)
+x_imu, x_s = synth.make_inputs(synth.PAPER, min(B, 64), 40)
+reps = (B + 63) // 64
+xi = torch.tensor(np.tile(x_imu, (reps, 1, 1))[:B]).cuda(); xs = torch.tensor(np.tile(x_s, (reps, 1, 1))[:B]).cuda()
+with torch.no_grad():
+    for _ in range(5):
+        m(xi, xs)
+    torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 32)()
+assert tlib.load().tip_debug_read_head_trace(buf, 32) == 0
+t = np.array(buf[:], dtype=np.float64)
+for wg, o in ((0, 0), (100, 16)):
+    # s_memtime ticks at 100 MHz on gfx950 (REFCLK) — report both raw ticks and us
+    tt = t[o:o + 16]
+    print(f"workgroup {wg}: raw", [int(v - tt[0]) for v in tt])

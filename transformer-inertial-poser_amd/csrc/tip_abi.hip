@@ -746,7 +746,15 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         if (plan == TIP_PLAN_LATENCY) {
             TIP_TRY(launch_latency_head(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, hM, d.S, s), "out_linear");
         } else {
-            TIP_TRY(launch_head_gemm(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, hM, d.S, Kh, s), "out_linear");
+            // window lengths that are multiples of 40 (the paper's and the scaled configuration's): the register-resident
+            // kernel for both forms of the output (bit-identical last rows); everything else: head_gemm_kernel for both
+            static const bool ksplit = !(getenv("TIP_HEAD") && getenv("TIP_HEAD")[0] == 'o');   // TIP_HEAD=old: measurement
+            hipError_t he = hipErrorInvalidValue;
+            if (ksplit && T % 40 == 0)
+                he = launch_head_ksplit(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, hM, d.S, Kh, last_only, h->num_cus, s);
+            if (he == hipErrorInvalidValue)
+                he = launch_head_gemm(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, hM, d.S, Kh, s);
+            TIP_TRY(he, "out_linear");
         }
     }
 #undef TIP_TRY

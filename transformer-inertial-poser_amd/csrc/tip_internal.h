@@ -319,6 +319,12 @@ bool rnn_uses_sentinel(const Dims& d, int B, int T, int cluster);
 hipError_t launch_head_gemm(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy,
                             int M, int N, int K, hipStream_t s);
 
+// the same product with the weight resident in registers (tip_head.hip): K = 512, 128 < N <= 144, window length a multiple of 40
+// (full output: M a multiple of 40; last_only: M = one row per window, bit-identical to row T-1 of the full output).
+// hipErrorInvalidValue = shape not served (nothing launched).
+hipError_t launch_head_ksplit(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy, int M, int N,
+                              int K, bool last_only, int num_cus, hipStream_t s);
+
 // ---- latency plan (tip_latency.hip): one window spread over many CUs, for few concurrent streams ----
 bool latency_supported(const Dims& d, int B, int T);
 size_t latency_workspace_floats(int B, int T);
