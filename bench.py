@@ -29,6 +29,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The host driver of this pool only supports dmabuf IPC: without this RCCL's intra-node transport fails with
+# `hipIpcGetMemHandle: invalid argument` as soon as a second rank exists.  Set before HIP / RCCL initialise.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -106,6 +109,30 @@ def p50_latency_ms(fn, iters):
         e1.synchronize()
         ts.append(e0.elapsed_time(e1))
     return float(np.median(ts))
+
+
+def output_digest(y):
+    """Order-sensitive 2 x int64 digest of a float32 tensor's BITS (wrap-around arithmetic: identical bits <=> identical digest
+    for all practical purposes; NaN payloads included)."""
+    b = y.contiguous().view(torch.int32).reshape(-1).to(torch.int64)
+    w = (torch.arange(b.numel(), device=b.device, dtype=torch.int64) % 65521) + 1
+    return torch.stack([b.sum(), (b * w).sum()])
+
+
+def probe_outputs(model, cfg, dev, T, batch_xi, batch_xs, last):
+    """Self-check of the multi-GPU run (nobody can rehearse it): 4 seed-derived probe windows, IDENTICAL on every rank, are run
+    (i) alone (whatever plan AUTO picks for 4 streams) and (ii) as the first 4 windows of this rank's own batch on the bench's
+    plan.  Streams are independent and every rank holds rank 0's weights, so both outputs must be bit-identical on all ranks
+    (north_star: no per-step cross-GPU dependency).  Returns a [4] int64 digest."""
+    px, ps = synth.make_inputs(cfg, 4, T, seed=424242)
+    px, ps = torch.tensor(px).to(dev), torch.tensor(ps).to(dev)
+    y_alone = model(px, ps)
+    xi2, xs2 = batch_xi.clone(), batch_xs.clone()
+    n = min(4, xi2.shape[0])
+    xi2[:n], xs2[:n] = px[:n], ps[:n]
+    y_in = (model.forward_last(xi2, xs2) if last else model(xi2, xs2))[:n]
+    torch.cuda.synchronize()
+    return torch.cat([output_digest(y_alone), output_digest(y_in)])
 
 
 def frac_of_peak(cfg, T, windows_per_s, n_gpus=1):
@@ -335,11 +362,33 @@ def main():
 
     rank, local_rank, world = tdist.env_rank()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TIP_BENCH_SHARE_GPU=1 + TIP_BENCH_BACKEND=gloo: every rank on cuda:0 over gloo — how tests/test_dist_gpu.py rehearses the
+    # world_size-2 control AND data flow of this very file on a 1-GPU box (with a plan without cooperating kernels)
+    share_gpu = os.environ.get("TIP_BENCH_SHARE_GPU", "0") == "1"
+    backend = os.environ.get("TIP_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_pg = "RANK" in os.environ          # launched by torch.distributed.run (also exercised with one rank)
     if use_pg:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def gather_all(t):
+        """all_gather of a small device tensor -> list of tensors on `dev` (gloo has no CUDA all_gather: host round trip)."""
+        if not (use_pg and world > 1):
+            return [t]
+        if backend == "nccl":
+            out = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(out, t)
+            return out
+        tc = t.cpu()
+        out = [torch.zeros_like(tc) for _ in range(world)]
+        dist.all_gather(out, tc)
+        return [o.to(dev) for o in out]
+
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     spec = CONFIGS[args.config]
@@ -356,9 +405,7 @@ def main():
     bcast_ms = (time.perf_counter() - t_b0) * 1e3
     # every rank must hold rank 0's image, bit for bit
     csum = packed.view(torch.int32).to(torch.int64).sum().reshape(1)
-    sums = [csum.clone() for _ in range(world)]
-    if use_pg and world > 1:
-        dist.all_gather(sums, csum)
+    sums = gather_all(csum)
     image_equal = all(int(s.item()) == int(sums[0].item()) for s in sums)
     assert image_equal, "a rank's packed weight image differs from rank 0's after the broadcast"
     model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=0)
@@ -398,12 +445,16 @@ def main():
         model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=0)
     assert torch.isfinite(y).all()
     model.check_handoffs()                 # a lost inter-workgroup hand-off is an error, not a number
+    # every rank's outputs for the same probe windows must be rank 0's, bit for bit
+    with torch.no_grad():
+        dig = probe_outputs(model, cfg, dev, T, xi, xs, last)
+    digs = gather_all(dig)
+    outputs_equal = all(torch.equal(d_, digs[0]) for d_ in digs)
+    assert outputs_equal, f"rank outputs differ for identical probe windows: {[d_.tolist() for d_ in digs]}"
     my_ms = elapsed / args.steps * 1e3
     rank_ms = [my_ms]
     if use_pg:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        all_t = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(all_t, t)
+        all_t = gather_all(torch.tensor([elapsed], device=dev, dtype=torch.float64))
         rank_ms = [float(v.item()) / args.steps * 1e3 for v in all_t]
         elapsed = max(float(v.item()) for v in all_t)
 
@@ -429,6 +480,31 @@ def main():
                         "avg_launch_ms": avg_ms, "launches_timed": launches, "flops_per_launch": fl}
 
     extra = {}
+    if args.config == "paper256" and not args.no_extra:
+        # north_star's table: frames/s at batch 1 and at 8192 streams in total (strong-scaled: 8192 / N per GPU, last-row output,
+        # BASELINE configs[3]) on this run's N GPUs, same barrier + max-over-ranks timing as the headline (which is batch 256/GPU)
+        table = {}
+        with torch.no_grad():
+            for name, bt, lastrow, nst in (("batch1_per_gpu", 1, True, 200), ("streams8192_total", max(8192 // world, 1), True, 10)):
+                reps = (bt + xi.shape[0] - 1) // xi.shape[0]
+                ti, ts_ = xi.repeat(reps, 1, 1)[:bt].contiguous(), xs.repeat(reps, 1, 1)[:bt].contiguous()
+                fn = (lambda: model.forward_last(ti, ts_)) if lastrow else (lambda: model(ti, ts_))
+                for _ in range(3):
+                    fn()
+                sync_all()
+                t1 = time.perf_counter()
+                for _ in range(nst):
+                    fn()
+                sync_all()
+                el = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+                els = gather_all(el)
+                el_max = max(float(v.item()) for v in els)
+                table[name] = {"streams_per_gpu": bt, "streams_total": bt * world, "steps": nst, "ms_per_step": el_max / nst * 1e3,
+                               "frames_per_s": bt * world * nst / el_max, "output": "last row" if lastrow else "full",
+                               "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(cfg, T, bt * world * nst / el_max, world)}
+                del ti, ts_
+        model.check_handoffs()
+        extra["scaling_table"] = table
     with torch.no_grad():
         if rank == 0 and world == 1 and not args.no_extra:
             extra["sustained"] = sustained_pass(step, my_ms, args.sustain_s)
@@ -471,9 +547,10 @@ def main():
             "cpu_baseline": cpu,
             "whole_forward_tflops": value * fpw / 1e12,
             "whole_forward_frac_of_fp32_mfma_peak": value * fpw / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
-            "world_size": world, "backend": "nccl (RCCL)" if use_pg else "single process",
+            "world_size": world, "backend": ("nccl (RCCL)" if backend == "nccl" else backend) if use_pg else "single process",
             "per_rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms},
             "packed_image_identical_on_all_ranks": image_equal,
+            "ranks_output_identical": outputs_equal, "probe_output_digest": [int(v) for v in digs[0].tolist()],
             "weight_broadcast_ms": bcast_ms, "prewarm_s": args.prewarm_s,
             "extra": extra,
         }

@@ -1,7 +1,9 @@
-"""GPU: the N>1 launch path end to end with the real backend — `python -m torch.distributed.run --nproc-per-node 1 bench.py`
+"""GPU: the N>1 launch path.  (i) end to end with the real backend — `python -m torch.distributed.run --nproc-per-node 1 bench.py`
 initialises RCCL ("nccl"), broadcasts the packed image, all-gathers the per-rank times and the image checksums, and prints the
 one JSON line the driver parses.  (More ranks need more GPUs than the test box has; the rank-count-independent control flow is
-what runs here, the world_size-2 data flow is covered on CPU by tests/test_dist_cpu.py.)"""
+what runs here.)  (ii) world_size 2 for real on the one GPU the box has: both ranks on cuda:0 over gloo, on a plan without cooperating
+kernels (fusedh + rnn_cluster 1) — bench.py itself (TIP_BENCH_SHARE_GPU / TIP_BENCH_BACKEND: its all-gathers, the probe-window
+output digests, the scaling table), and a worker pair whose shard outputs must concatenate to a single-process run bit for bit."""
 import json
 import os
 import socket
@@ -35,7 +37,59 @@ def test_bench_under_torchrun_with_rccl(config):
     assert len(lines) == 1, res.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["world_size"] == 1 and d["backend"].startswith("nccl")
-    assert d["packed_image_identical_on_all_ranks"] is True
+    assert d["packed_image_identical_on_all_ranks"] is True and d["ranks_output_identical"] is True
     assert d["config"]["name"] == config and d["value"] > 1000 and d["higher_is_better"] is True
     assert d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"]
     assert d["roofline"] and 0.05 < d["roofline"]["frac"] < 1.0
+
+
+def _torchrun(nproc, script_args, env_extra, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    return subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_bench_world_size_2_on_one_gpu():
+    """bench.py as the driver launches it for N = 2, except that both ranks share cuda:0 and talk over gloo: every rank-count-
+    dependent line of it runs with world_size 2 — broadcast of the packed image, image checksums, probe-window output digests
+    (`ranks_output_identical`), max-over-ranks timing, the scaling table."""
+    res = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--plan", "fusedh",
+                        "--rnn-cluster", "1", "--no-cpu-baseline", "--prewarm-s", "0.05"],
+                    {"TIP_BENCH_SHARE_GPU": "1", "TIP_BENCH_BACKEND": "gloo"})
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["backend"] == "gloo"
+    assert d["packed_image_identical_on_all_ranks"] is True and d["ranks_output_identical"] is True
+    assert d["config"]["global_batch"] == 512 and len(d["per_rank_ms_per_step"]["all"]) == 2
+    tab = d["extra"]["scaling_table"]
+    assert tab["batch1_per_gpu"]["streams_total"] == 2 and tab["streams8192_total"]["streams_per_gpu"] == 4096
+    assert tab["streams8192_total"]["frames_per_s"] > 1000
+
+
+def test_two_ranks_one_gpu_shards_equal_single_process(tmp_path):
+    """Data flow at world_size 2 with the REAL engine: rank 1 never sees the parameters (only the broadcast image); the two
+    shard outputs concatenate to this process's single-rank run of the whole batch, bit for bit, full and last-row output."""
+    import numpy as np
+    import torch
+    from tip_amd import synth
+    from test_host_cpu import make_model, load_synth
+    B, T = 37, 40
+    res = _torchrun(2, [os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(tmp_path), str(B), str(T)], {})
+    assert res.returncode == 0, res.stderr[-3000:]
+    ranges = [tuple(np.load(tmp_path / f"r{r}.npy")) for r in range(2)]
+    assert ranges == [(0, 19), (19, 37)]
+    assert int(np.load(tmp_path / "img0.npy")) == int(np.load(tmp_path / "img1.npy"))
+    cfg = synth.PAPER
+    m = make_model(cfg)
+    load_synth(m, cfg, 0)
+    m = m.cuda().eval()
+    m.set_plan("fusedh", rnn_cluster=1)
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=31)
+    with torch.no_grad():
+        y = m(torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()).cpu().numpy()
+        yl = m.forward_last(torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()).cpu().numpy()
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(2)]), y)
+    assert np.array_equal(np.concatenate([np.load(tmp_path / f"yl{r}.npy") for r in range(2)]), yl)

@@ -245,7 +245,7 @@ int tip_combine_sequence(const double* imu, const double* s, const double* c, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     double* la = static_cast<double*>(scratch);
     constexpr size_t comb_lds = (size_t)kCombLdsDoubles * sizeof(double);
-    static bool attr_set = false;
+    static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(combine_imu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)comb_lds) != hipSuccess)

@@ -572,7 +572,7 @@ hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float
     const int wb = (int)(fused_packed_floats(d) * 4), iob = (int)(fused_ih_off(d) * 4);
 #define TIP_FUSED_LAUNCH(A)                                                                                              \
     {                                                                                                                    \
-        static bool attr_set = false;                                                                                    \
+        static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();                                                                                    \
         if (!attr_set) {                                                                                                 \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_kernel<A>),                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);               \
@@ -601,7 +601,7 @@ hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* 
                               int num_cus, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (!fused_supported(d, T) || !fused_has_rnn_ih(d)) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_kernel<8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
@@ -1099,7 +1099,7 @@ hipError_t launch_fused_encoder_h(const Dims& d, const float* fused_w, const flo
                                   const float* keep_mask, float keep_scale, float* xout, float* ih_out, float* hall_sentinel,
                                   int B, int T, int num_cus, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         for (const void* f : {reinterpret_cast<const void*>(fused_encoder_h_kernel<false, false>), reinterpret_cast<const void*>(fused_encoder_h_kernel<true, false>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
@@ -1128,7 +1128,7 @@ hipError_t launch_fused_train_h(const Dims& d, const float* fused_w, const float
                                 int num_cus, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (!fused_supported(d, T) || !fused_has_rnn_ih(d)) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_h_kernel<false, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
@@ -1381,7 +1381,7 @@ hipError_t launch_ffn_bwd(const Dims& d, const FfnBwdArgs& a, int B, int T, int 
     if (B <= 0) return hipSuccess;
     if (!fused_supported(d, T) || (long long)B * T * d.F * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
     constexpr int lds = 3 * fz::RP * fz::LDX * 4;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -1704,7 +1704,7 @@ hipError_t launch_attn_bwd(const Dims& d, const AttnBwdArgs& a, int B, int T, in
     constexpr int lds = (fz::RP * fz::LDX + 8 * 3 * fz::RP * 20) * 4;   // datt_o + per-wave Q / K / dO transposition tiles
     static_assert(8 * 3 * fz::RP * 20 >= 8 * 3 * fz::D, "the LayerNorm partial scratch lives in the per-wave scratch region");
     if ((long long)B * T * 3 * d.D * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;

@@ -728,7 +728,7 @@ hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const floa
                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, int B,
                                  int num_cus, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         for (const void* f : {reinterpret_cast<const void*>(fused_encoder2_kernel<false>), reinterpret_cast<const void*>(fused_encoder2_kernel<true>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, f2::LDS_BYTES);
@@ -759,7 +759,7 @@ hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const flo
                                   int B, int num_cus, const Guard& gd, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (!fused2s_fits(B, num_cus)) return hipErrorInvalidValue;       // every workgroup must be resident: partners wait for each other
-    static bool attr_set = false;
+    static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder2s_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f2::LDS_BYTES);
@@ -776,7 +776,7 @@ hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const flo
     {
         // the runtime's own answer to "how many of these workgroups fit on a CU" (what a cooperative launch would check): the
         // 2 * npairs working ones must all be resident (surplus ids leave at once)
-        static int occ = -1;
+        static PerDeviceInt occ_dev; int& occ = occ_dev.cur();
         hipError_t ce = check_coresident(fused_encoder2s_kernel, f2::THREADS, (size_t)f2::LDS_BYTES, 2 * npairs, num_cus, &occ);
         if (ce != hipSuccess) return ce;
     }
@@ -819,7 +819,7 @@ hipError_t launch_pgemm(const float* A, int lda, const float* wfrag, size_t wfra
     if (M <= 0) return hipSuccess;
     if (!pgemm_ok(M, N, K) || wfrag_floats * 4 > 0x7fffffffULL) return hipErrorInvalidValue;
     ++g_pgemm_launches;
-    static bool attr_set = false;
+    static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         for (const void* f : {reinterpret_cast<const void*>(pgemm_kernel<0>), reinterpret_cast<const void*>(pgemm_kernel<1>),
                               reinterpret_cast<const void*>(pgemm_kernel<2>), reinterpret_cast<const void*>(pgemm_kernel<3>)}) {

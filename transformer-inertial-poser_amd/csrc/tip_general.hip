@@ -1243,6 +1243,14 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
 
 size_t rnn_flag_words(int B, int T) { return (size_t)((B + kRnnTile - 1) / kRnnTile) * (size_t)T + 1024; }
 
+// ONE process-wide launch tag for every kernel family that tags the XCC-exchange words of a workspace (rnn_resident_kernel and
+// rnn_rows4_kernel write the same `flags` words): with a counter each, a stale word left by one family could match the other's
+// tag and a wait would be satisfied by a stale XCC id.
+static unsigned next_rnn_launch_tag() {
+    static std::atomic<unsigned> launch_tag{[] { std::random_device rd; return (unsigned)rd(); }()};
+    return launch_tag.fetch_add(1u) & 0x7FFFFFu;   // 23 bits: fits the int kernel argument above the option bits
+}
+
 static int rnn_handoff_mode() {
     static int handoff = -1;
     if (handoff < 0) {
@@ -1268,7 +1276,7 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
     const size_t smem = ((size_t)kRnnTile * (512 + 4) + (size_t)(KSPLIT - 1) * (WAVES / KSPLIT) * 256) * sizeof(float);
     {
         // every member of a cluster must be resident while its partners wait for it: ask the runtime, do not assume
-        static int occ = -1;
+        static PerDeviceInt occ_dev; int& occ = occ_dev.cur();
         hipError_t ce = check_coresident(rnn_resident_kernel<WAVES, KSPLIT, 1>, WAVES * 64, smem, groups * CLUSTER, num_cus, &occ);
         if (ce != hipSuccess) return ce;
     }
@@ -1290,8 +1298,7 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
             if (e != hipSuccess) return e;
         }
         // XCC-id exchange words: tagged with a per-launch number instead of being zeroed (see the kernel)
-        static std::atomic<unsigned> launch_tag{[] { std::random_device rd; return (unsigned)rd(); }()};
-        const unsigned etag = launch_tag.fetch_add(1u) & 0x7FFFFFu;   // 23 bits: fits the int kernel argument above the option bits
+        const unsigned etag = next_rnn_launch_tag();
         static int trace = -1;
         if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
         static int prepoll_env = -1;   // TIP_RNN_PREPOLL=0: no arrival probe before the tile pull (measurement)
@@ -1317,7 +1324,7 @@ template <int NT>
 static hipError_t launch_rnn_rows4_nt(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T, int ntiles,
                                       int groups, long long hb, const Guard& gd, hipStream_t s, const float* gate, unsigned etag, int num_cus) {
     constexpr int smem = 2 * NT * kQ4Rows * kQ4LD * (int)sizeof(float);
-    static bool attr_set = false;
+    static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         for (const void* f : {reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, false>), reinterpret_cast<const void*>(rnn_rows4_kernel<NT, true, false>),
                               reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, true>)}) {
@@ -1326,7 +1333,7 @@ static hipError_t launch_rnn_rows4_nt(const float* ih, const float* whh_frag, fl
         }
         attr_set = true;
     }
-    static int occ = -1;   // every member of a cluster must be resident while its partners wait for it: ask the runtime
+    static PerDeviceInt occ_dev; int& occ = occ_dev.cur();   // every member of a cluster must be resident while its partners wait for it: ask the runtime
     hipError_t ce = check_coresident(rnn_rows4_kernel<NT, false, false>, 512, smem, groups * kQ4Cluster, num_cus, &occ);
     if (ce != hipSuccess) return ce;
     static int trace = -1, abl = -1;
@@ -1357,8 +1364,7 @@ static hipError_t launch_rnn_rows4(const float* ih, const float* whh_frag, float
         hipError_t e = hipMemsetAsync(hall, 0xFF, (size_t)hb, s);   // every word = kRnnSentinel
         if (e != hipSuccess) return e;
     }
-    static std::atomic<unsigned> launch_tag{[] { std::random_device rd; return (unsigned)rd(); }()};
-    const unsigned etag = launch_tag.fetch_add(1u) & 0x7FFFFFu;
+    const unsigned etag = next_rnn_launch_tag();
     // tiles a cluster advances together: as many as it owns, up to kQ4Tiles (3 -> 4: the pad tile is out of range and multiplies zeros)
     if (tpg <= 1) return launch_rnn_rows4_nt<1>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
     if (tpg == 2) return launch_rnn_rows4_nt<2>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);

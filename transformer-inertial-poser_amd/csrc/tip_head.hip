@@ -273,14 +273,13 @@ hipError_t launch_head_ksplit(const float* A, long long lda, const float* wfrag,
     if (lda * 4 > 0x7fffffffLL || ((long long)(M - 1) * lda + K) * 4 > 0xffffffffLL || (long long)M * ldy * 4 > 0x7fffffffLL)
         return hipErrorInvalidValue;
     const unsigned a_bytes = (unsigned)(((long long)(M - 1) * lda + K) * 4);
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    static bool attr_done[2][64] = {};
+    hipError_t e = hipSuccess;
+    static PerDeviceFlag attr_flag[2];
     auto prep = [&](const void* fn, int slot) -> hipError_t {
-        if (dev >= 0 && dev < 64 && attr_done[slot][dev]) return hipSuccess;
+        bool& done = attr_flag[slot].cur();
+        if (done) return hipSuccess;
         hipError_t e2 = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, hd::LDS_BYTES);
-        if (e2 == hipSuccess && dev >= 0 && dev < 64) attr_done[slot][dev] = true;
+        if (e2 == hipSuccess) done = true;
         return e2;
     };
     static const bool trace = getenv("TIP_HEAD_TRACE") && getenv("TIP_HEAD_TRACE")[0] == '1';

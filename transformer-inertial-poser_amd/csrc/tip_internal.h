@@ -168,6 +168,24 @@ __device__ __forceinline__ void guard_report(unsigned* err) {
     if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Launch-side caches are PER DEVICE, not per process: a process may hold one handle per GPU (include/tip_hip.h), and a
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) or an occupancy answer obtained on one device says nothing about the next.
+constexpr int kMaxDevices = 64;
+inline int tip_cur_device() {
+    int dv = 0;
+    if (hipGetDevice(&dv) != hipSuccess || dv < 0 || dv >= kMaxDevices) dv = 0;
+    return dv;
+}
+struct PerDeviceFlag {
+    bool v[kMaxDevices] = {};
+    bool& cur() { return v[tip_cur_device()]; }
+};
+struct PerDeviceInt {
+    int v[kMaxDevices];
+    PerDeviceInt() { for (int& x : v) x = -1; }
+    int& cur() { return v[tip_cur_device()]; }
+};
+
 // cooperating kernels need `grid` workgroups resident at once: checked against the runtime's own occupancy answer for THIS
 // kernel / block size / dynamic LDS (what hipLaunchCooperativeKernel checks, without its 15-19 us per launch); cached.
 template <typename K>

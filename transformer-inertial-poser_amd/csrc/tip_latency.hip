@@ -618,7 +618,7 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
     hipLaunchKernelGGL((lat_ln_gemm_kernel<false, false>), dim3(32, B), dim3(256), 0, s, fused_w, wbytes, xa, pg, pb, (int)(ih_off * 4),
                        (int)(ih_off + (size_t)R * D), ihb, R, (float*)nullptr, T);
     {
-        static int occ = -1;   // the 4 workgroups of every stream's cluster must be resident together
+        static PerDeviceInt occ_dev; int& occ = occ_dev.cur();   // the 4 workgroups of every stream's cluster must be resident together
         hipError_t ce = check_coresident(rnn_gemv_kernel, 512, (size_t)0, 4 * B, num_cus, &occ);
         if (ce != hipSuccess) return ce;
     }

@@ -400,7 +400,7 @@ static hipError_t lin_launch(const TG& g, const float* wfrag, hipStream_t s) {
     if (use_pg < 0) use_pg = (getenv("TIP_TRAIN_PGEMM") && getenv("TIP_TRAIN_PGEMM")[0] == '0') ? 0 : 1;
     if (!use_pg || !wfrag || !panel_ok(g.mm, g.nn, g.kva) || g.kva != g.kvb || (long long)g.nn * g.kva * 4 > 0x7fffffffLL)
         return tgemm16_launch(g, s);
-    static bool attr_set = false;
+    static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pgemm_tg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            pg::LDS_BYTES);
@@ -701,7 +701,8 @@ static int dw_choose_splits(int tiles, int slots, int M, long long per_total, si
 }
 
 static hipError_t dw_set_attrs() {
-    static bool done = false;
+    static PerDeviceFlag done_flag;
+    bool& done = done_flag.cur();
     if (done) return hipSuccess;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwgemm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, dw_lds_bytes<1>());
     if (e == hipSuccess)
