@@ -89,3 +89,26 @@ def test_b8192_auto_vs_oracle_and_shards():
     yo = oracle.forward(cfg, w, x_imu[sel], x_s[sel], dtype=np.float64)
     e = np.abs(y[torch.tensor(sel).cuda()].cpu().numpy() - yo).max()
     assert e < TOL_TIGHT, e
+
+
+def test_batch_beyond_the_32bit_descriptor_limit_is_chunked():
+    """B * T * widest row * 4 bytes >= 2^31 (B > 13 107 at T = 40) is beyond what one tip_forward call addresses
+    (TIP_ERR_UNSUPPORTED_CONFIG); the reference accepts any batch, so the host runs it in chunks — bit-identical to running the
+    pieces by hand, because streams are independent."""
+    m, _ = _gpu_model(0)
+    m.set_plan("auto")
+    B = 13107 + 150
+    x_imu, x_s = synth.make_inputs(synth.PAPER, 300, 40, seed=77)
+    reps = (B + 299) // 300
+    xi = torch.tensor(np.tile(x_imu, (reps, 1, 1))[:B]).cuda()
+    xs = torch.tensor(np.tile(x_s, (reps, 1, 1))[:B]).cuda()
+    n0 = m.hip_forward_count()
+    with torch.no_grad():
+        yl = m.forward_last(xi, xs)
+        assert m.hip_forward_count() == n0 + 2, "expected two chunks"
+        a, b = m.forward_last(xi[:13107], xs[:13107]), m.forward_last(xi[13107:], xs[13107:])
+    torch.cuda.synchronize()
+    assert yl.shape == (B, 131) and bool(torch.isfinite(yl).all())
+    assert torch.equal(yl, torch.cat([a, b]))
+    assert torch.equal(yl[:300], yl[300:600])          # the same windows, 300 streams further on
+    m.release_buffers()

@@ -471,6 +471,37 @@ def test_cluster_handoffs_under_uneven_load():
                 assert torch.equal(y, ref), (plan, B, it)
 
 
+def test_two_forwards_in_flight_on_two_streams():
+    """Two forwards of the AUTO plan (cooperating RNN clusters) issued back to back on two HIP streams, with no host
+    synchronisation in between, 40 times over: the library serialises them on the device (CoopSerial, tip_internal.h) — without
+    that each could hold half of the CUs and starve the other's cluster partners (a ~1 s spin, NaN poison, TipHandoffError).
+    Results are bit-identical to the single-stream run, and two module instances (two handles) are serialised as well."""
+    cfg = synth.PAPER
+    m, _ = _gpu_model(cfg, 0)
+    m2, _ = _gpu_model(cfg, 0)
+    m.set_plan("auto")
+    m2.set_plan("auto")
+    xa = [torch.tensor(v).cuda() for v in synth.make_inputs(cfg, 256, 40, seed=61)]
+    xb = [torch.tensor(v).cuda() for v in synth.make_inputs(cfg, 200, 40, seed=62)]
+    with torch.no_grad():
+        ya0, yb0 = m(*xa).clone(), m(*xb).clone()
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        for it in range(40):
+            mb = m2 if it % 2 else m
+            with torch.cuda.stream(s1):
+                ya = m(*xa)
+            with torch.cuda.stream(s2):
+                yb = mb(*xb)
+            if it % 8 == 7:
+                torch.cuda.synchronize()
+                assert torch.equal(ya, ya0) and torch.equal(yb, yb0), it
+        torch.cuda.synchronize()
+        assert torch.equal(ya, ya0) and torch.equal(yb, yb0)
+    m.check_handoffs()
+    m2.check_handoffs()
+
+
 @pytest.mark.parametrize("D,H,F,L,R,with_rnn,acc,B,T", [
     (64, 8, 48, 1, 64, True, True, 3, 5),       # d_head 8, narrow FFN, one layer
     (128, 4, 320, 2, 192, True, True, 5, 13),    # d_head 32 (attention scale applied in-kernel, not folded)

@@ -5,6 +5,7 @@
 
 #include <new>
 
+#include <mutex>
 #include "tip_internal.h"
 
 using namespace tip;
@@ -202,6 +203,41 @@ static hipError_t linear_gemm(const float* P, const tip::PackedLinear& p, const 
         return tip::launch_pgemm(A, lda, P + p.f_off, (size_t)p.N * p.K, P + p.b_off, res, ldres, C, ldc, M, p.N, p.K, flags, s);
     return tip::launch_gemm(A, lda, P + p.w_off, p.Kpad, P + p.b_off, res, ldres, C, ldc, M, p.N, p.Npad, flags, s);
 }
+
+namespace tip {
+namespace {
+struct DevSerialState {
+    std::mutex mu;
+    hipStream_t last = nullptr;
+    bool have = false, multi = false;
+    hipEvent_t ev = nullptr;
+};
+DevSerialState g_serial[kMaxDevices];
+}  // namespace
+
+CoopSerial::CoopSerial(hipStream_t s) : dev(tip_cur_device()), stream(s), status(hipSuccess) {
+    DevSerialState& st = g_serial[dev];
+    st.mu.lock();
+    if (st.have && st.last != s) {
+        if (!st.multi) {
+            // first stream switch on this device: there is no event behind the previous forward yet — drain the device once
+            status = hipDeviceSynchronize();
+            if (status == hipSuccess) status = hipEventCreateWithFlags(&st.ev, hipEventDisableTiming);
+            if (status == hipSuccess) st.multi = true;
+        } else {
+            status = hipStreamWaitEvent(s, st.ev, 0);
+        }
+    }
+}
+
+CoopSerial::~CoopSerial() {
+    DevSerialState& st = g_serial[dev];
+    if (st.multi) (void)hipEventRecord(st.ev, stream);
+    st.last = stream;
+    st.have = true;
+    st.mu.unlock();
+}
+}  // namespace tip
 
 extern "C" {
 
@@ -588,6 +624,8 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if (!workspace || reinterpret_cast<uintptr_t>(workspace) % 256 || workspace_bytes < ws.total_bytes)
         return TIP_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    CoopSerial serial(s);   // forwards of different streams do not overlap on the device (cooperating kernels)
+    if (serial.status != hipSuccess) return fail_hip(h, serial.status, "stream serialisation");
     const float* P = h->packed_dev;
     const PackedLayout& L = h->lay;
     float* W0 = static_cast<float*>(workspace);

@@ -1360,6 +1360,9 @@ static hipError_t launch_rnn_rows4(const float* ih, const float* whh_frag, float
     const int tpg = (ntiles + groups - 1) / groups;                          // tiles per cluster
     const long long hb = (long long)B * T * 512 * 4;
     if (hb > 0x7fffffffLL) return hipErrorInvalidValue;
+    // the kernel forms (tile * 4 + pad row) * row bytes in 32-bit unsigned arithmetic for up to 7 rows past the batch: those
+    // offsets must stay above the descriptor's range WITHOUT wrapping back into it (a window of > 149 k frames would)
+    if ((long long)(B + 7) * T * 512 * 4 > 0xffffffffLL) return hipErrorInvalidValue;
     if (!hall_armed) {
         hipError_t e = hipMemsetAsync(hall, 0xFF, (size_t)hb, s);   // every word = kRnnSentinel
         if (e != hipSuccess) return e;

@@ -186,6 +186,23 @@ struct PerDeviceInt {
     int& cur() { return v[tip_cur_device()]; }
 };
 
+// Forwards of different HIP streams are SERIALISED on the device.  The default plans launch cooperating kernels (RNN clusters,
+// the latency plan's GEMV cluster, the opt-in pair-split encoder) whose members must all be resident at once; check_coresident
+// checks one launch against an EMPTY GPU, so two forwards in flight on two streams could each hold half of the CUs and starve
+// the other's partners (a ~1 s spin, NaN poison, TIP_ERR_HANDOFF).  Every entry point that launches such kernels brackets its
+// launches with this guard: the first time a second stream shows up on a device the device is drained once, from then on the
+// new stream waits on an event recorded behind the previous forward (one hipEventRecord per forward, only in processes that
+// really use several streams).  A forward fills the GPU by itself: nothing is lost by not overlapping two of them.
+struct CoopSerial {
+    int dev;
+    hipStream_t stream;
+    hipError_t status;      // hipSuccess, or what the wait / drain returned (the caller reports it)
+    explicit CoopSerial(hipStream_t s);
+    ~CoopSerial();
+    CoopSerial(const CoopSerial&) = delete;
+    CoopSerial& operator=(const CoopSerial&) = delete;
+};
+
 // cooperating kernels need `grid` workgroups resident at once: checked against the runtime's own occupancy answer for THIS
 // kernel / block size / dynamic LDS (what hipLaunchCooperativeKernel checks, without its 15-19 us per launch); cached.
 template <typename K>

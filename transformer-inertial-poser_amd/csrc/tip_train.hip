@@ -1398,6 +1398,8 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     const TrainSaved L = saved_layout(d, B, T);
     if (reinterpret_cast<uintptr_t>(saved) % 256 || saved_bytes < L.total * sizeof(float)) return TIP_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    CoopSerial serial(s);   // see tip_internal.h: forwards of different streams do not overlap on the device
+    if (serial.status != hipSuccess) return train_fail(h, serial.status, "stream serialisation");
     float* W = static_cast<float*>(saved);
     const int M = B * T;
     const float* const* rp = params + P_LAYER0 + PL_COUNT * d.L;
@@ -1584,6 +1586,8 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     }
     if (grads_floats < gtot) return TIP_ERR_INVALID_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    CoopSerial serial(s);   // see tip_internal.h: forwards of different streams do not overlap on the device
+    if (serial.status != hipSuccess) return train_fail(h, serial.status, "stream serialisation");
     g_tgemm_cus = h->num_cus;
     const float* W = static_cast<const float*>(saved);
     float* X = static_cast<float*>(scratch);

@@ -17,12 +17,16 @@ Execution (ROCm tensors, fp32) — what `_dispatch` does:
     out, so they run with that dropout accidentally live) — goes to the HIP training step `tip_train_forward` /
     `tip_train_backward` (`_HipTrainFunction`): dropout drawn from a counter-based hash, activations stashed, every row
     computed.  Call .eval() for deterministic, stash-free inference (StreamingEngine warns when it is handed a
-    .train()-mode model).  Configurations the training kernels do not cover (rnn_hid_size != 512, CPU tensors, fp64,
-    gradients w.r.t. the inputs) run the torch-op composite with the same dropout, with a warning — never the
-    dropout-free inference kernels, so the behaviour does not depend on the configuration.
+    .train()-mode model).  Configurations the training kernels do not cover (rnn_hid_size != 512, fp64, gradients
+    w.r.t. the inputs; CPU tensors only when autograd records) run the torch-op composite with the same dropout, with a
+    warning — never the dropout-free inference kernels, so the behaviour does not depend on the configuration.  A no_grad
+    call on CPU tensors raises in either mode: inference values come from the HIP kernels or not at all.
   * .eval() with autograd on (the runners never enter no_grad): HIP forward wrapped in an autograd.Function whose
     backward, if ever called, recomputes the torch-op composite, so .backward() still works.
-  The handle's workspace / backward scratch are per (device, stream); one module may be driven from several streams.
+  The handle's workspace / backward scratch are per (device, stream) (a small LRU, `release_buffers()` drops them).  A module
+  may be called from several streams, but its forwards do NOT overlap on the device: the default plans launch cooperating
+  kernels that need all of their workgroups resident at once, so the library serialises forwards of different streams (one
+  event wait per stream switch; csrc/tip_internal.h, CoopSerial).  A forward fills the GPU by itself.
 
 Dropout semantics kept from the reference: `nn.Dropout(p)(x)` is constructed inside forward (:73,:77), i.e. it is
 always in training mode, so past_state_dropout / in_dropout are live even under .eval().  The HIP path draws the
@@ -116,6 +120,7 @@ class TF_RNN_Past_State(nn.Module):
         self._workspace = {}             # (device index, stream handle) -> uint8 tensor: calls on different streams never share one
         self._frozen = False
         self._warned_autograd = False
+        self._warned_train_nograd = False
         self._train_scratch = {}         # same keying for the backward scratch
         self.use_hip_training = True     # .train() + autograd on the GPU -> tip_train_forward / tip_train_backward
         self.keep_train_stash = False    # debugging/tests: keep the last activation stash (see train_activation())
@@ -169,6 +174,11 @@ class TF_RNN_Past_State(nn.Module):
         # same function as .eval() and takes the inference kernels below
         if self.training and (needs_grad or self.ENCODER_DROPOUT > 0.0) and self._hip_train_ok(x_imu, x_s):
             # train_model.py:171-196 on the HIP path: forward with saved activations + live encoder dropout, HIP backward
+            if not needs_grad and not self._warned_train_nograd:
+                warnings.warn("tip_amd: .train()-mode call under torch.no_grad() — running the TRAINING forward (encoder dropout "
+                              "p=0.1 live, every row computed, activation stash allocated), as the reference does when .eval() "
+                              "is never called (offline_testing_simple.py:98); call .eval() for the deterministic inference kernels")
+                self._warned_train_nograd = True
             xi = F.dropout(x_imu, self.in_dropout, training=True) if self.in_dropout > 0.0 else x_imu   # :73
             mask = self._draw_keep_mask(x_s)                                                            # :77
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())     # CPU generator: no device sync
@@ -310,16 +320,29 @@ class TF_RNN_Past_State(nn.Module):
     def hip_forward_count(self) -> int:
         return self._handle.forward_count() if self._handle is not None else 0
 
+    MAX_STREAM_BUFFERS = 4   # scratch buffers kept per table (least recently used beyond that are dropped)
+
     @staticmethod
     def _stream_buffer(table: dict, dev, stream: int, nbytes: int) -> torch.Tensor:
-        """The scratch buffer of (device, stream): grown on demand, never shared between streams (two forwards in flight on
-        two streams would otherwise race on it)."""
+        """The scratch buffer of (device, stream): grown on demand, never shared between streams.  The library serialises the
+        forwards of different streams on the device (cooperating kernels: csrc/tip_internal.h, CoopSerial), but a buffer per
+        stream keeps a forward queued on stream B from scribbling over the workspace of one still running on stream A only
+        because of that ordering — it does not depend on it.  The table is a small LRU (short-lived streams — per-request
+        streams, ExternalStream, a destroyed CU-mask stream whose handle value is later recycled — must not pin hundreds of MB
+        for the life of the module); `release_buffers()` drops everything."""
         key = (dev.index, int(stream))
-        buf = table.get(key)
+        buf = table.pop(key, None)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            table[key] = buf
+        table[key] = buf                                  # (re)inserted last = most recently used
+        while len(table) > TF_RNN_Past_State.MAX_STREAM_BUFFERS:
+            table.pop(next(iter(table)))
         return buf
+
+    def release_buffers(self):
+        """Drop every cached workspace / training scratch buffer (they are re-allocated on demand)."""
+        self._workspace.clear()
+        self._train_scratch.clear()
 
     def _forward_hip(self, x_imu, x_s, last_row_only: bool, keep_mask="draw", apply_in_dropout=True):
         if not (x_imu.is_cuda and x_s.is_cuda):
@@ -338,6 +361,20 @@ class TF_RNN_Past_State(nn.Module):
             raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied: got feature widths "
                                f"{x_imu.shape[2]}+{x_s.shape[2]}, in_linear expects {n_imu}+{self.size_s}")
         h = self._ensure_handle()
+        # The kernels address their activations through 32-bit buffer descriptors: B * T * widest row * 4 bytes must stay below
+        # 2^31 (tip_forward returns TIP_ERR_UNSUPPORTED_CONFIG beyond: B > 13 107 at T = 40 for the paper configuration).  Streams
+        # are independent (no op in :60-102 crosses batch elements), so a larger batch is run in chunks — same numbers, one
+        # launch sequence per chunk.  (The past-state keep mask and the input dropout are drawn per chunk, like any two calls.)
+        widest = max(3 * self.tf_in_dim, self.tf_hid_size, self.rnn_hid_size if self.with_rnn else 0, n_imu + self.size_s + 16)
+        max_b = max(1, (2 ** 31 - 1) // (4 * widest * max(T, 1)))
+        if B > max_b:
+            km = None if isinstance(keep_mask, str) else keep_mask
+            parts = []
+            for lo in range(0, B, max_b):
+                hi = min(B, lo + max_b)
+                parts.append(self._forward_hip(x_imu[lo:hi], x_s[lo:hi], last_row_only,
+                                               keep_mask if km is None else km[lo:hi], apply_in_dropout))
+            return torch.cat(parts, dim=0)
         with torch.cuda.device(dev):
             if self._packed_dev is None or self._packed_dev.device != dev or \
                     (not self._frozen and self._packed_key != self._param_key(dev)):
