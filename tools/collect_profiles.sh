@@ -8,7 +8,7 @@ ROUND=${1:-r02}
 OUT=$PWD/gpurun_out/$ROUND
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra"
+BENCH="python $PWD/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extra"
 
 # 1. the default bench line (with cpu_baseline) and the same command under rocprofv3 --kernel-trace --stats
 timeout 600 python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
@@ -19,6 +19,10 @@ for cfg in "256:" "1:--batch 1" "1024:--batch 1024"; do
         > "$OUT/bench_under_rocprof_B$tag.json" 2> /dev/null)
     f=$(find $d -name '*kernel_stats.csv' | head -1)
     [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_bench_B${tag}_T40.csv"
+    # rocprofv3's own averages include the first calls of a cold process (round 2: one 27.9-ms outlier in 13 calls moved the
+    # B = 1024 encoder's average by 5 %): the same trace with the first fifth of every kernel's calls dropped, min / median / avg
+    t=$(find $d -name '*kernel_trace.csv' | head -1)
+    [ -n "$t" ] && python tools/kstats_table.py "$t" > "$OUT/kernel_medians_bench_B${tag}_T40.txt"
     if [ "$tag" = 1 ]; then   # kernel timeline of one single-stream forward (latency plan)
         t=$(find $d -name '*kernel_trace.csv' | head -1)
         [ -n "$t" ] && python tools/timeline.py "$t" lat_in_kernel > "$OUT/timeline_B1.txt" 2> /dev/null

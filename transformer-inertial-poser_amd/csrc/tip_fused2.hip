@@ -117,18 +117,23 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
         WRing2<2> g_in;
         ring2_prefetch<2>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
         // ---- prologue (:63-78) for both windows: U rows 40w + t ------------------------------------------------------
+        // (an OPAQUE copy of the thread index: with the plain one the compiler hoists every per-thread row / column split of
+        // the staging loops and of the IH store epilogue out of the pair loop and carries them — 27 VGPRs — across the whole
+        // kernel, in scratch; recomputing them here costs a few dozen VALU instructions per pair)
+        int tp = tid;
+        asm volatile("" : "+v"(tp));
         float* U = C;
-        for (int i = tid; i < ROWS * LDU; i += THREADS) U[i] = 0.f;
+        for (int i = tp; i < ROWS * LDU; i += THREADS) U[i] = 0.f;
         __syncthreads();
         for (int w = 0; w < nwin; ++w) {
             const float* xi = x_imu + (size_t)(win0 + w) * T * NI;
-            for (int i = tid; i < T * NI; i += THREADS) {
+            for (int i = tp; i < T * NI; i += THREADS) {
                 const int r = i / NI, c = i - r * NI;
                 U[(w * T + r) * LDU + c] = xi[i];
             }
             const float* xs = x_s + (size_t)(win0 + w) * T * S;
             const float* km = keep_mask ? keep_mask + (size_t)(win0 + w) * T * S : nullptr;
-            for (int i = tid; i < T * S; i += THREADS) {
+            for (int i = tp; i < T * S; i += THREADS) {
                 const int r = i / S, c = i - r * S;
                 float v = xs[i];
                 if (v != v) v = 0.f;                  // :65
@@ -328,22 +333,27 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
             gemm_phase2<RB, 4, 16>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
             float* io = ih_out + (size_t)win0 * T * R;   // the two windows are consecutive: rows 0..79 map 1:1
             const int nrows = nwin * T;
+            int le = lane;                               // opaque lane index: store offsets are formed here, not in the prologue
+            asm volatile("" : "+v"(le));
+            const int l15e = le & 15, lge = le >> 4;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const int col = (wave * 4 + n) * 16 + l15;
+                const int col = (wave * 4 + n) * 16 + l15e;
                 const float bv = wts[ih_off_b / 4 + R * D + col];
 #pragma unroll
                 for (int r = 0; r < RB; ++r)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int row = r * 16 + lg * 4 + e;
+                        const int row = r * 16 + lge * 4 + e;
                         if (row < nrows) io[(size_t)row * R + col] = acc[r][n][e] + bv;
                     }
             }
         }
         if (hall_sentinel) {
             uint4* hp = reinterpret_cast<uint4*>(hall_sentinel + (size_t)win0 * T * R);
-            for (int i = tid; i < nwin * T * (R / 4); i += THREADS) hp[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            int ts = tid;
+            asm volatile("" : "+v"(ts));
+            for (int i = ts; i < nwin * T * (R / 4); i += THREADS) hp[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         }
         __syncthreads();
     }
