@@ -257,6 +257,51 @@ def sustained_pass(step, ms_est, seconds):
             "sclk_ghz_s_memtime": ghz, "probe_xcc": [int(p[2]), int(p[6])], "sclk_mhz_rocm_smi": smi}
 
 
+def train_step_times(cfg, dev, B=256, T=40, steps=20, warmup=5):
+    import warnings
+    m = build_model(cfg, 0, load=True).to(dev).train()
+    m.ENCODER_DROPOUT = 0.1
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    x_imu, x_s = synth.make_inputs(cfg, 64, T, seed=5)
+    xi = torch.tensor(np.tile(x_imu, (B // 64, 1, 1))).to(dev)
+    xs = torch.tensor(np.nan_to_num(np.tile(x_s, (B // 64, 1, 1)))).to(dev)
+    tgt = torch.randn(B, T, cfg["size_s"], device=dev)
+
+    def fwd():
+        return m(xi, xs)
+
+    def fb():
+        for p in m.parameters():
+            p.grad = None
+        fwd().backward(tgt)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = ((fwd() - tgt) ** 2).mean()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+
+    res = {"batch": B, "T": T, "encoder_dropout": 0.1, "optimizer": "AdamW + clip_grad_norm_ (torch)"}
+    n0 = m.hip_forward_count()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, fn in (("forward_ms", fwd), ("fwd_bwd_ms", fb), ("step_ms", step)):
+            for _ in range(warmup):
+                fn()
+            torch.cuda.synchronize()
+            res[name] = timed_loop(fn, steps)
+    assert m.hip_forward_count() > n0, "the HIP training kernels did not run"
+    fl = synth.flops_per_window(cfg, T)
+    res["fwd_bwd_tflops"] = 3 * B * fl / res["fwd_bwd_ms"] / 1e9
+    res["fwd_bwd_frac_of_fp32_mfma_peak"] = res["fwd_bwd_tflops"] / PEAK_FP32_MFMA_TFLOPS
+    res["windows_per_s_step"] = B / res["step_ms"] * 1e3
+    m.check_handoffs()
+    del m, opt
+    torch.cuda.empty_cache()
+    return res
+
+
 def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
     """Every other BASELINE.json configuration on this run's clock (N = 1).  A few seconds each."""
     out = {}
@@ -331,6 +376,13 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
                                               "60 frames of a cold process (clock ramp + first-use kernel loads), not the loop")
     except Exception as e:
         out["stream1_closed_loop"] = {"error": f"{type(e).__name__}: {e}"}
+    # -- row a14 / f-2: the training-mode model call and its backward (train_model.py:171-196) at the reference's batch size,
+    #    HIP kernels in both directions, encoder dropout p = 0.1 live; forward, forward+backward (3x the forward FLOPs) and the
+    #    whole step with clip + AdamW
+    try:
+        out["train_b256"] = train_step_times(cfg, dev)
+    except Exception as e:
+        out["train_b256"] = {"error": f"{type(e).__name__}: {e}"}
     # -- configs[4] share: scaled model, B=512, T=80 (random-init weights on the device)
     try:
         sc = synth.SCALED

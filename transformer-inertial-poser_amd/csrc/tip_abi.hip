@@ -624,6 +624,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if (!workspace || reinterpret_cast<uintptr_t>(workspace) % 256 || workspace_bytes < ws.total_bytes)
         return TIP_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const int cus = effective_cus(h->num_cus, s);   // the stream's CU mask counts, not the device's CU total
     CoopSerial serial(s);   // forwards of different streams do not overlap on the device (cooperating kernels)
     if (serial.status != hipSuccess) return fail_hip(h, serial.status, "stream serialisation");
     const float* P = h->packed_dev;
@@ -656,13 +657,13 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         // two windows per workgroup (80 rows = 5 full MFMA row blocks, 1.065 ms per round of 2 x #CUs windows): whichever
         // needs less time for this batch.  (The pair-split plan, 0.605 ms per round with 8 hand-offs per pair, lost its
         // place to the hybrid kernel and stays selectable for measurement.)
-        const long long cus = h->num_cus;
-        const long long rounds_h = (B + cus - 1) / cus, rounds_2 = ((B + 1) / 2 + cus - 1) / cus;
+        const long long cusl = cus;
+        const long long rounds_h = (B + cusl - 1) / cusl, rounds_2 = ((B + 1) / 2 + cusl - 1) / cusl;
         plan = (fused2_supported(d, T) && rounds_2 * 1065 < rounds_h * 553) ? TIP_PLAN_FUSED2 : TIP_PLAN_FUSEDH;
     }
     if ((plan == TIP_PLAN_FUSED || plan == TIP_PLAN_FUSEDH) && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
-    if (plan == TIP_PLAN_FUSED2S && !(fused2_supported(d, T) && fused2s_fits(B, h->num_cus) && B <= 1024)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (plan == TIP_PLAN_FUSED2S && !(fused2_supported(d, T) && fused2s_fits(B, cus) && B <= 1024)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
 
     float* enc_out = xa;  // encoder output [M, D]
@@ -674,7 +675,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         // auto: spread one 16-window tile over as many CUs as the tile count leaves idle
         const int ntiles = (B + kRnnTile - 1) / kRnnTile;
         rnn_cluster = 16;
-        while (rnn_cluster > 1 && ntiles * rnn_cluster > h->num_cus) rnn_cluster >>= 1;
+        while (rnn_cluster > 1 && ntiles * rnn_cluster > cus) rnn_cluster >>= 1;
         // rnn_hidden 512: four-row tiles on 4-workgroup clusters at every batch size (76 us at B = 256 against 114 for the best
         // 16-row variant; tools/rnn_variants2.py).  TIP_RNN_ROWS4=0 keeps the 16-row kernels (measurement).
         static const bool rows4 = !(getenv("TIP_RNN_ROWS4") && getenv("TIP_RNN_ROWS4")[0] == '0');
@@ -683,33 +684,33 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if (plan == TIP_PLAN_LATENCY) {
         StageScope sc(h, s, "latency_chain");
         TIP_TRY(launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall,
-                                    B, T, h->num_cus, gd, s), "latency_chain");
+                                    B, T, cus, gd, s), "latency_chain");
         rnn_done = true;
     } else if (plan == TIP_PLAN_FUSED2S) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = true;
         hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
         TIP_TRY(launch_fused_encoder2s(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr,
-                                       W0 + ws.xchg, B, h->num_cus, gd, s), "fused_encoder2s");
+                                       W0 + ws.xchg, B, cus, gd, s), "fused_encoder2s");
     } else if (plan == TIP_PLAN_FUSED2) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = true;
         hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
         TIP_TRY(launch_fused_encoder2(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr, B,
-                                      h->num_cus, s), "fused_encoder2");
+                                      cus, s), "fused_encoder2");
     } else if (plan == TIP_PLAN_FUSEDH) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = fused_has_rnn_ih(d);
         hall_armed = ih_done && rnn_uses_sentinel(d, B, T, rnn_cluster);
         TIP_TRY(launch_fused_encoder_h(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, ih_done ? nullptr : xa,
-                                       ih_done ? big : nullptr, hall_armed ? hall : nullptr, B, T, h->num_cus, s),
+                                       ih_done ? big : nullptr, hall_armed ? hall : nullptr, B, T, cus, s),
                 "fused_encoder_h");
     } else if (plan == TIP_PLAN_FUSED) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = fused_has_rnn_ih(d);
         hall_armed = ih_done && rnn_uses_sentinel(d, B, T, rnn_cluster);   // the encoder pre-fills its HALL rows
         TIP_TRY(launch_fused_encoder(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, ih_done ? nullptr : xa,
-                                     ih_done ? big : nullptr, hall_armed ? hall : nullptr, B, T, h->num_cus, s),
+                                     ih_done ? big : nullptr, hall_armed ? hall : nullptr, B, T, cus, s),
                 "fused_encoder");
     } else {
         {
@@ -768,7 +769,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         }
         {
             StageScope sc(h, s, "rnn_recurrence");
-            TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, rnn_cluster, h->num_cus, hall_armed, gd, s),
+            TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, rnn_cluster, cus, hall_armed, gd, s),
                     "rnn_recurrence");
         }
         head_in = hall;
@@ -789,7 +790,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
             static const bool ksplit = !(getenv("TIP_HEAD") && getenv("TIP_HEAD")[0] == 'o');   // TIP_HEAD=old: measurement
             hipError_t he = hipErrorInvalidValue;
             if (ksplit && T % 40 == 0)
-                he = launch_head_ksplit(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, hM, d.S, Kh, last_only, h->num_cus, s);
+                he = launch_head_ksplit(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, hM, d.S, Kh, last_only, cus, s);
             if (he == hipErrorInvalidValue)
                 he = launch_head_gemm(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, hM, d.S, Kh, s);
             TIP_TRY(he, "out_linear");

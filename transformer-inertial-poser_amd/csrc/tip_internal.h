@@ -203,6 +203,20 @@ struct CoopSerial {
     CoopSerial& operator=(const CoopSerial&) = delete;
 };
 
+// CUs the launches of a stream can actually use: the device's count, or the population of the stream's CU mask
+// (hipExtStreamCreateWithCUMask — the co-tenant / partitioned-GPU case).  Plan selection (rounds of #CUs windows), grid sizes and
+// above all the co-residency bound of the cooperating kernels (clusters <= CUs / members) are computed from THIS number.
+inline int effective_cus(int device_cus, hipStream_t s) {
+    uint32_t mask[32] = {0};
+    if (hipExtStreamGetCUMask(s, 32, mask) != hipSuccess) {
+        (void)hipGetLastError();
+        return device_cus;
+    }
+    int c = 0;
+    for (int i = 0; i < device_cus && i < 32 * 32; ++i) c += (mask[i >> 5] >> (i & 31)) & 1u;
+    return (c > 0 && c < device_cus) ? c : device_cus;
+}
+
 // cooperating kernels need `grid` workgroups resident at once: checked against the runtime's own occupancy answer for THIS
 // kernel / block size / dynamic LDS (what hipLaunchCooperativeKernel checks, without its 15-19 us per launch); cached.
 template <typename K>

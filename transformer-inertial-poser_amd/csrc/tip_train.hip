@@ -1398,6 +1398,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     const TrainSaved L = saved_layout(d, B, T);
     if (reinterpret_cast<uintptr_t>(saved) % 256 || saved_bytes < L.total * sizeof(float)) return TIP_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const int ecus = effective_cus(h->num_cus, s);   // the stream's CU mask counts (co-residency of the recurrence's clusters)
     CoopSerial serial(s);   // see tip_internal.h: forwards of different streams do not overlap on the device
     if (serial.status != hipSuccess) return train_fail(h, serial.status, "stream serialisation");
     float* W = static_cast<float*>(saved);
@@ -1448,10 +1449,10 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         const Drop dr = make_drop(p_drop, seed, 0);
         tr.seed = seed; tr.thresh = dr.thresh; tr.scale = dr.scale;
         // the encoder also pre-fills its windows' HALL rows with the recurrence's hand-off sentinel (saves a 21-MB memset)
-        hall_armed = rnn_uses_sentinel(d, B, T, auto_cluster(B, h->num_cus));
+        hall_armed = rnn_uses_sentinel(d, B, T, auto_cluster(B, ecus));
         static const bool padded = getenv("TIP_TRAIN_FWD_PADDED") != nullptr;   // A/B runs only (tools/train_bench.py)
         TT((padded ? launch_fused_train : launch_fused_train_h)(d, W + L.fused_img, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f,
-                                                                 W + L.ih, hall_armed ? W + L.hall : nullptr, tr, B, T, h->num_cus, s),
+                                                                 W + L.ih, hall_armed ? W + L.hall : nullptr, tr, B, T, ecus, s),
            "train_fused_encoder");
     } else {
     {
@@ -1552,8 +1553,8 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         TT(lin_launch(g, L.wih_f ? W + L.wih_f : nullptr, s), "train_rnn_ih");
     }
     }   // layer-by-layer path
-    TT(launch_rnn(d, W + L.ih, W + L.whh_f, W + L.hall, reinterpret_cast<unsigned*>(W + L.flags), B, T, auto_cluster(B, h->num_cus),
-                  h->num_cus, hall_armed, h->guard(), s), "train_rnn");
+    TT(launch_rnn(d, W + L.ih, W + L.whh_f, W + L.hall, reinterpret_cast<unsigned*>(W + L.flags), B, T, auto_cluster(B, ecus),
+                  ecus, hall_armed, h->guard(), s), "train_rnn");
     {
         TG g = tg_base(W + L.hall, d.R, rp[PR_LIN_W], d.R, y, d.S, M, d.S, d.R);
         g.bias = rp[PR_LIN_B];
@@ -1593,7 +1594,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     float* X = static_cast<float*>(scratch);
     const int M = B * T;
     const int Sp = round_up(d.S, 16);
-    const int ncu = h->num_cus;
+    const int ncu = effective_cus(h->num_cus, s);   // the stream's CU mask counts (co-residency of the recurrence's clusters)
     const int rbase = P_LAYER0 + PL_COUNT * d.L;
     float* part = X + S.part;
     float* colpart = X + S.colpart;
