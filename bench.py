@@ -380,7 +380,8 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
     #    HIP kernels in both directions, encoder dropout p = 0.1 live; forward, forward+backward (3x the forward FLOPs) and the
     #    whole step with clip + AdamW
     try:
-        out["train_b256"] = train_step_times(cfg, dev)
+        with torch.enable_grad():            # (the extras run inside the caller's no_grad block)
+            out["train_b256"] = train_step_times(cfg, dev)
     except Exception as e:
         out["train_b256"] = {"error": f"{type(e).__name__}: {e}"}
     # -- configs[4] share: scaled model, B=512, T=80 (random-init weights on the device)
