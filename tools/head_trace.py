@@ -23,3 +23,17 @@ for wg, o in ((0, 0), (100, 16)):
     # s_memtime ticks at 100 MHz on gfx950 (REFCLK) — report both raw ticks and us
     tt = t[o:o + 16]
     print(f"workgroup {wg}: raw", [int(v - tt[0]) for v in tt])
+
+wg = (ctypes.c_ulonglong * 512)()
+assert tlib.load().tip_debug_read_head_wg(wg, 512) == 0
+w = np.array(wg[:], dtype=np.float64).reshape(256, 2) / 100.0       # us
+n = min(256, (B * 40 + 39) // 40)
+w = w[:n]
+t0 = w[:, 0].min()
+dur = w[:, 1] - w[:, 0]
+print(f"all {n} workgroups (s_memrealtime): entries spread {w[:, 0].max() - t0:.2f} us, first entry -> last exit {w[:, 1].max() - t0:.2f} us")
+print(f"  per-workgroup lifetime: min {dur.min():.2f}  median {np.median(dur):.2f}  p90 {np.percentile(dur, 90):.2f}  max {dur.max():.2f} us")
+order = np.argsort(-dur)[:8]
+print("  slowest workgroups (id, xcd = id % 8, lifetime):", [(int(i), int(i) % 8, round(float(dur[i]), 2)) for i in order])
+byx = [float(np.median(dur[np.arange(n) % 8 == x])) for x in range(8)]
+print("  median lifetime per XCD:", [round(v, 2) for v in byx])

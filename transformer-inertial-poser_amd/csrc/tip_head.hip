@@ -58,6 +58,7 @@ __device__ __forceinline__ float hd_tail_reduce(const hf4& v) {
 // measurement only (TIP_HEAD_TRACE=1): s_memtime stamps of wave 0 of workgroups 0 and 100 — [16 wg + 0] entry, [1] weight loads
 // issued, [2 + i] after the barrier of tile i (i < 12), [15] exit
 __device__ unsigned long long g_hd_trace[32];
+__device__ unsigned long long g_hd_wg[2 * 1024];   // [wg][entry, exit] in s_memrealtime ticks (100 MHz, device-wide counter)
 #define HD_STAMP(slot) do { if (TRACE && (blockIdx.x == 0 || blockIdx.x == 100) && threadIdx.x == 0) \
         g_hd_trace[(blockIdx.x ? 16 : 0) + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(hd::THREADS) void head_ksplit_kernel(const float* _
     int g = blockIdx.x;
     if (g >= ngroups) return;
     HD_STAMP(0);
+    if (TRACE && threadIdx.x == 0 && blockIdx.x < 1024) g_hd_wg[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     int nstamp = 2;
     load_a(acur, g, 0);
     // the wave's slice of the weight, in the order the MFMAs consume it (k-block major)
@@ -256,6 +258,15 @@ __global__ __launch_bounds__(hd::THREADS) void head_ksplit_kernel(const float* _
         if (wave == WAVES - 1) c8_reduce(lt, buf ^ 1, prev_row0);
     }
     HD_STAMP(15);
+    if (TRACE) {
+        __syncthreads();
+        if (threadIdx.x == 0 && blockIdx.x < 1024) g_hd_wg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+extern "C" int tip_debug_read_head_wg(unsigned long long* out, int n) {
+    if (!out || n < 0 || n > 2048) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hd_wg), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
 }
 
 extern "C" int tip_debug_read_head_trace(unsigned long long* out, int n) {
