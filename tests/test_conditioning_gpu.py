@@ -22,7 +22,8 @@ from test_host_cpu import make_model
 
 pytestmark = pytest.mark.gpu
 
-PLANS = ["latency", "fusedh", "fused", "fused2", "general"]       # AUTO's candidates for the paper configuration
+PLANS = ["latency", "fusedh", "fused", "fused2", "general",      # AUTO's candidates for the paper configuration
+         "fused16"]                                                 # + the exploratory split-fp16 plan, held to the same bar
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

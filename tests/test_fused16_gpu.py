@@ -1,0 +1,82 @@
+"""The exploratory split-fp16 plan ("fused16", csrc/tip_s16.hip: fp32 GEMM operands emulated as hi + lo fp16 on the f16 matrix cores,
+fp32 accumulation) against the SAME bar as every other plan: golden vectors and oracle shapes ride in tests/test_hip_parity.py
+(ALL_PLANS), the conditioning sweep in tests/test_conditioning_gpu.py; here the properties — batch independence, last row, T = 1..40
+causality, keep-mask, determinism — and the error relative to the fp32-MFMA plan."""
+import numpy as np
+import pytest
+import torch
+
+from tip_amd import synth
+from oracle import oracle
+from test_host_cpu import make_model, load_synth
+
+pytestmark = pytest.mark.gpu
+TOL_TIGHT = 2e-5
+
+
+def _gpu_model(seed):
+    m = make_model(synth.PAPER)
+    w = load_synth(m, synth.PAPER, seed)
+    return m.cuda().eval(), w
+
+
+def _fwd(m, xi, xs, last=False):
+    n0 = m.hip_forward_count()
+    with torch.no_grad():
+        y = (m.forward_last if last else m)(torch.as_tensor(xi).cuda(), torch.as_tensor(xs).cuda())
+    torch.cuda.synchronize()
+    assert m.hip_forward_count() == n0 + 1
+    return y.cpu().numpy()
+
+
+@pytest.mark.parametrize("B,T", [(1, 40), (3, 17), (65, 40), (256, 40), (300, 33)])
+def test_fused16_vs_oracle_and_properties(B, T):
+    cfg = synth.PAPER
+    m, w = _gpu_model(2)
+    m.set_plan("fused16")
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=900 + B + T, nan_frac=0.02)
+    y = _fwd(m, x_imu, x_s)
+    assert np.isfinite(y).all()
+    assert np.array_equal(y, _fwd(m, x_imu, x_s)), "run-to-run difference"
+    n = min(B, 6)
+    yo = oracle.forward(cfg, w, x_imu[:n], x_s[:n], dtype=np.float64)
+    e16 = np.abs(y[:n] - yo).max()
+    assert e16 < TOL_TIGHT, e16
+    m.set_plan("fusedh")
+    e32 = np.abs(_fwd(m, x_imu[:n], x_s[:n]) - yo).max()
+    m.set_plan("fused16")
+    assert e16 < 3.0 * e32 + 1e-6, (e16, e32)          # not a less accurate implementation than the fp32-MFMA plan
+    assert np.array_equal(_fwd(m, x_imu, x_s, last=True), y[:, -1])
+    if B > 8:
+        sel = np.array([0, 1, B // 2, B - 1])
+        assert np.array_equal(_fwd(m, x_imu[sel], x_s[sel]), y[sel]), "a stream's result depends on its batch neighbours"
+
+
+def test_fused16_causality_T_1_to_40():
+    cfg = synth.PAPER
+    m, w = _gpu_model(0)
+    m.set_plan("fused16")
+    x_imu, x_s = synth.make_inputs(cfg, 2, 40, seed=9)
+    yfull = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
+    for T in range(1, 41):
+        yl = _fwd(m, x_imu[:, :T], x_s[:, :T], last=True)
+        assert np.abs(yl - yfull[:, T - 1]).max() < TOL_TIGHT, T
+
+
+def test_fused16_keep_mask_golden(golden):
+    from tip_amd import lib as tlib
+    case = golden["paper_mask_s0_B2_T40"]
+    m, _ = _gpu_model(0)
+    h = m._ensure_handle()
+    m.refresh_packed(torch.device("cuda:0"))
+    xi, xs = torch.tensor(case["x_imu"]).cuda(), torch.tensor(case["x_s"]).cuda()
+    mask = torch.tensor(case["mask"]).cuda()
+    p = float(case["p"][0])
+    y = torch.zeros(2, 40, 131, device="cuda")
+    ws = torch.empty(h.workspace_bytes(2, 40), dtype=torch.uint8, device="cuda")
+    h.set_option(tlib.TIP_OPT_PLAN, tlib.TIP_PLAN_FUSED16)
+    h.forward(xi.data_ptr(), xs.data_ptr(), y.data_ptr(), 2, 40, tlib.TIP_FWD_KEEP_MASK, mask.data_ptr(), 1.0 / (1.0 - p), ws.data_ptr(),
+              ws.numel(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.abs(y.cpu().numpy() - case["y64"]).max() < TOL_TIGHT
+    h.set_option(tlib.TIP_OPT_PLAN, tlib.TIP_PLAN_AUTO)

@@ -80,6 +80,8 @@ void build_layout(tip_handle* h) {
     }
     L.fused_floats = fused_packed_floats(d);
     L.fused_off = c.take(L.fused_floats);
+    L.s16_floats = s16_packed_floats(d);
+    L.s16_off = c.take(L.s16_floats);
     L.total_floats = c.off;
 }
 
@@ -327,7 +329,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
     if (!h) return TIP_ERR_INVALID_ARG;
     switch (option) {
         case TIP_OPT_PLAN:
-            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSEDH) return TIP_ERR_INVALID_ARG;
+            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED16) return TIP_ERR_INVALID_ARG;
             h->plan = value;
             return TIP_OK;
         case TIP_OPT_PROFILE:
@@ -471,6 +473,7 @@ int tip_pack_weights(const tip_handle* h, const float* const* t, int n, void* pa
                     }
     }
     if (L.fused_floats) fused_pack(d, t, img + L.fused_off);
+    if (L.s16_floats) s16_pack_host(d, img + L.fused_off, img + L.s16_off);
     return TIP_OK;
 }
 
@@ -551,6 +554,8 @@ int tip_pack_weights_device(const tip_handle* h, const float* const* t, int n, v
     if (L.fused_floats) fused_pack_ops(d, t, L.fused_off, ops);
     if (hipMemsetAsync(packed_dev, 0, L.total_floats * sizeof(float), s) != hipSuccess) return TIP_ERR_HIP;
     if (run_pack_ops(ops, static_cast<float*>(packed_dev), s) != hipSuccess) return TIP_ERR_HIP;
+    if (L.s16_floats && launch_s16_repack(d, static_cast<const float*>(packed_dev) + L.fused_off, static_cast<float*>(packed_dev) + L.s16_off, s) != hipSuccess)
+        return TIP_ERR_HIP;
     return TIP_OK;
 }
 
@@ -665,6 +670,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2S && !(fused2_supported(d, T) && fused2s_fits(B, cus) && B <= 1024)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (plan == TIP_PLAN_FUSED16 && !(s16_supported(d, T) && L.s16_floats)) return TIP_ERR_UNSUPPORTED_CONFIG;
 
     float* enc_out = xa;  // encoder output [M, D]
     bool ih_done = false;  // the fused plan also emits the RNN input projection
@@ -698,6 +704,12 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
         TIP_TRY(launch_fused_encoder2(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr, B,
                                       cus, s), "fused_encoder2");
+    } else if (plan == TIP_PLAN_FUSED16) {
+        StageScope sc(h, s, "fused_encoder");
+        ih_done = true;
+        hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
+        TIP_TRY(launch_fused_encoder_s16(d, P + L.fused_off, P + L.s16_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr,
+                                         B, T, cus, s), "fused_encoder_s16");
     } else if (plan == TIP_PLAN_FUSEDH) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = fused_has_rnn_ih(d);

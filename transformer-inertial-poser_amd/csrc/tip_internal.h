@@ -113,6 +113,9 @@ struct PackedLayout {
     // fused-plan section (paper configuration): weights in 16x16x4 B-fragment order, see tip_fused.hip
     size_t fused_off;
     size_t fused_floats;
+    // split-fp16 copy of the fused section's weight matrices (tip_s16.hip, TIP_PLAN_FUSED16): same float offsets, hi | lo halfs
+    size_t s16_off = 0;
+    size_t s16_floats = 0;
     size_t total_floats;
 };
 
@@ -373,6 +376,15 @@ hipError_t launch_head_gemm(const float* A, long long lda, const float* wfrag, c
 // hipErrorInvalidValue = shape not served (nothing launched).
 hipError_t launch_head_ksplit(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy, int M, int N,
                               int K, bool last_only, int num_cus, hipStream_t s);
+
+// ---- exploratory split-fp16 plan (tip_s16.hip) ----
+bool s16_supported(const Dims& d, int T);
+size_t s16_packed_floats(const Dims& d);
+void s16_pack_host(const Dims& d, const float* fused_src, float* dst);
+hipError_t launch_s16_repack(const Dims& d, const float* fused_src, float* dst, hipStream_t s);
+hipError_t launch_fused_encoder_s16(const Dims& d, const float* fused_w, const float* s16_w, const float* x_imu, const float* x_s,
+                                    const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, int B, int T,
+                                    int num_cus, hipStream_t s);
 
 // ---- latency plan (tip_latency.hip): one window spread over many CUs, for few concurrent streams ----
 bool latency_supported(const Dims& d, int B, int T);

@@ -1,0 +1,512 @@
+// tip_s16.hip — EXPLORATORY plan "fused16" (TIP_PLAN_FUSED16, opt-in, never AUTO's choice, never the headline):
+// the fused one-window encoder with every GEMM's fp32 operands EMULATED on the fp16 matrix cores.
+//
+// gfx950 multiplies f32-input MFMAs at 1/16 of the f16 rate (MI355X_MICROARCH.md), and the encoder is bound by exactly that
+// (DESIGN.md section 5).  Here both operands of a product are split
+//     x = xh + xl * 2^-11,   xh = fp16(x),   xl = fp16((x - xh) * 2^11)
+// (weights once, at pack time; activations in the epilogue that produces them) and
+//     x * w ~= xh wh + (xh wl + xl wh) * 2^-11              (the xl wl * 2^-22 term is dropped)
+// runs as THREE v_mfma_f32_16x16x32_f16 per 16 x 16 x 32 block with fp32 accumulation — products of two fp16 numbers are exact
+// in fp32 — into two accumulators (the hh sum and the cross sum), combined once per phase.  Operands keep 22 significant bits
+// (fp32: 24); measured against fp64 the result is NOT worse than an fp32 MFMA chain (tools/probes/ffn_split16_probe.hip: 0.4-0.5x
+// the error of a sequential fp32 dot product for gains 1 ... 16), because the accumulation, not the operand rounding, dominates.
+// The attention core (S = K Q^T, softmax, P V: 2.5 % of the FLOPs), LayerNorm, the residual stream, biases and every epilogue
+// stay in fp32 exactly as in fused_encoder_kernel.  dtype of the plan: "f32 emulated as split fp16 (22-bit operands), fp32
+// accumulate" — reported under bench.py's `extra` with that label only.
+//
+// Structure = fused_encoder_kernel (tip_fused.hip): one 512-thread workgroup per window, 48 padded rows, the residual stream X
+// [48][260] fp32 in LDS, weights streamed from L2 in fragment order, one head pair per wave from projection to attention output
+// in registers (attention_head_regs' operand trick: swapped MFMA operands leave Q^T / K^T in the accumulators).  New: every
+// GEMM input lives in LDS as two fp16 planes [48][272] (hi, lo; 544-byte rows: conflict-free 16-byte fragment reads), written by
+// the epilogue / LayerNorm pass that produces it.  LDS 154 368 B.
+// Weight image: the fused fp32 section re-expressed as [col block][32-k block][hi | lo][64 lanes][8 halfs] at the same float
+// offsets (4 bytes per weight either way), built from that section by s16_pack_host / launch_s16_repack, so every fold of the
+// fp32 image (channel shuffle, root-velocity columns, 1/sqrt(d_head), b_ih + b_hh) carries over.
+// Reference: /root/reference/simple_transformer_with_state.py:63-99.
+#include <stdlib.h>
+#include <string.h>
+
+#include "tip_internal.h"
+#include "tip_layernorm.h"
+
+namespace tip {
+
+typedef _Float16 s16h8 __attribute__((ext_vector_type(8)));
+typedef float s16f4 __attribute__((ext_vector_type(4)));
+
+namespace sz {
+constexpr int D = 256, F = 1024, RP = 48, RB = 3, TMAX = 40, R = 512, KIN = 224;
+constexpr int LDX = D + 4;            // fp32 residual stream
+constexpr int LDA = D + 16;           // halfs: split planes
+constexpr int PL = RP * LDA;          // halfs per plane
+constexpr int X_BYTES = RP * LDX * 4;
+constexpr int LDS_BYTES = X_BYTES + 4 * PL * 2;   // X | Ah | Al | Ch | Cl = 154 368 B
+constexpr int THREADS = 512;
+constexpr float SC = 2048.f, ISC = 1.f / 2048.f;
+// the fused fp32 section's offsets (floats; tip_fused.hip, namespace fz) — the s16 section uses the same ones
+constexpr size_t IN_W = 0;
+constexpr size_t IN_B = IN_W + (size_t)D * KIN;
+constexpr size_t LAYER0 = IN_B + D;
+constexpr size_t QKV_W = 0;
+constexpr size_t QKV_B = QKV_W + (size_t)3 * D * D;
+constexpr size_t WO_W = QKV_B + 3 * D;
+constexpr size_t WO_B = WO_W + (size_t)D * D;
+constexpr size_t W1_W = WO_B + D;
+constexpr size_t W1_B = W1_W + (size_t)F * D;
+constexpr size_t W2_W = W1_B + F;
+constexpr size_t W2_B = W2_W + (size_t)D * F;
+constexpr size_t G1 = W2_B + D;
+constexpr size_t BE1 = G1 + D;
+constexpr size_t G2 = BE1 + D;
+constexpr size_t BE2 = G2 + D;
+constexpr size_t LAYER_FLOATS = BE2 + D;
+}  // namespace sz
+
+bool s16_supported(const Dims& d, int T) { return fused_supported(d, T) && fused_has_rnn_ih(d); }
+size_t s16_packed_floats(const Dims& d) { return (fused_packed_floats(d) && fused_has_rnn_ih(d)) ? fused_packed_floats(d) : 0; }
+
+// the weight matrices of the fused section: (float offset, N, K padded to a multiple of 32)
+struct S16Mat {
+    size_t off;
+    int N, K;
+};
+static int s16_mats(const Dims& d, std::vector<S16Mat>& m) {
+    using namespace sz;
+    m.clear();
+    m.push_back({IN_W, D, KIN});
+    for (int l = 0; l < d.L; ++l) {
+        const size_t L = LAYER0 + (size_t)l * LAYER_FLOATS;
+        m.push_back({L + QKV_W, 3 * D, D});
+        m.push_back({L + WO_W, D, D});
+        m.push_back({L + W1_W, F, D});
+        m.push_back({L + W2_W, D, F});
+    }
+    m.push_back({LAYER0 + (size_t)d.L * LAYER_FLOATS, R, D});
+    return (int)m.size();
+}
+
+// element (col n, k) of a matrix stored in 16x16x4 fragment order [N/16][K/16][64][4]
+__host__ __device__ __forceinline__ size_t s16_src_index(int n, int k, int K) {
+    return (((size_t)(n >> 4) * (K >> 4) + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + (n & 15)) * 4 + (k & 3);
+}
+
+void s16_pack_host(const Dims& d, const float* fused_src, float* dst) {
+    std::vector<S16Mat> mats;
+    s16_mats(d, mats);
+    memset(dst, 0, s16_packed_floats(d) * sizeof(float));
+    for (const S16Mat& m : mats) {
+        _Float16* out = reinterpret_cast<_Float16*>(dst + m.off);
+        const float* src = fused_src + m.off;
+        const int KB = m.K / 32;
+        for (int nb = 0; nb < m.N / 16; ++nb)
+            for (int kb = 0; kb < KB; ++kb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 8; ++i) {
+                        const int n = nb * 16 + (lane & 15), k = kb * 32 + (lane >> 4) * 8 + i;
+                        const float w = src[s16_src_index(n, k, m.K)];
+                        const _Float16 h = (_Float16)w;
+                        const _Float16 l = (_Float16)((w - (float)h) * sz::SC);
+                        const size_t base = ((size_t)(nb * KB + kb) * 2) * 512;
+                        out[base + lane * 8 + i] = h;
+                        out[base + 512 + lane * 8 + i] = l;
+                    }
+    }
+}
+
+__global__ void s16_repack_kernel(const float* __restrict__ src, _Float16* __restrict__ out, int N, int K) {
+    const int KB = K / 32;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // (nb, kb, lane)
+    if (idx >= (long long)(N / 16) * KB * 64) return;
+    const int lane = (int)(idx & 63);
+    const int kb = (int)((idx >> 6) % KB), nb = (int)((idx >> 6) / KB);
+    const int n = nb * 16 + (lane & 15);
+    s16h8 h, l;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = kb * 32 + (lane >> 4) * 8 + i;
+        const float w = src[s16_src_index(n, k, K)];
+        h[i] = (_Float16)w;
+        l[i] = (_Float16)((w - (float)h[i]) * sz::SC);
+    }
+    const size_t base = ((size_t)(nb * KB + kb) * 2) * 512;
+    *reinterpret_cast<s16h8*>(out + base + lane * 8) = h;
+    *reinterpret_cast<s16h8*>(out + base + 512 + lane * 8) = l;
+}
+
+hipError_t launch_s16_repack(const Dims& d, const float* fused_src, float* dst, hipStream_t s) {
+    std::vector<S16Mat> mats;
+    s16_mats(d, mats);
+    hipError_t e = hipMemsetAsync(dst, 0, s16_packed_floats(d) * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    for (const S16Mat& m : mats) {
+        const long long n = (long long)(m.N / 16) * (m.K / 32) * 64;
+        hipLaunchKernelGGL(s16_repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, fused_src + m.off,
+                           reinterpret_cast<_Float16*>(dst + m.off), m.N, m.K);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void s16_split(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x;
+    l = (_Float16)((x - (float)h) * sz::SC);
+}
+
+// one fragment: lane l gets bytes [16 l, 16 l + 16) of the 1-KiB block at byte offset soff of the s16 section
+__device__ __forceinline__ s16h8 s16_ldw(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(s16h8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// acc_h[r][n] += Ah(rows of block r) Wh(block n);  acc_x[r][n] += Ah Wl + Al Wh     for k-blocks 0 .. KB-1
+//   Ap / Alp: this lane's fragment address in the hi / lo plane (row l15 of block 0, halfs 8 lg ..); block n of the weight is
+//   at byte offset soff + n * nstride_b, k-block kb at + kb * 2048 (hi) / + 1024 (lo).  The first SWAPN blocks with swapped
+//   operands (weights as A): transposed accumulators (channels 4 lg + e, row l15) for the attention's Q^T / K^T tiles.
+template <int NBW, int KB, int SWAPN = 0>
+__device__ __forceinline__ void s16_gemm(s16f4 (&acc_h)[sz::RB][NBW], s16f4 (&acc_x)[sz::RB][NBW], const _Float16* Ap, const _Float16* Alp,
+                                         __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b) {
+    // weight fragments two k-blocks ahead of their MFMAs in a three-slot register ring (the k loop is fully unrolled, so the slot
+    // indices are compile-time); a scheduling barrier per k-block keeps the compiler from hoisting every load of the phase to its
+    // top (it did: 660 bytes of scratch per lane)
+    s16h8 bh[3][NBW], bl[3][NBW];
+#pragma unroll
+    for (int p = 0; p < 2 && p < KB; ++p)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+            bh[p][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + p * 2048);
+            bl[p][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + p * 2048 + 1024);
+        }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        if (kb + 2 < KB) {
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) {
+                bh[(kb + 2) % 3][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + (kb + 2) * 2048);
+                bl[(kb + 2) % 3][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + (kb + 2) * 2048 + 1024);
+            }
+        }
+        s16h8 ah[sz::RB], al[sz::RB];
+#pragma unroll
+        for (int r = 0; r < sz::RB; ++r) {
+            ah[r] = *reinterpret_cast<const s16h8*>(Ap + r * 16 * sz::LDA + kb * 32);
+            al[r] = *reinterpret_cast<const s16h8*>(Alp + r * 16 * sz::LDA + kb * 32);
+        }
+        const int c = kb % 3;
+#pragma unroll
+        for (int r = 0; r < sz::RB; ++r)
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) {
+                if (n < SWAPN) {
+                    acc_h[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[c][n], ah[r], acc_h[r][n], 0, 0, 0);
+                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[c][n], ah[r], acc_x[r][n], 0, 0, 0);
+                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[c][n], al[r], acc_x[r][n], 0, 0, 0);
+                } else {
+                    acc_h[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bh[c][n], acc_h[r][n], 0, 0, 0);
+                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bl[c][n], acc_x[r][n], 0, 0, 0);
+                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r], bh[c][n], acc_x[r][n], 0, 0, 0);
+                }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int NBW>
+__device__ __forceinline__ void s16_zero(s16f4 (&a)[sz::RB][NBW], s16f4 (&b)[sz::RB][NBW]) {
+#pragma unroll
+    for (int r = 0; r < sz::RB; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) a[r][n] = b[r][n] = (s16f4){0.f, 0.f, 0.f, 0.f};
+}
+
+// causal attention of one head from register tiles (tip_attention.h, attention_head_regs — fp32 16x16x4 MFMAs, unchanged), the
+// output written as the SPLIT planes the out-projection reads
+__device__ __forceinline__ void s16_attention_head(const s16f4 (&qt)[3], const s16f4 (&kt)[3], const s16f4 (&v)[3], _Float16* Oh,
+                                                   _Float16* Ol, int c0, int lane) {
+    constexpr int RB = 3;
+    const int l15 = lane & 15, lg = lane >> 4;
+    s16f4 S[RB][RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int cb = 0; cb <= r; ++cb) {
+            s16f4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t = __builtin_amdgcn_mfma_f32_16x16x4f32(kt[cb][e], qt[r][e], t, 0, 0, 0);
+            S[r][cb] = t;
+        }
+    float mx[RB], rsum[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (lg * 4 + e <= l15) m = fmaxf(m, S[r][r][e]);
+#pragma unroll
+            for (int cb = 0; cb < r; ++cb) m = fmaxf(m, S[r][cb][e]);
+        }
+        mx[r] = m;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) mx[r] = lg4_max(mx[r]);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        float sm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int cb = 0; cb < r; ++cb) {
+                const float p = __expf(S[r][cb][e] - mx[r]);
+                S[r][cb][e] = p;
+                sm += p;
+            }
+            const float pd = (lg * 4 + e <= l15) ? __expf(S[r][r][e] - mx[r]) : 0.f;
+            S[r][r][e] = pd;
+            sm += pd;
+        }
+        rsum[r] = sm;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) rsum[r] = lg4_sum(rsum[r]);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) rsum[r] = 1.0f / rsum[r];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        s16f4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb <= r; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_16x16x4f32(S[r][kb][e], v[kb][e], o, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float inv = __shfl(rsum[r], lg * 4 + e, 64);
+            _Float16 h, l;
+            s16_split(o[e] * inv, h, l);
+            Oh[(r * 16 + lg * 4 + e) * sz::LDA + c0 + l15] = h;
+            Ol[(r * 16 + lg * 4 + e) * sz::LDA + c0 + l15] = l;
+        }
+    }
+}
+
+__global__ __launch_bounds__(sz::THREADS) void fused_encoder_s16_kernel(
+    const float* __restrict__ wts, const float* __restrict__ w16, const float* __restrict__ x_imu, const float* __restrict__ x_s,
+    const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ ih_out, unsigned* __restrict__ hall_sentinel, int B,
+    int T, int NI, int S, int L, int wbytes) {
+    using namespace sz;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* X = reinterpret_cast<float*>(smem_raw);
+    _Float16* Ah = reinterpret_cast<_Float16*>(smem_raw + X_BYTES);
+    _Float16* Al = Ah + PL;
+    _Float16* Ch = Al + PL;
+    _Float16* Cl = Ch + PL;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w16), 0, wbytes, 0x00020000);
+    const int voff = lane * 16;
+    const int aoff = l15 * LDA + lg * 8;   // this lane's A-fragment offset inside a 16-row block of a split plane (halfs)
+    // X -> (Ah, Al): the split copy every GEMM that reads the residual stream uses
+    auto split_x = [&]() {
+        for (int i = tid; i < RP * (D / 4); i += THREADS) {
+            const int r = i / (D / 4), c = (i - r * (D / 4)) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(X + r * LDX + c);
+            _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
+            s16_split(v.x, h0, l0); s16_split(v.y, h1, l1); s16_split(v.z, h2, l2); s16_split(v.w, h3, l3);
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<h4*>(Ah + r * LDA + c) = (h4){h0, h1, h2, h3};
+            *reinterpret_cast<h4*>(Al + r * LDA + c) = (h4){l0, l1, l2, l3};
+        }
+    };
+
+    for (int win = blockIdx.x; win < B; win += gridDim.x) {
+        // ---- prologue (:63-78): U = [x_imu | scrubbed, masked x_s | 0] as split planes, K padded to 224 (+ zero to 256) ----
+        for (int i = tid; i < RP * LDA; i += THREADS) Ah[i] = Al[i] = (_Float16)0.f;
+        __syncthreads();
+        {
+            const float* xi = x_imu + (size_t)win * T * NI;
+            for (int i = tid; i < T * NI; i += THREADS) {
+                const int r = i / NI, c = i - r * NI;
+                _Float16 h, l;
+                s16_split(xi[i], h, l);
+                Ah[r * LDA + c] = h;
+                Al[r * LDA + c] = l;
+            }
+            const float* xs = x_s + (size_t)win * T * S;
+            const float* km = keep_mask ? keep_mask + (size_t)win * T * S : nullptr;
+            for (int i = tid; i < T * S; i += THREADS) {
+                const int r = i / S, c = i - r * S;
+                float v = xs[i];
+                if (v != v) v = 0.f;                  // :65
+                if (km) v = v * km[i] * keep_scale;   // :77
+                _Float16 h, l;
+                s16_split(v, h, l);
+                Ah[r * LDA + NI + c] = h;
+                Al[r * LDA + NI + c] = l;
+            }
+        }
+        __syncthreads();
+        // ---- in_linear (:79) + channel shuffle (folded into the packed rows) ----
+        {
+            s16f4 ach[RB][2], acx[RB][2];
+            s16_zero<2>(ach, acx);
+            s16_gemm<2, KIN / 32>(ach, acx, Ah + aoff, Al + aoff, rsrc, voff, (int)(IN_W * 4) + (wave * 2) * (KIN / 32) * 2048,
+                                  (KIN / 32) * 2048);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = (wave * 2 + n) * 16 + l15;
+                const float bv = wts[IN_B + col];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] = ach[r][n][e] + acx[r][n][e] * ISC + bv;
+            }
+        }
+        __syncthreads();
+        split_x();
+        __syncthreads();
+
+#pragma unroll 1
+        for (int layer = 0; layer < L; ++layer) {
+            const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
+            const int lb = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);   // byte offset of the layer in either section
+            // ---- Q | K | V projection + attention: heads 2 wave, 2 wave + 1, projection to attention output in registers ----
+#pragma unroll 1
+            for (int hh = 0; hh < 2; ++hh) {
+                const int head = wave * 2 + hh;
+                s16f4 ph[RB][3], px[RB][3];
+                s16_zero<3>(ph, px);
+                // column blocks of the packed QKV weight: Q head -> block head, K -> 16 + head, V -> 32 + head
+                s16_gemm<3, D / 32, 2>(ph, px, Ah + aoff, Al + aoff, rsrc, voff, lb + (int)(QKV_W * 4) + head * (D / 32) * 2048,
+                                       16 * (D / 32) * 2048);
+                s16f4 qt[RB], kt[RB], vv[RB];
+                const float4 bq = *reinterpret_cast<const float4*>(LW + QKV_B + head * 16 + lg * 4);            // channels 4 lg + e
+                const float4 bk = *reinterpret_cast<const float4*>(LW + QKV_B + D + head * 16 + lg * 4);
+                const float bvv = LW[QKV_B + 2 * D + head * 16 + l15];
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    qt[r] = ph[r][0] + px[r][0] * ISC + (s16f4){bq.x, bq.y, bq.z, bq.w};
+                    kt[r] = ph[r][1] + px[r][1] * ISC + (s16f4){bk.x, bk.y, bk.z, bk.w};
+                    vv[r] = ph[r][2] + px[r][2] * ISC + bvv;
+                }
+                s16_attention_head(qt, kt, vv, Ch, Cl, head * 16, lane);
+            }
+            __syncthreads();
+            // ---- out-projection + residual, LayerNorm1 ----
+            {
+                s16f4 ach[RB][2], acx[RB][2];
+                s16_zero<2>(ach, acx);
+                s16_gemm<2, D / 32>(ach, acx, Ch + aoff, Cl + aoff, rsrc, voff, lb + (int)(WO_W * 4) + (wave * 2) * (D / 32) * 2048,
+                                    (D / 32) * 2048);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int col = (wave * 2 + n) * 16 + l15;
+                    const float bv = LW[WO_B + col];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += ach[r][n][e] + acx[r][n][e] * ISC + bv;
+                }
+            }
+            __syncthreads();
+            layernorm_rows16<RP, LDX>(X, LW + G1, LW + BE1, wave, lane);
+            __syncthreads();
+            split_x();
+            __syncthreads();
+            // ---- feed-forward: 4 hidden chunks of 256; linear2 accumulates in registers ----
+            {
+                s16f4 oh[RB][2], ox[RB][2];
+                s16_zero<2>(oh, ox);
+#pragma unroll 1
+                for (int f = 0; f < 4; ++f) {
+                    {
+                        s16f4 ach[RB][2], acx[RB][2];
+                        s16_zero<2>(ach, acx);
+                        s16_gemm<2, D / 32>(ach, acx, Ah + aoff, Al + aoff, rsrc, voff,
+                                            lb + (int)(W1_W * 4) + (f * 16 + wave * 2) * (D / 32) * 2048, (D / 32) * 2048);
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            const int col = (wave * 2 + n) * 16 + l15;
+                            const float bv = LW[W1_B + f * 256 + col];
+#pragma unroll
+                            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    _Float16 h, l;
+                                    s16_split(fmaxf(ach[r][n][e] + acx[r][n][e] * ISC + bv, 0.f), h, l);
+                                    Ch[(r * 16 + lg * 4 + e) * LDA + col] = h;
+                                    Cl[(r * 16 + lg * 4 + e) * LDA + col] = l;
+                                }
+                        }
+                    }
+                    __syncthreads();
+                    s16_gemm<2, 8>(oh, ox, Ch + aoff, Cl + aoff, rsrc, voff,
+                                   lb + (int)(W2_W * 4) + ((wave * 2) * (F / 32) + f * 8) * 2048, (F / 32) * 2048);
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int col = (wave * 2 + n) * 16 + l15;
+                    const float bv = LW[W2_B + col];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += oh[r][n][e] + ox[r][n][e] * ISC + bv;
+                }
+            }
+            __syncthreads();
+            layernorm_rows16<RP, LDX>(X, LW + G2, LW + BE2, wave, lane);
+            __syncthreads();
+            split_x();
+            __syncthreads();
+        }
+        // ---- RNN input projection: IH = X W_ih^T + (b_ih + b_hh) -> HBM (:98) ----
+        {
+            const size_t ih_off = LAYER0 + (size_t)L * LAYER_FLOATS;
+            float* io = ih_out + (size_t)win * T * R;
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                s16f4 ach[RB][2], acx[RB][2];
+                s16_zero<2>(ach, acx);
+                const int nb0 = wave * 4 + half * 2;
+                s16_gemm<2, D / 32>(ach, acx, Ah + aoff, Al + aoff, rsrc, voff, (int)(ih_off * 4) + nb0 * (D / 32) * 2048, (D / 32) * 2048);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int col = (nb0 + n) * 16 + l15;
+                    const float bv = wts[ih_off + (size_t)R * D + col];
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = r * 16 + lg * 4 + e;
+                            if (row < T) io[(size_t)row * R + col] = ach[r][n][e] + acx[r][n][e] * ISC + bv;
+                        }
+                }
+            }
+        }
+        if (hall_sentinel) {
+            uint4* hp = reinterpret_cast<uint4*>(hall_sentinel + (size_t)win * T * R);
+            for (int i = tid; i < T * (R / 4); i += THREADS) hp[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_fused_encoder_s16(const Dims& d, const float* fused_w, const float* s16_w, const float* x_imu, const float* x_s,
+                                    const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, int B, int T,
+                                    int num_cus, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (!s16_supported(d, T)) return hipErrorInvalidValue;
+    static PerDeviceFlag attr_flag;
+    bool& attr_set = attr_flag.cur();
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_s16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           sz::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int grid = B < num_cus ? B : num_cus;
+    hipLaunchKernelGGL(fused_encoder_s16_kernel, dim3(grid), dim3(sz::THREADS), sz::LDS_BYTES, s, fused_w, s16_w, x_imu, x_s, keep_mask,
+                       keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,
+                       (int)(s16_packed_floats(d) * 4));
+    return hipGetLastError();
+}
+
+}  // namespace tip
