@@ -159,29 +159,39 @@ __device__ __forceinline__ s16h8 s16_ldw(__amdgpu_buffer_rsrc_t r, int voff, int
 
 // acc_h[r][n] += Ah(rows of block r) Wh(block n);  acc_x[r][n] += Ah Wl + Al Wh     for k-blocks 0 .. KB-1
 //   Ap / Alp: this lane's fragment address in the hi / lo plane (row l15 of block 0, halfs 8 lg ..); block n of the weight is
-//   at byte offset soff + n * nstride_b, k-block kb at + kb * 2048 (hi) / + 1024 (lo).  The first SWAPN blocks with swapped
-//   operands (weights as A): transposed accumulators (channels 4 lg + e, row l15) for the attention's Q^T / K^T tiles.
-template <int NBW, int KB, int SWAPN = 0>
-__device__ __forceinline__ void s16_gemm(s16f4 (&acc_h)[sz::RB][NBW], s16f4 (&acc_x)[sz::RB][NBW], const _Float16* Ap, const _Float16* Alp,
-                                         __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b) {
-    // weight fragments two k-blocks ahead of their MFMAs in a three-slot register ring (the k loop is fully unrolled, so the slot
-    // indices are compile-time); a scheduling barrier per k-block keeps the compiler from hoisting every load of the phase to its
-    // top (it did: 660 bytes of scratch per lane)
+//   at byte offset soff + n * nstride_b, k-block kb at + kb * 2048 (hi) / + 1024 (lo).
+//   Blocks n < PLAIN_FROM run with SWAPPED operands (weights as A): the accumulator holds the TRANSPOSED tile — lane (l15, lg) =
+//   (output channels 16 n + 4 lg + e, row 16 r + l15) — i.e. four CONSECUTIVE channels of one row per lane: every epilogue is a
+//   16-byte fp32 or 8-byte fp16 access instead of four scattered scalars, and Q^T / K^T are what the attention wants anyway.
+//   Blocks n >= PLAIN_FROM keep the plain layout (rows 16 r + 4 lg + e, channel 16 n + l15): V, the B operand of P V.
+template <int NBW>
+struct S16Ring {
     s16h8 bh[3][NBW], bl[3][NBW];
+};
+// slots 0, 1 <- k-blocks 0, 1 of the phase whose first block is at soff
+template <int NBW>
+__device__ __forceinline__ void s16_prime(S16Ring<NBW>& g, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b) {
 #pragma unroll
-    for (int p = 0; p < 2 && p < KB; ++p)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int n = 0; n < NBW; ++n) {
-            bh[p][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + p * 2048);
-            bl[p][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + p * 2048 + 1024);
+            g.bh[p][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + p * 2048);
+            g.bl[p][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + p * 2048 + 1024);
         }
+}
+// the phase proper on a PRIMED ring.  KB % 3 == 2 (8 k-blocks) leaves slots 0, 1 free at the end: the caller primes them for the
+// next phase right behind the last MFMAs, in front of its epilogue and barrier (cross-phase prefetch).
+template <int NBW, int KB, int PLAIN_FROM = NBW>
+__device__ __forceinline__ void s16_gemm_run(s16f4 (&acc_h)[sz::RB][NBW], s16f4 (&acc_x)[sz::RB][NBW], const _Float16* Ap,
+                                             const _Float16* Alp, S16Ring<NBW>& g, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff,
+                                             int nstride_b) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         if (kb + 2 < KB) {
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
-                bh[(kb + 2) % 3][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + (kb + 2) * 2048);
-                bl[(kb + 2) % 3][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + (kb + 2) * 2048 + 1024);
+                g.bh[(kb + 2) % 3][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + (kb + 2) * 2048);
+                g.bl[(kb + 2) % 3][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + (kb + 2) * 2048 + 1024);
             }
         }
         s16h8 ah[sz::RB], al[sz::RB];
@@ -195,17 +205,83 @@ __device__ __forceinline__ void s16_gemm(s16f4 (&acc_h)[sz::RB][NBW], s16f4 (&ac
         for (int r = 0; r < sz::RB; ++r)
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
-                if (n < SWAPN) {
-                    acc_h[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[c][n], ah[r], acc_h[r][n], 0, 0, 0);
-                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[c][n], ah[r], acc_x[r][n], 0, 0, 0);
-                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[c][n], al[r], acc_x[r][n], 0, 0, 0);
+                if (n < PLAIN_FROM) {
+                    acc_h[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g.bh[c][n], ah[r], acc_h[r][n], 0, 0, 0);
+                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g.bl[c][n], ah[r], acc_x[r][n], 0, 0, 0);
+                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g.bh[c][n], al[r], acc_x[r][n], 0, 0, 0);
                 } else {
-                    acc_h[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bh[c][n], acc_h[r][n], 0, 0, 0);
-                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bl[c][n], acc_x[r][n], 0, 0, 0);
-                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r], bh[c][n], acc_x[r][n], 0, 0, 0);
+                    acc_h[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], g.bh[c][n], acc_h[r][n], 0, 0, 0);
+                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], g.bl[c][n], acc_x[r][n], 0, 0, 0);
+                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r], g.bh[c][n], acc_x[r][n], 0, 0, 0);
                 }
             }
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// prime + run in one go (phases without a cross-phase prefetch)
+template <int NBW, int KB, int PLAIN_FROM = NBW>
+__device__ __forceinline__ void s16_gemm(s16f4 (&acc_h)[sz::RB][NBW], s16f4 (&acc_x)[sz::RB][NBW], const _Float16* Ap, const _Float16* Alp,
+                                         __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b) {
+    S16Ring<NBW> g;
+    s16_prime<NBW>(g, rsrc, voff, soff, nstride_b);
+    s16_gemm_run<NBW, KB, PLAIN_FROM>(acc_h, acc_x, Ap, Alp, g, rsrc, voff, soff, nstride_b);
+}
+
+typedef _Float16 s16h4 __attribute__((ext_vector_type(4)));
+// four consecutive values -> their hi / lo halfs at p_hi / p_lo (8-byte stores)
+__device__ __forceinline__ void s16_split4_store(const s16f4& v, _Float16* p_hi, _Float16* p_lo) {
+    s16h4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = (_Float16)v[i];
+        l[i] = (_Float16)((v[i] - (float)h[i]) * sz::SC);
+    }
+    *reinterpret_cast<s16h4*>(p_hi) = h;
+    *reinterpret_cast<s16h4*>(p_lo) = l;
+}
+
+// LayerNorm of rows 0 .. 47 of X (tip_layernorm.h, layernorm_rows16: sixteen lanes per row, DPP row sums — same arithmetic), writing
+// the normalised rows to X AND, split, to the planes the next GEMM reads: no separate split pass, no barrier in between
+__device__ __forceinline__ void s16_layernorm_split(float* X, const float* __restrict__ g, const float* __restrict__ be, _Float16* Ph,
+                                                    _Float16* Pl, int wave, int lane) {
+    constexpr int DCOLS = 256, LD = sz::LDX;
+    const int q = lane & 15, sub = lane >> 4;
+    float4 gg[4], bb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        gg[j] = *reinterpret_cast<const float4*>(g + (q + 16 * j) * 4);
+        bb[j] = *reinterpret_cast<const float4*>(be + (q + 16 * j) * 4);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (p * 32 + wave * 4 < sz::RP) {
+            const int row = p * 32 + wave * 4 + sub;
+            float* xr = X + row * LD + q * 4;
+            float4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float4*>(xr + j * 64);
+            float s = ((v[0].x + v[0].y) + (v[0].z + v[0].w)) + ((v[1].x + v[1].y) + (v[1].z + v[1].w));
+            s += ((v[2].x + v[2].y) + (v[2].z + v[2].w)) + ((v[3].x + v[3].y) + (v[3].z + v[3].w));
+            const float mean = row16_sum(s) * (1.f / DCOLS);
+            float qs[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+                qs[j] = (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+            }
+            const float var = row16_sum((qs[0] + qs[1]) + (qs[2] + qs[3])) * (1.f / DCOLS);
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s16f4 o;
+                o[0] = v[j].x * rstd * gg[j].x + bb[j].x;
+                o[1] = v[j].y * rstd * gg[j].y + bb[j].y;
+                o[2] = v[j].z * rstd * gg[j].z + bb[j].z;
+                o[3] = v[j].w * rstd * gg[j].w + bb[j].w;
+                *reinterpret_cast<s16f4*>(xr + j * 64) = o;
+                s16_split4_store(o, Ph + row * sz::LDA + (q + 16 * j) * 4, Pl + row * sz::LDA + (q + 16 * j) * 4);
+            }
+        }
     }
 }
 
@@ -268,24 +344,26 @@ __device__ __forceinline__ void s16_attention_head(const s16f4 (&qt)[3], const s
     for (int r = 0; r < RB; ++r) rsum[r] = lg4_sum(rsum[r]);
 #pragma unroll
     for (int r = 0; r < RB; ++r) rsum[r] = 1.0f / rsum[r];
+    // P V with the operands the other way round (V tile as A: channel l15 / keys 4 lg + e; S tile as B: query l15 / the same keys):
+    // the output tile comes out TRANSPOSED — lane (l15, lg) = (channels 4 lg + e, query l15) — so a lane normalises with its own
+    // row sum (no shuffle) and stores four consecutive channels of one row: 8-byte writes into the split planes
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         s16f4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb <= r; ++kb)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_16x16x4f32(S[r][kb][e], v[kb][e], o, 0, 0, 0);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float inv = __shfl(rsum[r], lg * 4 + e, 64);
-            _Float16 h, l;
-            s16_split(o[e] * inv, h, l);
-            Oh[(r * 16 + lg * 4 + e) * sz::LDA + c0 + l15] = h;
-            Ol[(r * 16 + lg * 4 + e) * sz::LDA + c0 + l15] = l;
-        }
+            for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_16x16x4f32(v[kb][e], S[r][kb][e], o, 0, 0, 0);
+        o *= rsum[r];
+        s16_split4_store(o, Oh + (r * 16 + l15) * sz::LDA + c0 + lg * 4, Ol + (r * 16 + l15) * sz::LDA + c0 + lg * 4);
     }
 }
 
+// measurement only (TIP_S16_TRACE=1): s_memtime stamps of workgroup 0 / thread 0 (layer 1 for the per-layer slots)
+__device__ unsigned long long g_s16_trace[64];
+#define S16_STAMP(slot, cond) do { if (TRACE && blockIdx.x == 0 && tid == 0 && (cond)) g_s16_trace[slot] = __builtin_amdgcn_s_memtime(); } while (0)
+
+template <bool TRACE>
 __global__ __launch_bounds__(sz::THREADS) void fused_encoder_s16_kernel(
     const float* __restrict__ wts, const float* __restrict__ w16, const float* __restrict__ x_imu, const float* __restrict__ x_s,
     const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ ih_out, unsigned* __restrict__ hall_sentinel, int B,
@@ -303,68 +381,102 @@ __global__ __launch_bounds__(sz::THREADS) void fused_encoder_s16_kernel(
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w16), 0, wbytes, 0x00020000);
     const int voff = lane * 16;
     const int aoff = l15 * LDA + lg * 8;   // this lane's A-fragment offset inside a 16-row block of a split plane (halfs)
-    // X -> (Ah, Al): the split copy every GEMM that reads the residual stream uses
-    auto split_x = [&]() {
-        for (int i = tid; i < RP * (D / 4); i += THREADS) {
-            const int r = i / (D / 4), c = (i - r * (D / 4)) * 4;
-            const float4 v = *reinterpret_cast<const float4*>(X + r * LDX + c);
-            _Float16 h0, h1, h2, h3, l0, l1, l2, l3;
-            s16_split(v.x, h0, l0); s16_split(v.y, h1, l1); s16_split(v.z, h2, l2); s16_split(v.w, h3, l3);
-            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<h4*>(Ah + r * LDA + c) = (h4){h0, h1, h2, h3};
-            *reinterpret_cast<h4*>(Al + r * LDA + c) = (h4){l0, l1, l2, l3};
-        }
+    // transposed accumulator tile (r, column block nb): lane = row 16 r + l15, channels 16 nb + 4 lg .. + 3
+    auto bias4 = [&](const float* bp, int nb) -> s16f4 {
+        const float4 b = *reinterpret_cast<const float4*>(bp + nb * 16 + lg * 4);
+        return (s16f4){b.x, b.y, b.z, b.w};
     };
 
     for (int win = blockIdx.x; win < B; win += gridDim.x) {
-        // ---- prologue (:63-78): U = [x_imu | scrubbed, masked x_s | 0] as split planes, K padded to 224 (+ zero to 256) ----
-        for (int i = tid; i < RP * LDA; i += THREADS) Ah[i] = Al[i] = (_Float16)0.f;
+        S16_STAMP(0, true);
+        // ---- prologue (:63-78): U = [x_imu | scrubbed, masked x_s | 0] as split planes (Ch, Cl), K padded to 224 ----
+        {
+            uint4* z = reinterpret_cast<uint4*>(Ch);          // both C planes, contiguous
+            for (int i = tid; i < 2 * PL * 2 / 16; i += THREADS) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
         __syncthreads();
         {
-            const float* xi = x_imu + (size_t)win * T * NI;
-            for (int i = tid; i < T * NI; i += THREADS) {
-                const int r = i / NI, c = i - r * NI;
-                _Float16 h, l;
-                s16_split(xi[i], h, l);
-                Ah[r * LDA + c] = h;
-                Al[r * LDA + c] = l;
+            // rows wave, wave + 8, ... (five per wave at T = 40): unit-stride loads, no index division, and ALL of a wave's loads in
+            // flight before the first is used (one row after the other was a chain of five HBM round trips)
+            constexpr int NR = (TMAX + 7) / 8;
+            float vi[NR][2], vs[NR][3], vk[NR][3];
+            // (unconditional loads from clamped addresses: a guarded load `ok ? p[i] : 0` compiles to a branch with a full wait
+            //  behind it — 25 dependent HBM round trips, 35 k cycles measured)
+            const float* kmb = keep_mask ? keep_mask : x_s;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int r = wave + 8 * j;
+                const int rc = r < T ? r : T - 1;
+                const float* xi = x_imu + ((size_t)win * T + rc) * NI;
+                const float* xs = x_s + ((size_t)win * T + rc) * S;
+                const float* km = kmb + ((size_t)win * T + rc) * S;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) vi[j][q] = xi[lane + 64 * q < NI ? lane + 64 * q : NI - 1];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int c = lane + 64 * q < S ? lane + 64 * q : S - 1;
+                    vs[j][q] = xs[c];
+                    vk[j][q] = km[c] * keep_scale;
+                }
             }
-            const float* xs = x_s + (size_t)win * T * S;
-            const float* km = keep_mask ? keep_mask + (size_t)win * T * S : nullptr;
-            for (int i = tid; i < T * S; i += THREADS) {
-                const int r = i / S, c = i - r * S;
-                float v = xs[i];
-                if (v != v) v = 0.f;                  // :65
-                if (km) v = v * km[i] * keep_scale;   // :77
-                _Float16 h, l;
-                s16_split(v, h, l);
-                Ah[r * LDA + NI + c] = h;
-                Al[r * LDA + NI + c] = l;
+            // LDS addresses: one base per plane and part + COMPILE-TIME offsets (8 j rows, 64 q columns) — with the row / column
+            // arithmetic left in the index the compiler materialised forty address registers and spilled them
+            _Float16* ph_i = Ch + wave * LDA + lane;
+            _Float16* pl_i = Cl + wave * LDA + lane;
+            _Float16* ph_s = ph_i + NI;
+            _Float16* pl_s = pl_i + NI;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int r = wave + 8 * j;
+                if (r < T) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (lane + 64 * q < NI) {
+                            _Float16 h, l;
+                            s16_split(vi[j][q], h, l);
+                            ph_i[8 * j * LDA + 64 * q] = h;
+                            pl_i[8 * j * LDA + 64 * q] = l;
+                        }
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (lane + 64 * q < S) {
+                            float v = vs[j][q];
+                            if (v != v) v = 0.f;          // :65
+                            if (keep_mask) v *= vk[j][q];  // :77 (x * mask * 1/(1-p))
+                            _Float16 h, l;
+                            s16_split(v, h, l);
+                            ph_s[8 * j * LDA + 64 * q] = h;
+                            pl_s[8 * j * LDA + 64 * q] = l;
+                        }
+                }
             }
         }
         __syncthreads();
-        // ---- in_linear (:79) + channel shuffle (folded into the packed rows) ----
+        S16_STAMP(1, true);
+        // ---- in_linear (:79) + channel shuffle (folded into the packed rows): X and its split copy (Ah, Al) ----
         {
             s16f4 ach[RB][2], acx[RB][2];
             s16_zero<2>(ach, acx);
-            s16_gemm<2, KIN / 32>(ach, acx, Ah + aoff, Al + aoff, rsrc, voff, (int)(IN_W * 4) + (wave * 2) * (KIN / 32) * 2048,
+            s16_gemm<2, KIN / 32>(ach, acx, Ch + aoff, Cl + aoff, rsrc, voff, (int)(IN_W * 4) + (wave * 2) * (KIN / 32) * 2048,
                                   (KIN / 32) * 2048);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                const int col = (wave * 2 + n) * 16 + l15;
-                const float bv = wts[IN_B + col];
+                const s16f4 bv = bias4(wts + IN_B, wave * 2 + n);
 #pragma unroll
-                for (int r = 0; r < RB; ++r)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] = ach[r][n][e] + acx[r][n][e] * ISC + bv;
+                for (int r = 0; r < RB; ++r) {
+                    const s16f4 v = ach[r][n] + acx[r][n] * ISC + bv;
+                    const int row = r * 16 + l15, col = (wave * 2 + n) * 16 + lg * 4;
+                    *reinterpret_cast<s16f4*>(X + row * LDX + col) = v;
+                    s16_split4_store(v, Ah + row * LDA + col, Al + row * LDA + col);
+                }
             }
         }
         __syncthreads();
-        split_x();
-        __syncthreads();
+        S16_STAMP(2, true);
 
 #pragma unroll 1
         for (int layer = 0; layer < L; ++layer) {
+            S16_STAMP(8, layer == 1);
             const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
             const int lb = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);   // byte offset of the layer in either section
             // ---- Q | K | V projection + attention: heads 2 wave, 2 wave + 1, projection to attention output in registers ----
@@ -373,22 +485,24 @@ __global__ __launch_bounds__(sz::THREADS) void fused_encoder_s16_kernel(
                 const int head = wave * 2 + hh;
                 s16f4 ph[RB][3], px[RB][3];
                 s16_zero<3>(ph, px);
-                // column blocks of the packed QKV weight: Q head -> block head, K -> 16 + head, V -> 32 + head
+                // column blocks of the packed QKV weight: Q head -> block head, K -> 16 + head, V -> 32 + head (V in the plain layout)
                 s16_gemm<3, D / 32, 2>(ph, px, Ah + aoff, Al + aoff, rsrc, voff, lb + (int)(QKV_W * 4) + head * (D / 32) * 2048,
                                        16 * (D / 32) * 2048);
                 s16f4 qt[RB], kt[RB], vv[RB];
-                const float4 bq = *reinterpret_cast<const float4*>(LW + QKV_B + head * 16 + lg * 4);            // channels 4 lg + e
-                const float4 bk = *reinterpret_cast<const float4*>(LW + QKV_B + D + head * 16 + lg * 4);
+                const s16f4 bq = bias4(LW + QKV_B, head), bk = bias4(LW + QKV_B + D, head);
                 const float bvv = LW[QKV_B + 2 * D + head * 16 + l15];
 #pragma unroll
                 for (int r = 0; r < RB; ++r) {
-                    qt[r] = ph[r][0] + px[r][0] * ISC + (s16f4){bq.x, bq.y, bq.z, bq.w};
-                    kt[r] = ph[r][1] + px[r][1] * ISC + (s16f4){bk.x, bk.y, bk.z, bk.w};
+                    qt[r] = ph[r][0] + px[r][0] * ISC + bq;
+                    kt[r] = ph[r][1] + px[r][1] * ISC + bk;
                     vv[r] = ph[r][2] + px[r][2] * ISC + bvv;
                 }
+                S16_STAMP(9 + 2 * hh, layer == 1);
                 s16_attention_head(qt, kt, vv, Ch, Cl, head * 16, lane);
+                S16_STAMP(10 + 2 * hh, layer == 1);
             }
             __syncthreads();
+            S16_STAMP(13, layer == 1);
             // ---- out-projection + residual, LayerNorm1 ----
             {
                 s16f4 ach[RB][2], acx[RB][2];
@@ -397,67 +511,76 @@ __global__ __launch_bounds__(sz::THREADS) void fused_encoder_s16_kernel(
                                     (D / 32) * 2048);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    const int col = (wave * 2 + n) * 16 + l15;
-                    const float bv = LW[WO_B + col];
+                    const s16f4 bv = bias4(LW + WO_B, wave * 2 + n);
 #pragma unroll
-                    for (int r = 0; r < RB; ++r)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += ach[r][n][e] + acx[r][n][e] * ISC + bv;
+                    for (int r = 0; r < RB; ++r) {
+                        s16f4* xp = reinterpret_cast<s16f4*>(X + (r * 16 + l15) * LDX + (wave * 2 + n) * 16 + lg * 4);
+                        *xp = *xp + (ach[r][n] + acx[r][n] * ISC + bv);
+                    }
                 }
             }
             __syncthreads();
-            layernorm_rows16<RP, LDX>(X, LW + G1, LW + BE1, wave, lane);
+            S16_STAMP(14, layer == 1);
+            s16_layernorm_split(X, LW + G1, LW + BE1, Ah, Al, wave, lane);
             __syncthreads();
-            split_x();
-            __syncthreads();
-            // ---- feed-forward: 4 hidden chunks of 256; linear2 accumulates in registers ----
+            S16_STAMP(16, layer == 1);
+            // ---- feed-forward: 4 hidden chunks of 256; linear2 accumulates in registers.  ONE weight ring for the eight phases: each
+            //      phase primes the next one's first two k-blocks right behind its last MFMAs, so they travel under the epilogue and
+            //      the barrier instead of in front of the next phase's first MFMA ----
             {
                 s16f4 oh[RB][2], ox[RB][2];
                 s16_zero<2>(oh, ox);
+                S16Ring<2> g;
+                const int w1s = (D / 32) * 2048, w2s = (F / 32) * 2048;
+                auto w1off = [&](int f) { return lb + (int)(W1_W * 4) + (f * 16 + wave * 2) * (D / 32) * 2048; };
+                auto w2off = [&](int f) { return lb + (int)(W2_W * 4) + ((wave * 2) * (F / 32) + f * 8) * 2048; };
+                s16_prime<2>(g, rsrc, voff, w1off(0), w1s);
 #pragma unroll 1
                 for (int f = 0; f < 4; ++f) {
                     {
                         s16f4 ach[RB][2], acx[RB][2];
                         s16_zero<2>(ach, acx);
-                        s16_gemm<2, D / 32>(ach, acx, Ah + aoff, Al + aoff, rsrc, voff,
-                                            lb + (int)(W1_W * 4) + (f * 16 + wave * 2) * (D / 32) * 2048, (D / 32) * 2048);
+                        s16_gemm_run<2, D / 32>(ach, acx, Ah + aoff, Al + aoff, g, rsrc, voff, w1off(f), w1s);
+                        s16_prime<2>(g, rsrc, voff, w2off(f), w2s);
 #pragma unroll
                         for (int n = 0; n < 2; ++n) {
-                            const int col = (wave * 2 + n) * 16 + l15;
-                            const float bv = LW[W1_B + f * 256 + col];
+                            const s16f4 bv = bias4(LW + W1_B + f * 256, wave * 2 + n);
 #pragma unroll
-                            for (int r = 0; r < RB; ++r)
+                            for (int r = 0; r < RB; ++r) {
+                                s16f4 v = ach[r][n] + acx[r][n] * ISC + bv;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    _Float16 h, l;
-                                    s16_split(fmaxf(ach[r][n][e] + acx[r][n][e] * ISC + bv, 0.f), h, l);
-                                    Ch[(r * 16 + lg * 4 + e) * LDA + col] = h;
-                                    Cl[(r * 16 + lg * 4 + e) * LDA + col] = l;
-                                }
+                                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                                const int o = (r * 16 + l15) * LDA + (wave * 2 + n) * 16 + lg * 4;
+                                s16_split4_store(v, Ch + o, Cl + o);
+                            }
                         }
                     }
+                    S16_STAMP(17 + 3 * f, layer == 1);
                     __syncthreads();
-                    s16_gemm<2, 8>(oh, ox, Ch + aoff, Cl + aoff, rsrc, voff,
-                                   lb + (int)(W2_W * 4) + ((wave * 2) * (F / 32) + f * 8) * 2048, (F / 32) * 2048);
+                    S16_STAMP(18 + 3 * f, layer == 1);
+                    s16_gemm_run<2, 8>(oh, ox, Ch + aoff, Cl + aoff, g, rsrc, voff, w2off(f), w2s);
+                    if (f < 3) s16_prime<2>(g, rsrc, voff, w1off(f + 1), w1s);
                     __syncthreads();
+                    S16_STAMP(19 + 3 * f, layer == 1);
                 }
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    const int col = (wave * 2 + n) * 16 + l15;
-                    const float bv = LW[W2_B + col];
+                    const s16f4 bv = bias4(LW + W2_B, wave * 2 + n);
 #pragma unroll
-                    for (int r = 0; r < RB; ++r)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += oh[r][n][e] + ox[r][n][e] * ISC + bv;
+                    for (int r = 0; r < RB; ++r) {
+                        s16f4* xp = reinterpret_cast<s16f4*>(X + (r * 16 + l15) * LDX + (wave * 2 + n) * 16 + lg * 4);
+                        *xp = *xp + (oh[r][n] + ox[r][n] * ISC + bv);
+                    }
                 }
             }
             __syncthreads();
-            layernorm_rows16<RP, LDX>(X, LW + G2, LW + BE2, wave, lane);
+            S16_STAMP(30, layer == 1);
+            s16_layernorm_split(X, LW + G2, LW + BE2, Ah, Al, wave, lane);
             __syncthreads();
-            split_x();
-            __syncthreads();
+            S16_STAMP(31, layer == 1);
         }
-        // ---- RNN input projection: IH = X W_ih^T + (b_ih + b_hh) -> HBM (:98) ----
+        S16_STAMP(40, true);
+        // ---- RNN input projection: IH = X W_ih^T + (b_ih + b_hh) -> HBM (:98), 16-byte stores ----
         {
             const size_t ih_off = LAYER0 + (size_t)L * LAYER_FLOATS;
             float* io = ih_out + (size_t)win * T * R;
@@ -469,15 +592,12 @@ __global__ __launch_bounds__(sz::THREADS) void fused_encoder_s16_kernel(
                 s16_gemm<2, D / 32>(ach, acx, Ah + aoff, Al + aoff, rsrc, voff, (int)(ih_off * 4) + nb0 * (D / 32) * 2048, (D / 32) * 2048);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    const int col = (nb0 + n) * 16 + l15;
-                    const float bv = wts[ih_off + (size_t)R * D + col];
+                    const s16f4 bv = bias4(wts + ih_off + (size_t)R * D, nb0 + n);
 #pragma unroll
-                    for (int r = 0; r < RB; ++r)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int row = r * 16 + lg * 4 + e;
-                            if (row < T) io[(size_t)row * R + col] = ach[r][n][e] + acx[r][n][e] * ISC + bv;
-                        }
+                    for (int r = 0; r < RB; ++r) {
+                        const int row = r * 16 + l15;
+                        if (row < T) *reinterpret_cast<s16f4*>(io + (size_t)row * R + (nb0 + n) * 16 + lg * 4) = ach[r][n] + acx[r][n] * ISC + bv;
+                    }
                 }
             }
         }
@@ -486,7 +606,13 @@ __global__ __launch_bounds__(sz::THREADS) void fused_encoder_s16_kernel(
             for (int i = tid; i < T * (R / 4); i += THREADS) hp[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         }
         __syncthreads();
+        S16_STAMP(41, true);
     }
+}
+
+extern "C" int tip_debug_read_s16_trace(unsigned long long* out, int n) {
+    if (!out || n < 0 || n > 64) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s16_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
 }
 
 hipError_t launch_fused_encoder_s16(const Dims& d, const float* fused_w, const float* s16_w, const float* x_imu, const float* x_s,
@@ -497,13 +623,21 @@ hipError_t launch_fused_encoder_s16(const Dims& d, const float* fused_w, const f
     static PerDeviceFlag attr_flag;
     bool& attr_set = attr_flag.cur();
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_s16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           sz::LDS_BYTES);
-        if (e != hipSuccess) return e;
+        for (const void* f : {reinterpret_cast<const void*>(fused_encoder_s16_kernel<false>), reinterpret_cast<const void*>(fused_encoder_s16_kernel<true>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, sz::LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
     const int grid = B < num_cus ? B : num_cus;
-    hipLaunchKernelGGL(fused_encoder_s16_kernel, dim3(grid), dim3(sz::THREADS), sz::LDS_BYTES, s, fused_w, s16_w, x_imu, x_s, keep_mask,
+    static const bool trace = getenv("TIP_S16_TRACE") && getenv("TIP_S16_TRACE")[0] == '1';
+    if (trace) {
+        hipLaunchKernelGGL(fused_encoder_s16_kernel<true>, dim3(grid), dim3(sz::THREADS), sz::LDS_BYTES, s, fused_w, s16_w, x_imu, x_s, keep_mask,
+                           keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,
+                           (int)(s16_packed_floats(d) * 4));
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(fused_encoder_s16_kernel<false>, dim3(grid), dim3(sz::THREADS), sz::LDS_BYTES, s, fused_w, s16_w, x_imu, x_s, keep_mask,
                        keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,
                        (int)(s16_packed_floats(d) * 4));
     return hipGetLastError();
