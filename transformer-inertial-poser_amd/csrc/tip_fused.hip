@@ -782,22 +782,50 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
         ring_prefetch<2>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
         // ---- P0 prologue (:63-78) ------------------------------------------------------------------------------------
         float* U = C;
-        for (int i = tid; i < RP * LDU; i += THREADS) U[i] = 0.f;
+        for (int i = tid; i < RP * LDU / 4; i += THREADS) reinterpret_cast<float4*>(U)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         {
-            const float* xi = x_imu + (size_t)win * T * NI;
-            for (int i = tid; i < T * NI; i += THREADS) {
-                const int r = i / NI, c = i - r * NI;
-                U[r * LDU + c] = xi[i];
+            // Round 3: rows wave, wave + 8, ... (five per wave at T = 40), a lane per column: unit-stride loads without an index
+            // division, ALL of a wave's loads in flight before the first is used, unconditional (clamped addresses), and the LDS
+            // stores through one base + COMPILE-TIME offsets.  The element loop this replaces (i = tid, tid + 512, ...: 18 trips,
+            // each a dependent HBM round trip behind an integer division) took 17.2 k cycles per window; a first attempt at
+            // batching the loads (round 2) spilled its forty store addresses and was slower.
+            constexpr int NR = (TMAX + 7) / 8;
+            float vi[NR][2], vs[NR][3], vk[NR][3];
+            const float* kmb = keep_mask ? keep_mask : x_s;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int r = wave + 8 * j;
+                const int rc = r < T ? r : T - 1;
+                const float* xi = x_imu + ((size_t)win * T + rc) * NI;
+                const float* xs = x_s + ((size_t)win * T + rc) * S;
+                const float* km = kmb + ((size_t)win * T + rc) * S;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) vi[j][q] = xi[lane + 64 * q < NI ? lane + 64 * q : NI - 1];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int c = lane + 64 * q < S ? lane + 64 * q : S - 1;
+                    vs[j][q] = xs[c];
+                    vk[j][q] = km[c];
+                }
             }
-            const float* xs = x_s + (size_t)win * T * S;
-            const float* km = keep_mask ? keep_mask + (size_t)win * T * S : nullptr;
-            for (int i = tid; i < T * S; i += THREADS) {
-                const int r = i / S, c = i - r * S;
-                float v = xs[i];
-                if (v != v) v = 0.f;                  // :65
-                if (km) v = v * km[i] * keep_scale;   // :77 with an explicit keep-mask
-                U[r * LDU + NI + c] = v;
+            float* pu_i = U + wave * LDU + lane;
+            float* pu_s = pu_i + NI;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                if (wave + 8 * j < T) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (lane + 64 * q < NI) pu_i[8 * j * LDU + 64 * q] = vi[j][q];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (lane + 64 * q < S) {
+                            float v = vs[j][q];
+                            if (v != v) v = 0.f;                               // :65
+                            if (keep_mask) v = v * vk[j][q] * keep_scale;     // :77 with an explicit keep-mask
+                            pu_s[8 * j * LDU + 64 * q] = v;
+                        }
+                }
             }
         }
         __syncthreads();
@@ -1059,28 +1087,30 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             ring_prefetch<4>(g_ih, rsrc, voff, isoff, 16 * 1024);
             gemm_phase_h<4, 16, 0, TR>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
             float* io = ih_out + (size_t)win * T * R;
+            // (opaque lane index: the store offsets are formed here, not hoisted to the top of the kernel and carried in scratch)
+            const int lo = opaque(lane), l15o = lo & 15, lgo = lo >> 4;
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                const int col = (wave * 4 + n) * 16 + l15;
+                const int col = (wave * 4 + n) * 16 + l15o;
                 const float bv = wts[ih_off_b / 4 + R * D + col];
 #pragma unroll
                 for (int r = 0; r < RBM; ++r)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int row = r * 16 + lg * 4 + e;
+                        const int row = r * 16 + lgo * 4 + e;
                         if (row < T) io[(size_t)row * R + col] = acc[r][n][e] + bv;
                     }
 #pragma unroll
                 for (int r = 0; r < RBT; ++r) {
                     const float v = tail_reduce(acct[r][n], lg) + bv;
-                    const int row = TAIL0 + 4 * r + lg;
+                    const int row = TAIL0 + 4 * r + lgo;
                     if (row < T) io[(size_t)row * R + col] = v;
                 }
             }
         }
         if (hall_sentinel) {
             uint4* hp = reinterpret_cast<uint4*>(hall_sentinel + (size_t)win * T * R);
-            for (int i = tid; i < T * (R / 4); i += THREADS) hp[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            for (int i = opaque(tid); i < T * (R / 4); i += THREADS) hp[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         }
         if (xout) {
             float* out = xout + (size_t)win * T * D;
