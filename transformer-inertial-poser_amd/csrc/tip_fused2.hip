@@ -120,25 +120,51 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
         // (an OPAQUE copy of the thread index: with the plain one the compiler hoists every per-thread row / column split of
         // the staging loops and of the IH store epilogue out of the pair loop and carries them — 27 VGPRs — across the whole
         // kernel, in scratch; recomputing them here costs a few dozen VALU instructions per pair)
-        int tp = tid;
-        asm volatile("" : "+v"(tp));
         float* U = C;
-        for (int i = tp; i < ROWS * LDU; i += THREADS) U[i] = 0.f;
+        for (int i = tid; i < ROWS * LDU / 4; i += THREADS) reinterpret_cast<float4*>(U)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
-        for (int w = 0; w < nwin; ++w) {
-            const float* xi = x_imu + (size_t)(win0 + w) * T * NI;
-            for (int i = tp; i < T * NI; i += THREADS) {
-                const int r = i / NI, c = i - r * NI;
-                U[(w * T + r) * LDU + c] = xi[i];
+        {
+            // Round 3 (as in fused_encoder_h_kernel): rows wave, wave + 8, ... of the 80 (ten per wave), a lane per column — unit-stride
+            // loads without an index division, ALL of them in flight before the first is used, unconditional (clamped addresses),
+            // LDS stores through one base + compile-time offsets.  The element loops this replaces were 36 dependent HBM round trips
+            // per window pair.
+            constexpr int NR = (ROWS + 7) / 8;     // 10
+            const int nrows = nwin * T;
+            float vi[NR][2], vs[NR][3], vk[NR][3];
+            const float* kmb = keep_mask ? keep_mask : x_s;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int r = wave + 8 * j;              // row of the pair: window r / T, frame r % T (the two windows are consecutive)
+                const int rc = r < nrows ? r : nrows - 1;
+                const float* xi = x_imu + ((size_t)win0 * T + rc) * NI;
+                const float* xs = x_s + ((size_t)win0 * T + rc) * S;
+                const float* km = kmb + ((size_t)win0 * T + rc) * S;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) vi[j][q] = xi[lane + 64 * q < NI ? lane + 64 * q : NI - 1];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int c = lane + 64 * q < S ? lane + 64 * q : S - 1;
+                    vs[j][q] = xs[c];
+                    vk[j][q] = km[c];
+                }
             }
-            const float* xs = x_s + (size_t)(win0 + w) * T * S;
-            const float* km = keep_mask ? keep_mask + (size_t)(win0 + w) * T * S : nullptr;
-            for (int i = tp; i < T * S; i += THREADS) {
-                const int r = i / S, c = i - r * S;
-                float v = xs[i];
-                if (v != v) v = 0.f;                  // :65
-                if (km) v = v * km[i] * keep_scale;   // :77
-                U[(w * T + r) * LDU + NI + c] = v;
+            float* pu_i = U + wave * LDU + lane;
+            float* pu_s = pu_i + NI;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                if (wave + 8 * j < nrows) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (lane + 64 * q < NI) pu_i[8 * j * LDU + 64 * q] = vi[j][q];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        if (lane + 64 * q < S) {
+                            float v = vs[j][q];
+                            if (v != v) v = 0.f;                               // :65
+                            if (keep_mask) v = v * vk[j][q] * keep_scale;     // :77
+                            pu_s[8 * j * LDU + 64 * q] = v;
+                        }
+                }
             }
         }
         __syncthreads();
