@@ -376,6 +376,34 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
                                               "60 frames of a cold process (clock ramp + first-use kernel loads), not the loop")
     except Exception as e:
         out["stream1_closed_loop"] = {"error": f"{type(e).__name__}: {e}"}
+    # -- EXPLORATORY, never the headline: plan "fused16" (csrc/tip_s16.hip) — the same forward with every GEMM's fp32 operands
+    #    emulated on the fp16 matrix cores (operands split hi + lo * 2^-11 = 22 significant bits, three f16 MFMAs per product, fp32
+    #    accumulation; attention core / LayerNorm / residual stream in fp32).  Reported with its own dtype label, its error against
+    #    the fp64 oracle next to the fp32-MFMA plan's on the same windows, and the timing of both on this run's clock.
+    try:
+        from oracle import oracle as _oracle
+        x256i, x256s = xi[:256].contiguous(), xs[:256].contiguous()
+        res = {"dtype": "f32 emulated as split fp16 (hi + lo * 2^-11: 22-bit operands), fp32 accumulate; attention / LayerNorm / residual fp32",
+               "batch": int(x256i.shape[0]), "T": T, "status": "opt-in plan (set_plan('fused16')), never chosen by AUTO"}
+        w_np = synth.make_weights(cfg, seed=0)
+        nref = 4
+        yo = _oracle.forward(cfg, w_np, x256i[:nref].cpu().numpy(), x256s[:nref].cpu().numpy(), dtype=np.float64)
+        for plan_name in ("fusedh", "fused16"):
+            model.set_plan(plan_name)
+            for _ in range(20):
+                model(x256i, x256s)
+            torch.cuda.synchronize()
+            ms = timed_loop(lambda: model(x256i, x256s), 200)
+            err = float(np.abs(model(x256i[:nref], x256s[:nref]).cpu().numpy() - yo).max())
+            key = "fp32_mfma_plan_fusedh" if plan_name == "fusedh" else "split_fp16_plan_fused16"
+            res[key] = {"ms_per_step": ms, "frames_per_s": x256i.shape[0] / (ms * 1e-3), "max_abs_err_vs_fp64_oracle": err}
+        res["speedup_vs_fp32_mfma_plan"] = res["fp32_mfma_plan_fusedh"]["ms_per_step"] / res["split_fp16_plan_fused16"]["ms_per_step"]
+        res["fp32_equivalent_tflops"] = res["split_fp16_plan_fused16"]["frames_per_s"] * fpw / 1e12
+        model.set_plan("auto")
+        out["exploratory_fused16"] = res
+    except Exception as e:
+        model.set_plan("auto")
+        out["exploratory_fused16"] = {"error": f"{type(e).__name__}: {e}"}
     # -- row a14 / f-2: the training-mode model call and its backward (train_model.py:171-196) at the reference's batch size,
     #    HIP kernels in both directions, encoder dropout p = 0.1 live; forward, forward+backward (3x the forward FLOPs) and the
     #    whole step with clip + AdamW
@@ -415,7 +443,7 @@ def main():
     ap.add_argument("--config", default="paper256", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="windows (IMU streams) per GPU; 0 = the configuration's own")
     ap.add_argument("--seq-len", type=int, default=0)
-    ap.add_argument("--plan", default="auto", choices=["auto", "general", "fused", "latency", "fused2", "fused2s", "fusedh"])
+    ap.add_argument("--plan", default="auto", choices=["auto", "general", "fused", "latency", "fused2", "fused2s", "fusedh", "fused16"])
     ap.add_argument("--rnn-cluster", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.configs / extra.sustained (headline line only)")

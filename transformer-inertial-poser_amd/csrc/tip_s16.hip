@@ -185,6 +185,14 @@ template <int NBW, int KB, int PLAIN_FROM = NBW>
 __device__ __forceinline__ void s16_gemm_run(s16f4 (&acc_h)[sz::RB][NBW], s16f4 (&acc_x)[sz::RB][NBW], const _Float16* Ap,
                                              const _Float16* Alp, S16Ring<NBW>& g, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff,
                                              int nstride_b) {
+    // A fragments (LDS) one k-block ahead as well: with the scheduling barrier per k-block they would otherwise be requested and
+    // waited for in front of every block's MFMAs
+    s16h8 ah[2][sz::RB], al[2][sz::RB];
+#pragma unroll
+    for (int r = 0; r < sz::RB; ++r) {
+        ah[0][r] = *reinterpret_cast<const s16h8*>(Ap + r * 16 * sz::LDA);
+        al[0][r] = *reinterpret_cast<const s16h8*>(Alp + r * 16 * sz::LDA);
+    }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         if (kb + 2 < KB) {
@@ -194,27 +202,28 @@ __device__ __forceinline__ void s16_gemm_run(s16f4 (&acc_h)[sz::RB][NBW], s16f4 
                 g.bl[(kb + 2) % 3][n] = s16_ldw(rsrc, voff, soff + n * nstride_b + (kb + 2) * 2048 + 1024);
             }
         }
-        s16h8 ah[sz::RB], al[sz::RB];
+        if (kb + 1 < KB) {
 #pragma unroll
-        for (int r = 0; r < sz::RB; ++r) {
-            ah[r] = *reinterpret_cast<const s16h8*>(Ap + r * 16 * sz::LDA + kb * 32);
-            al[r] = *reinterpret_cast<const s16h8*>(Alp + r * 16 * sz::LDA + kb * 32);
-        }
-        const int c = kb % 3;
-#pragma unroll
-        for (int r = 0; r < sz::RB; ++r)
-#pragma unroll
-            for (int n = 0; n < NBW; ++n) {
-                if (n < PLAIN_FROM) {
-                    acc_h[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g.bh[c][n], ah[r], acc_h[r][n], 0, 0, 0);
-                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g.bl[c][n], ah[r], acc_x[r][n], 0, 0, 0);
-                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(g.bh[c][n], al[r], acc_x[r][n], 0, 0, 0);
-                } else {
-                    acc_h[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], g.bh[c][n], acc_h[r][n], 0, 0, 0);
-                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], g.bl[c][n], acc_x[r][n], 0, 0, 0);
-                    acc_x[r][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r], g.bh[c][n], acc_x[r][n], 0, 0, 0);
-                }
+            for (int r = 0; r < sz::RB; ++r) {
+                ah[(kb + 1) & 1][r] = *reinterpret_cast<const s16h8*>(Ap + r * 16 * sz::LDA + (kb + 1) * 32);
+                al[(kb + 1) & 1][r] = *reinterpret_cast<const s16h8*>(Alp + r * 16 * sz::LDA + (kb + 1) * 32);
             }
+        }
+        const int c = kb % 3, a = kb & 1;
+        // three sweeps over the tiles (hh, hl, lh) rather than three MFMAs per tile: the two cross products of a tile go into the
+        // same accumulator, and back to back the second would wait for the first's result
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+            for (int r = 0; r < sz::RB; ++r)
+#pragma unroll
+                for (int n = 0; n < NBW; ++n) {
+                    const s16h8 wv = pass == 1 ? g.bl[c][n] : g.bh[c][n];
+                    const s16h8 av = pass == 2 ? al[a][r] : ah[a][r];
+                    s16f4& acc = pass == 0 ? acc_h[r][n] : acc_x[r][n];
+                    acc = n < PLAIN_FROM ? __builtin_amdgcn_mfma_f32_16x16x32_f16(wv, av, acc, 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_16x16x32_f16(av, wv, acc, 0, 0, 0);
+                }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
