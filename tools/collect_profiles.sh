@@ -4,7 +4,7 @@
 # Everything lands in gpurun_out/<round>/; copy what should be judged into profiles/<round>/ afterwards.
 # PMC passes are run separately from each other and with --kernel-trace only (no sys/hip/hsa trace domains).
 set -u
-ROUND=${1:-r02}
+ROUND=${1:-r03}
 OUT=$PWD/gpurun_out/$ROUND
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -81,5 +81,14 @@ timeout 300 python tools/rnn_variants2.py 2> /dev/null | grep "^B=" > "$OUT/rnn_
 { for a in 0 2; do echo "TIP_RNN_ABLATE=$a"; TIP_RNN_ABLATE=$a timeout 120 python tools/rnn_tsweep.py 256 2> /dev/null | grep "^B=\|^fit"; done; } > "$OUT/rnn_tsweep_B256.txt"
 timeout 600 python tools/rnn_soak.py 300 2> /dev/null | grep -v "^model\|^number" > "$OUT/rnn_soak.txt"
 timeout 300 python tools/plan_bench.py 256 300 512 1024 2> /dev/null | grep "^B=" > "$OUT/plan_bench.txt"
-for p in mfma4x4_probe hop_probe permlane_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
+# round 3: output projection tile stamps / per-workgroup lifetimes, launch-ramp probe, the exploratory split-fp16 plan
+TIP_HEAD_TRACE=1 timeout 300 python tools/head_trace.py 256 2> /dev/null | grep -v "^model\|^number" > "$OUT/head_trace_B256.txt"
+TIP_HEAD_TRACE=1 timeout 300 python tools/head_trace.py 1024 2> /dev/null | grep -v "^model\|^number" > "$OUT/head_trace_B1024.txt"
+TIP_S16_TRACE=1 timeout 300 python tools/s16_trace.py 2> /dev/null | grep -v "^model\|^number" > "$OUT/s16_trace_B256.txt"
+timeout 300 python tools/stream_latency.py 1 400 2> /dev/null | grep "^{" > "$OUT/stream_latency_n1.json"
+d=/tmp/prof_f16; rm -rf $d
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $d -- $BENCH --plan fused16 > "$OUT/bench_fused16_under_rocprof.json" 2> /dev/null)
+t=$(find $d -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python tools/kstats_table.py "$t" > "$OUT/kernel_medians_bench_fused16_B256_T40.txt"
+timeout 300 python bench.py --plan fused16 --no-cpu-baseline --no-extra --steps 300 --warmup 20 > "$OUT/bench_fused16_n1.json" 2> /dev/null
+for p in mfma4x4_probe hop_probe permlane_probe launch_probe ffn_split16_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
 ls -la "$OUT"

@@ -17,7 +17,7 @@ m.set_plan("fusedh")
 x_imu, x_s = synth.make_inputs(cfg, 256, 40)
 xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
 with torch.no_grad():
-    for _ in range(5):
+    for _ in range(300):        # long enough for the clocks to settle
         m(xi, xs)
     torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 64)()
@@ -47,3 +47,14 @@ row("LayerNorm2 + barrier", d(31, 32))
 row("whole layer 1", d(8, 32))
 print("tail: RNN input projection + stores + sentinel", d(40, 41), "cyc =", d(40, 41) / GHZ / 1e3, "us")
 print("whole window (prologue .. end):", d(0, 41), "cyc =", d(0, 41) / GHZ / 1e3, "us")
+
+wg = (ctypes.c_ulonglong * 512)()
+if tlib.load().tip_debug_read_fh_wg(wg, 512) == 0:
+    w = np.array(wg[:], dtype=np.float64).reshape(256, 2) / 100.0       # us (s_memrealtime: 100 MHz, one counter for the device)
+    t0 = w[:, 0].min()
+    dur = w[:, 1] - w[:, 0]
+    print(f"all 256 workgroups: entries spread {w[:, 0].max() - t0:.2f} us; first entry -> last exit {w[:, 1].max() - t0:.2f} us")
+    print(f"  lifetime per workgroup: min {dur.min():.2f}  median {np.median(dur):.2f}  p90 {np.percentile(dur, 90):.2f}  max {dur.max():.2f} us")
+    print("  median lifetime per XCD (workgroup id % 8):", [round(float(np.median(dur[np.arange(256) % 8 == x])), 2) for x in range(8)])
+    order = np.argsort(-dur)[:6]
+    print("  slowest:", [(int(i), round(float(dur[i]), 2)) for i in order])

@@ -746,6 +746,7 @@ __device__ __forceinline__ f32x4 tail_gather_v(const f32x4& a0, const f32x4& a1,
 
 // measurement only (TIP_FUSEDH_TRACE=1): s_memtime stamps of workgroup 0 / thread 0 at the phase boundaries of layer 1
 __device__ unsigned long long g_fh_trace[64];
+__device__ unsigned long long g_fh_wg[2 * 1024];   // TRACE: [workgroup][entry, exit] in s_memrealtime ticks (100 MHz, device-wide)
 #define FH_STAMP(slot) do { if (TRACE && blockIdx.x == 0 && tid == 0 && (layer == 1 || (slot) < 4 || (slot) >= 40)) g_fh_trace[slot] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // TR: training forward (tip_train_forward) — the encoder's four dropout sites and the activation stash of the backward, exactly
@@ -777,6 +778,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
         {
         const int layer = -1;
         FH_STAMP(0);
+        if (TRACE && tid == 0 && win == (int)blockIdx.x && blockIdx.x < 1024) g_fh_wg[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         const int in_soff = (int)(IN_W * 4) + (wave * 2) * (KIN / 16) * 1024;
         WRing<2> g_in;
         ring_prefetch<2>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
@@ -1121,6 +1123,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
         }
         __syncthreads();
         { const int layer = -1; FH_STAMP(41); }
+        if (TRACE && tid == 0 && blockIdx.x < 1024) g_fh_wg[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     }
 }
 #undef FH_STAMP
@@ -1173,6 +1176,10 @@ hipError_t launch_fused_train_h(const Dims& d, const float* fused_w, const float
 }
 
 }  // namespace tip
+extern "C" int tip_debug_read_fh_wg(unsigned long long* out, int n) {
+    if (!out || n < 0 || n > 2048) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(tip::g_fh_wg), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
+}
 extern "C" int tip_debug_read_fh_trace(unsigned long long* out, int n) {
     if (!out || n < 0 || n > 64) return -1;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(tip::g_fh_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
