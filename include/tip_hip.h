@@ -144,7 +144,10 @@ int tip_spin_timeouts(unsigned* count);
  * TIP_ERR_HANDOFF at entry, i.e. the call AFTER the failed launch completed reports it.  tip_check(h, 0) returns
  * TIP_ERR_HANDOFF or TIP_OK without synchronising (synchronise the stream first for a definitive answer about launches in
  * flight); tip_check(h, 1) also clears the word.  The GPU must be exclusively this process's for the cooperating plans to
- * run at speed; TIP_PLAN_FUSED / TIP_PLAN_GENERAL with TIP_OPT_RNN_CLUSTER = 1 need no co-residency at all. */
+ * run at speed; TIP_PLAN_FUSED / TIP_PLAN_GENERAL with TIP_OPT_RNN_CLUSTER = 1 need no co-residency at all.
+ * Inside one process the library keeps the promise itself: tip_forward / tip_train_forward / tip_train_backward calls issued on
+ * DIFFERENT streams (any handle) are serialised on the device (one event wait per stream switch), and a stream created with a CU
+ * mask (hipExtStreamCreateWithCUMask) gets plan, grid and cluster sizes for the CUs its mask leaves. */
 int tip_check(tip_handle* h, int clear);
 
 /* ---- streaming front/back-end: the model-facing half of RTRunnerMin.step

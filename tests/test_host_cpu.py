@@ -156,6 +156,45 @@ def test_packed_image_folds():
     assert np.array_equal(blk, exp)
 
 
+def test_packed_image_split_fp16_section():
+    """The exploratory split-fp16 copy of the fused section (csrc/tip_s16.hip, plan "fused16"): the last section of the packed
+    image holds, at the fused section's own float offsets, every weight matrix as [column block][32-k block][hi | lo][64 lanes][8
+    halfs] with hi = fp16(w), lo = fp16((w - hi) * 2^11) — so hi + lo * 2^-11 reproduces w to 22 bits and every fold of the fp32
+    image carries over."""
+    cfg = synth.PAPER
+    m = make_model(cfg)
+    load_synth(m, cfg, 0)
+    img = m.pack_host().numpy()
+    f32 = img.view(np.float32)
+    NF = 3352320                                        # fused_packed_floats of the paper configuration (64-float aligned)
+    assert f32.size >= 2 * NF
+    fused, s16 = f32[-2 * NF:-NF], f32[-NF:].view(np.float16)
+    LAYER0, LAYER_FLOATS = 57600, 789760
+    W1_W = 3 * 256 * 256 + 3 * 256 + 256 * 256 + 256
+    for (off, N, K) in ((0, 256, 224), (LAYER0, 768, 256), (LAYER0 + 2 * LAYER_FLOATS + W1_W, 1024, 256),
+                        (LAYER0 + 4 * LAYER_FLOATS, 512, 256)):
+        KB = K // 32
+        rng = np.random.RandomState(off % 1000)
+        for _ in range(6):
+            nb, kb = int(rng.randint(N // 16)), int(rng.randint(KB))
+            lane = np.arange(64)[:, None]
+            i = np.arange(8)[None, :]
+            n, k = nb * 16 + (lane & 15), kb * 32 + (lane >> 4) * 8 + i
+            src = (((n >> 4) * (K >> 4) + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + (n & 15)) * 4 + (k & 3)   # 16x16x4 fragment order
+            w = fused[off + src]
+            base = off * 2 + ((nb * KB + kb) * 2) * 512
+            hi = s16[base: base + 512].reshape(64, 8)
+            lo = s16[base + 512: base + 1024].reshape(64, 8)
+            eh = w.astype(np.float16)
+            assert np.array_equal(hi, eh)
+            assert np.array_equal(lo, ((w - eh.astype(np.float32)) * np.float32(2048.0)).astype(np.float16))
+            rec = hi.astype(np.float64) + lo.astype(np.float64) / 2048.0
+            assert np.abs(rec - w).max() <= 2.0 ** -21 * np.abs(w).max() + 1e-12
+    # the scaled configuration has no fused section, hence no split copy: the image is what it was
+    ms = make_model(synth.TINY)
+    assert ms._ensure_handle().packed_bytes() % 256 == 0
+
+
 def test_zero_edit_drop_in_import_path():
     """`from simple_transformer_with_state import TF_RNN_Past_State` (train_model.py:14) must resolve to our module
     when the package directory is put first on PYTHONPATH."""
