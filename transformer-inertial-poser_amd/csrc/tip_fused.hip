@@ -1087,7 +1087,10 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             const int isoff = ih_off_b + (wave * 4) * 16 * 1024;
             WRing<4> g_ih;
             ring_prefetch<4>(g_ih, rsrc, voff, isoff, 16 * 1024);
-            gemm_phase_h<4, 16, 0, TR>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
+            // Round 3: the 16-row blocks with SWAPPED operands — transposed accumulators, (columns 16 n + 4 lg + e, row 16 r + l15): a
+            // lane stores four consecutive columns of one row with ONE 16-byte store instead of four scattered 4-byte ones (the
+            // store tail is issue-bound: 32 -> 8 store instructions per wave for rows 0-31).  Same products, same sums.
+            gemm_phase_h<4, 16, 4, TR>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
             float* io = ih_out + (size_t)win * T * R;
             // (opaque lane index: the store offsets are formed here, not hoisted to the top of the kernel and carried in scratch)
             const int lo = opaque(lane), l15o = lo & 15, lgo = lo >> 4;
@@ -1095,13 +1098,12 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             for (int n = 0; n < 4; ++n) {
                 const int col = (wave * 4 + n) * 16 + l15o;
                 const float bv = wts[ih_off_b / 4 + R * D + col];
+                const f32x4 bv4 = *reinterpret_cast<const f32x4*>(wts + ih_off_b / 4 + R * D + (wave * 4 + n) * 16 + lgo * 4);
 #pragma unroll
-                for (int r = 0; r < RBM; ++r)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int row = r * 16 + lgo * 4 + e;
-                        if (row < T) io[(size_t)row * R + col] = acc[r][n][e] + bv;
-                    }
+                for (int r = 0; r < RBM; ++r) {
+                    const int row = r * 16 + l15o;
+                    if (row < T) *reinterpret_cast<f32x4*>(io + (size_t)row * R + (wave * 4 + n) * 16 + lgo * 4) = acc[r][n] + bv4;
+                }
 #pragma unroll
                 for (int r = 0; r < RBT; ++r) {
                     const float v = tail_reduce(acct[r][n], lg) + bv;
