@@ -10,7 +10,7 @@ import tip_amd
 from tip_amd import synth
 from oracle import train_oracle
 from test_host_cpu import make_model, load_synth
-from test_train_oracle import GOLD, CASES, case_inputs, check_y, digest_close
+from test_train_oracle import GOLD, CASES, COND_GOLD, COND_GAINS, case_inputs, check_y, digest_close
 
 pytestmark = pytest.mark.gpu
 
@@ -67,6 +67,36 @@ def _check_grads(g, go, rel=REL):
         assert np.isfinite(g[n]).all(), n
         assert err < rel, (n, err)
     return worst
+
+
+@pytest.mark.parametrize("gain", COND_GAINS)
+def test_gradients_outside_random_init(gain):
+    """Training parity outside the random-init regime (weights x gain 2 / 3; goldens from the reference run in fp32 AND fp64):
+    every one of the 56 gradient tensors of the HIP step within max(1e-5, 3 x the reference's own fp32 gradient noise) of the
+    fp64 oracle (relative L2; the oracle differentiates the linear piece the run under test was on), y within 2e-5 / 3 x noise."""
+    z = np.load(COND_GOLD)
+    cfg = synth.PAPER
+    m = make_model(cfg)
+    w = synth.make_weights(cfg, seed=0, gain=gain)
+    m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+    m = m.cuda().train()
+    m.ENCODER_DROPOUT = 0.0
+    m.keep_train_stash = True
+    tag = f"traincond_g{gain:g}"
+    x_imu, x_s, cot = z["x_imu"], z["x_s"], z["cot"]
+    y, g, _ = _hip_step(m, x_imu, x_s, cot)
+    ynoise = float(np.abs(z[tag + "/y32"] - z[tag + "/y64"]).max())
+    assert np.abs(y - z[tag + "/y64"]).max() <= max(2e-5, 3 * ynoise)
+    B, T = x_imu.shape[:2]
+    yo, go = train_oracle.step(cfg, w, x_imu, x_s, cot, relu_gates=_gates(m, cfg, B, T))
+    noise = z[tag + "/ref_grad_noise"]
+    worst = 0.0
+    for i, (n, ref) in enumerate(go.items()):
+        err = np.linalg.norm(g[n].astype(np.float64) - ref) / (np.linalg.norm(ref) + 1e-30)
+        assert np.isfinite(g[n]).all(), n
+        assert err <= max(1e-5, 3.0 * float(noise[i])), (n, err, float(noise[i]))
+        worst = max(worst, err / max(float(noise[i]), 1e-7))
+    print(f"gain {gain}: worst HIP gradient error / reference fp32 gradient noise = {worst:.2f}")
 
 
 @pytest.mark.parametrize("tag", list(CASES))

@@ -62,6 +62,31 @@ def test_oracle_matches_reference_gradients(tag):
         digest_close(n, train_oracle.digest(n, grads[n]), z[tag + "/digests"][i])
 
 
+COND_GOLD = os.path.join(os.path.dirname(__file__), "golden", "tip_train_cond_golden.npz")
+COND_GAINS = (2.0, 3.0)
+
+
+@pytest.mark.parametrize("gain", COND_GAINS)
+def test_oracle_matches_reference_gradients_outside_random_init(gain):
+    """The training conditioning cases (tests/golden/make_train_golden.py --cond: weights x gain 2 / 3): the fp64 oracle against
+    digests of the reference's fp64 gradients (tight) and of its fp32 gradients (to the reference's own fp32 noise)."""
+    z = np.load(COND_GOLD)
+    cfg = synth.PAPER
+    w = synth.make_weights(cfg, seed=0, gain=gain)
+    tag = f"traincond_g{gain:g}"
+    y, grads = train_oracle.step(cfg, w, z["x_imu"], z["x_s"], z["cot"])
+    assert np.abs(y - z[tag + "/y64"]).max() < 1e-10
+    names = list(w.keys())
+    gn = np.sqrt(sum((g.astype(np.float64) ** 2).sum() for g in grads.values()))
+    assert abs(gn - z[tag + "/gnorm"][0]) < 1e-9 * gn
+    noise = z[tag + "/ref_grad_noise"]
+    assert noise.max() < 1e-4
+    for i, n in enumerate(names):
+        d = train_oracle.digest(n, grads[n])
+        digest_close(n, d, z[tag + "/digests64"][i], rtol=1e-9)
+        digest_close(n, d, z[tag + "/digests"][i], rtol=max(2e-4, 20 * float(noise[i])))
+
+
 def test_dropout_hash_statistics_and_determinism():
     a = train_oracle.drop_scale(1234, 5, 200000, 0.1)
     b = train_oracle.drop_scale(1234, 5, 200000, 0.1)
