@@ -42,7 +42,23 @@ def cond_golden():
         cases.setdefault(tag, {})[name] = z[k]
     for c in cases.values():
         c["noise"] = max(float(np.abs(c["y32"] - c["y64"]).max()), float(np.abs(c["y32_alt"] - c["y64"]).max()))
-    return {"x_imu": z["x_imu"], "x_s": z["x_s"], "cases": cases}
+    # tags "g<gain>_ln<gamma>": paper configuration on the stored windows; "<config>__g.._ln..": another width, inputs regenerated
+    paper = {t: c for t, c in cases.items() if "__" not in t}
+    other = {t: c for t, c in cases.items() if "__" in t}
+    return {"x_imu": z["x_imu"], "x_s": z["x_s"], "cases": paper, "other": other}
+
+
+def cond_other_case(tag, c):
+    """(cfg, weights, x_imu, x_s) of a non-paper conditioning case (tests/golden/make_golden.py --cond)."""
+    import tip_amd
+    s = tip_amd.synth
+    name = tag.split("__")[0]
+    cfg = {"scaled2": dict(s.SCALED, tf_layers=2), "tiny": s.TINY}[name]
+    g, lg = (float(v) for v in c["gain_ln"])
+    B, T = (int(v) for v in c["shape"])
+    w = s.make_weights(cfg, seed=0, gain=g, ln_gamma=lg)
+    x_imu, x_s = s.make_inputs(cfg, B, T, seed=4321)
+    return cfg, w, x_imu, x_s
 
 
 def cfg_for_tag(tag):

@@ -161,6 +161,24 @@ COND_GAINS = (1.0, 1.5, 2.0, 3.0, 4.0)
 COND_LN = (1.0, 3.0)
 
 
+def _cond_case(out, tag, cfg, w, x_imu, x_s, B):
+    m32 = build_ref(cfg, w, torch.float32)
+    y32, _ = run_ref(m32, x_imu, x_s, torch.float32, False)
+    # the same windows one at a time on one thread: other GEMM blocking, other rounding, same arithmetic
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(1)
+    y32_alt = np.concatenate([run_ref(m32, x_imu[b:b + 1], x_s[b:b + 1], torch.float32, False)[0] for b in range(B)], axis=0)
+    torch.set_num_threads(nthr)
+    m64 = build_ref(cfg, w, torch.float64)
+    y64, _ = run_ref(m64, x_imu.astype(np.float64), x_s.astype(np.float64), torch.float64, False)
+    out[tag + "/y32"] = y32.astype(np.float32)
+    out[tag + "/y32_alt"] = y32_alt.astype(np.float32)
+    out[tag + "/y64"] = y64
+    out[tag + "/wsum"] = weights_checksum(w)
+    n1, n2 = np.abs(y32 - y64).max(), np.abs(y32_alt - y64).max()
+    print(f"{tag}: reference fp32 noise {n1:.3e} / {n2:.3e} (alt shape)   |y|max = {np.abs(y64).max():.3f}")
+
+
 def cond_main():
     """Conditioning sweep (reference: /root/reference/simple_transformer_with_state.py:60-102 run as-is)."""
     cfg, seed, B, T = synth.PAPER, 0, 2, 40
@@ -171,24 +189,20 @@ def cond_main():
             if g == 1.0 and lg == 1.0:
                 continue                       # the random-init regime is tip_forward_golden.npz
             w = synth.make_weights(cfg, seed=seed, gain=g, ln_gamma=lg)
-            m32 = build_ref(cfg, w, torch.float32)
-            y32, _ = run_ref(m32, x_imu, x_s, torch.float32, False)
-            # the same windows one at a time on one thread: other GEMM blocking, other rounding, same arithmetic
-            nthr = torch.get_num_threads()
-            torch.set_num_threads(1)
-            y32_alt = np.concatenate([run_ref(m32, x_imu[b:b + 1], x_s[b:b + 1], torch.float32, False)[0]
-                                      for b in range(B)], axis=0)
-            torch.set_num_threads(nthr)
-            m64 = build_ref(cfg, w, torch.float64)
-            y64, _ = run_ref(m64, x_imu.astype(np.float64), x_s.astype(np.float64), torch.float64, False)
             tag = f"g{g:g}_ln{lg:g}"
-            out[tag + "/y32"] = y32.astype(np.float32)
-            out[tag + "/y32_alt"] = y32_alt.astype(np.float32)
-            out[tag + "/y64"] = y64
-            out[tag + "/wsum"] = weights_checksum(w)
+            _cond_case(out, tag, cfg, w, x_imu, x_s, B)
             out[tag + "/gain_ln"] = np.array([g, lg])
-            n1, n2 = np.abs(y32 - y64).max(), np.abs(y32_alt - y64).max()
-            print(f"{tag}: reference fp32 noise {n1:.3e} / {n2:.3e} (alt shape)   |y|max = {np.abs(y64).max():.3f}")
+    # other widths (the general plan's GEMM / attention kernels: d_head 64 and 32, rnn 192, T = 80): inputs are regenerated by the
+    # tests from the seeds, tag = <config>__g<gain>_ln<gamma>
+    for name, c2, B2, T2, g, lg in (("scaled2", dict(synth.SCALED, tf_layers=2), 2, 80, 2.0, 1.0),
+                                    ("scaled2", dict(synth.SCALED, tf_layers=2), 2, 80, 3.0, 3.0),
+                                    ("tiny", synth.TINY, 3, 33, 3.0, 1.0), ("tiny", synth.TINY, 3, 33, 4.0, 3.0)):
+        xi2, xs2 = synth.make_inputs(c2, B2, T2, seed=4321)
+        w = synth.make_weights(c2, seed=seed, gain=g, ln_gamma=lg)
+        tag = f"{name}__g{g:g}_ln{lg:g}"
+        _cond_case(out, tag, c2, w, xi2, xs2, B2)
+        out[tag + "/gain_ln"] = np.array([g, lg])
+        out[tag + "/shape"] = np.array([B2, T2])
     torch.set_default_dtype(torch.float32)
     path = os.path.join(HERE, "tip_cond_golden.npz")
     np.savez_compressed(path, **out)

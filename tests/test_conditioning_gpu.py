@@ -19,6 +19,7 @@ import torch
 
 from tip_amd import synth
 from test_host_cpu import make_model
+from conftest import cond_other_case
 
 pytestmark = pytest.mark.gpu
 
@@ -71,3 +72,24 @@ def test_conditioning_sweep_all_plans(cond_golden):
     except OSError:
         pass
     print("worst HIP-error / reference-noise ratio:", worst)
+
+
+def test_conditioning_other_widths_general_plan(cond_golden):
+    """The same bar for the configurations only the general plan serves (scaled widths d = 1024 / d_head 64 at 2 layers with
+    T = 80 — the panel GEMM and the matrix-core attention —, and the small configuration with d_head 32 / rnn 192 at T = 33)."""
+    assert torch.cuda.is_available()
+    for tag, c in sorted(cond_golden["other"].items()):
+        cfg, w, x_imu, x_s = cond_other_case(tag, c)
+        m = make_model(cfg)
+        m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
+        m = m.cuda().eval()
+        n0 = m.hip_forward_count()
+        with torch.no_grad():
+            y = m(torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()).cpu().numpy()
+            yl = m.forward_last(torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()).cpu().numpy()
+        assert m.hip_forward_count() == n0 + 2
+        err, noise = float(np.abs(y - c["y64"]).max()), c["noise"]
+        bound = max(2e-5, 3.0 * noise)
+        assert np.isfinite(y).all() and err <= bound, (tag, err, noise)
+        assert np.abs(yl - c["y64"][:, -1]).max() <= bound, (tag, "last row")
+        print(f"{tag}: HIP error / reference fp32 noise = {err / noise:.2f}")

@@ -6,7 +6,7 @@ import pytest
 import tip_amd
 from tip_amd import synth
 from oracle import oracle
-from conftest import cfg_for_tag, seed_for_tag
+from conftest import cfg_for_tag, seed_for_tag, cond_other_case
 
 
 def _weights_for(tag, case):
@@ -70,6 +70,17 @@ def test_oracle_conditioning_sweep(cond_golden):
         # fp64 rounding (1e-16) is amplified like fp32 rounding (6e-8): noise * 2^-29 * margin
         assert e64 < max(1e-12, c["noise"] * 1e-7), (tag, e64, c["noise"])
         assert e32 < max(5e-6, 3.0 * c["noise"]), (tag, e32, c["noise"])
+    # other widths (d_head 64 / 32, rnn 192, T = 80 / 33): the general plan's territory
+    assert len(cond_golden["other"]) == 4
+    for tag, c in cond_golden["other"].items():
+        cfg2, w, xi2, xs2 = cond_other_case(tag, c)
+        s = sum(float(v.astype(np.float64).sum()) for v in w.values())
+        s2 = sum(float((v.astype(np.float64) ** 2).sum()) for v in w.values())
+        np.testing.assert_allclose([s, s2], c["wsum"], rtol=1e-12)
+        y64 = oracle.forward(cfg2, w, xi2, xs2, dtype=np.float64)
+        y32 = oracle.forward(cfg2, w, xi2, xs2, dtype=np.float32)
+        assert np.abs(y64 - c["y64"]).max() < max(1e-12, c["noise"] * 1e-7), tag
+        assert np.abs(y32 - c["y64"]).max() < max(5e-6, 3.0 * c["noise"]), tag
 
 
 def test_oracle_taps_match_reference_hooks(golden):
