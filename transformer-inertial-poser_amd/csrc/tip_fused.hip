@@ -832,6 +832,9 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
         }
         __syncthreads();
         FH_STAMP(1);
+        // training forward: the staged input rows are dW_in's operand in the backward — stashed from here instead of by a launch of
+        // their own (tip_train.hip)
+        if (TR && tr.u) rows_to_hbm(U, LDU, KIN, tr.sv + (size_t)tr.u * 64 + (size_t)win * T * KIN, KIN, T, opaque(tid));
         // ---- P1 in_linear (:79) + channel shuffle (folded) -------------------------------------------------------------
         {
             f32x4 acc[RBM][2], acct[RBT][2];

@@ -64,6 +64,7 @@ struct FusedTrain {
     // float offsets into `sv` in units of 64 floats (every stash array is 64-float aligned): 32-bit, because this struct
     // lives in SGPRs for the whole kernel and the training forward is short of them
     unsigned x0, qkv, ast, att, z1, st1, x1, hid, z2, st2, xo, layer_stride;
+    unsigned u = 0;      // 0: U (the staged input rows [M][224], dW_in's operand) is written by a prologue launch; else its offset: the hybrid kernel stashes it
     unsigned long long seed;
     unsigned thresh;   // 0 = dropout off
     float scale;

@@ -823,9 +823,22 @@ static hipError_t grad_weight(const float* dY, long long ldy, int n_rows_pad, in
 // ---------------------------------------------------------------------------------------------------------------------
 // column sums (bias gradients): out[n] = sum_m X[m*ld + n]; two deterministic stages
 // ---------------------------------------------------------------------------------------------------------------------
+// A data-movement side task that rides in a column-sum launch (grid-stride over all its blocks, after their reduction): the
+// backward's pad-rows and shift-rows copies read arrays the neighbouring column sum reads or writes next to, and as launches
+// of their own they cost more in launch overhead than in bytes.
+struct ColSide {
+    int kind = 0;                 // 0 none; 1: dst[r][c] = c < n ? src[r][n-wide row][c] : 0 (row padding n -> npad);
+                                  // 2: dst[b,t] = src[b,t-1], dst[b,0] = 0 over float4s (rows of R4 float4s, T rows per window)
+    const float* src = nullptr;
+    float* dst = nullptr;
+    int n = 0, npad = 0;          // kind 1
+    int T = 0, R4 = 0;            // kind 2
+    long long total = 0;          // elements (kind 1) / float4s (kind 2)
+};
+
 // block = 64 columns x 4 row lanes; grid (ceil(N/64), Z)
 __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, long long ld, int M, int N,
-                                                          int rows_per, float* __restrict__ part) {
+                                                          int rows_per, float* __restrict__ part, ColSide side) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
@@ -844,6 +857,24 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
     red[rl][c] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (rl == 0 && n < N) part[(long long)blockIdx.y * N + n] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (side.kind) {
+        const long long nthreads = (long long)gridDim.x * gridDim.y * 256;
+        const long long t0 = ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        if (side.kind == 1) {
+            for (long long i = t0; i < side.total; i += nthreads) {
+                const long long r = i / side.npad;
+                const int cc = (int)(i - r * side.npad);
+                side.dst[i] = cc < side.n ? side.src[r * side.n + cc] : 0.f;
+            }
+        } else {
+            for (long long i = t0; i < side.total; i += nthreads) {
+                const long long row = i / side.R4;
+                const int t = (int)(row % side.T);
+                reinterpret_cast<float4*>(side.dst)[i] =
+                    t ? reinterpret_cast<const float4*>(side.src)[i - side.R4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
 }
 
 // out[n] = sum_z part[z][n]; block = 64 columns x 4 z lanes
@@ -890,6 +921,8 @@ struct ColSrc {
     float* out_hi;       // columns [nsplit, nsplit2)
     float* out_hi2;      // columns [nsplit2, N)
     int N, nsplit, nsplit2;
+    int Z = 0;           // partial rows of THIS source (0: the batch-wide ColMulti::Z)
+    float* out_dup = nullptr;   // second copy of the low part (b_ih and b_hh receive the same gradient)
 };
 struct ColMulti {
     ColSrc src[kColMulti];
@@ -898,7 +931,7 @@ struct ColMulti {
 __global__ __launch_bounds__(256) void colreduce_multi_kernel(ColMulti m) {
     __shared__ float red[4][64];
     const ColSrc& q = m.src[blockIdx.y];
-    const int N = q.N, Z = m.Z;
+    const int N = q.N, Z = q.Z ? q.Z : m.Z;
     if ((int)blockIdx.x * 64 >= N) return;
     const float* __restrict__ part = q.part;
     const int c = threadIdx.x & 63, zl = threadIdx.x >> 6;
@@ -920,16 +953,28 @@ __global__ __launch_bounds__(256) void colreduce_multi_kernel(ColMulti m) {
         const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
         if (n >= q.nsplit2) q.out_hi2[n - q.nsplit2] = v;
         else if (n >= q.nsplit) q.out_hi[n - q.nsplit] = v;
-        else q.out[n] = v;
+        else {
+            q.out[n] = v;
+            if (q.out_dup) q.out_dup[n] = v;
+        }
     }
 }
 
 constexpr int kColZ = 64;
 
-static hipError_t colsum(const float* X, long long ld, int M, int N, float* part, float* out, float* out2, hipStream_t s) {
+// `defer` (fused backward): only the partial pass runs here; the source is appended to the one multi-source reduction launched at
+// the end of the backward (its partial array must then stay untouched until that launch)
+static hipError_t colsum(const float* X, long long ld, int M, int N, float* part, float* out, float* out2, hipStream_t s,
+                         ColSrc* defer = nullptr, const ColSide& side = ColSide()) {
     const int rows_per = (M + kColZ - 1) / kColZ;
     const int Z = (M + rows_per - 1) / rows_per;
-    hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, Z), dim3(256), 0, s, X, ld, M, N, rows_per, part);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, Z), dim3(256), 0, s, X, ld, M, N, rows_per, part, side);
+    if (defer) {
+        *defer = ColSrc{part, out, nullptr, nullptr, N, N, N};
+        defer->Z = Z;
+        defer->out_dup = out2;
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(colreduce_kernel, dim3((N + 63) / 64), dim3(256), 0, s, part, Z, N, out, out2, N, nullptr);
     return hipGetLastError();
 }
@@ -1187,6 +1232,7 @@ struct TrainSaved {
 };
 struct TrainScratch {
     size_t dyp, dh, delta, hprev, ga, gb, gc, gbig, datt, part, colpart, dwin_p, dbin_p;
+    size_t colpart_out, colpart_rnn, colpart_in;   // partial column sums reduced by the backward's last launch (fused path)
     size_t gbig2;          // fused backward: dqkv of the attention half (dff2 / dpre of the FFN half stay alive for the layer's one dW launch)
     size_t bwimg, lnwin;   // fused backward: transposed-weight fragment image, per-window LayerNorm partials [B][3D]
     size_t part_floats;
@@ -1276,6 +1322,10 @@ static TrainScratch scratch_layout(const Dims& d, int B, int T) {
     size_t cmax = (size_t)kColZ * (size_t)(3 * d.D > d.F ? 3 * d.D : d.F);
     if (ln_parts > cmax) cmax = ln_parts;
     S.colpart = take(off, cmax);
+    // partials whose reduction is deferred to the end of the backward (output bias, recurrence biases, in_linear bias)
+    S.colpart_out = take(off, (size_t)kColZ * round_up(d.S, 64));
+    S.colpart_rnn = take(off, (size_t)kColZ * d.R);
+    S.colpart_in = take(off, (size_t)kColZ * d.D);
     S.dwin_p = take(off, (size_t)d.D * d.InPad);
     S.dbin_p = take(off, d.D);
     S.bwimg = take(off, fused_bwd_image_floats(d));
@@ -1405,28 +1455,41 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     const int M = B * T;
     const float* const* rp = params + P_LAYER0 + PL_COUNT * d.L;
 
-    hipLaunchKernelGGL(prep_in_kernel, dim3(grid_for((long long)d.D * d.InPad)), dim3(256), 0, s, params[P_IN_W], params[P_IN_B],
-                       W + L.win_p, W + L.bin_p, d.D, d.H, d.In, d.InPad, d.n_imu_total + d.rootv0, d.n_imu_total + d.rootv1);
-    hipLaunchKernelGGL(prep_rnn_kernel, dim3(grid_for((long long)d.R * d.R)), dim3(256), 0, s, rp[PR_WHH], rp[PR_BIH], rp[PR_BHH],
-                       W + L.whh_f, W + L.whh_b, W + L.bsum, d.R);
-    {
-        TrBatch tb;
-        tb.n = 0;
-        int tiles = 0;
-        tr_add(tb, tiles, rp[PR_LIN_W], W + L.wout_t, d.S, d.R, round_up(d.S, 16));
-        tr_add(tb, tiles, rp[PR_WIH], W + L.wih_t, d.R, d.D, d.R);
-        for (int l = 0; l < d.L; ++l) {
-            const float* const* lp = params + P_LAYER0 + PL_COUNT * l;
-            const TrainLayer& t = L.layers[l];
-            tr_add(tb, tiles, lp[PL_QKV_W], W + t.wqkv_t, 3 * d.D, d.D, 3 * d.D);
-            tr_add(tb, tiles, lp[PL_OUT_W], W + t.wo_t, d.D, d.D, d.D);
-            tr_add(tb, tiles, lp[PL_L1_W], W + t.w1_t, d.F, d.D, d.F);
-            tr_add(tb, tiles, lp[PL_L2_W], W + t.w2_t, d.D, d.F, d.D);
+    // Paper configuration: the encoder runs as ONE kernel (below) on a fused weight image, and the only other layouts the step
+    // needs are W_hh in fragment order (forward / transposed for the backward) and the transposed W_out / W_ih of the two dX GEMMs
+    // that stay batch-wide: they ride in the fused image's pack launches (round 3: prep_in, prep_rnn and the batched transpose of
+    // every layer's weights were three more launches, ~20 us, most of it for copies only the layer-by-layer path reads).
+    static int use_fused_prep = -1;
+    if (use_fused_prep < 0) use_fused_prep = (getenv("TIP_TRAIN_FUSED") && getenv("TIP_TRAIN_FUSED")[0] == '0') ? 0 : 1;
+    const bool fused_prep = use_fused_prep && fused_supported(d, T) && fused_has_rnn_ih(d) && fused_packed_floats(d) > 0 &&
+                            fused_bwd_image_floats(d) > 0 && !(getenv("TIP_TRAIN_FUSED_BWD") && getenv("TIP_TRAIN_FUSED_BWD")[0] == '0');
+    if (!fused_prep) {
+        hipLaunchKernelGGL(prep_in_kernel, dim3(grid_for((long long)d.D * d.InPad)), dim3(256), 0, s, params[P_IN_W], params[P_IN_B],
+                           W + L.win_p, W + L.bin_p, d.D, d.H, d.In, d.InPad, d.n_imu_total + d.rootv0, d.n_imu_total + d.rootv1);
+        hipLaunchKernelGGL(prep_rnn_kernel, dim3(grid_for((long long)d.R * d.R)), dim3(256), 0, s, rp[PR_WHH], rp[PR_BIH], rp[PR_BHH],
+                           W + L.whh_f, W + L.whh_b, W + L.bsum, d.R);
+        {
+            TrBatch tb;
+            tb.n = 0;
+            int tiles = 0;
+            tr_add(tb, tiles, rp[PR_LIN_W], W + L.wout_t, d.S, d.R, round_up(d.S, 16));
+            tr_add(tb, tiles, rp[PR_WIH], W + L.wih_t, d.R, d.D, d.R);
+            for (int l = 0; l < d.L; ++l) {
+                const float* const* lp = params + P_LAYER0 + PL_COUNT * l;
+                const TrainLayer& t = L.layers[l];
+                tr_add(tb, tiles, lp[PL_QKV_W], W + t.wqkv_t, 3 * d.D, d.D, 3 * d.D);
+                tr_add(tb, tiles, lp[PL_OUT_W], W + t.wo_t, d.D, d.D, d.D);
+                tr_add(tb, tiles, lp[PL_L1_W], W + t.w1_t, d.F, d.D, d.F);
+                tr_add(tb, tiles, lp[PL_L2_W], W + t.w2_t, d.D, d.F, d.D);
+            }
+            hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(256), 0, s, tb);
         }
-        hipLaunchKernelGGL(transpose_batch_kernel, dim3(tiles), dim3(256), 0, s, tb);
     }
     TT(hipGetLastError(), "train_prep");
-    TT(launch_prologue(d, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f, W + L.U, M, s), "train_prologue");
+    // (the hybrid fused forward stashes U itself: FusedTrain::u)
+    static const bool padded_fwd = getenv("TIP_TRAIN_FWD_PADDED") != nullptr;
+    const bool u_in_kernel = fused_prep && !padded_fwd && d.InPad == 224;
+    if (!u_in_kernel) TT(launch_prologue(d, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f, W + L.U, M, s), "train_prologue");
     // Paper configuration: the encoder runs as ONE kernel — the fused inference kernel with its activations stashed and the
     // dropout sites live (tip_fused.hip, fused_encoder_kernel<8>) — on a weight image packed on the GPU from the live
     // parameters.  Any other supported configuration takes the layer-by-layer path below.
@@ -1436,9 +1499,21 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     bool hall_armed = false;
     if (fused) {
         std::vector<PackOp> ops;
-        fused_pack_ops(d, params, 0, ops);
+        fused_pack_ops(d, params, L.fused_img, ops);
+        if (fused_prep) {
+            auto op = [&](const float* src, size_t dst, int N, int K, int src_rows, int src_cols, int frag, int transpose) {
+                PackOp o;
+                o.src = src; o.src2 = nullptr; o.dst_off = dst; o.N = N; o.K = K; o.src_rows = src_rows; o.src_cols = src_cols; o.frag = frag;
+                o.shuffle_h = 0; o.shuffle_dh = 0; o.z0 = 0; o.z1 = 0; o.scale_rows = 0; o.scale = 1.f; o.transpose = transpose;
+                ops.push_back(o);
+            };
+            op(rp[PR_WHH], L.whh_f, d.R, d.R, d.R, d.R, 1, 0);                              // W_hh fragments (forward recurrence)
+            op(rp[PR_WHH], L.whh_b, d.R, d.R, d.R, d.R, 1, 1);                              // W_hh^T fragments (backward recurrence)
+            op(rp[PR_LIN_W], L.wout_t, d.R, round_up(d.S, 16), d.R, d.S, 0, 1);             // W_out^T [R][S padded to 16] (dH = dy W_out)
+            op(rp[PR_WIH], L.wih_t, d.D, d.R, d.D, d.R, 0, 1);                              // W_ih^T [D][R] (d_enc = delta W_ih)
+        }
         TT(hipMemsetAsync(W + L.fused_img, 0, fused_packed_floats(d) * sizeof(float), s), "train_fused_pack");
-        TT(run_pack_ops(ops, W + L.fused_img, s), "train_fused_pack");
+        TT(run_pack_ops(ops, W, s), "train_fused_pack");
         FusedTrain tr;
         tr.sv = W;
         const TrainLayer& t0 = L.layers[0];
@@ -1446,6 +1521,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         tr.x0 = u64(L.x0); tr.qkv = u64(t0.qkv); tr.ast = u64(t0.ast); tr.att = u64(t0.att); tr.z1 = u64(t0.z1);
         tr.st1 = u64(t0.st1); tr.x1 = u64(t0.x1); tr.hid = u64(t0.hid); tr.z2 = u64(t0.z2); tr.st2 = u64(t0.st2); tr.xo = u64(t0.xo);
         tr.layer_stride = d.L > 1 ? u64(L.layers[1].qkv - t0.qkv) : 0;
+        tr.u = u_in_kernel ? u64(L.U) : 0;
         const Drop dr = make_drop(p_drop, seed, 0);
         tr.seed = seed; tr.thresh = dr.thresh; tr.scale = dr.scale;
         // the encoder also pre-fills its windows' HALL rows with the recurrence's hand-off sentinel (saves a 21-MB memset)
@@ -1608,10 +1684,19 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
         fused_bwd_pack_ops(d, params, 0, ops);
         TT(run_pack_ops(ops, X + S.bwimg, s), "bwd_pack");
     }
+    // fused backward: the per-window LayerNorm / bias partials of every layer AND the three batch-wide bias partials (output
+    // projection, recurrence, in_linear) stay in place and are reduced by ONE launch after the loop
+    const bool col_multi = fbwd && 2 * d.L + 3 <= kColMulti;
+    ColMulti cm;
+    cm.Z = B;
+    for (int i = 0; i < kColMulti; ++i) cm.src[i] = ColSrc{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     // ---- output projection (:102): y = h W_out^T + b ---------------------------------------------------------------
-    hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for((long long)M * Sp)), dim3(256), 0, s, dy, d.S, X + S.dyp, Sp, (long long)M);
-    TT(hipGetLastError(), "bwd_pad_dy");
-    TT(colsum(dy, d.S, M, d.S, colpart, grads + goff[rbase + PR_LIN_B], nullptr, s), "bwd_db_out");
+    {
+        ColSide pad;      // dy [M][S] -> dyp [M][S padded to 16] rides in the bias-gradient launch
+        pad.kind = 1; pad.src = dy; pad.dst = X + S.dyp; pad.n = d.S; pad.npad = Sp; pad.total = (long long)M * Sp;
+        TT(colsum(dy, d.S, M, d.S, col_multi ? X + S.colpart_out : colpart, grads + goff[rbase + PR_LIN_B], nullptr, s,
+                  col_multi ? &cm.src[2 * d.L] : nullptr, pad), "bwd_db_out");
+    }
     TT(grad_weight(X + S.dyp, Sp, Sp, d.S, W + L.hall, d.R, d.R, M, part, S.part_floats, grads + goff[rbase + PR_LIN_W], ncu, s),
        "bwd_dW_out");
     {
@@ -1621,10 +1706,12 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     // ---- recurrence (:98-99), time reversed: delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2) -------------------------
     TT(launch_rnn_bwd(d, X + S.dh, W + L.whh_b, W + L.hall, X + S.delta, reinterpret_cast<unsigned*>(const_cast<float*>(W + L.flags)),
                       B, T, auto_cluster(B, ncu), ncu, h->guard(), s), "bwd_rnn");
-    hipLaunchKernelGGL(shift_rows_kernel, dim3(grid_for((long long)M * d.R / 4)), dim3(256), 0, s, W + L.hall, X + S.hprev, T,
-                       d.R / 4, (long long)M * d.R / 4);
-    TT(hipGetLastError(), "bwd_shift");
-    TT(colsum(X + S.delta, d.R, M, d.R, colpart, grads + goff[rbase + PR_BIH], grads + goff[rbase + PR_BHH], s), "bwd_db_rnn");
+    {
+        ColSide sh;       // hprev[b,t] = h[b,t-1] (dW_hh's operand) rides in the recurrence-bias launch
+        sh.kind = 2; sh.src = W + L.hall; sh.dst = X + S.hprev; sh.T = T; sh.R4 = d.R / 4; sh.total = (long long)M * d.R / 4;
+        TT(colsum(X + S.delta, d.R, M, d.R, col_multi ? X + S.colpart_rnn : colpart, grads + goff[rbase + PR_BIH], grads + goff[rbase + PR_BHH],
+                  s, col_multi ? &cm.src[2 * d.L + 1] : nullptr, sh), "bwd_db_rnn");
+    }
     const float* enc = W + L.layers[d.L - 1].xo;
     {
         // dW_hh = delta^T h_prev and dW_ih = delta^T x share delta and the row range: one launch
@@ -1649,10 +1736,6 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     // ---- encoder layers, last to first -----------------------------------------------------------------------------------
     // fused backward: the per-window LayerNorm / bias partials of every layer stay in place and are reduced by ONE launch after
     // the loop (two small launches per layer otherwise)
-    const bool col_multi = fbwd && 2 * d.L <= kColMulti;
-    ColMulti cm;
-    cm.Z = B;
-    for (int i = 0; i < kColMulti; ++i) cm.src[i] = ColSrc{nullptr, nullptr, nullptr, nullptr, 0, 0, 0};
     for (int l = d.L - 1; l >= 0; --l) {
         const int pb = P_LAYER0 + PL_COUNT * l;
         const float* const* lp = params + pb;
@@ -1795,13 +1878,15 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
         }
         }
     }
+    // ---- in_linear (:79) ---------------------------------------------------------------------------------------------------
+    TT(colsum(gx, d.D, M, d.D, col_multi ? X + S.colpart_in : colpart, X + S.dbin_p, nullptr, s, col_multi ? &cm.src[2 * d.L + 2] : nullptr),
+       "bwd_db_in");
     if (col_multi) {
-        hipLaunchKernelGGL(colreduce_multi_kernel, dim3((3 * d.D + d.F + 63) / 64 > (6 * d.D + 63) / 64 ? (3 * d.D + d.F + 63) / 64 : (6 * d.D + 63) / 64, 2 * d.L),
-                           dim3(256), 0, s, cm);
+        int gxm = (3 * d.D + d.F + 63) / 64;
+        for (int v : {(6 * d.D + 63) / 64, (d.R + 63) / 64, (d.S + 63) / 64}) gxm = v > gxm ? v : gxm;
+        hipLaunchKernelGGL(colreduce_multi_kernel, dim3(gxm, 2 * d.L + 3), dim3(256), 0, s, cm);
         TT(hipGetLastError(), "bwd_ln_params");
     }
-    // ---- in_linear (:79) ---------------------------------------------------------------------------------------------------
-    TT(colsum(gx, d.D, M, d.D, colpart, X + S.dbin_p, nullptr, s), "bwd_db_in");
     TT(grad_weight(gx, d.D, d.D, d.D, W + L.U, d.InPad, d.InPad, M, part, S.part_floats, X + S.dwin_p, ncu, s), "bwd_dW_in");
     hipLaunchKernelGGL(finish_in_kernel, dim3(grid_for((long long)d.D * d.In)), dim3(256), 0, s, X + S.dwin_p, X + S.dbin_p,
                        grads + goff[P_IN_W], grads + goff[P_IN_B], d.D, d.H, d.In, d.InPad, d.n_imu_total + d.rootv0,
