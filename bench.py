@@ -416,7 +416,12 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
     try:
         sc = synth.SCALED
         torch.manual_seed(0)
-        ms_model = build_model(sc, 0, load=False).to(dev).eval()
+        os.environ["TIP_S16_GENERAL"] = "1"     # the image also carries the split-fp16 copies of the big linears (exploratory line below)
+        try:
+            ms_model = build_model(sc, 0, load=False).to(dev).eval()
+            ms_model._ensure_handle()
+        finally:
+            del os.environ["TIP_S16_GENERAL"]
         Bs, Ts = 512, 80
         s_imu, s_s = synth.make_inputs(sc, 64, Ts, seed=99)
         si = torch.tensor(s_imu).to(dev).repeat(Bs // 64, 1, 1)
@@ -427,6 +432,21 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
         out["scaled_b512_t80"] = {"batch": Bs, "T": Ts, "ms_per_step": ms, "frames_per_s": Bs / (ms * 1e-3),
                                   "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(sc, Ts, Bs / (ms * 1e-3)),
                                   "tflops": Bs / (ms * 1e-3) * synth.flops_per_window(sc, Ts) / 1e12}
+        # EXPLORATORY, never the headline: the same forward with the big linears on split-fp16 operands (plan "general16")
+        try:
+            y32 = ms_model(si[:8], ss[:8])
+            ms_model.set_plan("general16")
+            ms_model(si, ss)
+            ms16 = timed_loop(lambda: ms_model(si, ss), 3)
+            y16 = ms_model(si[:8], ss[:8])
+            out["scaled_b512_t80"]["exploratory_general16"] = {
+                "dtype": "big linears: f32 emulated as split fp16 (22-bit operands), fp32 accumulate; everything else fp32",
+                "ms_per_step": ms16, "frames_per_s": Bs / (ms16 * 1e-3), "speedup_vs_fp32_mfma_plan": ms / ms16,
+                "fp32_equivalent_tflops": Bs / (ms16 * 1e-3) * synth.flops_per_window(sc, Ts) / 1e12,
+                "max_abs_diff_vs_fp32_plan_8_windows": float((y16 - y32).abs().max().item()), "max_abs_y": float(y32.abs().max().item())}
+            ms_model.set_plan("auto")
+        except Exception as e2:
+            out["scaled_b512_t80"]["exploratory_general16"] = {"error": f"{type(e2).__name__}: {e2}"}
         del ms_model, si, ss
         torch.cuda.empty_cache()
     except Exception as e:

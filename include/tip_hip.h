@@ -76,6 +76,9 @@ typedef enum tip_status {
 #define TIP_PLAN_FUSED16 7 /* EXPLORATORY, opt-in only (never AUTO's choice): TIP_PLAN_FUSED with every GEMM's fp32 operands emulated on the
                               fp16 matrix cores — operands split hi + lo * 2^-11 (22 significant bits), three f16 MFMAs per product,
                               fp32 accumulation; attention core, LayerNorm, residual stream and epilogues in fp32 (csrc/tip_s16.hip) */
+#define TIP_PLAN_GENERAL16 8 /* EXPLORATORY, opt-in only: TIP_PLAN_GENERAL with the big linears (panel GEMM shapes) on split-fp16 operands as in
+                               TIP_PLAN_FUSED16; needs TIP_S16_GENERAL=1 in the environment at tip_create (the split weight copies double the
+                               packed image of a big model, so they are not packed by default) */
 #define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);
                               AUTO picks it for B <= 64 */
 

@@ -80,3 +80,44 @@ def test_fused16_keep_mask_golden(golden):
     torch.cuda.synchronize()
     assert np.abs(y.cpu().numpy() - case["y64"]).max() < TOL_TIGHT
     h.set_option(tlib.TIP_OPT_PLAN, tlib.TIP_PLAN_AUTO)
+
+
+def _model_s16_general(cfg, seed):
+    """A model whose packed image carries the split-fp16 copies of the general plan's big linears (TIP_S16_GENERAL=1 is read at
+    handle creation)."""
+    import os
+    os.environ["TIP_S16_GENERAL"] = "1"
+    try:
+        m = make_model(cfg)
+        w = load_synth(m, cfg, seed)
+        m = m.cuda().eval()
+        m._ensure_handle()
+    finally:
+        del os.environ["TIP_S16_GENERAL"]
+    return m, w
+
+
+@pytest.mark.parametrize("B,T", [(5, 80), (9, 40)])
+def test_general16_scaled_widths_vs_oracle(B, T):
+    """Exploratory "general16": the general plan with its big linears (d = 1024, ffn = 4096: panel-GEMM shapes, M >= 320 rows) on
+    split-fp16 operands — same tolerance as the fp32 general plan, error not worse than 3x its error; host and device packers
+    produce the same image including the split copies."""
+    cfg = dict(synth.SCALED, tf_layers=2)
+    m, w = _model_s16_general(cfg, 0)
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=14 + B)
+    yo = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
+    m.set_plan("general")
+    e32 = np.abs(_fwd(m, x_imu, x_s) - yo).max()
+    m.set_plan("general16")
+    y = _fwd(m, x_imu, x_s)
+    e16 = np.abs(y - yo).max()
+    assert np.isfinite(y).all() and e16 < TOL_TIGHT, e16
+    assert e16 < 3.0 * e32 + 1e-6, (e16, e32)
+    assert np.array_equal(y, _fwd(m, x_imu, x_s))
+    assert np.array_equal(_fwd(m, x_imu, x_s, last=True), y[:, -1])
+    # the image: host packer == device packer, split copies included
+    host = m.pack_host()
+    dev = m.pack_device(torch.device("cuda:0")).cpu()
+    assert host.numel() == dev.numel() and torch.equal(host, dev)
+    m0 = make_model(cfg)
+    assert m0._ensure_handle().packed_bytes() < m._ensure_handle().packed_bytes(), "the split copies must be opt-in"

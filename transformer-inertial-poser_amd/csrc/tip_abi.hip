@@ -66,6 +66,11 @@ void build_layout(tip_handle* h) {
         // big linears also in MFMA fragment order for the panel GEMM (tip_fused2.hip, launch_pgemm)
         for (PackedLinear* p : {&pl.qkv, &pl.out, &pl.ff1, &pl.ff2})
             if (pgemm_shape_ok(1 << 20, p->N, p->K)) p->f_off = c.take((size_t)p->N * p->K);
+        // exploratory TIP_PLAN_GENERAL16: split-fp16 copies of the same matrices, only on request (they double a big model's image)
+        const bool s16_general = getenv("TIP_S16_GENERAL") && getenv("TIP_S16_GENERAL")[0] == 0x31;   // read at every tip_create
+        if (s16_general)
+            for (PackedLinear* p : {&pl.qkv, &pl.out, &pl.ff1, &pl.ff2})
+                if (p->f_off && pgemm16_shape_ok(1 << 20, p->N, p->K)) p->s_off = c.take((size_t)p->N * p->K);
     }
     if (d.with_rnn) {
         L.rnn_ih = carve_linear(c, d.R, d.D);
@@ -198,7 +203,9 @@ struct StageScope {
 // y = epi(x W^T + b (+ res)) for one packed linear of the general plan: the panel GEMM on the fragment copy when the layer
 // has one and the batch is big enough, else the LDS-tiled GEMM on the row-major copy
 static hipError_t linear_gemm(const float* P, const tip::PackedLinear& p, const float* A, int lda, const float* res, int ldres,
-                              float* C, int ldc, int M, int flags, hipStream_t s) {
+                              float* C, int ldc, int M, int flags, hipStream_t s, bool s16 = false) {
+    if (s16 && p.s_off && tip::pgemm16_shape_ok(M, p.N, p.K))   // TIP_PLAN_GENERAL16 (exploratory): split-fp16 operands
+        return tip::launch_pgemm16(A, lda, P + p.s_off, (size_t)p.N * p.K, P + p.b_off, res, ldres, C, ldc, M, p.N, p.K, flags, s);
     static int use_pg = -1;   // TIP_GENERAL_PGEMM=0 keeps the LDS-tiled kernel (measurement)
     if (use_pg < 0) use_pg = (getenv("TIP_GENERAL_PGEMM") && getenv("TIP_GENERAL_PGEMM")[0] == '0') ? 0 : 1;
     if (use_pg && p.f_off && tip::pgemm_shape_ok(M, p.N, p.K))
@@ -329,7 +336,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
     if (!h) return TIP_ERR_INVALID_ARG;
     switch (option) {
         case TIP_OPT_PLAN:
-            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED16) return TIP_ERR_INVALID_ARG;
+            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_GENERAL16) return TIP_ERR_INVALID_ARG;
             h->plan = value;
             return TIP_OK;
         case TIP_OPT_PROFILE:
@@ -436,6 +443,7 @@ int tip_pack_weights(const tip_handle* h, const float* const* t, int n, void* pa
                         for (int s4 = 0; s4 < 4; ++s4)
                             f[((size_t)(nb * KBn + kb) * 64 + lane) * 4 + s4] =
                                 w[(size_t)(nb * 16 + (lane & 15)) * p->Kpad + kb * 16 + 4 * (lane >> 4) + s4];
+            if (p->s_off) s16_convert_host(f, img + p->s_off, p->N, p->K);
         }
         memcpy(img + pl.g1_off, lw[8], sizeof(float) * d.D);
         memcpy(img + pl.be1_off, lw[9], sizeof(float) * d.D);
@@ -556,6 +564,10 @@ int tip_pack_weights_device(const tip_handle* h, const float* const* t, int n, v
     if (run_pack_ops(ops, static_cast<float*>(packed_dev), s) != hipSuccess) return TIP_ERR_HIP;
     if (L.s16_floats && launch_s16_repack(d, static_cast<const float*>(packed_dev) + L.fused_off, static_cast<float*>(packed_dev) + L.s16_off, s) != hipSuccess)
         return TIP_ERR_HIP;
+    for (const PackedLayer& pl : L.layers)
+        for (const PackedLinear* p : {&pl.qkv, &pl.out, &pl.ff1, &pl.ff2})
+            if (p->s_off && launch_s16_convert(static_cast<const float*>(packed_dev) + p->f_off, static_cast<float*>(packed_dev) + p->s_off, p->N, p->K, s) != hipSuccess)
+                return TIP_ERR_HIP;
     return TIP_OK;
 }
 
@@ -673,6 +685,8 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED16 && !(s16_supported(d, T) && L.s16_floats)) return TIP_ERR_UNSUPPORTED_CONFIG;
 
+    const bool g16 = plan == TIP_PLAN_GENERAL16;   // exploratory: the general plan with split-fp16 panel GEMMs
+    if (g16) plan = TIP_PLAN_GENERAL;
     float* enc_out = xa;  // encoder output [M, D]
     bool ih_done = false;  // the fused plan also emits the RNN input projection
     bool rnn_done = false;
@@ -739,7 +753,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
             const PackedLayer& pl = L.layers[l];
             {
                 StageScope sc(h, s, "qkv_gemm");
-                TIP_TRY(linear_gemm(P, pl.qkv, xa, d.D, nullptr, 0, big, 3 * d.D, M, 0, s), "qkv_gemm");
+                TIP_TRY(linear_gemm(P, pl.qkv, xa, d.D, nullptr, 0, big, 3 * d.D, M, 0, s, g16), "qkv_gemm");
             }
             {
                 StageScope sc(h, s, "attention");
@@ -747,7 +761,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
             }
             {
                 StageScope sc(h, s, "out_proj_gemm");
-                TIP_TRY(linear_gemm(P, pl.out, att, d.D, xa, d.D, xb, d.D, M, 2, s), "out_proj_gemm");
+                TIP_TRY(linear_gemm(P, pl.out, att, d.D, xa, d.D, xb, d.D, M, 2, s, g16), "out_proj_gemm");
             }
             {
                 StageScope sc(h, s, "layernorm1");
@@ -755,11 +769,11 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
             }
             {
                 StageScope sc(h, s, "ffn1_gemm");
-                TIP_TRY(linear_gemm(P, pl.ff1, xb, d.D, nullptr, 0, big, d.F, M, 1, s), "ffn1_gemm");
+                TIP_TRY(linear_gemm(P, pl.ff1, xb, d.D, nullptr, 0, big, d.F, M, 1, s, g16), "ffn1_gemm");
             }
             {
                 StageScope sc(h, s, "ffn2_gemm");
-                TIP_TRY(linear_gemm(P, pl.ff2, big, d.F, xb, d.D, xa, d.D, M, 2, s), "ffn2_gemm");
+                TIP_TRY(linear_gemm(P, pl.ff2, big, d.F, xb, d.D, xa, d.D, M, 2, s, g16), "ffn2_gemm");
             }
             {
                 StageScope sc(h, s, "layernorm2");

@@ -97,6 +97,7 @@ struct PackedLinear {
     size_t b_off;
     int N, K, Npad, Kpad;
     size_t f_off = 0;   // the same weight in 16x16x4 B-fragment order (+ tail padding) for launch_pgemm; 0 = not packed
+    size_t s_off = 0;   // ... and as split fp16 [N/16][K/32][hi | lo][64][8] for launch_pgemm16 (TIP_S16_GENERAL=1 only); 0 = not packed
 };
 
 struct PackedLayer {
@@ -379,6 +380,11 @@ hipError_t launch_head_ksplit(const float* A, long long lda, const float* wfrag,
                               int K, bool last_only, int num_cus, hipStream_t s);
 
 // ---- exploratory split-fp16 plan (tip_s16.hip) ----
+bool pgemm16_shape_ok(int M, int N, int K);
+hipError_t launch_pgemm16(const float* A, int lda, const float* w16, size_t w_floats, const float* bias, const float* res, int ldres,
+                          float* C, int ldc, int M, int N, int K, int flags, hipStream_t s);
+void s16_convert_host(const float* src_frag, float* dst, int N, int K);
+hipError_t launch_s16_convert(const float* src_frag, float* dst, int N, int K, hipStream_t s);
 bool s16_supported(const Dims& d, int T);
 size_t s16_packed_floats(const Dims& d);
 void s16_pack_host(const Dims& d, const float* fused_src, float* dst);

@@ -181,17 +181,17 @@ __device__ __forceinline__ void s16_prime(S16Ring<NBW>& g, __amdgpu_buffer_rsrc_
 }
 // the phase proper on a PRIMED ring.  KB % 3 == 2 (8 k-blocks) leaves slots 0, 1 free at the end: the caller primes them for the
 // next phase right behind the last MFMAs, in front of its epilogue and barrier (cross-phase prefetch).
-template <int NBW, int KB, int PLAIN_FROM = NBW>
-__device__ __forceinline__ void s16_gemm_run(s16f4 (&acc_h)[sz::RB][NBW], s16f4 (&acc_x)[sz::RB][NBW], const _Float16* Ap,
+template <int NBW, int KB, int PLAIN_FROM = NBW, int RBN = sz::RB, int LD = sz::LDA>
+__device__ __forceinline__ void s16_gemm_run(s16f4 (&acc_h)[RBN][NBW], s16f4 (&acc_x)[RBN][NBW], const _Float16* Ap,
                                              const _Float16* Alp, S16Ring<NBW>& g, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff,
                                              int nstride_b) {
     // A fragments (LDS) one k-block ahead as well: with the scheduling barrier per k-block they would otherwise be requested and
     // waited for in front of every block's MFMAs
-    s16h8 ah[2][sz::RB], al[2][sz::RB];
+    s16h8 ah[2][RBN], al[2][RBN];
 #pragma unroll
-    for (int r = 0; r < sz::RB; ++r) {
-        ah[0][r] = *reinterpret_cast<const s16h8*>(Ap + r * 16 * sz::LDA);
-        al[0][r] = *reinterpret_cast<const s16h8*>(Alp + r * 16 * sz::LDA);
+    for (int r = 0; r < RBN; ++r) {
+        ah[0][r] = *reinterpret_cast<const s16h8*>(Ap + r * 16 * LD);
+        al[0][r] = *reinterpret_cast<const s16h8*>(Alp + r * 16 * LD);
     }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -204,9 +204,9 @@ __device__ __forceinline__ void s16_gemm_run(s16f4 (&acc_h)[sz::RB][NBW], s16f4 
         }
         if (kb + 1 < KB) {
 #pragma unroll
-            for (int r = 0; r < sz::RB; ++r) {
-                ah[(kb + 1) & 1][r] = *reinterpret_cast<const s16h8*>(Ap + r * 16 * sz::LDA + (kb + 1) * 32);
-                al[(kb + 1) & 1][r] = *reinterpret_cast<const s16h8*>(Alp + r * 16 * sz::LDA + (kb + 1) * 32);
+            for (int r = 0; r < RBN; ++r) {
+                ah[(kb + 1) & 1][r] = *reinterpret_cast<const s16h8*>(Ap + r * 16 * LD + (kb + 1) * 32);
+                al[(kb + 1) & 1][r] = *reinterpret_cast<const s16h8*>(Alp + r * 16 * LD + (kb + 1) * 32);
             }
         }
         const int c = kb % 3, a = kb & 1;
@@ -215,7 +215,7 @@ __device__ __forceinline__ void s16_gemm_run(s16f4 (&acc_h)[sz::RB][NBW], s16f4 
 #pragma unroll
         for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
-            for (int r = 0; r < sz::RB; ++r)
+            for (int r = 0; r < RBN; ++r)
 #pragma unroll
                 for (int n = 0; n < NBW; ++n) {
                     const s16h8 wv = pass == 1 ? g.bl[c][n] : g.bh[c][n];
@@ -649,6 +649,152 @@ hipError_t launch_fused_encoder_s16(const Dims& d, const float* fused_w, const f
     hipLaunchKernelGGL(fused_encoder_s16_kernel<false>, dim3(grid), dim3(sz::THREADS), sz::LDS_BYTES, s, fused_w, s16_w, x_imu, x_s, keep_mask,
                        keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,
                        (int)(s16_packed_floats(d) * 4));
+    return hipGetLastError();
+}
+
+// =====================================================================================================================
+// General plan, exploratory twin of pgemm_kernel (tip_fused2.hip / tip_pgemm.h): C[M,N] = epi(A[M,K] W^T + bias (+ res)) for the BIG
+// linears of any configuration (the scaled model's d = 1024, ffn = 4096) with split-fp16 operands.  An 80-row x 256-column panel per
+// 512-thread workgroup; the A panel is read from HBM / L2 as fp32, SPLIT on the way into LDS (hi / lo planes, K-chunks of 128,
+// double-buffered, one barrier per chunk); the weights never touch LDS: their split copy in the packed image
+// ([column block][32-k block][hi | lo][64 lanes][8 halfs], PackedLinear::s_off, present when TIP_S16_GENERAL=1 at tip_create) is
+// streamed into the three-slot register ring, primed across chunk boundaries.  Transposed accumulator tiles: 16-byte epilogues.
+// Selected by TIP_PLAN_GENERAL16 only.
+// =====================================================================================================================
+namespace pg16 {
+constexpr int ROWS = 80, RB = 5, NBW = 2, KC = 128, LDA = KC + 16, THREADS = 512, COLS = 8 * NBW * 16;   // 256 columns per workgroup
+constexpr int PLANE = ROWS * LDA;                       // halfs
+constexpr int LDS_BYTES = 2 * 2 * PLANE * 2;            // [buffer][hi | lo]: 92 160 B
+}  // namespace pg16
+
+template <int FLAGS>   // 1 = relu, 2 = residual
+__global__ __launch_bounds__(pg16::THREADS) void pgemm16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ w16,
+                                                                int wbytes, const float* __restrict__ bias, const float* __restrict__ res,
+                                                                int ldres, float* __restrict__ C, int ldc, int M, int N, int K) {
+    using namespace pg16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16* planes = reinterpret_cast<_Float16*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w16), 0, wbytes, 0x00020000);
+    const int voff = lane * 16;
+    const int row0 = blockIdx.y * ROWS;
+    const int nb0 = blockIdx.x * (COLS / 16) + wave * NBW;
+    const int KB32 = K >> 5, nchunks = K / KC;
+    const int nstride = KB32 * 2048;
+    const int wsoff = nb0 * nstride;
+    float4 st[5];
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int f = tid + u * THREADS, r = f >> 5, k4 = f & 31;
+            const int rr = row0 + r < M ? row0 + r : M - 1;           // clamped: unconditional loads
+            st[u] = *reinterpret_cast<const float4*>(A + (size_t)rr * lda + c * KC + k4 * 4);
+            if (row0 + r >= M) st[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&](int buf) {
+        _Float16* ph = planes + buf * 2 * PLANE;
+        _Float16* pl = ph + PLANE;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int f = tid + u * THREADS, r = f >> 5, k4 = f & 31;
+            const s16f4 v = {st[u].x, st[u].y, st[u].z, st[u].w};
+            s16_split4_store(v, ph + r * LDA + k4 * 4, pl + r * LDA + k4 * 4);
+        }
+    };
+    s16f4 acc_h[RB][NBW], acc_x[RB][NBW];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) acc_h[r][n] = acc_x[r][n] = (s16f4){0.f, 0.f, 0.f, 0.f};
+    S16Ring<NBW> g;
+    s16_prime<NBW>(g, rsrc, voff, wsoff, nstride);
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    const int aoff = l15 * LDA + lg * 8;
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) fetch(c + 1);
+        const _Float16* ph = planes + (c & 1) * 2 * PLANE + aoff;
+        s16_gemm_run<NBW, KC / 32, NBW, RB, LDA>(acc_h, acc_x, ph, ph + PLANE, g, rsrc, voff, wsoff + c * (KC / 32) * 2048, nstride);
+        // next chunk's first two k-blocks (a harmless re-read of the last ones after the last chunk: the ring is dead then)
+        s16_prime<NBW>(g, rsrc, voff, wsoff + (c + 1 < nchunks ? c + 1 : c) * (KC / 32) * 2048, nstride);
+        if (c + 1 < nchunks) stage((c + 1) & 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int n = 0; n < NBW; ++n) {
+        const int col = (nb0 + n) * 16 + lg * 4;
+        if (col >= N) continue;
+        const float4 b4 = *reinterpret_cast<const float4*>(bias + col);
+        const s16f4 bv = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int row = row0 + r * 16 + l15;
+            if (row < M) {
+                s16f4 v = acc_h[r][n] + acc_x[r][n] * sz::ISC + bv;
+                if (FLAGS & 2) v = v + *reinterpret_cast<const s16f4*>(res + (size_t)row * ldres + col);
+                if (FLAGS & 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+                *reinterpret_cast<s16f4*>(C + (size_t)row * ldc + col) = v;
+            }
+        }
+    }
+}
+
+bool pgemm16_shape_ok(int M, int N, int K) { return N % pg16::COLS == 0 && K % pg16::KC == 0 && M >= 4 * pg16::ROWS; }
+
+hipError_t launch_pgemm16(const float* A, int lda, const float* w16, size_t w_floats, const float* bias, const float* res, int ldres,
+                          float* C, int ldc, int M, int N, int K, int flags, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    if (!pgemm16_shape_ok(M, N, K) || w_floats * 4 > 0x7fffffffULL || (lda & 3) || (ldc & 3) || ((flags & 2) && (ldres & 3)))
+        return hipErrorInvalidValue;
+    static PerDeviceFlag attr_flag;
+    bool& attr_set = attr_flag.cur();
+    if (!attr_set) {
+        for (const void* f : {reinterpret_cast<const void*>(pgemm16_kernel<0>), reinterpret_cast<const void*>(pgemm16_kernel<1>),
+                              reinterpret_cast<const void*>(pgemm16_kernel<2>), reinterpret_cast<const void*>(pgemm16_kernel<3>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, pg16::LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
+        attr_set = true;
+    }
+    const dim3 grid(N / pg16::COLS, (M + pg16::ROWS - 1) / pg16::ROWS), block(pg16::THREADS);
+    const int wb = (int)(w_floats * 4);
+    switch (flags & 3) {
+        case 0: hipLaunchKernelGGL(pgemm16_kernel<0>, grid, block, pg16::LDS_BYTES, s, A, lda, w16, wb, bias, res, ldres, C, ldc, M, N, K); break;
+        case 1: hipLaunchKernelGGL(pgemm16_kernel<1>, grid, block, pg16::LDS_BYTES, s, A, lda, w16, wb, bias, res, ldres, C, ldc, M, N, K); break;
+        case 2: hipLaunchKernelGGL(pgemm16_kernel<2>, grid, block, pg16::LDS_BYTES, s, A, lda, w16, wb, bias, res, ldres, C, ldc, M, N, K); break;
+        default: hipLaunchKernelGGL(pgemm16_kernel<3>, grid, block, pg16::LDS_BYTES, s, A, lda, w16, wb, bias, res, ldres, C, ldc, M, N, K); break;
+    }
+    return hipGetLastError();
+}
+
+// split copy of ONE matrix given in 16x16x4 fragment order (the general plan's PackedLinear::f_off copies): host and device
+void s16_convert_host(const float* src_frag, float* dst, int N, int K) {
+    _Float16* out = reinterpret_cast<_Float16*>(dst);
+    const int KB = K / 32;
+    for (int nb = 0; nb < N / 16; ++nb)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    const int n = nb * 16 + (lane & 15), k = kb * 32 + (lane >> 4) * 8 + i;
+                    const float w = src_frag[s16_src_index(n, k, K)];
+                    const _Float16 h = (_Float16)w;
+                    const _Float16 l = (_Float16)((w - (float)h) * sz::SC);
+                    const size_t base = ((size_t)(nb * KB + kb) * 2) * 512;
+                    out[base + lane * 8 + i] = h;
+                    out[base + 512 + lane * 8 + i] = l;
+                }
+}
+hipError_t launch_s16_convert(const float* src_frag, float* dst, int N, int K, hipStream_t s) {
+    const long long n = (long long)(N / 16) * (K / 32) * 64;
+    hipLaunchKernelGGL(s16_repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src_frag, reinterpret_cast<_Float16*>(dst), N, K);
     return hipGetLastError();
 }
 

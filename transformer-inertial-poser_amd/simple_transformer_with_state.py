@@ -293,7 +293,7 @@ class TF_RNN_Past_State(nn.Module):
         workgroups per 16-window tile (1: no inter-workgroup hand-off in the recurrence).  profile: 1 = per-stage timers
         (profile_read())."""
         h = self._ensure_handle()
-        h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fused2s": 5, "fusedh": 6, "fused16": 7}[plan])
+        h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fused2s": 5, "fusedh": 6, "fused16": 7, "general16": 8}[plan])
         h.set_option(_lib.TIP_OPT_RNN_CLUSTER, int(rnn_cluster))
         h.set_option(_lib.TIP_OPT_PROFILE, int(profile))
 
