@@ -404,6 +404,22 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
     except Exception as e:
         model.set_plan("auto")
         out["exploratory_fused16"] = {"error": f"{type(e).__name__}: {e}"}
+    # -- self-check: EVERY window of the headline batch against the same forward in fp64 ON THE DEVICE (tip_forward_f64: the module
+    #    as train_model.py --double builds it; itself held to 1e-11 of the reference's fp64 outputs by tests/test_f64_gpu.py)
+    try:
+        x256i, x256s = xi[:256].contiguous(), xs[:256].contiguous()
+        m64 = build_model(cfg, 0, load=True).double().to(dev).eval()
+        xi64, xs64 = x256i.double(), x256s.double()
+        y64 = m64(xi64, xs64)
+        ms64 = timed_loop(lambda: m64(xi64, xs64), 3)
+        model.set_plan("auto")
+        err = float((model(x256i, x256s).double() - y64).abs().max().item())
+        out["f64_b256"] = {"batch": int(x256i.shape[0]), "T": T, "dtype": "f64", "ms_per_step": ms64,
+                           "headline_plan_max_abs_err_vs_on_device_fp64_all_windows": err, "max_abs_y": float(y64.abs().max().item()),
+                           "note": "debugging path (layer-by-layer fp64 kernels), not tuned"}
+        del m64, y64
+    except Exception as e:
+        out["f64_b256"] = {"error": f"{type(e).__name__}: {e}"}
     # -- row a14 / f-2: the training-mode model call and its backward (train_model.py:171-196) at the reference's batch size,
     #    HIP kernels in both directions, encoder dropout p = 0.1 live; forward, forward+backward (3x the forward FLOPs) and the
     #    whole step with clip + AdamW

@@ -9,8 +9,9 @@
  * tip_status; device pointers are caller-owned, contiguous, row-major fp32; tip_forward is asynchronous on
  * the caller's HIP stream; one handle per GPU, used from one thread at a time; the library allocates no
  * device memory (packed weights and workspace are caller-provided buffers; the one allocation is a 64-byte pinned HOST
- * block per handle, the hand-off error word of tip_check).  Arithmetic is fp32 only: the reference's `--double` switch
- * (train_model.py:84-85) has no counterpart here — an fp64 tensor is refused by the Python host, not converted.
+ * block per handle, the hand-off error word of tip_check).  Arithmetic is fp32; the reference's `--double` switch
+ * (train_model.py:84-85) is served by tip_forward_f64 (fp64 parameters and windows, every operation in IEEE double) for the
+ * forward, and by the Python host's torch-op composite for the training step.  Tensors are never converted silently.
  */
 #ifndef TIP_HIP_H
 #define TIP_HIP_H
@@ -126,6 +127,17 @@ int tip_workspace_bytes(const tip_handle* h, int B, int T, size_t* bytes);
 int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
                 const float* keep_mask, float keep_scale, void* workspace, size_t workspace_bytes,
                 tip_stream_t stream);
+
+/* ---- forward in fp64: the module built under `--double` (train_model.py:62-63,84-85: torch.set_default_dtype(float64), fp64
+ *      windows :161-164).  Same function as tip_forward (simple_transformer_with_state.py:60-102) with every operation in IEEE
+ *      double on the fp64 matrix cores.  `params` = host array of n_params DEVICE pointers to the fp64 state-dict tensors in
+ *      tip_tensor_info() order, RAW (nothing is packed, no tip_attach_packed needed); x_imu / x_s / keep_mask / y as in tip_forward
+ *      but double; flags: TIP_FWD_LAST_ROW_ONLY; workspace of tip_forward_f64_bytes(), 256-byte aligned.  Any configuration and
+ *      any T >= 1.  A debugging / verification path: layer-by-layer kernels, not tuned. */
+int tip_forward_f64_bytes(const tip_handle* h, int B, int T, size_t* bytes);
+int tip_forward_f64(tip_handle* h, const double* const* params, int n_params, const double* x_imu, const double* x_s, double* y,
+                    int B, int T, int flags, const double* keep_mask, double keep_scale, void* workspace, size_t workspace_bytes,
+                    tip_stream_t stream);
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 /* number of tip_forward calls that launched HIP kernels since tip_create (lets tests prove the HIP path ran) */

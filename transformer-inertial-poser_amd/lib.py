@@ -26,7 +26,7 @@ TIP_LOSS_Q, TIP_LOSS_C, TIP_LOSS_J, TIP_LOSS_STATS = 1, 2, 4, 16
 EXPORTS = (
     "tip_abi_version", "tip_create", "tip_destroy", "tip_strerror", "tip_last_hip_error", "tip_set_option",
     "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
-    "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_forward", "tip_forward_count", "tip_profile_read",
+    "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_forward", "tip_forward_f64_bytes", "tip_forward_f64", "tip_forward_count", "tip_profile_read",
     "tip_spin_timeouts", "tip_check", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
     "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward",
     "tip_combine_frames", "tip_combine_scratch_bytes", "tip_combine_sequence", "tip_gather_windows",
@@ -103,6 +103,8 @@ def load() -> ctypes.CDLL:
     lib.tip_attach_packed.argtypes = [vp, vp, sz]
     lib.tip_workspace_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
     lib.tip_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, ctypes.c_float, vp, sz, vp]
+    lib.tip_forward_f64_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
+    lib.tip_forward_f64.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, vp, i32, i32, i32, vp, ctypes.c_double, vp, sz, vp]
     lib.tip_forward_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.tip_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float),
                                      ctypes.POINTER(i32), i32]
@@ -217,6 +219,18 @@ class Handle:
         a, b = ctypes.c_size_t(), ctypes.c_size_t()
         self._check(self.lib.tip_train_saved_view(self._h, B, T, what, layer, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def forward_f64_bytes(self, B: int, T: int) -> int:
+        n = ctypes.c_size_t()
+        self._check(self.lib.tip_forward_f64_bytes(self._h, B, T, ctypes.byref(n)))
+        return n.value
+
+    def forward_f64(self, param_ptrs: List[int], x_imu: int, x_s: int, y: int, B: int, T: int, flags: int,
+                    keep_mask: Optional[int], keep_scale: float, workspace: int, workspace_bytes: int, stream: int):
+        """The module built under train_model.py's --double: fp64 parameters (raw device pointers, state-dict order) and windows."""
+        arr = (ctypes.c_void_p * len(param_ptrs))(*param_ptrs)
+        self._check(self.lib.tip_forward_f64(self._h, arr, len(param_ptrs), x_imu, x_s, y, B, T, flags, keep_mask, keep_scale,
+                                             workspace, workspace_bytes, stream))
 
     def train_forward(self, param_ptrs: List[int], x_imu: int, x_s: int, keep_mask: Optional[int], keep_scale: float,
                       p_drop: float, seed: int, y: int, saved: int, saved_bytes: int, B: int, T: int, stream: int):

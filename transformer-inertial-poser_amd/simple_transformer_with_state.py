@@ -8,8 +8,10 @@ Mirrors the reference's module surface (/root/reference/simple_transformer_with_
 
 Execution (ROCm tensors, fp32) — what `_dispatch` does:
   * .eval() (or .train() with encoder dropout 0) and no gradient wanted: `tip_forward`, the inference plans
-    (csrc/libtip_hip.so, include/tip_hip.h).  No fallback: a missing library, a CPU tensor under no_grad or an fp64
-    tensor raises.
+    (csrc/libtip_hip.so, include/tip_hip.h).  No fallback: a missing library or a CPU tensor under no_grad raises.
+    A module built under train_model.py's --double (:84-85: fp64 parameters, fp64 windows) runs `tip_forward_f64` — the same
+    function in IEEE double on the fp64 matrix cores; a precision MIX (fp64 windows into an fp32 module or the reverse)
+    raises, nothing is converted silently.
   * .train(): the reference's encoder layers carry torch's default dropout p=0.1 (nn.TransformerEncoderLayer default;
     the constructor's `dropout` argument only reaches nn.RNN, where it is a no-op for one layer), live in train mode
     WHETHER OR NOT autograd records.  Such a call — with gradients (train_model.py:132,175,192) or under
@@ -349,9 +351,12 @@ class TF_RNN_Past_State(nn.Module):
             raise RuntimeError("tip_amd.TF_RNN_Past_State: the inference forward runs on an MI355X through "
                                "libtip_hip.so only — move the module and its inputs to the GPU (.cuda()); "
                                "there is no CPU fallback")
-        if x_imu.dtype != torch.float32 or x_s.dtype != torch.float32:
-            raise RuntimeError("tip_amd.TF_RNN_Past_State: the HIP path computes in fp32; got "
-                               f"{x_imu.dtype}/{x_s.dtype}")
+        pdt = self.in_linear.weight.dtype
+        if x_imu.dtype != x_s.dtype or x_imu.dtype != pdt or pdt not in (torch.float32, torch.float64):
+            raise RuntimeError("tip_amd.TF_RNN_Past_State: the HIP path computes in fp32 (or, for a module built under "
+                               "train_model.py's --double, in fp64) and never converts tensors silently; got inputs "
+                               f"{x_imu.dtype}/{x_s.dtype} for {pdt} parameters")
+        f64 = pdt == torch.float64          # train_model.py:84-85: the whole model in double -> tip_forward_f64
         dev = x_imu.device
         if x_imu.dim() != 3 or x_s.dim() != 3 or x_imu.shape[:2] != x_s.shape[:2]:
             raise RuntimeError("expected x_imu [B,T,n_imu] and x_s [B,T,size_s]")
@@ -376,8 +381,8 @@ class TF_RNN_Past_State(nn.Module):
                                                keep_mask if km is None else km[lo:hi], apply_in_dropout))
             return torch.cat(parts, dim=0)
         with torch.cuda.device(dev):
-            if self._packed_dev is None or self._packed_dev.device != dev or \
-                    (not self._frozen and self._packed_key != self._param_key(dev)):
+            if not f64 and (self._packed_dev is None or self._packed_dev.device != dev or
+                            (not self._frozen and self._packed_key != self._param_key(dev))):
                 self.refresh_packed(dev)
             x_imu_c = x_imu.contiguous()
             x_s_c = x_s.contiguous()
@@ -388,16 +393,25 @@ class TF_RNN_Past_State(nn.Module):
             mask = self._draw_keep_mask(x_s_c) if isinstance(keep_mask, str) else keep_mask   # :77
             if mask is not None:
                 p = self.past_state_dropout
-                mask = mask.to(torch.float32).contiguous()
+                mask = mask.to(pdt).contiguous()
                 mask_ptr, scale = mask.data_ptr(), (1.0 / (1.0 - p) if p < 1.0 else 0.0)
                 flags |= _lib.TIP_FWD_KEEP_MASK
             if last_row_only:
                 flags |= _lib.TIP_FWD_LAST_ROW_ONLY
-                y = torch.empty((B, self.size_s), dtype=torch.float32, device=dev)
+                y = torch.empty((B, self.size_s), dtype=pdt, device=dev)
             else:
-                y = torch.empty((B, T, self.size_s), dtype=torch.float32, device=dev)
-            need = h.workspace_bytes(B, T)
+                y = torch.empty((B, T, self.size_s), dtype=pdt, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
+            if f64:
+                params = [p.detach() for p in self.state_dict().values()]
+                if any(p.dtype != torch.float64 or p.device != dev for p in params):
+                    raise RuntimeError("tip_amd.TF_RNN_Past_State: fp64 forward needs every parameter in fp64 on the inputs' GPU")
+                params = [p.contiguous() for p in params]
+                ws = self._stream_buffer(self._workspace, dev, stream, h.forward_f64_bytes(B, T))
+                h.forward_f64([p.data_ptr() for p in params], x_imu_c.data_ptr(), x_s_c.data_ptr(), y.data_ptr(), B, T,
+                              flags & _lib.TIP_FWD_LAST_ROW_ONLY, mask_ptr, scale, ws.data_ptr(), ws.numel(), stream)
+                return y
+            need = h.workspace_bytes(B, T)
             ws = self._stream_buffer(self._workspace, dev, stream, need)
             h.forward(x_imu_c.data_ptr(), x_s_c.data_ptr(), y.data_ptr(), B, T, flags, mask_ptr, scale,
                       ws.data_ptr(), ws.numel(), stream)
