@@ -783,6 +783,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     }
 
     const bool last_only = (flags & TIP_FWD_LAST_ROW_ONLY) != 0;
+    bool head_done = false;
     const float* head_in = enc_out;
     int head_ld = d.D;
     if (d.with_rnn && rnn_done) {
@@ -796,13 +797,21 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         }
         {
             StageScope sc(h, s, "rnn_recurrence");
-            TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, rnn_cluster, cus, hall_armed, gd, s),
-                    "rnn_recurrence");
+            // the output projection rides as the recurrence's epilogue when the launch qualifies (rnn_rows4_kernel<.., HEAD>;
+            // TIP_RNN_HEAD=0 keeps it a launch of its own: measurement)
+            static const bool fuse_head = !(getenv("TIP_RNN_HEAD") && getenv("TIP_RNN_HEAD")[0] == '0') &&
+                                          !(getenv("TIP_HEAD") && getenv("TIP_HEAD")[0] == 'o');
+            HeadFuse hf;
+            hf.wfrag = P + L.out_frag_off; hf.bias = P + L.out_lin.b_off; hf.y = y; hf.ldy = d.S; hf.N = d.S;
+            const bool can_fuse = fuse_head && !last_only && plan != TIP_PLAN_LATENCY && d.R == 512 && d.S > 128 && d.S <= 144 &&
+                                  (long long)M * d.S * 4 <= 0x7fffffffLL;
+            TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, rnn_cluster, cus, hall_armed, gd, s,
+                               can_fuse ? &hf : nullptr, &head_done), "rnn_recurrence");
         }
         head_in = hall;
         head_ld = d.R;
     }
-    {
+    if (!head_done) {
         StageScope sc(h, s, "out_linear");
         const int Kh = d.with_rnn ? d.R : d.D;
         // rows the projection runs on: all M, or row T-1 of every window (real_time_runner_minimal.py:150)

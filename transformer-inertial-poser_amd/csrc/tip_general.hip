@@ -18,6 +18,7 @@
 #include <random>
 
 #include "tip_internal.h"
+#include "tip_head.h"
 #include "tip_layernorm.h"
 
 namespace tip {
@@ -1026,11 +1027,14 @@ constexpr int kQ4Rows = 4, kQ4Cluster = 4, kQ4Tiles = 4, kQ4LD = 512 + 16;
 //     >= hall_bytes, so the descriptor's range check returns zeros for their loads and drops their stores (the scalar offset is
 //     not part of that check: the row term alone decides); such tiles multiply zeros;
 //   * the poll loop is per WAVE: all its lanes re-ask until none of them sees a sentinel.
-template <int NT, bool TRACE, bool BWD>
+// HEAD (NT = 1, forward, one tile per cluster, T = 40): the output projection y = h W_out^T + b (:102) runs as the kernel's epilogue
+// — head_ksplit_body (tip_head.h), member `cid` of a cluster taking window 4 tile + cid — instead of as a launch of its own: the
+// weight loads go out while the last step's stores travel, and the launch boundary (fixed cost + ramp, ~3 us) disappears.
+template <int NT, bool TRACE, bool BWD, bool HEAD = false>
 __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict__ ih, const float* __restrict__ whh_frag,
                                                         float* __restrict__ hall, unsigned* __restrict__ flags, int B, int T,
                                                         int ntiles, int hall_bytes, const float* __restrict__ gate, Guard gd,
-                                                        unsigned etag, int abl, int ngroups) {
+                                                        unsigned etag, int abl, int ngroups, HeadFuse hf) {
     // abl: MEASUREMENT-ONLY ablations (wrong results), TIP_RNN_ABLATE: 1 = polls never wait, 2 = no MFMAs
     constexpr int R = 512, KB = R / 16, CLUSTER = kQ4Cluster, LD = kQ4LD;
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [2 buffers][NT tiles][4 rows][LD]
@@ -1046,7 +1050,10 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hall, 0, hall_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ih), 0, hall_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BWD ? gate : ih), 0, hall_bytes, 0x00020000);
-    if ((gd.fault & 2) && group == 0 && cid == 1) return;         // TIP_OPT_FAULT_INJECT: this member never arrives
+    // TIP_OPT_FAULT_INJECT: this member never arrives.  (HEAD: it still runs the epilogue for its window — over state columns that
+    // stay sentinel words, i.e. NaN — so that what a dead member owed is NaN in y too, never stale memory.)
+    const bool dead = (gd.fault & 2) && group == 0 && cid == 1;
+    if (dead && !HEAD) return;
     const unsigned spin_big = guard_spin_limit(gd.fault, 1u << 22), spin_pull = guard_spin_limit(gd.fault, 1u << 20);
 
     // W_hh slice -> registers, once: all 32 k-blocks of this wave's 16 columns (in flight during the exchange below)
@@ -1058,7 +1065,8 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
     }
     // same-XCD fast path, verified at run time through launch-tagged exchange words (see rnn_resident_kernel)
     __shared__ int s_same_xcd;
-    if (tid == 0) {
+    if (tid == 0 && dead) s_same_xcd = 0;
+    if (tid == 0 && !dead) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         xcc &= 0xf;
@@ -1092,7 +1100,7 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
 
     const int tpg = (ntiles + ngroups - 1) / ngroups;             // tiles per cluster
     const unsigned rowbytes = (unsigned)T * R * 4;
-    for (int q0 = 0; q0 < tpg; q0 += NT) {
+    for (int q0 = dead ? tpg : 0; q0 < tpg; q0 += NT) {
         int vpull[NT], vout[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -1239,6 +1247,36 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
         retire_touch();
         __syncthreads();   // the next batch's second step rewrites the buffer the last step of this one may still be reading
     }
+    if constexpr (HEAD) {
+        // one tile per cluster (host-side condition): this member projects window 4 * group + cid.  Rows 0 .. T-2 of the tile were
+        // pulled complete by this workgroup in the steps above; row T-1 is awaited below, behind the weight loads.
+        const int win = group * kQ4Rows + cid;
+        if (win >= B) return;
+        struct Ctl {
+            int win, nwin, vpull, so, same_xcd, spin_pull, poisoned;
+            __amdgpu_buffer_rsrc_t hrs;
+            unsigned* err;
+            __device__ __forceinline__ int first() const { return win; }
+            __device__ __forceinline__ int stride() const { return nwin; }
+            __device__ __forceinline__ void after_weights() const {
+                bool gave_up = true;
+                const unsigned lim = poisoned ? 1u : (unsigned)spin_pull;
+                for (unsigned spins = 0; spins < lim; ++spins) {
+                    asm volatile("" ::: "memory");
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(hrs, vpull, so, 16);
+                    const bool pend = v.x == kRnnSentinel || v.y == kRnnSentinel || v.z == kRnnSentinel || v.w == kRnnSentinel;
+                    if (__builtin_amdgcn_ballot_w64(pend) == 0) { gave_up = false; break; }
+                    if (!same_xcd) __builtin_amdgcn_s_sleep(2);
+                }
+                if (gave_up && !poisoned && (threadIdx.x & 63) == 0) note_spin_timeout(err);   // the rows stay sentinel = NaN: y is NaN there
+                __syncthreads();
+            }
+        };
+        const unsigned rowbytes_h = (unsigned)T * R * 4;
+        Ctl ctl{win, B, (int)((unsigned)(group * kQ4Rows + prow) * rowbytes_h + (unsigned)pcol * 4u), (T - 1) * (R * 4),
+                same_xcd ? 1 : 0, (int)spin_pull, poisoned ? 1 : 0, hrs, gd.err};
+        head_ksplit_body<0, false, 16>(hall, (unsigned)(R * 4), (unsigned)hall_bytes, hf.wfrag, hf.bias, hf.y, hf.ldy, B * T, hf.N, B, ctl);
+    }
 }
 
 size_t rnn_flag_words(int B, int T) { return (size_t)((B + kRnnTile - 1) / kRnnTile) * (size_t)T + 1024; }
@@ -1322,8 +1360,33 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
 // four-row tiles on 4-workgroup clusters (rnn_rows4_kernel); sentinel hand-off only
 template <int NT>
 static hipError_t launch_rnn_rows4_nt(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T, int ntiles,
-                                      int groups, long long hb, const Guard& gd, hipStream_t s, const float* gate, unsigned etag, int num_cus) {
+                                      int groups, long long hb, const Guard& gd, hipStream_t s, const float* gate, unsigned etag, int num_cus,
+                                      const HeadFuse* hf = nullptr, bool* head_done = nullptr) {
     constexpr int smem = 2 * NT * kQ4Rows * kQ4LD * (int)sizeof(float);
+    static int trace = -1, abl = -1;
+    if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
+    if (abl < 0) abl = getenv("TIP_RNN_ABLATE") ? atoi(getenv("TIP_RNN_ABLATE")) : 0;   // measurement only (profiles/): never set in production
+    if constexpr (NT == 1) {
+        // output projection fused as the kernel's epilogue (see the kernel): one tile per cluster, T = 40, forward, no tracing
+        if (hf && !gate && !trace && !abl && T == 40 && ntiles <= groups) {
+            constexpr int smem_h = smem > hd::LDS_BYTES ? smem : hd::LDS_BYTES;
+            static PerDeviceFlag attr_h; bool& set_h = attr_h.cur();
+            if (!set_h) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_rows4_kernel<1, false, false, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem_h);
+                if (e != hipSuccess) return e;
+                set_h = true;
+            }
+            static PerDeviceInt occ_h; int& occh = occ_h.cur();
+            hipError_t ce = check_coresident(rnn_rows4_kernel<1, false, false, true>, 512, smem_h, groups * kQ4Cluster, num_cus, &occh);
+            if (ce != hipSuccess) return ce;
+            const dim3 gridh((groups + 7) / 8 * 8 * kQ4Cluster), blockh(512);
+            hipLaunchKernelGGL((rnn_rows4_kernel<1, false, false, true>), gridh, blockh, smem_h, s, ih, whh_frag, hall, flags, B, T, ntiles,
+                               (int)hb, gate, gd, etag, abl, groups, *hf);
+            if (head_done) *head_done = true;
+            return hipGetLastError();
+        }
+    }
     static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         for (const void* f : {reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, false>), reinterpret_cast<const void*>(rnn_rows4_kernel<NT, true, false>),
@@ -1336,23 +1399,21 @@ static hipError_t launch_rnn_rows4_nt(const float* ih, const float* whh_frag, fl
     static PerDeviceInt occ_dev; int& occ = occ_dev.cur();   // every member of a cluster must be resident while its partners wait for it: ask the runtime
     hipError_t ce = check_coresident(rnn_rows4_kernel<NT, false, false>, 512, smem, groups * kQ4Cluster, num_cus, &occ);
     if (ce != hipSuccess) return ce;
-    static int trace = -1, abl = -1;
-    if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
-    if (abl < 0) abl = getenv("TIP_RNN_ABLATE") ? atoi(getenv("TIP_RNN_ABLATE")) : 0;   // measurement only (profiles/): never set in production
     // Members of a cluster are taken 8 workgroup ids apart (one XCD); that needs a grid of whole rounds of 8 clusters.  The
     // workgroups of the clusters that pad the last round exit at once (they hold no resources anybody waits for).
     const dim3 grid((groups + 7) / 8 * 8 * kQ4Cluster), block(512);
     if (gate)
-        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, true>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups);
+        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, true>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups, HeadFuse{});
     else if (trace)
-        hipLaunchKernelGGL((rnn_rows4_kernel<NT, true, false>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups);
+        hipLaunchKernelGGL((rnn_rows4_kernel<NT, true, false>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups, HeadFuse{});
     else
-        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, false>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups);
+        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, false>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups, HeadFuse{});
     return hipGetLastError();
 }
 
 static hipError_t launch_rnn_rows4(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T, int num_cus,
-                                   bool hall_armed, const Guard& gd, hipStream_t s, const float* gate = nullptr) {
+                                   bool hall_armed, const Guard& gd, hipStream_t s, const float* gate = nullptr,
+                                   const HeadFuse* hf = nullptr, bool* head_done = nullptr) {
     const int ntiles = (B + kQ4Rows - 1) / kQ4Rows;
     int groups = ntiles;
     const int maxg = num_cus / kQ4Cluster > 0 ? num_cus / kQ4Cluster : 1;   // keep every cluster co-resident
@@ -1369,7 +1430,7 @@ static hipError_t launch_rnn_rows4(const float* ih, const float* whh_frag, float
     }
     const unsigned etag = next_rnn_launch_tag();
     // tiles a cluster advances together: as many as it owns, up to kQ4Tiles (3 -> 4: the pad tile is out of range and multiplies zeros)
-    if (tpg <= 1) return launch_rnn_rows4_nt<1>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
+    if (tpg <= 1) return launch_rnn_rows4_nt<1>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus, hf, head_done);
     if (tpg == 2) return launch_rnn_rows4_nt<2>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
     return launch_rnn_rows4_nt<kQ4Tiles>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
 }
@@ -1390,14 +1451,14 @@ hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_fra
 }
 
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
-                      int T, int cluster, int num_cus, bool hall_armed, const Guard& gd, hipStream_t s) {
+                      int T, int cluster, int num_cus, bool hall_armed, const Guard& gd, hipStream_t s, const HeadFuse* hf, bool* head_done) {
     if (B <= 0) return hipSuccess;
     const int R = d.R;
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
     if (cluster < 1) cluster = 1;
     if (R == 512 && (long long)B * T * 512 * 4 <= 0x7fffffffLL) {
         if (cluster == kRnnRows4) {
-            if (rnn_handoff_mode() == 1) return launch_rnn_rows4(ih, whh_frag, hall, flags, B, T, num_cus, hall_armed, gd, s);
+            if (rnn_handoff_mode() == 1) return launch_rnn_rows4(ih, whh_frag, hall, flags, B, T, num_cus, hall_armed, gd, s, nullptr, hf, head_done);
             cluster = 16;   // (TIP_RNN_HANDOFF=0, measurement: the counter protocol exists for the 16-row kernels only)
         }
         // register-resident clustered kernel: W_hh slice lives in VGPRs, 4/8/16 workgroups per window tile
