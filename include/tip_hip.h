@@ -93,6 +93,11 @@ typedef enum tip_status {
                                  stream 0.  The partners' waits then MUST give up (after a shortened spin): the error path of
                                  tip_check is exercised deterministically.  0 = off (default). */
 
+#define TIP_OPT_FUSE_HEAD 5 /* 1: the output projection (:102) runs as the epilogue of the four-window recurrence kernel instead of as a
+                               launch of its own, when the launch qualifies (T = 40, full output, one tile per cluster, i.e. B <= 256 on
+                               a full part); bit-identical results.  0 (default): separate launch.  Measured neutral to -1.2 us per
+                               step; kept selectable.  Environment TIP_RNN_HEAD=1 makes 1 the default. */
+
 /* ---- lifetime: replaces TF_RNN_Past_State.__init__ (simple_transformer_with_state.py:9-54) ---------------- */
 int tip_abi_version(void);
 int tip_create(const tip_config* cfg, tip_handle** out);

@@ -636,30 +636,29 @@ def test_pair_split_plan_refuses_what_it_cannot_hold():
 
 @pytest.mark.parametrize("B", [65, 200, 256])
 def test_projection_fused_into_the_recurrence(B):
-    """AUTO at 64 < B <= 256, T = 40 runs the output projection (:102) as the epilogue of rnn_rows4_kernel (tip_general.hip, HEAD):
-    same arithmetic, in the same order, as the stand-alone register-resident kernel — so (a) the last rows equal forward_last's
-    (whose projection IS the stand-alone kernel, MODE 2) bit for bit, and (b) the whole output equals, bit for bit, that of a
-    process run with TIP_RNN_HEAD=0 (projection as a launch of its own)."""
-    import subprocess, sys, tempfile, os
+    """TIP_OPT_FUSE_HEAD: at 64 < B <= 256, T = 40 the output projection (:102) runs as the epilogue of rnn_rows4_kernel
+    (tip_general.hip, HEAD) — the same arithmetic in the same order as the stand-alone register-resident kernel: the whole output
+    equals the separate launch's bit for bit, the last rows equal forward_last's (whose projection stays the stand-alone MODE 2),
+    and other window lengths / forward_last simply do not fuse."""
     cfg = synth.PAPER
     m, w = _gpu_model(cfg, 0)
+    h = m._ensure_handle()
     x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=123 + B, nan_frac=0.01)
-    y = _run(m, x_imu, x_s)
-    assert np.isfinite(y).all()
-    assert np.array_equal(y[:, -1], _run(m, x_imu, x_s, last=True))
+    assert h.get_option(tlib.TIP_OPT_FUSE_HEAD) in (0, 1)
+    h.set_option(tlib.TIP_OPT_FUSE_HEAD, 0)
+    m.set_plan("auto", profile=1)
+    y0 = _run(m, x_imu, x_s)
+    assert "out_linear" in [n for n, _, _ in m.profile_read()]
+    h.set_option(tlib.TIP_OPT_FUSE_HEAD, 1)
+    m.set_plan("auto", profile=1)
+    y1 = _run(m, x_imu, x_s)
+    assert "out_linear" not in [n for n, _, _ in m.profile_read()], "the projection was still launched on its own"
+    assert np.isfinite(y1).all() and np.array_equal(y0, y1)
+    assert np.array_equal(y1[:, -1], _run(m, x_imu, x_s, last=True))
     yo = oracle.forward(cfg, w, x_imu[:3], x_s[:3], dtype=np.float64)
-    assert np.abs(y[:3] - yo).max() < TOL_TIGHT
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "y.npy")
-        code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-                "from tip_amd import synth\n"
-                "from test_host_cpu import make_model, load_synth\n"
-                "m = make_model(synth.PAPER); load_synth(m, synth.PAPER, 0); m = m.cuda().eval()\n"
-                "xi, xs = synth.make_inputs(synth.PAPER, %d, 40, seed=%d, nan_frac=0.01)\n"
-                "with torch.no_grad(): y = m(torch.tensor(xi).cuda(), torch.tensor(xs).cuda())\n"
-                "np.save(%r, y.cpu().numpy())\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                                    os.path.dirname(os.path.abspath(__file__)), B, 123 + B, out)
-        env = dict(os.environ, TIP_RNN_HEAD="0")
-        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        assert np.array_equal(np.load(out), y), "fused and stand-alone projection differ"
+    assert np.abs(y1[:3] - yo).max() < TOL_TIGHT
+    # T = 39: does not qualify, same results either way
+    m.set_plan("auto")
+    a = _run(m, x_imu[:, :39], x_s[:, :39])
+    h.set_option(tlib.TIP_OPT_FUSE_HEAD, 0)
+    assert np.array_equal(a, _run(m, x_imu[:, :39], x_s[:, :39]))

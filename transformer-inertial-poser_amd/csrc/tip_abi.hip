@@ -293,6 +293,7 @@ int tip_create(const tip_config* cfg, tip_handle** out) {
     h->d = d;
     build_tensor_table(h);
     build_layout(h);
+    h->fuse_head = (getenv("TIP_RNN_HEAD") && getenv("TIP_RNN_HEAD")[0] == '1') ? 1 : 0;   // TIP_OPT_FUSE_HEAD's default
     int dev = -1;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0) {
         h->device = dev;
@@ -353,6 +354,10 @@ int tip_set_option(tip_handle* h, int option, int value) {
             if (value < 0 || value > 7) return TIP_ERR_INVALID_ARG;
             h->fault_inject = value;
             return TIP_OK;
+        case TIP_OPT_FUSE_HEAD:
+            if (value < 0 || value > 1) return TIP_ERR_INVALID_ARG;
+            h->fuse_head = value;
+            return TIP_OK;
         default: return TIP_ERR_INVALID_ARG;
     }
 }
@@ -372,6 +377,7 @@ int tip_get_option(const tip_handle* h, int option, int* value) {
         case TIP_OPT_PROFILE: *value = h->profile; return TIP_OK;
         case TIP_OPT_RNN_CLUSTER: *value = h->rnn_cluster; return TIP_OK;
         case TIP_OPT_FAULT_INJECT: *value = h->fault_inject; return TIP_OK;
+        case TIP_OPT_FUSE_HEAD: *value = h->fuse_head; return TIP_OK;
         default: return TIP_ERR_INVALID_ARG;
     }
 }
@@ -797,10 +803,9 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         }
         {
             StageScope sc(h, s, "rnn_recurrence");
-            // the output projection rides as the recurrence's epilogue when the launch qualifies (rnn_rows4_kernel<.., HEAD>;
-            // TIP_RNN_HEAD=0 keeps it a launch of its own: measurement)
-            static const bool fuse_head = !(getenv("TIP_RNN_HEAD") && getenv("TIP_RNN_HEAD")[0] == '0') &&
-                                          !(getenv("TIP_HEAD") && getenv("TIP_HEAD")[0] == 'o');
+            // TIP_OPT_FUSE_HEAD: the output projection rides as the recurrence's epilogue when the launch qualifies
+            // (rnn_rows4_kernel<.., HEAD>)
+            const bool fuse_head = h->fuse_head && !(getenv("TIP_HEAD") && getenv("TIP_HEAD")[0] == 'o');
             HeadFuse hf;
             hf.wfrag = P + L.out_frag_off; hf.bias = P + L.out_lin.b_off; hf.y = y; hf.ldy = d.S; hf.N = d.S;
             const bool can_fuse = fuse_head && !last_only && plan != TIP_PLAN_LATENCY && d.R == 512 && d.S > 128 && d.S <= 144 &&

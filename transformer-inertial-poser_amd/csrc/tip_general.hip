@@ -1056,6 +1056,49 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
     if (dead && !HEAD) return;
     const unsigned spin_big = guard_spin_limit(gd.fault, 1u << 22), spin_pull = guard_spin_limit(gd.fault, 1u << 20);
 
+    const int prow = tid >> 7, pcol = (tid & 127) * 4;            // this thread's 16 bytes of a pulled tile: row, first column
+    const int tpg = (ntiles + ngroups - 1) / ngroups;             // tiles per cluster
+    const unsigned rowbytes = (unsigned)T * R * 4;
+    int vpull[NT], vout[NT];
+    auto set_tiles = [&](int q0) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            int tile = group + ngroups * (q0 + n);
+            if (q0 + n >= tpg || tile >= ntiles) tile = ntiles;   // past the batch: rows >= B, out of the descriptor's range
+            vpull[n] = (int)((unsigned)(tile * kQ4Rows + prow) * rowbytes + (unsigned)pcol * 4u);
+            vout[n] = (int)((unsigned)(tile * kQ4Rows + lg) * rowbytes + (unsigned)(nb * 16 + l15) * 4u);
+        }
+    };
+    // The input term (and the backward's gate) of step t + 1 is requested during step t's MFMA phase, AFTER its pull: vector
+    // memory returns in order, so an HBM-latency load issued in front of the poll loads would hold every one of them back.
+    float ihn[NT], gn[NT];
+    auto request_inputs = [&](int te_) {
+        const int so = te_ * (R * 4);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            ihn[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, vout[n], so, 0));
+            gn[n] = BWD ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, vout[n], so, 0)) : 0.f;
+        }
+    };
+    // The rows the producers are about to write sit in HBM / Infinity Cache (the encoder armed them with the sentinel long
+    // ago): a 64-byte store then allocates a PARTIALLY valid line in L2, and the first poll of that line waits for its fill
+    // from memory.  Each member therefore touches (one 16-byte load per thread and tile, result unused) the rows of step
+    // t + 2 during step t: the producers' stores then hit valid lines and the polls are plain L2 hits.
+    u32x4 pfv[NT];
+    auto touch_rows = [&](int te_) {
+        const int so = te_ * (R * 4);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) pfv[n] = __builtin_amdgcn_raw_buffer_load_b128(hrs, vpull[n], so, 16);
+    };
+    auto retire_touch = [&]() {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) asm volatile("" :: "v"(pfv[n]));
+    };
+    // Step 0 of the first batch needs no W_hh (h_{-1} = 0): its input term and row touches are requested IN FRONT of the 256-KB
+    // weight load (vector memory returns in order), so that step is over when the weights land instead of starting then.
+    set_tiles(0);
+    request_inputs(BWD ? T - 1 : 0);
+    touch_rows(BWD ? T - 1 : 0);
     // W_hh slice -> registers, once: all 32 k-blocks of this wave's 16 columns (in flight during the exchange below)
     float4 wreg[KB];
     {
@@ -1093,49 +1136,16 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         g_rnn_trace[7] = __builtin_amdgcn_s_memtime();   // XCC exchange done, W_hh slice in registers
     }
-    const int prow = tid >> 7, pcol = (tid & 127) * 4;            // this thread's 16 bytes of a pulled tile: row, first column
     const int aoff = (lane & 3) * LD + lg * 4;                    // this lane's A operand: row lane & 3, k = 16 kb + 4 lg ..
     const int lds_w = prow * LD + pcol;                            // where this thread's 16 bytes of a pulled tile go
     bool poisoned = false;                                         // (wave-uniform)
 
-    const int tpg = (ntiles + ngroups - 1) / ngroups;             // tiles per cluster
-    const unsigned rowbytes = (unsigned)T * R * 4;
     for (int q0 = dead ? tpg : 0; q0 < tpg; q0 += NT) {
-        int vpull[NT], vout[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            int tile = group + ngroups * (q0 + n);
-            if (q0 + n >= tpg || tile >= ntiles) tile = ntiles;   // past the batch: rows >= B, out of the descriptor's range
-            vpull[n] = (int)((unsigned)(tile * kQ4Rows + prow) * rowbytes + (unsigned)pcol * 4u);
-            vout[n] = (int)((unsigned)(tile * kQ4Rows + lg) * rowbytes + (unsigned)(nb * 16 + l15) * 4u);
+        if (q0 > 0) {
+            set_tiles(q0);
+            request_inputs(BWD ? T - 1 : 0);
+            touch_rows(BWD ? T - 1 : 0);
         }
-        // The input term (and the backward's gate) of step t + 1 is requested during step t's MFMA phase, AFTER its pull: vector
-        // memory returns in order, so an HBM-latency load issued in front of the poll loads would hold every one of them back.
-        float ihn[NT], gn[NT];
-        auto request_inputs = [&](int te_) {
-            const int so = te_ * (R * 4);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                ihn[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(irs, vout[n], so, 0));
-                gn[n] = BWD ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(grs, vout[n], so, 0)) : 0.f;
-            }
-        };
-        // The rows the producers are about to write sit in HBM / Infinity Cache (the encoder armed them with the sentinel long
-        // ago): a 64-byte store then allocates a PARTIALLY valid line in L2, and the first poll of that line waits for its fill
-        // from memory.  Each member therefore touches (one 16-byte load per thread and tile, result unused) the rows of step
-        // t + 2 during step t: the producers' stores then hit valid lines and the polls are plain L2 hits.
-        u32x4 pfv[NT];
-        auto touch_rows = [&](int te_) {
-            const int so = te_ * (R * 4);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) pfv[n] = __builtin_amdgcn_raw_buffer_load_b128(hrs, vpull[n], so, 16);
-        };
-        auto retire_touch = [&]() {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) asm volatile("" :: "v"(pfv[n]));
-        };
-        request_inputs(BWD ? T - 1 : 0);
-        touch_rows(BWD ? T - 1 : 0);
         retire_touch();
         if (T > 1) touch_rows(BWD ? T - 2 : 1);
 #pragma unroll 1

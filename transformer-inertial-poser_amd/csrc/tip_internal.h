@@ -256,6 +256,7 @@ struct tip_handle {
     unsigned* err_host = nullptr;   // 64-byte pinned, device-mapped host block: word 0 = "a hand-off wait gave up" (sticky)
     unsigned* err_dev = nullptr;    // the device's address of it
     int fault_inject = 0;           // TIP_OPT_FAULT_INJECT (tests)
+    int fuse_head = 0;              // TIP_OPT_FUSE_HEAD
     tip::Guard guard() const { return tip::Guard{err_dev, fault_inject}; }
 };
 
