@@ -374,6 +374,9 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
         out["stream1_closed_loop"] = stream_latency.measure(model, 1, frames=300)
         out["stream1_closed_loop"]["note"] = ("warm (260 frames before the first timed one): round 2's 1.37 ms figure was the first "
                                               "60 frames of a cold process (clock ramp + first-use kernel loads), not the loop")
+        out["stream1_closed_loop_hip_graph"] = stream_latency.measure(model, 1, frames=300, use_graph=True)
+        out["stream1_closed_loop_hip_graph"]["note"] = ("StreamingEngine(use_graph=True): ingest + forward_last + consume captured once, "
+                                                        "one graph launch per frame; bit-identical outputs (tests/test_streaming_gpu.py)")
     except Exception as e:
         out["stream1_closed_loop"] = {"error": f"{type(e).__name__}: {e}"}
     # -- EXPLORATORY, never the headline: plan "fused16" (csrc/tip_s16.hip) — the same forward with every GEMM's fp32 operands

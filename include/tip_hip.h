@@ -178,7 +178,14 @@ int tip_check(tip_handle* h, int clear);
  *          tip_stream_ingest(state, raw_imu[n,72], n, f, x_imu[n,T,90], x_s[n,T,131], stream);
  *          if (T > 0) { tip_forward(..., TIP_FWD_LAST_ROW_ONLY) -> y_last[n,131];
  *                       tip_stream_consume(state, y_last, n, f - 5, s_rest[n,111] (= s_t[3:114]), c_t[n,20], stream); }
- *      PyBullet FK and the SBP root-translation correction (:169-194) stay with the host. */
+ *      PyBullet FK and the SBP root-translation correction (:169-194) stay with the host.
+ *      HIP graphs: kernel arguments are frozen at capture, so once the window is full (frame_idx >= 43 has been ingested, T = 40
+ *      from then on) both calls accept TIP_STREAM_FRAME_AUTO for frame_idx / call_idx — "the frame after the last one ingested",
+ *      read from a counter the ingest kernel keeps in `state`.  The triple ingest(AUTO) -> tip_forward -> consume(AUTO) can then be
+ *      captured once (hipStreamBeginCapture) and replayed per frame: one graph launch instead of ~23 kernel launches
+ *      (tip_amd.StreamingEngine(use_graph=True)).  Entry points called on a capturing stream skip the cross-stream serialisation
+ *      and the CU-mask query (see tip_check above): replay such a graph when no other forward is in flight on the device. */
+#define TIP_STREAM_FRAME_AUTO (-1)
 int tip_stream_state_bytes(int n_streams, size_t* bytes);
 int tip_stream_reset(void* state, const float* s_init /* [n,114] device */, int n_streams, tip_stream_t stream);
 int tip_stream_window_len(int frame_idx); /* 0 while the 11-tap smoother primes (frames 0..4), then 1..40 */

@@ -210,3 +210,40 @@ def test_rotation_branches_against_scipy_conventions():
         k += 1
     assert k == frames - 5
     print("rotation-branch worst |axis-angle - scipy| =", worst)
+
+
+@pytest.mark.parametrize("B", [1, 3, 100])
+def test_graph_mode_equals_launch_by_launch(B):
+    """StreamingEngine(use_graph=True): from frame 44 on (T = 40) a frame is one HIP-graph launch — ingest / forward_last / consume
+    captured once, frame and call indices read from the counter the ingest kernel keeps in the state buffer
+    (TIP_STREAM_FRAME_AUTO).  Same kernels, same arguments otherwise: the closed loop stays bit-identical to the launch-by-launch
+    engine over the capture frame and 60 replays; reset() starts over (priming frames, growing windows, a fresh capture)."""
+    from scipy.spatial.transform import Rotation
+    cfg = synth.PAPER
+    m = make_model(cfg)
+    load_synth(m, cfg, 0)
+    m = m.cuda().eval()
+    rng = np.random.RandomState(3)
+    F = 105
+    raw = np.zeros((F, B, 72), dtype=np.float32)
+    for f in range(F):
+        raw[f, :, :54] = Rotation.random(B * 6, random_state=100 + f).as_matrix().reshape(B, 54)
+        raw[f, :, 54:] = rng.randn(B, 18)
+    s_init = rng.randn(B, 114).astype(np.float32) * 0.2
+    ref = tip_amd.streaming.StreamingEngine(m, s_init)
+    eng = tip_amd.streaming.StreamingEngine(m, s_init, use_graph=True)
+    for rounds in range(2):
+        for f in range(F):
+            a, b = ref.step(raw[f]), eng.step(raw[f])
+            assert (a is None) == (b is None)
+            if a is None:
+                continue
+            torch.cuda.synchronize()
+            for k in ("s_rest", "c_t", "y_last"):
+                assert torch.equal(a[k], b[k]), (rounds, f, k)
+            assert a["T"] == b["T"]
+        assert eng._graph is not None
+        m.check_handoffs()
+        ref.reset()
+        eng.reset()
+        assert eng._graph is None

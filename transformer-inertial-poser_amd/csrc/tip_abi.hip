@@ -224,9 +224,10 @@ struct DevSerialState {
 DevSerialState g_serial[kMaxDevices];
 }  // namespace
 
-CoopSerial::CoopSerial(hipStream_t s) : dev(tip_cur_device()), stream(s), status(hipSuccess) {
+CoopSerial::CoopSerial(hipStream_t s) : dev(tip_cur_device()), stream(s), capturing(stream_is_capturing(s)), status(hipSuccess) {
     DevSerialState& st = g_serial[dev];
     st.mu.lock();
+    if (capturing) return;   // see stream_is_capturing (tip_internal.h)
     if (st.have && st.last != s) {
         if (!st.multi) {
             // first stream switch on this device: there is no event behind the previous forward yet — drain the device once
@@ -241,9 +242,11 @@ CoopSerial::CoopSerial(hipStream_t s) : dev(tip_cur_device()), stream(s), status
 
 CoopSerial::~CoopSerial() {
     DevSerialState& st = g_serial[dev];
-    if (st.multi) (void)hipEventRecord(st.ev, stream);
-    st.last = stream;
-    st.have = true;
+    if (!capturing) {
+        if (st.multi) (void)hipEventRecord(st.ev, stream);
+        st.last = stream;
+        st.have = true;
+    }
     st.mu.unlock();
 }
 }  // namespace tip

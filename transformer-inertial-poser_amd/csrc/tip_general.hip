@@ -993,6 +993,12 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
             }
         }
     }
+    // Leave the XCC-exchange word cleared: a REPLAY of this launch from a captured HIP graph carries the same tag, and must wait
+    // for that launch's words instead of finding this one's.  (T >= 2: a member that has finished has consumed every partner's
+    // step-0 state, which a partner stores only after its own exchange — nobody can still be polling this word.  With T = 1
+    // there is no such ordering and the word stays.)
+    if (HANDOFF == 1 && T >= 2 && tid == 0)
+        __hip_atomic_store(flags + group * CLUSTER + cid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1257,6 +1263,8 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
         retire_touch();
         __syncthreads();   // the next batch's second step rewrites the buffer the last step of this one may still be reading
     }
+    // leave the XCC-exchange word cleared for a replay of this launch from a HIP graph (same tag): see rnn_resident_kernel
+    if (T >= 2 && tid == 0 && !dead) __hip_atomic_store(flags + group * CLUSTER + cid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if constexpr (HEAD) {
         // one tile per cluster (host-side condition): this member projects window 4 * group + cid.  Rows 0 .. T-2 of the tile were
         // pulled complete by this workgroup in the steps above; row T-1 is awaited below, behind the weight loads.

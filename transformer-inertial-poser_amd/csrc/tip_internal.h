@@ -198,9 +198,22 @@ struct PerDeviceInt {
 // launches with this guard: the first time a second stream shows up on a device the device is drained once, from then on the
 // new stream waits on an event recorded behind the previous forward (one hipEventRecord per forward, only in processes that
 // really use several streams).  A forward fills the GPU by itself: nothing is lost by not overlapping two of them.
+// A stream that is being CAPTURED into a HIP graph (hipStreamBeginCapture: the streaming engine's graph mode, or any caller's) is
+// left alone: an event recorded inside a capture cannot order work outside it.  A captured forward is therefore not serialised
+// against other streams by the library — replay the graph on the stream the other forwards use, or when none is in flight.
+inline bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return cs != hipStreamCaptureStatusNone;
+}
+
 struct CoopSerial {
     int dev;
     hipStream_t stream;
+    bool capturing;
     hipError_t status;      // hipSuccess, or what the wait / drain returned (the caller reports it)
     explicit CoopSerial(hipStream_t s);
     ~CoopSerial();
@@ -212,6 +225,7 @@ struct CoopSerial {
 // (hipExtStreamCreateWithCUMask — the co-tenant / partitioned-GPU case).  Plan selection (rounds of #CUs windows), grid sizes and
 // above all the co-residency bound of the cooperating kernels (clusters <= CUs / members) are computed from THIS number.
 inline int effective_cus(int device_cus, hipStream_t s) {
+    if (stream_is_capturing(s)) return device_cus;   // no runtime queries inside a capture; a graph is sized for the whole device
     uint32_t mask[32] = {0};
     if (hipExtStreamGetCUMask(s, 32, mask) != hipSuccess) {
         (void)hipGetLastError();

@@ -15,7 +15,9 @@
 // root translation, which is not a model input.
 //
 // State per stream (floats, caller-owned device buffer): raw[11][72] | loc[40][72] | accs[40][18] | hist[40][131] |
-// outs[6][131] | last[54].  Frame / call counters live on the host (all streams advance in lock step).
+// outs[6][131] | last[54] | frame counter (int).  Frame / call counters live on the host (all streams advance in lock step); the
+// ingest kernel also leaves the frame index in the state, so that a call with TIP_STREAM_FRAME_AUTO continues from it — kernel
+// arguments are frozen in a captured HIP graph, a counter in HBM is not.
 #include "tip_internal.h"
 
 namespace tip {
@@ -28,7 +30,8 @@ constexpr int ACCS = LOC + WIN * NIMU;        // 3672
 constexpr int HIST = ACCS + WIN * 18;         // 4392
 constexpr int OUTS = HIST + WIN * NS;         // 9632
 constexpr int LAST = OUTS + OUTN * NS;        // 10418
-constexpr int STRIDE = 10496;                 // LAST + 54 = 10472, padded to a multiple of 64
+constexpr int CTR = LAST + 54;                // 10472: frame index of the last ingest (int)
+constexpr int STRIDE = 10496;                 // CTR + 1 = 10473, padded to a multiple of 64
 }  // namespace sz
 
 // ---- scipy.spatial.transform.Rotation restated (fp32) -------------------------------------------------------
@@ -158,6 +161,12 @@ __global__ __launch_bounds__(256) void stream_ingest_kernel(float* __restrict__ 
     __shared__ float sm[NIMU], loc[NIMU], inv[9];
     const int b = blockIdx.x, tid = threadIdx.x;
     float* S = state + (size_t)b * STRIDE;
+    int* ctr = reinterpret_cast<int*>(S + CTR);
+    if (f < 0) {   // TIP_STREAM_FRAME_AUTO: the frame after the last one ingested (every thread reads before thread 0 writes)
+        f = *ctr + 1;
+        __syncthreads();
+    }
+    if (tid == 0) *ctr = f;
     if (tid < NIMU) {
         const float v = raw_in[(size_t)b * NIMU + tid];
         if (f == 0) {
@@ -230,6 +239,7 @@ __global__ __launch_bounds__(192) void stream_consume_kernel(float* __restrict__
     float* S = state + (size_t)b * STRIDE;
     const float coeff[OUTN] = {0.07776f, 0.1296f, 0.216f, 0.36f, 0.6f, 1.0f};   // 0.6^(5..0) (:57)
     const float csum = 0.07776f + 0.1296f + 0.216f + 0.36f + 0.6f + 1.0f;
+    if (k < 0) k = *reinterpret_cast<const int*>(S + CTR) - 5;   // TIP_STREAM_FRAME_AUTO: the call that belongs to the last ingested frame
     const int n = k + 1;
     if (tid < NS) {
         const float y = y_last[(size_t)b * NS + tid];
@@ -324,8 +334,8 @@ int tip_stream_window_len(int frame_idx) {   // T of the model call issued for f
 
 int tip_stream_ingest(void* state, const float* raw_imu, int n_streams, int frame_idx, float* x_imu, float* x_s,
                       tip_stream_t stream) {
-    if (!state || !raw_imu || n_streams < 0 || frame_idx < 0) return TIP_ERR_INVALID_ARG;
-    const int T = tip_stream_window_len(frame_idx);
+    if (!state || !raw_imu || n_streams < 0 || frame_idx < TIP_STREAM_FRAME_AUTO) return TIP_ERR_INVALID_ARG;
+    const int T = frame_idx == TIP_STREAM_FRAME_AUTO ? sz::WIN : tip_stream_window_len(frame_idx);
     if (T > 0 && (!x_imu || !x_s)) return TIP_ERR_INVALID_ARG;
     if (n_streams == 0) return TIP_OK;
     hipLaunchKernelGGL(stream_ingest_kernel, dim3(n_streams), dim3(256), 0, static_cast<hipStream_t>(stream),
@@ -335,7 +345,7 @@ int tip_stream_ingest(void* state, const float* raw_imu, int n_streams, int fram
 
 int tip_stream_consume(void* state, const float* y_last, int n_streams, int call_idx, float* s_rest, float* c_t,
                        tip_stream_t stream) {
-    if (!state || !y_last || !s_rest || !c_t || n_streams < 0 || call_idx < 0) return TIP_ERR_INVALID_ARG;
+    if (!state || !y_last || !s_rest || !c_t || n_streams < 0 || call_idx < TIP_STREAM_FRAME_AUTO) return TIP_ERR_INVALID_ARG;
     if (n_streams == 0) return TIP_OK;
     hipLaunchKernelGGL(stream_consume_kernel, dim3(n_streams), dim3(192), 0, static_cast<hipStream_t>(stream),
                        static_cast<float*>(state), y_last, n_streams, call_idx, s_rest, c_t);

@@ -10,6 +10,13 @@ Everything between the raw IMU frame and the fed-back history row stays in HBM: 
 rotation, acc-sum feature, window gather, the forward pass (TIP_FWD_LAST_ROW_ONLY), output filter, SBP decode,
 6D <-> axis-angle and the pose averaging (csrc/tip_stream.hip).  PyBullet FK and the SBP root-translation correction
 (:169-194) remain the host's job (they never feed back into the model input).
+
+use_graph=True: once the window is full (T = 40 from frame 44 on) the three calls of a frame — ingest, forward_last, consume:
+about 23 kernel launches for a handful of streams, each ~8 us of host time, which is what bounds a single stream's frame rate —
+are captured ONCE into a HIP graph (torch.cuda.CUDAGraph; frame / call indices come from a counter in the state buffer,
+TIP_STREAM_FRAME_AUTO) and every further frame is one copy of the raw frame into a static buffer + one graph launch.  Outputs are
+bit-identical to the launch-by-launch loop (tests/test_streaming_gpu.py).  The graph freezes the model's packed weights and plan:
+call reset() (or build a new engine) after changing parameters.
 """
 from __future__ import annotations
 
@@ -22,8 +29,10 @@ from . import lib as _lib
 
 
 class StreamingEngine:
-    def __init__(self, model, s_init: torch.Tensor):
+    def __init__(self, model, s_init: torch.Tensor, use_graph: bool = False):
         self.model = model
+        self.use_graph = bool(use_graph)
+        self._graph = None
         self.lib = _lib.load()
         s_init = torch.as_tensor(s_init, dtype=torch.float32)
         if s_init.dim() == 1:
@@ -46,6 +55,7 @@ class StreamingEngine:
         self.x_s = torch.empty((self.n, 40, 131), dtype=torch.float32, device=self.device)
         self.s_rest = torch.empty((self.n, 111), dtype=torch.float32, device=self.device)
         self.c_t = torch.empty((self.n, 20), dtype=torch.float32, device=self.device)
+        self.raw = torch.empty((self.n, 72), dtype=torch.float32, device=self.device)    # static input of the captured graph
         self.reset()
 
     def _check(self, status: int):
@@ -57,11 +67,36 @@ class StreamingEngine:
 
     def reset(self):
         self.frame = 0
+        self._graph = None
+        self._y_last = None
         with torch.cuda.device(self.device):
             self._check(self.lib.tip_stream_reset(self.state.data_ptr(), self.s_init.data_ptr(), self.n, self._stream()))
 
+    def _frame_auto(self):
+        """ingest -> forward_last -> consume with the frame index taken from the state buffer (capturable)."""
+        st = self._stream()
+        self._check(self.lib.tip_stream_ingest(self.state.data_ptr(), self.raw.data_ptr(), self.n, _lib.TIP_STREAM_FRAME_AUTO,
+                                               self.x_imu.data_ptr(), self.x_s.data_ptr(), st))
+        y_last = self.model.forward_last(self.x_imu, self.x_s)
+        self._check(self.lib.tip_stream_consume(self.state.data_ptr(), y_last.data_ptr(), self.n, _lib.TIP_STREAM_FRAME_AUTO,
+                                                self.s_rest.data_ptr(), self.c_t.data_ptr(), st))
+        return y_last
+
     @torch.no_grad()
     def step(self, raw_imu: torch.Tensor) -> Optional[dict]:
+        if self.use_graph and self.frame >= 44 and not self.model.training:
+            # steady state (T = 40): one copy + one graph launch per frame
+            self.raw.copy_(torch.as_tensor(raw_imu, dtype=torch.float32).reshape(self.n, 72), non_blocking=True)
+            with torch.cuda.device(self.device):
+                if self._graph is None:
+                    torch.cuda.current_stream(self.device).synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._y_last = self._frame_auto()
+                    self._graph = g
+                self._graph.replay()
+            self.frame += 1
+            return {"s_rest": self.s_rest, "c_t": self.c_t, "y_last": self._y_last, "T": 40}
         raw = torch.as_tensor(raw_imu, dtype=torch.float32).reshape(self.n, 72).to(self.device, non_blocking=True).contiguous()
         f = self.frame
         T = int(self.lib.tip_stream_window_len(f))
