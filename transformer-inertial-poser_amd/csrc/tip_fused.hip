@@ -1761,6 +1761,94 @@ hipError_t launch_attn_bwd(const Dims& d, const AttnBwdArgs& a, int B, int T, in
     return hipGetLastError();
 }
 
+// =====================================================================================================================
+// Training step, the dX products outside the encoder layers, per window:  out[T][N] = A[T][K] W'^T  with W' [N][16 KB] in
+// fragment order.  These were batch-wide LDS-tiled GEMMs (tgemm16: dH = dy W_out 29.7 us, d_enc = delta W_ih 36.6 us at B = 256 —
+// 46 / 73 TFLOP/s: 10 240 rows x 256-512 columns is 640-1 280 tiles of 64 x 64 on 256 CUs with both operands staged per tile);
+// here a workgroup takes one window: its 40 rows go to LDS once (whole K), each wave owns NBW column blocks and streams their
+// weight fragments through the register ring of the fused kernels, rows 0-31 on 16x16x4 and rows 32-39 on 4x4x1 MFMAs
+// (gemm_phase_h) — nothing on pad rows, no per-tile operand staging.
+//   <2, 32>: N = 256, K = 512 (d_enc);   <4, 10>: N = 512, K = 160 (dH: dy padded to 144 columns, the k-blocks come in pairs)
+// =====================================================================================================================
+template <int NBW, int KB>
+__global__ __launch_bounds__(fz::THREADS) void win_gemm_kernel(WinGemmArgs a, int B, int T) {
+    using namespace fz;
+    using namespace fzh;
+    constexpr int K = KB * 16, LDA = K + 4, C4 = K / 4, NI = (RP * C4 + THREADS - 1) / THREADS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // A rows [RP][LDA]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wfrag), 0, a.wbytes, 0x00020000);
+    const int voff = lane * 16;
+    const int wsoff = wave * NBW * KB * 1024;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int win = blockIdx.x; win < B; win += gridDim.x) {
+        WRing<NBW> g;
+        ring_prefetch<NBW>(g, rsrc, voff, wsoff, KB * 1024);
+        // the window's rows -> LDS: every load in flight before the first store (clamped addresses, zeros afterwards)
+        f32x4 v[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int i = tid + j * THREADS, row = i / C4, c = (i - row * C4) * 4;
+            const int rc = row < T ? row : T - 1, cc = c < a.kvalid ? c : a.kvalid - 4;
+            v[j] = *reinterpret_cast<const f32x4*>(a.A + ((size_t)win * T + rc) * a.lda + cc);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int i = tid + j * THREADS, row = i / C4, c = (i - row * C4) * 4;
+            if (i < RP * C4) *reinterpret_cast<f32x4*>(smem + row * LDA + c) = (row < T && c < a.kvalid) ? v[j] : zero4;
+        }
+        __syncthreads();
+        f32x4 acc[RBM][NBW], acct[RBT][NBW];
+        zero_acc_h<NBW>(acc, acct);
+        gemm_phase_h<NBW, KB, 0, true>(acc, acct, smem + l15 * LDA + lg * 4, smem + (TAIL0 + (lane & 3)) * LDA + lg * 4, LDA, rsrc, voff, wsoff,
+                                       KB * 1024, g, wsoff, KB * 1024);
+        float* out = a.out + (size_t)win * T * a.ldo;
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) {
+            const int col = (wave * NBW + n) * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < RBM; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = r * 16 + lg * 4 + e;
+                    if (row < T) out[(size_t)row * a.ldo + col] = acc[r][n][e];
+                }
+#pragma unroll
+            for (int rb = 0; rb < RBT; ++rb) {
+                const int row = TAIL0 + 4 * rb + lg;
+                const float t = tail_reduce(acct[rb][n], lg);
+                if (row < T) out[(size_t)row * a.ldo + col] = t;
+            }
+        }
+        __syncthreads();   // the next window's rows overwrite the LDS image
+    }
+}
+
+template <int NBW, int KB>
+static hipError_t launch_win_gemm_t(const WinGemmArgs& a, int B, int T, int num_cus, hipStream_t s) {
+    constexpr int lds = fz::RP * (KB * 16 + 4) * 4;
+    static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(win_gemm_kernel<NBW, KB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((win_gemm_kernel<NBW, KB>), dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, a, B, T);
+    return hipGetLastError();
+}
+
+// N = 16 * 8 * nbw columns, K = 16 * kb (weights [N][K] in fragment order, zero padded); hipErrorInvalidValue for other shapes
+hipError_t launch_win_gemm(int N, int K, const WinGemmArgs& a, int B, int T, int num_cus, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (T < 1 || T > fz::TMAX || a.kvalid % 4 || a.kvalid < 4 || a.kvalid > K || a.lda % 4 || (long long)N * K * 4 != (long long)a.wbytes)
+        return hipErrorInvalidValue;
+    if (N == 256 && K == 512) return launch_win_gemm_t<2, 32>(a, B, T, num_cus, s);
+    if (N == 512 && K == 160) return launch_win_gemm_t<4, 10>(a, B, T, num_cus, s);
+    return hipErrorInvalidValue;
+}
+
 }  // namespace tip
 
 extern "C" int tip_debug_read_bwd_trace(unsigned long long* out, int n) {

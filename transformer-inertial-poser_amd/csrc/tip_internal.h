@@ -383,6 +383,16 @@ struct AttnBwdArgs {
     float scale;
 };
 hipError_t launch_attn_bwd(const Dims& d, const AttnBwdArgs& a, int B, int T, int num_cus, hipStream_t s);
+// per-window dX products of the training backward outside the encoder layers (win_gemm_kernel, tip_fused.hip)
+struct WinGemmArgs {
+    const float* A;       // [B * T][lda]
+    int lda, kvalid;      // row stride (floats, multiple of 4); valid columns (multiple of 4): the rest of K reads as zero
+    const float* wfrag;   // W' [N][K] in 16x16x4 B-fragment order, zero padded
+    int wbytes;
+    float* out;           // [B * T][ldo]
+    int ldo;
+};
+hipError_t launch_win_gemm(int N, int K, const WinGemmArgs& a, int B, int T, int num_cus, hipStream_t s);
 // the same kernel as the training forward: activations stashed per `tr`, encoder dropout live (tip_train.hip)
 hipError_t launch_fused_train(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s, const float* keep_mask,
                               float keep_scale, float* ih_out, float* hall_sentinel, const FusedTrain& tr, int B, int T,

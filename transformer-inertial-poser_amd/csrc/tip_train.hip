@@ -1226,6 +1226,7 @@ struct TrainSaved {
     size_t win_p, bin_p, bsum, whh_f, whh_b, U, x0, ih, hall, flags;
     size_t wout_t, wih_t;
     size_t wih_f = 0, wih_tf = 0;
+    size_t wout_f = 0, wout_tf = 0;   // fused path: W_out fragments [144][R] (forward projection) and W_out^T fragments [R][160] (dH)
     size_t fused_img;   // fused-plan weight image (fragment order), packed on the GPU every step; 0 floats when unsupported
     std::vector<TrainLayer> layers;
     size_t total;
@@ -1238,6 +1239,9 @@ struct TrainScratch {
     size_t part_floats;
     size_t total;
 };
+
+// shapes win_gemm_kernel / head_ksplit_kernel are instantiated for: the paper configuration's widths
+static bool win_gemm_shapes(const Dims& d) { return d.D == 256 && d.R == 512 && d.S > 128 && d.S <= 144; }
 
 static size_t take(size_t& off, size_t n) {
     const size_t o = off;
@@ -1262,6 +1266,11 @@ static TrainSaved saved_layout(const Dims& d, int B, int T) {
     const bool frags = !(fused_supported(d, T) && fused_has_rnn_ih(d));
     if (frags && panel_ok((int)M, d.R, d.D)) L.wih_f = take(off, (size_t)d.R * d.D);
     if (frags && panel_ok((int)M, d.D, d.R)) L.wih_tf = take(off, (size_t)d.R * d.D);
+    if (!frags && win_gemm_shapes(d)) {   // the per-window kernels of the fused path (win_gemm_kernel, head_ksplit_kernel)
+        L.wih_tf = take(off, (size_t)d.R * d.D);
+        L.wout_tf = take(off, (size_t)d.R * 160);
+        L.wout_f = take(off, (size_t)144 * d.R);
+    }
     for (int l = 0; l < d.L; ++l) {
         TrainLayer t;
         t.qkv = take(off, M * 3 * d.D);
@@ -1392,6 +1401,15 @@ static int train_fail(tip_handle* h, hipError_t e, const char* what) {
     return TIP_ERR_HIP;
 }
 
+// true when the forward packs its weight layouts through the fused image's pack launches (paper configuration, both fused halves on):
+// only then do the fragment copies the per-window kernels of the backward read (wih_tf, wout_tf) exist in `saved`
+static bool train_fused_prep(const Dims& d, int T) {
+    static int use_fused_prep = -1;
+    if (use_fused_prep < 0) use_fused_prep = (getenv("TIP_TRAIN_FUSED") && getenv("TIP_TRAIN_FUSED")[0] == '0') ? 0 : 1;
+    return use_fused_prep && fused_supported(d, T) && fused_has_rnn_ih(d) && fused_packed_floats(d) > 0 &&
+           fused_bwd_image_floats(d) > 0 && !(getenv("TIP_TRAIN_FUSED_BWD") && getenv("TIP_TRAIN_FUSED_BWD")[0] == '0');
+}
+
 #define TT(expr, what)                                   \
     do {                                                 \
         hipError_t e_ = (expr);                          \
@@ -1459,10 +1477,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     // needs are W_hh in fragment order (forward / transposed for the backward) and the transposed W_out / W_ih of the two dX GEMMs
     // that stay batch-wide: they ride in the fused image's pack launches (round 3: prep_in, prep_rnn and the batched transpose of
     // every layer's weights were three more launches, ~20 us, most of it for copies only the layer-by-layer path reads).
-    static int use_fused_prep = -1;
-    if (use_fused_prep < 0) use_fused_prep = (getenv("TIP_TRAIN_FUSED") && getenv("TIP_TRAIN_FUSED")[0] == '0') ? 0 : 1;
-    const bool fused_prep = use_fused_prep && fused_supported(d, T) && fused_has_rnn_ih(d) && fused_packed_floats(d) > 0 &&
-                            fused_bwd_image_floats(d) > 0 && !(getenv("TIP_TRAIN_FUSED_BWD") && getenv("TIP_TRAIN_FUSED_BWD")[0] == '0');
+    const bool fused_prep = train_fused_prep(d, T);
     if (!fused_prep) {
         hipLaunchKernelGGL(prep_in_kernel, dim3(grid_for((long long)d.D * d.InPad)), dim3(256), 0, s, params[P_IN_W], params[P_IN_B],
                            W + L.win_p, W + L.bin_p, d.D, d.H, d.In, d.InPad, d.n_imu_total + d.rootv0, d.n_imu_total + d.rootv1);
@@ -1511,6 +1526,11 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
             op(rp[PR_WHH], L.whh_b, d.R, d.R, d.R, d.R, 1, 1);                              // W_hh^T fragments (backward recurrence)
             op(rp[PR_LIN_W], L.wout_t, d.R, round_up(d.S, 16), d.R, d.S, 0, 1);             // W_out^T [R][S padded to 16] (dH = dy W_out)
             op(rp[PR_WIH], L.wih_t, d.D, d.R, d.D, d.R, 0, 1);                              // W_ih^T [D][R] (d_enc = delta W_ih)
+            if (L.wout_f) {
+                op(rp[PR_WIH], L.wih_tf, d.D, d.R, d.D, d.R, 1, 1);                         // ... and in fragment order (win_gemm_kernel)
+                op(rp[PR_LIN_W], L.wout_tf, d.R, 160, d.R, d.S, 1, 1);                      // W_out^T fragments [R][160], zero padded (dH)
+                op(rp[PR_LIN_W], L.wout_f, 144, d.R, d.S, d.R, 1, 0);                       // W_out fragments [144][R] (forward projection)
+            }
         }
         TT(hipMemsetAsync(W + L.fused_img, 0, fused_packed_floats(d) * sizeof(float), s), "train_fused_pack");
         TT(run_pack_ops(ops, W, s), "train_fused_pack");
@@ -1632,9 +1652,18 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     TT(launch_rnn(d, W + L.ih, W + L.whh_f, W + L.hall, reinterpret_cast<unsigned*>(W + L.flags), B, T, auto_cluster(B, ecus),
                   ecus, hall_armed, h->guard(), s), "train_rnn");
     {
-        TG g = tg_base(W + L.hall, d.R, rp[PR_LIN_W], d.R, y, d.S, M, d.S, d.R);
-        g.bias = rp[PR_LIN_B];
-        TT(tgemm16_launch(g, s), "train_head");
+        // fused path, windows of 40 frames: the register-resident projection of the inference path (tip_head.hip) on fragments
+        // packed from the live W_out (27 -> 17 us at B = 256); otherwise the LDS-tiled GEMM
+        static const bool win_k = !(getenv("TIP_TRAIN_WIN_GEMM") && getenv("TIP_TRAIN_WIN_GEMM")[0] == '0');
+        hipError_t he = hipErrorInvalidValue;
+        if (win_k && fused && fused_prep && L.wout_f && T % 40 == 0)
+            he = launch_head_ksplit(W + L.hall, d.R, W + L.wout_f, rp[PR_LIN_B], y, d.S, M, d.S, d.R, false, ecus, s);
+        if (he == hipErrorInvalidValue) {
+            TG g = tg_base(W + L.hall, d.R, rp[PR_LIN_W], d.R, y, d.S, M, d.S, d.R);
+            g.bias = rp[PR_LIN_B];
+            he = tgemm16_launch(g, s);
+        }
+        TT(he, "train_head");
     }
     h->forward_count++;
     return TIP_OK;
@@ -1699,9 +1728,19 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     }
     TT(grad_weight(X + S.dyp, Sp, Sp, d.S, W + L.hall, d.R, d.R, M, part, S.part_floats, grads + goff[rbase + PR_LIN_W], ncu, s),
        "bwd_dW_out");
+    static const bool win_k = !(getenv("TIP_TRAIN_WIN_GEMM") && getenv("TIP_TRAIN_WIN_GEMM")[0] == '0');   // TIP_TRAIN_WIN_GEMM=0: measurement
+    const bool win_g = win_k && fbwd && train_fused_prep(d, T) && L.wout_tf && T <= 40 && Sp <= 160 && Sp % 4 == 0;
     {
-        TG g = tg_base(X + S.dyp, Sp, W + L.wout_t, Sp, X + S.dh, d.R, M, d.R, Sp);
-        TT(tgemm16_launch(g, s), "bwd_dH");
+        hipError_t he = hipErrorInvalidValue;
+        if (win_g) {
+            WinGemmArgs wa{X + S.dyp, Sp, Sp, W + L.wout_tf, (int)((size_t)d.R * 160 * 4), X + S.dh, d.R};
+            he = launch_win_gemm(d.R, 160, wa, B, T, ncu, s);
+        }
+        if (he == hipErrorInvalidValue) {
+            TG g = tg_base(X + S.dyp, Sp, W + L.wout_t, Sp, X + S.dh, d.R, M, d.R, Sp);
+            he = tgemm16_launch(g, s);
+        }
+        TT(he, "bwd_dH");
     }
     // ---- recurrence (:98-99), time reversed: delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2) -------------------------
     TT(launch_rnn_bwd(d, X + S.dh, W + L.whh_b, W + L.hall, X + S.delta, reinterpret_cast<unsigned*>(const_cast<float*>(W + L.flags)),
@@ -1730,8 +1769,16 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     float* gx = X + S.ga;     // gradient w.r.t. the current layer's output
     float* galt = X + S.gb;
     {
-        TG g = tg_base(X + S.delta, d.R, W + L.wih_t, d.R, gx, d.D, M, d.D, d.R);
-        TT(lin_launch(g, L.wih_tf ? W + L.wih_tf : nullptr, s), "bwd_d_enc");
+        hipError_t he = hipErrorInvalidValue;
+        if (win_g) {
+            WinGemmArgs wa{X + S.delta, d.R, d.R, W + L.wih_tf, (int)((size_t)d.D * d.R * 4), gx, d.D};
+            he = launch_win_gemm(d.D, d.R, wa, B, T, ncu, s);
+        }
+        if (he == hipErrorInvalidValue) {
+            TG g = tg_base(X + S.delta, d.R, W + L.wih_t, d.R, gx, d.D, M, d.D, d.R);
+            he = lin_launch(g, L.wih_tf ? W + L.wih_tf : nullptr, s);
+        }
+        TT(he, "bwd_d_enc");
     }
     // ---- encoder layers, last to first -----------------------------------------------------------------------------------
     // fused backward: the per-window LayerNorm / bias partials of every layer stay in place and are reduced by ONE launch after
