@@ -20,7 +20,20 @@ python - "$t" > $R/gpurun_out/$ROUND/timeline_train_step.txt <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'tip::' in r['Kernel_Name']]
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'prep_in_kernel' in r['Kernel_Name']]
+def step_starts():
+    # a step begins with the weight-image pack launches in front of the training forward's encoder kernel (fused path), or with
+    # prep_in_kernel (layer-by-layer path)
+    st = [i for i, r in enumerate(rows) if 'prep_in_kernel' in r['Kernel_Name']]
+    if st:
+        return st
+    for i, r in enumerate(rows):
+        if 'fused_encoder_h_kernel<false, true>' in r['Kernel_Name'] or 'fused_encoder_kernel<8' in r['Kernel_Name']:
+            j = i
+            while j > 0 and 'pack_ops_kernel' in rows[j - 1]['Kernel_Name']:
+                j -= 1
+            st.append(j)
+    return st
+idx = step_starts()
 a, b = idx[-2], idx[-1]          # one full step (forward + backward) near the end
 t0 = int(rows[a]['Start_Timestamp'])
 prev = None
