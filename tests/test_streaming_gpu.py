@@ -247,3 +247,34 @@ def test_graph_mode_equals_launch_by_launch(B):
         ref.reset()
         eng.reset()
         assert eng._graph is None
+
+
+def test_graph_capture_keeps_past_state_dropout_live():
+    """The reference's fresh nn.Dropout(past_state_dropout) is stochastic on every call (:77).  A forward captured into a HIP graph
+    (what StreamingEngine(use_graph=True) does) must re-draw the keep mask on every replay (torch's graph-safe generator), not
+    freeze the one drawn at capture: two replays on identical inputs differ; with p = 0 they are bit-identical."""
+    cfg = synth.PAPER
+    x_imu, x_s = synth.make_inputs(cfg, 2, 40, seed=3)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    for p_state, live in ((0.8, True), (0.0, False)):
+        m = make_model(cfg, p_state=p_state)
+        load_synth(m, cfg, 0)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            m.forward_last(xi, xs)                      # warm: packed image, attributes, workspace
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                y = m.forward_last(xi, xs)
+            g.replay()
+            torch.cuda.synchronize()
+            a = y.clone()
+            g.replay()
+            torch.cuda.synchronize()
+            b = y.clone()
+        assert torch.isfinite(a).all() and torch.isfinite(b).all()
+        if live:
+            assert (a - b).abs().max().item() > 1e-3
+        else:
+            assert torch.equal(a, b)
+        m.check_handoffs()
