@@ -535,14 +535,17 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
             // of them it would hold every poll back by its own round trip) and flies during the dot products
             if (t + 1 < T) ih_next = ihw[(size_t)(t + 1) * R + row];
             const float* hq = hs + lg * 132;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            // four chains (one per float4 component), written as two 2-wide FMAs on the ADJACENT halves of the operands: the
+            // compiler's own pairing of the scalar form — (x, z) and (y, w) — cost three register moves per v_pk_fma_f32
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 const float4 hv = *reinterpret_cast<const float4*>(hq + j * 4);
-                a0 = fmaf(w[j].x, hv.x, a0); a1 = fmaf(w[j].y, hv.y, a1);
-                a2 = fmaf(w[j].z, hv.z, a2); a3 = fmaf(w[j].w, hv.w, a3);
+                a01 = __builtin_elementwise_fma((f2){w[j].x, w[j].y}, (f2){hv.x, hv.y}, a01);
+                a23 = __builtin_elementwise_fma((f2){w[j].z, w[j].w}, (f2){hv.z, hv.w}, a23);
             }
-            acc = (a0 + a1) + (a2 + a3);
+            acc = (a01[0] + a01[1]) + (a23[0] + a23[1]);
             acc = lg4_sum(acc);   // the four K quarters (lane ^ 16, lane ^ 32) on permlane swaps: no LDS round trips on the serial chain
         }
         if (lg == 0) {
