@@ -184,7 +184,10 @@ int tip_check(tip_handle* h, int clear);
  *      read from a counter the ingest kernel keeps in `state`.  The triple ingest(AUTO) -> tip_forward -> consume(AUTO) can then be
  *      captured once (hipStreamBeginCapture) and replayed per frame: one graph launch instead of ~23 kernel launches
  *      (tip_amd.StreamingEngine(use_graph=True)).  Entry points called on a capturing stream skip the cross-stream serialisation
- *      and the CU-mask query (see tip_check above): replay such a graph when no other forward is in flight on the device. */
+ *      and the CU-mask query (see tip_check above): replay such a graph when no other forward is in flight on the device.
+ *      (tip_forward itself may be captured the same way for any batch; the clustered recurrence's per-launch XCC-exchange words are
+ *      cleared by the kernels at their end for T >= 2, so a replay never reads a previous replay's words; capture T = 1 launches of
+ *      more than 64 windows only if they are not replayed.) */
 #define TIP_STREAM_FRAME_AUTO (-1)
 int tip_stream_state_bytes(int n_streams, size_t* bytes);
 int tip_stream_reset(void* state, const float* s_init /* [n,114] device */, int n_streams, tip_stream_t stream);
