@@ -112,6 +112,46 @@ def test_handle_table_status_and_errors():
         h2.forward(0, 1, 1, 1, 1, 0, None, 1.0, 0, 0, 0)
 
 
+def test_new_entry_points_check_their_arguments_without_a_gpu():
+    """Round-3 entry points, the paths that return before any kernel is launched (safe on the CPU box): tip_forward_f64 /
+    tip_forward_f64_bytes, TIP_OPT_FUSE_HEAD, TIP_STREAM_FRAME_AUTO."""
+    import ctypes
+    cfg = synth.PAPER
+    m = make_model(cfg)
+    h = m._ensure_handle()
+    lib = tlib.load()
+    # fp64 forward: workspace size grows with B * T and covers every activation of the layer-by-layer path in doubles
+    n1, n2 = h.forward_f64_bytes(1, 40), h.forward_f64_bytes(256, 40)
+    per_row = 8 * (221 + 256 + 768 + 256 + 1024 + 512 + 512)
+    assert n2 > n1 >= 40 * per_row and n2 >= 256 * 40 * per_row
+    n_t = len(h.tensor_table())
+    ptrs = [8] * n_t
+    h.forward_f64(ptrs, 8, 8, 8, 0, 40, 0, None, 1.0, 0, 0, 0)            # B = 0: nothing to do, TIP_OK
+    with pytest.raises(tlib.TipStatusError) as ei:                          # wrong tensor count
+        h.forward_f64(ptrs[:-1], 8, 8, 8, 1, 40, 0, None, 1.0, 256, 1 << 30, 0)
+    assert ei.value.status == -1
+    with pytest.raises(tlib.TipStatusError) as ei:                          # workspace too small
+        h.forward_f64(ptrs, 8, 8, 8, 1, 40, 0, None, 1.0, 256, 1024, 0)
+    assert ei.value.status == -4
+    with pytest.raises(tlib.TipStatusError) as ei:                          # misaligned workspace
+        h.forward_f64(ptrs, 8, 8, 8, 1, 40, 0, None, 1.0, 264, 1 << 30, 0)
+    assert ei.value.status == -4
+    # options
+    assert h.get_option(tlib.TIP_OPT_FUSE_HEAD) == (1 if os.environ.get("TIP_RNN_HEAD", "0")[:1] == "1" else 0)
+    h.set_option(tlib.TIP_OPT_FUSE_HEAD, 1)
+    assert h.get_option(tlib.TIP_OPT_FUSE_HEAD) == 1
+    with pytest.raises(tlib.TipStatusError):
+        h.set_option(tlib.TIP_OPT_FUSE_HEAD, 2)
+    h.set_option(tlib.TIP_OPT_FUSE_HEAD, 0)
+    # streaming: AUTO is -1, anything below is refused; zero streams is a no-op
+    assert tlib.TIP_STREAM_FRAME_AUTO == -1
+    assert lib.tip_stream_ingest(ctypes.c_void_p(8), ctypes.c_void_p(8), 0, -1, ctypes.c_void_p(8), ctypes.c_void_p(8), None) == 0
+    assert lib.tip_stream_ingest(ctypes.c_void_p(8), ctypes.c_void_p(8), 1, -2, ctypes.c_void_p(8), ctypes.c_void_p(8), None) == -1
+    assert lib.tip_stream_consume(ctypes.c_void_p(8), ctypes.c_void_p(8), 0, -1, ctypes.c_void_p(8), ctypes.c_void_p(8), None) == 0
+    assert lib.tip_stream_consume(ctypes.c_void_p(8), ctypes.c_void_p(8), 1, -2, ctypes.c_void_p(8), ctypes.c_void_p(8), None) == -1
+    assert [lib.tip_stream_window_len(f) for f in (0, 4, 5, 43, 44, 45, 1000)] == [0, 0, 1, 39, 40, 40, 40]
+
+
 def _unpack_linear(img, off_w, off_b, N, K, Npad, Kpad):
     W = img[off_w: off_w + Npad * Kpad].reshape(Npad, Kpad)
     return W[:N, :K], img[off_b: off_b + N], W
