@@ -208,7 +208,10 @@ static hipError_t linear_gemm(const float* P, const tip::PackedLinear& p, const 
         return tip::launch_pgemm16(A, lda, P + p.s_off, (size_t)p.N * p.K, P + p.b_off, res, ldres, C, ldc, M, p.N, p.K, flags, s);
     static int use_pg = -1;   // TIP_GENERAL_PGEMM=0 keeps the LDS-tiled kernel (measurement)
     if (use_pg < 0) use_pg = (getenv("TIP_GENERAL_PGEMM") && getenv("TIP_GENERAL_PGEMM")[0] == '0') ? 0 : 1;
-    if (use_pg && p.f_off && tip::pgemm_shape_ok(M, p.N, p.K))
+    // (the panel kernel's epilogue moves 16 bytes per lane: bias / residual / output rows must be 16-byte aligned — they are for
+    //  every buffer the library carves out itself)
+    auto al16 = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0; };
+    if (use_pg && p.f_off && tip::pgemm_shape_ok(M, p.N, p.K) && al16(P + p.b_off, 0) && al16(C, ldc) && (!(flags & 2) || al16(res, ldres)))
         return tip::launch_pgemm(A, lda, P + p.f_off, (size_t)p.N * p.K, P + p.b_off, res, ldres, C, ldc, M, p.N, p.K, flags, s);
     return tip::launch_gemm(A, lda, P + p.w_off, p.Kpad, P + p.b_off, res, ldres, C, ldc, M, p.N, p.Npad, flags, s);
 }

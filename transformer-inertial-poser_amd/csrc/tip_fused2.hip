@@ -830,11 +830,21 @@ struct PgEpi {
     const float* res;
     float* C;
     int ldres, ldc;
-    __device__ __forceinline__ void operator()(int row, int col, float v) const {
-        v += bias[col];
-        if (FLAGS & 2) v += res[(size_t)row * ldres + col];
-        if (FLAGS & 1) v = v > 0.f ? v : 0.f;
-        C[(size_t)row * ldc + col] = v;
+    typedef f32x4 Col;
+    typedef f32x4 Aux;
+    __device__ __forceinline__ Col begin(int col) const { return *reinterpret_cast<const f32x4*>(bias + col); }
+    __device__ __forceinline__ Aux load(int row, int col) const {
+        if (FLAGS & 2) return *reinterpret_cast<const f32x4*>(res + (size_t)row * ldres + col);
+        return (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ void store(int row, int col, f32x4 v, const Col& b, const Aux& r) const {
+        v = v + b;
+        if (FLAGS & 2) v = v + r;
+        if (FLAGS & 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(C + (size_t)row * ldc + col) = v;
     }
 };
 

@@ -26,24 +26,19 @@ __device__ __forceinline__ void ring2_prefetch(WRing2<NBW>& g, __amdgpu_buffer_r
     }
 }
 
-template <int NRB, int NBW>
+// SWAP: operands exchanged — the instruction then delivers the TRANSPOSED tile (lane (l15, lg) holds row l15, columns 4 lg .. 4 lg + 3
+// instead of column l15, rows 4 lg .. + 3), bit for bit the same sums: an epilogue can then move 16 bytes per lane.
+template <int NRB, int NBW, bool SWAP = false>
 __device__ __forceinline__ void mfma_block2(f32x4 (&acc)[NRB][NBW], const float4 (&a)[NRB], const float4 (&w)[NBW]) {
-#pragma unroll
-    for (int r = 0; r < NRB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].x, w[n].x, acc[r][n], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < NRB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].y, w[n].y, acc[r][n], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < NRB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].z, w[n].z, acc[r][n], 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < NRB; ++r)
-#pragma unroll
-        for (int n = 0; n < NBW; ++n) acc[r][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].w, w[n].w, acc[r][n], 0, 0, 0);
+#define TIP_MFMA2_STEP(c)                                                                                               \
+    _Pragma("unroll") for (int r = 0; r < NRB; ++r) _Pragma("unroll") for (int n = 0; n < NBW; ++n)                      \
+        acc[r][n] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x4f32(w[n].c, a[r].c, acc[r][n], 0, 0, 0)                     \
+                         : __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].c, w[n].c, acc[r][n], 0, 0, 0);
+    TIP_MFMA2_STEP(x)
+    TIP_MFMA2_STEP(y)
+    TIP_MFMA2_STEP(z)
+    TIP_MFMA2_STEP(w)
+#undef TIP_MFMA2_STEP
 }
 
 template <int NRB, int NBW>
@@ -67,7 +62,14 @@ constexpr int ROWS = 80, RB = 5, NBW = 4, KC = 128, LDA = KC + 4, THREADS = 512,
 constexpr int LDS_BYTES = 2 * ROWS * LDA * 4;                                                          // 84 480
 }  // namespace pg
 
-// Epi: a functor `void operator()(int row, int col, float acc) const` that finishes and stores one output element.
+// Epi finishes and stores the outputs in groups of FOUR consecutive columns of one row (the tiles are computed transposed):
+//   Col  begin(col)                       what a column group needs whatever the row: the bias (loaded once per group, not per element)
+//   Aux  load(row, col)                   the group's other inputs (residual, gate): requested for all five row blocks before the first
+//                                         is used
+//   void store(row, col, acc, Col, Aux)   16-byte store
+// (round 3: the first form, `epi(row, col, acc)` per ELEMENT with its bias / residual loads inside, compiled to 80 dependent
+// load -> wait -> store round trips per lane — the optimiser may not move a load across a store it cannot prove disjoint — and cost
+// 13-28 us of every 80 x 512 panel: the big linears of the scaled configuration ran at 71-87 % of the matrix peak because of it.)
 template <typename Epi>
 __device__ __forceinline__ void pgemm_body(const float* __restrict__ A, int lda, const float* __restrict__ wfrag, int wbytes, int M,
                                            int N, int K, const Epi& epi) {
@@ -118,13 +120,13 @@ __device__ __forceinline__ void pgemm_body(const float* __restrict__ A, int lda,
             const int gkb = c * (KC / 16) + kb + 2;                 // the k-blocks the ring fetches next (may run past K: padded image)
 #pragma unroll
             for (int r = 0; r < RB; ++r) a1[r] = *reinterpret_cast<const float4*>(As + r * 16 * LDA + (kb + 1) * 16);
-            mfma_block2<RB, NBW>(acc, a0, g.w0);
+            mfma_block2<RB, NBW, true>(acc, a0, g.w0);
 #pragma unroll
             for (int n = 0; n < NBW; ++n) g.w0[n] = ldfrag2(rsrc, voff, wsoff + (n * KB + gkb) * 1024);
             __builtin_amdgcn_sched_barrier(0);   // keep each refill behind the block that freed its registers (not next to its use)
 #pragma unroll
             for (int r = 0; r < RB; ++r) a0[r] = *reinterpret_cast<const float4*>(As + r * 16 * LDA + ((kb + 2) & (KC / 16 - 1)) * 16);
-            mfma_block2<RB, NBW>(acc, a1, g.w1);
+            mfma_block2<RB, NBW, true>(acc, a1, g.w1);
 #pragma unroll
             for (int n = 0; n < NBW; ++n) g.w1[n] = ldfrag2(rsrc, voff, wsoff + (n * KB + gkb + 1) * 1024);
             __builtin_amdgcn_sched_barrier(0);
@@ -132,18 +134,29 @@ __device__ __forceinline__ void pgemm_body(const float* __restrict__ A, int lda,
         if (c + 1 < nchunks) stage((c + 1) & 1);
         __syncthreads();
     }
-    // epilogue.  C/D layout of 16x16: col = lane&15, row = 4*(lane>>4) + e.
+    // epilogue.  Transposed tiles: lane (l15, lg) holds row l15, columns 4 lg .. 4 lg + 3 of its 16 x 16 block.
+    // (N is a multiple of the panel width: every column group exists.)  The inputs of group n + 1 are requested before group n is
+    // stored — different columns, so this order is right even for an in-place residual — and a group's five row blocks together.
+    typename Epi::Aux aux[2][RB];
+    auto request = [&](int n, typename Epi::Aux (&a)[RB]) {
+        const int col = (nb0 + n) * 16 + lg * 4;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int row = row0 + r * 16 + l15;
+            a[r] = epi.load(row < M ? row : M - 1, col);   // clamped, unconditional
+        }
+    };
+    request(0, aux[0]);
 #pragma unroll
     for (int n = 0; n < NBW; ++n) {
-        const int col = (nb0 + n) * 16 + l15;
-        if (col >= N) continue;
+        const int col = (nb0 + n) * 16 + lg * 4;
+        const typename Epi::Col cb = epi.begin(col);
+        if (n + 1 < NBW) request(n + 1, aux[(n + 1) & 1]);
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = row0 + r * 16 + lg * 4 + e;
-                if (row < M) epi(row, col, acc[r][n][e]);
-            }
+        for (int r = 0; r < RB; ++r) {
+            const int row = row0 + r * 16 + l15;
+            if (row < M) epi.store(row, col, acc[r][n], cb, aux[n & 1][r]);
+        }
     }
 }
 

@@ -374,13 +374,31 @@ static hipError_t tgemm16_launch(TG g, hipStream_t s) {
 // fits (N % 512 == 0, K % 128 == 0): the scaled configuration's linears, forward and dX alike.
 struct TgEpi {
     TG g;
-    __device__ __forceinline__ void operator()(int row, int col, float v) const {
-        if (g.bias) v += g.bias[col];
-        if (g.relu) v = v > 0.f ? v : 0.f;
-        v *= drop_factor(g.drop, (unsigned long long)row * (unsigned)g.nn + (unsigned)col);
-        if (g.gate) v *= g.gate[(long long)row * g.ldgate + col] > 0.f ? g.gate_scale : 0.f;
-        if (g.res) v += g.res[(long long)row * g.ldres + col];
-        g.C[(long long)row * g.ldc + col] = v;
+    typedef f32x4 Col;
+    struct Aux {
+        f32x4 gate, res;
+    };
+    __device__ __forceinline__ Col begin(int col) const {
+        return g.bias ? *reinterpret_cast<const f32x4*>(g.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __device__ __forceinline__ Aux load(int row, int col) const {
+        Aux a;
+        a.gate = g.gate ? *reinterpret_cast<const f32x4*>(g.gate + (long long)row * g.ldgate + col) : (f32x4){1.f, 1.f, 1.f, 1.f};
+        a.res = g.res ? *reinterpret_cast<const f32x4*>(g.res + (long long)row * g.ldres + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        return a;
+    }
+    __device__ __forceinline__ void store(int row, int col, f32x4 v, const Col& b, const Aux& a) const {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e];
+            if (g.bias) x += b[e];
+            if (g.relu) x = x > 0.f ? x : 0.f;
+            x *= drop_factor(g.drop, (unsigned long long)row * (unsigned)g.nn + (unsigned)(col + e));
+            if (g.gate) x *= a.gate[e] > 0.f ? g.gate_scale : 0.f;
+            if (g.res) x += a.res[e];
+            v[e] = x;
+        }
+        *reinterpret_cast<f32x4*>(g.C + (long long)row * g.ldc + col) = v;
     }
 };
 
@@ -398,7 +416,9 @@ static bool panel_ok(int M, int N, int K) {
 static hipError_t lin_launch(const TG& g, const float* wfrag, hipStream_t s) {
     static int use_pg = -1;   // TIP_TRAIN_PGEMM=0: LDS-tiled kernel everywhere (measurement)
     if (use_pg < 0) use_pg = (getenv("TIP_TRAIN_PGEMM") && getenv("TIP_TRAIN_PGEMM")[0] == '0') ? 0 : 1;
-    if (!use_pg || !wfrag || !panel_ok(g.mm, g.nn, g.kva) || g.kva != g.kvb || (long long)g.nn * g.kva * 4 > 0x7fffffffLL)
+    auto al16 = [](const void* q, long long ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
+    if (!use_pg || !wfrag || !panel_ok(g.mm, g.nn, g.kva) || g.kva != g.kvb || (long long)g.nn * g.kva * 4 > 0x7fffffffLL ||
+        !al16(g.bias, 0) || !al16(g.C, g.ldc) || !al16(g.res, g.ldres) || !al16(g.gate, g.ldgate))   // 16-byte epilogue accesses
         return tgemm16_launch(g, s);
     static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
