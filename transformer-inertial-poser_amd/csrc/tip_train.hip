@@ -311,12 +311,24 @@ __global__ __launch_bounds__(64 * WI * WJ) void tgemm16_kernel(TG g) {
         if (k0 + 2 * BK < g.kk) stage(0, ra[0], rb[0]);
         __syncthreads();
     }
-    // epilogue.  C/D layout of 16x16: col = lane&15, row = 4*(lane>>4) + r.
+    // epilogue.  C/D layout of 16x16: col = lane&15, row = 4*(lane>>4) + r.  The gate / residual inputs of a column block are ALL
+    // requested before its first store (clamped addresses, unconditional): written element by element the loop compiles to one
+    // dependent load -> wait -> store round trip per element (see pgemm_body, tip_pgemm.h).
 #pragma unroll
     for (int j = 0; j < RJ; ++j) {
         const int col = j0 + wn * (TJ / WJ) + j * 16 + l15;
         if (col >= g.nn) continue;
         const float bv = g.bias ? g.bias[col] : 0.f;
+        float gv[RI][4], rv[RI][4];
+#pragma unroll
+        for (int i = 0; i < RI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wm * (TI / WI) + i * 16 + lg * 4 + r;
+                const int rc = row < g.c_rows ? row : g.c_rows - 1;
+                gv[i][r] = g.gate ? g.gate[(long long)rc * g.ldgate + col] : 1.f;
+                rv[i][r] = g.res ? g.res[(long long)rc * g.ldres + col] : 0.f;
+            }
 #pragma unroll
         for (int i = 0; i < RI; ++i) {
 #pragma unroll
@@ -326,8 +338,8 @@ __global__ __launch_bounds__(64 * WI * WJ) void tgemm16_kernel(TG g) {
                 float v = acc[i][j][r] + bv;
                 if (g.relu) v = v > 0.f ? v : 0.f;
                 v *= drop_factor(g.drop, (unsigned long long)row * (unsigned)g.nn + (unsigned)col);
-                if (g.gate) v *= g.gate[(long long)row * g.ldgate + col] > 0.f ? g.gate_scale : 0.f;
-                if (g.res) v += g.res[(long long)row * g.ldres + col];
+                if (g.gate) v *= gv[i][r] > 0.f ? g.gate_scale : 0.f;
+                if (g.res) v += rv[i][r];
                 g.C[(long long)row * g.ldc + col] = v;
             }
         }
