@@ -1682,8 +1682,30 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
             static_assert(2 * RP * LDA <= 8 * 3 * RP * 20, "chunk buffers fit the scratch region");
             // hybrid row tiling (fused_encoder_h_kernel): rows 0-31 on 16x16x4, rows 32-39 on 4x4x1 MFMAs, nothing on the pad rows
             using namespace fzh;
+            // The accumulators START at dz1 (the residual path of dx_in = dz1 + dqkv Wqkv^T) instead of at zero, so that the epilogue
+            // only stores: written as `dx_in[i] = dz1[i] + acc` per element it compiled to one dependent load -> wait -> store round
+            // trip per element, 20 per lane at the end of every window (the optimiser may not move a load across a store it cannot
+            // prove disjoint, tip_pgemm.h), and this kernel has no registers left to batch the loads in.  Tail blocks: lane group 0
+            // carries dz1 in its k-partial, the other three start at zero (tail_reduce sums the four).
             f32x4 acc_i[RBM][2], acc_it[RBT][2];
-            zero_acc_h<2>(acc_i, acc_it);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int col = (wave * 2 + n) * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < RBM; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = r * 16 + lg * 4 + e;
+                        acc_i[r][n][e] = row < T ? a.dz1[(grow0 + row) * D + col] : 0.f;
+                    }
+#pragma unroll
+                for (int rb = 0; rb < RBT; ++rb)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = TAIL0 + 4 * rb + e;
+                        acc_it[rb][n][e] = (lg == 0 && row < T) ? a.dz1[(grow0 + row) * D + col] : 0.f;
+                    }
+            }
             float* Ab = Sc;
             const int wq = lbase + (int)(fb::WQT * 4) + (wave * 2) * 48 * 1024;
             WRing<2> g_q;
@@ -1725,13 +1747,13 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int row = r * 16 + lg * 4 + e;
-                        if (row < T) a.dx_in[(grow0 + row) * D + col] = a.dz1[(grow0 + row) * D + col] + acc_i[r][n][e];
+                        if (row < T) a.dx_in[(grow0 + row) * D + col] = acc_i[r][n][e];
                     }
 #pragma unroll
                 for (int rb = 0; rb < RBT; ++rb) {
                     const int row = TAIL0 + 4 * rb + lg;
                     const float v = tail_reduce(acc_it[rb][n], lg);
-                    if (row < T) a.dx_in[(grow0 + row) * D + col] = a.dz1[(grow0 + row) * D + col] + v;
+                    if (row < T) a.dx_in[(grow0 + row) * D + col] = v;
                 }
             }
         }
