@@ -966,7 +966,20 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             }
             __syncthreads();
             FH_STAMP(16);
-            // residual + bias, then LayerNorm1
+            // residual + bias, then LayerNorm1.  The residual values of this lane's 20 elements are READ before the first is written
+            // back: `X[i] += v` per element compiles to a chain of ds_read -> wait -> ds_write round trips (2-3 k cycles per epilogue
+            // with the matrix pipe idle; the optimiser may not move a read across a write it cannot prove disjoint).
+            float xr[2][RBM][4], xt[2][RBT];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {   // (the unroll pragma above binds to this loop)
+                const int col = (wave * 2 + n) * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < RBM; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xr[n][r][e] = X[(r * 16 + lg * 4 + e) * LDX + col];
+#pragma unroll
+                for (int r = 0; r < RBT; ++r) xt[n][r] = X[(TAIL0 + 4 * r + lg) * LDX + col];
+            }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int col = (wave * 2 + n) * 16 + l15;
@@ -978,14 +991,14 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                         float v = acc_o[r][n][e] + bv;
                         if (TR && tr.thresh)
                             v = tip_drop_hash_k(dk1, (grow0 + r * 16 + lg * 4 + e) * D + col) >= tr.thresh ? v * tr.scale : 0.f;
-                        X[(r * 16 + lg * 4 + e) * LDX + col] += v;
+                        X[(r * 16 + lg * 4 + e) * LDX + col] = xr[n][r][e] + v;
                     }
 #pragma unroll
                 for (int r = 0; r < RBT; ++r) {
                     float v = tail_reduce(acc_ot[r][n], lg) + bv;
                     if (TR && tr.thresh)
                         v = tip_drop_hash_k(dk1, (grow0 + TAIL0 + 4 * r + lg) * D + col) >= tr.thresh ? v * tr.scale : 0.f;
-                    X[(TAIL0 + 4 * r + lg) * LDX + col] += v;
+                    X[(TAIL0 + 4 * r + lg) * LDX + col] = xt[n][r] + v;
                 }
             }
             __syncthreads();
@@ -1052,6 +1065,16 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             if (layer + 1 < L)
                 ring_prefetch<3>(g_qkv, rsrc, voff, lbase + (int)(LAYER_FLOATS * 4) + (int)(QKV_W * 4) + wave * 16 * 1024, 16 * 16 * 1024);
 #pragma unroll
+            for (int n = 0; n < 2; ++n) {   // residual values first (as after the out-projection)
+                const int col = (wave * 2 + n) * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < RBM; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xr[n][r][e] = X[(r * 16 + lg * 4 + e) * LDX + col];
+#pragma unroll
+                for (int r = 0; r < RBT; ++r) xt[n][r] = X[(TAIL0 + 4 * r + lg) * LDX + col];
+            }
+#pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int col = (wave * 2 + n) * 16 + l15;
                 const float bv = bv2[n];
@@ -1062,14 +1085,14 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                         float v = acc_f[r][n][e] + bv;
                         if (TR && tr.thresh)
                             v = tip_drop_hash_k(dk3, (grow0 + r * 16 + lg * 4 + e) * D + col) >= tr.thresh ? v * tr.scale : 0.f;
-                        X[(r * 16 + lg * 4 + e) * LDX + col] += v;
+                        X[(r * 16 + lg * 4 + e) * LDX + col] = xr[n][r][e] + v;
                     }
 #pragma unroll
                 for (int r = 0; r < RBT; ++r) {
                     float v = tail_reduce(acc_ft[r][n], lg) + bv;
                     if (TR && tr.thresh)
                         v = tip_drop_hash_k(dk3, (grow0 + TAIL0 + 4 * r + lg) * D + col) >= tr.thresh ? v * tr.scale : 0.f;
-                    X[(TAIL0 + 4 * r + lg) * LDX + col] += v;
+                    X[(TAIL0 + 4 * r + lg) * LDX + col] = xt[n][r] + v;
                 }
             }
             __syncthreads();

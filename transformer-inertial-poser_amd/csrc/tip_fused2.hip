@@ -284,12 +284,19 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
+                // (a column block's residual values are READ before the first is written back: `X[i] += v` per element compiles to a
+                //  chain of ds_read -> wait -> ds_write round trips)
                 const int col = (wave * 2 + n) * 16 + l15;
                 const float bv = LW[WO_B + col];
+                float xr[RB][4];
 #pragma unroll
                 for (int r = 0; r < RB; ++r)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_o[r][n][e] + bv;
+                    for (int e = 0; e < 4; ++e) xr[r][e] = X[(r * 16 + lg * 4 + e) * LDX + col];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] = xr[r][e] + (acc_o[r][n][e] + bv);
             }
             __syncthreads();
             F2_STAMP(21);
@@ -334,12 +341,19 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                                   lbase + (int)(LAYER_FLOATS * 4) + (int)(QKV_W * 4) + ((wave >> 2) * 16 + (wave & 3)) * 16 * 1024, 0);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
+                // (a column block's residual values are READ before the first is written back: `X[i] += v` per element compiles to a
+                //  chain of ds_read -> wait -> ds_write round trips)
                 const int col = (wave * 2 + n) * 16 + l15;
                 const float bv = LW[W2_B + col];
+                float xr[RB][4];
 #pragma unroll
                 for (int r = 0; r < RB; ++r)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += acc_f[r][n][e] + bv;
+                    for (int e = 0; e < 4; ++e) xr[r][e] = X[(r * 16 + lg * 4 + e) * LDX + col];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] = xr[r][e] + (acc_f[r][n][e] + bv);
             }
             __syncthreads();
             F2_STAMP(40);
