@@ -691,6 +691,10 @@ __device__ __forceinline__ void gemm_phase_h(f32x4 (&acc)[fzh::RBM][NBW], f32x4 
         for (int r = 0; r < fzh::RBM; ++r) a0[r] = *reinterpret_cast<const float4*>(Am + r * 16 * lda + (kb + 2) * 16);
 #pragma unroll
         for (int r = 0; r < fzh::RBT; ++r) t0[r] = *reinterpret_cast<const float4*>(At + r * 4 * lda + (kb + 2) * 16);
+        // the NEXT pair's first A fragments are requested HERE, half an iteration ahead: left to itself the scheduler sinks these reads
+        // to the top of the next iteration, right in front of the MFMA that needs them, and both waves of a SIMD — in step behind every
+        // barrier — then sit out an LDS round trip per k-block pair with the matrix pipe idle
+        __builtin_amdgcn_sched_barrier(0);
         mfma_block_h<NBW, SWAPN>(acc, acct, a1, t1, g.w1);
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w1[n] = load_frag(rsrc, voff, o + n * st + 1024);
