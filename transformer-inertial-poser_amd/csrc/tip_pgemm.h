@@ -126,6 +126,7 @@ __device__ __forceinline__ void pgemm_body(const float* __restrict__ A, int lda,
             __builtin_amdgcn_sched_barrier(0);   // keep each refill behind the block that freed its registers (not next to its use)
 #pragma unroll
             for (int r = 0; r < RB; ++r) a0[r] = *reinterpret_cast<const float4*>(As + r * 16 * LDA + ((kb + 2) & (KC / 16 - 1)) * 16);
+            __builtin_amdgcn_sched_barrier(0);   // the next pair's A fragments stay here, half a trip ahead of their first MFMA (gemm_phase_h)
             mfma_block2<RB, NBW, true>(acc, a1, g.w1);
 #pragma unroll
             for (int n = 0; n < NBW; ++n) g.w1[n] = ldfrag2(rsrc, voff, wsoff + (n * KB + gkb + 1) * 1024);
