@@ -682,14 +682,14 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         else plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
     }
     if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO) {
-        // One window per workgroup with the hybrid row tiling (no hand-offs, 0.541 ms per round of #CUs windows at T = 40), or
-        // two windows per workgroup (80 rows = 5 full MFMA row blocks, 1.054 ms per round of 2 x #CUs windows; only the RATIO of
+        // One window per workgroup with the hybrid row tiling (no hand-offs, 0.527 ms per round of #CUs windows at T = 40), or
+        // two windows per workgroup (80 rows = 5 full MFMA row blocks, 1.049 ms per round of 2 x #CUs windows; only the RATIO of
         // the two matters, and #CUs is the stream's effective count): whichever
         // needs less time for this batch.  (The pair-split plan, 0.605 ms per round with 8 hand-offs per pair, lost its
         // place to the hybrid kernel and stays selectable for measurement.)
         const long long cusl = cus;
         const long long rounds_h = (B + cusl - 1) / cusl, rounds_2 = ((B + 1) / 2 + cusl - 1) / cusl;
-        plan = (fused2_supported(d, T) && rounds_2 * 1054 < rounds_h * 541) ? TIP_PLAN_FUSED2 : TIP_PLAN_FUSEDH;
+        plan = (fused2_supported(d, T) && rounds_2 * 1049 < rounds_h * 527) ? TIP_PLAN_FUSED2 : TIP_PLAN_FUSEDH;
     }
     if ((plan == TIP_PLAN_FUSED || plan == TIP_PLAN_FUSEDH) && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
