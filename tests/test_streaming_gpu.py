@@ -278,3 +278,55 @@ def test_graph_capture_keeps_past_state_dropout_live():
         else:
             assert torch.equal(a, b)
         m.check_handoffs()
+
+
+def test_degenerate_6d_axes_never_poison_the_pose():
+    """A predicted 6D rotation whose two axes are (anti)parallel, or vanish, has no unique nearest rotation: scipy's from_matrix (SVD)
+    returns SOME rotation for it, the back-end's closed-form polar factor used to divide by zero there — and the NaN then lived on in
+    the averaged pose for the rest of the stream (seen once in 300 k stream-frames of a random-weight closed loop, tools/options_soak.py).
+    Whatever is returned must be finite, a proper rotation in the fed-back 6D history, and must not disturb the other joints."""
+    lib = tlib.load()
+    n = 4
+    rng = np.random.RandomState(7)
+    nbytes = ctypes.c_size_t()
+    assert lib.tip_stream_state_bytes(n, ctypes.byref(nbytes)) == 0
+    state = torch.zeros(nbytes.value, dtype=torch.uint8, device="cuda")
+    s_init = torch.tensor(rng.randn(n, 114).astype(np.float32) * 0.2).cuda()
+    assert lib.tip_stream_reset(state.data_ptr(), s_init.data_ptr(), n, None) == 0
+    from scipy.spatial.transform import Rotation
+    raw = np.zeros((n, 72), dtype=np.float32)
+    raw[:, :54] = Rotation.random(n * 6, random_state=3).as_matrix().reshape(n, 54)
+    raw_d = torch.tensor(raw).cuda()
+    x_imu = torch.empty(n, 40, 90, device="cuda")
+    x_s = torch.empty(n, 40, 131, device="cuda")
+    s_rest = torch.empty(n, 111, device="cuda")
+    c_t = torch.empty(n, 20, device="cuda")
+    good = Rotation.random(18, random_state=5).as_matrix()[:, :, :2].reshape(-1).astype(np.float32)
+    for f in range(12):
+        assert lib.tip_stream_ingest(state.data_ptr(), raw_d.data_ptr(), n, f, x_imu.data_ptr(), x_s.data_ptr(), None) == 0
+        if f < 5:
+            continue
+        y = np.zeros((n, 131), dtype=np.float32)
+        y[:, :108] = good
+        y[:, 108:] = rng.randn(n, 23) * 0.3
+        a = rng.randn(3).astype(np.float32)
+        j = 5
+        d6 = y[:, 6 * j: 6 * j + 6].reshape(n, 3, 2)
+        d6[0, :, 0], d6[0, :, 1] = a, -0.58 * a          # stream 0: anti-parallel axes
+        d6[1, :, 0], d6[1, :, 1] = a, 2.0 * a            # stream 1: parallel axes
+        d6[2, :, 0], d6[2, :, 1] = 0.0, a                # stream 2: first axis vanishes
+        # stream 3 keeps a proper rotation
+        y_d = torch.tensor(y).cuda()
+        assert lib.tip_stream_consume(state.data_ptr(), y_d.data_ptr(), n, f - 5, s_rest.data_ptr(), c_t.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        sr = s_rest.cpu().numpy()
+        assert np.isfinite(sr).all() and np.isfinite(c_t.cpu().numpy()).all(), f
+    # the fed-back history rows hold proper rotations (first two columns orthonormal) for every joint of every stream
+    st = state.view(torch.float32).cpu().numpy().reshape(n, -1)
+    HIST, NS = 4392, 131
+    for b in range(n):
+        for row in range(1, 7):
+            h = st[b, HIST + row * NS: HIST + row * NS + 108].reshape(18, 3, 2)
+            assert np.isfinite(h).all()
+            g = np.einsum("jik,jil->jkl", h, h)
+            assert np.abs(g - np.eye(2)).max() < 1e-4, (b, row)

@@ -48,9 +48,31 @@ __device__ __forceinline__ void polar_two_axis(const float a1[3], const float a2
     const float c = a1[0] * a2[0] + a1[1] * a2[1] + a1[2] * a2[2];
     const float d = sqrtf(fmaxf(p * q - c * c, 0.f));
     const float tau = sqrtf(p + q + 2.f * d);
-    const float f = tau / ((p + d) * (q + d) - c * c);
+    const float den = (p + d) * (q + d) - c * c;
+    const float n3sq = a3[0] * a3[0] + a3[1] * a3[1] + a3[2] * a3[2];
+    if (!(den > 1e-10f) || !(n3sq > 1e-12f)) {
+        // (anti)parallel or vanishing predicted axes: M is singular, its polar factor is not unique (scipy's SVD returns SOME rotation
+        // there) and the closed form above divides by zero — seen once in 300 k stream-frames of a random-weight closed loop, after
+        // which the NaN lived on in the pose average.  Any orthonormal frame is as right as another: first axis along a1 (or x), the
+        // second from the coordinate axis least aligned with it.
+        float e1[3] = {a1[0], a1[1], a1[2]};
+        float n1 = sqrtf(p);
+        if (!(n1 > 1e-12f)) { e1[0] = 1.f; e1[1] = 0.f; e1[2] = 0.f; n1 = 1.f; }
+        for (int i = 0; i < 3; ++i) e1[i] /= n1;
+        const float ax = fabsf(e1[0]), ay = fabsf(e1[1]), az = fabsf(e1[2]);
+        float h[3] = {0.f, 0.f, 0.f};
+        h[(ax <= ay && ax <= az) ? 0 : (ay <= az ? 1 : 2)] = 1.f;
+        const float hd = h[0] * e1[0] + h[1] * e1[1] + h[2] * e1[2];
+        float e2[3] = {h[0] - hd * e1[0], h[1] - hd * e1[1], h[2] - hd * e1[2]};
+        const float n2 = sqrtf(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+        for (int i = 0; i < 3; ++i) e2[i] /= n2;
+        const float e3[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        for (int i = 0; i < 3; ++i) { m[i][0] = e1[i]; m[i][1] = e2[i]; m[i][2] = e3[i]; }
+        return;
+    }
+    const float f = tau / den;
     const float b00 = (q + d) * f, b01 = -c * f, b11 = (p + d) * f;
-    const float n3 = 1.f / sqrtf(a3[0] * a3[0] + a3[1] * a3[1] + a3[2] * a3[2]);
+    const float n3 = 1.f / sqrtf(n3sq);
     for (int i = 0; i < 3; ++i) {
         m[i][0] = a1[i] * b00 + a2[i] * b01;
         m[i][1] = a1[i] * b01 + a2[i] * b11;
