@@ -1121,24 +1121,33 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             // lane stores four consecutive columns of one row with ONE 16-byte store instead of four scattered 4-byte ones (the
             // store tail is issue-bound: 32 -> 8 store instructions per wave for rows 0-31).  Same products, same sums.
             gemm_phase_h<4, 16, 4, TR>(acc, acct, X + am(LDX), X + at(LDX), LDX, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
-            float* io = ih_out + (size_t)win * T * R;
+            // This window's IH rows as a buffer of T rows: the stores of the pad rows are dropped by the range check, not by a branch
+            // around each store.  The biases of all four column blocks are requested BEFORE the first store: loaded inside the loop, each
+            // block's bias load sat behind the previous block's stores (the optimiser may not hoist a load over a store it cannot prove
+            // disjoint) — four exposed L2 round trips at the end of every window.
+            const __amdgpu_buffer_rsrc_t io_rs = __builtin_amdgcn_make_buffer_rsrc(ih_out + (size_t)win * T * R, 0, T * R * 4, 0x00020000);
             // (opaque lane index: the store offsets are formed here, not hoisted to the top of the kernel and carried in scratch)
             const int lo = opaque(lane), l15o = lo & 15, lgo = lo >> 4;
+            float bvs[4];
+            f32x4 bv4s[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                bvs[n] = wts[ih_off_b / 4 + R * D + (wave * 4 + n) * 16 + l15o];
+                bv4s[n] = *reinterpret_cast<const f32x4*>(wts + ih_off_b / 4 + R * D + (wave * 4 + n) * 16 + lgo * 4);
+            }
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 const int col = (wave * 4 + n) * 16 + l15o;
-                const float bv = wts[ih_off_b / 4 + R * D + col];
-                const f32x4 bv4 = *reinterpret_cast<const f32x4*>(wts + ih_off_b / 4 + R * D + (wave * 4 + n) * 16 + lgo * 4);
 #pragma unroll
                 for (int r = 0; r < RBM; ++r) {
                     const int row = r * 16 + l15o;
-                    if (row < T) *reinterpret_cast<f32x4*>(io + (size_t)row * R + (wave * 4 + n) * 16 + lgo * 4) = acc[r][n] + bv4;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r][n] + bv4s[n]), io_rs, (row * R + (wave * 4 + n) * 16 + lgo * 4) * 4, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < RBT; ++r) {
-                    const float v = tail_reduce(acct[r][n], lg) + bv;
+                    const float v = tail_reduce(acct[r][n], lg) + bvs[n];
                     const int row = TAIL0 + 4 * r + lgo;
-                    if (row < T) io[(size_t)row * R + col] = v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), io_rs, (row * R + col) * 4, 0, 0);
                 }
             }
         }
@@ -1430,14 +1439,21 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
         bwd_stamp(a.trace, 6);
         // ---- dx1 = dz2 + dpre W1 -------------------------------------------------------------------------------------------
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < 2; ++n) {   // dz2 values read before the first write-back (tip_pgemm.h: `G[i] += v` serialises read -> wait -> write)
             const int col = (wave * 2 + n) * 16 + l15;
+            float gr_[RBM][4], gt_[RBT];
 #pragma unroll
             for (int r = 0; r < RBM; ++r)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) G[(r * 16 + lg * 4 + e) * LDX + col] += acc_x[r][n][e];
+                for (int e = 0; e < 4; ++e) gr_[r][e] = G[(r * 16 + lg * 4 + e) * LDX + col];
 #pragma unroll
-            for (int rb = 0; rb < RBT; ++rb) G[(TAIL0 + 4 * rb + lg) * LDX + col] += tail_reduce(acc_xt[rb][n], lg);
+            for (int rb = 0; rb < RBT; ++rb) gt_[rb] = G[(TAIL0 + 4 * rb + lg) * LDX + col];
+#pragma unroll
+            for (int r = 0; r < RBM; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) G[(r * 16 + lg * 4 + e) * LDX + col] = gr_[r][e] + acc_x[r][n][e];
+#pragma unroll
+            for (int rb = 0; rb < RBT; ++rb) G[(TAIL0 + 4 * rb + lg) * LDX + col] = gt_[rb] + tail_reduce(acc_xt[rb][n], lg);
         }
         __syncthreads();
         rows_to_hbm(G, LDX, D, a.dx1 + grow0 * D, D, T, tid);
@@ -1475,6 +1491,10 @@ hipError_t launch_ffn_bwd(const Dims& d, const FfnBwdArgs& a, int B, int T, int 
 // weight-gradient GEMMs.
 // =====================================================================================================================
 
+// DROP: attention / out-proj dropout on (a.thresh != 0).  A template parameter, and the masked elements below are SELECTS, not branches:
+// with `if (valid) { ... }` around each element (and a uniform `if (a.thresh)` inside it) the attention part was 450 basic blocks,
+// MFMA -> branch -> exp -> MFMA strictly in program order, nothing for the scheduler to overlap (the heads ran at 50 % of their MFMA time).
+template <bool DROP>
 __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, int B, int T) {
     using namespace fz;
     constexpr int LDT = 20;                             // per-wave transposition tiles [48][16 + 4]
@@ -1523,7 +1543,7 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
                     o.z = rstd * (az - m1 - xh.z * m2); o.w = rstd * (aw - m1 - xh.w * m2);
                     *reinterpret_cast<float4*>(a.dz1 + gr * D + lane * 4) = o;
                     m = o;
-                    if (a.thresh) {
+                    if (DROP) {
                         const unsigned long long idx = gr * D + lane * 4;
                         m.x = tip_drop_hash_k(dkey1, idx) >= a.thresh ? o.x * a.scale : 0.f;
                         m.y = tip_drop_hash_k(dkey1, idx + 1) >= a.thresh ? o.y * a.scale : 0.f;
@@ -1556,23 +1576,29 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
             bwd_stamp(a.trace, 10 + c);
             const int head = c * 8 + wave;
             const unsigned long long bh = (unsigned long long)win * H + head;
-            const float* qb = a.qkv + grow0 * (3 * D) + head * 16;
+            const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.qkv) + grow0 * (3 * D), 0, T * 3 * D * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.att) + grow0 * D, 0, T * D * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t st_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ast) + bh * T * 2, 0, T * 8, 0x00020000);
+            // this window's dq | dk | dv rows as a buffer whose extent is T rows: stores to the padded rows are dropped by the
+            // hardware's range check instead of by a branch around every store (each one ended a basic block)
+            const __amdgpu_buffer_rsrc_t dq_rs = __builtin_amdgcn_make_buffer_rsrc(a.dqkv + grow0 * (3 * D), 0, T * 3 * D * 4, 0x00020000);
+            const int dq_col = (head * 16 + l15) * 4;
             // q, k, v, O row fragments and the softmax statistics are requested before the dO product
             f32x4 qf[RB], kf[RB], vf[RB], of[RB];
             float mq[RB], iq[RB];
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const int row = r * 16 + l15;
-                qf[r] = kf[r] = vf[r] = of[r] = zero4;
-                mq[r] = 0.f; iq[r] = 0.f;
-                if (row < T) {
-                    qf[r] = *reinterpret_cast<const f32x4*>(qb + (size_t)row * (3 * D) + lg * 4);
-                    kf[r] = *reinterpret_cast<const f32x4*>(qb + (size_t)row * (3 * D) + D + lg * 4);
-                    vf[r] = *reinterpret_cast<const f32x4*>(qb + (size_t)row * (3 * D) + 2 * D + lg * 4);
-                    of[r] = *reinterpret_cast<const f32x4*>(a.att + (grow0 + row) * D + head * 16 + lg * 4);
-                    mq[r] = a.ast[(bh * T + row) * 2];
-                    iq[r] = a.ast[(bh * T + row) * 2 + 1];
-                }
+                // rows >= T: out of the buffers' extent -> zeros, no branch
+                const int qo = row * (3 * D * 4) + head * 64 + lg * 16;
+                qf[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q_rs, qo, 0, 0));
+                kf[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q_rs, qo + D * 4, 0, 0));
+                vf[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(q_rs, qo + 2 * D * 4, 0, 0));
+                of[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(o_rs, row * (D * 4) + head * 64 + lg * 16, 0, 0));
+                typedef float tf2 __attribute__((ext_vector_type(2)));
+                const tf2 mi = __builtin_bit_cast(tf2, __builtin_amdgcn_raw_buffer_load_b64(st_rs, row * 8, 0, 0));
+                mq[r] = mi[0];
+                iq[r] = mi[1];
             }
             // dO of this head: [48 x 16] = datt_o [48 x 256] * Wo^T(:, head): gp = accumulator layout (rows 4*lg + e, channel l15);
             // gs = the same tile as row fragments (row l15, channels 4*lg + e), obtained through the wave's scratch
@@ -1633,13 +1659,12 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int kk = cb * 16 + lg * 4 + e;
-                        float v = 0.f;
-                        if (kk <= q && q < T) {
-                            const float p = __expf(s1[e] * a.q_scale - mq[r]) * iq[r];
-                            float kf_ = 1.f;
-                            if (a.thresh) kf_ = tip_drop_hash_k(dkey0, (bh * T + q) * T + kk) >= a.thresh ? a.scale : 0.f;
-                            v = p * (p1[e] * kf_ - dd[r]);
-                        }
+                        // masked (kk > q) or padded (q >= T) elements: the select sits on the exponent (exp(-inf) = 0 -> p = 0 -> v = 0
+                        // exactly), where both sides are cheap; a select on the RESULT is turned back into a branch around the exp
+                        const float p = __expf((kk <= q && q < T) ? s1[e] * a.q_scale - mq[r] : -INFINITY) * iq[r];
+                        float kf_ = 1.f;
+                        if (DROP) kf_ = tip_drop_hash_k(dkey0, (bh * T + q) * T + kk) >= a.thresh ? a.scale : 0.f;
+                        const float v = p * (p1[e] * kf_ - dd[r]);
                         dq = __builtin_amdgcn_mfma_f32_16x16x4f32(v, Ks[(cb * 16 + lg * 4 + e) * LDT + l15], dq, 0, 0, 0);
                     }
                     // layout 2: (query 4*lg + e, key l15) -> dK, dV
@@ -1653,14 +1678,11 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int qq = r * 16 + lg * 4 + e;
-                        float dsv = 0.f, pdv = 0.f;
-                        if (key <= qq && qq < T) {
-                            const float p = __expf(s2[e] * a.q_scale - m2[e]) * i2[e];
-                            float kf_ = 1.f;
-                            if (a.thresh) kf_ = tip_drop_hash_k(dkey0, (bh * T + qq) * T + key) >= a.thresh ? a.scale : 0.f;
-                            pdv = p * kf_;
-                            dsv = p * (p2[e] * kf_ - d2[e]);
-                        }
+                        const float p = __expf((key <= qq && qq < T) ? s2[e] * a.q_scale - m2[e] : -INFINITY) * i2[e];
+                        float kf_ = 1.f;
+                        if (DROP) kf_ = tip_drop_hash_k(dkey0, (bh * T + qq) * T + key) >= a.thresh ? a.scale : 0.f;
+                        const float pdv = p * kf_;
+                        const float dsv = p * (p2[e] * kf_ - d2[e]);
                         dv[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pdv, gp[r][e], dv[cb], 0, 0, 0);
                         dk[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsv, Qs[qq * LDT + l15], dk[cb], 0, 0, 0);
                     }
@@ -1669,7 +1691,7 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int qq = r * 16 + lg * 4 + e;
-                    if (qq < T) a.dqkv[(grow0 + qq) * (3 * D) + head * 16 + l15] = dq[e] * a.q_scale;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dq[e] * a.q_scale), dq_rs, qq * (3 * D * 4) + dq_col, 0, 0);
                     sq += dq[e] * a.q_scale;   // rows >= T are exactly zero (their dS is masked)
                 }
             }
@@ -1679,10 +1701,8 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int kk = cb * 16 + lg * 4 + e;
-                    if (kk < T) {
-                        a.dqkv[(grow0 + kk) * (3 * D) + D + head * 16 + l15] = dk[cb][e] * a.q_scale;
-                        a.dqkv[(grow0 + kk) * (3 * D) + 2 * D + head * 16 + l15] = dv[cb][e];
-                    }
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dk[cb][e] * a.q_scale), dq_rs, kk * (3 * D * 4) + D * 4 + dq_col, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dv[cb][e]), dq_rs, kk * (3 * D * 4) + 2 * D * 4 + dq_col, 0, 0);
                     sk += dk[cb][e] * a.q_scale;
                     sv += dv[cb][e];
                 }
@@ -1715,6 +1735,8 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
             // prove disjoint, tip_pgemm.h), and this kernel has no registers left to batch the loads in.  Tail blocks: lane group 0
             // carries dz1 in its k-partial, the other three start at zero (tail_reduce sums the four).
             f32x4 acc_i[RBM][2], acc_it[RBT][2];
+            const __amdgpu_buffer_rsrc_t z_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dz1) + grow0 * D, 0, T * D * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(a.dx_in + grow0 * D, 0, T * D * 4, 0x00020000);
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const int col = (wave * 2 + n) * 16 + l15;
@@ -1722,15 +1744,16 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
                 for (int r = 0; r < RBM; ++r)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int row = r * 16 + lg * 4 + e;
-                        acc_i[r][n][e] = row < T ? a.dz1[(grow0 + row) * D + col] : 0.f;
+                        const int row = r * 16 + lg * 4 + e;      // rows >= T: outside the buffer -> 0
+                        acc_i[r][n][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rs, (row * D + col) * 4, 0, 0));
                     }
 #pragma unroll
                 for (int rb = 0; rb < RBT; ++rb)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int row = TAIL0 + 4 * rb + e;
-                        acc_it[rb][n][e] = (lg == 0 && row < T) ? a.dz1[(grow0 + row) * D + col] : 0.f;
+                        const float zv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(z_rs, (row * D + col) * 4, 0, 0));
+                        acc_it[rb][n][e] = lg == 0 ? zv : 0.f;
                     }
             }
             float* Ab = Sc;
@@ -1774,13 +1797,13 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int row = r * 16 + lg * 4 + e;
-                        if (row < T) a.dx_in[(grow0 + row) * D + col] = acc_i[r][n][e];
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc_i[r][n][e]), x_rs, (row * D + col) * 4, 0, 0);
                     }
 #pragma unroll
                 for (int rb = 0; rb < RBT; ++rb) {
                     const int row = TAIL0 + 4 * rb + lg;
                     const float v = tail_reduce(acc_it[rb][n], lg);
-                    if (row < T) a.dx_in[(grow0 + row) * D + col] = v;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), x_rs, (row * D + col) * 4, 0, 0);
                 }
             }
         }
@@ -1797,7 +1820,8 @@ hipError_t launch_attn_bwd(const Dims& d, const AttnBwdArgs& a, int B, int T, in
     if ((long long)B * T * 3 * d.D * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
     static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -1806,7 +1830,8 @@ hipError_t launch_attn_bwd(const Dims& d, const AttnBwdArgs& a, int B, int T, in
     static int trace = -1;
     if (trace < 0) trace = getenv("TIP_BWD_TRACE") ? 1 : 0;
     aa.trace = trace;
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
+    if (aa.thresh) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
+    else hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
     return hipGetLastError();
 }
 
