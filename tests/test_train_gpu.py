@@ -242,3 +242,52 @@ def test_train_mode_without_autograd_still_draws_encoder_dropout():
         m.train()
         m.ENCODER_DROPOUT = 0.0
         assert (m(xi, xs) - e1).abs().max() < 2e-5   # p = 0: same function
+
+
+def test_training_trajectory_matches_the_composite():
+    """train_model.py:161-198 as a LOOP, not one step: 30 iterations of forward -> loss -> backward -> clip_grad_norm_ -> AdamW
+    on fresh batches, once through the HIP training path and once through the module's torch-op composite from the same initial
+    weights (dropout off, so both see the same function).  Every iteration re-packs the weight image from the weights the optimizer
+    just changed, reuses the stash and the scratch of the previous step, and feeds its result to the next — a stale image, a
+    gradient accumulated into the wrong buffer or a missed re-pack shows up as a diverging loss curve.  Tolerances: fp32 vs fp32
+    with different summation orders, amplified by Adam's normalisation — losses to 1e-5 relative, the final weights' distance to
+    0.2 % of the distance they travelled."""
+    import copy
+    import warnings
+    cfg = synth.PAPER
+    ma = make_model(cfg, p_state=0.0)
+    load_synth(ma, cfg, 2)
+    ma = ma.cuda().train()
+    ma.ENCODER_DROPOUT = 0.0
+    mb = copy.deepcopy(ma)
+    mb.use_hip_training = False
+    w0 = {n: p.detach().clone() for n, p in ma.named_parameters()}
+    B, T, steps = 32, 40, 30
+    curves = []
+    for m in (ma, mb):
+        opt = torch.optim.AdamW(m.parameters(), lr=2e-4)
+        losses = []
+        for it in range(steps):
+            x_imu, x_s = synth.make_inputs(cfg, B, T, seed=100 + it)
+            tgt = torch.tensor(synth.normal(200 + it, "tgt", B * T * cfg["size_s"]).reshape(B, T, -1).astype(np.float32) * 0.3).cuda()
+            opt.zero_grad()
+            n0 = m.hip_forward_count()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                y = m(torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda())
+            assert (m.hip_forward_count() == n0 + 1) == (m is ma)
+            loss = ((y - tgt) ** 2).mean()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+            opt.step()
+            losses.append(float(loss.detach()))
+        curves.append(np.array(losses))
+    la, lb = curves
+    assert np.isfinite(la).all() and la[-5:].mean() < la[:5].mean() * 0.8, la      # it learns
+    assert np.abs(la - lb).max() / lb.max() < 1e-5, (la, lb)        # measured 1.3e-7
+    moved = dev = 0.0
+    for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        moved += float(((pb.detach() - w0[n]) ** 2).sum())
+        dev += float(((pa.detach() - pb.detach()) ** 2).sum())
+    print("loss", la[0], "->", la[-1], " max |dloss|/loss", np.abs(la - lb).max() / lb.max(), " weights: deviation / distance travelled", (dev / moved) ** 0.5)
+    assert (dev / moved) ** 0.5 < 2e-3                                  # measured 1.6e-4
