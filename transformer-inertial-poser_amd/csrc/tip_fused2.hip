@@ -21,6 +21,8 @@
 
 namespace tip {
 
+typedef unsigned int u32x4_f2 __attribute__((ext_vector_type(4)));
+
 namespace f2 {
 constexpr int D = 256, F = 1024, R = 512, T = 40, ROWS = 80, RB = 5, KIN = 224;
 constexpr int LDX = D + 4;           // 260
@@ -45,7 +47,7 @@ static_assert(C_FLOATS >= ROWS * LDU && C_FLOATS >= ROWS * LDH, "chunk region mu
 // (its row of row-block r, k-offset 4*(lane>>4)) — row blocks need not be equally spaced (remapped planes).
 // Ring semantics as in tip_fused.hip: k-blocks 0,1 on entry; the last pair of prefetches is redirected to the next
 // phase (nsoff, nnstride_b).
-template <int NRB, int NBW, int KB>
+template <int NRB, int NBW, int KB, bool SWAP = false>   // SWAP: transposed accumulator tiles (mfma_block2)
 __device__ __forceinline__ void gemm_phase2(f32x4 (&acc)[NRB][NBW], const float* lds, const int (&aoff)[NRB],
                                             __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b, WRing2<NBW>& g,
                                             int nsoff, int nnstride_b) {
@@ -60,7 +62,7 @@ __device__ __forceinline__ void gemm_phase2(f32x4 (&acc)[NRB][NBW], const float*
         const int st = last ? nnstride_b : nstride_b;
 #pragma unroll
         for (int r = 0; r < NRB; ++r) a1[r] = *reinterpret_cast<const float4*>(lds + aoff[r] + (kb + 1) * 16);
-        mfma_block2<NRB, NBW>(acc, a0, g.w0);
+        mfma_block2<NRB, NBW, SWAP>(acc, a0, g.w0);
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w0[n] = ldfrag2(rsrc, voff, o + n * st);
         // pin the refill here: left alone, the scheduler sinks it behind the second MFMA block, next to its use at the top of the
@@ -68,7 +70,7 @@ __device__ __forceinline__ void gemm_phase2(f32x4 (&acc)[NRB][NBW], const float*
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < NRB; ++r) a0[r] = *reinterpret_cast<const float4*>(lds + aoff[r] + (kb + 2) * 16);
-        mfma_block2<NRB, NBW>(acc, a1, g.w1);
+        mfma_block2<NRB, NBW, SWAP>(acc, a1, g.w1);
 #pragma unroll
         for (int n = 0; n < NBW; ++n) g.w1[n] = ldfrag2(rsrc, voff, o + n * st + 1024);
         __builtin_amdgcn_sched_barrier(0);
@@ -370,24 +372,26 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
             ring2_prefetch<4>(g_ih, rsrc, voff, isoff, 16 * 1024);
             int ax[RB];
             rows_off(ax, 0, LDX);
-            gemm_phase2<RB, 4, 16>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
-            float* io = ih_out + (size_t)win0 * T * R;   // the two windows are consecutive: rows 0..79 map 1:1
-            const int nrows = nwin * T;
+            // Swapped operands: transposed accumulators, lane (l15, lg) = row 16 r + l15, columns 16 n + 4 lg ..: ONE 16-byte store per
+            // tile instead of four scattered 4-byte ones, through a buffer whose extent is the pair's real rows (the second window's
+            // pad rows, and an absent second window, are dropped by the range check instead of by a branch around every store), and
+            // the four bias vectors requested before the first store (a load cannot be hoisted over a store that may alias).
+            // Was 80 guarded 4-byte stores per lane, each behind its own 64-bit address computation, and a bias round trip per block.
+            gemm_phase2<RB, 4, 16, true>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
+            const int nrows = nwin * T;                  // the two windows are consecutive: rows 0..79 map 1:1
+            const __amdgpu_buffer_rsrc_t io_rs = __builtin_amdgcn_make_buffer_rsrc(ih_out + (size_t)win0 * T * R, 0, nrows * R * 4, 0x00020000);
             int le = lane;                               // opaque lane index: store offsets are formed here, not in the prologue
             asm volatile("" : "+v"(le));
             const int l15e = le & 15, lge = le >> 4;
+            f32x4 bv4[4];
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const int col = (wave * 4 + n) * 16 + l15e;
-                const float bv = wts[ih_off_b / 4 + R * D + col];
+            for (int n = 0; n < 4; ++n) bv4[n] = *reinterpret_cast<const f32x4*>(wts + ih_off_b / 4 + R * D + (wave * 4 + n) * 16 + lge * 4);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
 #pragma unroll
                 for (int r = 0; r < RB; ++r)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int row = r * 16 + lge * 4 + e;
-                        if (row < nrows) io[(size_t)row * R + col] = acc[r][n][e] + bv;
-                    }
-            }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_f2, acc[r][n] + bv4[n]), io_rs,
+                                                           ((r * 16 + l15e) * R + (wave * 4 + n) * 16 + lge * 4) * 4, 0, 0);
         }
         if (hall_sentinel) {
             uint4* hp = reinterpret_cast<uint4*>(hall_sentinel + (size_t)win0 * T * R);
@@ -749,21 +753,19 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         ring2_prefetch<2>(g_ih, rsrc, voff, isoff, 16 * 1024);
         int ax[RB];
         rows_off(ax, 0, LDX);
-        gemm_phase2<RB, 2, 16>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
-        float* io = ih_out + (size_t)win0 * T * R;
+        // (transposed tiles, 16-byte buffer stores bounded to the pair's real rows, biases first: as in fused_encoder2_kernel)
+        gemm_phase2<RB, 2, 16, true>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
         const int nrows = nwin * T;
+        const __amdgpu_buffer_rsrc_t io_rs = __builtin_amdgcn_make_buffer_rsrc(ih_out + (size_t)win0 * T * R, 0, nrows * R * 4, 0x00020000);
+        f32x4 bv4[2];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int col = (half * 16 + wave * 2 + n) * 16 + l15;
-            const float bv = wts[ih_off_b / 4 + R * D + col];
+        for (int n = 0; n < 2; ++n) bv4[n] = *reinterpret_cast<const f32x4*>(wts + ih_off_b / 4 + R * D + (half * 16 + wave * 2 + n) * 16 + lg * 4);
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < RB; ++r)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = r * 16 + lg * 4 + e;
-                    if (row < nrows) io[(size_t)row * R + col] = acc[r][n][e] + bv;
-                }
-        }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_f2, acc[r][n] + bv4[n]), io_rs,
+                                                       ((r * 16 + l15) * R + (half * 16 + wave * 2 + n) * 16 + lg * 4) * 4, 0, 0);
     }
     if (hall_sentinel) {   // each half arms half of the pair's HALL rows
         uint4* hp = reinterpret_cast<uint4*>(hall_sentinel + (size_t)win0 * T * R);
