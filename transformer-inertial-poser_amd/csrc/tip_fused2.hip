@@ -78,6 +78,14 @@ __device__ __forceinline__ void gemm_phase2(f32x4 (&acc)[NRB][NBW], const float*
 }
 
 
+// A wave-uniform pointer the compiler has lost track of (here: derived from the pair loop's induction variable), forced back into
+// SGPRs: a buffer descriptor built from VGPRs makes every buffer instruction a readfirstlane "waterfall" loop.
+__device__ __forceinline__ float* uniform_ptr(float* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+}
+
 // plane row of X row r: window 1 (rows 40..79) starts at plane row 48
 __device__ __forceinline__ int prow(int r) { return r + (r >= f2::T ? 8 : 0); }
 
@@ -379,7 +387,8 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
             // Was 80 guarded 4-byte stores per lane, each behind its own 64-bit address computation, and a bias round trip per block.
             gemm_phase2<RB, 4, 16, true>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
             const int nrows = nwin * T;                  // the two windows are consecutive: rows 0..79 map 1:1
-            const __amdgpu_buffer_rsrc_t io_rs = __builtin_amdgcn_make_buffer_rsrc(ih_out + (size_t)win0 * T * R, 0, nrows * R * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t io_rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ih_out + (size_t)win0 * T * R), 0,
+                                                                                    __builtin_amdgcn_readfirstlane(nrows * R * 4), 0x00020000);
             int le = lane;                               // opaque lane index: store offsets are formed here, not in the prologue
             asm volatile("" : "+v"(le));
             const int l15e = le & 15, lge = le >> 4;
@@ -756,7 +765,8 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         // (transposed tiles, 16-byte buffer stores bounded to the pair's real rows, biases first: as in fused_encoder2_kernel)
         gemm_phase2<RB, 2, 16, true>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
         const int nrows = nwin * T;
-        const __amdgpu_buffer_rsrc_t io_rs = __builtin_amdgcn_make_buffer_rsrc(ih_out + (size_t)win0 * T * R, 0, nrows * R * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t io_rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ih_out + (size_t)win0 * T * R), 0,
+                                                                                __builtin_amdgcn_readfirstlane(nrows * R * 4), 0x00020000);
         f32x4 bv4[2];
 #pragma unroll
         for (int n = 0; n < 2; ++n) bv4[n] = *reinterpret_cast<const f32x4*>(wts + ih_off_b / 4 + R * D + (half * 16 + wave * 2 + n) * 16 + lg * 4);
