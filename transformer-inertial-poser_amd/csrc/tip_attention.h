@@ -158,23 +158,24 @@ __device__ __forceinline__ void attention_head_regs(const f32x4_att (&qt)[3], co
 #pragma unroll
     for (int r = 0; r < RB; ++r) rsum[r] = 1.0f / rsum[r];
     if (TRAIN) {
+        // Straight-line code: the statistics go out through a buffer of this head's T (max, 1 / sum) pairs — lanes other than lg == 0 and
+        // queries >= T aim past its extent — and the keep decisions are drawn for the pad queries too (their probabilities only feed
+        // pad rows of O, which nobody reads).  With `if (q < T) { if (lg == 0) ...; if (thresh) ... }` the hash sat inside two nested
+        // divergent regions per row block.
         const unsigned dkey = tip_drop_key_s(seed, site);
+        const __amdgpu_buffer_rsrc_t ars = tip_rows_buffer(ast + bh * T * 2, T * 8);
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const int q = r * 16 + l15;
-            if (q < T) {
-                if (lg == 0) {
-                    ast[(bh * T + q) * 2] = mx[r];
-                    ast[(bh * T + q) * 2 + 1] = rsum[r];
-                }
-                if (thresh) {
-                    const unsigned long long pb = (bh * T + q) * T;
+            const ln_u32x2 mr = {__float_as_uint(mx[r]), __float_as_uint(rsum[r])};
+            __builtin_amdgcn_raw_buffer_store_b64(mr, ars, lg == 0 ? q * 8 : T * 8, 0, 0);
+            if (thresh) {
+                const unsigned pb = (unsigned)((bh * T + q) * T);
 #pragma unroll
-                    for (int cb = 0; cb <= r; ++cb)
+                for (int cb = 0; cb <= r; ++cb)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            S[r][cb][e] = tip_drop_hash_k(dkey, pb + cb * 16 + lg * 4 + e) >= thresh ? S[r][cb][e] * dscale : 0.f;
-                }
+                    for (int e = 0; e < 4; ++e)
+                        S[r][cb][e] = tip_drop_hash_k(dkey, pb + cb * 16 + lg * 4 + e) >= thresh ? S[r][cb][e] * dscale : 0.f;
             }
         }
     }

@@ -935,20 +935,18 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                 if (TR) {
                     // raw q (the packed W_q carries the 1/sqrt(d_head) fold: undo it exactly), k, v -> [M, 3D]; the third block has
                     // the same fragment layout as the padded kernel's (rows 32 + l15 / rows 32 + 4 lg + e), pad rows masked by T
-                    float* qp = svl + (size_t)tr.qkv * 64 + grow0 * (3 * D) + head * 16;
+                    // (a buffer of this window's T rows: the pad rows' stores are dropped by the range check, not by a branch each)
+                    const __amdgpu_buffer_rsrc_t qp_rs = tip_rows_buffer(svl + (size_t)tr.qkv * 64 + grow0 * (3 * D), T * 3 * D * 4);
                     const int lo = opaque(lane), l15o = lo & 15, lgo = lo >> 4;
 #pragma unroll
                     for (int r = 0; r < RB; ++r) {
-                        const int row = r * 16 + l15o;
-                        if (row < T) {
-                            __builtin_nontemporal_store(qt[r] * 4.0f, reinterpret_cast<f32x4*>(qp + row * (3 * D) + lgo * 4));
-                            __builtin_nontemporal_store(kt[r], reinterpret_cast<f32x4*>(qp + row * (3 * D) + D + lgo * 4));
-                        }
+                        const int qo = ((r * 16 + l15o) * (3 * D) + head * 16 + lgo * 4) * 4;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, qt[r] * 4.0f), qp_rs, qo, 0, kTipNT);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, kt[r]), qp_rs, qo + D * 4, 0, kTipNT);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int vr = r * 16 + lgo * 4 + e;
-                            if (vr < T) __builtin_nontemporal_store(vv[r][e], qp + vr * (3 * D) + 2 * D + l15o);
-                        }
+                        for (int e = 0; e < 4; ++e)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(vv[r][e]), qp_rs,
+                                                                  ((r * 16 + lgo * 4 + e) * (3 * D) + 2 * D + head * 16 + l15o) * 4, 0, kTipNT);
                     }
                     attention_head_regs<LDX, true>(qt, kt, vv, Oc, head * 16, lo, TMAX, svl + (size_t)tr.ast * 64,
                                                    (unsigned long long)win * H + head, T, tr.seed, (unsigned)(layer * 4 + 0), tr.thresh,

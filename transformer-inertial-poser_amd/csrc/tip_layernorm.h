@@ -61,11 +61,32 @@ __device__ __forceinline__ float wave64_sum(float v) { return lg4_sum(row16_sum(
 // row 32 p + 4 wave + sub — so both row statistics are a 16-value local sum plus row16_sum: four DPP adds instead of six LDS
 // round trips.  SAVE (training forward): the pre-norm rows, (mean, rstd) and the normalised rows also go to HBM for rows < T.
 typedef float ln_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned ln_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned ln_u32x2 __attribute__((ext_vector_type(2)));
+
+// A wave-uniform pointer forced into SGPRs (a buffer descriptor built from VGPRs turns every buffer instruction into a readfirstlane
+// "waterfall" loop), and the first `bytes` bytes behind it as a raw buffer: loads past the extent return 0, stores past it are
+// dropped — the pad rows of a window are masked by the hardware's range check instead of by a branch around every access.
+template <typename P>
+__device__ __forceinline__ P* tip_uniform_ptr(P* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<P*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tip_rows_buffer(const float* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tip_uniform_ptr(p)), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+constexpr int kTipNT = 2;   // buffer-store cache policy: non-temporal (streaming stash: read next by the backward, not by this kernel)
+
 template <int ROWS, int LD, bool SAVE = false>
 __device__ __forceinline__ void layernorm_rows16(float* X, const float* __restrict__ g, const float* __restrict__ be, int wave,
                                                  int lane, float* zs = nullptr, float* sts = nullptr, float* xs = nullptr, int T = 0) {
     constexpr int DCOLS = 256, NPASS = (ROWS + 31) / 32;
     const int q = lane & 15, sub = lane >> 4;
+    // SAVE: the three stash arrays as buffers of T rows (rows >= T are dropped by the range check)
+    const __amdgpu_buffer_rsrc_t zrs = tip_rows_buffer(SAVE ? zs : X, SAVE ? T * DCOLS * 4 : 0);
+    const __amdgpu_buffer_rsrc_t xrs = tip_rows_buffer(SAVE ? xs : X, SAVE ? T * DCOLS * 4 : 0);
+    const __amdgpu_buffer_rsrc_t srs = tip_rows_buffer(SAVE ? sts : X, SAVE ? T * 8 : 0);
     float4 gg[4], bb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -82,7 +103,7 @@ __device__ __forceinline__ void layernorm_rows16(float* X, const float* __restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 v[j] = *reinterpret_cast<const float4*>(xr + j * 64);
-                if (SAVE && row < T) __builtin_nontemporal_store(__builtin_bit_cast(ln_f32x4, v[j]), reinterpret_cast<ln_f32x4*>(zs + (size_t)row * DCOLS + (q + 16 * j) * 4));
+                if (SAVE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ln_u32x4, v[j]), zrs, (row * DCOLS + (q + 16 * j) * 4) * 4, 0, kTipNT);
             }
             s = ((v[0].x + v[0].y) + (v[0].z + v[0].w)) + ((v[1].x + v[1].y) + (v[1].z + v[1].w));
             s += ((v[2].x + v[2].y) + (v[2].z + v[2].w)) + ((v[3].x + v[3].y) + (v[3].z + v[3].w));
@@ -103,11 +124,11 @@ __device__ __forceinline__ void layernorm_rows16(float* X, const float* __restri
                 o.z = v[j].z * rstd * gg[j].z + bb[j].z;
                 o.w = v[j].w * rstd * gg[j].w + bb[j].w;
                 *reinterpret_cast<float4*>(xr + j * 64) = o;
-                if (SAVE && row < T) __builtin_nontemporal_store(__builtin_bit_cast(ln_f32x4, o), reinterpret_cast<ln_f32x4*>(xs + (size_t)row * DCOLS + (q + 16 * j) * 4));
+                if (SAVE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ln_u32x4, o), xrs, (row * DCOLS + (q + 16 * j) * 4) * 4, 0, kTipNT);
             }
-            if (SAVE && row < T && q == 0) {
-                sts[row * 2] = mean;
-                sts[row * 2 + 1] = rstd;
+            if (SAVE) {   // one 8-byte store per row from lane q == 0 (the other lanes aim past the extent)
+                const ln_u32x2 mr = {__float_as_uint(mean), __float_as_uint(rstd)};
+                __builtin_amdgcn_raw_buffer_store_b64(mr, srs, q == 0 ? row * 8 : T * 8, 0, 0);
             }
         }
     }
