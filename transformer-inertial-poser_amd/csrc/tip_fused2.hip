@@ -8,7 +8,7 @@
 //
 // LDS (161,024 B): X [80][260] residual stream of both windows | C: per 4-head "quad" Q [96][68], K [96][68],
 // V^T [64][100] (window 1 starts at plane row 48 so each window has its own 8 pad rows for the 3x16-row attention
-// blocks), reused as U [80][228] (prologue) and Hc [80][132] (FFN hidden chunk of 128).
+// blocks), reused as U [80][232] (prologue) and Hc [80][136] (FFN hidden chunk of 128).
 // Per layer: 4 quads x { Q|K projection (one 16-column block per wave), V projection (head = wave&3, waves 0-3 take
 // row blocks 0-2, waves 4-7 row blocks 3-4), attention (wave = head x window), out-projection partial } ->
 // LayerNorm1 -> 8 x { linear1 chunk + ReLU, linear2 partial } -> LayerNorm2.
@@ -25,15 +25,15 @@ typedef unsigned int u32x4_f2 __attribute__((ext_vector_type(4)));
 
 namespace f2 {
 constexpr int D = 256, F = 1024, R = 512, T = 40, ROWS = 80, RB = 5, KIN = 224;
-constexpr int LDX = D + 4;           // 260
+constexpr int LDX = D + 8;           // 264: row stride = 8 (mod 64) dwords: conflict-free ds_read_b128 A fragments (tip_fused.hip)
 constexpr int LDQ = 64 + 4;          // 68: Q / K plane of one quad (4 heads x 16 channels)
 constexpr int PROWS = 96;            // plane rows: window w occupies rows 48w .. 48w+39 (+8 pad)
 constexpr int LDV = PROWS + 4;       // 100: V^T [64 channels][96 keys]
-constexpr int LDU = KIN + 4;         // 228
-constexpr int LDH = 128 + 4;         // 132: FFN hidden chunk
-constexpr int X_FLOATS = ROWS * LDX;                       // 20800
+constexpr int LDU = KIN + 8;         // 232
+constexpr int LDH = 128 + 8;         // 136: FFN hidden chunk
+constexpr int X_FLOATS = ROWS * LDX;                       // 21120
 constexpr int C_FLOATS = 2 * PROWS * LDQ + 64 * LDV;       // 19456
-constexpr int LDS_BYTES = (X_FLOATS + C_FLOATS) * 4;       // 161024
+constexpr int LDS_BYTES = (X_FLOATS + C_FLOATS) * 4;       // 162304
 constexpr int THREADS = 512;
 // packed fused section (identical to tip_fused.hip)
 constexpr size_t IN_W = 0, IN_B = IN_W + (size_t)D * KIN, LAYER0 = IN_B + D;

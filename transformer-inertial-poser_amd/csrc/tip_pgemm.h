@@ -58,8 +58,8 @@ __device__ __forceinline__ void zero_acc2(f32x4 (&acc)[NRB][NBW]) {
 // MFMAs, 16 flop per L2 byte) this reads 40 flop per L2 byte and keeps the matrix pipe fed between barriers.
 // =====================================================================================================================
 namespace pg {
-constexpr int ROWS = 80, RB = 5, NBW = 4, KC = 128, LDA = KC + 4, THREADS = 512, COLS = 8 * NBW * 16;   // 512
-constexpr int LDS_BYTES = 2 * ROWS * LDA * 4;                                                          // 84 480
+constexpr int ROWS = 80, RB = 5, NBW = 4, KC = 128, LDA = KC + 8, THREADS = 512, COLS = 8 * NBW * 16;   // 512
+constexpr int LDS_BYTES = 2 * ROWS * LDA * 4;                                                          // 87 040
 }  // namespace pg
 
 // Epi finishes and stores the outputs in groups of FOUR consecutive columns of one row (the tiles are computed transposed):
