@@ -290,7 +290,10 @@ def train_step_times(cfg, dev, B=256, T=40, steps=20, warmup=5):
             for _ in range(warmup):
                 fn()
             torch.cuda.synchronize()
-            res[name] = timed_loop(fn, steps)
+            # best of two loops: a one-off allocator event (the caching allocator re-growing the 0.5-GB activation stash after the
+            # previous section's empty_cache) otherwise lands in one loop's mean — seen once as forward 3.8 ms instead of 0.80
+            res[name] = min(timed_loop(fn, steps), timed_loop(fn, steps))
+    res["timing"] = "best of two loops of %d calls" % steps
     assert m.hip_forward_count() > n0, "the HIP training kernels did not run"
     fl = synth.flops_per_window(cfg, T)
     res["fwd_bwd_tflops"] = 3 * B * fl / res["fwd_bwd_ms"] / 1e9

@@ -181,19 +181,19 @@ __global__ __launch_bounds__(256) void lat_in_kernel(const float* __restrict__ w
             const int row = wave + i * 4;
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
+                // One unconditional load per element from a SELECTED (clamped, always valid) address, the result masked by selects: with
+                // `if (row < T) { if (c < NI) .. else if (c < NI + S) .. }` around each of the 48 loads the compiler emitted 160 exec-mask
+                // branches and waited for each load inside its own region.
                 const int c = ch * 64 + lane;
-                float x = 0.f;
-                if (row < T) {
-                    if (c < NI) {
-                        x = xi[(size_t)row * NI + c];
-                    } else if (c < NI + S) {
-                        const size_t j = (size_t)row * S + (c - NI);
-                        x = xs[j];
-                        if (x != x) x = 0.f;                    // :65
-                        if (km) x = x * km[j] * keep_scale;     // :77
-                    }
-                }
-                v[i][ch] = x;
+                const int rc = row < T ? row : T - 1;
+                const bool imu = c < NI;
+                const int cs = c - NI < 0 ? 0 : (c - NI < S ? c - NI : S - 1);
+                const float* pa = imu ? xi + (size_t)rc * NI + c : xs + (size_t)rc * S + cs;
+                const float x = *pa;
+                float kv = 1.f;
+                if (km) kv = *(imu ? pa : km + (size_t)rc * S + cs);                  // :77 (km: wave-uniform; IMU lanes read a dummy)
+                const float xs_v = (x != x ? 0.f : x) * kv * (km ? keep_scale : 1.f); // :65, then (x * mask) * scale as before
+                v[i][ch] = (row < T && c < NI + S) ? (imu ? x : xs_v) : 0.f;
             }
         }
 #pragma unroll
