@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void lat_in_kernel(const float* __restrict__ w
     const int nkb = KB - kb0 < 4 ? KB - kb0 : 4;
     f32x4 w[4];
     load_kslice<4>(w, rsrc, lane * 16, in_w_off_b + (nb * KB + kb0) * 1024, nkb);
+    const float bv_in = wts[in_b_off + nb * 16 + l15];
     // the first column block also clears this stream's RNN hand-off granules (tags must start at 0 every launch)
     if (nb == 0) {
         unsigned long long* gq = gran + (size_t)win * 2 * R;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void lat_in_kernel(const float* __restrict__ w
     const f32x4 s = reduce_partials<4>(red, acc, wave, lane);
     if (wave < RB) {
         const int col = nb * 16 + l15;
-        const float bv = wts[in_b_off + col];
+        const float bv = bv_in;
         float* o = xpre + (size_t)win * T * D;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(256) void lat_ln_gemm_kernel(const float* __restric
     const int kb0 = wave * 4;  // K = 256: 16 k-blocks, 4 per wave
     f32x4 w[4];
     load_kslice<4>(w, rsrc, lane * 16, w_off_b + (nb * 16 + kb0) * 1024, 4);
+    const float bv = wts[b_off + nb * 16 + l15];   // requested with the operands, not behind the reduction's barrier
     stage_rows_ln<256>(Xs, xpre + (size_t)win * T * D, T, g, be,
                        (stats && nb == 0) ? stats + (size_t)win * RP * 2 : nullptr);
     __syncthreads();
@@ -247,7 +249,6 @@ __global__ __launch_bounds__(256) void lat_ln_gemm_kernel(const float* __restric
     const f32x4 s = reduce_partials<4>(red, acc, wave, lane);
     if (wave < RB) {
         const int col = nb * 16 + l15;
-        const float bv = wts[b_off + col];
         float* o = out + (size_t)win * T * ldo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -284,17 +285,19 @@ __global__ __launch_bounds__(256) void lat_qkv_attn_kernel(const float* __restri
 #pragma unroll
     for (int which = 0; which < 3; ++which)
         load_kslice<4>(w[which], rsrc, lane * 16, w_off_b + ((which * 16 + head) * 16 + kb0) * 1024, 4);
+    float bqkv[3];                                     // requested with the operands, not behind each reduction's barrier
+#pragma unroll
+    for (int which = 0; which < 3; ++which) bqkv[which] = wts[b_off + (which * 16 + head) * 16 + l15];
     stage_rows_ln<256>(Xs, xpre + (size_t)win * T * D, T, g, be,
                        (stats && head == 0) ? stats + (size_t)win * RP * 2 : nullptr);
     __syncthreads();
 #pragma unroll
     for (int which = 0; which < 3; ++which) {
         f32x4 acc[RB] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const int nb = which * 16 + head;
         mma_kslice<4>(acc, Xs + l15 * LDX + lg * 4 + kb0 * 16, LDX, w[which], 4);
         const f32x4 sres = reduce_partials<4>(red, acc, wave, lane);
         if (wave < RB) {
-            const float bv = wts[b_off + nb * 16 + l15];
+            const float bv = bqkv[which];
             if (which < 2) {
                 float* dst = which == 0 ? Qs : Ks;
 #pragma unroll
@@ -339,6 +342,20 @@ __global__ __launch_bounds__(NW * 64) void lat_res_gemm_kernel(const float* __re
     f32x4 w[KBW];
 #pragma unroll
     for (int k = 0; k < KBW; ++k) w[k] = ldfrag(rsrc, lane * 16, w_off_b + (nb * KBT + kb0 + k) * 1024);
+    // The epilogue's inputs (bias, LayerNorm parameters / statistics, residual values) are requested HERE, with the operands: loaded
+    // where they are used — behind the reduction's barrier — they are one more exposed L2 round trip in each of the forward's 18 kernels.
+    const int ecol = nb * 16 + l15;
+    const int ewave = wave < RB ? wave : 0;               // (waves >= RB load a dummy row block: keeps the loads unconditional)
+    const float bv = wts[b_off + ecol];
+    const float gc = g ? g[ecol] : 1.f, bc = g ? be[ecol] : 0.f;
+    float xres[4], smean[4], srstd[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = ewave * 16 + lg * 4 + e, rc = row < T ? row : T - 1;
+        xres[e] = xpre[(size_t)win * T * D + (size_t)rc * D + ecol];
+        smean[e] = g ? stats[(size_t)win * RP * 2 + rc * 2] : 0.f;
+        srstd[e] = g ? stats[(size_t)win * RP * 2 + rc * 2 + 1] : 1.f;
+    }
     const float* Ab = A + (size_t)win * T * lda + lg * 4;   // lda = K: a window's blocked image has T*K floats
     float4 a[RB][KBW];
 #pragma unroll
@@ -363,20 +380,13 @@ __global__ __launch_bounds__(NW * 64) void lat_res_gemm_kernel(const float* __re
     }
     const f32x4 s = reduce_partials<NW>(red, acc, wave, lane);
     if (wave < RB) {
-        const int col = nb * 16 + l15;
-        const float bv = wts[b_off + col];
-        const float gc = g ? g[col] : 1.f, bc = g ? be[col] : 0.f;
-        const float* xp = xpre + (size_t)win * T * D;
-        const float* st = stats + (size_t)win * RP * 2;
         float* o = out + (size_t)win * T * D;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = wave * 16 + lg * 4 + e;
-            if (row < T) {
-                float x = xp[(size_t)row * D + col];
-                if (g) x = (x - st[row * 2]) * st[row * 2 + 1] * gc + bc;
-                o[(size_t)row * D + col] = x + s[e] + bv;
-            }
+            float x = xres[e];
+            if (g) x = (x - smean[e]) * srstd[e] * gc + bc;
+            if (row < T) o[(size_t)row * D + ecol] = x + s[e] + bv;
         }
     }
 }
