@@ -189,6 +189,28 @@ __global__ __launch_bounds__(256) void stream_ingest_kernel(float* __restrict__ 
         __syncthreads();
     }
     if (tid == 0) *ctr = f;
+    // Everything that does not depend on THIS frame goes first, so that it runs under the latency of the smoothing chain below (five
+    // dependent phases with a barrier and a global round trip each) instead of after it: the whole x_s window (history rows written by
+    // earlier consume calls), rows 0 .. T-2 of x_imu (local-frame rows and acc-sums of earlier frames) and the acc-sum of the older
+    // frames.  As one tail behind the chain these copies were two thirds of the kernel's 13 us at one stream.
+    const int k = f - 5;  // index of the smoothed frame produced now == index of this model call (f >= 5)
+    float acc_old = 0.f;  // threads < 18: acc-sum over the window's older frames, oldest first (:136)
+    if (f >= 5) {
+        float* xs = x_s + (size_t)b * T * NS;
+#pragma unroll 4
+        for (int i = tid; i < T * NS; i += 256) {
+            const int t = i / NS, c = i - t * NS, j = k + 1 - T + t;   // history entries k+1-T .. k (:144)
+            xs[i] = S[HIST + (j % WIN) * NS + c];
+        }
+        float* xi = x_imu + (size_t)b * T * NX;
+#pragma unroll 4
+        for (int i = tid; i < (T - 1) * NX; i += 256) {
+            const int t = i / NX, c = i - t * NX, j = k - T + 1 + t;
+            xi[i] = c < NIMU ? S[LOC + (j % WIN) * NIMU + c] : S[ACCS + (j % WIN) * 18 + (c - NIMU)] / 15.0f;   // :139-141
+        }
+        if (tid < 18)
+            for (int j = k - T + 1; j < k; ++j) acc_old += S[LOC + (j % WIN) * NIMU + 54 + tid];
+    }
     if (tid < NIMU) {
         const float v = raw_in[(size_t)b * NIMU + tid];
         if (f == 0) {
@@ -199,7 +221,6 @@ __global__ __launch_bounds__(256) void stream_ingest_kernel(float* __restrict__ 
     }
     __syncthreads();
     if (f < 5) return;   // fewer than 11 raw entries: the smoother is still priming (:68, :125-128)
-    const int k = f - 5;  // index of the smoothed frame produced now == index of this model call
     if (tid < 54) {
         sm[tid] = S[RAW + (f % RAWN) * NIMU + tid];            // rotations of the frame 5 steps back (:71)
     } else if (tid < NIMU) {
@@ -232,23 +253,16 @@ __global__ __launch_bounds__(256) void stream_ingest_kernel(float* __restrict__ 
         loc[tid] = inv[i * 3 + 0] * am[0] + inv[i * 3 + 1] * am[1] + inv[i * 3 + 2] * am[2];
     }
     __syncthreads();
-    if (tid < NIMU) S[LOC + (k % WIN) * NIMU + tid] = loc[tid];
-    __syncthreads();
-    if (tid < 18) {   // acc-sum feature over the (<= 40-frame) window, oldest -> newest (:136)
-        float acc = 0.f;
-        for (int j = k - T + 1; j <= k; ++j) acc += S[LOC + (j % WIN) * NIMU + 54 + tid];
+    // this frame's row: to the state (next frames read it) and straight to the newest row of x_imu, both from LDS
+    float* xin = x_imu + (size_t)b * T * NX + (size_t)(T - 1) * NX;
+    if (tid < NIMU) {
+        S[LOC + (k % WIN) * NIMU + tid] = loc[tid];
+        xin[tid] = loc[tid];
+    }
+    if (tid < 18) {   // acc-sum feature over the (<= 40-frame) window: the older frames' partial + this frame, added last (:136)
+        const float acc = acc_old + loc[54 + tid];
         S[ACCS + (k % WIN) * 18 + tid] = acc;
-    }
-    __syncthreads();
-    float* xi = x_imu + (size_t)b * T * NX;
-    for (int i = tid; i < T * NX; i += 256) {
-        const int t = i / NX, c = i - t * NX, j = k - T + 1 + t;
-        xi[i] = c < NIMU ? S[LOC + (j % WIN) * NIMU + c] : S[ACCS + (j % WIN) * 18 + (c - NIMU)] / 15.0f;   // :139-141
-    }
-    float* xs = x_s + (size_t)b * T * NS;
-    for (int i = tid; i < T * NS; i += 256) {
-        const int t = i / NS, c = i - t * NS, j = k + 1 - T + t;   // history entries k+1-T .. k (:144)
-        xs[i] = S[HIST + (j % WIN) * NS + c];
+        xin[NIMU + tid] = acc / 15.0f;                        // :139-141
     }
 }
 
