@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void stream_reset_kernel(float* __restrict__ st
 __global__ __launch_bounds__(256) void stream_ingest_kernel(float* __restrict__ state, const float* __restrict__ raw_in, int B,
                                                             int f, float* __restrict__ x_imu, float* __restrict__ x_s, int T) {
     using namespace sz;
-    __shared__ float sm[NIMU], loc[NIMU], inv[9];
+    __shared__ float sm[NIMU], loc[NIMU];
     const int b = blockIdx.x, tid = threadIdx.x;
     float* S = state + (size_t)b * STRIDE;
     int* ctr = reinterpret_cast<int*>(S + CTR);
@@ -196,61 +196,94 @@ __global__ __launch_bounds__(256) void stream_ingest_kernel(float* __restrict__ 
     const int k = f - 5;  // index of the smoothed frame produced now == index of this model call (f >= 5)
     float acc_old = 0.f;  // threads < 18: acc-sum over the window's older frames, oldest first (:136)
     if (f >= 5) {
+        // (compile-time trip counts, every load of a loop requested before its first store: 36 round trips in flight together)
+        constexpr int XS_IT = (WIN * NS + 255) / 256, XI_IT = (WIN * NX + 255) / 256;
         float* xs = x_s + (size_t)b * T * NS;
-#pragma unroll 4
-        for (int i = tid; i < T * NS; i += 256) {
-            const int t = i / NS, c = i - t * NS, j = k + 1 - T + t;   // history entries k+1-T .. k (:144)
-            xs[i] = S[HIST + (j % WIN) * NS + c];
+        float vs[XS_IT];
+#pragma unroll
+        for (int u = 0; u < XS_IT; ++u) {
+            const int i = tid + 256 * u, ic = i < T * NS ? i : 0;
+            const int t = ic / NS, c = ic - t * NS, j = k + 1 - T + t;   // history entries k+1-T .. k (:144)
+            vs[u] = S[HIST + (j % WIN) * NS + c];
         }
         float* xi = x_imu + (size_t)b * T * NX;
-#pragma unroll 4
-        for (int i = tid; i < (T - 1) * NX; i += 256) {
-            const int t = i / NX, c = i - t * NX, j = k - T + 1 + t;
-            xi[i] = c < NIMU ? S[LOC + (j % WIN) * NIMU + c] : S[ACCS + (j % WIN) * 18 + (c - NIMU)] / 15.0f;   // :139-141
+        float vi[XI_IT];
+#pragma unroll
+        for (int u = 0; u < XI_IT; ++u) {
+            const int i = tid + 256 * u, ic = i < (T - 1) * NX ? i : 0;
+            const int t = ic / NX, c = ic - t * NX, j = k - T + 1 + t;
+            const float* pv = c < NIMU ? S + LOC + (j % WIN) * NIMU + c : S + ACCS + (j % WIN) * 18 + (c - NIMU);
+            const float x = *pv;
+            vi[u] = c < NIMU ? x : x / 15.0f;                                                            // :139-141
         }
-        if (tid < 18)
-            for (int j = k - T + 1; j < k; ++j) acc_old += S[LOC + (j % WIN) * NIMU + 54 + tid];
+#pragma unroll
+        for (int u = 0; u < XS_IT; ++u)
+            if (tid + 256 * u < T * NS) xs[tid + 256 * u] = vs[u];
+#pragma unroll
+        for (int u = 0; u < XI_IT; ++u)
+            if (tid + 256 * u < (T - 1) * NX) xi[tid + 256 * u] = vi[u];
+        if (tid < 18) {   // all (up to 39) loads first, then the sum in the reference's order: one round trip, not one per frame
+            float av[WIN - 1];
+#pragma unroll
+            for (int u = 0; u < WIN - 1; ++u) {
+                const int j = k - T + 1 + u;
+                av[u] = S[LOC + ((j < k ? j : k - 1 < 0 ? 0 : k - 1) % WIN) * NIMU + 54 + tid];
+            }
+#pragma unroll
+            for (int u = 0; u < WIN - 1; ++u)
+                if (k - T + 1 + u < k) acc_old += av[u];
+        }
     }
+    // The chain: two LDS barriers.  The raw frame is used from its register (it also goes to the ring for the next ten calls), the ten
+    // older raw rows do not depend on this call, and every thread inverts the 3 x 3 root matrix for itself (40 flops) — with the
+    // frame stored, re-read behind a barrier, and the inverse computed by thread 0 between two more, the chain was five barriers
+    // with a global round trip each.
+    float vnew = 0.f;
     if (tid < NIMU) {
-        const float v = raw_in[(size_t)b * NIMU + tid];
+        vnew = raw_in[(size_t)b * NIMU + tid];
         if (f == 0) {
-            for (int e = 0; e < 6; ++e) S[RAW + e * NIMU + tid] = v;   // 5 priming copies + the frame itself (:61-66)
+            for (int e = 0; e < 6; ++e) S[RAW + e * NIMU + tid] = vnew;   // 5 priming copies + the frame itself (:61-66)
         } else {
-            S[RAW + ((f + 5) % RAWN) * NIMU + tid] = v;
+            S[RAW + ((f + 5) % RAWN) * NIMU + tid] = vnew;
         }
     }
-    __syncthreads();
     if (f < 5) return;   // fewer than 11 raw entries: the smoother is still priming (:68, :125-128)
     if (tid < 54) {
         sm[tid] = S[RAW + (f % RAWN) * NIMU + tid];            // rotations of the frame 5 steps back (:71)
     } else if (tid < NIMU) {
         float acc = 0.f;
-        for (int i = 0; i < RAWN; ++i) acc += S[RAW + ((f - 5 + i) % RAWN) * NIMU + tid];   // oldest -> newest (:72)
+        for (int i = 0; i < RAWN - 1; ++i) acc += S[RAW + ((f - 5 + i) % RAWN) * NIMU + tid];   // oldest -> newest (:72) ...
+        acc += vnew;                                                                             // ... the newest is this call's frame
         sm[tid] = acc / (float)RAWN;
     }
     __syncthreads();
-    if (tid == 0) {   // general 3x3 inverse (np.linalg.inv at data_utils.py:200,211), adjugate / determinant
-        const float a = sm[0], bq = sm[1], c = sm[2], d = sm[3], e = sm[4], g = sm[5], h = sm[6], i9 = sm[7], j = sm[8];
-        const float A = e * j - g * i9, Bc = -(d * j - g * h), Cc = d * i9 - e * h;
-        const float det = a * A + bq * Bc + c * Cc;
-        const float id = 1.f / det;
-        inv[0] = A * id;  inv[1] = -(bq * j - c * i9) * id; inv[2] = (bq * g - c * e) * id;
-        inv[3] = Bc * id; inv[4] = (a * j - c * h) * id;    inv[5] = -(a * g - c * d) * id;
-        inv[6] = Cc * id; inv[7] = -(a * i9 - bq * h) * id; inv[8] = (a * e - bq * d) * id;
-    }
-    __syncthreads();
-    if (tid < 9) {
-        loc[tid] = sm[tid];
-    } else if (tid < 54) {
-        const int s = (tid - 9) / 9, e = (tid - 9) % 9, i = e / 3, j = e % 3;
-        const float* Rm = sm + 9 + s * 9;
-        loc[tid] = inv[i * 3 + 0] * Rm[0 * 3 + j] + inv[i * 3 + 1] * Rm[1 * 3 + j] + inv[i * 3 + 2] * Rm[2 * 3 + j];
-    } else if (tid < 57) {
-        loc[tid] = sm[tid];
-    } else if (tid < NIMU) {
-        const int s = (tid - 57) / 3, i = (tid - 57) % 3;
-        const float* am = sm + 57 + s * 3;
-        loc[tid] = inv[i * 3 + 0] * am[0] + inv[i * 3 + 1] * am[1] + inv[i * 3 + 2] * am[2];
+    if (tid < NIMU) {
+        // general 3x3 inverse (np.linalg.inv at data_utils.py:200,211), adjugate / determinant
+        float inv[9];
+        {
+            const float a = sm[0], bq = sm[1], c = sm[2], d = sm[3], e = sm[4], g = sm[5], h = sm[6], i9 = sm[7], j = sm[8];
+            const float A = e * j - g * i9, Bc = -(d * j - g * h), Cc = d * i9 - e * h;
+            const float det = a * A + bq * Bc + c * Cc;
+            const float id = 1.f / det;
+            inv[0] = A * id;  inv[1] = -(bq * j - c * i9) * id; inv[2] = (bq * g - c * e) * id;
+            inv[3] = Bc * id; inv[4] = (a * j - c * h) * id;    inv[5] = -(a * g - c * d) * id;
+            inv[6] = Cc * id; inv[7] = -(a * i9 - bq * h) * id; inv[8] = (a * e - bq * d) * id;
+        }
+        float lv;
+        if (tid < 9) {
+            lv = sm[tid];
+        } else if (tid < 54) {
+            const int s = (tid - 9) / 9, e = (tid - 9) % 9, i = e / 3, j = e % 3;
+            const float* Rm = sm + 9 + s * 9;
+            lv = inv[i * 3 + 0] * Rm[0 * 3 + j] + inv[i * 3 + 1] * Rm[1 * 3 + j] + inv[i * 3 + 2] * Rm[2 * 3 + j];
+        } else if (tid < 57) {
+            lv = sm[tid];
+        } else {
+            const int s = (tid - 57) / 3, i = (tid - 57) % 3;
+            const float* am = sm + 57 + s * 3;
+            lv = inv[i * 3 + 0] * am[0] + inv[i * 3 + 1] * am[1] + inv[i * 3 + 2] * am[2];
+        }
+        loc[tid] = lv;
     }
     __syncthreads();
     // this frame's row: to the state (next frames read it) and straight to the newest row of x_imu, both from LDS
@@ -277,13 +310,24 @@ __global__ __launch_bounds__(192) void stream_consume_kernel(float* __restrict__
     const float csum = 0.07776f + 0.1296f + 0.216f + 0.36f + 0.6f + 1.0f;
     if (k < 0) k = *reinterpret_cast<const int*>(S + CTR) - 5;   // TIP_STREAM_FRAME_AUTO: the call that belongs to the last ingested frame
     const int n = k + 1;
+    // requested up front, with the prediction row: the previous pose / root velocity (the averaging below) and the root IMU rotation
+    // — behind the first barrier each was one more exposed round trip
+    float last3[3] = {0.f, 0.f, 0.f}, rr[9];
+    if (tid >= 1 && tid < 18 && k > 0)
+        for (int e = 0; e < 3; ++e) last3[e] = S[LAST + (tid - 1) * 3 + e];
+    if (tid >= 64 && tid < 67 && k > 0) last3[0] = S[LAST + 51 + (tid - 64)];
+    if (tid == 0)
+        for (int e = 0; e < 9; ++e) rr[e] = S[LOC + (k % WIN) * NIMU + e];
     if (tid < NS) {
         const float y = y_last[(size_t)b * NS + tid];
         S[OUTS + (k % OUTN) * NS + tid] = y;
         float v;
         if (n >= OUTN) {
+            // the five older rows do not depend on this call's row: their loads go out with its load; the newest term is y itself
+            // (the row just stored: same value, no store -> load round trip)
             float acc = 0.f;
-            for (int i = 0; i < OUTN; ++i) acc += S[OUTS + ((k - 5 + i) % OUTN) * NS + tid] * coeff[i];
+            for (int i = 0; i < OUTN - 1; ++i) acc += S[OUTS + ((k - 5 + i) % OUTN) * NS + tid] * coeff[i];
+            acc += y * coeff[OUTN - 1];
             v = acc / csum;
         } else {
             v = y;
@@ -301,8 +345,7 @@ __global__ __launch_bounds__(192) void stream_consume_kernel(float* __restrict__
     if (tid < 18) {
         float rv[3];
         if (tid == 0) {   // root rotation comes from the IMU, not from the prediction (:160-162)
-            const float* Rr = S + LOC + (k % WIN) * NIMU;
-            float m[3][3] = {{Rr[0], Rr[1], Rr[2]}, {Rr[3], Rr[4], Rr[5]}, {Rr[6], Rr[7], Rr[8]}};
+            float m[3][3] = {{rr[0], rr[1], rr[2]}, {rr[3], rr[4], rr[5]}, {rr[6], rr[7], rr[8]}};
             polar_newton(m);
             float q[4];
             mat_to_quat(m, q);
@@ -319,7 +362,7 @@ __global__ __launch_bounds__(192) void stream_consume_kernel(float* __restrict__
             mat_to_quat(m, q);
             quat_to_rotvec(q, rv);
             if (k > 0) {  // averaged with the previous pose (:165-166)
-                for (int e = 0; e < 3; ++e) rv[e] = (rv[e] + S[LAST + (tid - 1) * 3 + e]) * 0.5f;
+                for (int e = 0; e < 3; ++e) rv[e] = (rv[e] + last3[e]) * 0.5f;
             }
             for (int e = 0; e < 3; ++e) S[LAST + (tid - 1) * 3 + e] = rv[e];
         }
@@ -330,7 +373,7 @@ __global__ __launch_bounds__(192) void stream_consume_kernel(float* __restrict__
     } else if (tid >= 64 && tid < 67) {
         const int e = tid - 64;
         float v = s[108 + e];
-        if (k > 0) v = (v + S[LAST + 51 + e]) * 0.5f;
+        if (k > 0) v = (v + last3[0]) * 0.5f;
         S[LAST + 51 + e] = v;
         rootv[e] = v;
         S[HIST + ((k + 1) % WIN) * NS + 108 + e] = v;
