@@ -1881,25 +1881,22 @@ __global__ __launch_bounds__(fz::THREADS) void win_gemm_kernel(WinGemmArgs a, in
         __syncthreads();
         f32x4 acc[RBM][NBW], acct[RBT][NBW];
         zero_acc_h<NBW>(acc, acct);
-        gemm_phase_h<NBW, KB, 0, true>(acc, acct, smem + l15 * LDA + lg * 4, smem + (TAIL0 + (lane & 3)) * LDA + lg * 4, LDA, rsrc, voff, wsoff,
-                                       KB * 1024, g, wsoff, KB * 1024);
-        float* out = a.out + (size_t)win * T * a.ldo;
+        // rows 0-31 with swapped operands (transposed accumulators: lane = row l15, columns 4 lg ..): one 16-byte store per tile instead
+        // of four 4-byte ones; the window's output rows as a buffer of T rows, so the pad rows are dropped by the range check instead
+        // of by a branch around every store (as the hybrid encoder's IH epilogue).  Same products, same sums.
+        gemm_phase_h<NBW, KB, NBW, true>(acc, acct, smem + l15 * LDA + lg * 4, smem + (TAIL0 + (lane & 3)) * LDA + lg * 4, LDA, rsrc, voff, wsoff,
+                                         KB * 1024, g, wsoff, KB * 1024);
+        const __amdgpu_buffer_rsrc_t o_rs = tip_rows_buffer(a.out + (size_t)win * T * a.ldo, T * a.ldo * 4);
 #pragma unroll
         for (int n = 0; n < NBW; ++n) {
-            const int col = (wave * NBW + n) * 16 + l15;
 #pragma unroll
             for (int r = 0; r < RBM; ++r)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[r][n]), o_rs,
+                                                       ((r * 16 + l15) * a.ldo + (wave * NBW + n) * 16 + lg * 4) * 4, 0, 0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = r * 16 + lg * 4 + e;
-                    if (row < T) out[(size_t)row * a.ldo + col] = acc[r][n][e];
-                }
-#pragma unroll
-            for (int rb = 0; rb < RBT; ++rb) {
-                const int row = TAIL0 + 4 * rb + lg;
-                const float t = tail_reduce(acct[rb][n], lg);
-                if (row < T) out[(size_t)row * a.ldo + col] = t;
-            }
+            for (int rb = 0; rb < RBT; ++rb)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tail_reduce(acct[rb][n], lg)), o_rs,
+                                                      ((TAIL0 + 4 * rb + lg) * a.ldo + (wave * NBW + n) * 16 + l15) * 4, 0, 0);
         }
         __syncthreads();   // the next window's rows overwrite the LDS image
     }
@@ -1921,7 +1918,7 @@ static hipError_t launch_win_gemm_t(const WinGemmArgs& a, int B, int T, int num_
 // N = 16 * 8 * nbw columns, K = 16 * kb (weights [N][K] in fragment order, zero padded); hipErrorInvalidValue for other shapes
 hipError_t launch_win_gemm(int N, int K, const WinGemmArgs& a, int B, int T, int num_cus, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (T < 1 || T > fz::TMAX || a.kvalid % 4 || a.kvalid < 4 || a.kvalid > K || a.lda % 4 || (long long)N * K * 4 != (long long)a.wbytes)
+    if (T < 1 || T > fz::TMAX || a.kvalid % 4 || a.kvalid < 4 || a.kvalid > K || a.lda % 4 || a.ldo % 4 || (reinterpret_cast<uintptr_t>(a.out) & 15) || (long long)T * a.ldo * 4 > 0x7fffffffLL || (long long)N * K * 4 != (long long)a.wbytes)
         return hipErrorInvalidValue;
     if (N == 256 && K == 512) return launch_win_gemm_t<2, 32>(a, B, T, num_cus, s);
     if (N == 512 && K == 160) return launch_win_gemm_t<4, 10>(a, B, T, num_cus, s);
