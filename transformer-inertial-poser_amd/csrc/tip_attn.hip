@@ -27,7 +27,12 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(const float* __restrict_
     const int b = bh / H, h = bh - b * H;
     const int D = H * DH, ld = 3 * D;
     const int l15 = lane & 15, lg = lane >> 4;
-    const float* base = qkv + (size_t)b * T * ld + h * DH;
+    // This window's q | k | v rows and output rows as buffers of T rows: rows past the window read 0 / are dropped by the range check
+    // (no branch around every load and store; the window index is wave-uniform but derived from threadIdx, hence the forced-uniform
+    // pointers).  Byte offsets inside a window stay far below 2^31 (T * 3D * 4).
+    const __amdgpu_buffer_rsrc_t qrs = tip_rows_buffer(qkv + (size_t)b * T * ld, T * ld * 4);
+    const __amdgpu_buffer_rsrc_t ors = tip_rows_buffer(out + (size_t)b * T * D, T * D * 4);
+    const int hoff = h * DH * 4;
     const int nb = (T + 15) >> 4;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -36,8 +41,7 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(const float* __restrict_
         f32x4 qf[KB];
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
-            qf[kb] = zero4;
-            if (q < T) qf[kb] = *reinterpret_cast<const f32x4*>(base + (size_t)q * ld + kb * 16 + lg * 4);
+            qf[kb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, q * ld * 4 + hoff + (kb * 16 + lg * 4) * 4, 0, 0));
         }
         // ---- S^T tiles: element (key jb*16 + 4*lg + r, query q) ---------------------------------------------------------
         f32x4 st[NBMAX];
@@ -49,8 +53,7 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(const float* __restrict_
                 const int key = jb * 16 + l15;
 #pragma unroll
                 for (int kb = 0; kb < KB; ++kb) {
-                    f32x4 kf = zero4;
-                    if (key < T) kf = *reinterpret_cast<const f32x4*>(base + (size_t)key * ld + D + kb * 16 + lg * 4);
+                    const f32x4 kf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, key * ld * 4 + hoff + (D + kb * 16 + lg * 4) * 4, 0, 0));
                     st[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.x, qf[kb].x, st[jb], 0, 0, 0);
                     st[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.y, qf[kb].y, st[jb], 0, 0, 0);
                     st[jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[kb].z, st[jb], 0, 0, 0);
@@ -101,11 +104,11 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(const float* __restrict_
                 const int k0 = jb * 16 + lg * 4;
 #pragma unroll
                 for (int cb = 0; cb < KB; ++cb) {
-                    const float* vp = base + (size_t)k0 * ld + 2 * D + cb * 16 + l15;
-                    const float v0 = k0 + 0 < T ? vp[0] : 0.f;
-                    const float v1 = k0 + 1 < T ? vp[(size_t)ld] : 0.f;
-                    const float v2 = k0 + 2 < T ? vp[(size_t)2 * ld] : 0.f;
-                    const float v3 = k0 + 3 < T ? vp[(size_t)3 * ld] : 0.f;
+                    const int vo = k0 * ld * 4 + hoff + (2 * D + cb * 16 + l15) * 4;
+                    const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qrs, vo, 0, 0));
+                    const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qrs, vo + ld * 4, 0, 0));
+                    const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qrs, vo + 2 * ld * 4, 0, 0));
+                    const float v3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(qrs, vo + 3 * ld * 4, 0, 0));
                     o[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jb][0], v0, o[cb], 0, 0, 0);
                     o[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jb][1], v1, o[cb], 0, 0, 0);
                     o[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(st[jb][2], v2, o[cb], 0, 0, 0);
@@ -118,11 +121,9 @@ __global__ __launch_bounds__(256) void mattn_fwd_kernel(const float* __restrict_
         for (int r = 0; r < 4; ++r) {
             const float ir = __shfl(inv, lg * 4 + r, 64);
             const int qq = ib * 16 + lg * 4 + r;
-            if (qq < T) {
-                float* op = out + ((size_t)b * T + qq) * D + h * DH + l15;
 #pragma unroll
-                for (int cb = 0; cb < KB; ++cb) op[cb * 16] = o[cb][r] * ir;
-            }
+            for (int cb = 0; cb < KB; ++cb)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o[cb][r] * ir), ors, qq * D * 4 + hoff + (cb * 16 + l15) * 4, 0, 0);
         }
     }
 }
