@@ -90,5 +90,5 @@ d=/tmp/prof_f16; rm -rf $d
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $d -- $BENCH --plan fused16 > "$OUT/bench_fused16_under_rocprof.json" 2> /dev/null)
 t=$(find $d -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python tools/kstats_table.py "$t" > "$OUT/kernel_medians_bench_fused16_B256_T40.txt"
 timeout 300 python bench.py --plan fused16 --no-cpu-baseline --no-extra --steps 300 --warmup 20 > "$OUT/bench_fused16_n1.json" 2> /dev/null
-for p in mfma4x4_probe hop_probe permlane_probe launch_probe ffn_split16_probe mfma_f64_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
+for p in mfma4x4_probe hop_probe permlane_probe launch_probe ffn_split16_probe mfma_f64_probe imul_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
 ls -la "$OUT"
