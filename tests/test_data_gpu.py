@@ -44,7 +44,7 @@ def test_window_dataset_matches_reference_sampling_and_slices():
     z = np.load(GOLD)
     IMU, SUM, S = (torch.tensor(z[k]).cuda() for k in ("IMU", "SUM", "S"))
     random.seed(99)
-    ds = tip_amd.data.TrainSubDataset(40, z["info"], IMU, S, IMU_sum=SUM)
+    ds = tip_amd.data.TrainSubDataset.from_arrays(40, z["info"], IMU, S, IMU_sum=SUM)
     assert len(ds) == int(z["n_windows"][0])
     x_imu, x_s, y = (t.cpu().numpy() for t in ds.batch(range(len(ds))))
     sums = np.stack([[np.nansum(a[k].astype(np.float64)) for a in (x_imu, x_s, y)] for k in range(len(ds))])
@@ -57,7 +57,7 @@ def test_window_dataset_matches_reference_sampling_and_slices():
     assert np.array_equal(a.cpu().numpy(), x_imu[5]) and a.shape == (40, 90) and b.shape == (40, 131) and c.shape == (40, 131)
     # without acc-sum features (training_data_loader.py:60 with_acc_sum=False)
     random.seed(99)
-    ds2 = tip_amd.data.TrainSubDataset(40, z["info"], IMU, S, with_acc_sum=False)
+    ds2 = tip_amd.data.TrainSubDataset.from_arrays(40, z["info"], IMU, S, with_acc_sum=False)
     xi2, _, _ = ds2.batch([0, 1, 2])
     assert xi2.shape == (3, 40, 72) and np.array_equal(xi2.cpu().numpy(), x_imu[:3, :, :72])
 
@@ -73,7 +73,7 @@ def test_large_sequence_against_oracle_and_training_handoff():
     assert np.abs(cmb.SUM.cpu().numpy() - b).max() < 2e-5      # sums of 40 terms around 1e1: a few float32 ulps
     assert np.abs(cmb.S.cpu().numpy() - cc).max() < TOL
     random.seed(1)
-    ds = tip_amd.data.TrainSubDataset(40, cmb.info, cmb.IMU, cmb.S, IMU_sum=cmb.SUM)
+    ds = tip_amd.data.TrainSubDataset.from_arrays(40, cmb.info, cmb.IMU, cmb.S, IMU_sum=cmb.SUM)
     x_imu, x_s, y = ds.batch(range(min(64, len(ds))))
     from test_host_cpu import make_model, load_synth
     from tip_amd import synth

@@ -237,14 +237,14 @@ def test_packed_image_split_fp16_section():
 
 def test_zero_edit_drop_in_import_path():
     """`from simple_transformer_with_state import TF_RNN_Past_State` (train_model.py:14) must resolve to our module
-    when the package directory is put first on PYTHONPATH."""
+    when the drop-in directory is put first on PYTHONPATH (the full recipe: tests/test_dropin_cpu.py)."""
     import subprocess
     import sys
     code = ("from simple_transformer_with_state import TF_RNN_Past_State as M; import inspect;"
             "m = M(72, 131, rnn_hid_size=64, tf_hid_size=32, tf_in_dim=32, n_heads=4, tf_layers=1, dropout=0.0,"
             "in_dropout=0.0, past_state_dropout=0.8, with_acc_sum=True);"
             "print(len(m.state_dict()), 'tip_amd' in inspect.getsourcefile(M) or 'inertial-poser_amd' in inspect.getsourcefile(M))")
-    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "transformer-inertial-poser_amd"))
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "transformer-inertial-poser_amd", "dropin"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd="/tmp")
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip().splitlines()[-1] == "20 True"

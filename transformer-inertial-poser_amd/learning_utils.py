@@ -15,7 +15,9 @@ fp32 CUDA(HIP) tensors only; there is no CPU path (TipLibraryError / TypeError o
 from __future__ import annotations
 
 import ctypes
+import random
 
+import numpy as np
 import torch
 
 from . import lib as _lib
@@ -116,3 +118,20 @@ def train_loss(y_pred: torch.Tensor, y: torch.Tensor, n_sbps: int = 5, with_jerk
     total, parts = _Loss.apply(y_pred, y, int(y_pred.size()[0]), int(y_pred.size()[1]), n_pose, 3, n_sbps,
                                Q | C | (J if with_jerk else 0))
     return (total, parts) if return_parts else total
+
+
+def set_seed(seed):
+    """learning_utils.py:81-85: seeds python `random` (TrainSubDataset's window sampling), numpy (the combiner's bias draw)
+    and torch's CPU and device generators (parameter init, dropout masks, train_model.py:172's input noise)."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+
+
+def top_k_logits(logits, k):
+    """learning_utils.py:88-92 (unused by the training / inference scripts; kept so `from learning_utils import *` is whole)."""
+    v, ix = torch.topk(logits, k)
+    out = logits.clone()
+    out[out < v[:, [-1]]] = -float('Inf')
+    return out

@@ -1,4 +1,5 @@
-"""Drop-in for the reference module of the same name: `from simple_transformer_with_state import TF_RNN_Past_State`.
+"""Drop-in for the reference module of the same name: `from simple_transformer_with_state import TF_RNN_Past_State`
+resolves here through dropin/simple_transformer_with_state.py.
 
 Mirrors the reference's module surface (/root/reference/simple_transformer_with_state.py):
   * constructor signature                                   (:9-17)
@@ -44,14 +45,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-try:
-    from . import lib as _lib
-except ImportError:  # imported as the top-level module `simple_transformer_with_state` (zero-edit drop-in:
-    # PYTHONPATH=<repo>/transformer-inertial-poser_amd ahead of the reference directory)
-    import os as _os
-    import sys as _sys
-    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
-    from tip_amd import lib as _lib
+from . import lib as _lib
 
 
 class _Leaf(nn.Module):
