@@ -438,12 +438,7 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
     try:
         sc = synth.SCALED
         torch.manual_seed(0)
-        os.environ["TIP_S16_GENERAL"] = "1"     # the image also carries the split-fp16 copies of the big linears (exploratory line below)
-        try:
-            ms_model = build_model(sc, 0, load=False).to(dev).eval()
-            ms_model._ensure_handle()
-        finally:
-            del os.environ["TIP_S16_GENERAL"]
+        ms_model = build_model(sc, 0, load=False).to(dev).eval()
         Bs, Ts = 512, 80
         s_imu, s_s = synth.make_inputs(sc, 64, Ts, seed=99)
         si = torch.tensor(s_imu).to(dev).repeat(Bs // 64, 1, 1)
@@ -469,6 +464,20 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
             ms_model.set_plan("auto")
         except Exception as e2:
             out["scaled_b512_t80"]["exploratory_general16"] = {"error": f"{type(e2).__name__}: {e2}"}
+        # -- configs[4] at its own batch on ONE GPU: B = 4096 as one call (the host runs it in chunks of at most tip_max_batch
+        #    windows: 32-bit buffer offsets) — the absolute single-GPU number next to the 512-window per-GPU share
+        try:
+            B4 = 4096
+            si4, ss4 = si.repeat(B4 // Bs, 1, 1), ss.repeat(B4 // Bs, 1, 1)
+            ms_model(si4, ss4)
+            ms4 = timed_loop(lambda: ms_model(si4, ss4), 2)
+            out["scaled_b4096_one_gpu"] = {"batch": B4, "T": Ts, "ms_per_step": ms4, "frames_per_s": B4 / (ms4 * 1e-3),
+                                           "chunk": int(ms_model.chunk_batch(Ts)), "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(sc, Ts, B4 / (ms4 * 1e-3)),
+                                           "tflops": B4 / (ms4 * 1e-3) * synth.flops_per_window(sc, Ts) / 1e12,
+                                           "vs_8x_the_512_share": ms4 / (8 * ms)}
+            del si4, ss4
+        except Exception as e2:
+            out["scaled_b4096_one_gpu"] = {"error": f"{type(e2).__name__}: {e2}"}
         del ms_model, si, ss
         torch.cuda.empty_cache()
     except Exception as e:

@@ -23,7 +23,12 @@
 extern "C" {
 #endif
 
-#define TIP_ABI_VERSION 1
+#define TIP_ABI_VERSION 2 /* 2: packed image without the exploratory split-fp16 section unless asked for (TIP_CREATE_S16, tip_create_ex);
+                             tip_max_batch; export list = this header (+ tip_hip_debug.h), everything else hidden */
+
+/* The library is built with -fvisibility=hidden: the functions declared here (and the measurement hooks of
+ * tip_hip_debug.h) are its whole dynamic symbol table (tests/test_host_cpu.py compares `nm -D` with the two headers). */
+#define TIP_API __attribute__((visibility("default")))
 
 typedef struct tip_handle tip_handle;
 typedef void* tip_stream_t; /* hipStream_t */
@@ -74,11 +79,11 @@ typedef enum tip_status {
 #define TIP_PLAN_FUSEDH  6 /* TIP_PLAN_FUSED with a hybrid row tiling: rows 0-31 on 16x16x4 MFMAs, rows 32-39 on 4x4x1 MFMAs fed by the
                               same weight fragments — no matrix-core work on the pad rows 40-47 outside the QKV projection.  No
                               inter-workgroup hand-off in the encoder.  Rows 0-31 bit-identical to TIP_PLAN_FUSED. */
-#define TIP_PLAN_FUSED16 7 /* EXPLORATORY, opt-in only (never AUTO's choice): TIP_PLAN_FUSED with every GEMM's fp32 operands emulated on the
+#define TIP_PLAN_FUSED16 7 /* EXPLORATORY, opt-in only (never AUTO's choice; needs TIP_OPT_PACK_SPLIT16 bit 0 set before packing): TIP_PLAN_FUSED with every GEMM's fp32 operands emulated on the
                               fp16 matrix cores — operands split hi + lo * 2^-11 (22 significant bits), three f16 MFMAs per product,
                               fp32 accumulation; attention core, LayerNorm, residual stream and epilogues in fp32 (csrc/tip_s16.hip) */
 #define TIP_PLAN_GENERAL16 8 /* EXPLORATORY, opt-in only: TIP_PLAN_GENERAL with the big linears (panel GEMM shapes) on split-fp16 operands as in
-                               TIP_PLAN_FUSED16; needs TIP_S16_GENERAL=1 in the environment at tip_create (the split weight copies double the
+                               TIP_PLAN_FUSED16; needs TIP_OPT_PACK_SPLIT16 bit 1 set before packing (the split weight copies double the
                                packed image of a big model, so they are not packed by default) */
 #define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);
                               AUTO picks it for B <= 64 */
@@ -98,38 +103,59 @@ typedef enum tip_status {
                                a full part); bit-identical results.  0 (default): separate launch.  Measured neutral to -1.2 us per
                                step; kept selectable.  Environment TIP_RNN_HEAD=1 makes 1 the default. */
 
+#define TIP_OPT_PACK_SPLIT16 6 /* which EXPLORATORY split-fp16 weight copies the packed image carries (default 0: none).  Bit 0
+                                 (TIP_PACK_SPLIT16_FUSED): the fused section's, for TIP_PLAN_FUSED16 (+15 MB for the paper configuration);
+                                 bit 1 (TIP_PACK_SPLIT16_GENERAL): the big linears', for TIP_PLAN_GENERAL16 (doubles a big model's image).
+                                 Changing it changes tip_packed_bytes() and the image layout and DETACHES the attached image
+                                 (tip_forward returns TIP_ERR_NOT_READY until an image packed under the new setting is attached).
+                                 The choice lives in the handle, not in the environment: ranks that exchange images (RCCL broadcast)
+                                 set the same value. */
+#define TIP_PACK_SPLIT16_FUSED   1
+#define TIP_PACK_SPLIT16_GENERAL 2
+#define TIP_OPT_AUTO_DEMOTE 7 /* 1 (default): hosts may answer the first TIP_ERR_HANDOFF of this handle by demoting it (TIP_OPT_DEMOTED)
+                                 and re-issuing the call; 0: they report the error.  A flag for the host layer (the library itself never
+                                 re-issues a call); the Python host honours it. */
+#define TIP_OPT_DEMOTED     8 /* 1: TIP_PLAN_AUTO and the automatic TIP_OPT_RNN_CLUSTER choose only kernels WITHOUT inter-workgroup hand-offs
+                                 (hybrid one-window / two-window encoder or the general plan, single-workgroup recurrence tiles): no
+                                 co-residency needed, a co-tenant costs throughput instead of frames.  Explicit plans / cluster sizes are
+                                 still honoured.  tip_forward only: the training step's recurrences always cooperate.  Default 0. */
+
 /* ---- lifetime: replaces TF_RNN_Past_State.__init__ (simple_transformer_with_state.py:9-54) ---------------- */
-int tip_abi_version(void);
-int tip_create(const tip_config* cfg, tip_handle** out);
-void tip_destroy(tip_handle* h);
-const char* tip_strerror(int status);
-const char* tip_last_hip_error(const tip_handle* h);
-int tip_set_option(tip_handle* h, int option, int value);
-int tip_get_option(const tip_handle* h, int option, int* value);
+TIP_API int tip_abi_version(void);
+TIP_API int tip_create(const tip_config* cfg, tip_handle** out);
+TIP_API void tip_destroy(tip_handle* h);
+TIP_API const char* tip_strerror(int status);
+TIP_API const char* tip_last_hip_error(const tip_handle* h);
+TIP_API int tip_set_option(tip_handle* h, int option, int value);
+TIP_API int tip_get_option(const tip_handle* h, int option, int* value);
 
 /* ---- parameters: replaces state_dict()/load_state_dict() (train_model.py:109-111,220-225;
  *      offline_testing_simple.py:96).  Tensor i is the i-th entry of the reference's state_dict(), same shape. */
-int tip_num_tensors(const tip_handle* h);
-int tip_tensor_info(const tip_handle* h, int i, const char** name, int* rows, int* cols /* 0 for 1-D */);
+TIP_API int tip_num_tensors(const tip_handle* h);
+TIP_API int tip_tensor_info(const tip_handle* h, int i, const char** name, int* rows, int* cols /* 0 for 1-D */);
 /* size of the packed weight image (padded / permuted / folded copy the kernels read) */
-int tip_packed_bytes(const tip_handle* h, size_t* bytes);
+TIP_API int tip_packed_bytes(const tip_handle* h, size_t* bytes);
 /* host: build the packed image from the n state-dict tensors (host pointers, fp32, reference layout).
  * Folds applied here: channel shuffle :88-89 into in_linear rows; root-velocity zeroing :75 into in_linear
  * columns; 1/sqrt(d_head) into W_q/b_q when exact; b_ih + b_hh; MFMA-fragment ordering of W_hh. */
-int tip_pack_weights(const tip_handle* h, const float* const* host_tensors, int n, void* packed_host_out, size_t bytes);
+TIP_API int tip_pack_weights(const tip_handle* h, const float* const* host_tensors, int n, void* packed_host_out, size_t bytes);
 /* device: point the handle at a packed image resident in HBM (caller-owned; e.g. the buffer every rank
  * receives from the one-time RCCL broadcast).  Must stay valid until the next attach / destroy. */
 /* tip_pack_weights on the GPU: `tensors` are DEVICE pointers (the live parameters), `packed_dev` a device buffer of
  * tip_packed_bytes(); asynchronous on `stream`.  Bit-identical image; microseconds instead of a host pack + 27 MB upload. */
-int tip_pack_weights_device(const tip_handle* h, const float* const* tensors, int n, void* packed_dev, size_t bytes,
+TIP_API int tip_pack_weights_device(const tip_handle* h, const float* const* tensors, int n, void* packed_dev, size_t bytes,
                             tip_stream_t stream);
-int tip_attach_packed(tip_handle* h, const void* packed_device, size_t bytes);
+TIP_API int tip_attach_packed(tip_handle* h, const void* packed_device, size_t bytes);
 
 /* ---- forward: replaces TF_RNN_Past_State.forward(x_imu, x_s) (simple_transformer_with_state.py:60-102) ---- */
-int tip_workspace_bytes(const tip_handle* h, int B, int T, size_t* bytes);
+TIP_API int tip_workspace_bytes(const tip_handle* h, int B, int T, size_t* bytes);
+/* largest batch one tip_forward (fp64 = 0) / tip_forward_f64 (fp64 = 1) call serves at window length T (32-bit buffer offsets
+ * and grid limits); beyond it the calls return TIP_ERR_UNSUPPORTED_CONFIG.  Windows are independent (:60-102 has no op across
+ * batch elements): a host runs a larger batch as chunks of at most this size. */
+TIP_API int tip_max_batch(const tip_handle* h, int T, int fp64, int* max_batch);
 /* x_imu [B,T,input_size_imu(+18)], x_s [B,T,size_s] (NaNs allowed, :65), y [B,T,size_s] (or [B,size_s] with
  * TIP_FWD_LAST_ROW_ONLY).  Inputs are not modified (:63-64).  keep_mask may be NULL. */
-int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
+TIP_API int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
                 const float* keep_mask, float keep_scale, void* workspace, size_t workspace_bytes,
                 tip_stream_t stream);
 
@@ -139,22 +165,22 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
  *      tip_tensor_info() order, RAW (nothing is packed, no tip_attach_packed needed); x_imu / x_s / keep_mask / y as in tip_forward
  *      but double; flags: TIP_FWD_LAST_ROW_ONLY; workspace of tip_forward_f64_bytes(), 256-byte aligned.  Any configuration and
  *      any T >= 1.  A debugging / verification path: layer-by-layer kernels, not tuned. */
-int tip_forward_f64_bytes(const tip_handle* h, int B, int T, size_t* bytes);
-int tip_forward_f64(tip_handle* h, const double* const* params, int n_params, const double* x_imu, const double* x_s, double* y,
+TIP_API int tip_forward_f64_bytes(const tip_handle* h, int B, int T, size_t* bytes);
+TIP_API int tip_forward_f64(tip_handle* h, const double* const* params, int n_params, const double* x_imu, const double* x_s, double* y,
                     int B, int T, int flags, const double* keep_mask, double keep_scale, void* workspace, size_t workspace_bytes,
                     tip_stream_t stream);
 
 /* ---- measurement ------------------------------------------------------------------------------------------ */
 /* number of tip_forward calls that launched HIP kernels since tip_create (lets tests prove the HIP path ran) */
-int tip_forward_count(const tip_handle* h, uint64_t* n);
+TIP_API int tip_forward_count(const tip_handle* h, uint64_t* n);
 /* after the stream is synchronised: per-stage totals accumulated since TIP_OPT_PROFILE was last set.
  * ms[i] = summed duration of stage names[i], launches[i] = event pairs summed.  Arrays of length `cap`;
  * returns the number of stages (<= cap) or a negative status. */
-int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches, int cap);
+TIP_API int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches, int cap);
 /* (synchronises the device) number of inter-workgroup hand-off waits that gave up since the library was loaded.
  * The cooperating kernels (RNN clusters) never spin forever; if a peer does not arrive within ~1 s they continue
  * and bump this counter: non-zero => the outputs of that launch are invalid.  Must be 0 in a healthy process. */
-int tip_spin_timeouts(unsigned* count);
+TIP_API int tip_spin_timeouts(unsigned* count);
 /* Hand-off failures are ERRORS, not numbers.  The cooperating plans (pair-split encoder, clustered / GEMV RNN) rely on
  * all their workgroups being resident at once: the launchers refuse a grid the runtime's occupancy query says cannot be
  * (hipErrorCooperativeLaunchTooLarge -> TIP_ERR_HIP), but another process or stream holding CUs can still starve a
@@ -165,10 +191,13 @@ int tip_spin_timeouts(unsigned* count);
  * TIP_ERR_HANDOFF or TIP_OK without synchronising (synchronise the stream first for a definitive answer about launches in
  * flight); tip_check(h, 1) also clears the word.  The GPU must be exclusively this process's for the cooperating plans to
  * run at speed; TIP_PLAN_FUSED / TIP_PLAN_GENERAL with TIP_OPT_RNN_CLUSTER = 1 need no co-residency at all.
- * Inside one process the library keeps the promise itself: tip_forward / tip_train_forward / tip_train_backward calls issued on
- * DIFFERENT streams (any handle) are serialised on the device (one event wait per stream switch), and a stream created with a CU
- * mask (hipExtStreamCreateWithCUMask) gets plan, grid and cluster sizes for the CUs its mask leaves. */
-int tip_check(tip_handle* h, int clear);
+ * Inside one process the library helps: tip_forward / tip_forward_f64 / tip_train_forward / tip_train_backward calls issued on
+ * DIFFERENT streams of the handle's device (any handle) are serialised on the device (one event wait per stream switch; streams
+ * are told apart by handle value, so a destroyed stream whose handle the runtime recycles counts as the same stream; calls on a
+ * CAPTURING stream are exempt — see the HIP-graph note below), and a stream created with a CU mask
+ * (hipExtStreamCreateWithCUMask) gets plan, grid and cluster sizes for the CUs its mask leaves.
+ * After a lost hand-off a host can keep going without co-residency: tip_check(h, 1), tip_set_option(h, TIP_OPT_DEMOTED, 1). */
+TIP_API int tip_check(tip_handle* h, int clear);
 
 /* ---- streaming front/back-end: the model-facing half of RTRunnerMin.step
  *      (real_time_runner_minimal.py:59-85 record_raw_imu / record_state_aa_and_c, :87-112 smooth_and_split_s_c,
@@ -189,12 +218,12 @@ int tip_check(tip_handle* h, int clear);
  *      cleared by the kernels at their end for T >= 2, so a replay never reads a previous replay's words; capture T = 1 launches of
  *      more than 64 windows only if they are not replayed.) */
 #define TIP_STREAM_FRAME_AUTO (-1)
-int tip_stream_state_bytes(int n_streams, size_t* bytes);
-int tip_stream_reset(void* state, const float* s_init /* [n,114] device */, int n_streams, tip_stream_t stream);
-int tip_stream_window_len(int frame_idx); /* 0 while the 11-tap smoother primes (frames 0..4), then 1..40 */
-int tip_stream_ingest(void* state, const float* raw_imu, int n_streams, int frame_idx, float* x_imu, float* x_s,
+TIP_API int tip_stream_state_bytes(int n_streams, size_t* bytes);
+TIP_API int tip_stream_reset(void* state, const float* s_init /* [n,114] device */, int n_streams, tip_stream_t stream);
+TIP_API int tip_stream_window_len(int frame_idx); /* 0 while the 11-tap smoother primes (frames 0..4), then 1..40 */
+TIP_API int tip_stream_ingest(void* state, const float* raw_imu, int n_streams, int frame_idx, float* x_imu, float* x_s,
                       tip_stream_t stream);
-int tip_stream_consume(void* state, const float* y_last, int n_streams, int call_idx, float* s_rest, float* c_t,
+TIP_API int tip_stream_consume(void* state, const float* y_last, int n_streams, int call_idx, float* s_rest, float* c_t,
                        tip_stream_t stream);
 
 /* ---- training step: the model call of train_model.py:171-196 ---------------------
@@ -216,7 +245,7 @@ int tip_stream_consume(void* state, const float* y_last, int n_streams, int call
  *   scratch   backward workspace (scratch_bytes); grads = one flat buffer, tensors in tip_tensor_info() order.
  * Supported: with_rnn, rnn_hid_size 512, tf_in_dim 256/512/1024, head width 16/32/64, T <= 128 — else
  * TIP_ERR_UNSUPPORTED_CONFIG (the Python module then differentiates its torch-op composite instead). */
-int tip_train_bytes(const tip_handle* h, int B, int T, size_t* saved_bytes, size_t* scratch_bytes);
+TIP_API int tip_train_bytes(const tip_handle* h, int B, int T, size_t* saved_bytes, size_t* scratch_bytes);
 /* where one stashed activation of encoder layer `layer` lives inside `saved` (float offset, float count): */
 #define TIP_SAVED_QKV  0 /* [M,3D] in-projection output (q | k | v)                                   */
 #define TIP_SAVED_ATT  1 /* [M,D]  attention output before out_proj                                    */
@@ -224,11 +253,11 @@ int tip_train_bytes(const tip_handle* h, int B, int T, size_t* saved_bytes, size
 #define TIP_SAVED_HID  3 /* [M,F]  linear1 output after ReLU and dropout (> 0 exactly where the unit's gate is open) */
 #define TIP_SAVED_XOUT 4 /* [M,D]  layer output (LayerNorm2)                                            */
 #define TIP_SAVED_HALL 5 /* [M,R]  RNN states h_t (layer argument ignored but must be valid)           */
-int tip_train_saved_view(const tip_handle* h, int B, int T, int what, int layer, size_t* float_offset, size_t* floats);
-int tip_train_forward(tip_handle* h, const float* const* params, int n_params, const float* x_imu, const float* x_s,
+TIP_API int tip_train_saved_view(const tip_handle* h, int B, int T, int what, int layer, size_t* float_offset, size_t* floats);
+TIP_API int tip_train_forward(tip_handle* h, const float* const* params, int n_params, const float* x_imu, const float* x_s,
                       const float* keep_mask, float keep_scale, float p_drop, unsigned long long seed, float* y, void* saved,
                       size_t saved_bytes, int B, int T, tip_stream_t stream);
-int tip_train_backward(tip_handle* h, const float* const* params, int n_params, const float* dy, const void* saved,
+TIP_API int tip_train_backward(tip_handle* h, const float* const* params, int n_params, const float* dy, const void* saved,
                        size_t saved_bytes, void* scratch, size_t scratch_bytes, float* grads, size_t grads_floats, float p_drop,
                        unsigned long long seed, int B, int T, tip_stream_t stream);
 
@@ -241,12 +270,12 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
  * tip_gather_windows replaces TrainSubDataset's window slicing (training_data_loader.py:53-58,72-86): for each sampled
  *   end frame t_idx[i] (device int64, seq_length <= t < n_frames): x_imu[i] = [IMU[t-T:t] | SUM[t-T:t]] ([T,90]; [T,72]
  *   when sum_c is NULL), x_s[i] = S[t-T:t], y[i] = S[t-T+1:t+1]. */
-int tip_combine_frames(int L_imu, int L_s);
-int tip_combine_scratch_bytes(int L_imu, int L_s, size_t* bytes);
-int tip_combine_sequence(const double* imu, const double* s, const double* c, int L_imu, int L_s, const double* bias,
+TIP_API int tip_combine_frames(int L_imu, int L_s);
+TIP_API int tip_combine_scratch_bytes(int L_imu, int L_s, size_t* bytes);
+TIP_API int tip_combine_sequence(const double* imu, const double* s, const double* c, int L_imu, int L_s, const double* bias,
                          int nan_root_vel, float* imu_out, float* sum_out, float* s_out, void* scratch, size_t scratch_bytes,
                          tip_stream_t stream);
-int tip_gather_windows(const float* imu_c, const float* sum_c, const float* s_c, long long n_frames, const long long* t_idx,
+TIP_API int tip_gather_windows(const float* imu_c, const float* sum_c, const float* s_c, long long n_frames, const long long* t_idx,
                        int n, int T, float* x_imu, float* x_s, float* y, tip_stream_t stream);
 
 /* ---- training losses and their gradient ---------------------------------------------------
@@ -264,10 +293,10 @@ int tip_gather_windows(const float* imu_c, const float* sum_c, const float* s_c,
 #define TIP_LOSS_C 2 /* loss_constr_multi (learning_utils.py:13-35) */
 #define TIP_LOSS_J 4 /* loss_jerk         (learning_utils.py:38-47) */
 #define TIP_LOSS_STATS 16
-int tip_loss_ws_bytes(int B, int T, size_t* bytes);
-int tip_loss_forward(const float* pred, long long ld_pred, const float* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
+TIP_API int tip_loss_ws_bytes(int B, int T, size_t* bytes);
+TIP_API int tip_loss_forward(const float* pred, long long ld_pred, const float* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
                      int n_sbp, int terms, float* stats, void* ws, size_t ws_bytes, tip_stream_t stream);
-int tip_loss_backward(const float* pred, long long ld_pred, const float* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
+TIP_API int tip_loss_backward(const float* pred, long long ld_pred, const float* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
                       int n_sbp, int terms, const float* stats, const float* gout, float* dpred, long long ld_dpred,
                       tip_stream_t stream);
 

@@ -1,0 +1,127 @@
+"""GPU: self-demotion after a lost inter-workgroup hand-off (include/tip_hip.h: TIP_OPT_AUTO_DEMOTE / TIP_OPT_DEMOTED).
+
+The default plans launch cooperating kernels; a co-tenant holding CUs can starve a partner workgroup.  The launch that loses a
+hand-off yields NaN rows and a sticky flag (tests/test_handoff_fault_gpu.py).  What happens NEXT is tested here: the first
+TipHandoffError of a handle makes the Python host clear the flag, switch the handle to the plans that need no co-resident
+workgroups (hybrid one-window encoder + single-workgroup recurrence tiles: `fusedh` + `rnn_cluster=1`), re-issue the call and warn
+once — with the fault STILL injected, every later forward is finite and bit-identical to the explicit non-cooperating plan."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from tip_amd import synth, streaming
+from tip_amd import lib as tlib
+from oracle import oracle
+from test_host_cpu import make_model, load_synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _model():
+    m = make_model(synth.PAPER)
+    w = load_synth(m, synth.PAPER, 0)
+    return m.cuda().eval(), w
+
+
+@pytest.mark.handoff_fault
+@pytest.mark.parametrize("B,bits", [(40, 2), (3, 4), (300, 2)])   # clustered recurrence; latency plan's GEMV recurrence; two rounds
+def test_lost_handoff_demotes_and_the_next_call_runs(B, bits):
+    m, w = _model()
+    h = m._ensure_handle()
+    x_imu, x_s = synth.make_inputs(synth.PAPER, B, 40, seed=9)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    with torch.no_grad():
+        ref_auto = m(xi, xs).cpu().numpy()
+        # the explicit non-cooperating plan AUTO falls back to: hybrid one-window encoder, or two windows per workgroup when that
+        # needs fewer rounds (B = 300 on 256 CUs), with single-workgroup recurrence tiles
+        m.set_plan("fused2" if B == 300 else "fusedh", rnn_cluster=1)
+        ref_safe = m(xi, xs).cpu().numpy()
+        m.set_plan("auto")
+        yo = oracle.forward(synth.PAPER, w, x_imu[:2], x_s[:2], dtype=np.float64)
+        assert np.abs(ref_safe[:2] - yo).max() < 2e-5 and np.abs(ref_auto - ref_safe).max() < 5e-6
+        h.set_option(tlib.TIP_OPT_FAULT_INJECT, bits)         # from here on every cooperating launch loses a hand-off
+        y_bad = m(xi, xs)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(y_bad).any()) and not m.is_demoted()
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            y1 = m(xi, xs)                                    # entry check trips -> demote -> this call runs
+            torch.cuda.synchronize()
+        assert any("lost an inter-workgroup hand-off" in str(r.message) for r in rec)
+        assert m.is_demoted() and m.demotions == 1
+        assert np.array_equal(y1.cpu().numpy(), ref_safe), "the demoted AUTO plan is not the explicit fusedh + cluster-1 plan"
+        for _ in range(3):                                    # the fault is still injected: nothing cooperating runs any more
+            assert np.array_equal(m(xi, xs).cpu().numpy(), ref_safe)
+        assert np.array_equal(m.forward_last(xi, xs).cpu().numpy(), ref_safe[:, -1])
+        m.check_handoffs()                                    # clean
+        # back to the default plans once the GPU is ours again
+        h.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)
+        m.undemote()
+        assert np.array_equal(m(xi, xs).cpu().numpy(), ref_auto)
+        m.check_handoffs()
+
+
+@pytest.mark.handoff_fault
+def test_auto_demote_off_reports_the_error():
+    m, _ = _model()
+    h = m._ensure_handle()
+    h.set_option(tlib.TIP_OPT_AUTO_DEMOTE, 0)
+    x_imu, x_s = synth.make_inputs(synth.PAPER, 40, 40, seed=9)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    with torch.no_grad():
+        m(xi, xs)
+        h.set_option(tlib.TIP_OPT_FAULT_INJECT, 2)
+        m(xi, xs)
+        torch.cuda.synchronize()
+        h.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)
+        with pytest.raises(tlib.TipHandoffError):
+            m(xi, xs)
+        assert not m.is_demoted()
+        h.check_clear()
+        assert bool(torch.isfinite(m(xi, xs)).all())
+
+
+@pytest.mark.handoff_fault
+def test_graph_mode_streaming_engine_polls_the_handoff_word():
+    """a HIP-graph replay never re-enters tip_forward, so its entry check cannot report a lost hand-off.  The engine
+    polls the pinned word before every replay: the frame after the lost one raises, the engine is re-primed and the handle
+    demoted, and the stream then runs on (re-captured under the non-cooperating plan) with finite outputs."""
+    m, _ = _model()
+    h = m._ensure_handle()
+    n = 2
+    rng = np.random.RandomState(3)
+    s_init = torch.zeros(n, 114)
+    eng = streaming.StreamingEngine(m, s_init, use_graph=True)
+
+    def frame():
+        R = np.tile(np.eye(3).reshape(-1), (n, 6)).astype(np.float32)
+        acc = rng.randn(n, 18).astype(np.float32)
+        return torch.tensor(np.concatenate([R, acc], axis=1)).cuda()
+
+    for _ in range(50):                                        # prime + capture + a few replays
+        out = eng.step(frame())
+    torch.cuda.synchronize()
+    assert eng._graph is not None and bool(torch.isfinite(out["y_last"]).all())
+    ws_ptr = eng._graph_refs[0].data_ptr()
+    m.release_buffers()                                        # the module's evictable buffers are not what the graph points at
+    out = eng.step(frame())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out["y_last"]).all()) and eng._graph_refs[0].data_ptr() == ws_ptr
+    # a launch of this handle loses a hand-off (kernel arguments of the captured graph are frozen, so the fault is injected
+    # through a direct call on the same handle: the word the replays would set is the same word)
+    x_imu, x_s = synth.make_inputs(synth.PAPER, n, 40, seed=2)
+    h.set_option(tlib.TIP_OPT_FAULT_INJECT, 4)                # latency plan's GEMV recurrence (B = 2)
+    with torch.no_grad():
+        m.forward_last(torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda())
+    torch.cuda.synchronize()
+    with pytest.raises(tlib.TipHandoffError):
+        eng.step(frame())                                      # the poll before the replay
+    assert eng.frame == 0 and eng._graph is None and m.is_demoted()
+    for _ in range(60):                                        # re-primed, demoted, fault still injected: runs clean
+        out = eng.step(frame())
+    torch.cuda.synchronize()
+    assert out is not None and bool(torch.isfinite(out["y_last"]).all()) and eng._graph is not None
+    m.check_handoffs()
+    h.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)

@@ -83,17 +83,13 @@ def test_fused16_keep_mask_golden(golden):
 
 
 def _model_s16_general(cfg, seed):
-    """A model whose packed image carries the split-fp16 copies of the general plan's big linears (TIP_S16_GENERAL=1 is read at
-    handle creation)."""
-    import os
-    os.environ["TIP_S16_GENERAL"] = "1"
-    try:
-        m = make_model(cfg)
-        w = load_synth(m, cfg, seed)
-        m = m.cuda().eval()
-        m._ensure_handle()
-    finally:
-        del os.environ["TIP_S16_GENERAL"]
+    """A model whose packed image carries the split-fp16 copies of the general plan's big linears (set_plan("general16") sets
+    TIP_OPT_PACK_SPLIT16 bit 1 on the handle; the tests switch plans afterwards without losing the copies)."""
+    m = make_model(cfg)
+    w = load_synth(m, cfg, seed)
+    m = m.cuda().eval()
+    m.set_plan("general16")
+    m.set_plan("auto")
     return m, w
 
 

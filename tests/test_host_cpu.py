@@ -80,13 +80,55 @@ def test_inference_on_cpu_fails_loudly():
 
 
 def test_c_abi_exports_every_declared_symbol():
+    """The dynamic symbol table of libtip_hip.so IS the two headers: include/tip_hip.h (the drop-in boundary) and
+    include/tip_hip_debug.h (measurement hooks) — nothing else is visible (-fvisibility=hidden + csrc/tip_exports.map)."""
+    import subprocess
     hdr = open(os.path.join(ROOT, "include", "tip_hip.h")).read()
     declared = set(re.findall(r"\b(tip_[a-z0-9_]+)\s*\(", hdr)) - {"tip_stream_t"}
     assert declared == set(tlib.EXPORTS), declared ^ set(tlib.EXPORTS)
+    dbg = set(re.findall(r"\b(tip_debug_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "tip_hip_debug.h")).read()))
+    assert len(dbg) == 12
     lib = ctypes.CDLL(tlib.LIB_PATH)
-    for name in declared:
+    for name in declared | dbg:
         assert hasattr(lib, name), name
-    assert tlib.load().tip_abi_version() == 1
+    out = subprocess.run(["nm", "-D", "--defined-only", tlib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported == declared | dbg, exported ^ (declared | dbg)
+    assert tlib.load().tip_abi_version() == tlib.TIP_ABI_VERSION == 2
+    assert int(re.search(r"#define TIP_ABI_VERSION (\d+)", hdr).group(1)) == 2
+
+
+def test_max_batch_and_pack_options_without_a_gpu():
+    """ABI 2: tip_max_batch (the host chunks by the library's own limit), TIP_OPT_PACK_SPLIT16 (the exploratory split-fp16
+    sections are not in the image unless asked for; the choice lives in the handle), TIP_OPT_AUTO_DEMOTE / TIP_OPT_DEMOTED."""
+    m = make_model(synth.PAPER)
+    h = m._ensure_handle()
+    assert h.max_batch(40) == (2 ** 31 - 1) // (4 * 1024 * 40) == 13107          # widest row: the 1024-wide FFN hidden
+    assert h.max_batch(40, fp64=True) == min((2 ** 31 - 1) // (1024 * 40), 65535 * 64 // 40)
+    assert h.max_batch(4096) == (2 ** 31 - 1) // (4 * 1024 * 4096)
+    with pytest.raises(tlib.TipStatusError):
+        h.max_batch(0)
+    hs = make_model(synth.SCALED)._ensure_handle()
+    assert hs.max_batch(80) == (2 ** 31 - 1) // (4 * 4096 * 80) == 1638            # BASELINE config 5 (B = 4096) runs as >= 3 chunks
+    base = h.packed_bytes()
+    assert h.get_option(tlib.TIP_OPT_PACK_SPLIT16) == 0
+    h.set_option(tlib.TIP_OPT_PACK_SPLIT16, tlib.TIP_PACK_SPLIT16_FUSED)
+    assert h.packed_bytes() == base + 3352320 * 4                                    # + the fused section's split copy
+    h.set_option(tlib.TIP_OPT_PACK_SPLIT16, 0)
+    assert h.packed_bytes() == base
+    b0 = hs.packed_bytes()
+    hs.set_option(tlib.TIP_OPT_PACK_SPLIT16, tlib.TIP_PACK_SPLIT16_GENERAL)
+    assert hs.packed_bytes() > b0 + 12 * (3 * 1024 * 1024 + 1024 * 1024 + 2 * 4096 * 1024) * 4 * 0.99
+    with pytest.raises(tlib.TipStatusError):
+        hs.set_option(tlib.TIP_OPT_PACK_SPLIT16, 4)
+    assert h.get_option(tlib.TIP_OPT_AUTO_DEMOTE) == 1 and h.get_option(tlib.TIP_OPT_DEMOTED) == 0
+    h.set_option(tlib.TIP_OPT_DEMOTED, 1)
+    assert m.is_demoted()
+    m.undemote()
+    assert not m.is_demoted()
+    # set_plan("fused16") asks for the section and invalidates the attached image
+    m.set_plan("fused16")
+    assert h.get_option(tlib.TIP_OPT_PACK_SPLIT16) == tlib.TIP_PACK_SPLIT16_FUSED and m._packed_dev is None
 
 
 def test_handle_table_status_and_errors():
@@ -204,7 +246,10 @@ def test_packed_image_split_fp16_section():
     cfg = synth.PAPER
     m = make_model(cfg)
     load_synth(m, cfg, 0)
+    plain = m.pack_host().numpy()
+    m.set_plan("fused16")                               # TIP_OPT_PACK_SPLIT16 bit 0: the image now carries the split copy
     img = m.pack_host().numpy()
+    assert img.size == plain.size + 3352320 * 4 and np.array_equal(img[:plain.size], plain)
     f32 = img.view(np.float32)
     NF = 3352320                                        # fused_packed_floats of the paper configuration (64-float aligned)
     assert f32.size >= 2 * NF

@@ -52,7 +52,7 @@ void build_layout(tip_handle* h) {
     Carver c;
     PackedLayout& L = h->lay;
     L.in_lin = carve_linear(c, d.D, d.In);
-    L.layers.resize(d.L);
+    L.layers.assign(d.L, PackedLayer{});
     for (int l = 0; l < d.L; ++l) {
         PackedLayer& pl = L.layers[l];
         pl.qkv = carve_linear(c, 3 * d.D, d.D);
@@ -67,8 +67,7 @@ void build_layout(tip_handle* h) {
         for (PackedLinear* p : {&pl.qkv, &pl.out, &pl.ff1, &pl.ff2})
             if (pgemm_shape_ok(1 << 20, p->N, p->K)) p->f_off = c.take((size_t)p->N * p->K);
         // exploratory TIP_PLAN_GENERAL16: split-fp16 copies of the same matrices, only on request (they double a big model's image)
-        const bool s16_general = getenv("TIP_S16_GENERAL") && getenv("TIP_S16_GENERAL")[0] == 0x31;   // read at every tip_create
-        if (s16_general)
+        if (h->pack_split16 & TIP_PACK_SPLIT16_GENERAL)
             for (PackedLinear* p : {&pl.qkv, &pl.out, &pl.ff1, &pl.ff2})
                 if (p->f_off && pgemm16_shape_ok(1 << 20, p->N, p->K)) p->s_off = c.take((size_t)p->N * p->K);
     }
@@ -85,8 +84,9 @@ void build_layout(tip_handle* h) {
     }
     L.fused_floats = fused_packed_floats(d);
     L.fused_off = c.take(L.fused_floats);
-    L.s16_floats = s16_packed_floats(d);
-    L.s16_off = c.take(L.s16_floats);
+    // exploratory TIP_PLAN_FUSED16: split-fp16 copy of the fused section, only on request (TIP_OPT_PACK_SPLIT16)
+    L.s16_floats = (h->pack_split16 & TIP_PACK_SPLIT16_FUSED) ? s16_packed_floats(d) : 0;
+    L.s16_off = L.s16_floats ? c.take(L.s16_floats) : 0;
     L.total_floats = c.off;
 }
 
@@ -227,17 +227,25 @@ struct DevSerialState {
 DevSerialState g_serial[kMaxDevices];
 }  // namespace
 
-CoopSerial::CoopSerial(hipStream_t s) : dev(tip_cur_device()), stream(s), capturing(stream_is_capturing(s)), status(hipSuccess) {
+CoopSerial::CoopSerial(int device, hipStream_t s)
+    : dev(device >= 0 && device < kMaxDevices ? device : tip_cur_device()), stream(s), capturing(stream_is_capturing(s)), status(hipSuccess) {
     DevSerialState& st = g_serial[dev];
     st.mu.lock();
     if (capturing) return;   // see stream_is_capturing (tip_internal.h)
     if (st.have && st.last != s) {
-        if (!st.multi) {
-            // first stream switch on this device: there is no event behind the previous forward yet — drain the device once
-            status = hipDeviceSynchronize();
-            if (status == hipSuccess) status = hipEventCreateWithFlags(&st.ev, hipEventDisableTiming);
+        if (!st.ev) status = hipEventCreateWithFlags(&st.ev, hipEventDisableTiming);
+        if (status == hipSuccess && !st.multi) {
+            // first stream switch on this device: put an event behind the previous stream's work now (nothing was recorded while
+            // the process used one stream).  No device-wide drain: hipDeviceSynchronize fails — and invalidates the capture —
+            // when any other stream is mid-capture.  If the previous stream no longer exists, its handle is dead: drain instead.
+            if (hipEventRecord(st.ev, st.last) != hipSuccess) {
+                (void)hipGetLastError();
+                status = hipDeviceSynchronize();
+            } else {
+                status = hipStreamWaitEvent(s, st.ev, 0);
+            }
             if (status == hipSuccess) st.multi = true;
-        } else {
+        } else if (status == hipSuccess) {
             status = hipStreamWaitEvent(s, st.ev, 0);
         }
     }
@@ -364,6 +372,23 @@ int tip_set_option(tip_handle* h, int option, int value) {
             if (value < 0 || value > 1) return TIP_ERR_INVALID_ARG;
             h->fuse_head = value;
             return TIP_OK;
+        case TIP_OPT_PACK_SPLIT16:
+            if (value < 0 || value > (TIP_PACK_SPLIT16_FUSED | TIP_PACK_SPLIT16_GENERAL)) return TIP_ERR_INVALID_ARG;
+            if (value != h->pack_split16) {
+                // the layout of the packed image changes: whatever was attached no longer matches it
+                h->pack_split16 = value;
+                build_layout(h);
+                h->packed_dev = nullptr;
+            }
+            return TIP_OK;
+        case TIP_OPT_AUTO_DEMOTE:
+            if (value < 0 || value > 1) return TIP_ERR_INVALID_ARG;
+            h->auto_demote = value;
+            return TIP_OK;
+        case TIP_OPT_DEMOTED:
+            if (value < 0 || value > 1) return TIP_ERR_INVALID_ARG;
+            h->demoted = value;
+            return TIP_OK;
         default: return TIP_ERR_INVALID_ARG;
     }
 }
@@ -384,6 +409,9 @@ int tip_get_option(const tip_handle* h, int option, int* value) {
         case TIP_OPT_RNN_CLUSTER: *value = h->rnn_cluster; return TIP_OK;
         case TIP_OPT_FAULT_INJECT: *value = h->fault_inject; return TIP_OK;
         case TIP_OPT_FUSE_HEAD: *value = h->fuse_head; return TIP_OK;
+        case TIP_OPT_PACK_SPLIT16: *value = h->pack_split16; return TIP_OK;
+        case TIP_OPT_AUTO_DEMOTE: *value = h->auto_demote; return TIP_OK;
+        case TIP_OPT_DEMOTED: *value = h->demoted; return TIP_OK;
         default: return TIP_ERR_INVALID_ARG;
     }
 }
@@ -597,6 +625,25 @@ int tip_workspace_bytes(const tip_handle* h, int B, int T, size_t* bytes) {
     return TIP_OK;
 }
 
+int tip_max_batch(const tip_handle* h, int T, int fp64, int* max_batch) {
+    if (!h || !max_batch || T < 1) return TIP_ERR_INVALID_ARG;
+    const Dims& d = h->d;
+    long long m;
+    if (fp64) {
+        // tip_forward_f64: element offsets of the widest activation and of the attention grid in 32 bits; 64-row GEMM tiles on grid.y
+        const long long widest = 3 * d.D > d.F ? 3 * d.D : d.F;
+        m = 0x7fffffffLL / (widest * T);
+        m = std::min(m, 0x7fffffffLL / ((long long)T * d.H));
+        m = std::min(m, 65535LL * 64 / T);
+    } else {
+        // tip_forward: byte offsets of the widest activation row block through 32-bit buffer descriptors
+        const long long widest = std::max(std::max(3 * d.D, d.F), std::max(d.R, d.InPad));
+        m = 0x7fffffffLL / (4 * widest * T);
+    }
+    *max_batch = (int)std::min<long long>(m, 0x7fffffff);
+    return TIP_OK;
+}
+
 int tip_forward_count(const tip_handle* h, uint64_t* n) {
     if (!h || !n) return TIP_ERR_INVALID_ARG;
     *n = h->forward_count;
@@ -654,7 +701,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         return TIP_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int cus = effective_cus(h->num_cus, s);   // the stream's CU mask counts, not the device's CU total
-    CoopSerial serial(s);   // forwards of different streams do not overlap on the device (cooperating kernels)
+    CoopSerial serial(h->device, s);   // forwards of different streams do not overlap on the device (cooperating kernels)
     if (serial.status != hipSuccess) return fail_hip(h, serial.status, "stream serialisation");
     const float* P = h->packed_dev;
     const PackedLayout& L = h->lay;
@@ -678,7 +725,8 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
 
     int plan = h->plan;
     if (plan == TIP_PLAN_AUTO) {
-        if (latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;   // <= 64 streams: spread each window over many CUs (0.65 vs 0.86 ms at B = 64)
+        // (a demoted handle — TIP_OPT_DEMOTED, after a lost hand-off — takes no cooperating kernel: the latency plan's GEMV recurrence is one)
+        if (!h->demoted && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;   // <= 64 streams: spread each window over many CUs (0.65 vs 0.86 ms at B = 64)
         else plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
     }
     if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO) {
@@ -704,7 +752,9 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     bool rnn_done = false;
     bool hall_armed = false;
     int rnn_cluster = h->rnn_cluster;
-    if (rnn_cluster == 0) {
+    if (rnn_cluster == 0 && h->demoted) {
+        rnn_cluster = 1;   // one workgroup per 16-window tile: no inter-workgroup hand-off
+    } else if (rnn_cluster == 0) {
         // auto: spread one 16-window tile over as many CUs as the tile count leaves idle
         const int ntiles = (B + kRnnTile - 1) / kRnnTile;
         rnn_cluster = 16;

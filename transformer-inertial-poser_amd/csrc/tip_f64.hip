@@ -256,7 +256,8 @@ int tip_forward_f64(tip_handle* h, const double* const* params, int n_params, co
     if (!x_imu || !x_s || !y || !workspace) return TIP_ERR_INVALID_ARG;
     const Dims& d = h->d;
     const long long M = (long long)B * T;
-    if (M * (long long)(3 * d.D > d.F ? 3 * d.D : d.F) > 0x7fffffffLL || (long long)B * T * d.H > 0x7fffffffLL) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (M * (long long)(3 * d.D > d.F ? 3 * d.D : d.F) > 0x7fffffffLL || (long long)B * T * d.H > 0x7fffffffLL || M > 65535LL * f64::TM)
+        return TIP_ERR_UNSUPPORTED_CONFIG;   // tip_max_batch(h, T, 1, &b) gives the largest B served
     const f64::Layout L = f64::layout(d, B, T);
     if (reinterpret_cast<uintptr_t>(workspace) % 256 || workspace_bytes < L.total * sizeof(double)) return TIP_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -265,6 +266,10 @@ int tip_forward_f64(tip_handle* h, const double* const* params, int n_params, co
         h->last_hip_error = std::string(what) + ": " + hipGetErrorString(e);
         return (int)TIP_ERR_HIP;
     };
+    // no cooperating kernel here, but these launches can hold CUs while a cooperating fp32 forward of another stream needs them
+    // all: same cross-stream guard as tip_forward
+    CoopSerial serial(h->device, s);
+    if (serial.status != hipSuccess) return fail(serial.status, "stream serialisation");
 #define TF(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_, what); } while (0)
     // state-dict order (simple_transformer_with_state.py:20-46): in_linear W, b; per layer in_proj W, b, out_proj W, b, linear1 W, b,
     // linear2 W, b, norm1 g, b, norm2 g, b; rnn W_ih, W_hh, b_ih, b_hh; linear W, b

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/tip_hip.h"
+#include "../../include/tip_hip_debug.h"
 
 namespace tip {
 
@@ -97,7 +98,7 @@ struct PackedLinear {
     size_t b_off;
     int N, K, Npad, Kpad;
     size_t f_off = 0;   // the same weight in 16x16x4 B-fragment order (+ tail padding) for launch_pgemm; 0 = not packed
-    size_t s_off = 0;   // ... and as split fp16 [N/16][K/32][hi | lo][64][8] for launch_pgemm16 (TIP_S16_GENERAL=1 only); 0 = not packed
+    size_t s_off = 0;   // ... and as split fp16 [N/16][K/32][hi | lo][64][8] for launch_pgemm16 (TIP_OPT_PACK_SPLIT16 bit 2 only); 0 = not packed
 };
 
 struct PackedLayer {
@@ -195,9 +196,10 @@ struct PerDeviceInt {
 // the latency plan's GEMV cluster, the opt-in pair-split encoder) whose members must all be resident at once; check_coresident
 // checks one launch against an EMPTY GPU, so two forwards in flight on two streams could each hold half of the CUs and starve
 // the other's partners (a ~1 s spin, NaN poison, TIP_ERR_HANDOFF).  Every entry point that launches such kernels brackets its
-// launches with this guard: the first time a second stream shows up on a device the device is drained once, from then on the
-// new stream waits on an event recorded behind the previous forward (one hipEventRecord per forward, only in processes that
-// really use several streams).  A forward fills the GPU by itself: nothing is lost by not overlapping two of them.
+// launches with this guard: the first time a second stream shows up on a device an event is recorded behind the previous
+// stream's work and the new stream waits on it; from then on every forward records the event and a stream switch waits on it
+// (one hipEventRecord per forward, only in processes that really use several streams).  Streams are told apart by their handle
+// value: a destroyed stream whose handle the runtime recycles counts as the same stream.  A forward fills the GPU by itself: nothing is lost by not overlapping two of them.
 // A stream that is being CAPTURED into a HIP graph (hipStreamBeginCapture: the streaming engine's graph mode, or any caller's) is
 // left alone: an event recorded inside a capture cannot order work outside it.  A captured forward is therefore not serialised
 // against other streams by the library — replay the graph on the stream the other forwards use, or when none is in flight.
@@ -215,7 +217,7 @@ struct CoopSerial {
     hipStream_t stream;
     bool capturing;
     hipError_t status;      // hipSuccess, or what the wait / drain returned (the caller reports it)
-    explicit CoopSerial(hipStream_t s);
+    CoopSerial(int device, hipStream_t s);   // device = the handle's (tip_handle::device), not the thread's current one
     ~CoopSerial();
     CoopSerial(const CoopSerial&) = delete;
     CoopSerial& operator=(const CoopSerial&) = delete;
@@ -271,6 +273,9 @@ struct tip_handle {
     unsigned* err_dev = nullptr;    // the device's address of it
     int fault_inject = 0;           // TIP_OPT_FAULT_INJECT (tests)
     int fuse_head = 0;              // TIP_OPT_FUSE_HEAD
+    int pack_split16 = 0;           // TIP_OPT_PACK_SPLIT16: which exploratory split-fp16 sections the packed image carries
+    int auto_demote = 1;            // TIP_OPT_AUTO_DEMOTE
+    int demoted = 0;                // TIP_OPT_DEMOTED: set by tip_demote after a lost hand-off: AUTO then avoids every cooperating kernel
     tip::Guard guard() const { return tip::Guard{err_dev, fault_inject}; }
 };
 

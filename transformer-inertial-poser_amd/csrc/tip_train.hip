@@ -1532,7 +1532,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     if (reinterpret_cast<uintptr_t>(saved) % 256 || saved_bytes < L.total * sizeof(float)) return TIP_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int ecus = effective_cus(h->num_cus, s);   // the stream's CU mask counts (co-residency of the recurrence's clusters)
-    CoopSerial serial(s);   // see tip_internal.h: forwards of different streams do not overlap on the device
+    CoopSerial serial(h->device, s);   // see tip_internal.h: forwards of different streams do not overlap on the device
     if (serial.status != hipSuccess) return train_fail(h, serial.status, "stream serialisation");
     float* W = static_cast<float*>(saved);
     const int M = B * T;
@@ -1757,7 +1757,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     }
     if (grads_floats < gtot) return TIP_ERR_INVALID_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    CoopSerial serial(s);   // see tip_internal.h: forwards of different streams do not overlap on the device
+    CoopSerial serial(h->device, s);   // see tip_internal.h: forwards of different streams do not overlap on the device
     if (serial.status != hipSuccess) return train_fail(h, serial.status, "stream serialisation");
     g_tgemm_cus = h->num_cus;
     const float* W = static_cast<const float*>(saved);

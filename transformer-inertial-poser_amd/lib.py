@@ -14,20 +14,23 @@ LIB_PATH = os.path.join(CSRC, "libtip_hip.so")
 TIP_FWD_LAST_ROW_ONLY = 0x1
 TIP_FWD_KEEP_MASK = 0x2
 TIP_PLAN_AUTO, TIP_PLAN_GENERAL, TIP_PLAN_FUSED, TIP_PLAN_LATENCY, TIP_PLAN_FUSED2, TIP_PLAN_FUSED2S, TIP_PLAN_FUSEDH = 0, 1, 2, 3, 4, 5, 6
-TIP_PLAN_GENERAL16 = 8  # exploratory: general plan with split-fp16 panel GEMMs (needs TIP_S16_GENERAL=1 at handle creation)
+TIP_PLAN_GENERAL16 = 8  # exploratory: general plan with split-fp16 panel GEMMs (needs TIP_OPT_PACK_SPLIT16 bit 1 before packing)
 TIP_PLAN_FUSED16 = 7   # exploratory: fp32 operands emulated as split fp16 on the f16 matrix cores (csrc/tip_s16.hip); opt-in only
 TIP_SAVED_QKV, TIP_SAVED_ATT, TIP_SAVED_X1, TIP_SAVED_HID, TIP_SAVED_XOUT, TIP_SAVED_HALL = range(6)
 TIP_STREAM_FRAME_AUTO = -1   # tip_stream_ingest / tip_stream_consume: continue from the counter in the state buffer (HIP graphs)
 TIP_OPT_PLAN, TIP_OPT_PROFILE, TIP_OPT_RNN_CLUSTER, TIP_OPT_FAULT_INJECT, TIP_OPT_FUSE_HEAD = 1, 2, 3, 4, 5
+TIP_OPT_PACK_SPLIT16, TIP_OPT_AUTO_DEMOTE, TIP_OPT_DEMOTED = 6, 7, 8
+TIP_PACK_SPLIT16_FUSED, TIP_PACK_SPLIT16_GENERAL = 1, 2
+TIP_ABI_VERSION = 2
 TIP_RNN_CLUSTER_ROWS4 = 0x44   # TIP_OPT_RNN_CLUSTER value: 4-window tiles on 4-workgroup clusters (AUTO's choice for rnn_hidden 512)
 TIP_ERR_HANDOFF = -8
 TIP_LOSS_Q, TIP_LOSS_C, TIP_LOSS_J, TIP_LOSS_STATS = 1, 2, 4, 16
 
-# every symbol include/tip_hip.h declares (tests check the .so exports exactly these)
+# every symbol include/tip_hip.h declares (tests check that the .so exports exactly these + the hooks of tip_hip_debug.h)
 EXPORTS = (
     "tip_abi_version", "tip_create", "tip_destroy", "tip_strerror", "tip_last_hip_error", "tip_set_option",
     "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
-    "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_forward", "tip_forward_f64_bytes", "tip_forward_f64", "tip_forward_count", "tip_profile_read",
+    "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_max_batch", "tip_forward", "tip_forward_f64_bytes", "tip_forward_f64", "tip_forward_count", "tip_profile_read",
     "tip_spin_timeouts", "tip_check", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
     "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward",
     "tip_combine_frames", "tip_combine_scratch_bytes", "tip_combine_sequence", "tip_gather_windows",
@@ -103,6 +106,7 @@ def load() -> ctypes.CDLL:
     lib.tip_pack_weights_device.argtypes = [vp, ctypes.POINTER(vp), i32, vp, sz, vp]
     lib.tip_attach_packed.argtypes = [vp, vp, sz]
     lib.tip_workspace_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
+    lib.tip_max_batch.argtypes = [vp, i32, i32, ctypes.POINTER(i32)]
     lib.tip_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, ctypes.c_float, vp, sz, vp]
     lib.tip_forward_f64_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
     lib.tip_forward_f64.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, vp, i32, i32, i32, vp, ctypes.c_double, vp, sz, vp]
@@ -133,8 +137,8 @@ def load() -> ctypes.CDLL:
     for name in EXPORTS:
         if name not in ("tip_destroy", "tip_strerror", "tip_last_hip_error"):
             getattr(lib, name).restype = i32
-    if lib.tip_abi_version() != 1:
-        raise TipLibraryError("libtip_hip.so ABI version mismatch")
+    if lib.tip_abi_version() != TIP_ABI_VERSION:
+        raise TipLibraryError(f"libtip_hip.so ABI version {lib.tip_abi_version()} != {TIP_ABI_VERSION}: rebuild it (make -C csrc)")
     _lib = lib
     return lib
 
@@ -202,6 +206,12 @@ class Handle:
         self._check(self.lib.tip_workspace_bytes(self._h, B, T, ctypes.byref(n)))
         return n.value
 
+    def max_batch(self, T: int, fp64: bool = False) -> int:
+        """Largest batch one forward / forward_f64 call serves at window length T (the host chunks beyond it)."""
+        n = ctypes.c_int()
+        self._check(self.lib.tip_max_batch(self._h, T, 1 if fp64 else 0, ctypes.byref(n)))
+        return n.value
+
     def forward(self, x_imu: int, x_s: int, y: int, B: int, T: int, flags: int, keep_mask: Optional[int],
                 keep_scale: float, workspace: int, workspace_bytes: int, stream: int):
         self._check(self.lib.tip_forward(self._h, x_imu, x_s, y, B, T, flags, keep_mask, keep_scale, workspace,
@@ -250,6 +260,10 @@ class Handle:
         """Raise TipHandoffError if a hand-off wait of a completed launch gave up (no device sync: synchronise the stream first
         for a definitive answer about launches in flight).  clear=True also resets the sticky word."""
         self._check(self.lib.tip_check(self._h, 1 if clear else 0))
+
+    def check_clear(self):
+        """Reset the sticky hand-off word without raising."""
+        self.lib.tip_check(self._h, 1)
 
     def forward_count(self) -> int:
         n = ctypes.c_uint64()

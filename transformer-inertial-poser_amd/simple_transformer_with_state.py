@@ -121,6 +121,7 @@ class TF_RNN_Past_State(nn.Module):
         self.use_hip_training = True     # .train() + autograd on the GPU -> tip_train_forward / tip_train_backward
         self.keep_train_stash = False    # debugging/tests: keep the last activation stash (see train_activation())
         self.last_train_stash = None
+        self.demotions = 0               # times a lost hand-off switched the handle to the non-cooperating plans (_forward_hip)
         self.t_max = 80                  # sizing hint handed to the handle; any window length is served (general plan beyond T = 40)
 
     # ------------------------------------------------------------------------------------------
@@ -157,10 +158,26 @@ class TF_RNN_Past_State(nn.Module):
     def forward(self, x_imu, x_s):
         return self._dispatch(x_imu, x_s, last_row_only=False)
 
-    def forward_last(self, x_imu, x_s):
+    def forward_last(self, x_imu, x_s, *, workspace=None, out=None):
         """Row T-1 of every window only ([B, size_s]) — what RTRunnerMin.step consumes
-        (real_time_runner_minimal.py:150).  Extension over the reference API; same numerics as forward()[:, -1]."""
+        (real_time_runner_minimal.py:150).  Extension over the reference API; same numerics as forward()[:, -1].
+        workspace / out (inference kernels only): caller-owned uint8 workspace of at least workspace_bytes(B, T) and output
+        tensor [B, size_s] — what a HIP-graph capture must own itself (StreamingEngine), since the module's per-stream
+        workspaces are an LRU that may drop a buffer a live graph still points at."""
+        if workspace is not None or out is not None:
+            if self.training or torch.is_grad_enabled():
+                raise RuntimeError("tip_amd: workspace= / out= serve the inference kernels (.eval() under torch.no_grad())")
+            return self._forward_hip(x_imu, x_s, True, workspace=workspace, out=out)
         return self._dispatch(x_imu, x_s, last_row_only=True)
+
+    def chunk_batch(self, T: int, fp64: bool = False) -> int:
+        """Windows per launch sequence when a batch exceeds what one tip_forward call serves (tip_max_batch): the library's
+        limit, rounded down to whole rounds of 256 windows when it is that large (full waves of one-window workgroups)."""
+        m = max(1, self._ensure_handle().max_batch(max(int(T), 1), fp64=fp64))
+        return m - m % 256 if m >= 512 else m
+
+    def workspace_bytes(self, B: int, T: int) -> int:
+        return self._ensure_handle().workspace_bytes(int(B), int(T))
 
     def _dispatch(self, x_imu, x_s, last_row_only: bool):
         needs_grad = torch.is_grad_enabled() and (x_imu.requires_grad or x_s.requires_grad or
@@ -289,6 +306,12 @@ class TF_RNN_Past_State(nn.Module):
         workgroups per 16-window tile (1: no inter-workgroup hand-off in the recurrence).  profile: 1 = per-stage timers
         (profile_read())."""
         h = self._ensure_handle()
+        # the exploratory split-fp16 plans read weight copies the packed image carries only on request
+        want = {"fused16": _lib.TIP_PACK_SPLIT16_FUSED, "general16": _lib.TIP_PACK_SPLIT16_GENERAL}.get(plan, 0)
+        have = h.get_option(_lib.TIP_OPT_PACK_SPLIT16)
+        if want and not (have & want):
+            h.set_option(_lib.TIP_OPT_PACK_SPLIT16, have | want)    # new image layout: detach, re-pack on the next forward
+            self._packed_dev, self._packed_key = None, None
         h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fused2s": 5, "fusedh": 6, "fused16": 7, "general16": 8}[plan])
         h.set_option(_lib.TIP_OPT_RNN_CLUSTER, int(rnn_cluster))
         h.set_option(_lib.TIP_OPT_PROFILE, int(profile))
@@ -309,6 +332,14 @@ class TF_RNN_Past_State(nn.Module):
                     self._handle.check(clear=True)
                 except _lib.TipHandoffError:
                     pass
+
+    def undemote(self):
+        """Back to the default (cooperating) plans after a self-demotion (see _forward_hip): the GPU is this process's again."""
+        if self._handle is not None:
+            self._handle.set_option(_lib.TIP_OPT_DEMOTED, 0)
+
+    def is_demoted(self) -> bool:
+        return bool(self._handle is not None and self._handle.get_option(_lib.TIP_OPT_DEMOTED))
 
     def profile_read(self):
         return self._ensure_handle().profile_read()
@@ -340,7 +371,7 @@ class TF_RNN_Past_State(nn.Module):
         self._workspace.clear()
         self._train_scratch.clear()
 
-    def _forward_hip(self, x_imu, x_s, last_row_only: bool, keep_mask="draw", apply_in_dropout=True):
+    def _forward_hip(self, x_imu, x_s, last_row_only: bool, keep_mask="draw", apply_in_dropout=True, workspace=None, out=None):
         if not (x_imu.is_cuda and x_s.is_cuda):
             raise RuntimeError("tip_amd.TF_RNN_Past_State: the inference forward runs on an MI355X through "
                                "libtip_hip.so only — move the module and its inputs to the GPU (.cuda()); "
@@ -360,13 +391,15 @@ class TF_RNN_Past_State(nn.Module):
             raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied: got feature widths "
                                f"{x_imu.shape[2]}+{x_s.shape[2]}, in_linear expects {n_imu}+{self.size_s}")
         h = self._ensure_handle()
-        # The kernels address their activations through 32-bit buffer descriptors: B * T * widest row * 4 bytes must stay below
-        # 2^31 (tip_forward returns TIP_ERR_UNSUPPORTED_CONFIG beyond: B > 13 107 at T = 40 for the paper configuration).  Streams
-        # are independent (no op in :60-102 crosses batch elements), so a larger batch is run in chunks — same numbers, one
-        # launch sequence per chunk.  (The past-state keep mask and the input dropout are drawn per chunk, like any two calls.)
-        widest = max(3 * self.tf_in_dim, self.tf_hid_size, self.rnn_hid_size if self.with_rnn else 0, n_imu + self.size_s + 16)
-        max_b = max(1, (2 ** 31 - 1) // (4 * widest * max(T, 1)))
+        # The kernels address their activations through 32-bit buffer descriptors (tip_forward) / 32-bit element offsets and grid
+        # limits (tip_forward_f64): the library says how many windows one call serves (tip_max_batch; TIP_ERR_UNSUPPORTED_CONFIG
+        # beyond: B > 13 107 at T = 40 for the paper configuration).  Streams are independent (no op in :60-102 crosses batch
+        # elements), so a larger batch is run in chunks — same numbers, one launch sequence per chunk.  (The past-state keep
+        # mask and the input dropout are drawn per chunk, like any two calls.)
+        max_b = self.chunk_batch(T, f64)
         if B > max_b:
+            if workspace is not None or out is not None:
+                raise RuntimeError("tip_amd: workspace= / out= serve a single launch sequence (batch within tip_max_batch)")
             km = None if isinstance(keep_mask, str) else keep_mask
             parts = []
             for lo in range(0, B, max_b):
@@ -392,23 +425,48 @@ class TF_RNN_Past_State(nn.Module):
                 flags |= _lib.TIP_FWD_KEEP_MASK
             if last_row_only:
                 flags |= _lib.TIP_FWD_LAST_ROW_ONLY
-                y = torch.empty((B, self.size_s), dtype=pdt, device=dev)
+            shape = (B, self.size_s) if last_row_only else (B, T, self.size_s)
+            if out is not None:
+                if tuple(out.shape) != shape or out.dtype != pdt or out.device != dev or not out.is_contiguous():
+                    raise RuntimeError(f"tip_amd: out= must be a contiguous {pdt} tensor of shape {shape} on {dev}")
+                y = out
             else:
-                y = torch.empty((B, T, self.size_s), dtype=pdt, device=dev)
+                y = torch.empty(shape, dtype=pdt, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             if f64:
                 params = [p.detach() for p in self.state_dict().values()]
                 if any(p.dtype != torch.float64 or p.device != dev for p in params):
                     raise RuntimeError("tip_amd.TF_RNN_Past_State: fp64 forward needs every parameter in fp64 on the inputs' GPU")
                 params = [p.contiguous() for p in params]
-                ws = self._stream_buffer(self._workspace, dev, stream, h.forward_f64_bytes(B, T))
+                ws = workspace if workspace is not None else self._stream_buffer(self._workspace, dev, stream, h.forward_f64_bytes(B, T))
                 h.forward_f64([p.data_ptr() for p in params], x_imu_c.data_ptr(), x_s_c.data_ptr(), y.data_ptr(), B, T,
                               flags & _lib.TIP_FWD_LAST_ROW_ONLY, mask_ptr, scale, ws.data_ptr(), ws.numel(), stream)
                 return y
             need = h.workspace_bytes(B, T)
-            ws = self._stream_buffer(self._workspace, dev, stream, need)
-            h.forward(x_imu_c.data_ptr(), x_s_c.data_ptr(), y.data_ptr(), B, T, flags, mask_ptr, scale,
-                      ws.data_ptr(), ws.numel(), stream)
+            if workspace is not None:
+                if workspace.dtype != torch.uint8 or workspace.device != dev or workspace.numel() < need or workspace.data_ptr() % 256:
+                    raise RuntimeError(f"tip_amd: workspace= must be a 256-byte aligned uint8 tensor of >= {need} bytes on {dev}")
+                ws = workspace
+            else:
+                ws = self._stream_buffer(self._workspace, dev, stream, need)
+            try:
+                h.forward(x_imu_c.data_ptr(), x_s_c.data_ptr(), y.data_ptr(), B, T, flags, mask_ptr, scale,
+                          ws.data_ptr(), ws.numel(), stream)
+            except _lib.TipHandoffError:
+                # An EARLIER launch of this handle lost an inter-workgroup hand-off (a co-tenant held CUs): its outputs were
+                # NaN-poisoned and flagged.  First time: demote the handle to the plans that need no co-residency (hybrid
+                # encoder + single-workgroup recurrence tiles), clear the word and run THIS call — a co-tenant then costs
+                # throughput, not every following frame.  TIP_OPT_AUTO_DEMOTE = 0 (or a second loss) reports the error.
+                if not h.get_option(_lib.TIP_OPT_AUTO_DEMOTE) or h.get_option(_lib.TIP_OPT_DEMOTED):
+                    raise
+                warnings.warn("tip_amd: an earlier forward lost an inter-workgroup hand-off (is another process or stream holding "
+                              "CUs of this GPU?) — its outputs were NaN.  This model now runs the plans that need no co-resident "
+                              "workgroups (TIP_OPT_DEMOTED: slower, safe under co-tenancy); model.undemote() restores the default")
+                h.check_clear()
+                h.set_option(_lib.TIP_OPT_DEMOTED, 1)
+                self.demotions += 1
+                h.forward(x_imu_c.data_ptr(), x_s_c.data_ptr(), y.data_ptr(), B, T, flags, mask_ptr, scale,
+                          ws.data_ptr(), ws.numel(), stream)
         return y
 
     # -- torch-op composite (autograd / training) -----------------------------------------------

@@ -16,7 +16,13 @@ about 23 kernel launches for a handful of streams, each ~8 us of host time, whic
 are captured ONCE into a HIP graph (torch.cuda.CUDAGraph; frame / call indices come from a counter in the state buffer,
 TIP_STREAM_FRAME_AUTO) and every further frame is one copy of the raw frame into a static buffer + one graph launch.  Outputs are
 bit-identical to the launch-by-launch loop (tests/test_streaming_gpu.py).  The graph freezes the model's packed weights and plan:
-call reset() (or build a new engine) after changing parameters.
+call reset() (or build a new engine) after changing parameters.  What the graph points at is OWNED by the engine for the graph's
+lifetime (its own workspace, output row, and a reference to the packed weight image), never the module's evictable per-stream
+buffers.  A captured forward is outside the library's cross-stream serialisation (include/tip_hip.h): replay it on the stream
+the device's other forwards use, or when none is in flight.  Every replayed frame polls the handle's hand-off word (a pinned
+host word, no synchronisation): a lost hand-off of an earlier replay — its y_last was NaN and went into the history ring —
+re-primes the engine (reset()), demotes the handle to the non-cooperating plans when TIP_OPT_AUTO_DEMOTE allows, and raises
+TipHandoffError, exactly as the launch-by-launch engine's next forward would have.
 """
 from __future__ import annotations
 
@@ -56,6 +62,8 @@ class StreamingEngine:
         self.s_rest = torch.empty((self.n, 111), dtype=torch.float32, device=self.device)
         self.c_t = torch.empty((self.n, 20), dtype=torch.float32, device=self.device)
         self.raw = torch.empty((self.n, 72), dtype=torch.float32, device=self.device)    # static input of the captured graph
+        self._graph_ws = None
+        self._graph_y = None
         self.reset()
 
     def _check(self, status: int):
@@ -68,16 +76,30 @@ class StreamingEngine:
     def reset(self):
         self.frame = 0
         self._graph = None
+        self._graph_refs = None      # (workspace, packed weight image, y_last): what the captured kernels point at
         self._y_last = None
         with torch.cuda.device(self.device):
             self._check(self.lib.tip_stream_reset(self.state.data_ptr(), self.s_init.data_ptr(), self.n, self._stream()))
+
+    def _poll_handoff(self):
+        """Graph mode: tip_forward's entry check never runs during a replay, so the engine reads the hand-off word itself."""
+        try:
+            self.model.check_handoffs(synchronize=False)
+        except _lib.TipHandoffError:
+            h = self.model._ensure_handle()
+            h.check_clear()
+            if h.get_option(_lib.TIP_OPT_AUTO_DEMOTE) and not h.get_option(_lib.TIP_OPT_DEMOTED):
+                h.set_option(_lib.TIP_OPT_DEMOTED, 1)
+                self.model.demotions += 1
+            self.reset()          # the NaN row of the lost frame is in the history ring: re-prime (and re-capture, demoted)
+            raise
 
     def _frame_auto(self):
         """ingest -> forward_last -> consume with the frame index taken from the state buffer (capturable)."""
         st = self._stream()
         self._check(self.lib.tip_stream_ingest(self.state.data_ptr(), self.raw.data_ptr(), self.n, _lib.TIP_STREAM_FRAME_AUTO,
                                                self.x_imu.data_ptr(), self.x_s.data_ptr(), st))
-        y_last = self.model.forward_last(self.x_imu, self.x_s)
+        y_last = self.model.forward_last(self.x_imu, self.x_s, workspace=self._graph_ws, out=self._graph_y)
         self._check(self.lib.tip_stream_consume(self.state.data_ptr(), y_last.data_ptr(), self.n, _lib.TIP_STREAM_FRAME_AUTO,
                                                 self.s_rest.data_ptr(), self.c_t.data_ptr(), st))
         return y_last
@@ -89,11 +111,20 @@ class StreamingEngine:
             self.raw.copy_(torch.as_tensor(raw_imu, dtype=torch.float32).reshape(self.n, 72), non_blocking=True)
             with torch.cuda.device(self.device):
                 if self._graph is None:
+                    # buffers the captured kernels will point at: allocated OUTSIDE the capture and held by the engine
+                    if self._graph_ws is None:
+                        self._graph_ws = torch.empty(self.model.workspace_bytes(self.n, 40), dtype=torch.uint8, device=self.device)
+                        self._graph_y = torch.empty((self.n, self.model.size_s), dtype=torch.float32, device=self.device)
+                    self.model.forward_last(self.x_imu, self.x_s, workspace=self._graph_ws, out=self._graph_y)   # packs / attaches outside the capture
                     torch.cuda.current_stream(self.device).synchronize()
+                    self._poll_handoff()
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         self._y_last = self._frame_auto()
                     self._graph = g
+                    self._graph_refs = (self._graph_ws, self.model._packed_dev, self._graph_y)
+                else:
+                    self._poll_handoff()
                 self._graph.replay()
             self.frame += 1
             return {"s_rest": self.s_rest, "c_t": self.c_t, "y_last": self._y_last, "T": 40}
