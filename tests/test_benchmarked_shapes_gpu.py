@@ -93,8 +93,8 @@ def test_b8192_auto_vs_oracle_and_shards():
 
 def test_batch_beyond_the_32bit_descriptor_limit_is_chunked():
     """B * T * widest row * 4 bytes >= 2^31 (B > 13 107 at T = 40) is beyond what one tip_forward call addresses
-    (TIP_ERR_UNSUPPORTED_CONFIG); the reference accepts any batch, so the host runs it in chunks — bit-identical to running the
-    pieces by hand, because streams are independent."""
+    (TIP_ERR_UNSUPPORTED_CONFIG; tip_max_batch reports the limit); the reference accepts any batch, so the host runs it in chunks
+    of chunk_batch() windows (the limit rounded down to whole rounds of 256) — bit-identical to running the pieces by hand."""
     m, _ = _gpu_model(0)
     m.set_plan("auto")
     B = 13107 + 150
@@ -106,7 +106,9 @@ def test_batch_beyond_the_32bit_descriptor_limit_is_chunked():
     with torch.no_grad():
         yl = m.forward_last(xi, xs)
         assert m.hip_forward_count() == n0 + 2, "expected two chunks"
-        a, b = m.forward_last(xi[:13107], xs[:13107]), m.forward_last(xi[13107:], xs[13107:])
+        cb = m.chunk_batch(40)
+        assert m._ensure_handle().max_batch(40) == 13107 and cb == 13056
+        a, b = m.forward_last(xi[:cb], xs[:cb]), m.forward_last(xi[cb:], xs[cb:])
     torch.cuda.synchronize()
     assert yl.shape == (B, 131) and bool(torch.isfinite(yl).all())
     assert torch.equal(yl, torch.cat([a, b]))

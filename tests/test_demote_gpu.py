@@ -26,7 +26,7 @@ def _model():
 
 
 @pytest.mark.handoff_fault
-@pytest.mark.parametrize("B,bits", [(40, 2), (3, 4), (300, 2)])   # clustered recurrence; latency plan's GEMV recurrence; two rounds
+@pytest.mark.parametrize("B,bits", [(100, 2), (3, 4), (300, 2)])   # clustered recurrence; latency plan's GEMV recurrence; two rounds
 def test_lost_handoff_demotes_and_the_next_call_runs(B, bits):
     m, w = _model()
     h = m._ensure_handle()
@@ -68,7 +68,7 @@ def test_auto_demote_off_reports_the_error():
     m, _ = _model()
     h = m._ensure_handle()
     h.set_option(tlib.TIP_OPT_AUTO_DEMOTE, 0)
-    x_imu, x_s = synth.make_inputs(synth.PAPER, 40, 40, seed=9)
+    x_imu, x_s = synth.make_inputs(synth.PAPER, 100, 40, seed=9)    # AUTO: hybrid encoder + clustered recurrence
     xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
     with torch.no_grad():
         m(xi, xs)

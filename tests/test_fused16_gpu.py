@@ -68,6 +68,7 @@ def test_fused16_keep_mask_golden(golden):
     case = golden["paper_mask_s0_B2_T40"]
     m, _ = _gpu_model(0)
     h = m._ensure_handle()
+    h.set_option(tlib.TIP_OPT_PACK_SPLIT16, tlib.TIP_PACK_SPLIT16_FUSED)    # the image must carry the split-fp16 section (C-ABI spelling)
     m.refresh_packed(torch.device("cuda:0"))
     xi, xs = torch.tensor(case["x_imu"]).cuda(), torch.tensor(case["x_s"]).cuda()
     mask = torch.tensor(case["mask"]).cuda()

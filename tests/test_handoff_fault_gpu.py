@@ -20,9 +20,13 @@ pytestmark = pytest.mark.gpu
 
 
 def _model():
+    """(TIP_OPT_AUTO_DEMOTE off: these tests are about the raw error path — NaN rows, sticky TIP_ERR_HANDOFF; what the host does
+    with the first error by default is tests/test_demote_gpu.py)"""
     m = make_model(synth.PAPER)
     load_synth(m, synth.PAPER, 0)
-    return m.cuda().eval()
+    m = m.cuda().eval()
+    m._ensure_handle().set_option(tlib.TIP_OPT_AUTO_DEMOTE, 0)
+    return m
 
 
 def _fault(m, bits):
