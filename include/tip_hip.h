@@ -88,6 +88,13 @@ typedef enum tip_status {
 #define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);
                               AUTO picks it for B <= 64 */
 
+#define TIP_PLAN_LATENCY1 9 /* TIP_PLAN_LATENCY as ONE persistent kernel (B <= 8): the same stages separated by grid barriers instead of
+                               kernel boundaries, recurrence and output projection as its tail; bit-identical to TIP_PLAN_LATENCY.  32
+                               co-resident workgroups (one XCD).  Its hand-off flags live in the last 1 KiB of the packed weight image
+                               (zero after packing; the only part of the image a forward writes).  OPT-IN, never AUTO's choice: measured no
+                               faster than the launch chain (181-207 us against 176 at B = 1: the stage bodies, not the kernel boundaries,
+                               bound it); kept as the single-kernel, HIP-graph-replayable form of the few-stream forward. */
+
 #define TIP_OPT_PLAN        1
 #define TIP_OPT_PROFILE     2 /* 0 off; 1: bracket every stage with a HIP event pair; 2: only the dominant stage
                                  (cheap enough for a timed region).  Setting it resets the accumulated times. */

@@ -87,6 +87,7 @@ void build_layout(tip_handle* h) {
     // exploratory TIP_PLAN_FUSED16: split-fp16 copy of the fused section, only on request (TIP_OPT_PACK_SPLIT16)
     L.s16_floats = (h->pack_split16 & TIP_PACK_SPLIT16_FUSED) ? s16_packed_floats(d) : 0;
     L.s16_off = L.s16_floats ? c.take(L.s16_floats) : 0;
+    L.sync_off = c.take(kLat1SyncWords);
     L.total_floats = c.off;
 }
 
@@ -150,7 +151,7 @@ Workspace carve_workspace(const Dims& d, int B, int T) {
     w.att = take(Mp * d.D);
     w.hall = take(Mp * (d.with_rnn ? d.R : 1));
     w.flags = take(rnn_flag_words(B, T) + 64);
-    w.lat = take(latency_supported(d, B, T) ? latency_workspace_floats(B, T) : 0);
+    w.lat = take(latency_supported(d, B, T) ? latency_workspace_floats(B, T) : 0);   // (the persistent variant uses the same buffers)
     // pair-split plan: partial-sum images two partner workgroups exchange (only batches that can be co-resident use it)
     w.xchg = take(fused2_supported(d, T) && B <= 1024 ? fused2s_xchg_floats(B) : 0);
     w.total_bytes = off * sizeof(float);
@@ -351,7 +352,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
     if (!h) return TIP_ERR_INVALID_ARG;
     switch (option) {
         case TIP_OPT_PLAN:
-            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_GENERAL16) return TIP_ERR_INVALID_ARG;
+            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_LATENCY1) return TIP_ERR_INVALID_ARG;
             h->plan = value;
             return TIP_OK;
         case TIP_OPT_PROFILE:
@@ -398,6 +399,7 @@ int tip_check(tip_handle* h, int clear) {
     if (!h->err_host) return TIP_OK;
     const unsigned v = *const_cast<volatile unsigned*>(h->err_host);
     if (clear) *const_cast<volatile unsigned*>(h->err_host) = 0u;
+    if (v) h->sync_dirty = 1;   // the persistent kernel's flag words may have been left mid-protocol
     return v ? TIP_ERR_HANDOFF : TIP_OK;
 }
 
@@ -726,7 +728,11 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     int plan = h->plan;
     if (plan == TIP_PLAN_AUTO) {
         // (a demoted handle — TIP_OPT_DEMOTED, after a lost hand-off — takes no cooperating kernel: the latency plan's GEMV recurrence is one)
-        if (!h->demoted && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;   // <= 64 streams: spread each window over many CUs (0.65 vs 0.86 ms at B = 64)
+        // (TIP_PLAN_LATENCY1, the same chain as one persistent kernel, is opt-in: measured 181-207 us against the chain's 176 at B = 1 —
+        // the stage bodies, not the kernel boundaries, bound the chain; DESIGN.md section 5.  TIP_LAT1=1 makes AUTO take it: measurement.)
+        static const bool lat1 = getenv("TIP_LAT1") && getenv("TIP_LAT1")[0] == '1';
+        if (!h->demoted && lat1 && cus == h->num_cus && latency1_supported(d, B, T)) plan = TIP_PLAN_LATENCY1;
+        else if (!h->demoted && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;   // <= 64 streams: spread each window over many CUs (0.65 vs 0.86 ms at B = 64)
         else plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
     }
     if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO) {
@@ -743,6 +749,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2S && !(fused2_supported(d, T) && fused2s_fits(B, cus) && B <= 1024)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (plan == TIP_PLAN_LATENCY1 && !latency1_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED16 && !(s16_supported(d, T) && L.s16_floats)) return TIP_ERR_UNSUPPORTED_CONFIG;
 
     const bool g16 = plan == TIP_PLAN_GENERAL16;   // exploratory: the general plan with split-fp16 panel GEMMs
@@ -764,7 +771,20 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         static const bool rows4 = !(getenv("TIP_RNN_ROWS4") && getenv("TIP_RNN_ROWS4")[0] == '0');
         if (rows4 && d.R == 512) rnn_cluster = kRnnRows4;
     }
-    if (plan == TIP_PLAN_LATENCY) {
+    bool head_done = false;
+    if (plan == TIP_PLAN_LATENCY1) {
+        StageScope sc(h, s, "latency_chain");
+        unsigned* sync = reinterpret_cast<unsigned*>(const_cast<float*>(P + L.sync_off));
+        if (h->sync_dirty) {   // a hand-off failed earlier: the flag words may have been left mid-protocol
+            TIP_TRY(hipMemsetAsync(sync, 0, kLat1SyncWords * sizeof(unsigned), s), "latency1 sync reset");
+            h->sync_dirty = 0;
+        }
+        TIP_TRY(launch_latency1_plan(d, P + L.fused_off, P + L.whh_frag_off, P + L.out_frag_off, P + L.out_lin.b_off, x_imu, x_s, mask,
+                                     keep_scale, W0, ws.total_bytes, ws.lat, ws.hall, sync, y, (flags & TIP_FWD_LAST_ROW_ONLY) != 0, B, T,
+                                     cus, gd, s), "latency1");
+        rnn_done = true;
+        head_done = true;
+    } else if (plan == TIP_PLAN_LATENCY) {
         StageScope sc(h, s, "latency_chain");
         TIP_TRY(launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall,
                                     B, T, cus, gd, s), "latency_chain");
@@ -845,7 +865,6 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     }
 
     const bool last_only = (flags & TIP_FWD_LAST_ROW_ONLY) != 0;
-    bool head_done = false;
     const float* head_in = enc_out;
     int head_ld = d.D;
     if (d.with_rnn && rnn_done) {
