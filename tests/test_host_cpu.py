@@ -249,11 +249,13 @@ def test_packed_image_split_fp16_section():
     plain = m.pack_host().numpy()
     m.set_plan("fused16")                               # TIP_OPT_PACK_SPLIT16 bit 0: the image now carries the split copy
     img = m.pack_host().numpy()
-    assert img.size == plain.size + 3352320 * 4 and np.array_equal(img[:plain.size], plain)
+    SYNC = 256                                          # the persistent latency kernel's flag words close every image (zero after packing)
+    assert img.size == plain.size + 3352320 * 4 and np.array_equal(img[:plain.size - SYNC * 4], plain[:-SYNC * 4])
+    assert not plain[-SYNC * 4:].any() and not img[-SYNC * 4:].any()
     f32 = img.view(np.float32)
     NF = 3352320                                        # fused_packed_floats of the paper configuration (64-float aligned)
-    assert f32.size >= 2 * NF
-    fused, s16 = f32[-2 * NF:-NF], f32[-NF:].view(np.float16)
+    assert f32.size >= 2 * NF + SYNC
+    fused, s16 = f32[-(2 * NF + SYNC):-(NF + SYNC)], f32[-(NF + SYNC):-SYNC].view(np.float16)
     LAYER0, LAYER_FLOATS = 57600, 789760
     W1_W = 3 * 256 * 256 + 3 * 256 + 256 * 256 + 256
     for (off, N, K) in ((0, 256, 224), (LAYER0, 768, 256), (LAYER0 + 2 * LAYER_FLOATS + W1_W, 1024, 256),
