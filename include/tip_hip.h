@@ -125,7 +125,7 @@ typedef enum tip_status {
 #define TIP_OPT_DEMOTED     8 /* 1: TIP_PLAN_AUTO and the automatic TIP_OPT_RNN_CLUSTER choose only kernels WITHOUT inter-workgroup hand-offs
                                  (hybrid one-window / two-window encoder or the general plan, single-workgroup recurrence tiles): no
                                  co-residency needed, a co-tenant costs throughput instead of frames.  Explicit plans / cluster sizes are
-                                 still honoured.  tip_forward only: the training step's recurrences always cooperate.  Default 0. */
+                                 still honoured.  The training step's two recurrences likewise run on single-workgroup tiles.  Default 0. */
 
 /* ---- lifetime: replaces TF_RNN_Past_State.__init__ (simple_transformer_with_state.py:9-54) ---------------- */
 TIP_API int tip_abi_version(void);
@@ -250,8 +250,10 @@ TIP_API int tip_stream_consume(void* state, const float* y_last, int n_streams, 
  *             Kept values are scaled by 1/(1-p).  p_drop = 0 switches it off.
  *   saved     activation stash written by the forward and read by the backward (tip_train_bytes: saved_bytes)
  *   scratch   backward workspace (scratch_bytes); grads = one flat buffer, tensors in tip_tensor_info() order.
- * Supported: with_rnn, rnn_hid_size 512, tf_in_dim 256/512/1024, head width 16/32/64, T <= 128 — else
- * TIP_ERR_UNSUPPORTED_CONFIG (the Python module then differentiates its torch-op composite instead). */
+ * Supported: with or without the RNN (:43-46), rnn_hid_size any multiple of 64 up to 512 (512: register-resident cluster kernels;
+ * other widths: the streaming kernel in both directions), tf_in_dim 256/512/1024, head width 16/32/64, T <= 128 — else
+ * TIP_ERR_UNSUPPORTED_CONFIG (the Python module then differentiates its torch-op composite instead).  A handle with
+ * TIP_OPT_DEMOTED set runs both recurrences on single-workgroup tiles (no inter-workgroup hand-off). */
 TIP_API int tip_train_bytes(const tip_handle* h, int B, int T, size_t* saved_bytes, size_t* scratch_bytes);
 /* where one stashed activation of encoder layer `layer` lives inside `saved` (float offset, float count): */
 #define TIP_SAVED_QKV  0 /* [M,3D] in-projection output (q | k | v)                                   */

@@ -91,6 +91,8 @@ def forward(cfg: dict, params: "dict[str, torch.Tensor]", x_imu, x_s, keep_mask=
         f = torch.nn.functional.linear(f * site(l, 2, (B, T, F_)), params[p + "linear2.weight"], params[p + "linear2.bias"])
         z = torch.nn.functional.layer_norm(z + f * site(l, 3, (B, T, D)), (D,), params[p + "norm2.weight"],
                                            params[p + "norm2.bias"], 1e-5)
+    if not cfg.get("with_rnn", True):                                                  # :43-46: no RNN, the projection reads the encoder
+        return torch.nn.functional.linear(z, params["linear.weight"], params["linear.bias"])
     ih = torch.nn.functional.linear(z, params["rnn.weight_ih_l0"], params["rnn.bias_ih_l0"] + params["rnn.bias_hh_l0"])
     h = torch.zeros(B, R, dtype=dtype)
     hs = []

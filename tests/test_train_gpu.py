@@ -291,3 +291,62 @@ def test_training_trajectory_matches_the_composite():
         dev += float(((pa.detach() - pb.detach()) ** 2).sum())
     print("loss", la[0], "->", la[-1], " max |dloss|/loss", np.abs(la - lb).max() / lb.max(), " weights: deviation / distance travelled", (dev / moved) ** 0.5)
     assert (dev / moved) ** 0.5 < 2e-3                                  # measured 1.6e-4
+
+
+WIDER = [dict(synth.PAPER, with_rnn=False),                       # simple_transformer_with_state.py:43-46
+         dict(synth.PAPER, rnn_hid_size=256),                     # train_model.py:47-48 --rnn_nhid
+         dict(synth.PAPER, rnn_hid_size=448, tf_layers=2),
+         dict(synth.PAPER, rnn_hid_size=64, tf_layers=1),
+         dict(synth.PAPER, tf_in_dim=512, n_heads=16, tf_hid_size=512, rnn_hid_size=128, tf_layers=2)]   # layer-by-layer encoder too
+
+
+@pytest.mark.parametrize("ci", range(len(WIDER)))
+@pytest.mark.parametrize("B,T", [(3, 40), (17, 23), (40, 40)])
+def test_training_step_without_rnn_and_other_rnn_widths(ci, B, T):
+    """VERDICT r03 missing #5: `tip_train_*` for with_rnn = False and rnn_hid_size != 512 (any multiple of 64 the inference path
+    serves).  The recurrences of the other widths run on the streaming kernel (rnn_kernel<.., BWD> for the backward), with 1 - 8
+    workgroups per window tile depending on the batch: y and every gradient tensor against the fp64 oracle, deterministic."""
+    cfg = WIDER[ci]
+    m, w = _train_model(cfg, 5, 0.0)
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=60 + B)
+    cot = synth.normal(9, "cot", B * T * cfg["size_s"]).reshape(B, T, -1).astype(np.float32)
+    y, g, _ = _hip_step(m, x_imu, x_s, cot)
+    assert len(g) == (56 if cfg.get("with_rnn", True) else 52) - 12 * (4 - cfg["tf_layers"])
+    yo, go = train_oracle.step(cfg, w, x_imu, x_s, cot, relu_gates=_gates(m, cfg, B, T))
+    assert np.abs(y - yo).max() < 2e-5, np.abs(y - yo).max()
+    print("worst tensor", _check_grads(g, go))
+    y2, g2, _ = _hip_step(m, x_imu, x_s, cot)
+    assert np.array_equal(y, y2) and all(np.array_equal(g[n], g2[n]) for n in g)
+
+
+def test_training_step_with_live_dropout_without_rnn():
+    cfg = dict(synth.PAPER, with_rnn=False)
+    m, w = _train_model(cfg, 3, 0.1)
+    B, T, seed = 5, 40, 987654321
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=78)
+    cot = synth.normal(8, "cot", B * T * cfg["size_s"]).reshape(B, T, -1).astype(np.float32)
+    y, g, _ = _hip_step(m, x_imu, x_s, cot, seed=seed)
+    yo, go = train_oracle.step(cfg, w, x_imu, x_s, cot, p_drop=0.1, seed=seed, relu_gates=_gates(m, cfg, B, T))
+    assert np.abs(y - yo).max() < 2e-5, np.abs(y - yo).max()
+    print("worst tensor", _check_grads(g, go))
+
+
+def test_demoted_handle_trains_without_cooperating_recurrences():
+    """TIP_OPT_DEMOTED: both recurrences of the training step on single-workgroup tiles (no inter-workgroup hand-off), same
+    numbers as the oracle; with the clustered-recurrence fault injected nothing can time out any more."""
+    cfg = synth.PAPER
+    m, w = _train_model(cfg, 2, 0.0)
+    h = m._ensure_handle()
+    h.set_option(tlib.TIP_OPT_DEMOTED, 1)
+    h.set_option(tlib.TIP_OPT_FAULT_INJECT, 2)
+    B, T = 40, 40
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=41)
+    cot = synth.normal(7, "cot", B * T * cfg["size_s"]).reshape(B, T, -1).astype(np.float32)
+    t0 = tlib.spin_timeouts()
+    y, g, _ = _hip_step(m, x_imu, x_s, cot)
+    assert tlib.spin_timeouts() == t0
+    yo, go = train_oracle.step(cfg, w, x_imu, x_s, cot, relu_gates=_gates(m, cfg, B, T))
+    assert np.abs(y - yo).max() < 2e-5
+    print("worst tensor", _check_grads(g, go))
+    h.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)
+    m.check_handoffs()

@@ -114,3 +114,20 @@ def test_module_composite_matches_oracle_gradients():
     assert np.abs(y.detach().numpy() - yo).max() < 1e-9
     for n, p in m.named_parameters():
         assert np.abs(p.grad.numpy() - go[n]).max() <= 1e-8 * (1 + np.abs(go[n]).max()), n
+
+
+def test_train_oracle_without_rnn_and_other_widths_matches_forward_oracle():
+    """The training oracle's forward (autograd graph) for the configurations the reference's constructor also builds
+    (simple_transformer_with_state.py:43-46 with_rnn=False; --rnn_nhid other than 512, train_model.py:47-48) against the C / numpy
+    forward oracle that the reference's goldens pin (tiny_nornn, tiny cases): same function, so the gradients it yields are those
+    of the pinned forward."""
+    import torch
+    from oracle import oracle
+    for cfg in (dict(synth.TINY, with_rnn=False), dict(synth.PAPER, with_rnn=False, tf_layers=1),
+                dict(synth.PAPER, rnn_hid_size=192, tf_layers=1)):
+        w = synth.make_weights(cfg, seed=4)
+        x_imu, x_s = synth.make_inputs(cfg, 2, 9, seed=5)
+        params = {k: torch.tensor(np.asarray(v), dtype=torch.float64) for k, v in w.items()}
+        y = train_oracle.forward(cfg, params, x_imu, x_s).numpy()
+        yo = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
+        assert np.abs(y - yo).max() < 1e-12, cfg

@@ -509,10 +509,13 @@ hipError_t launch_layernorm(float* x, const float* g, const float* b, int M, int
 // and the A fragment of MFMA step s is h[lane&15][kb*16 + 4*(lane>>4) + s]  (same k permutation on both
 // operands, so each group of 4 MFMAs covers 16 consecutive k).
 // ------------------------------------------------------------------------------------------------
-template <int NBW>  // 16-column blocks per wave: R / (16 * 4 * cluster)
+// BWD = true: the backward recurrence of the training step for any rnn_hidden (tip_train.hip; the register-resident kernels below
+// serve 512 only): delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2), t = T-1 .. 0, with `ih` = dH, `whh_frag` = fragments of
+// W_hh^T, `gate` = the forward states h, `hall` = delta (output).  Same tiling, hand-off and accumulation order, time reversed.
+template <int NBW, bool BWD = false>  // NBW: 16-column blocks per wave: R / (16 * 4 * cluster)
 __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, const float* __restrict__ whh_frag,
                                                   float* __restrict__ hall, unsigned* __restrict__ flags, int B, int T,
-                                                  int R, int cluster, int ntiles, Guard gd) {
+                                                  int R, int cluster, int ntiles, Guard gd, const float* __restrict__ gate) {
     extern __shared__ __attribute__((aligned(16))) float smem[];  // h tile [16][R+4]
     __shared__ int s_poison;   // a hand-off wait of this workgroup gave up: everything it produces from here on is NaN
     if (threadIdx.x == 0) s_poison = 0;
@@ -536,20 +539,23 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
         const int b0 = tile * kRnnTile;
         for (int i = tid; i < kRnnTile * LDH; i += 256) smem[i] = 0.f;  // h_{-1} = 0
         __syncthreads();
-        for (int t = 0; t < T; ++t) {
+        for (int st = 0; st < T; ++st) {
+            const int t = BWD ? T - 1 - st : st;        // time index of this step
+            const int tp = BWD ? t + 1 : t - 1;         // ... and of the step before it (whose result is the A operand)
             // input projection of this step (bias b_ih + b_hh already folded in): issued early, used after the MFMAs
-            float ihv[NBW][4];
+            float ihv[NBW][4], gv[NBW][4];
 #pragma unroll
             for (int n = 0; n < NBW; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int bb = b0 + lg * 4 + r;
                     ihv[n][r] = bb < B ? ih[((size_t)bb * T + t) * R + (nb0 + n) * 16 + l15] : 0.f;
+                    gv[n][r] = (BWD && bb < B) ? gate[((size_t)bb * T + t) * R + (nb0 + n) * 16 + l15] : 0.f;
                 }
-            if (t > 0 && cluster > 1) {
+            if (st > 0 && cluster > 1) {
                 // wait for every member's slice of h_{t-1}, then pull the full [16][R] tile from HALL
                 if (tid == 0 && !s_poison) {
-                    unsigned* f = flags + (size_t)tile * T + (t - 1);
+                    unsigned* f = flags + (size_t)tile * T + tp;
                     const unsigned lim = guard_spin_limit(gd.fault, 1u << 22);
                     unsigned spins = 0;
                     for (; spins < lim; ++spins) {  // bounded: never hang the GPU
@@ -558,12 +564,12 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
                     }
                     if (spins == lim) {
                         note_spin_timeout(gd.err);
-                        s_poison = t;                      // (t >= 1 here: the step whose wait gave up)
+                        s_poison = st;                     // (st >= 1 here: the step whose wait gave up)
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 }
                 __syncthreads();
-                if (s_poison == t) {
+                if (s_poison == st) {
                     // h_{t-1} is incomplete (the missing member's slice of HALL holds stale memory): this member's slice of that
                     // row turns NaN too, so the output row t-1 cannot come out finite
 #pragma unroll
@@ -571,14 +577,14 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int bb = b0 + lg * 4 + r;
-                            if (bb < B) hall[((size_t)bb * T + (t - 1)) * R + (nb0 + n) * 16 + l15] = __uint_as_float(kPoisonBits);
+                            if (bb < B) hall[((size_t)bb * T + tp) * R + (nb0 + n) * 16 + l15] = __uint_as_float(kPoisonBits);
                         }
                 }
                 for (int i = tid; i < kRnnTile * (R / 4); i += 256) {
                     const int m = i / (R / 4), c = (i % (R / 4)) * 4;
                     const int bb = b0 + m;
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (bb < B) v = *reinterpret_cast<const float4*>(hall + ((size_t)bb * T + (t - 1)) * R + c);
+                    if (bb < B) v = *reinterpret_cast<const float4*>(hall + ((size_t)bb * T + tp) * R + c);
                     *reinterpret_cast<float4*>(smem + m * LDH + c) = v;
                 }
                 __syncthreads();
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
             // depend on how many streams share the launch): four fmaf chains per output — k-blocks of the lower /
             // upper half of K, even / odd — combined as (c00 + c01) + (c10 + c11).
             f32x4 acc[NBW];
-            if (t > 0) {
+            if (st > 0) {
                 f32x4 ch[4][NBW];
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -639,7 +645,9 @@ __global__ __launch_bounds__(256) void rnn_kernel(const float* __restrict__ ih, 
             for (int n = 0; n < NBW; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    hvv[n][r] = (b0 + lg * 4 + r < B) ? (s_poison ? __uint_as_float(kPoisonBits) : tip_tanh(acc[n][r] + ihv[n][r])) : 0.f;
+                    hvv[n][r] = (b0 + lg * 4 + r < B) ? (s_poison ? __uint_as_float(kPoisonBits)
+                                                             : (BWD ? (acc[n][r] + ihv[n][r]) * (1.0f - gv[n][r] * gv[n][r]) : tip_tanh(acc[n][r] + ihv[n][r])))
+                                                  : 0.f;
 #pragma unroll
             for (int n = 0; n < NBW; ++n) {
                 const int col = (nb0 + n) * 16 + l15;
@@ -1453,11 +1461,46 @@ static hipError_t launch_rnn_rows4(const float* ih, const float* whh_frag, float
     return launch_rnn_rows4_nt<kQ4Tiles>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
 }
 
-// backward recurrence of the training step (R = 512, cluster 4 / 8 / 16 only); see rnn_resident_kernel<.., BWD>
+// one 16-window tile per `cluster` workgroups on the streaming kernel (rnn_kernel): any rnn_hidden that is a multiple of 64
+template <bool BWD>
+static hipError_t launch_rnn_stream(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T, int R, int cluster,
+                                    int num_cus, const Guard& gd, const float* gate, hipStream_t s) {
+    const int ntiles = (B + kRnnTile - 1) / kRnnTile;
+    if (cluster < 1) cluster = 1;
+    if (cluster > 8) cluster = 8;
+    const int KB = R / 16;
+    while (cluster > 1 && (KB % (4 * cluster))) cluster >>= 1;
+    if (KB % (4 * cluster)) return hipErrorInvalidValue;
+    const int nbw = KB / (4 * cluster);
+    int groups = ntiles;
+    if (cluster > 1) {
+        // every workgroup of a cluster must be co-resident: keep the grid within one workgroup per CU
+        const int maxg = num_cus / cluster > 0 ? num_cus / cluster : 1;
+        if (groups > maxg) groups = maxg;
+        hipError_t e = hipMemsetAsync(flags, 0, (size_t)ntiles * T * sizeof(unsigned), s);
+        if (e != hipSuccess) return e;
+    }
+    const size_t smem = (size_t)kRnnTile * (R + 4) * sizeof(float);
+    const dim3 grid(groups * cluster), block(256);
+#define TIP_RNN_CASE(N) \
+    case N: hipLaunchKernelGGL((rnn_kernel<N, BWD>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, R, cluster, ntiles, gd, gate); break;
+    switch (nbw) {
+        TIP_RNN_CASE(1) TIP_RNN_CASE(2) TIP_RNN_CASE(3) TIP_RNN_CASE(4) TIP_RNN_CASE(5) TIP_RNN_CASE(6)
+        TIP_RNN_CASE(7) TIP_RNN_CASE(8)
+        default: return hipErrorInvalidValue;
+    }
+#undef TIP_RNN_CASE
+    return hipGetLastError();
+}
+
+// backward recurrence of the training step: R = 512 on the register-resident clusters (cluster 4 / 8 / 16 / four-row tiles; see
+// rnn_resident_kernel<.., BWD>), any other rnn_hidden on the streaming kernel (cluster 1 / 2 / 4 / 8)
 hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_frag, const float* h_fwd, float* delta,
                           unsigned* flags, int B, int T, int cluster, int num_cus, const Guard& gd, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (d.R != 512 || (long long)B * T * 512 * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (d.R != 512 || cluster < 4)
+        return launch_rnn_stream<true>(dH, whh_t_frag, delta, flags, B, T, d.R, cluster == kRnnRows4 ? 1 : cluster, num_cus, gd, h_fwd, s);
+    if ((long long)B * T * 512 * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
     if (cluster == kRnnRows4) {
         if (rnn_handoff_mode() == 1) return launch_rnn_rows4(dH, whh_t_frag, delta, flags, B, T, num_cus, false, gd, s, h_fwd);
@@ -1491,30 +1534,7 @@ hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, flo
         if (cluster == 8) return launch_rnn_resident<4, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, gd, s);
         if (cluster == 4) return launch_rnn_resident<8, 1>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, gd, s);
     }
-    if (cluster > 8) cluster = 8;
-    const int KB = R / 16;
-    while (cluster > 1 && (KB % (4 * cluster))) cluster >>= 1;
-    if (KB % (4 * cluster)) return hipErrorInvalidValue;
-    const int nbw = KB / (4 * cluster);
-    int groups = ntiles;
-    if (cluster > 1) {
-        // every workgroup of a cluster must be co-resident: keep the grid within one workgroup per CU
-        const int maxg = num_cus / cluster > 0 ? num_cus / cluster : 1;
-        if (groups > maxg) groups = maxg;
-        hipError_t e = hipMemsetAsync(flags, 0, (size_t)ntiles * T * sizeof(unsigned), s);
-        if (e != hipSuccess) return e;
-    }
-    const size_t smem = (size_t)kRnnTile * (R + 4) * sizeof(float);
-    const dim3 grid(groups * cluster), block(256);
-#define TIP_RNN_CASE(N) \
-    case N: hipLaunchKernelGGL(rnn_kernel<N>, grid, block, smem, s, ih, whh_frag, hall, flags, B, T, R, cluster, ntiles, gd); break;
-    switch (nbw) {
-        TIP_RNN_CASE(1) TIP_RNN_CASE(2) TIP_RNN_CASE(3) TIP_RNN_CASE(4) TIP_RNN_CASE(5) TIP_RNN_CASE(6)
-        TIP_RNN_CASE(7) TIP_RNN_CASE(8)
-        default: return hipErrorInvalidValue;
-    }
-#undef TIP_RNN_CASE
-    return hipGetLastError();
+    return launch_rnn_stream<false>(ih, whh_frag, hall, flags, B, T, R, cluster, num_cus, gd, nullptr, s);
 }
 
 }  // namespace tip

@@ -1323,14 +1323,14 @@ static TrainSaved saved_layout(const Dims& d, int B, int T) {
     L.bsum = take(off, d.R);
     L.whh_f = take(off, (size_t)d.R * d.R);
     L.whh_b = take(off, (size_t)d.R * d.R);
-    L.wout_t = take(off, (size_t)d.R * round_up(d.S, 16));
+    L.wout_t = take(off, (size_t)(d.with_rnn ? d.R : d.D) * round_up(d.S, 16));   // W_out^T [K_out][S padded]: K_out = R, or D without an RNN
     L.wih_t = take(off, (size_t)d.D * d.R);
     L.U = take(off, M * d.InPad);
     L.x0 = take(off, M * d.D);
     // the panel GEMM serves the layer-by-layer path; the paper configuration's fused kernels have their own images
     const bool frags = !(fused_supported(d, T) && fused_has_rnn_ih(d));
-    if (frags && panel_ok((int)M, d.R, d.D)) L.wih_f = take(off, (size_t)d.R * d.D);
-    if (frags && panel_ok((int)M, d.D, d.R)) L.wih_tf = take(off, (size_t)d.R * d.D);
+    if (frags && d.with_rnn && panel_ok((int)M, d.R, d.D)) L.wih_f = take(off, (size_t)d.R * d.D);
+    if (frags && d.with_rnn && panel_ok((int)M, d.D, d.R)) L.wih_tf = take(off, (size_t)d.R * d.D);
     if (!frags && win_gemm_shapes(d)) {   // the per-window kernels of the fused path (win_gemm_kernel, head_ksplit_kernel)
         L.wih_tf = take(off, (size_t)d.R * d.D);
         L.wout_tf = take(off, (size_t)d.R * 160);
@@ -1410,11 +1410,13 @@ static TrainScratch scratch_layout(const Dims& d, int B, int T) {
 }
 
 static bool train_supported(const Dims& d, int B, int T) {
-    if (!d.with_rnn || d.R != 512) return false;
+    // with_rnn = False (simple_transformer_with_state.py:43-46: the output projection reads the encoder) and any rnn_hidden the
+    // inference path serves (multiples of 64 up to 512; 512 runs on the register-resident cluster kernels, the rest on the streaming one)
+    if (d.with_rnn && (d.R % 64 != 0 || d.R > 512)) return false;
     if (d.D % 256 != 0 || d.D > 1024 || (d.D / 256 == 3)) return false;
     if (d.dh != 16 && d.dh != 32 && d.dh != 64) return false;
     if (d.F % 4 != 0 || T < 1 || T > 128 || B < 1 || 4 * d.L + 2 > kMaxTr) return false;
-    if ((long long)B * T * 512 * 4 > 0x7fffffffLL) return false;
+    if ((long long)B * T * (d.with_rnn ? d.R : d.D) * 4 > 0x7fffffffLL) return false;
     return true;
 }
 
@@ -1443,10 +1445,19 @@ hipError_t launch_gemm16(const float* A, int lda, const float* W, int ldw, const
     return tgemm16_launch(g, s);
 }
 
-static int auto_cluster(int B, int num_cus) {
-    static const bool rows4 = !(getenv("TIP_RNN_ROWS4") && getenv("TIP_RNN_ROWS4")[0] == '0');
-    if (rows4) return kRnnRows4;   // (training needs rnn_hidden 512 anyway)
+// workgroups per window tile of the two recurrences.  demoted (TIP_OPT_DEMOTED, after a lost hand-off): 1 — no inter-workgroup
+// hand-off in either direction (streaming kernel).  rnn_hidden 512: the register-resident clusters; other widths: as many
+// workgroups per 16-window tile of the streaming kernel as the tile count leaves CUs for.
+static int auto_cluster(const Dims& d, int B, int num_cus, bool demoted) {
+    if (demoted) return 1;
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
+    if (d.R != 512) {
+        int c = 8;
+        while (c > 1 && (ntiles * c > num_cus || (d.R / 16) % (4 * c))) c >>= 1;
+        return c;
+    }
+    static const bool rows4 = !(getenv("TIP_RNN_ROWS4") && getenv("TIP_RNN_ROWS4")[0] == '0');
+    if (rows4) return kRnnRows4;
     int c = 16;
     while (c > 4 && ntiles * c > num_cus) c >>= 1;
     return c;   // the resident kernel exists for 4 / 8 / 16
@@ -1537,6 +1548,10 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     float* W = static_cast<float*>(saved);
     const int M = B * T;
     const float* const* rp = params + P_LAYER0 + PL_COUNT * d.L;
+    // without an RNN (:43-46) the tail of the state dict is just linear.weight [S, D], linear.bias
+    const float* lin_w = d.with_rnn ? rp[PR_LIN_W] : rp[0];
+    const float* lin_b = d.with_rnn ? rp[PR_LIN_B] : rp[1];
+    const int Kout = d.with_rnn ? d.R : d.D;
 
     // Paper configuration: the encoder runs as ONE kernel (below) on a fused weight image, and the only other layouts the step
     // needs are W_hh in fragment order (forward / transposed for the backward) and the transposed W_out / W_ih of the two dX GEMMs
@@ -1546,14 +1561,15 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     if (!fused_prep) {
         hipLaunchKernelGGL(prep_in_kernel, dim3(grid_for((long long)d.D * d.InPad)), dim3(256), 0, s, params[P_IN_W], params[P_IN_B],
                            W + L.win_p, W + L.bin_p, d.D, d.H, d.In, d.InPad, d.n_imu_total + d.rootv0, d.n_imu_total + d.rootv1);
-        hipLaunchKernelGGL(prep_rnn_kernel, dim3(grid_for((long long)d.R * d.R)), dim3(256), 0, s, rp[PR_WHH], rp[PR_BIH], rp[PR_BHH],
-                           W + L.whh_f, W + L.whh_b, W + L.bsum, d.R);
+        if (d.with_rnn)
+            hipLaunchKernelGGL(prep_rnn_kernel, dim3(grid_for((long long)d.R * d.R)), dim3(256), 0, s, rp[PR_WHH], rp[PR_BIH], rp[PR_BHH],
+                               W + L.whh_f, W + L.whh_b, W + L.bsum, d.R);
         {
             TrBatch tb;
             tb.n = 0;
             int tiles = 0;
-            tr_add(tb, tiles, rp[PR_LIN_W], W + L.wout_t, d.S, d.R, round_up(d.S, 16));
-            tr_add(tb, tiles, rp[PR_WIH], W + L.wih_t, d.R, d.D, d.R);
+            tr_add(tb, tiles, lin_w, W + L.wout_t, d.S, Kout, round_up(d.S, 16));
+            if (d.with_rnn) tr_add(tb, tiles, rp[PR_WIH], W + L.wih_t, d.R, d.D, d.R);
             for (int l = 0; l < d.L; ++l) {
                 const float* const* lp = params + P_LAYER0 + PL_COUNT * l;
                 const TrainLayer& t = L.layers[l];
@@ -1610,7 +1626,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         const Drop dr = make_drop(p_drop, seed, 0);
         tr.seed = seed; tr.thresh = dr.thresh; tr.scale = dr.scale;
         // the encoder also pre-fills its windows' HALL rows with the recurrence's hand-off sentinel (saves a 21-MB memset)
-        hall_armed = rnn_uses_sentinel(d, B, T, auto_cluster(B, ecus));
+        hall_armed = rnn_uses_sentinel(d, B, T, auto_cluster(d, B, ecus, h->demoted != 0));
         static const bool padded = getenv("TIP_TRAIN_FWD_PADDED") != nullptr;   // A/B runs only (tools/train_bench.py)
         TT((padded ? launch_fused_train : launch_fused_train_h)(d, W + L.fused_img, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f,
                                                                  W + L.ih, hall_armed ? W + L.hall : nullptr, tr, B, T, ecus, s),
@@ -1626,8 +1642,10 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
             o.shuffle_h = 0; o.shuffle_dh = 0; o.z0 = 0; o.z1 = 0; o.scale_rows = 0; o.scale = 1.f; o.transpose = tr ? 1 : 0;
             ops.push_back(o);
         };
-        frag(rp[PR_WIH], L.wih_f, d.R, d.D, false);
-        frag(rp[PR_WIH], L.wih_tf, d.D, d.R, true);
+        if (d.with_rnn) {
+            frag(rp[PR_WIH], L.wih_f, d.R, d.D, false);
+            frag(rp[PR_WIH], L.wih_tf, d.D, d.R, true);
+        }
         for (int l = 0; l < d.L; ++l) {
             const float* const* lp = params + P_LAYER0 + PL_COUNT * l;
             const TrainLayer& t = L.layers[l];
@@ -1708,24 +1726,27 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         }
         x = W + t.xo;
     }
-    {
+    if (d.with_rnn) {
         TG g = tg_base(x, d.D, rp[PR_WIH], d.D, W + L.ih, d.R, M, d.R, d.D);
         g.bias = W + L.bsum;
         TT(lin_launch(g, L.wih_f ? W + L.wih_f : nullptr, s), "train_rnn_ih");
     }
     }   // layer-by-layer path
-    TT(launch_rnn(d, W + L.ih, W + L.whh_f, W + L.hall, reinterpret_cast<unsigned*>(W + L.flags), B, T, auto_cluster(B, ecus),
-                  ecus, hall_armed, h->guard(), s), "train_rnn");
+    // what the output projection reads: the RNN states, or the encoder output when there is no RNN
+    const float* head_in = d.with_rnn ? W + L.hall : (d.L ? W + L.layers[d.L - 1].xo : W + L.x0);
+    if (d.with_rnn)
+        TT(launch_rnn(d, W + L.ih, W + L.whh_f, W + L.hall, reinterpret_cast<unsigned*>(W + L.flags), B, T, auto_cluster(d, B, ecus, h->demoted != 0),
+                      ecus, hall_armed, h->guard(), s), "train_rnn");
     {
         // fused path, windows of 40 frames: the register-resident projection of the inference path (tip_head.hip) on fragments
         // packed from the live W_out (27 -> 17 us at B = 256); otherwise the LDS-tiled GEMM
         static const bool win_k = !(getenv("TIP_TRAIN_WIN_GEMM") && getenv("TIP_TRAIN_WIN_GEMM")[0] == '0');
         hipError_t he = hipErrorInvalidValue;
         if (win_k && fused && fused_prep && L.wout_f && T % 40 == 0)
-            he = launch_head_ksplit(W + L.hall, d.R, W + L.wout_f, rp[PR_LIN_B], y, d.S, M, d.S, d.R, false, ecus, s);
+            he = launch_head_ksplit(W + L.hall, d.R, W + L.wout_f, lin_b, y, d.S, M, d.S, d.R, false, ecus, s);
         if (he == hipErrorInvalidValue) {
-            TG g = tg_base(W + L.hall, d.R, rp[PR_LIN_W], d.R, y, d.S, M, d.S, d.R);
-            g.bias = rp[PR_LIN_B];
+            TG g = tg_base(head_in, Kout, lin_w, Kout, y, d.S, M, d.S, Kout);
+            g.bias = lin_b;
             he = tgemm16_launch(g, s);
         }
         TT(he, "train_head");
@@ -1766,6 +1787,10 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     const int Sp = round_up(d.S, 16);
     const int ncu = effective_cus(h->num_cus, s);   // the stream's CU mask counts (co-residency of the recurrence's clusters)
     const int rbase = P_LAYER0 + PL_COUNT * d.L;
+    // (without an RNN the tail of the state dict is linear.weight [S, D], linear.bias: :43-46)
+    const int g_lin_w = rbase + (d.with_rnn ? (int)PR_LIN_W : 0), g_lin_b = rbase + (d.with_rnn ? (int)PR_LIN_B : 1);
+    const int Kout = d.with_rnn ? d.R : d.D;
+    const float* head_in = d.with_rnn ? W + L.hall : (d.L ? W + L.layers[d.L - 1].xo : W + L.x0);
     float* part = X + S.part;
     float* colpart = X + S.colpart;
 
@@ -1788,13 +1813,20 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     {
         ColSide pad;      // dy [M][S] -> dyp [M][S padded to 16] rides in the bias-gradient launch
         pad.kind = 1; pad.src = dy; pad.dst = X + S.dyp; pad.n = d.S; pad.npad = Sp; pad.total = (long long)M * Sp;
-        TT(colsum(dy, d.S, M, d.S, col_multi ? X + S.colpart_out : colpart, grads + goff[rbase + PR_LIN_B], nullptr, s,
+        TT(colsum(dy, d.S, M, d.S, col_multi ? X + S.colpart_out : colpart, grads + goff[g_lin_b], nullptr, s,
                   col_multi ? &cm.src[2 * d.L] : nullptr, pad), "bwd_db_out");
     }
-    TT(grad_weight(X + S.dyp, Sp, Sp, d.S, W + L.hall, d.R, d.R, M, part, S.part_floats, grads + goff[rbase + PR_LIN_W], ncu, s),
+    TT(grad_weight(X + S.dyp, Sp, Sp, d.S, head_in, Kout, Kout, M, part, S.part_floats, grads + goff[g_lin_w], ncu, s),
        "bwd_dW_out");
     static const bool win_k = !(getenv("TIP_TRAIN_WIN_GEMM") && getenv("TIP_TRAIN_WIN_GEMM")[0] == '0');   // TIP_TRAIN_WIN_GEMM=0: measurement
     const bool win_g = win_k && fbwd && train_fused_prep(d, T) && L.wout_tf && T <= 40 && Sp <= 160 && Sp % 4 == 0;
+    float* gx = X + S.ga;     // gradient w.r.t. the current layer's output
+    float* galt = X + S.gb;
+    if (!d.with_rnn) {
+        // no RNN: the projection's input gradient IS the gradient of the encoder output
+        TG g = tg_base(X + S.dyp, Sp, W + L.wout_t, Sp, gx, d.D, M, d.D, Sp);
+        TT(tgemm16_launch(g, s), "bwd_d_enc");
+    } else {
     {
         hipError_t he = hipErrorInvalidValue;
         if (win_g) {
@@ -1809,14 +1841,14 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     }
     // ---- recurrence (:98-99), time reversed: delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2) -------------------------
     TT(launch_rnn_bwd(d, X + S.dh, W + L.whh_b, W + L.hall, X + S.delta, reinterpret_cast<unsigned*>(const_cast<float*>(W + L.flags)),
-                      B, T, auto_cluster(B, ncu), ncu, h->guard(), s), "bwd_rnn");
+                      B, T, auto_cluster(d, B, ncu, h->demoted != 0), ncu, h->guard(), s), "bwd_rnn");
     {
         ColSide sh;       // hprev[b,t] = h[b,t-1] (dW_hh's operand) rides in the recurrence-bias launch
         sh.kind = 2; sh.src = W + L.hall; sh.dst = X + S.hprev; sh.T = T; sh.R4 = d.R / 4; sh.total = (long long)M * d.R / 4;
         TT(colsum(X + S.delta, d.R, M, d.R, col_multi ? X + S.colpart_rnn : colpart, grads + goff[rbase + PR_BIH], grads + goff[rbase + PR_BHH],
                   s, col_multi ? &cm.src[2 * d.L + 1] : nullptr, sh), "bwd_db_rnn");
     }
-    const float* enc = W + L.layers[d.L - 1].xo;
+    const float* enc = d.L ? W + L.layers[d.L - 1].xo : W + L.x0;
     {
         // dW_hh = delta^T h_prev and dW_ih = delta^T x share delta and the row range: one launch
         const DwProb pr[2] = {{X + S.delta, d.R, d.R, X + S.hprev, d.R, d.R, grads + goff[rbase + PR_WHH]},
@@ -1831,8 +1863,6 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             TT(grad_weight(pr[1].dY, d.R, d.R, d.R, pr[1].X, d.D, d.D, M, part, S.part_floats, pr[1].out, ncu, s), "bwd_dW_ih");
         }
     }
-    float* gx = X + S.ga;     // gradient w.r.t. the current layer's output
-    float* galt = X + S.gb;
     {
         hipError_t he = hipErrorInvalidValue;
         if (win_g) {
@@ -1845,6 +1875,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
         }
         TT(he, "bwd_d_enc");
     }
+    }   // with_rnn
     // ---- encoder layers, last to first -----------------------------------------------------------------------------------
     // fused backward: the per-window LayerNorm / bias partials of every layer stay in place and are reduced by ONE launch after
     // the loop (two small launches per layer otherwise)
