@@ -620,6 +620,11 @@ def main():
                     traffic = None
             roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                        # achieved / frac / avg_launch_ms are measured in THIS run (event pairs around every launch of the kernel);
+                        # traffic is NOT: PMC counters need rocprofv3 passes of their own, so the number is the stored result of
+                        # tools/collect_profiles.sh's last collection (same kernel, same batch)
+                        "traffic_source": "profiles/traffic.json (stored: rocprofv3 PMC passes of tools/collect_profiles.sh, not measured by this run)"
+                        if traffic is not None else None,
                         "avg_launch_ms": avg_ms, "launches_timed": launches, "flops_per_launch": fl}
 
     extra = {}
