@@ -108,7 +108,7 @@ typedef enum tip_status {
 #define TIP_OPT_FUSE_HEAD 5 /* 1: the output projection (:102) runs as the epilogue of the four-window recurrence kernel instead of as a
                                launch of its own, when the launch qualifies (T = 40, full output, one tile per cluster, i.e. B <= 256 on
                                a full part); bit-identical results.  0 (default): separate launch.  Measured neutral to -1.2 us per
-                               step; kept selectable.  Environment TIP_RNN_HEAD=1 makes 1 the default. */
+                               step; kept selectable (CHANGELOG.md, round 3).  Environment TIP_RNN_HEAD=1 makes 1 the default. */
 
 #define TIP_OPT_PACK_SPLIT16 6 /* which EXPLORATORY split-fp16 weight copies the packed image carries (default 0: none).  Bit 0
                                  (TIP_PACK_SPLIT16_FUSED): the fused section's, for TIP_PLAN_FUSED16 (+15 MB for the paper configuration);

@@ -9,7 +9,7 @@ grows from 6e-7 to 1e-2.  The bar: for every plan AUTO can pick,
 
     |hip - y64| <= max(2e-5, 3 x the reference's own fp32 noise)     and     <= 1e-4 wherever that noise is < 2.5e-5.
 
-The measured ratios go to gpurun_out/cond_ratio.json (DESIGN.md section 3 quotes them)."""
+The measured ratios go to gpurun_out/cond_ratio.json (docs/DESIGN_NOTES_r01-r03.md section 3 quotes them)."""
 import json
 import os
 

@@ -729,7 +729,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if (plan == TIP_PLAN_AUTO) {
         // (a demoted handle — TIP_OPT_DEMOTED, after a lost hand-off — takes no cooperating kernel: the latency plan's GEMV recurrence is one)
         // (TIP_PLAN_LATENCY1, the same chain as one persistent kernel, is opt-in: measured 181-207 us against the chain's 176 at B = 1 —
-        // the stage bodies, not the kernel boundaries, bound the chain; DESIGN.md section 5.  TIP_LAT1=1 makes AUTO take it: measurement.)
+        // the stage bodies, not the kernel boundaries, bound the chain; CHANGELOG.md, round 4.  TIP_LAT1=1 makes AUTO take it: measurement.)
         static const bool lat1 = getenv("TIP_LAT1") && getenv("TIP_LAT1")[0] == '1';
         if (!h->demoted && lat1 && cus == h->num_cus && latency1_supported(d, B, T)) plan = TIP_PLAN_LATENCY1;
         else if (!h->demoted && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;   // <= 64 streams: spread each window over many CUs (0.65 vs 0.86 ms at B = 64)

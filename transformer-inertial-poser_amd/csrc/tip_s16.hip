@@ -2,7 +2,7 @@
 // the fused one-window encoder with every GEMM's fp32 operands EMULATED on the fp16 matrix cores.
 //
 // gfx950 multiplies f32-input MFMAs at 1/16 of the f16 rate (MI355X_MICROARCH.md), and the encoder is bound by exactly that
-// (DESIGN.md section 5).  Here both operands of a product are split
+// (docs/DESIGN_NOTES_r01-r03.md section 9).  Here both operands of a product are split
 //     x = xh + xl * 2^-11,   xh = fp16(x),   xl = fp16((x - xh) * 2^11)
 // (weights once, at pack time; activations in the epilogue that produces them) and
 //     x * w ~= xh wh + (xh wl + xl wh) * 2^-11              (the xl wl * 2^-22 term is dropped)
