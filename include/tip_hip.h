@@ -11,7 +11,7 @@
  * device memory (packed weights and workspace are caller-provided buffers; the one allocation is a 64-byte pinned HOST
  * block per handle, the hand-off error word of tip_check).  Arithmetic is fp32; the reference's `--double` switch
  * (train_model.py:84-85) is served by tip_forward_f64 (fp64 parameters and windows, every operation in IEEE double) for the
- * forward, and by the Python host's torch-op composite for the training step.  Tensors are never converted silently.
+ * forward and by tip_train_forward_f64 / tip_train_backward_f64 for the training step.  Tensors are never converted silently.
  */
 #ifndef TIP_HIP_H
 #define TIP_HIP_H
@@ -269,6 +269,20 @@ TIP_API int tip_train_forward(tip_handle* h, const float* const* params, int n_p
 TIP_API int tip_train_backward(tip_handle* h, const float* const* params, int n_params, const float* dy, const void* saved,
                        size_t saved_bytes, void* scratch, size_t scratch_bytes, float* grads, size_t grads_floats, float p_drop,
                        unsigned long long seed, int B, int T, tip_stream_t stream);
+
+/* ---- the same step for a module built under `--double` (train_model.py:84-85): fp64 parameters (raw, state-dict order), windows,
+ *      keep mask, cotangent and gradients; same dropout decisions as the fp32 step for the same seed (kept values scaled by the fp32
+ *      value of 1 / (1 - p), widened).  Any configuration tip_forward_f64 serves (with or without the RNN, any widths) with T <= 128 and
+ *      (4 T d_head + 2 T^2) doubles of LDS <= 160 KB (attention backward: T <= 90 at head width 16) — else TIP_ERR_UNSUPPORTED_CONFIG.
+ *      A debugging / verification path like tip_forward_f64: layer by layer, deterministic, not tuned.  saved / scratch: 256-byte
+ *      aligned, tip_train_bytes_f64(); grads: one flat fp64 buffer, tensors in tip_tensor_info() order. */
+TIP_API int tip_train_bytes_f64(const tip_handle* h, int B, int T, size_t* saved_bytes, size_t* scratch_bytes);
+TIP_API int tip_train_forward_f64(tip_handle* h, const double* const* params, int n_params, const double* x_imu, const double* x_s,
+                          const double* keep_mask, double keep_scale, float p_drop, unsigned long long seed, double* y, void* saved,
+                          size_t saved_bytes, int B, int T, tip_stream_t stream);
+TIP_API int tip_train_backward_f64(tip_handle* h, const double* const* params, int n_params, const double* dy, const void* saved,
+                           size_t saved_bytes, void* scratch, size_t scratch_bytes, double* grads, size_t grads_doubles, float p_drop,
+                           unsigned long long seed, int B, int T, tip_stream_t stream);
 
 /* ---- train-set combiner and window gather -------------------------------------------------
  * tip_combine_sequence replaces the per-file body of store_imu_s_info (preprocess_and_combine_syn_amass.py:73-101):

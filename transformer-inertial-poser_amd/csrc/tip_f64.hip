@@ -322,3 +322,601 @@ int tip_forward_f64(tip_handle* h, const double* const* params, int n_params, co
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Training step in fp64: the model call of train_model.py:175 and its backward (:192) for a module built under `--double`
+// (:84-85).  Same contract as tip_train_forward / tip_train_backward (include/tip_hip.h) with double tensors: raw fp64 parameters
+// in state-dict order, the four dropout sites of every nn.TransformerEncoderLayer from the same counter-based hash (same keep
+// decisions as the fp32 step for the same seed; kept values scaled by the fp32 value of 1 / (1 - p), widened), activations
+// stashed in `saved`, gradients as one flat fp64 buffer in state-dict order.  Like the fp64 forward this is the debugging /
+// verification path of the training script: built for exactness and any configuration (with or without the RNN, any widths),
+// layer by layer, deterministic (fixed-order reductions), not tuned.
+// =====================================================================================================================
+namespace tip {
+namespace f64 {
+
+struct DropD {
+    unsigned key, thresh;
+    double scale;
+};
+static DropD make_drop_d(float p, unsigned long long seed, unsigned site) {
+    DropD d;
+    d.key = tip_drop_key(seed, site);
+    if (p <= 0.f) { d.thresh = 0; d.scale = 1.0; return d; }
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    d.thresh = (unsigned)t;
+    if (d.thresh == 0) d.thresh = 1;
+    d.scale = (double)(1.0f / (1.0f - p));
+    return d;
+}
+__device__ __forceinline__ double drop_factor(const DropD& d, unsigned long long idx) {
+    if (!d.thresh) return 1.0;
+    return tip_drop_hash_k(d.key, (unsigned)idx) >= d.thresh ? d.scale : 0.0;
+}
+
+// y[i] = (res ? res[i] : 0) + x[i] * keep(i)   (dropout sites 1 / 3 with their residual; site 2 in place with res = null)
+__global__ void drop_res_kernel(const double* __restrict__ x, const double* __restrict__ res, double* __restrict__ y, long long n, DropD d) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = (res ? res[i] : 0.0) + x[i] * drop_factor(d, (unsigned long long)i);
+}
+
+// attention with dropout on the probabilities (site 4 l): one wave per (window, head, query); P is recomputed by the backward
+__global__ __launch_bounds__(64) void attention_train_kernel(const double* __restrict__ qkv, double* __restrict__ att, int T, int D, int H,
+                                                            int dh, double scale, DropD dr) {
+    extern __shared__ double p[];   // [T]
+    const int lane = threadIdx.x;
+    const long long u = blockIdx.x;
+    const int i = (int)(u % T);
+    const int hd = (int)((u / T) % H);
+    const long long b = u / ((long long)T * H);
+    const double* base = qkv + b * T * 3 * D;
+    const double* q = base + (long long)i * 3 * D + hd * dh;
+    double mx = -INFINITY;
+    for (int j = lane; j <= i; j += 64) {
+        const double* k = base + (long long)j * 3 * D + D + hd * dh;
+        double s = 0.0;
+        for (int e = 0; e < dh; ++e) s += (q[e] * scale) * k[e];
+        p[j] = s;
+        mx = s > mx ? s : mx;
+    }
+    mx = wave_max(mx);
+    double den = 0.0;
+    for (int j = lane; j <= i; j += 64) {
+        const double e_ = exp(p[j] - mx);
+        p[j] = e_;
+        den += e_;
+    }
+    den = wave_sum(den);
+    for (int j = lane; j <= i; j += 64)
+        p[j] = (p[j] / den) * drop_factor(dr, (unsigned long long)((b * H + hd) * T + i) * T + j);
+    __syncthreads();
+    for (int e = lane; e < dh; e += 64) {
+        double o = 0.0;
+        for (int j = 0; j <= i; ++j) o += p[j] * base[(long long)j * 3 * D + 2 * D + hd * dh + e];
+        att[(b * T + i) * D + hd * dh + e] = o;
+    }
+}
+
+// attention backward: one workgroup per (window, head).  dqkv rows of this head <- d(att) of this head.
+//   P_ij = softmax_j(q_i k_j * scale), Pd = P * keep; O = Pd V;  dPd_ij = dO_i . v_j;  dV_j = sum_i Pd_ij dO_i;
+//   dP = dPd * keep;  dS_ij = P_ij (dP_ij - sum_k dP_ik P_ik);  dq_i = scale sum_j dS_ij k_j;  dk_j = scale sum_i dS_ij q_i
+__global__ __launch_bounds__(128) void attention_bwd_kernel(const double* __restrict__ qkv, const double* __restrict__ datt, double* __restrict__ dqkv,
+                                                            int T, int D, int H, int dh, double scale, DropD dr) {
+    extern __shared__ double sm[];   // q, k, v, do: [T][dh] each; P, dS: [T][T]
+    double* qs = sm;
+    double* ks = qs + T * dh;
+    double* vs = ks + T * dh;
+    double* dos = vs + T * dh;
+    double* P = dos + T * dh;
+    double* dS = P + T * T;
+    const int hd = blockIdx.x % H;
+    const long long b = blockIdx.x / H;
+    const double* base = qkv + b * T * 3 * D;
+    for (int i = threadIdx.x; i < T * dh; i += blockDim.x) {
+        const int r = i / dh, e = i - r * dh;
+        qs[i] = base[(long long)r * 3 * D + hd * dh + e];
+        ks[i] = base[(long long)r * 3 * D + D + hd * dh + e];
+        vs[i] = base[(long long)r * 3 * D + 2 * D + hd * dh + e];
+        dos[i] = datt[(b * T + r) * D + hd * dh + e];
+    }
+    __syncthreads();
+    // one thread per query row: softmax, then dS of the row
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+        double mx = -INFINITY;
+        for (int j = 0; j <= i; ++j) {
+            double s = 0.0;
+            for (int e = 0; e < dh; ++e) s += (qs[i * dh + e] * scale) * ks[j * dh + e];
+            P[i * T + j] = s;
+            mx = s > mx ? s : mx;
+        }
+        double den = 0.0;
+        for (int j = 0; j <= i; ++j) { const double e_ = exp(P[i * T + j] - mx); P[i * T + j] = e_; den += e_; }
+        double dot = 0.0;
+        for (int j = 0; j <= i; ++j) {
+            const double pij = P[i * T + j] / den;
+            const double kf = drop_factor(dr, (unsigned long long)((b * H + hd) * T + i) * T + j);
+            double dpd = 0.0;
+            for (int e = 0; e < dh; ++e) dpd += dos[i * dh + e] * vs[j * dh + e];
+            const double dp = dpd * kf;
+            P[i * T + j] = pij;
+            dS[i * T + j] = dp;           // dP for now
+            dot += dp * pij;
+        }
+        for (int j = 0; j <= i; ++j) dS[i * T + j] = P[i * T + j] * (dS[i * T + j] - dot);
+        for (int j = i + 1; j < T; ++j) { P[i * T + j] = 0.0; dS[i * T + j] = 0.0; }
+    }
+    __syncthreads();
+    double* out = dqkv + b * T * 3 * D;
+    for (int i = threadIdx.x; i < T * dh; i += blockDim.x) {
+        const int r = i / dh, e = i - r * dh;
+        double dq = 0.0, dk = 0.0, dv = 0.0;
+        for (int j = 0; j <= r; ++j) dq += dS[r * T + j] * ks[j * dh + e];
+        for (int ii = r; ii < T; ++ii) {
+            dk += dS[ii * T + r] * qs[ii * dh + e];
+            dv += P[ii * T + r] * drop_factor(dr, (unsigned long long)((b * H + hd) * T + ii) * T + r) * dos[ii * dh + e];
+        }
+        out[(long long)r * 3 * D + hd * dh + e] = dq * scale;
+        out[(long long)r * 3 * D + D + hd * dh + e] = dk * scale;
+        out[(long long)r * 3 * D + 2 * D + hd * dh + e] = dv;
+    }
+}
+
+// LayerNorm forward into a separate output (the pre-norm sum is kept for the backward)
+__global__ __launch_bounds__(64) void ln_fwd_kernel(const double* __restrict__ Z, const double* __restrict__ g, const double* __restrict__ be,
+                                                   double* __restrict__ X, int D) {
+    const double* z = Z + (long long)blockIdx.x * D;
+    double* x = X + (long long)blockIdx.x * D;
+    const int lane = threadIdx.x;
+    double s = 0.0;
+    for (int c = lane; c < D; c += 64) s += z[c];
+    const double mean = wave_sum(s) / D;
+    double v = 0.0;
+    for (int c = lane; c < D; c += 64) { const double d = z[c] - mean; v += d * d; }
+    const double rstd = 1.0 / sqrt(wave_sum(v) / D + 1e-5);
+    for (int c = lane; c < D; c += 64) x[c] = (z[c] - mean) * rstd * g[c] + be[c];
+}
+// LayerNorm backward: dz = rstd (dxh - mean(dxh) - xh mean(dxh xh)), dxh = dy g; dgx = dy xh (column sums of dgx / dy = dgamma / dbeta)
+__global__ __launch_bounds__(64) void ln_bwd_kernel(const double* __restrict__ Z, const double* __restrict__ g, const double* __restrict__ dY,
+                                                   double* __restrict__ dZ, double* __restrict__ dGX, int D) {
+    const long long r = blockIdx.x;
+    const double* z = Z + r * D;
+    const double* dy = dY + r * D;
+    const int lane = threadIdx.x;
+    double s = 0.0;
+    for (int c = lane; c < D; c += 64) s += z[c];
+    const double mean = wave_sum(s) / D;
+    double v = 0.0;
+    for (int c = lane; c < D; c += 64) { const double d = z[c] - mean; v += d * d; }
+    const double rstd = 1.0 / sqrt(wave_sum(v) / D + 1e-5);
+    double a = 0.0, bsum = 0.0;
+    for (int c = lane; c < D; c += 64) {
+        const double xh = (z[c] - mean) * rstd, dxh = dy[c] * g[c];
+        a += dxh;
+        bsum += dxh * xh;
+    }
+    a = wave_sum(a) / D;
+    bsum = wave_sum(bsum) / D;
+    for (int c = lane; c < D; c += 64) {
+        const double xh = (z[c] - mean) * rstd, dxh = dy[c] * g[c];
+        dZ[r * D + c] = rstd * (dxh - a - xh * bsum);
+        dGX[r * D + c] = dy[c] * xh;
+    }
+}
+
+// out[c] (+= when acc) = sum over rows of x[r][c]: 256 rows per block in a fixed order, then a fixed-order pass over the blocks
+__global__ __launch_bounds__(256) void colsum_part_kernel(const double* __restrict__ x, int ld, long long M, int N, double* __restrict__ part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const long long r0 = (long long)blockIdx.y * 256, r1 = r0 + 256 < M ? r0 + 256 : M;
+    double s = 0.0;
+    for (long long r = r0; r < r1; ++r) s += x[r * ld + c];
+    part[(long long)blockIdx.y * N + c] = s;
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ part, int nparts, int N, double* __restrict__ out, double* __restrict__ out2) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    double s = 0.0;
+    for (int p_ = 0; p_ < nparts; ++p_) s += part[(long long)p_ * N + c];
+    out[c] = s;
+    if (out2) out2[c] = s;
+}
+
+// dW[N][K] partials: part[z][n][k] = sum over the rows of slice z of dY[m][n] X[m][k]  (64 x 64 tiles, fp64 matrix cores)
+constexpr int TNS = 64;   // rows of a split
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const double* __restrict__ dY, int ldy, const double* __restrict__ X, int ldx, long long M,
+                                                      int N, int K, long long rows_per_split, double* __restrict__ part) {
+    __shared__ double Ys[KC * (TM + 1)], Xs[KC * (TN + 1)];   // [m][n], [m][k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int n0 = blockIdx.y * TM, k0 = blockIdx.x * TN;
+    const long long m0 = (long long)blockIdx.z * rows_per_split, m1 = m0 + rows_per_split < M ? m0 + rows_per_split : M;
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    const int lm = tid >> 4, lc = (tid & 15) * 4;   // this thread stages 4 consecutive columns of row lm of both operands
+    for (long long mm = m0; mm < m1; mm += KC) {
+        double yv[4], xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long m = mm + lm;
+            yv[q] = (m < m1 && n0 + lc + q < N) ? dY[m * ldy + n0 + lc + q] : 0.0;
+            xv[q] = (m < m1 && k0 + lc + q < K) ? X[m * ldx + k0 + lc + q] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            Ys[lm * (TM + 1) + lc + q] = yv[q];
+            Xs[lm * (TN + 1) + lc + q] = xv[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KC / 4; ++s) {
+            double a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = Ys[(4 * s + lg) * (TM + 1) + wr * 32 + i * 16 + l15];
+                b[i] = Xs[(4 * s + lg) * (TN + 1) + wc * 32 + i * 16 + l15];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    double* P = part + (long long)blockIdx.z * N * K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + wc * 32 + j * 16 + l15;
+            if (k >= K) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + wr * 32 + i * 16 + e * 4 + lg;
+                if (n < N) P[(long long)n * K + k] = acc[i][j][e];
+            }
+        }
+}
+// out[map(n)][k] = sum_z part[z][n][k]; shuffle (H > 0): row n = a*H + b of the product is row b*dh + a of the tensor (:88-89 undone);
+// columns [z0, z1) are written as 0 (the root-velocity columns :75 never reach the model)
+__global__ __launch_bounds__(256) void splitk_sum_kernel(const double* __restrict__ part, int nsplit, int N, int K, double* __restrict__ out,
+                                                         int H, int dh, int z0, int z1) {
+    const long long total = (long long)N * K;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+        double s = 0.0;
+        for (int z = 0; z < nsplit; ++z) s += part[(long long)z * total + i];
+        const int on = H ? (n % H) * dh + n / H : n;
+        out[(long long)on * K + k] = (k >= z0 && k < z1) ? 0.0 : s;
+    }
+}
+__global__ void unshuffle_vec_kernel(const double* __restrict__ in, double* __restrict__ out, int D, int H, int dh) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < D) out[(n % H) * dh + n / H] = in[n];
+}
+
+// general transpose: out[c][r] = in[r][c]
+__global__ void transpose2_kernel(const double* __restrict__ in, double* __restrict__ out, int rows, int cols) {
+    const long long n = (long long)rows * cols;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i / rows), r = (int)(i - (long long)c * rows);
+        out[i] = in[(long long)r * cols + c];
+    }
+}
+
+// dpre = dhid * [hid > 0] * scale2   (hid is stored after ReLU and dropout: > 0 exactly where the unit's gate is open)
+__global__ void relu_gate_kernel(const double* __restrict__ dhid, const double* __restrict__ hid, double* __restrict__ dpre, long long n, double scale) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dpre[i] = hid[i] > 0.0 ? dhid[i] * scale : 0.0;
+}
+__global__ void add_kernel(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ y, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = a[i] + b[i];
+}
+
+// backward recurrence: delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2); one workgroup per window; also hprev[t] = h[t-1]
+// (dH and hprev may be the SAME buffer: a thread reads dH[b,t,c] before it writes hprev[b,t,c]; hence no __restrict__ on the two)
+__global__ void rnn_bwd_kernel(const double* dH, const double* __restrict__ Whh, const double* __restrict__ HALL,
+                               double* __restrict__ delta, double* hprev, int T, int R) {
+    extern __shared__ double dbuf[];   // [2][R]
+    const long long b = blockIdx.x;
+    for (int c = threadIdx.x; c < R; c += blockDim.x) dbuf[c] = 0.0;
+    __syncthreads();
+    for (int st = 0; st < T; ++st) {
+        const int t = T - 1 - st;
+        const double* dn = dbuf + (st & 1) * R;
+        double* dc = dbuf + ((st + 1) & 1) * R;
+        for (int c = threadIdx.x; c < R; c += blockDim.x) {
+            double a = 0.0;
+            if (st > 0)
+                for (int k = 0; k < R; ++k) a += dn[k] * Whh[(long long)k * R + c];   // (delta_{t+1} W_hh)[c]
+            const double h = HALL[(b * T + t) * R + c];
+            const double v = (dH[(b * T + t) * R + c] + a) * (1.0 - h * h);
+            dc[c] = v;
+            delta[(b * T + t) * R + c] = v;
+            hprev[(b * T + t) * R + c] = t > 0 ? HALL[(b * T + t - 1) * R + c] : 0.0;
+        }
+        __syncthreads();
+    }
+}
+
+struct TrainLay {
+    // saved (doubles)
+    size_t U, X0, IH, HALL, WT, total_saved;
+    size_t qkv[16], att[16], z1[16], x1[16], hid[16], z2[16], xo[16];
+    // scratch (doubles)
+    size_t ga, gb, gc, gbig, gbig2, wt, part, colpart, dwin, dbin, total_scratch;
+    int nsplit;
+    long long rows_per_split;
+};
+constexpr int kMaxLayersF64 = 16;
+
+static TrainLay train_layout(const Dims& d, int B, int T) {
+    TrainLay L{};
+    const size_t M = (size_t)B * T;
+    auto al = [](size_t v) { return (v + 31) & ~(size_t)31; };
+    size_t o = 0;
+    L.U = o; o += al(M * d.In);
+    L.X0 = o; o += al(M * d.D);
+    for (int l = 0; l < d.L; ++l) {
+        L.qkv[l] = o; o += al(M * 3 * d.D);
+        L.att[l] = o; o += al(M * d.D);
+        L.z1[l] = o; o += al(M * d.D);
+        L.x1[l] = o; o += al(M * d.D);
+        L.hid[l] = o; o += al(M * d.F);
+        L.z2[l] = o; o += al(M * d.D);
+        L.xo[l] = o; o += al(M * d.D);
+    }
+    L.IH = o; o += al(d.with_rnn ? M * d.R : 0);
+    L.HALL = o; o += al(d.with_rnn ? M * d.R : 0);
+    L.WT = o; o += al(d.with_rnn ? (size_t)d.R * d.R : 0);   // W_hh^T for the forward recurrence
+    L.total_saved = o;
+    o = 0;
+    size_t wide = 3 * (size_t)d.D;
+    if ((size_t)d.F > wide) wide = d.F;
+    if ((size_t)d.R > wide) wide = d.R;
+    if ((size_t)round_up(d.S, 4) > wide) wide = round_up(d.S, 4);
+    L.ga = o; o += al(M * d.D);
+    L.gb = o; o += al(M * d.D);
+    L.gc = o; o += al(M * d.D);
+    L.gbig = o; o += al(M * wide);
+    L.gbig2 = o; o += al(M * wide);
+    size_t wmax = (size_t)d.F * d.D;
+    for (size_t v : {(size_t)3 * d.D * d.D, (size_t)d.R * d.R, (size_t)d.R * d.D, (size_t)d.S * (d.with_rnn ? d.R : d.D), (size_t)d.D * d.In})
+        if (v > wmax) wmax = v;
+    L.wt = o; o += al(wmax);
+    L.rows_per_split = 512;
+    L.nsplit = (int)((M + L.rows_per_split - 1) / L.rows_per_split);
+    if (L.nsplit > 64) { L.nsplit = 64; L.rows_per_split = (long long)((M + 63) / 64); L.rows_per_split = (L.rows_per_split + KC - 1) / KC * KC; L.nsplit = (int)((M + L.rows_per_split - 1) / L.rows_per_split); }
+    L.part = o; o += al(wmax * L.nsplit);
+    L.colpart = o; o += al(((M + 255) / 256) * wide);
+    L.dwin = o; o += al((size_t)d.D * d.In);
+    L.dbin = o; o += al(d.D);
+    L.total_scratch = o;
+    return L;
+}
+
+static int grid_n(long long n) { const long long g = (n + 255) / 256; return (int)(g < 65536 ? (g > 0 ? g : 1) : 65536); }
+
+}  // namespace f64
+}  // namespace tip
+
+extern "C" {
+
+int tip_train_bytes_f64(const tip_handle* h, int B, int T, size_t* saved_bytes, size_t* scratch_bytes) {
+    if (!h || B < 0 || T < 0) return TIP_ERR_INVALID_ARG;
+    const Dims& d = h->d;
+    if (d.L > f64::kMaxLayersF64 || T > 128) return TIP_ERR_UNSUPPORTED_CONFIG;   // attention backward keeps two T x T tiles in LDS
+    const long long M = (long long)B * T;
+    if (M * (long long)(3 * d.D > d.F ? 3 * d.D : d.F) > 0x7fffffffLL || M * d.H > 0x7fffffffLL || M > 65535LL * f64::TM) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if ((size_t)(4 * T * d.dh + 2 * T * T) * sizeof(double) > 160 * 1024) return TIP_ERR_UNSUPPORTED_CONFIG;
+    const f64::TrainLay L = f64::train_layout(d, B > 0 ? B : 1, T > 0 ? T : 1);
+    if (saved_bytes) *saved_bytes = L.total_saved * sizeof(double) + 256;
+    if (scratch_bytes) *scratch_bytes = L.total_scratch * sizeof(double) + 256;
+    return TIP_OK;
+}
+
+int tip_train_forward_f64(tip_handle* h, const double* const* params, int n_params, const double* x_imu, const double* x_s,
+                          const double* keep_mask, double keep_scale, float p_drop, unsigned long long seed, double* y, void* saved,
+                          size_t saved_bytes, int B, int T, void* stream) {
+    if (!h || !params || !x_imu || !x_s || !y || !saved || B < 1 || T < 1) return TIP_ERR_INVALID_ARG;
+    if (n_params != (int)h->tensor_names.size()) return TIP_ERR_INVALID_ARG;
+    if (p_drop < 0.f || p_drop >= 1.f) return TIP_ERR_INVALID_ARG;
+    size_t need = 0;
+    const int st = tip_train_bytes_f64(h, B, T, &need, nullptr);
+    if (st != TIP_OK) return st;
+    if (reinterpret_cast<uintptr_t>(saved) % 256 || saved_bytes < need - 256) return TIP_ERR_WORKSPACE;
+    const Dims& d = h->d;
+    const f64::TrainLay L = f64::train_layout(d, B, T);
+    const long long M = (long long)B * T;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* W = static_cast<double*>(saved);
+    auto fail = [&](hipError_t e, const char* what) {
+        h->last_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+        return (int)TIP_ERR_HIP;
+    };
+    CoopSerial serial(h->device, s);
+    if (serial.status != hipSuccess) return fail(serial.status, "stream serialisation");
+#define TF(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_, what); } while (0)
+    const double* const* tw = params + 2 + 12 * d.L;
+    hipLaunchKernelGGL(f64::prologue_kernel, dim3(f64::grid_n(M * d.In)), dim3(256), 0, s, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.0, W + L.U,
+                       M, d.n_imu_total, d.S, d.rootv0, d.rootv1);
+    TF(hipGetLastError(), "f64 train prologue");
+    TF(f64::gemm(4, W + L.U, d.In, params[0], params[1], nullptr, 0, W + L.X0, d.D, M, d.D, d.In, d.H, d.dh, s), "f64 train in_linear");
+    const double scale = 1.0 / sqrt((double)d.dh);
+    const double* x = W + L.X0;
+    for (int l = 0; l < d.L; ++l) {
+        const double* const* lp = params + 2 + 12 * l;
+        TF(f64::gemm(0, x, d.D, lp[0], lp[1], nullptr, 0, W + L.qkv[l], 3 * d.D, M, 3 * d.D, d.D, 0, 1, s), "f64 train in_proj");
+        hipLaunchKernelGGL(f64::attention_train_kernel, dim3((unsigned)(M * d.H)), dim3(64), (size_t)T * sizeof(double), s, W + L.qkv[l],
+                           W + L.att[l], T, d.D, d.H, d.dh, scale, f64::make_drop_d(p_drop, seed, 4 * l + 0));
+        TF(hipGetLastError(), "f64 train attention");
+        // z1 = x + drop1(att Wo^T + bo): the product lands in z1, then the dropout / residual pass rewrites it in place
+        TF(f64::gemm(0, W + L.att[l], d.D, lp[2], lp[3], nullptr, 0, W + L.z1[l], d.D, M, d.D, d.D, 0, 1, s), "f64 train out_proj");
+        hipLaunchKernelGGL(f64::drop_res_kernel, dim3(f64::grid_n(M * d.D)), dim3(256), 0, s, W + L.z1[l], x, W + L.z1[l], M * d.D,
+                           f64::make_drop_d(p_drop, seed, 4 * l + 1));
+        hipLaunchKernelGGL(f64::ln_fwd_kernel, dim3((unsigned)M), dim3(64), 0, s, W + L.z1[l], lp[8], lp[9], W + L.x1[l], d.D);
+        TF(hipGetLastError(), "f64 train norm1");
+        TF(f64::gemm(1, W + L.x1[l], d.D, lp[4], lp[5], nullptr, 0, W + L.hid[l], d.F, M, d.F, d.D, 0, 1, s), "f64 train linear1");
+        hipLaunchKernelGGL(f64::drop_res_kernel, dim3(f64::grid_n(M * d.F)), dim3(256), 0, s, W + L.hid[l], (const double*)nullptr, W + L.hid[l],
+                           M * d.F, f64::make_drop_d(p_drop, seed, 4 * l + 2));
+        TF(f64::gemm(0, W + L.hid[l], d.F, lp[6], lp[7], nullptr, 0, W + L.z2[l], d.D, M, d.D, d.F, 0, 1, s), "f64 train linear2");
+        hipLaunchKernelGGL(f64::drop_res_kernel, dim3(f64::grid_n(M * d.D)), dim3(256), 0, s, W + L.z2[l], W + L.x1[l], W + L.z2[l], M * d.D,
+                           f64::make_drop_d(p_drop, seed, 4 * l + 3));
+        hipLaunchKernelGGL(f64::ln_fwd_kernel, dim3((unsigned)M), dim3(64), 0, s, W + L.z2[l], lp[10], lp[11], W + L.xo[l], d.D);
+        TF(hipGetLastError(), "f64 train norm2");
+        x = W + L.xo[l];
+    }
+    const double* feat = x;
+    int fw = d.D;
+    if (d.with_rnn) {
+        TF(f64::gemm(0, x, d.D, tw[0], tw[2], nullptr, 0, W + L.IH, d.R, M, d.R, d.D, 0, 1, s), "f64 train rnn W_ih");
+        hipLaunchKernelGGL(f64::transpose_kernel, dim3(f64::grid_n((long long)d.R * d.R)), dim3(256), 0, s, tw[1], W + L.WT, d.R);
+        const int threads = d.R < 1024 ? ((d.R + 63) / 64) * 64 : 1024;
+        hipLaunchKernelGGL(f64::rnn_kernel, dim3(B), dim3(threads), 2 * (size_t)d.R * sizeof(double), s, W + L.IH, W + L.WT, tw[3], W + L.HALL, T, d.R);
+        TF(hipGetLastError(), "f64 train rnn");
+        feat = W + L.HALL;
+        fw = d.R;
+        tw += 4;
+    }
+    TF(f64::gemm(0, feat, fw, tw[0], tw[1], nullptr, 0, y, d.S, M, d.S, fw, 0, 1, s), "f64 train linear");
+#undef TF
+    ++h->forward_count;
+    return TIP_OK;
+}
+
+int tip_train_backward_f64(tip_handle* h, const double* const* params, int n_params, const double* dy, const void* saved, size_t saved_bytes,
+                           void* scratch, size_t scratch_bytes, double* grads, size_t grads_doubles, float p_drop, unsigned long long seed,
+                           int B, int T, void* stream) {
+    if (!h || !params || !dy || !saved || !scratch || !grads || B < 1 || T < 1) return TIP_ERR_INVALID_ARG;
+    if (n_params != (int)h->tensor_names.size()) return TIP_ERR_INVALID_ARG;
+    size_t need_s = 0, need_x = 0;
+    const int st = tip_train_bytes_f64(h, B, T, &need_s, &need_x);
+    if (st != TIP_OK) return st;
+    if (reinterpret_cast<uintptr_t>(saved) % 256 || saved_bytes < need_s - 256) return TIP_ERR_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(scratch) % 256 || scratch_bytes < need_x - 256) return TIP_ERR_WORKSPACE;
+    const Dims& d = h->d;
+    const f64::TrainLay L = f64::train_layout(d, B, T);
+    const long long M = (long long)B * T;
+    std::vector<size_t> goff(n_params);
+    size_t gtot = 0;
+    for (int i = 0; i < n_params; ++i) {
+        goff[i] = gtot;
+        const auto& sh = h->tensor_shapes[i];
+        gtot += (size_t)sh.first * (sh.second ? sh.second : 1);
+    }
+    if (grads_doubles < gtot) return TIP_ERR_INVALID_ARG;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const double* W = static_cast<const double*>(saved);
+    double* X = static_cast<double*>(scratch);
+    auto fail = [&](hipError_t e, const char* what) {
+        h->last_hip_error = std::string(what) + ": " + hipGetErrorString(e);
+        return (int)TIP_ERR_HIP;
+    };
+    CoopSerial serial(h->device, s);
+    if (serial.status != hipSuccess) return fail(serial.status, "stream serialisation");
+#define TF(expr, what) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail(e_, what); } while (0)
+    // out[N][K] = dY^T X (fixed-order split over the rows); shuffle / zeroed columns for in_linear only
+    auto grad_w = [&](const double* dYp, int ldy, const double* Xp, int ldx, int N, int K, double* out, int H = 0, int dh = 0, int z0 = 0, int z1 = 0) -> hipError_t {
+        const dim3 grid((K + f64::TN - 1) / f64::TN, (N + f64::TM - 1) / f64::TM, L.nsplit);
+        hipLaunchKernelGGL(f64::gemm_tn_kernel, grid, dim3(256), 0, s, dYp, ldy, Xp, ldx, M, N, K, L.rows_per_split, X + L.part);
+        hipLaunchKernelGGL(f64::splitk_sum_kernel, dim3(f64::grid_n((long long)N * K)), dim3(256), 0, s, X + L.part, L.nsplit, N, K, out, H, dh, z0, z1);
+        return hipGetLastError();
+    };
+    auto col_sum = [&](const double* x, int ld, int N, double* out, double* out2 = nullptr) -> hipError_t {
+        const int nparts = (int)((M + 255) / 256);
+        hipLaunchKernelGGL(f64::colsum_part_kernel, dim3((N + 255) / 256, nparts), dim3(256), 0, s, x, ld, M, N, X + L.colpart);
+        hipLaunchKernelGGL(f64::colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, X + L.colpart, nparts, N, out, out2);
+        return hipGetLastError();
+    };
+    // dX[M][K] = dY[M][N] W[N][K]: the NT GEMM on a transposed copy of the weight
+    auto grad_x = [&](const double* dYp, int ldy, const double* Wp, int N, int K, double* out, const double* res) -> hipError_t {
+        hipLaunchKernelGGL(f64::transpose2_kernel, dim3(f64::grid_n((long long)N * K)), dim3(256), 0, s, Wp, X + L.wt, N, K);   // wt [K][N]
+        return f64::gemm(res ? 2 : 0, dYp, ldy, X + L.wt, nullptr, res, K, out, K, M, K, N, 0, 1, s);
+    };
+    const int rbase = 2 + 12 * d.L;
+    const int g_lin_w = rbase + (d.with_rnn ? 4 : 0), g_lin_b = g_lin_w + 1;
+    const int Kout = d.with_rnn ? d.R : d.D;
+    const double* enc = d.L ? W + L.xo[d.L - 1] : W + L.X0;
+    const double* head_in = d.with_rnn ? W + L.HALL : enc;
+    double* gx = X + L.ga;      // gradient w.r.t. the current layer's output
+    double* galt = X + L.gb;
+    // ---- output projection (:102) ------------------------------------------------------------------------------------
+    TF(col_sum(dy, d.S, d.S, grads + goff[g_lin_b]), "f64 bwd db_out");
+    TF(grad_w(dy, d.S, head_in, Kout, d.S, Kout, grads + goff[g_lin_w]), "f64 bwd dW_out");
+    if (d.with_rnn) {
+        double* dH = X + L.gbig;
+        double* delta = X + L.gbig2;
+        TF(grad_x(dy, d.S, params[g_lin_w], d.S, d.R, dH, nullptr), "f64 bwd dH");
+        // ---- recurrence (:98-99), time reversed; hprev lands in dH's place afterwards (dH is dead once delta exists) — not in
+        //      place: the kernel reads dH[t] and writes hprev[t] at the same index in the same thread, after the read
+        const int threads = d.R < 1024 ? ((d.R + 63) / 64) * 64 : 1024;
+        hipLaunchKernelGGL(f64::rnn_bwd_kernel, dim3(B), dim3(threads), 2 * (size_t)d.R * sizeof(double), s, dH, params[rbase + 1], W + L.HALL, delta, dH, T, d.R);
+        TF(hipGetLastError(), "f64 bwd rnn");
+        TF(col_sum(delta, d.R, d.R, grads + goff[rbase + 2], grads + goff[rbase + 3]), "f64 bwd db_rnn");
+        TF(grad_w(delta, d.R, dH /* = hprev */, d.R, d.R, d.R, grads + goff[rbase + 1]), "f64 bwd dW_hh");
+        TF(grad_w(delta, d.R, enc, d.D, d.R, d.D, grads + goff[rbase + 0]), "f64 bwd dW_ih");
+        TF(grad_x(delta, d.R, params[rbase + 0], d.R, d.D, gx, nullptr), "f64 bwd d_enc");
+    } else {
+        TF(grad_x(dy, d.S, params[g_lin_w], d.S, d.D, gx, nullptr), "f64 bwd d_enc");
+    }
+    // ---- encoder layers, last to first -----------------------------------------------------------------------------------
+    const double qs = 1.0 / sqrt((double)d.dh);
+    const size_t att_smem = (size_t)(4 * T * d.dh + 2 * T * T) * sizeof(double);
+    if (att_smem > 64 * 1024)   // (per call: cheap, and correct for every device the process drives)
+        TF(hipFuncSetAttribute(reinterpret_cast<const void*>(f64::attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)att_smem),
+           "f64 attention_bwd LDS");
+    for (int l = d.L - 1; l >= 0; --l) {
+        const int pb = 2 + 12 * l;
+        const double* const* lp = params + pb;
+        const double* x_in = l ? W + L.xo[l - 1] : W + L.X0;
+        double* dz = galt;            // LayerNorm input gradient (= the residual path's gradient)
+        double* dgx = X + L.gc;       // dy * xhat (dgamma's summand), then reused
+        double* big = X + L.gbig;
+        double* big2 = X + L.gbig2;
+        // LayerNorm2
+        hipLaunchKernelGGL(f64::ln_bwd_kernel, dim3((unsigned)M), dim3(64), 0, s, W + L.z2[l], lp[10], gx, dz, dgx, d.D);
+        TF(col_sum(dgx, d.D, d.D, grads + goff[pb + 10]), "f64 bwd dgamma2");
+        TF(col_sum(gx, d.D, d.D, grads + goff[pb + 11]), "f64 bwd dbeta2");
+        // linear2: its output gradient is dz under dropout site 3
+        double* dff2 = X + L.gc;
+        hipLaunchKernelGGL(f64::drop_res_kernel, dim3(f64::grid_n(M * d.D)), dim3(256), 0, s, dz, (const double*)nullptr, dff2, M * d.D,
+                           f64::make_drop_d(p_drop, seed, 4 * l + 3));
+        TF(col_sum(dff2, d.D, d.D, grads + goff[pb + 7]), "f64 bwd db2");
+        TF(grad_w(dff2, d.D, W + L.hid[l], d.F, d.D, d.F, grads + goff[pb + 6]), "f64 bwd dW2");
+        TF(grad_x(dff2, d.D, lp[6], d.D, d.F, big, nullptr), "f64 bwd dhid");
+        hipLaunchKernelGGL(f64::relu_gate_kernel, dim3(f64::grid_n(M * d.F)), dim3(256), 0, s, big, W + L.hid[l], big, M * d.F,
+                           f64::make_drop_d(p_drop, seed, 4 * l + 2).scale);
+        TF(col_sum(big, d.F, d.F, grads + goff[pb + 5]), "f64 bwd db1");
+        TF(grad_w(big, d.F, W + L.x1[l], d.D, d.F, d.D, grads + goff[pb + 4]), "f64 bwd dW1");
+        TF(grad_x(big, d.F, lp[4], d.F, d.D, gx, dz), "f64 bwd dx1");          // gx = dz2 + dpre W1
+        // LayerNorm1
+        hipLaunchKernelGGL(f64::ln_bwd_kernel, dim3((unsigned)M), dim3(64), 0, s, W + L.z1[l], lp[8], gx, dz, dgx, d.D);
+        TF(col_sum(dgx, d.D, d.D, grads + goff[pb + 8]), "f64 bwd dgamma1");
+        TF(col_sum(gx, d.D, d.D, grads + goff[pb + 9]), "f64 bwd dbeta1");
+        double* dout = X + L.gc;
+        hipLaunchKernelGGL(f64::drop_res_kernel, dim3(f64::grid_n(M * d.D)), dim3(256), 0, s, dz, (const double*)nullptr, dout, M * d.D,
+                           f64::make_drop_d(p_drop, seed, 4 * l + 1));
+        TF(col_sum(dout, d.D, d.D, grads + goff[pb + 3]), "f64 bwd dbo");
+        TF(grad_w(dout, d.D, W + L.att[l], d.D, d.D, d.D, grads + goff[pb + 2]), "f64 bwd dWo");
+        double* datt = gx;            // gx is free until dx_in is formed
+        TF(grad_x(dout, d.D, lp[2], d.D, d.D, datt, nullptr), "f64 bwd datt");
+        hipLaunchKernelGGL(f64::attention_bwd_kernel, dim3((unsigned)(B * d.H)), dim3(128), att_smem, s,
+                           W + L.qkv[l], datt, big2, T, d.D, d.H, d.dh, qs, f64::make_drop_d(p_drop, seed, 4 * l + 0));
+        TF(hipGetLastError(), "f64 bwd attention");
+        TF(col_sum(big2, 3 * d.D, 3 * d.D, grads + goff[pb + 1]), "f64 bwd dbqkv");
+        TF(grad_w(big2, 3 * d.D, x_in, d.D, 3 * d.D, d.D, grads + goff[pb + 0]), "f64 bwd dWqkv");
+        TF(grad_x(big2, 3 * d.D, lp[0], 3 * d.D, d.D, gx, dz), "f64 bwd dx_in");   // gx = dz1 + dqkv Wqkv
+    }
+    // ---- in_linear (:79) with the channel shuffle (:88-89) undone and the root-velocity columns (:75) at zero ----------------
+    TF(col_sum(gx, d.D, d.D, X + L.dbin), "f64 bwd db_in");
+    hipLaunchKernelGGL(f64::unshuffle_vec_kernel, dim3((d.D + 255) / 256), dim3(256), 0, s, X + L.dbin, grads + goff[1], d.D, d.H, d.dh);
+    TF(grad_w(gx, d.D, W + L.U, d.In, d.D, d.In, grads + goff[0], d.H, d.dh, d.n_imu_total + d.rootv0, d.n_imu_total + d.rootv1), "f64 bwd dW_in");
+#undef TF
+    return TIP_OK;
+}
+
+}  // extern "C"

@@ -34,6 +34,7 @@ EXPORTS = (
     "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_max_batch", "tip_forward", "tip_forward_f64_bytes", "tip_forward_f64", "tip_forward_count", "tip_profile_read",
     "tip_spin_timeouts", "tip_check", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
     "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward",
+    "tip_train_bytes_f64", "tip_train_forward_f64", "tip_train_backward_f64",
     "tip_combine_frames", "tip_combine_scratch_bytes", "tip_combine_sequence", "tip_gather_windows",
     "tip_loss_ws_bytes", "tip_loss_forward", "tip_loss_backward",
 )
@@ -127,6 +128,10 @@ def load() -> ctypes.CDLL:
     lib.tip_train_saved_view.argtypes = [vp, i32, i32, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.tip_train_forward.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, vp, f32, f32, u64, vp, vp, sz, i32, i32, vp]
     lib.tip_train_backward.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, sz, vp, sz, vp, sz, f32, u64, i32, i32, vp]
+    f64t = ctypes.c_double
+    lib.tip_train_bytes_f64.argtypes = [vp, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.tip_train_forward_f64.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, vp, f64t, f32, u64, vp, vp, sz, i32, i32, vp]
+    lib.tip_train_backward_f64.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, sz, vp, sz, vp, sz, f32, u64, i32, i32, vp]
     lib.tip_combine_frames.argtypes = [i32, i32]
     lib.tip_combine_scratch_bytes.argtypes = [i32, i32, ctypes.POINTER(sz)]
     lib.tip_combine_sequence.argtypes = [vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]
@@ -219,11 +224,12 @@ class Handle:
                                          workspace_bytes, stream))
 
     # -- training step (train_model.py:171-196) -------------------------------------------------------
-    def train_bytes(self, B: int, T: int) -> Tuple[int, int]:
-        """(saved_bytes, scratch_bytes); raises TipStatusError(-4: unsupported config) when the HIP training path
-        does not cover this configuration."""
+    def train_bytes(self, B: int, T: int, fp64: bool = False) -> Tuple[int, int]:
+        """(saved_bytes, scratch_bytes); raises TipStatusError(-2: unsupported config) when the HIP training path
+        does not cover this configuration.  fp64: the step of a module built under --double (tip_train_*_f64)."""
         a, b = ctypes.c_size_t(), ctypes.c_size_t()
-        self._check(self.lib.tip_train_bytes(self._h, B, T, ctypes.byref(a), ctypes.byref(b)))
+        fn = self.lib.tip_train_bytes_f64 if fp64 else self.lib.tip_train_bytes
+        self._check(fn(self._h, B, T, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
     def train_saved_view(self, B: int, T: int, what: int, layer: int) -> Tuple[int, int]:
@@ -245,17 +251,18 @@ class Handle:
                                              workspace, workspace_bytes, stream))
 
     def train_forward(self, param_ptrs: List[int], x_imu: int, x_s: int, keep_mask: Optional[int], keep_scale: float,
-                      p_drop: float, seed: int, y: int, saved: int, saved_bytes: int, B: int, T: int, stream: int):
+                      p_drop: float, seed: int, y: int, saved: int, saved_bytes: int, B: int, T: int, stream: int, fp64: bool = False):
         arr = (ctypes.c_void_p * len(param_ptrs))(*param_ptrs)
-        self._check(self.lib.tip_train_forward(self._h, arr, len(param_ptrs), x_imu, x_s, keep_mask, keep_scale, p_drop,
-                                               seed, y, saved, saved_bytes, B, T, stream))
+        fn = self.lib.tip_train_forward_f64 if fp64 else self.lib.tip_train_forward
+        self._check(fn(self._h, arr, len(param_ptrs), x_imu, x_s, keep_mask, keep_scale, p_drop, seed, y, saved, saved_bytes, B, T, stream))
 
     def train_backward(self, param_ptrs: List[int], dy: int, saved: int, saved_bytes: int, scratch: int,
                        scratch_bytes: int, grads: int, grads_floats: int, p_drop: float, seed: int, B: int, T: int,
-                       stream: int):
+                       stream: int, fp64: bool = False):
         arr = (ctypes.c_void_p * len(param_ptrs))(*param_ptrs)
-        self._check(self.lib.tip_train_backward(self._h, arr, len(param_ptrs), dy, saved, saved_bytes, scratch,
-                                                scratch_bytes, grads, grads_floats, p_drop, seed, B, T, stream))
+        fn = self.lib.tip_train_backward_f64 if fp64 else self.lib.tip_train_backward
+        self._check(fn(self._h, arr, len(param_ptrs), dy, saved, saved_bytes, scratch, scratch_bytes, grads, grads_floats, p_drop, seed,
+                       B, T, stream))
 
     def check(self, clear: bool = False):
         """Raise TipHandoffError if a hand-off wait of a completed launch gave up (no device sync: synchronise the stream first

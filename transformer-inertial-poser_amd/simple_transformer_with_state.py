@@ -216,18 +216,22 @@ class TF_RNN_Past_State(nn.Module):
         return _HipForwardTorchBackward.apply(self, last_row_only, xi, x_s, mask, *self.parameters())
 
     def _hip_train_ok(self, x_imu, x_s) -> bool:
-        """True when the HIP training step (libtip_hip tip_train_*) covers this call: fp32 CUDA tensors, gradients wanted
-        for parameters only, and a configuration the kernels support (TIP_ERR_UNSUPPORTED_CONFIG otherwise)."""
+        """True when the HIP training step (libtip_hip tip_train_*, or tip_train_*_f64 for a module built under --double) covers
+        this call: CUDA tensors of the parameters' precision (fp32 or fp64, no mix), gradients wanted for parameters only, and
+        a configuration the kernels support (TIP_ERR_UNSUPPORTED_CONFIG otherwise)."""
         if not self.use_hip_training or not (x_imu.is_cuda and x_s.is_cuda):
             return False
-        if x_imu.requires_grad or x_s.requires_grad or x_imu.dtype != torch.float32 or x_s.dtype != torch.float32:
+        pdt = self.in_linear.weight.dtype
+        if pdt not in (torch.float32, torch.float64):
+            return False
+        if x_imu.requires_grad or x_s.requires_grad or x_imu.dtype != pdt or x_s.dtype != pdt:
             return False
         if x_imu.dim() != 3 or x_s.dim() != 3 or x_imu.shape[:2] != x_s.shape[:2]:
             return False
-        if any(p.dtype != torch.float32 or not p.is_cuda for p in self.parameters()):
+        if any(p.dtype != pdt or not p.is_cuda for p in self.parameters()):
             return False
         try:
-            self._ensure_handle().train_bytes(int(x_imu.shape[0]), int(x_imu.shape[1]))
+            self._ensure_handle().train_bytes(int(x_imu.shape[0]), int(x_imu.shape[1]), fp64=pdt == torch.float64)
         except _lib.TipStatusError:
             return False
         return True
@@ -522,20 +526,22 @@ class _HipTrainFunction(torch.autograd.Function):
         if x_imu.shape[2] != n_imu or x_s.shape[2] != module.size_s:
             raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied: got feature widths "
                                f"{x_imu.shape[2]}+{x_s.shape[2]}, in_linear expects {n_imu}+{module.size_s}")
+        pdt = x_imu.dtype                                  # fp32, or fp64 for a module built under --double (_hip_train_ok: no mixes)
+        f64 = pdt == torch.float64
         with torch.cuda.device(dev):
-            saved_bytes, _ = h.train_bytes(B, T)
+            saved_bytes, _ = h.train_bytes(B, T, fp64=f64)
             saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
             xi, xs = x_imu.contiguous(), x_s.contiguous()
             pc = [p.detach().contiguous() for p in params]
             mask_ptr, scale = None, 1.0
             if mask is not None:
                 pd = module.past_state_dropout
-                mask = mask.to(torch.float32).contiguous()
+                mask = mask.to(pdt).contiguous()
                 mask_ptr, scale = mask.data_ptr(), (1.0 / (1.0 - pd) if pd < 1.0 else 0.0)
-            y = torch.empty((B, T, module.size_s), dtype=torch.float32, device=dev)
+            y = torch.empty((B, T, module.size_s), dtype=pdt, device=dev)
             h.train_forward([p.data_ptr() for p in pc], xi.data_ptr(), xs.data_ptr(), mask_ptr, scale, p_drop, seed,
-                            y.data_ptr(), saved.data_ptr(), saved.numel(), B, T, torch.cuda.current_stream(dev).cuda_stream)
-        ctx.module, ctx.dims, ctx.p_drop, ctx.seed = module, (B, T), p_drop, seed
+                            y.data_ptr(), saved.data_ptr(), saved.numel(), B, T, torch.cuda.current_stream(dev).cuda_stream, fp64=f64)
+        ctx.module, ctx.dims, ctx.p_drop, ctx.seed, ctx.f64 = module, (B, T), p_drop, seed, f64
         ctx.saved_stash = saved
         if module.keep_train_stash:
             module.last_train_stash = (saved, B, T)
@@ -554,16 +560,18 @@ class _HipTrainFunction(torch.autograd.Function):
                 raise RuntimeError("tip_amd: backward through the HIP training step a second time — the activation stash "
                                    "is released after the first backward (retain_graph=True is not supported; run the "
                                    "forward again)")
-            _, scratch_bytes = h.train_bytes(B, T)
+            f64 = ctx.f64
+            pdt = torch.float64 if f64 else torch.float32
+            _, scratch_bytes = h.train_bytes(B, T, fp64=f64)
             stream = torch.cuda.current_stream(dev).cuda_stream
             scratch = module._stream_buffer(module._train_scratch, dev, stream, scratch_bytes)
             total = sum(p.numel() for p in params)
-            flat = torch.empty(total, dtype=torch.float32, device=dev)
+            flat = torch.empty(total, dtype=pdt, device=dev)
             pc = [p.detach().contiguous() for p in params]
-            g = gy.to(torch.float32).contiguous()
+            g = gy.to(pdt).contiguous()
             h.train_backward([p.data_ptr() for p in pc], g.data_ptr(), saved.data_ptr(), saved.numel(),
                              scratch.data_ptr(), scratch.numel(), flat.data_ptr(), total,
-                             ctx.p_drop, ctx.seed, B, T, stream)
+                             ctx.p_drop, ctx.seed, B, T, stream, fp64=f64)
         ctx.saved_stash = None
         out, off = [], 0
         for i, p in enumerate(params):
