@@ -323,6 +323,13 @@ TIP_API int tip_loss_backward(const float* pred, long long ld_pred, const float*
                       int n_sbp, int terms, const float* stats, const float* gout, float* dpred, long long ld_dpred,
                       tip_stream_t stream);
 
+/* the same two passes for fp64 rows (train_model.py --double): pred / gt / stats / gout / dpred in double, everything else as above */
+TIP_API int tip_loss_forward_f64(const double* pred, long long ld_pred, const double* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
+                         int n_sbp, int terms, double* stats, void* ws, size_t ws_bytes, tip_stream_t stream);
+TIP_API int tip_loss_backward_f64(const double* pred, long long ld_pred, const double* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
+                          int n_sbp, int terms, const double* stats, const double* gout, double* dpred, long long ld_dpred,
+                          tip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,7 +124,8 @@ def _check_losses(tmp, res, rel):
     from oracle import loss_oracle
     for k, rec in enumerate(res["log"], start=1):
         z = torch.load(os.path.join(tmp, f"step{k}.pt"))
-        total, parts, _ = loss_oracle.train_loss(z["y_pred"].double().numpy(), z["y"].double().numpy(), 5)
+        total, parts, _ = loss_oracle.train_loss(z["y_pred"].double().numpy(), z["y"].double().numpy(), 5,
+                                                 f32_sigmoid=z["y_pred"].dtype == torch.float32)
         got = np.array([rec["q"], rec["c"], rec["j"]])
         assert np.allclose(got, parts, rtol=rel, atol=0, equal_nan=True), (k, got, parts)
         assert np.isclose(rec["loss"], total, rtol=rel, equal_nan=True), (k, rec["loss"], total)
@@ -142,3 +143,18 @@ def test_train_loop_body_through_the_dropin(tmp_path):
     assert res["moved"] == res["n_params"] == 56                           # every state-dict tensor received a gradient and stepped
     assert "torch-op training composite" not in out.stderr
     _check_losses(tmp, res, 2e-5)
+
+
+def test_train_loop_body_through_the_dropin_under_double(tmp_path):
+    """The same unedited loop with args.double (train_model.py:84-85,161-164): the module is built in fp64, its training step runs
+    tip_train_forward_f64 / tip_train_backward_f64, the three losses tip_loss_*_f64 — no torch-op composite anywhere."""
+    tmp = str(tmp_path)
+    res, out = _run(tmp, True)
+    assert res["dtype"] == "torch.float64" and len(res["log"]) == 3
+    for rec in res["log"]:
+        assert rec["model_fn"].startswith("_HipTrainFunction"), rec
+        assert rec["loss_fn"].startswith("_Loss"), rec
+        assert np.isfinite(rec["norm"]) and rec["norm"] > 0
+    assert res["moved"] == res["n_params"] == 56
+    assert "torch-op training composite" not in out.stderr
+    _check_losses(tmp, res, 1e-9)

@@ -138,8 +138,10 @@ def test_loud_failures_and_argument_checks():
     pred, gt = make_case("mix", 2, 5, 0)
     with pytest.raises(TypeError):
         lu.train_loss(torch.tensor(pred), torch.tensor(gt))                      # CPU tensors: no fallback
+    with pytest.raises(TypeError):                                                   # precision mixes are refused, nothing is converted
+        lu.train_loss(torch.tensor(pred).cuda().double(), torch.tensor(gt).cuda())
     with pytest.raises(TypeError):
-        lu.train_loss(torch.tensor(pred).cuda().double(), torch.tensor(gt).cuda().double())
+        lu.train_loss(torch.tensor(pred).cuda().half(), torch.tensor(gt).cuda().half())
     with pytest.raises(AssertionError):
         lu.loss_q_only_2axis(torch.zeros(4, 110).cuda(), torch.zeros(4, 110).cuda())   # the reference asserts 18*6+3
     lib = tip_amd.lib.load()
@@ -173,3 +175,35 @@ def test_constraint_loss_with_more_than_16_constraints_per_row(tag):
     o_loss, o_grad = loss_oracle.loss_constr_multi(gt, pred)
     assert abs(float(loss) - o_loss) <= 2e-6 * abs(o_loss), (float(loss), o_loss)
     assert np.abs(g - o_grad).max() <= 2e-6 * np.abs(o_grad).max()
+
+
+def test_fused_loss_fp64_matches_oracle():
+    """train_model.py --double: predictions and targets in float64 -> tip_loss_forward_f64 / tip_loss_backward_f64; total, the
+    three parts and the gradient against the fp64 oracle (sigmoid in fp64 too) to fp64 rounding; masked rows exactly zero."""
+    lu = tip_amd.learning_utils
+    for tag, (B, T, seed) in {"full": (64, 40, 3), "short": (5, 3, 4), "one": (1, 1, 5)}.items():
+        pred, gt = make_case("full", B, T, seed)
+        pred, gt = pred.astype(np.float64), gt.astype(np.float64)
+        yp = torch.tensor(pred).cuda().requires_grad_(True)
+        total, parts = lu.train_loss(yp, torch.tensor(gt).cuda(), N_SBPS, return_parts=True)
+        assert total.dtype == torch.float64
+        total.backward()
+        o_total, o_parts, o_grad = loss_oracle.train_loss(pred, gt, N_SBPS, f32_sigmoid=False)
+        g = yp.grad.cpu().numpy()
+        if np.isnan(o_total):
+            assert np.isnan(float(total))
+            continue
+        assert abs(float(total) - o_total) <= 1e-12 * abs(o_total), (tag, float(total), o_total)
+        assert np.allclose(parts.cpu().numpy(), o_parts, rtol=1e-12, atol=0, equal_nan=True)
+        assert np.abs(g - o_grad).max() <= 1e-12 * max(np.abs(o_grad).max(), 1e-300), tag
+        # the three reference functions one by one on column slices, as train_model.py:177-185 calls them
+        y2 = torch.tensor(pred).cuda().requires_grad_(True)
+        yf, gf = y2.reshape(-1, y2.shape[-1]), torch.tensor(gt).cuda().reshape(-1, gt.shape[-1])
+        lj = lu.loss_jerk(y2[:, :, :-3 - 4 * N_SBPS])
+        lq = lu.loss_q_only_2axis(gf[:, :-4 * N_SBPS], yf[:, :-4 * N_SBPS])
+        lc = lu.loss_constr_multi(gf[:, -4 * N_SBPS:], yf[:, -4 * N_SBPS:])
+        (lc + lq + lj).backward()
+        assert np.allclose([float(lq), float(lc), float(lj)], o_parts, rtol=1e-12, atol=0, equal_nan=True)
+        assert np.abs(y2.grad.cpu().numpy() - o_grad).max() <= 1e-12 * max(np.abs(o_grad).max(), 1e-300)
+    with pytest.raises(TypeError):                              # no silent conversion: fp32 prediction against fp64 targets
+        lu.train_loss(torch.zeros(2, 4, 131, device="cuda"), torch.zeros(2, 4, 131, device="cuda", dtype=torch.float64), N_SBPS)

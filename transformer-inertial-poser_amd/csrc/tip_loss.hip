@@ -26,18 +26,32 @@ struct LossShape {
 // stats[] slots (floats, TIP_LOSS_STATS of them)
 enum { ST_TOTAL = 0, ST_Q, ST_C, ST_J, ST_KPOSE, ST_KXY, ST_KZ, ST_KBCE, ST_KOFF, ST_KJ, ST_NVEL, ST_NSBP };
 
+// float / double math of the two instantiations (fp32: the reference's default; fp64: train_model.py --double)
+template <typename R> struct Mth;
+template <> struct Mth<float> {
+    static __device__ __forceinline__ float exp(float x) { return expf(x); }
+    static __device__ __forceinline__ float log(float x) { return logf(x); }
+    static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
+};
+template <> struct Mth<double> {
+    static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+    static __device__ __forceinline__ double log(double x) { return ::log(x); }
+    static __device__ __forceinline__ double max(double a, double b) { return fmax(a, b); }
+};
+
 // Stage rows [first, first + n) of a [M, W] array (row stride ld) into an LDS tile [n][W], kLossDepth loads per thread in
 // flight before the first LDS store (this is latency-bound streaming: the bytes in flight set the rate); with ld == W the
 // span is contiguous.
-__device__ __forceinline__ void stage_rows(float* __restrict__ tile, const float* __restrict__ src, long long ld, long long first,
+template <typename R>
+__device__ __forceinline__ void stage_rows(R* __restrict__ tile, const R* __restrict__ src, long long ld, long long first,
                                            int n, int W) {
     const int tid = threadIdx.x;
     const int total = n * W;
-    const float* s = src + first * ld;
+    const R* s = src + first * ld;
     // loads are unconditional (index clamped) so that nothing but the address arithmetic sits between them
     auto batch = [&](auto&& index) {
         for (int e0 = tid; e0 < total; e0 += kLossThreads * kLossDepth) {
-            float v[kLossDepth];
+            R v[kLossDepth];
 #pragma unroll
             for (int u = 0; u < kLossDepth; ++u) v[u] = s[index(min(e0 + u * kLossThreads, total - 1))];
 #pragma unroll
@@ -56,7 +70,8 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ tile, const float
 }
 
 // which rows of this workgroup's tile count for the masked terms (learning_utils.py:19, :67); gt tile already in LDS
-__device__ __forceinline__ void row_masks(const float* gtile, bool have_gt, const LossShape& sh, int nrows, int W,
+template <typename R>
+__device__ __forceinline__ void row_masks(const R* gtile, bool have_gt, const LossShape& sh, int nrows, int W,
                                           unsigned char* vmask, unsigned char* cmask) {
     const int tid = threadIdx.x;
     if (tid < kLossRows) {
@@ -92,23 +107,27 @@ __device__ __forceinline__ ColWalk col_walk(int W, int nrows) {
 }
 
 // binary_cross_entropy(sigmoid(x), t) as torch evaluates it in fp32: both logs clamped at -100
-__device__ __forceinline__ float bce_sigmoid(float x, float t) {
-    const float p = 1.0f / (1.0f + expf(-x));
-    return (t - 1.0f) * fmaxf(logf(1.0f - p), -100.0f) - t * fmaxf(logf(p), -100.0f);
+template <typename R>
+__device__ __forceinline__ R bce_sigmoid(R x, R t) {
+    const R p = R(1.0) / (R(1.0) + Mth<R>::exp(-x));
+    return (t - R(1.0)) * Mth<R>::max(Mth<R>::log(R(1.0) - p), -R(100.0)) - t * Mth<R>::max(Mth<R>::log(p), -R(100.0));
 }
 
 // d/dx of the above through torch's two backward formulas (binary_cross_entropy_backward, eps 1e-12; sigmoid_backward):
 // equals p - t until the sigmoid saturates in fp32, exactly 0 after.
-__device__ __forceinline__ float bce_sigmoid_grad(float x, float t) {
-    const float p = 1.0f / (1.0f + expf(-x));
-    const float pq = (1.0f - p) * p;
-    return (p - t) / fmaxf(pq, 1e-12f) * pq;
+template <typename R>
+__device__ __forceinline__ R bce_sigmoid_grad(R x, R t) {
+    const R p = R(1.0) / (R(1.0) + Mth<R>::exp(-x));
+    const R pq = (R(1.0) - p) * p;
+    return (p - t) / Mth<R>::max(pq, R(1e-12)) * pq;
 }
 
-__global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(const float* __restrict__ pred, long long ldp,
-                                                                    const float* __restrict__ gt, long long ldg, LossShape sh,
+template <typename R>
+__global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(const R* __restrict__ pred, long long ldp,
+                                                                    const R* __restrict__ gt, long long ldg, LossShape sh,
                                                                     double* __restrict__ part) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    R* lds = reinterpret_cast<R*>(lds_raw);
     __shared__ unsigned char vmask[kLossRows], cmask[kLossRows];
     __shared__ double red[kLossThreads / 64][kLossPart];
     const int tid = threadIdx.x;
@@ -116,13 +135,13 @@ __global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(const float*
     const int row0 = blockIdx.x * kLossRows;
     const int nrows = min(kLossRows, M - row0);
     const int W = sh.n_pose + sh.n_vel + sh.n_sbp4;
-    float* pt = lds;                                // prediction rows row0 .. row0 + nrows + 2 (3 more for the third difference)
-    float* gtl = lds + (kLossRows + 3) * W;         // GT rows row0 .. row0 + nrows - 1
+    R* pt = lds;                                // prediction rows row0 .. row0 + nrows + 2 (3 more for the third difference)
+    R* gtl = lds + (kLossRows + 3) * W;         // GT rows row0 .. row0 + nrows - 1
     stage_rows(pt, pred, ldp, row0, min(kLossRows + 3, M - row0), W);
     if (gt) stage_rows(gtl, gt, ldg, row0, nrows, W);
     __syncthreads();
     row_masks(gtl, gt != nullptr, sh, nrows, W, vmask, cmask);
-    float s_pose = 0.f, s_xy = 0.f, s_z = 0.f, s_bce = 0.f, s_off = 0.f, s_j = 0.f;
+    R s_pose = R(0), s_xy = R(0), s_z = R(0), s_bce = R(0), s_off = R(0), s_j = R(0);
     const ColWalk cw = col_walk(W, nrows);
     if (cw.rbeg < cw.rend) {
         const int col = cw.col;
@@ -132,17 +151,17 @@ __global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(const float*
             const bool doq = sh.terms & TIP_LOSS_Q, doj = sh.terms & TIP_LOSS_J;
             int t = (row0 + cw.rbeg) % sh.T;             // frame index inside the window
             const int left = M - row0 - cw.rbeg;          // rows from rbeg to the end of the array (all staged up to +3)
-            float ya = pt[cw.rbeg * W + col];
-            float yb = left > 1 ? pt[(cw.rbeg + 1) * W + col] : 0.f;
-            float yc = left > 2 ? pt[(cw.rbeg + 2) * W + col] : 0.f;
+            R ya = pt[cw.rbeg * W + col];
+            R yb = left > 1 ? pt[(cw.rbeg + 1) * W + col] : R(0);
+            R yc = left > 2 ? pt[(cw.rbeg + 2) * W + col] : R(0);
             for (int r = cw.rbeg; r < cw.rend; ++r) {
-                const float yn = row0 + r + 3 < M ? pt[(r + 3) * W + col] : 0.f;
+                const R yn = row0 + r + 3 < M ? pt[(r + 3) * W + col] : R(0);
                 if (doq) {
-                    const float d = ya - gtl[r * W + col];
+                    const R d = ya - gtl[r * W + col];
                     s_pose += d * d;
                 }
                 if (doj && t + 3 < sh.T) {
-                    const float j = yn - 3.0f * yc + 3.0f * yb - ya;
+                    const R j = yn - R(3.0) * yc + R(3.0) * yb - ya;
                     s_j += j * j;
                 }
                 ya = yb, yb = yc, yc = yn;
@@ -150,14 +169,14 @@ __global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(const float*
             }
         } else if (kind != 3) {
             for (int r = cw.rbeg; r < cw.rend; ++r) {
-                const float p = pt[r * W + col];
+                const R p = pt[r * W + col];
                 if (kind <= 2) {
                     if ((sh.terms & TIP_LOSS_Q) && vmask[r]) {
-                        const float d = gtl[r * W + col] - p;
+                        const R d = gtl[r * W + col] - p;
                         if (kind == 1) s_xy += d * d; else s_z += d * d;
                     }
                 } else if ((sh.terms & TIP_LOSS_C) && cmask[r]) {
-                    const float d = p - gtl[r * W + col] * 5.0f;
+                    const R d = p - gtl[r * W + col] * R(5.0);
                     s_off += d * d;
                 }
             }
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(const float*
         const int nf = sh.n_sbp4 >> 2;
         for (int e = tid; e < nrows * nf; e += kLossThreads) {
             const int r = e / nf, col = sh.n_pose + sh.n_vel + 4 * (e - r * nf);
-            if (cmask[r]) s_bce += bce_sigmoid(pt[r * W + col], gtl[r * W + col]);
+            if (cmask[r]) s_bce += bce_sigmoid<R>(pt[r * W + col], gtl[r * W + col]);
         }
     }
     double v[kLossPart] = {s_pose, s_xy, s_z, 0.0, s_bce, s_off, 0.0, s_j};
@@ -189,8 +208,9 @@ __global__ __launch_bounds__(kLossThreads) void loss_partial_kernel(const float*
 }
 
 // one workgroup: fixed-order sum of the partials, then the losses and the gradient coefficients
+template <typename R>
 __global__ __launch_bounds__(kLossThreads) void loss_final_kernel(const double* __restrict__ part, int nblocks, LossShape sh,
-                                                                  float* __restrict__ stats) {
+                                                                  R* __restrict__ stats) {
     __shared__ double red[kLossThreads][kLossPart];
     const int tid = threadIdx.x;
     double v[kLossPart] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -219,27 +239,29 @@ __global__ __launch_bounds__(kLossThreads) void loss_final_kernel(const double* 
         }
         if (sh.terms & TIP_LOSS_C) lc = (S_bce / Nc + S_off / (3.0 * Nc) * 4.0) / n_c * 2.5;
         if (sh.terms & TIP_LOSS_J) lj = S_j / Nj * 100.0;
-        stats[ST_TOTAL] = (float)((lc + lq) + lj);      // train_model.py:187-189
-        stats[ST_Q] = (float)lq;
-        stats[ST_C] = (float)lc;
-        stats[ST_J] = (float)lj;
-        stats[ST_KPOSE] = (float)(200.0 / (M * sh.n_pose));
-        stats[ST_KXY] = (float)(6.0 / Nv);               // 2 * 6 / (2 Nv)
-        stats[ST_KZ] = (float)(24.0 / Nv);
-        stats[ST_KBCE] = (float)(2.5 / n_c / Nc);
-        stats[ST_KOFF] = (float)(2.5 / n_c * 8.0 / (3.0 * Nc));
-        stats[ST_KJ] = (float)(200.0 / Nj);
-        stats[ST_NVEL] = (float)Nv;
-        stats[ST_NSBP] = (float)Nc;
-        for (int i = ST_NSBP + 1; i < TIP_LOSS_STATS; ++i) stats[i] = 0.f;
+        stats[ST_TOTAL] = (R)((lc + lq) + lj);      // train_model.py:187-189
+        stats[ST_Q] = (R)lq;
+        stats[ST_C] = (R)lc;
+        stats[ST_J] = (R)lj;
+        stats[ST_KPOSE] = (R)(200.0 / (M * sh.n_pose));
+        stats[ST_KXY] = (R)(6.0 / Nv);               // 2 * 6 / (2 Nv)
+        stats[ST_KZ] = (R)(24.0 / Nv);
+        stats[ST_KBCE] = (R)(2.5 / n_c / Nc);
+        stats[ST_KOFF] = (R)(2.5 / n_c * 8.0 / (3.0 * Nc));
+        stats[ST_KJ] = (R)(200.0 / Nj);
+        stats[ST_NVEL] = (R)Nv;
+        stats[ST_NSBP] = (R)Nc;
+        for (int i = ST_NSBP + 1; i < TIP_LOSS_STATS; ++i) stats[i] = R(0);
     }
 }
 
-__global__ __launch_bounds__(kLossThreads) void loss_grad_kernel(const float* __restrict__ pred, long long ldp,
-                                                                 const float* __restrict__ gt, long long ldg, LossShape sh,
-                                                                 const float* __restrict__ stats, const float* __restrict__ gout,
-                                                                 float* __restrict__ dy, long long ldd) {
-    extern __shared__ float lds[];
+template <typename R>
+__global__ __launch_bounds__(kLossThreads) void loss_grad_kernel(const R* __restrict__ pred, long long ldp,
+                                                                 const R* __restrict__ gt, long long ldg, LossShape sh,
+                                                                 const R* __restrict__ stats, const R* __restrict__ gout,
+                                                                 R* __restrict__ dy, long long ldd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    R* lds = reinterpret_cast<R*>(lds_raw);
     __shared__ unsigned char vmask[kLossRows], cmask[kLossRows];
     const int M = sh.B * sh.T;
     const int row0 = blockIdx.x * kLossRows;
@@ -247,21 +269,21 @@ __global__ __launch_bounds__(kLossThreads) void loss_grad_kernel(const float* __
     const int W = sh.n_pose + sh.n_vel + sh.n_sbp4;
     // prediction rows row0 - 3 .. row0 + nrows + 2: y[t] enters the third differences u = t-3 .. t, which reach y[t+3]
     const int lead = min(3, row0);
-    float* pt = lds + (3 - lead) * W;               // pt[(r + 3) * W + c] = prediction row row0 + r
-    float* gtl = lds + (kLossRows + 6) * W;
+    R* pt = lds + (3 - lead) * W;               // pt[(r + 3) * W + c] = prediction row row0 + r
+    R* gtl = lds + (kLossRows + 6) * W;
     stage_rows(pt, pred, ldp, row0 - lead, min(lead + kLossRows + 3, M - row0 + lead), W);
     if (gt) stage_rows(gtl, gt, ldg, row0, nrows, W);
     __syncthreads();
     row_masks(gtl, gt != nullptr, sh, nrows, W, vmask, cmask);
-    const float go = gout ? gout[0] : 1.0f;
-    const float k_pose = stats[ST_KPOSE], k_xy = stats[ST_KXY], k_z = stats[ST_KZ];
-    const float k_bce = stats[ST_KBCE], k_off = stats[ST_KOFF], k_j = stats[ST_KJ];
+    const R go = gout ? gout[0] : R(1.0);
+    const R k_pose = stats[ST_KPOSE], k_xy = stats[ST_KXY], k_z = stats[ST_KZ];
+    const R k_bce = stats[ST_KBCE], k_off = stats[ST_KOFF], k_j = stats[ST_KJ];
     const int tid = threadIdx.x;
     // the flag columns (exp, divide) one per thread rather than a column's 16 rows in sequence
     for (int e = tid, nf = sh.n_sbp4 >> 2; e < nrows * nf; e += kLossThreads) {
         const int r = e / nf, col = sh.n_pose + sh.n_vel + 4 * (e - r * nf);
-        float g = 0.f;
-        if ((sh.terms & TIP_LOSS_C) && cmask[r]) g = k_bce * bce_sigmoid_grad(lds[(3 + r) * W + col], gtl[r * W + col]);
+        R g = R(0);
+        if ((sh.terms & TIP_LOSS_C) && cmask[r]) g = k_bce * bce_sigmoid_grad<R>(lds[(3 + r) * W + col], gtl[r * W + col]);
         dy[(size_t)(row0 + r) * ldd + col] = g * go;
     }
     const ColWalk cw = col_walk(W, nrows);
@@ -270,33 +292,33 @@ __global__ __launch_bounds__(kLossThreads) void loss_grad_kernel(const float* __
     const int kind = col < sh.n_pose ? 0 : col < sh.n_pose + sh.n_vel ? (col - sh.n_pose < 2 ? 1 : 2)
                                      : (((col - sh.n_pose - sh.n_vel) & 3) == 0 ? 3 : 4);
     if (kind == 3) return;
-    const float* y0 = lds + 3 * W + col;   // y0[r * W] = prediction (row0 + r, col), r >= -3
+    const R* y0 = lds + 3 * W + col;   // y0[r * W] = prediction (row0 + r, col), r >= -3
     if (kind == 0) {
         // jitter[u] = y[u+3] - 3 y[u+2] + 3 y[u+1] - y[u] for frames u <= T-4 of a window (jv = 0 elsewhere);
         // d loss_j / d y[q] = k_j * (-jv[q] + 3 jv[q-1] - 3 jv[q-2] + jv[q-3]).  jv and y slide through registers.
         const bool doq = sh.terms & TIP_LOSS_Q, doj = (sh.terms & TIP_LOSS_J) && sh.T > 3;
-        float jm[3] = {0.f, 0.f, 0.f};     // jv[q-3], jv[q-2], jv[q-1]
+        R jm[3] = {R(0), R(0), R(0)};     // jv[q-3], jv[q-2], jv[q-1]
         if (doj) {
 #pragma unroll
             for (int k = 3; k >= 1; --k) {
                 const int rr = cw.rbeg - k, qq = row0 + rr;
                 if (qq >= 0 && qq % sh.T + 3 < sh.T)
-                    jm[3 - k] = y0[(rr + 3) * W] - 3.0f * y0[(rr + 2) * W] + 3.0f * y0[(rr + 1) * W] - y0[rr * W];
+                    jm[3 - k] = y0[(rr + 3) * W] - R(3.0) * y0[(rr + 2) * W] + R(3.0) * y0[(rr + 1) * W] - y0[rr * W];
             }
         }
         int t = (row0 + cw.rbeg) % sh.T;
         const int left = M - row0 - cw.rbeg;
-        float ya = y0[cw.rbeg * W];
-        float yb = left > 1 ? y0[(cw.rbeg + 1) * W] : 0.f;
-        float yc = left > 2 ? y0[(cw.rbeg + 2) * W] : 0.f;
+        R ya = y0[cw.rbeg * W];
+        R yb = left > 1 ? y0[(cw.rbeg + 1) * W] : R(0);
+        R yc = left > 2 ? y0[(cw.rbeg + 2) * W] : R(0);
         for (int r = cw.rbeg; r < cw.rend; ++r) {
-            const float yn = row0 + r + 3 < M ? y0[(r + 3) * W] : 0.f;
-            float g = doq ? k_pose * (ya - gtl[r * W + col]) : 0.f;
+            const R yn = row0 + r + 3 < M ? y0[(r + 3) * W] : R(0);
+            R g = doq ? k_pose * (ya - gtl[r * W + col]) : R(0);
             if (doj) {
-                const float jn = t + 3 < sh.T ? yn - 3.0f * yc + 3.0f * yb - ya : 0.f;
-                float acc = -jn;
-                acc += 3.0f * jm[2];
-                acc += -3.0f * jm[1];
+                const R jn = t + 3 < sh.T ? yn - R(3.0) * yc + R(3.0) * yb - ya : R(0);
+                R acc = -jn;
+                acc += R(3.0) * jm[2];
+                acc += -R(3.0) * jm[1];
                 acc += jm[0];
                 g += k_j * acc;
                 jm[0] = jm[1], jm[1] = jm[2], jm[2] = jn;
@@ -308,18 +330,19 @@ __global__ __launch_bounds__(kLossThreads) void loss_grad_kernel(const float* __
         return;
     }
     for (int r = cw.rbeg; r < cw.rend; ++r) {
-        const float p = y0[r * W];
-        float g = 0.f;
+        const R p = y0[r * W];
+        R g = R(0);
         if (kind <= 2) {
             if ((sh.terms & TIP_LOSS_Q) && vmask[r]) g = (kind == 1 ? k_xy : k_z) * (p - gtl[r * W + col]);
         } else if ((sh.terms & TIP_LOSS_C) && cmask[r]) {
-            g = k_off * (p - gtl[r * W + col] * 5.0f);
+            g = k_off * (p - gtl[r * W + col] * R(5.0));
         }
         dy[(size_t)(row0 + r) * ldd + col] = g * go;
     }
 }
 
-int check_shape(const float* pred, long long ldp, const float* gt, long long ldg, int B, int T, int n_pose, int n_vel, int n_sbp,
+template <typename R>
+int check_shape(const R* pred, long long ldp, const R* gt, long long ldg, int B, int T, int n_pose, int n_vel, int n_sbp,
                 int terms, LossShape* sh) {
     if (!pred || B < 0 || T < 0 || n_pose < 0 || n_sbp < 0 || (n_vel != 0 && n_vel != 3)) return TIP_ERR_INVALID_ARG;
     if (!terms || (terms & ~(TIP_LOSS_Q | TIP_LOSS_C | TIP_LOSS_J))) return TIP_ERR_INVALID_ARG;
@@ -339,6 +362,39 @@ inline int loss_blocks(int B, int T) { return (int)(((long long)B * T + kLossRow
 
 using namespace tip;
 
+template <typename R>
+static int loss_forward_t(const R* pred, long long ld_pred, const R* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
+                          int n_sbp, int terms, R* stats, void* ws, size_t ws_bytes, void* stream) {
+    LossShape sh;
+    const int rc = check_shape<R>(pred, ld_pred, gt, ld_gt, B, T, n_pose, n_vel, n_sbp, terms, &sh);
+    if (rc != TIP_OK) return rc;
+    if (!stats || !ws) return TIP_ERR_INVALID_ARG;
+    const int nb = loss_blocks(B, T);
+    if (ws_bytes < (size_t)(nb > 0 ? nb : 1) * kLossPart * sizeof(double) || reinterpret_cast<uintptr_t>(ws) % 8) return TIP_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    double* part = static_cast<double*>(ws);
+    const int W = sh.n_pose + sh.n_vel + sh.n_sbp4;
+    if (nb > 0)
+        hipLaunchKernelGGL(loss_partial_kernel<R>, dim3(nb), dim3(kLossThreads), (size_t)(2 * kLossRows + 3) * W * sizeof(R), st, pred, ld_pred, gt, ld_gt, sh, part);
+    hipLaunchKernelGGL(loss_final_kernel<R>, dim3(1), dim3(kLossThreads), 0, st, part, nb, sh, stats);
+    return hipGetLastError() == hipSuccess ? TIP_OK : TIP_ERR_HIP;
+}
+
+template <typename R>
+static int loss_backward_t(const R* pred, long long ld_pred, const R* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
+                           int n_sbp, int terms, const R* stats, const R* gout, R* dpred, long long ld_dpred, void* stream) {
+    LossShape sh;
+    const int rc = check_shape<R>(pred, ld_pred, gt, ld_gt, B, T, n_pose, n_vel, n_sbp, terms, &sh);
+    if (rc != TIP_OK) return rc;
+    if (!stats || !dpred || ld_dpred < sh.n_pose + sh.n_vel + sh.n_sbp4) return TIP_ERR_INVALID_ARG;
+    const int nb = loss_blocks(B, T);
+    if (nb == 0) return TIP_OK;
+    hipLaunchKernelGGL(loss_grad_kernel<R>, dim3(nb), dim3(kLossThreads),
+                       (size_t)(2 * kLossRows + 6) * (sh.n_pose + sh.n_vel + sh.n_sbp4) * sizeof(R), static_cast<hipStream_t>(stream), pred, ld_pred, gt, ld_gt,
+                       sh, stats, gout, dpred, ld_dpred);
+    return hipGetLastError() == hipSuccess ? TIP_OK : TIP_ERR_HIP;
+}
+
 extern "C" {
 
 int tip_loss_ws_bytes(int B, int T, size_t* bytes) {
@@ -349,33 +405,19 @@ int tip_loss_ws_bytes(int B, int T, size_t* bytes) {
 
 int tip_loss_forward(const float* pred, long long ld_pred, const float* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
                      int n_sbp, int terms, float* stats, void* ws, size_t ws_bytes, void* stream) {
-    LossShape sh;
-    const int rc = check_shape(pred, ld_pred, gt, ld_gt, B, T, n_pose, n_vel, n_sbp, terms, &sh);
-    if (rc != TIP_OK) return rc;
-    if (!stats || !ws) return TIP_ERR_INVALID_ARG;
-    const int nb = loss_blocks(B, T);
-    if (ws_bytes < (size_t)(nb > 0 ? nb : 1) * kLossPart * sizeof(double) || reinterpret_cast<uintptr_t>(ws) % 8) return TIP_ERR_WORKSPACE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    double* part = static_cast<double*>(ws);
-    const int W = sh.n_pose + sh.n_vel + sh.n_sbp4;
-    if (nb > 0)
-        hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(kLossThreads), (size_t)(2 * kLossRows + 3) * W * sizeof(float), st, pred, ld_pred, gt, ld_gt, sh, part);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(kLossThreads), 0, st, part, nb, sh, stats);
-    return hipGetLastError() == hipSuccess ? TIP_OK : TIP_ERR_HIP;
+    return loss_forward_t<float>(pred, ld_pred, gt, ld_gt, B, T, n_pose, n_vel, n_sbp, terms, stats, ws, ws_bytes, stream);
 }
-
 int tip_loss_backward(const float* pred, long long ld_pred, const float* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
                       int n_sbp, int terms, const float* stats, const float* gout, float* dpred, long long ld_dpred, void* stream) {
-    LossShape sh;
-    const int rc = check_shape(pred, ld_pred, gt, ld_gt, B, T, n_pose, n_vel, n_sbp, terms, &sh);
-    if (rc != TIP_OK) return rc;
-    if (!stats || !dpred || ld_dpred < sh.n_pose + sh.n_vel + sh.n_sbp4) return TIP_ERR_INVALID_ARG;
-    const int nb = loss_blocks(B, T);
-    if (nb == 0) return TIP_OK;
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(nb), dim3(kLossThreads),
-                       (size_t)(2 * kLossRows + 6) * (sh.n_pose + sh.n_vel + sh.n_sbp4) * sizeof(float), static_cast<hipStream_t>(stream), pred, ld_pred, gt, ld_gt,
-                       sh, stats, gout, dpred, ld_dpred);
-    return hipGetLastError() == hipSuccess ? TIP_OK : TIP_ERR_HIP;
+    return loss_backward_t<float>(pred, ld_pred, gt, ld_gt, B, T, n_pose, n_vel, n_sbp, terms, stats, gout, dpred, ld_dpred, stream);
+}
+int tip_loss_forward_f64(const double* pred, long long ld_pred, const double* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
+                         int n_sbp, int terms, double* stats, void* ws, size_t ws_bytes, void* stream) {
+    return loss_forward_t<double>(pred, ld_pred, gt, ld_gt, B, T, n_pose, n_vel, n_sbp, terms, stats, ws, ws_bytes, stream);
+}
+int tip_loss_backward_f64(const double* pred, long long ld_pred, const double* gt, long long ld_gt, int B, int T, int n_pose, int n_vel,
+                          int n_sbp, int terms, const double* stats, const double* gout, double* dpred, long long ld_dpred, void* stream) {
+    return loss_backward_t<double>(pred, ld_pred, gt, ld_gt, B, T, n_pose, n_vel, n_sbp, terms, stats, gout, dpred, ld_dpred, stream);
 }
 
 }  // extern "C"

@@ -10,7 +10,8 @@ instead of a few dozen elementwise / boolean-index torch kernels with a host syn
     loss = train_loss(y_pred, y, n_sbps=5)          # == loss_c + loss_q + loss_j of the reference loop
     loss.backward()
 
-fp32 CUDA(HIP) tensors only; there is no CPU path (TipLibraryError / TypeError otherwise).
+Device tensors only, fp32 or — under train_model.py's --double — fp64 (no mixes); there is no CPU path (TipLibraryError /
+TypeError otherwise).
 """
 from __future__ import annotations
 
@@ -25,12 +26,13 @@ from . import lib as _lib
 Q, C, J = _lib.TIP_LOSS_Q, _lib.TIP_LOSS_C, _lib.TIP_LOSS_J
 
 
-def _rows(t: torch.Tensor, what: str):
-    """(tensor to keep alive, row stride in floats) of a [..., W] fp32 device tensor whose rows are evenly spaced in memory
-    (a column slice of a contiguous array qualifies); anything else is made contiguous first."""
-    if not t.is_cuda or t.dtype != torch.float32:
-        raise TypeError(f"tip_amd.learning_utils: {what} must be a float32 tensor on the HIP device "
-                        f"(got {t.dtype} on {t.device}); the losses have no CPU / fp64 path")
+def _rows(t: torch.Tensor, what: str, dtype=None):
+    """(tensor to keep alive, row stride in elements) of a [..., W] fp32 / fp64 device tensor whose rows are evenly spaced in
+    memory (a column slice of a contiguous array qualifies); anything else is made contiguous first."""
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.float64) or (dtype is not None and t.dtype != dtype):
+        raise TypeError(f"tip_amd.learning_utils: {what} must be a float32 (or, under --double, float64) tensor on the HIP device"
+                        f"{'' if dtype is None else ' of the prediction precision ' + str(dtype)} "
+                        f"(got {t.dtype} on {t.device}); the losses have no CPU path and convert nothing")
     W = t.shape[-1]
     ok = t.stride(-1) == 1 and t.stride(-2) >= W
     if ok and t.dim() == 3:
@@ -50,18 +52,19 @@ class _Loss(torch.autograd.Function):
         lib = _lib.load()
         dev = pred.device
         p, ldp = _rows(pred.detach(), "prediction")
+        dt = p.dtype
         if gt is not None:
-            g, ldg = _rows(gt.detach(), "ground truth")
+            g, ldg = _rows(gt.detach(), "ground truth", dt)
         else:
             g, ldg = None, 0
-        stats = torch.empty(_lib.TIP_LOSS_STATS, dtype=torch.float32, device=dev)
+        stats = torch.empty(_lib.TIP_LOSS_STATS, dtype=dt, device=dev)
         nbytes = ctypes.c_size_t()
         rc = lib.tip_loss_ws_bytes(B, T, ctypes.byref(nbytes))
         if rc < 0:
             raise _lib.TipStatusError(rc, "tip_loss_ws_bytes")
         ws = torch.empty(max(nbytes.value // 8, 1), dtype=torch.float64, device=dev)
         with torch.cuda.device(dev):
-            rc = lib.tip_loss_forward(p.data_ptr(), ldp, g.data_ptr() if g is not None else None, ldg, B, T, n_pose, n_vel,
+            rc = (lib.tip_loss_forward_f64 if dt == torch.float64 else lib.tip_loss_forward)(p.data_ptr(), ldp, g.data_ptr() if g is not None else None, ldg, B, T, n_pose, n_vel,
                                       n_sbp, terms, stats.data_ptr(), ws.data_ptr(), nbytes.value,
                                       torch.cuda.current_stream(dev).cuda_stream)
         if rc < 0:
@@ -78,10 +81,11 @@ class _Loss(torch.autograd.Function):
         ldp, ldg, B, T, n_pose, n_vel, n_sbp, terms, shape = ctx.args
         dev = p.device
         W = n_pose + n_vel + 4 * n_sbp
-        dpred = torch.empty(shape, dtype=torch.float32, device=dev)
-        go = g_total.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+        dpred = torch.empty(shape, dtype=p.dtype, device=dev)
+        go = g_total.detach().to(device=dev, dtype=p.dtype).reshape(1).contiguous()
         with torch.cuda.device(dev):
-            rc = _lib.load().tip_loss_backward(p.data_ptr(), ldp, g.data_ptr() if g is not None else None, ldg, B, T, n_pose,
+            lib = _lib.load()
+            rc = (lib.tip_loss_backward_f64 if p.dtype == torch.float64 else lib.tip_loss_backward)(p.data_ptr(), ldp, g.data_ptr() if g is not None else None, ldg, B, T, n_pose,
                                                n_vel, n_sbp, terms, stats.data_ptr(), go.data_ptr(), dpred.data_ptr(), W,
                                                torch.cuda.current_stream(dev).cuda_stream)
         if rc < 0:

@@ -36,7 +36,7 @@ EXPORTS = (
     "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward",
     "tip_train_bytes_f64", "tip_train_forward_f64", "tip_train_backward_f64",
     "tip_combine_frames", "tip_combine_scratch_bytes", "tip_combine_sequence", "tip_gather_windows",
-    "tip_loss_ws_bytes", "tip_loss_forward", "tip_loss_backward",
+    "tip_loss_ws_bytes", "tip_loss_forward", "tip_loss_backward", "tip_loss_forward_f64", "tip_loss_backward_f64",
 )
 
 
@@ -140,6 +140,8 @@ def load() -> ctypes.CDLL:
     lib.tip_loss_ws_bytes.argtypes = [i32, i32, ctypes.POINTER(sz)]
     lib.tip_loss_forward.argtypes = [vp, ll, vp, ll, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]
     lib.tip_loss_backward.argtypes = [vp, ll, vp, ll, i32, i32, i32, i32, i32, i32, vp, vp, vp, ll, vp]
+    lib.tip_loss_forward_f64.argtypes = lib.tip_loss_forward.argtypes
+    lib.tip_loss_backward_f64.argtypes = lib.tip_loss_backward.argtypes
     for name in EXPORTS:
         if name not in ("tip_destroy", "tip_strerror", "tip_last_hip_error"):
             getattr(lib, name).restype = i32

@@ -21,7 +21,7 @@ Execution (ROCm tensors, fp32) — what `_dispatch` does:
     `tip_train_backward` (`_HipTrainFunction`): dropout drawn from a counter-based hash, activations stashed, every row
     computed.  Call .eval() for deterministic, stash-free inference (StreamingEngine warns when it is handed a
     .train()-mode model).  Configurations the training kernels do not cover (widths outside tip_train_bytes' range — d_model not 256/512/1024,
-    rnn_hid_size not a multiple of 64 up to 512 —, fp64, gradients
+    rnn_hid_size not a multiple of 64 up to 512 —, gradients
     w.r.t. the inputs; CPU tensors only when autograd records) run the torch-op composite with the same dropout, with a
     warning — never the dropout-free inference kernels, so the behaviour does not depend on the configuration.  A no_grad
     call on CPU tensors raises in either mode: inference values come from the HIP kernels or not at all.
@@ -202,7 +202,7 @@ class TF_RNN_Past_State(nn.Module):
             # not covered by the HIP training step: the torch-op composite, with the encoder dropout .train() implies
             if not self._warned_autograd:
                 warnings.warn("tip_amd: .train()-mode call (or autograd on CPU) that the HIP training kernels do not cover "
-                              "(unsupported widths, fp64, CPU tensors or gradients w.r.t. the inputs) — using the torch-op training "
+                              "(unsupported widths, CPU tensors or gradients w.r.t. the inputs) — using the torch-op training "
                               "composite with encoder dropout p=0.1 live, as in the reference; call .eval() for the "
                               "inference kernels")
                 self._warned_autograd = True
