@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from tip_amd import synth
+from tip_amd import lib as tlib
 from oracle import oracle
 from test_host_cpu import make_model, load_synth
 
@@ -114,3 +115,46 @@ def test_batch_beyond_the_32bit_descriptor_limit_is_chunked():
     assert torch.equal(yl, torch.cat([a, b]))
     assert torch.equal(yl[:300], yl[300:600])          # the same windows, 300 streams further on
     m.release_buffers()
+
+
+@pytest.mark.parametrize("B", [256 + 1, 256 + 16, 256 + 44, 512 + 7])
+def test_auto_splits_whole_rounds_and_a_small_remainder(B):
+    """VERDICT r03 weak #6 (batch quantisation): AUTO runs a batch of whole rounds of #CUs windows plus a small remainder as two
+    launch sequences — the rounds on the one-/two-window encoder, the remainder on the few-stream latency plan — when its cost model
+    says that beats one more full round.  One forward for the caller; every window bit-identical to what its part gives when
+    it is run on its own; both output forms; keep mask carried to both parts."""
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    if ncu != 256:
+        pytest.skip("the split is sized for a full 256-CU part")
+    m, w = _gpu_model(0)
+    x_imu, x_s = synth.make_inputs(synth.PAPER, B, 40, seed=300 + B)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    bm = B - B % 256
+    with torch.no_grad():
+        m.set_plan("auto", profile=1)
+        n0 = m.hip_forward_count()
+        y = m(xi, xs)
+        torch.cuda.synchronize()
+        assert m.hip_forward_count() == n0 + 1
+        stages = {n: k for n, _, k in m.profile_read()}
+        assert stages.get("fused_encoder") == 1 and stages.get("latency_chain") == 1, stages   # both parts ran
+        m.set_plan("auto", profile=0)
+        a, b = m(xi[:bm], xs[:bm]), m(xi[bm:], xs[bm:])
+        assert torch.equal(y, torch.cat([a, b]))
+        yl = m.forward_last(xi, xs)
+        assert torch.equal(yl, y[:, -1])
+        mask = (torch.rand_like(xs) > 0.3).float()
+        h = m._ensure_handle()
+        ws = torch.empty(h.workspace_bytes(B, 40), dtype=torch.uint8, device="cuda")
+        outs = []
+        for lo, hi in ((0, B), (0, bm), (bm, B)):
+            o = torch.empty(hi - lo, 40, 131, device="cuda")
+            h.forward(xi[lo:hi].contiguous().data_ptr(), xs[lo:hi].contiguous().data_ptr(), o.data_ptr(), hi - lo, 40, tlib.TIP_FWD_KEEP_MASK,
+                      mask[lo:hi].contiguous().data_ptr(), 1.25, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+            outs.append(o)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], torch.cat(outs[1:]))
+    sel = np.array([0, bm - 1, bm, B - 1])
+    yo = oracle.forward(synth.PAPER, w, x_imu[sel], x_s[sel], dtype=np.float64)
+    assert np.abs(y[torch.tensor(sel).cuda()].cpu().numpy() - yo).max() < TOL_TIGHT
+    m.check_handoffs()

@@ -339,3 +339,37 @@ def test_reset_parameters_matches_torch_initialisers(cfg):
         tol = 4.0 / np.sqrt(n)                               # ~4 sigma of the sample statistics of a uniform
         assert abs(float(a.mean())) <= bound * tol, k
         assert abs(float(a.std()) / (bound / np.sqrt(3.0)) - 1.0) <= 1.5 * tol + 0.01, k
+
+
+def test_f64_training_and_loss_entry_points_check_their_arguments_without_a_gpu():
+    """Round-4 entry points, the paths that return before any kernel is launched: tip_train_*_f64, tip_loss_*_f64."""
+    import ctypes
+    m = make_model(synth.PAPER)
+    h = m._ensure_handle()
+    lib = tlib.load()
+    s1, x1 = h.train_bytes(4, 40, fp64=True)
+    s2, x2 = h.train_bytes(8, 40, fp64=True)
+    per_row = 8 * (221 + 256 + 4 * (768 + 256 * 5 + 1024) + 512 * 2)        # U, X0, per layer qkv + att/z1/x1/z2/xo + hid, IH, HALL
+    assert s2 > s1 >= 4 * 40 * per_row and x2 > x1 > 0
+    with pytest.raises(tlib.TipStatusError) as ei:
+        h.train_bytes(4, 200, fp64=True)                                     # attention backward keeps two T x T tiles in LDS
+    assert ei.value.status == -2
+    assert make_model(dict(synth.TINY, with_rnn=False))._ensure_handle().train_bytes(2, 9, fp64=True)[0] > 0    # any configuration
+    n_t = len(h.tensor_table())
+    ptrs = [8] * n_t
+    with pytest.raises(tlib.TipStatusError) as ei:                          # wrong tensor count
+        h.train_forward(ptrs[:-1], 8, 8, None, 1.0, 0.1, 1, 8, 256, 1 << 40, 1, 40, 0, fp64=True)
+    assert ei.value.status == -1
+    with pytest.raises(tlib.TipStatusError) as ei:                          # stash too small
+        h.train_forward(ptrs, 8, 8, None, 1.0, 0.1, 1, 8, 256, 1024, 1, 40, 0, fp64=True)
+    assert ei.value.status == -4
+    with pytest.raises(tlib.TipStatusError) as ei:                          # p_drop out of range
+        h.train_forward(ptrs, 8, 8, None, 1.0, 1.0, 1, 8, 256, 1 << 40, 1, 40, 0, fp64=True)
+    assert ei.value.status == -1
+    with pytest.raises(tlib.TipStatusError) as ei:                          # gradient buffer too small
+        h.train_backward(ptrs, 8, 256, 1 << 40, 256, 1 << 40, 8, 10, 0.1, 1, 1, 40, 0, fp64=True)
+    assert ei.value.status == -1
+    vp = ctypes.c_void_p
+    assert lib.tip_loss_forward_f64(vp(8), 131, vp(8), 131, 2, 5, 108, 2, 5, 7, vp(8), vp(8), 512, None) == -1     # n_vel must be 0 or 3
+    assert lib.tip_loss_forward_f64(vp(8), 131, vp(8), 131, 2, 5, 108, 3, 5, 7, vp(8), vp(8), 8, None) == -4       # workspace too small
+    assert lib.tip_loss_backward_f64(vp(8), 131, vp(8), 131, 2, 5, 108, 3, 5, 7, vp(8), None, vp(8), 100, None) == -1   # ld_dpred < W

@@ -703,6 +703,36 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         return TIP_ERR_WORKSPACE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int cus = effective_cus(h->num_cus, s);   // the stream's CU mask counts, not the device's CU total
+    // AUTO, a batch that is whole rounds of #CUs windows plus a SMALL remainder: the one-window kernel takes a full round (0.53 ms +
+    // the tail) for the remainder alone, the few-stream latency plan takes 0.18-0.5 ms for up to ~50 windows.  Run the whole rounds
+    // and the remainder as two launch sequences when the model below says so (stream-ordered: they share the workspace); every
+    // window's result is bit-identical to what its part's plan gives on its own (tests/test_benchmarked_shapes_gpu.py).
+    // Costs in us from profiles/r04/plan_bench.txt and lat1_bench (B = 256 step 0.62 ms; latency plan 176 us up to 8 windows,
+    // + 8.2 us per further window); TIP_AUTO_SPLIT=0 disables (measurement).
+    if (h->plan == TIP_PLAN_AUTO && !h->demoted && cus == h->num_cus && B > cus && fused_supported(d, T) && fused_has_rnn_ih(d)) {
+        static const bool split_on = !(getenv("TIP_AUTO_SPLIT") && getenv("TIP_AUTO_SPLIT")[0] == '0');
+        const int r = B % cus, bm = B - r;
+        if (split_on && r >= 1 && latency_supported(d, r, T)) {
+            auto single = [&](long long b) {   // encoder rounds of the cheaper of the two fused kernels + recurrence / projection rounds
+                const long long rh = (b + cus - 1) / cus, r2 = ((b + 1) / 2 + cus - 1) / cus;
+                const long long enc = (fused2_supported(d, T) && r2 * 1049 < rh * 527) ? r2 * 1049 : rh * 527;
+                return enc + 96 * rh;
+            };
+            const long long lat = r <= 8 ? 176 + 2 * r : 192 + (long long)(8.2 * (r - 8));
+            if (single(bm) + lat < single(B)) {
+                const size_t row_i = (size_t)T * d.n_imu_total, row_s = (size_t)T * d.S;
+                const size_t row_y = (flags & TIP_FWD_LAST_ROW_ONLY) ? (size_t)d.S : row_s;
+                const uint64_t count0 = h->forward_count;
+                int st = tip_forward(h, x_imu, x_s, y, bm, T, flags, keep_mask, keep_scale, workspace, workspace_bytes, stream);
+                if (st != TIP_OK) return st;
+                st = tip_forward(h, x_imu + bm * row_i, x_s + bm * row_s, y + bm * row_y, r, T, flags, keep_mask ? keep_mask + bm * row_s : nullptr,
+                                 keep_scale, workspace, workspace_bytes, stream);
+                if (st != TIP_OK) return st;
+                h->forward_count = count0 + 1;   // one forward, two launch sequences
+                return TIP_OK;
+            }
+        }
+    }
     CoopSerial serial(h->device, s);   // forwards of different streams do not overlap on the device (cooperating kernels)
     if (serial.status != hipSuccess) return fail_hip(h, serial.status, "stream serialisation");
     const float* P = h->packed_dev;
