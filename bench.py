@@ -344,6 +344,22 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
                     "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(cfg, T, Bx / (ms * 1e-3)),
                     "headroom_vs_60fps": (1000.0 / ms) / 60.0}
         del bi, bs
+    # -- batches that are not whole rounds of 256 windows: AUTO runs whole rounds + a small remainder as two launch
+    #    sequences when that is cheaper than one more full round; a 300-window batch still pays most of a second round
+    try:
+        rem = {}
+        for Bx in (272, 300, 1000):
+            reps = (Bx + xi.shape[0] - 1) // xi.shape[0]
+            bi, bs = xi.repeat(reps, 1, 1)[:Bx].contiguous(), xs.repeat(reps, 1, 1)[:Bx].contiguous()
+            for _ in range(3):
+                model(bi, bs)
+            ms = timed_loop(lambda: model(bi, bs), 20)
+            rem[f"b{Bx}"] = {"ms_per_step": ms, "frames_per_s": Bx / (ms * 1e-3),
+                             "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(cfg, T, Bx / (ms * 1e-3))}
+            del bi, bs
+        out["non_round_batches"] = rem
+    except Exception as e:
+        out["non_round_batches"] = {"error": f"{type(e).__name__}: {e}"}
     # -- configs[2]: 1024 closed-loop streams through the on-device streaming engine (ingest -> forward(last row) -> consume)
     try:
         from scipy.spatial.transform import Rotation
