@@ -707,8 +707,8 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     // the tail) for the remainder alone, the few-stream latency plan takes 0.18-0.5 ms for up to ~50 windows.  Run the whole rounds
     // and the remainder as two launch sequences when the model below says so (stream-ordered: they share the workspace); every
     // window's result is bit-identical to what its part's plan gives on its own (tests/test_benchmarked_shapes_gpu.py).
-    // Costs in us from profiles/r04/plan_bench.txt and lat1_bench (B = 256 step 0.62 ms; latency plan 176 us up to 8 windows,
-    // + 8.2 us per further window); TIP_AUTO_SPLIT=0 disables (measurement).
+    // Costs in us from profiles/r04/plan_bench_split.txt (B = 256 step 0.625 ms; the remainder's latency-plan forward measured
+    // 163 / 177 / 201 / 282 / 372 us for 1 / 8 / 16 / 32 / 44 windows behind it); TIP_AUTO_SPLIT=0 disables (measurement).
     if (h->plan == TIP_PLAN_AUTO && !h->demoted && cus == h->num_cus && B > cus && fused_supported(d, T) && fused_has_rnn_ih(d)) {
         static const bool split_on = !(getenv("TIP_AUTO_SPLIT") && getenv("TIP_AUTO_SPLIT")[0] == '0');
         const int r = B % cus, bm = B - r;
@@ -718,7 +718,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
                 const long long enc = (fused2_supported(d, T) && r2 * 1049 < rh * 527) ? r2 * 1049 : rh * 527;
                 return enc + 96 * rh;
             };
-            const long long lat = r <= 8 ? 176 + 2 * r : 192 + (long long)(8.2 * (r - 8));
+            const long long lat = r <= 8 ? 162 + 2 * r : 178 + (long long)(6.6 * (r - 8));
             if (single(bm) + lat < single(B)) {
                 const size_t row_i = (size_t)T * d.n_imu_total, row_s = (size_t)T * d.S;
                 const size_t row_y = (flags & TIP_FWD_LAST_ROW_ONLY) ? (size_t)d.S : row_s;
