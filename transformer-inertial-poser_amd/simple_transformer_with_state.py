@@ -7,7 +7,7 @@ Mirrors the reference's module surface (/root/reference/simple_transformer_with_
   * forward(x_imu [B,T,72(+18)], x_s [B,T,size_s]) -> [B,T,size_s], inputs untouched, NaNs in x_s scrubbed (:60-102)
   * nn.Module services the callers use: .cuda(), .eval()/.train(), .parameters(), load_state_dict, torch.save
 
-Execution (ROCm tensors, fp32) — what `_dispatch` does:
+Execution (ROCm tensors; fp32, or fp64 throughout for a module built under --double) — what `_dispatch` does:
   * .eval() (or .train() with encoder dropout 0) and no gradient wanted: `tip_forward`, the inference plans
     (csrc/libtip_hip.so, include/tip_hip.h).  No fallback: a missing library or a CPU tensor under no_grad raises.
     A module built under train_model.py's --double (:84-85: fp64 parameters, fp64 windows) runs `tip_forward_f64` — the same
@@ -18,11 +18,11 @@ Execution (ROCm tensors, fp32) — what `_dispatch` does:
     WHETHER OR NOT autograd records.  Such a call — with gradients (train_model.py:132,175,192) or under
     torch.no_grad() (the reference's inference scripts never call .eval(): offline_testing_simple.py:98 is commented
     out, so they run with that dropout accidentally live) — goes to the HIP training step `tip_train_forward` /
-    `tip_train_backward` (`_HipTrainFunction`): dropout drawn from a counter-based hash, activations stashed, every row
-    computed.  Call .eval() for deterministic, stash-free inference (StreamingEngine warns when it is handed a
-    .train()-mode model).  Configurations the training kernels do not cover (widths outside tip_train_bytes' range — d_model not 256/512/1024,
-    rnn_hid_size not a multiple of 64 up to 512 —, gradients
-    w.r.t. the inputs; CPU tensors only when autograd records) run the torch-op composite with the same dropout, with a
+    `tip_train_backward` (`_HipTrainFunction`; `tip_train_forward_f64` / `tip_train_backward_f64` for an fp64 module): dropout
+    drawn from a counter-based hash, activations stashed, every row computed.  Call .eval() for deterministic, stash-free inference (StreamingEngine warns when it is handed a
+    .train()-mode model).  Configurations the training kernels do not cover (fp32 widths outside tip_train_bytes' range — d_model
+    not 256/512/1024, rnn_hid_size not a multiple of 64 up to 512 —, gradients w.r.t. the inputs; CPU tensors only when
+    autograd records) run the torch-op composite with the same dropout, with a
     warning — never the dropout-free inference kernels, so the behaviour does not depend on the configuration.  A no_grad
     call on CPU tensors raises in either mode: inference values come from the HIP kernels or not at all.
   * .eval() with autograd on (the runners never enter no_grad): HIP forward wrapped in an autograd.Function whose
@@ -30,7 +30,9 @@ Execution (ROCm tensors, fp32) — what `_dispatch` does:
   The handle's workspace / backward scratch are per (device, stream) (a small LRU, `release_buffers()` drops them).  A module
   may be called from several streams, but its forwards do NOT overlap on the device: the default plans launch cooperating
   kernels that need all of their workgroups resident at once, so the library serialises forwards of different streams (one
-  event wait per stream switch; csrc/tip_internal.h, CoopSerial).  A forward fills the GPU by itself.
+  event wait per stream switch; csrc/tip_internal.h, CoopSerial).  A forward fills the GPU by itself.  If another PROCESS holds
+  CUs and a cooperating launch loses a hand-off, that launch's rows are NaN and flagged; the next call demotes the handle to the
+  plans without hand-offs (TIP_OPT_DEMOTED; `undemote()` restores) and runs — see `_forward_hip`.
 
 Dropout semantics kept from the reference: `nn.Dropout(p)(x)` is constructed inside forward (:73,:77), i.e. it is
 always in training mode, so past_state_dropout / in_dropout are live even under .eval().  The HIP path draws the
