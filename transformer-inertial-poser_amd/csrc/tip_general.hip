@@ -1044,13 +1044,20 @@ constexpr int kQ4Rows = 4, kQ4Cluster = 4, kQ4Tiles = 4, kQ4LD = 512 + 16;
 // HEAD (NT = 1, forward, one tile per cluster, T = 40): the output projection y = h W_out^T + b (:102) runs as the kernel's epilogue
 // — head_ksplit_body (tip_head.h), member `cid` of a cluster taking window 4 tile + cid — instead of as a launch of its own: the
 // weight loads go out while the last step's stores travel, and the launch boundary (fixed cost + ramp, ~3 us) disappears.
-template <int NT, bool TRACE, bool BWD, bool HEAD = false>
-__global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict__ ih, const float* __restrict__ whh_frag,
+// WAVES = 4 (round 4): a member is a 4-wave workgroup owning 64 columns, a cluster EIGHT members, and TWO workgroups — members of
+// different clusters, i.e. different tiles — share a CU: the matrix work per CU is what it was, but while one workgroup sits in its
+// hand-off (pull, LDS, barrier: 0.7 us of a 1.9-us step) the other one's MFMAs have the pipe.  Same fragments per wave (16 columns x
+// all k), same accumulation order: bit-identical to WAVES = 8.
+template <int NT, bool TRACE, bool BWD, bool HEAD = false, int WAVES = 8>
+__global__ __launch_bounds__(WAVES * 64) void rnn_rows4_kernel(const float* __restrict__ ih, const float* __restrict__ whh_frag,
                                                         float* __restrict__ hall, unsigned* __restrict__ flags, int B, int T,
                                                         int ntiles, int hall_bytes, const float* __restrict__ gate, Guard gd,
                                                         unsigned etag, int abl, int ngroups, HeadFuse hf) {
     // abl: MEASUREMENT-ONLY ablations (wrong results), TIP_RNN_ABLATE: 1 = polls never wait, 2 = no MFMAs
-    constexpr int R = 512, KB = R / 16, CLUSTER = kQ4Cluster, LD = kQ4LD;
+    constexpr int R = 512, KB = R / 16, CLUSTER = 32 / WAVES, LD = kQ4LD;
+    constexpr int THREADS = WAVES * 64, PL = 8 / WAVES;            // 16-byte pieces of a pulled tile per thread: 1 (8 waves) or 2 (4 waves)
+    static_assert(WAVES == 8 || WAVES == 4, "cluster of 4 or 8 members");
+    static_assert(!HEAD || WAVES == 8, "the projection epilogue is written for 8-wave members");
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [2 buffers][NT tiles][4 rows][LD]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1060,7 +1067,7 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
     // never assumed); the grid is whole rounds of 8 clusters, the clusters past `ngroups` have nothing to do
     const int cid = (blockIdx.x >> 3) % CLUSTER, group = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / CLUSTER);
     if (group >= ngroups) return;
-    const int nb = cid * 8 + wave;                                // global 16-column block of this wave
+    const int nb = cid * WAVES + wave;                            // global 16-column block of this wave
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hall, 0, hall_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ih), 0, hall_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BWD ? gate : ih), 0, hall_bytes, 0x00020000);
@@ -1070,7 +1077,8 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
     if (dead && !HEAD) return;
     const unsigned spin_big = guard_spin_limit(gd.fault, 1u << 22), spin_pull = guard_spin_limit(gd.fault, 1u << 20);
 
-    const int prow = tid >> 7, pcol = (tid & 127) * 4;            // this thread's 16 bytes of a pulled tile: row, first column
+    // this thread's 16-byte pieces of a pulled tile: row prow, columns pcol + 4 i (i < PL)
+    const int prow = tid / (THREADS / 4), pcol = (tid % (THREADS / 4)) * (4 * PL);
     const int tpg = (ntiles + ngroups - 1) / ngroups;             // tiles per cluster
     const unsigned rowbytes = (unsigned)T * R * 4;
     int vpull[NT], vout[NT];
@@ -1174,16 +1182,18 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
                 // pull h_{t-1}: 16 bytes per thread and tile, sc1 loads (agent-scope coherent); the wave re-asks while any of
                 // its lanes still sees a sentinel word
                 const int so = tp * (R * 4);
-                u32x4 v[NT];
+                u32x4 v[NT * PL];
                 bool gave_up = true;
                 const unsigned pull_lim = poisoned ? 1u : spin_pull;
                 for (unsigned spins = 0; spins < pull_lim; ++spins) {
                     bool pend = false;
                     asm volatile("" ::: "memory");   // the addresses are loop invariant: without this the optimiser polls a register
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) v[n] = __builtin_amdgcn_raw_buffer_load_b128(hrs, vpull[n], so, 16);
-#pragma unroll
                     for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int i = 0; i < PL; ++i) v[n * PL + i] = __builtin_amdgcn_raw_buffer_load_b128(hrs, vpull[n] + 16 * i, so, 16);
+#pragma unroll
+                    for (int n = 0; n < NT * PL; ++n)
                         pend |= v[n].x == kRnnSentinel || v[n].y == kRnnSentinel || v[n].z == kRnnSentinel || v[n].w == kRnnSentinel;
                     if (TRACE && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 24) {
                         if (spins == 0) g_rnn_trace[160 + (t - 1) * 4 + 0] = __builtin_amdgcn_s_memtime();
@@ -1198,7 +1208,7 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
                     if (!poisoned && lane == 0) note_spin_timeout(gd.err);
                     poisoned = true;
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {   // what never arrived becomes NaN, not the sentinel
+                    for (int n = 0; n < NT * PL; ++n) {   // what never arrived becomes NaN, not the sentinel
                         if (v[n].x == kRnnSentinel) v[n].x = kPoisonBits;
                         if (v[n].y == kRnnSentinel) v[n].y = kPoisonBits;
                         if (v[n].z == kRnnSentinel) v[n].z = kPoisonBits;
@@ -1206,7 +1216,9 @@ __global__ __launch_bounds__(512) void rnn_rows4_kernel(const float* __restrict_
                     }
                 }
 #pragma unroll
-                for (int n = 0; n < NT; ++n) *reinterpret_cast<u32x4*>(buf + n * kQ4Rows * LD + lds_w) = v[n];
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int i = 0; i < PL; ++i) *reinterpret_cast<u32x4*>(buf + n * kQ4Rows * LD + lds_w + 4 * i) = v[n * PL + i];
                 if (TRACE && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 24) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     g_rnn_trace[160 + (t - 1) * 4 + 2] = __builtin_amdgcn_s_memtime();
@@ -1383,16 +1395,18 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
     return hipGetLastError();
 }
 
-// four-row tiles on 4-workgroup clusters (rnn_rows4_kernel); sentinel hand-off only
-template <int NT>
+// four-row tiles on 4-workgroup clusters of 8-wave members, or (WAVES = 4) 8-workgroup clusters of 4-wave members, two per CU
+// (rnn_rows4_kernel); sentinel hand-off only
+template <int NT, int WAVES>
 static hipError_t launch_rnn_rows4_nt(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T, int ntiles,
                                       int groups, long long hb, const Guard& gd, hipStream_t s, const float* gate, unsigned etag, int num_cus,
                                       const HeadFuse* hf = nullptr, bool* head_done = nullptr) {
     constexpr int smem = 2 * NT * kQ4Rows * kQ4LD * (int)sizeof(float);
+    constexpr int CLUSTER = 32 / WAVES, THREADS = WAVES * 64;
     static int trace = -1, abl = -1;
     if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
     if (abl < 0) abl = getenv("TIP_RNN_ABLATE") ? atoi(getenv("TIP_RNN_ABLATE")) : 0;   // measurement only (profiles/): never set in production
-    if constexpr (NT == 1) {
+    if constexpr (NT == 1 && WAVES == 8) {
         // output projection fused as the kernel's epilogue (see the kernel): one tile per cluster, T = 40, forward, no tracing
         if (hf && !gate && !trace && !abl && T == 40 && ntiles <= groups) {
             constexpr int smem_h = smem > hd::LDS_BYTES ? smem : hd::LDS_BYTES;
@@ -1415,25 +1429,25 @@ static hipError_t launch_rnn_rows4_nt(const float* ih, const float* whh_frag, fl
     }
     static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
-        for (const void* f : {reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, false>), reinterpret_cast<const void*>(rnn_rows4_kernel<NT, true, false>),
-                              reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, true>)}) {
+        for (const void* f : {reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, false, false, WAVES>), reinterpret_cast<const void*>(rnn_rows4_kernel<NT, true, false, false, WAVES>),
+                              reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, true, false, WAVES>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return e;
         }
         attr_set = true;
     }
     static PerDeviceInt occ_dev; int& occ = occ_dev.cur();   // every member of a cluster must be resident while its partners wait for it: ask the runtime
-    hipError_t ce = check_coresident(rnn_rows4_kernel<NT, false, false>, 512, smem, groups * kQ4Cluster, num_cus, &occ);
+    hipError_t ce = check_coresident(rnn_rows4_kernel<NT, false, false, false, WAVES>, THREADS, smem, groups * CLUSTER, num_cus, &occ);
     if (ce != hipSuccess) return ce;
     // Members of a cluster are taken 8 workgroup ids apart (one XCD); that needs a grid of whole rounds of 8 clusters.  The
     // workgroups of the clusters that pad the last round exit at once (they hold no resources anybody waits for).
-    const dim3 grid((groups + 7) / 8 * 8 * kQ4Cluster), block(512);
+    const dim3 grid((groups + 7) / 8 * 8 * CLUSTER), block(THREADS);
     if (gate)
-        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, true>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups, HeadFuse{});
+        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, true, false, WAVES>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups, HeadFuse{});
     else if (trace)
-        hipLaunchKernelGGL((rnn_rows4_kernel<NT, true, false>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups, HeadFuse{});
+        hipLaunchKernelGGL((rnn_rows4_kernel<NT, true, false, false, WAVES>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups, HeadFuse{});
     else
-        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, false>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups, HeadFuse{});
+        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, false, false, WAVES>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups, HeadFuse{});
     return hipGetLastError();
 }
 
@@ -1441,8 +1455,15 @@ static hipError_t launch_rnn_rows4(const float* ih, const float* whh_frag, float
                                    bool hall_armed, const Guard& gd, hipStream_t s, const float* gate = nullptr,
                                    const HeadFuse* hf = nullptr, bool* head_done = nullptr) {
     const int ntiles = (B + kQ4Rows - 1) / kQ4Rows;
+    // 4-wave members, 8 per cluster: when the batch leaves CUs idle (tiles x 8 <= #CUs, i.e. B <= 128 on a full part) every member
+    // gets a CU of its own with half the matrix work per step: 62 vs 76 us at B = 100.  With two members per CU (B = 256) the hoped-for
+    // overlap of one's hand-off with the other's MFMAs does not happen: 84 vs 78 us (profiles/r04/rnn_w4.txt), so the 8-wave members
+    // stay there.  Bit-identical either way.  TIP_RNN_W4=0 / 1 forces one (measurement).
+    static int w4 = -2;
+    if (w4 == -2) w4 = getenv("TIP_RNN_W4") ? (getenv("TIP_RNN_W4")[0] == '1' ? 1 : 0) : -1;
+    const bool use_w4 = (w4 == 1 || (w4 == -1 && ntiles * 8 <= num_cus)) && !(hf && !gate);   // (the fused output projection exists for 8-wave members)
     int groups = ntiles;
-    const int maxg = num_cus / kQ4Cluster > 0 ? num_cus / kQ4Cluster : 1;   // keep every cluster co-resident
+    const int maxg = num_cus / kQ4Cluster > 0 ? num_cus / kQ4Cluster : 1;   // keep every cluster co-resident (W4: 8 members, two per CU: the same count)
     if (groups > maxg) groups = maxg;
     const int tpg = (ntiles + groups - 1) / groups;                          // tiles per cluster
     const long long hb = (long long)B * T * 512 * 4;
@@ -1456,9 +1477,14 @@ static hipError_t launch_rnn_rows4(const float* ih, const float* whh_frag, float
     }
     const unsigned etag = next_rnn_launch_tag();
     // tiles a cluster advances together: as many as it owns, up to kQ4Tiles (3 -> 4: the pad tile is out of range and multiplies zeros)
-    if (tpg <= 1) return launch_rnn_rows4_nt<1>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus, hf, head_done);
-    if (tpg == 2) return launch_rnn_rows4_nt<2>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
-    return launch_rnn_rows4_nt<kQ4Tiles>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
+    if (use_w4) {
+        if (tpg <= 1) return launch_rnn_rows4_nt<1, 4>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
+        if (tpg == 2) return launch_rnn_rows4_nt<2, 4>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
+        return launch_rnn_rows4_nt<kQ4Tiles, 4>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
+    }
+    if (tpg <= 1) return launch_rnn_rows4_nt<1, 8>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus, hf, head_done);
+    if (tpg == 2) return launch_rnn_rows4_nt<2, 8>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
+    return launch_rnn_rows4_nt<kQ4Tiles, 8>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
 }
 
 // one 16-window tile per `cluster` workgroups on the streaming kernel (rnn_kernel): any rnn_hidden that is a multiple of 64
