@@ -192,15 +192,22 @@ def test_two_window_plan_golden_and_auto_selection(golden):
         y = _run(models[key], case["x_imu"], case["x_s"])
         assert np.abs(y - case["y64"]).max() < TOL_TIGHT, tag
     # AUTO weighs rounds of the two-window kernel (2 x #CUs windows each, 1.065 ms) against rounds of the hybrid one-window
-    # kernel (#CUs windows, 0.553 ms): the result is bit-identical to the explicit plan it picked
+    # kernel (#CUs windows, 0.553 ms): the result is bit-identical to the explicit plan it picked.  A remainder of up to 64 windows
+    # behind whole rounds goes to the latency plan as a second launch sequence (round 4): bit-identical to the two parts run alone.
     m, _ = _gpu_model(cfg, 0)
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    for B, picked in ((ncu + 3, "fused2"), (2 * ncu + 3, "fusedh"), (3 * ncu + 5, "fused2"), (ncu - 1, "fusedh"), (65, "fusedh")):
+    for B, picked, rem in ((ncu + 100, "fused2", 0), (2 * ncu + 100, "fusedh", 0), (3 * ncu + 105, "fused2", 0), (ncu - 1, "fusedh", 0),
+                           (65, "fusedh", 0), (ncu + 3, "fusedh", 3), (2 * ncu + 3, "fused2", 3), (3 * ncu + 5, "fusedh", 5)):
         x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=77)
         m.set_plan("auto")
         ya = _run(m, x_imu, x_s)
         m.set_plan(picked)
-        assert np.array_equal(ya, _run(m, x_imu, x_s)), (B, picked)
+        bm = B - rem
+        parts = [_run(m, x_imu[:bm], x_s[:bm])]
+        if rem:
+            m.set_plan("latency")
+            parts.append(_run(m, x_imu[bm:], x_s[bm:]))
+        assert np.array_equal(ya, np.concatenate(parts)), (B, picked, rem)
 
 
 @pytest.mark.parametrize("B,T", [(1, 40), (5, 40), (3, 33), (2, 36), (256, 40), (300, 40)])
