@@ -196,8 +196,9 @@ def test_two_window_plan_golden_and_auto_selection(golden):
     # behind whole rounds goes to the latency plan as a second launch sequence (round 4): bit-identical to the two parts run alone.
     m, _ = _gpu_model(cfg, 0)
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    for B, picked, rem in ((ncu + 100, "fused2", 0), (2 * ncu + 100, "fusedh", 0), (3 * ncu + 105, "fused2", 0), (ncu - 1, "fusedh", 0),
-                           (65, "fusedh", 0), (ncu + 3, "fusedh", 3), (2 * ncu + 3, "fused2", 3), (3 * ncu + 5, "fusedh", 5)):
+    for B, picked, rem in ((ncu + 200, "fused2", 0), (2 * ncu + 200, "fusedh", 0), (3 * ncu + 205, "fused2", 0), (ncu - 1, "fusedh", 0),
+                           (65, "fused1s", 0), (ncu // 2, "fused1s", 0), (ncu // 2 + 1, "fusedh", 0), (49, "fused1s", 0), (48, "latency", 0),
+                           (ncu + 3, "fusedh", 3), (2 * ncu + 3, "fused2", 3), (3 * ncu + 5, "fusedh", 5), (ncu + 100, "fusedh", 100)):
         x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=77)
         m.set_plan("auto")
         ya = _run(m, x_imu, x_s)
@@ -205,7 +206,7 @@ def test_two_window_plan_golden_and_auto_selection(golden):
         bm = B - rem
         parts = [_run(m, x_imu[:bm], x_s[:bm])]
         if rem:
-            m.set_plan("latency")
+            m.set_plan("latency" if rem <= 48 else "fused1s")
             parts.append(_run(m, x_imu[bm:], x_s[bm:]))
         assert np.array_equal(ya, np.concatenate(parts)), (B, picked, rem)
 

@@ -352,7 +352,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
     if (!h) return TIP_ERR_INVALID_ARG;
     switch (option) {
         case TIP_OPT_PLAN:
-            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_LATENCY1) return TIP_ERR_INVALID_ARG;
+            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED1S) return TIP_ERR_INVALID_ARG;
             h->plan = value;
             return TIP_OK;
         case TIP_OPT_PROFILE:
@@ -704,7 +704,8 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int cus = effective_cus(h->num_cus, s);   // the stream's CU mask counts, not the device's CU total
     // AUTO, a batch that is whole rounds of #CUs windows plus a SMALL remainder: the one-window kernel takes a full round (0.53 ms +
-    // the tail) for the remainder alone, the few-stream latency plan takes 0.18-0.5 ms for up to ~50 windows.  Run the whole rounds
+    // the tail) for the remainder alone; the few-stream latency plan takes 0.16-0.4 ms for up to 48 windows and the window-split
+    // encoder 0.45 ms for up to #CUs / 2.  Run the whole rounds
     // and the remainder as two launch sequences when the model below says so (stream-ordered: they share the workspace); every
     // window's result is bit-identical to what its part's plan gives on its own (tests/test_benchmarked_shapes_gpu.py).
     // Costs in us from profiles/r04/plan_bench_split.txt (B = 256 step 0.625 ms; the remainder's latency-plan forward measured
@@ -712,14 +713,19 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if (h->plan == TIP_PLAN_AUTO && !h->demoted && cus == h->num_cus && B > cus && fused_supported(d, T) && fused_has_rnn_ih(d)) {
         static const bool split_on = !(getenv("TIP_AUTO_SPLIT") && getenv("TIP_AUTO_SPLIT")[0] == '0');
         const int r = B % cus, bm = B - r;
-        if (split_on && r >= 1 && latency_supported(d, r, T)) {
+        // what the remainder costs on its own (us; AUTO's choice for that many windows, below): the latency plan up to 48 windows
+        // (measured 163 / 177 / 201 / 282 / 372 us for 1 / 8 / 16 / 32 / 44), the window-split encoder up to #CUs / 2 (0.45 ms)
+        long long rem = -1;
+        if (r >= 1 && r <= 48 && latency_supported(d, r, T)) rem = r <= 8 ? 162 + 2 * r : 178 + (long long)(6.6 * (r - 8));
+        else if (r >= 1 && fused2_supported(d, T) && fused1s_fits(r, cus)) rem = 452;
+        else if (r >= 1 && latency_supported(d, r, T)) rem = 178 + (long long)(6.6 * (r - 8));
+        if (split_on && rem >= 0) {
             auto single = [&](long long b) {   // encoder rounds of the cheaper of the two fused kernels + recurrence / projection rounds
                 const long long rh = (b + cus - 1) / cus, r2 = ((b + 1) / 2 + cus - 1) / cus;
                 const long long enc = (fused2_supported(d, T) && r2 * 1049 < rh * 527) ? r2 * 1049 : rh * 527;
                 return enc + 96 * rh;
             };
-            const long long lat = r <= 8 ? 162 + 2 * r : 178 + (long long)(6.6 * (r - 8));
-            if (single(bm) + lat < single(B)) {
+            if (single(bm) + rem < single(B)) {
                 const size_t row_i = (size_t)T * d.n_imu_total, row_s = (size_t)T * d.S;
                 const size_t row_y = (flags & TIP_FWD_LAST_ROW_ONLY) ? (size_t)d.S : row_s;
                 const uint64_t count0 = h->forward_count;
@@ -761,8 +767,13 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         // (TIP_PLAN_LATENCY1, the same chain as one persistent kernel, is opt-in: measured 181-207 us against the chain's 176 at B = 1 —
         // the stage bodies, not the kernel boundaries, bound the chain; CHANGELOG.md, round 4.  TIP_LAT1=1 makes AUTO take it: measurement.)
         static const bool lat1 = getenv("TIP_LAT1") && getenv("TIP_LAT1")[0] == '1';
+        // few streams: the latency plan up to 48 windows (0.18-0.4 ms), then ONE window on TWO CUs while half of the CUs would idle
+        // otherwise (window-split encoder, 0.45 ms per step against 0.60 for one window per CU; T = 40 only), the latency plan again
+        // where that does not apply (49-64 windows of a shorter window)
         if (!h->demoted && lat1 && cus == h->num_cus && latency1_supported(d, B, T)) plan = TIP_PLAN_LATENCY1;
-        else if (!h->demoted && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;   // <= 64 streams: spread each window over many CUs (0.65 vs 0.86 ms at B = 64)
+        else if (!h->demoted && B <= 48 && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;
+        else if (!h->demoted && fused2_supported(d, T) && fused1s_fits(B, cus)) plan = TIP_PLAN_FUSED1S;
+        else if (!h->demoted && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;   // <= 64 streams: spread each window over many CUs
         else plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
     }
     if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO) {
@@ -778,6 +789,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if ((plan == TIP_PLAN_FUSED || plan == TIP_PLAN_FUSEDH) && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2S && !(fused2_supported(d, T) && fused2s_fits(B, cus) && B <= 1024)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (plan == TIP_PLAN_FUSED1S && !(fused2_supported(d, T) && fused1s_fits(B, cus))) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY1 && !latency1_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED16 && !(s16_supported(d, T) && L.s16_floats)) return TIP_ERR_UNSUPPORTED_CONFIG;
@@ -819,6 +831,12 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         TIP_TRY(launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall,
                                     B, T, cus, gd, s), "latency_chain");
         rnn_done = true;
+    } else if (plan == TIP_PLAN_FUSED1S) {
+        StageScope sc(h, s, "fused_encoder");
+        ih_done = true;
+        hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
+        TIP_TRY(launch_fused_encoder1s(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr,
+                                       W0 + ws.xchg, B, cus, gd, s), "fused_encoder1s");
     } else if (plan == TIP_PLAN_FUSED2S) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = true;

@@ -448,13 +448,25 @@ constexpr int IMG_FLOATS = ROWS * D;                 // one partial-sum image: 8
 constexpr int PAIR_IMG_FLOATS = 4 * IMG_FLOATS;      // per pair: [slot 2][half 2] images
 constexpr int PAIR_FLAG_WORDS = 32;                  // per pair, behind ALL images: [0..1] hand-off counters, [16..17] XCC id + 1
 }
-size_t fused2s_xchg_floats(int B) { return (size_t)((B + 1) / 2) * (f2::PAIR_IMG_FLOATS + f2::PAIR_FLAG_WORDS); }
+// (sized for either form: window pairs, or — B <= 128 — single windows with 48-row images)
+size_t fused2s_xchg_floats(int B) {
+    const size_t pair = (size_t)((B + 1) / 2) * (f2::PAIR_IMG_FLOATS + f2::PAIR_FLAG_WORDS);
+    const size_t one = B <= 128 ? (size_t)B * (4 * 48 * f2::D + f2::PAIR_FLAG_WORDS) : 0;
+    return pair > one ? pair : one;
+}
 
+// NWIN = 2: a window PAIR on two workgroups (80 rows = 5 row blocks, no padding).  NWIN = 1 (round 4): ONE window on two workgroups
+// (48 rows = 3 row blocks, 8 of them pad): the same column split and hand-offs, 3/5 of the matrix work per workgroup — for batches
+// that leave at least half of the CUs idle (64 < B <= #CUs / 2), where a window's latency, not the round count, is what a step costs.
+template <int NWIN>
 __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
     const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ ih_out, unsigned* __restrict__ hall_sentinel,
     float* __restrict__ xchg, int xchg_bytes, int B, int NI, int S, int L, int wbytes, int ih_off_b, Guard gd) {
     using namespace f2;
+    constexpr int RBK = NWIN == 2 ? 5 : 3;                     // 16-row blocks a workgroup carries
+    constexpr int IMG = RBK * 16 * D;                          // one partial-sum image: 8 waves x 2 RBK tiles x 64 lanes x 4
+    constexpr int PAIR_IMG = 4 * IMG;                          // per pair: [slot 2][half 2] images
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int s_same_xcd;
     __shared__ int s_poison;   // a hand-off wait gave up: the partner's partial sums count as NaN from here on (and no wait spins again)
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, wbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xchg, 0, xchg_bytes, 0x00020000);
     const int voff = lane * 16;
-    const int npairs = (B + 1) / 2;
+    const int npairs = (B + NWIN - 1) / NWIN;                  // "pair" = the NWIN windows two partner workgroups share
     // workgroup -> (pair, half): the two halves of a pair are 8 workgroup ids apart, i.e. on the same XCD when ids go
     // round-robin over the 8 XCDs (checked below, never assumed)
     const int xslot = blockIdx.x & 7, jj = blockIdx.x >> 3;
@@ -477,13 +489,13 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     const int pair = (jj >> 1) * 8 + xslot;
     if (pair >= npairs) return;                           // (both halves of a surplus pair leave together)
     if ((gd.fault & 1) && pair == 0 && half == 1) return; // TIP_OPT_FAULT_INJECT: this partner never arrives
-    float* px = xchg + (size_t)pair * PAIR_IMG_FLOATS;
-    unsigned* pflag = reinterpret_cast<unsigned*>(xchg + (size_t)npairs * PAIR_IMG_FLOATS) + pair * PAIR_FLAG_WORDS;
-    const int px_off_b = (int)((size_t)pair * PAIR_IMG_FLOATS * 4);
+    float* px = xchg + (size_t)pair * PAIR_IMG;
+    unsigned* pflag = reinterpret_cast<unsigned*>(xchg + (size_t)npairs * PAIR_IMG) + pair * PAIR_FLAG_WORDS;
+    const int px_off_b = (int)((size_t)pair * PAIR_IMG * 4);
 
-    auto rows_off = [&](int (&off)[RB], int base, int ld) {
+    auto rows_off = [&](int (&off)[RBK], int base, int ld) {
 #pragma unroll
-        for (int r = 0; r < RB; ++r) off[r] = base + (r * 16 + l15) * ld + lg * 4;
+        for (int r = 0; r < RBK; ++r) off[r] = base + (r * 16 + l15) * ld + lg * 4;
     };
     if (tid == 0) {
         unsigned xcc;
@@ -495,14 +507,14 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     for (int i = tid; i < C_FLOATS; i += THREADS) C[i] = 0.f;
     __syncthreads();
 
-    const int win0 = pair * 2;
-    const int nwin = (win0 + 1 < B) ? 2 : 1;
+    const int win0 = pair * NWIN;
+    const int nwin = (NWIN == 2 && win0 + 1 < B) ? 2 : 1;
     int handoff = 0;                                      // hand-offs done so far (uniform)
 
     // X[:, all columns] += (partial of half 0 + partial of half 1) + bias: acc holds THIS half's partial.
     // (A wave-to-wave variant — every wave publishing its own 10 tiles under its own counter and waiting only for its twin,
     // no workgroup barrier inside the hand-off — measured SLOWER: 0.787 vs 0.768 ms per step.)
-    auto exchange_add = [&](f32x4 (&acc)[RB][2], const float* bias) {
+    auto exchange_add = [&](f32x4 (&acc)[RBK][2], const float* bias) {
         if (tid == 0 && s_same_xcd < 0) {                  // first hand-off: are the partners on one XCD?
             unsigned mine = 0, theirs = 0;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(mine));
@@ -524,14 +536,14 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         if (blockIdx.x == 0 && tid == 0 && handoff < 8) g_f2s_trace[handoff * 4 + 0] = __builtin_amdgcn_s_memtime();
         const bool same = s_same_xcd == 1;
         const int slot = handoff & 1;
-        float* mine_img = px + (size_t)(slot * 2 + half) * IMG_FLOATS;
-        const int their_off_b = px_off_b + (slot * 2 + (1 - half)) * IMG_FLOATS * 4;
+        float* mine_img = px + (size_t)(slot * 2 + half) * IMG;
+        const int their_off_b = px_off_b + (slot * 2 + (1 - half)) * IMG * 4;
         // image: [wave][r * 2 + n][lane] float4
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
+        for (int r = 0; r < RBK; ++r)
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                float* dst = mine_img + ((wave * (RB * 2) + r * 2 + n) * 64 + lane) * 4;
+                float* dst = mine_img + ((wave * (RBK * 2) + r * 2 + n) * 64 + lane) * 4;
                 if (same) {
                     *reinterpret_cast<f32x4*>(dst) = acc[r][n];
                 } else {
@@ -560,19 +572,19 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         __syncthreads();
         const bool poisoned = s_poison != 0;
         if (blockIdx.x == 0 && tid == 0 && handoff < 8) g_f2s_trace[handoff * 4 + 2] = __builtin_amdgcn_s_memtime();
-        f32x4 other[RB][2];
+        f32x4 other[RBK][2];
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
+        for (int r = 0; r < RBK; ++r)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
                 other[r][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                  xrs, lane * 16, their_off_b + (wave * (RB * 2) + r * 2 + n) * 1024, 16));   // sc1: not from L1
+                                  xrs, lane * 16, their_off_b + (wave * (RBK * 2) + r * 2 + n) * 1024, 16));   // sc1: not from L1
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int col = (wave * 2 + n) * 16 + l15;
             const float bv = bias[col];
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
+            for (int r = 0; r < RBK; ++r)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float oth = poisoned ? __uint_as_float(kPoisonBits) : other[r][n][e];
@@ -611,17 +623,17 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         }
         __syncthreads();
         // ---- in_linear (:79) + channel shuffle (folded), all 256 columns on both halves ----------------------------------
-        f32x4 acc[RB][2];
-        zero_acc2<RB, 2>(acc);
-        int au[RB];
+        f32x4 acc[RBK][2];
+        zero_acc2<RBK, 2>(acc);
+        int au[RBK];
         rows_off(au, X_FLOATS, LDU);
-        gemm_phase2<RB, 2, KIN / 16>(acc, smem, au, rsrc, voff, in_soff, (KIN / 16) * 1024, g_in, in_soff, (KIN / 16) * 1024);
+        gemm_phase2<RBK, 2, KIN / 16>(acc, smem, au, rsrc, voff, in_soff, (KIN / 16) * 1024, g_in, in_soff, (KIN / 16) * 1024);
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int col = (wave * 2 + n) * 16 + l15;
             const float bv = wts[IN_B + col];
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
+            for (int r = 0; r < RBK; ++r)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] = acc[r][n][e] + bv;
         }
@@ -634,8 +646,8 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     for (int layer = 0; layer < L; ++layer) {
         const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
         const int lbase = (int)((LAYER0 + (size_t)layer * LAYER_FLOATS) * 4);
-        f32x4 acc_o[RB][2];
-        zero_acc2<RB, 2>(acc_o);
+        f32x4 acc_o[RBK][2];
+        zero_acc2<RBK, 2>(acc_o);
         WRing2<2> g_o, g_f2r;
         WRing2<1> g_v, g_f1;
 #pragma unroll 1
@@ -645,42 +657,48 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
             const int head = q * 4 + hl;
             {
                 const int isk = wave >> 2;            // 0: Q, 1: K
-                f32x4 acc[RB][1];
-                zero_acc2<RB, 1>(acc);
+                f32x4 acc[RBK][1];
+                zero_acc2<RBK, 1>(acc);
                 const int soff = lbase + (int)(QKV_W * 4) + (isk * 16 + head) * 16 * 1024;
-                int ax[RB];
+                int ax[RBK];
                 rows_off(ax, 0, LDX);
-                gemm_phase2<RB, 1, 16>(acc, smem, ax, rsrc, voff, soff, 0, g_q, soff, 0);
+                gemm_phase2<RBK, 1, 16>(acc, smem, ax, rsrc, voff, soff, 0, g_q, soff, 0);
                 const int vsoff = lbase + (int)(QKV_W * 4) + (32 + head) * 16 * 1024;
                 ring2_prefetch<1>(g_v, rsrc, voff, vsoff, 0);
                 const float bv = LW[QKV_B + isk * D + head * 16 + l15];
                 float* plane = isk ? Kp : Qp;
 #pragma unroll
-                for (int r = 0; r < RB; ++r)
+                for (int r = 0; r < RBK; ++r)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         plane[prow(r * 16 + lg * 4 + e) * LDQ + hl * 16 + l15] = acc[r][0][e] + bv;
                 const float bvv = LW[QKV_B + 2 * D + head * 16 + l15];
+                // V of head hl: waves hl and 4 + hl share the row blocks (0-2 | 3-4 for a pair, 0-1 | 2 for one window)
+                constexpr int VA = NWIN == 2 ? 3 : 2, VB = RBK - VA;
                 if (wave < 4) {
-                    f32x4 av[3][1];
-                    zero_acc2<3, 1>(av);
-                    const int ar[3] = {ax[0], ax[1], ax[2]};
-                    gemm_phase2<3, 1, 16>(av, smem, ar, rsrc, voff, vsoff, 0, g_v, vsoff, 0);
+                    f32x4 av[VA][1];
+                    zero_acc2<VA, 1>(av);
+                    int ar[VA];
 #pragma unroll
-                    for (int r = 0; r < 3; ++r)
+                    for (int r = 0; r < VA; ++r) ar[r] = ax[r];
+                    gemm_phase2<VA, 1, 16>(av, smem, ar, rsrc, voff, vsoff, 0, g_v, vsoff, 0);
+#pragma unroll
+                    for (int r = 0; r < VA; ++r)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             Vt[(hl * 16 + l15) * LDV + prow(r * 16 + lg * 4 + e)] = av[r][0][e] + bvv;
                 } else {
-                    f32x4 av[2][1];
-                    zero_acc2<2, 1>(av);
-                    const int ar[2] = {ax[3], ax[4]};
-                    gemm_phase2<2, 1, 16>(av, smem, ar, rsrc, voff, vsoff, 0, g_v, vsoff, 0);
+                    f32x4 av[VB][1];
+                    zero_acc2<VB, 1>(av);
+                    int ar[VB];
 #pragma unroll
-                    for (int r = 0; r < 2; ++r)
+                    for (int r = 0; r < VB; ++r) ar[r] = ax[VA + r];
+                    gemm_phase2<VB, 1, 16>(av, smem, ar, rsrc, voff, vsoff, 0, g_v, vsoff, 0);
+#pragma unroll
+                    for (int r = 0; r < VB; ++r)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            Vt[(hl * 16 + l15) * LDV + prow((r + 3) * 16 + lg * 4 + e)] = av[r][0][e] + bvv;
+                            Vt[(hl * 16 + l15) * LDV + prow((r + VA) * 16 + lg * 4 + e)] = av[r][0][e] + bvv;
                 }
                 for (int i = tid; i < 64 * 16; i += THREADS) {
                     const int ch = i >> 4, k = i & 15;
@@ -702,36 +720,36 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
                 ring2_prefetch<1>(g_f1, rsrc, voff, lbase + (int)(W1_W * 4) + (half * 32 + wave) * 16 * 1024, 0);
             {
                 const int osoff = lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + q * 4) * 1024;
-                int ao[RB];
+                int ao[RBK];
 #pragma unroll
-                for (int r = 0; r < RB; ++r) ao[r] = X_FLOATS + prow(r * 16 + l15) * LDQ + lg * 4;
-                gemm_phase2<RB, 2, 4>(acc_o, smem, ao, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
+                for (int r = 0; r < RBK; ++r) ao[r] = X_FLOATS + prow(r * 16 + l15) * LDQ + lg * 4;
+                gemm_phase2<RBK, 2, 4>(acc_o, smem, ao, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
             }
             __syncthreads();
         }
         exchange_add(acc_o, LW + WO_B);               // X += out-projection (both halves' heads) + bias
         __syncthreads();
-        layernorm_rows16<f2::ROWS, f2::LDX>(X, LW + G1, LW + BE1, wave, lane);
+        layernorm_rows16<RBK * 16, f2::LDX>(X, LW + G1, LW + BE1, wave, lane);
         __syncthreads();
         // ---- feed-forward: this half's 4 hidden chunks of 128; its K-half of linear2 accumulates in registers ---------------
         float* Hc = C;
-        f32x4 acc_f[RB][2];
-        zero_acc2<RB, 2>(acc_f);
+        f32x4 acc_f[RBK][2];
+        zero_acc2<RBK, 2>(acc_f);
 #pragma unroll 1
         for (int ff = 0; ff < 4; ++ff) {
             const int f = half * 4 + ff;
             {
-                f32x4 acc[RB][1];
-                zero_acc2<RB, 1>(acc);
+                f32x4 acc[RBK][1];
+                zero_acc2<RBK, 1>(acc);
                 const int w1off = lbase + (int)(W1_W * 4) + (f * 8 + wave) * 16 * 1024;
-                int ax[RB];
+                int ax[RBK];
                 rows_off(ax, 0, LDX);
-                gemm_phase2<RB, 1, 16>(acc, smem, ax, rsrc, voff, w1off, 0, g_f1, w1off, 0);
+                gemm_phase2<RBK, 1, 16>(acc, smem, ax, rsrc, voff, w1off, 0, g_f1, w1off, 0);
                 ring2_prefetch<2>(g_f2r, rsrc, voff, lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 8) * 1024, 64 * 1024);
                 const int col = wave * 16 + l15;
                 const float bv = LW[W1_B + f * 128 + col];
 #pragma unroll
-                for (int r = 0; r < RB; ++r)
+                for (int r = 0; r < RBK; ++r)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) Hc[(r * 16 + lg * 4 + e) * LDH + col] = fmaxf(acc[r][0][e] + bv, 0.f);
             }
@@ -739,9 +757,9 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
             {
                 if (ff < 3) ring2_prefetch<1>(g_f1, rsrc, voff, lbase + (int)(W1_W * 4) + ((f + 1) * 8 + wave) * 16 * 1024, 0);
                 const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 8) * 1024;
-                int ah[RB];
+                int ah[RBK];
                 rows_off(ah, X_FLOATS, LDH);
-                gemm_phase2<RB, 2, 8>(acc_f, smem, ah, rsrc, voff, w2off, 64 * 1024, g_f2r, w2off, 64 * 1024);
+                gemm_phase2<RBK, 2, 8>(acc_f, smem, ah, rsrc, voff, w2off, 64 * 1024, g_f2r, w2off, 64 * 1024);
             }
             __syncthreads();
         }
@@ -750,20 +768,20 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
                                                    ((wave >> 2) * 16 + half * 8 + (wave & 3)) * 16 * 1024, 0);
         exchange_add(acc_f, LW + W2_B);               // X += linear2 (both halves' hidden units) + bias
         __syncthreads();
-        layernorm_rows16<f2::ROWS, f2::LDX>(X, LW + G2, LW + BE2, wave, lane);
+        layernorm_rows16<RBK * 16, f2::LDX>(X, LW + G2, LW + BE2, wave, lane);
         __syncthreads();
     }
     // ---- RNN input projection, columns 256 * half ..: IH = X W_ih^T + (b_ih + b_hh) -> HBM ------------------------------------
     {
-        f32x4 acc[RB][2];
-        zero_acc2<RB, 2>(acc);
+        f32x4 acc[RBK][2];
+        zero_acc2<RBK, 2>(acc);
         const int isoff = ih_off_b + (half * 16 + wave * 2) * 16 * 1024;
         WRing2<2> g_ih;
         ring2_prefetch<2>(g_ih, rsrc, voff, isoff, 16 * 1024);
-        int ax[RB];
+        int ax[RBK];
         rows_off(ax, 0, LDX);
         // (transposed tiles, 16-byte buffer stores bounded to the pair's real rows, biases first: as in fused_encoder2_kernel)
-        gemm_phase2<RB, 2, 16, true>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
+        gemm_phase2<RBK, 2, 16, true>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
         const int nrows = nwin * T;
         const __amdgpu_buffer_rsrc_t io_rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ih_out + (size_t)win0 * T * R), 0,
                                                                                 __builtin_amdgcn_readfirstlane(nrows * R * 4), 0x00020000);
@@ -773,7 +791,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
+            for (int r = 0; r < RBK; ++r)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_f2, acc[r][n] + bv4[n]), io_rs,
                                                        ((r * 16 + l15) * R + (half * 16 + wave * 2 + n) * 16 + lg * 4) * 4, 0, 0);
     }
@@ -815,38 +833,54 @@ hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const floa
 }
 
 bool fused2s_fits(int B, int num_cus) { return B >= 1 && 2 * ((B + 1) / 2) <= num_cus; }
+bool fused1s_fits(int B, int num_cus) { return B >= 1 && 2 * B <= num_cus && B <= 128; }
 
-hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
-                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
-                                  int B, int num_cus, const Guard& gd, hipStream_t s) {
+// nwin = 2: a window pair per two workgroups (TIP_PLAN_FUSED2S); nwin = 1: ONE window per two workgroups (TIP_PLAN_FUSED1S)
+template <int NWIN>
+static hipError_t launch_fused_encoder_split(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
+                                             const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
+                                             int B, int num_cus, const Guard& gd, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (!fused2s_fits(B, num_cus)) return hipErrorInvalidValue;       // every workgroup must be resident: partners wait for each other
+    if (!(NWIN == 2 ? fused2s_fits(B, num_cus) : fused1s_fits(B, num_cus))) return hipErrorInvalidValue;   // every workgroup must be resident: partners wait for each other
     static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder2s_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder2s_kernel<NWIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f2::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int npairs = (B + 1) / 2;
-    const size_t xbytes = fused2s_xchg_floats(B) * sizeof(float);
-    if (xbytes > 0x7fffffffull) return hipErrorInvalidValue;
+    constexpr int RBK = NWIN == 2 ? 5 : 3;
+    constexpr size_t PAIR_IMG = (size_t)4 * RBK * 16 * f2::D;
+    const int npairs = (B + NWIN - 1) / NWIN;
+    const size_t xbytes = (size_t)npairs * (PAIR_IMG + f2::PAIR_FLAG_WORDS) * sizeof(float);
+    if (xbytes > 0x7fffffffull || xbytes > fused2s_xchg_floats(B) * sizeof(float)) return hipErrorInvalidValue;
     // hand-off counters and XCC words (behind all images) start from zero every forward
-    hipError_t e = hipMemsetAsync(xchg + (size_t)npairs * f2::PAIR_IMG_FLOATS, 0, (size_t)npairs * f2::PAIR_FLAG_WORDS * 4, s);
+    hipError_t e = hipMemsetAsync(xchg + (size_t)npairs * PAIR_IMG, 0, (size_t)npairs * f2::PAIR_FLAG_WORDS * 4, s);
     if (e != hipSuccess) return e;
     const int grid = (2 * npairs + 15) / 16 * 16;                      // whole (xcd, j) blocks of the id -> (pair, half) map
     {
         // the runtime's own answer to "how many of these workgroups fit on a CU" (what a cooperative launch would check): the
         // 2 * npairs working ones must all be resident (surplus ids leave at once)
         static PerDeviceInt occ_dev; int& occ = occ_dev.cur();
-        hipError_t ce = check_coresident(fused_encoder2s_kernel, f2::THREADS, (size_t)f2::LDS_BYTES, 2 * npairs, num_cus, &occ);
+        hipError_t ce = check_coresident(fused_encoder2s_kernel<NWIN>, f2::THREADS, (size_t)f2::LDS_BYTES, 2 * npairs, num_cus, &occ);
         if (ce != hipSuccess) return ce;
     }
     const size_t ih_off = f2::LAYER0 + (size_t)d.L * f2::LAYER_FLOATS;
-    hipLaunchKernelGGL(fused_encoder2s_kernel, dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+    hipLaunchKernelGGL(fused_encoder2s_kernel<NWIN>, dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
                        keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), xchg, (int)xbytes, B, d.n_imu_total, d.S, d.L,
                        (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4), gd);
     return hipGetLastError();
+}
+
+hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
+                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
+                                  int B, int num_cus, const Guard& gd, hipStream_t s) {
+    return launch_fused_encoder_split<2>(d, fused_w, x_imu, x_s, keep_mask, keep_scale, ih_out, hall_sentinel, xchg, B, num_cus, gd, s);
+}
+hipError_t launch_fused_encoder1s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
+                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
+                                  int B, int num_cus, const Guard& gd, hipStream_t s) {
+    return launch_fused_encoder_split<1>(d, fused_w, x_imu, x_s, keep_mask, keep_scale, ih_out, hall_sentinel, xchg, B, num_cus, gd, s);
 }
 
 // general plan: bias (+ residual) (+ ReLU)

@@ -471,5 +471,10 @@ hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const flo
 hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, int B,
                                  int num_cus, hipStream_t s);
+// window-split form: ONE window on two co-resident workgroups (columns split, 48 rows each), for 2 B <= #CUs, B <= 128
+bool fused1s_fits(int B, int num_cus);
+hipError_t launch_fused_encoder1s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
+                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
+                                  int B, int num_cus, const Guard& gd, hipStream_t s);
 
 }  // namespace tip

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(CSRC, "libtip_hip.so")
 TIP_FWD_LAST_ROW_ONLY = 0x1
 TIP_FWD_KEEP_MASK = 0x2
 TIP_PLAN_AUTO, TIP_PLAN_GENERAL, TIP_PLAN_FUSED, TIP_PLAN_LATENCY, TIP_PLAN_FUSED2, TIP_PLAN_FUSED2S, TIP_PLAN_FUSEDH = 0, 1, 2, 3, 4, 5, 6
+TIP_PLAN_FUSED1S = 10   # one window on two co-resident workgroups (64 < B <= 128)
 TIP_PLAN_LATENCY1 = 9   # the latency plan as one persistent kernel (B <= 8)
 TIP_PLAN_GENERAL16 = 8  # exploratory: general plan with split-fp16 panel GEMMs (needs TIP_OPT_PACK_SPLIT16 bit 1 before packing)
 TIP_PLAN_FUSED16 = 7   # exploratory: fp32 operands emulated as split fp16 on the f16 matrix cores (csrc/tip_s16.hip); opt-in only
