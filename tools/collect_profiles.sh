@@ -90,5 +90,12 @@ d=/tmp/prof_f16; rm -rf $d
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $d -- $BENCH --plan fused16 > "$OUT/bench_fused16_under_rocprof.json" 2> /dev/null)
 t=$(find $d -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python tools/kstats_table.py "$t" > "$OUT/kernel_medians_bench_fused16_B256_T40.txt"
 timeout 300 python bench.py --plan fused16 --no-cpu-baseline --no-extra --steps 300 --warmup 20 > "$OUT/bench_fused16_n1.json" 2> /dev/null
+# round 4: AUTO over a batch sweep against the round-3 selection (remainder split, window-split plan), the persistent latency kernel
+{ echo "AUTO (round 4)"; timeout 300 python tools/auto_sweep.py 2> /dev/null; echo "round-3 selection (TIP_PLAN_BASE=1)"; TIP_PLAN_BASE=1 timeout 300 python tools/auto_sweep.py 2> /dev/null; } > "$OUT/auto_sweep.txt"
+timeout 300 python tools/lat1_bench.py 2> /dev/null | grep "^B=" > "$OUT/lat1_bench.txt"
+TIP_LAT1_TRACE=1 timeout 120 python tools/lat1_trace.py 1 2> /dev/null | grep -v "^model\|^number" > "$OUT/lat1_trace_B1.txt"
+timeout 300 python tools/f1s_bench.py 2> /dev/null | grep "^B=\|fused1s vs" > "$OUT/f1s_bench.txt"
+{ echo "8-wave members"; TIP_RNN_W4=0 timeout 200 python tools/rnn_ab.py 2> /dev/null | grep "^B="; echo "4-wave members (TIP_RNN_W4=1)"; TIP_RNN_W4=1 timeout 200 python tools/rnn_ab.py 2> /dev/null | grep "^B="; } > "$OUT/rnn_w4.txt"
+timeout 300 python tools/plan_bench.py 257 272 300 356 1000 2> /dev/null | grep "^B=" > "$OUT/plan_bench_split.txt"
 for p in mfma4x4_probe hop_probe permlane_probe launch_probe ffn_split16_probe mfma_f64_probe imul_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
 ls -la "$OUT"
