@@ -86,12 +86,13 @@ typedef enum tip_status {
                                TIP_PLAN_FUSED16; needs TIP_OPT_PACK_SPLIT16 bit 1 set before packing (the split weight copies double the
                                packed image of a big model, so they are not packed by default) */
 #define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);
-                              AUTO picks it for B <= 64 */
+                              AUTO picks it for B <= 48 (and up to 64 where TIP_PLAN_FUSED1S does not apply: T < 40) */
 
 #define TIP_PLAN_FUSED1S 10 /* window-split: ONE window on TWO co-resident workgroups of one XCD — TIP_PLAN_FUSED2S's column split and
                                hand-offs at 48 rows (3/5 of the matrix work per workgroup) — for batches that leave at least half of the
                                CUs idle: needs 2 B <= #CUs and B <= 128.  Its own summation order (K-halves of out-proj / linear2 summed
-                               across the partners). */
+                               across the partners).  AUTO picks it for 48 < B <= #CUs / 2 at T = 40 and for remainders of 49-128
+                               windows behind whole rounds. */
 #define TIP_PLAN_LATENCY1 9 /* TIP_PLAN_LATENCY as ONE persistent kernel (B <= 8): the same stages separated by grid barriers instead of
                                kernel boundaries, recurrence and output projection as its tail; bit-identical to TIP_PLAN_LATENCY.  32
                                co-resident workgroups (one XCD).  Its hand-off flags live in the last 1 KiB of the packed weight image
