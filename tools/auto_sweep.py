@@ -27,11 +27,13 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 8, 32, 48, 49, 64, 65, 100, 128, 
             m(xi, xs)
         torch.cuda.synchronize()
         n = 200 if B <= 512 else 50
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(n):
-            m(xi, xs)
-        e1.record(); e1.synchronize()
-    ms = e0.elapsed_time(e1) / n
+        ms = 1e9
+        for _ in range(3):                       # best of three loops: a loop of 30-100 ms can catch a clock dip or a neighbour's burst
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                m(xi, xs)
+            e1.record(); e1.synchronize()
+            ms = min(ms, e0.elapsed_time(e1) / n)
     print(f"B={B:5d}: {ms * 1e3:8.1f} us/step  {B / ms:9.1f} k frames/s  {B / (ms * 1e-3) * fpw / 157.3e12:6.3f} of fp32-MFMA peak", flush=True)
 m.check_handoffs()
