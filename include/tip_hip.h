@@ -86,13 +86,17 @@ typedef enum tip_status {
                                TIP_PLAN_FUSED16; needs TIP_OPT_PACK_SPLIT16 bit 1 set before packing (the split weight copies double the
                                packed image of a big model, so they are not packed by default) */
 #define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);
-                              AUTO picks it for B <= 48 (and up to 64 where TIP_PLAN_FUSED1S does not apply: T < 40) */
+                              AUTO picks it for B <= 32 (up to 48 where four CUs per window are not to be had, and up to 64 where
+                              TIP_PLAN_FUSED1S does not apply: T < 40) */
 
 #define TIP_PLAN_FUSED1S 10 /* window-split: ONE window on TWO co-resident workgroups of one XCD — TIP_PLAN_FUSED2S's column split and
                                hand-offs at 48 rows (3/5 of the matrix work per workgroup) — for batches that leave at least half of the
                                CUs idle: needs 2 B <= #CUs and B <= 128.  Its own summation order (K-halves of out-proj / linear2 summed
-                               across the partners).  AUTO picks it for 48 < B <= #CUs / 2 at T = 40 and for remainders of 49-128
-                               windows behind whole rounds. */
+                               across the partners).  While 4 B <= #CUs (and B <= 64) the window is carried by FOUR workgroups instead (quads
+                               of heads, quarters of the hidden units and of the RNN input projection; partial sums added p0 + p1 + p2 + p3
+                               in every partner; TIP_OPT_F1S_PARTS pins the form) — the two forms differ in summation order, each is
+                               deterministic.  AUTO picks it for 32 < B <= #CUs / 2 at T = 40 and for remainders of 33-128 windows behind
+                               whole rounds. */
 #define TIP_PLAN_LATENCY1 9 /* TIP_PLAN_LATENCY as ONE persistent kernel (B <= 8): the same stages separated by grid barriers instead of
                                kernel boundaries, recurrence and output projection as its tail; bit-identical to TIP_PLAN_LATENCY.  32
                                co-resident workgroups (one XCD).  Its hand-off flags live in the last 1 KiB of the packed weight image
@@ -131,6 +135,8 @@ typedef enum tip_status {
                                  (hybrid one-window / two-window encoder or the general plan, single-workgroup recurrence tiles): no
                                  co-residency needed, a co-tenant costs throughput instead of frames.  Explicit plans / cluster sizes are
                                  still honoured.  The training step's two recurrences likewise run on single-workgroup tiles.  Default 0. */
+#define TIP_OPT_F1S_PARTS   9 /* workgroups that share ONE window under TIP_PLAN_FUSED1S: 2, 4, or 0 (default) = four while 4 B <= #CUs and
+                                 B <= 64, two otherwise.  An explicit 4 outside that range is TIP_ERR_UNSUPPORTED_CONFIG at the forward. */
 
 /* ---- lifetime: replaces TF_RNN_Past_State.__init__ (simple_transformer_with_state.py:9-54) ---------------- */
 TIP_API int tip_abi_version(void);

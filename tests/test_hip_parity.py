@@ -192,13 +192,14 @@ def test_two_window_plan_golden_and_auto_selection(golden):
         y = _run(models[key], case["x_imu"], case["x_s"])
         assert np.abs(y - case["y64"]).max() < TOL_TIGHT, tag
     # AUTO weighs rounds of the two-window kernel (2 x #CUs windows each, 1.065 ms) against rounds of the hybrid one-window
-    # kernel (#CUs windows, 0.553 ms): the result is bit-identical to the explicit plan it picked.  A remainder of up to 64 windows
-    # behind whole rounds goes to the latency plan as a second launch sequence (round 4): bit-identical to the two parts run alone.
+    # kernel (#CUs windows, 0.553 ms): the result is bit-identical to the explicit plan it picked.  A remainder
+    # behind whole rounds goes to the latency plan (<= 32 windows) or the window-split encoder as a second launch sequence (round 4): bit-identical to the two parts run alone.
     m, _ = _gpu_model(cfg, 0)
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     for B, picked, rem in ((ncu + 200, "fused2", 0), (2 * ncu + 200, "fusedh", 0), (3 * ncu + 205, "fused2", 0), (ncu - 1, "fusedh", 0),
-                           (65, "fused1s", 0), (ncu // 2, "fused1s", 0), (ncu // 2 + 1, "fusedh", 0), (49, "fused1s", 0), (48, "latency", 0),
-                           (ncu + 3, "fusedh", 3), (2 * ncu + 3, "fused2", 3), (3 * ncu + 5, "fusedh", 5), (ncu + 100, "fusedh", 100)):
+                           (65, "fused1s", 0), (ncu // 2, "fused1s", 0), (ncu // 2 + 1, "fusedh", 0), (49, "fused1s", 0), (33, "fused1s", 0), (32, "latency", 0),
+                           (ncu + 3, "fusedh", 3), (2 * ncu + 3, "fused2", 3), (3 * ncu + 5, "fusedh", 5), (ncu + 100, "fusedh", 100),
+                           (ncu + 40, "fusedh", 40)):
         x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=77)
         m.set_plan("auto")
         ya = _run(m, x_imu, x_s)
@@ -206,7 +207,7 @@ def test_two_window_plan_golden_and_auto_selection(golden):
         bm = B - rem
         parts = [_run(m, x_imu[:bm], x_s[:bm])]
         if rem:
-            m.set_plan("latency" if rem <= 48 else "fused1s")
+            m.set_plan("latency" if rem <= 32 else "fused1s")
             parts.append(_run(m, x_imu[bm:], x_s[bm:]))
         assert np.array_equal(ya, np.concatenate(parts)), (B, picked, rem)
 

@@ -53,7 +53,7 @@ def test_auto_keeps_the_launch_chain():
     """latency1 is opt-in (measured no faster than the chain): AUTO's few-stream plan is still "latency" + a separate output
     projection."""
     m, _ = _model()
-    for B in (1, 8, 9, 48):                                  # (beyond 48 windows of 40 frames AUTO takes the window-split encoder)
+    for B in (1, 8, 9, 32):                                  # (beyond 32 windows of 40 frames AUTO takes the window-split encoder)
         x_imu, x_s = synth.make_inputs(synth.PAPER, B, 40, seed=3)
         xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
         m.set_plan("auto", profile=1)

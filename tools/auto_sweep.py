@@ -13,7 +13,7 @@ m.load_state_dict({k: torch.tensor(v) for k, v in synth.make_weights(cfg, seed=0
 m = m.cuda().eval()
 base = os.environ.get("TIP_PLAN_BASE") == "1"
 fpw = synth.flops_per_window(cfg, 40)
-for B in [int(a) for a in sys.argv[1:]] or [1, 8, 32, 48, 49, 64, 65, 100, 128, 129, 200, 256, 257, 272, 300, 356, 384, 512, 556, 1000, 1024, 2048]:
+for B in [int(a) for a in sys.argv[1:]] or [1, 8, 32, 33, 40, 48, 49, 64, 65, 100, 128, 129, 200, 256, 257, 272, 300, 320, 356, 384, 512, 556, 1000, 1024, 2048]:
     x_imu, x_s = synth.make_inputs(cfg, min(B, 256), 40)
     xi = torch.tensor(np.tile(x_imu, ((B + 255) // 256, 1, 1))[:B]).cuda()
     xs = torch.tensor(np.tile(x_s, ((B + 255) // 256, 1, 1))[:B]).cuda()

@@ -12,7 +12,7 @@ with contextlib.redirect_stdout(sys.stderr):
 m.load_state_dict({k: torch.tensor(v) for k, v in synth.make_weights(cfg, seed=0).items()})
 m = m.cuda().eval()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
-sizes = [49, 64, 100, 127, 128, 257, 300, 356, 384, 1, 7, 48]
+sizes = [33, 49, 64, 100, 127, 128, 257, 300, 320, 356, 384, 1, 7, 32, 48]
 data, ref = {}, {}
 for B in sizes:
     x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=B)

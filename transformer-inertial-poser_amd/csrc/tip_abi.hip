@@ -390,6 +390,10 @@ int tip_set_option(tip_handle* h, int option, int value) {
             if (value < 0 || value > 1) return TIP_ERR_INVALID_ARG;
             h->demoted = value;
             return TIP_OK;
+        case TIP_OPT_F1S_PARTS:
+            if (value != 0 && value != 2 && value != 4) return TIP_ERR_INVALID_ARG;
+            h->f1s_parts = value;
+            return TIP_OK;
         default: return TIP_ERR_INVALID_ARG;
     }
 }
@@ -414,6 +418,7 @@ int tip_get_option(const tip_handle* h, int option, int* value) {
         case TIP_OPT_PACK_SPLIT16: *value = h->pack_split16; return TIP_OK;
         case TIP_OPT_AUTO_DEMOTE: *value = h->auto_demote; return TIP_OK;
         case TIP_OPT_DEMOTED: *value = h->demoted; return TIP_OK;
+        case TIP_OPT_F1S_PARTS: *value = h->f1s_parts; return TIP_OK;
         default: return TIP_ERR_INVALID_ARG;
     }
 }
@@ -704,8 +709,8 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int cus = effective_cus(h->num_cus, s);   // the stream's CU mask counts, not the device's CU total
     // AUTO, a batch that is whole rounds of #CUs windows plus a SMALL remainder: the one-window kernel takes a full round (0.53 ms +
-    // the tail) for the remainder alone; the few-stream latency plan takes 0.16-0.4 ms for up to 48 windows and the window-split
-    // encoder 0.45 ms for up to #CUs / 2.  Run the whole rounds
+    // the tail) for the remainder alone; the few-stream latency plan takes 0.16-0.28 ms for up to 32 windows and the window-split
+    // encoder 0.30 ms for up to #CUs / 4 (one window on four CUs), 0.45 ms for up to #CUs / 2.  Run the whole rounds
     // and the remainder as two launch sequences when the model below says so (stream-ordered: they share the workspace); every
     // window's result is bit-identical to what its part's plan gives on its own (tests/test_benchmarked_shapes_gpu.py).
     // Costs in us from profiles/r04/plan_bench_split.txt (B = 256 step 0.625 ms; the remainder's latency-plan forward measured
@@ -713,11 +718,13 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if (h->plan == TIP_PLAN_AUTO && !h->demoted && cus == h->num_cus && B > cus && fused_supported(d, T) && fused_has_rnn_ih(d)) {
         static const bool split_on = !(getenv("TIP_AUTO_SPLIT") && getenv("TIP_AUTO_SPLIT")[0] == '0');
         const int r = B % cus, bm = B - r;
-        // what the remainder costs on its own (us; AUTO's choice for that many windows, below): the latency plan up to 48 windows
-        // (measured 163 / 177 / 201 / 282 / 372 us for 1 / 8 / 16 / 32 / 44), the window-split encoder up to #CUs / 2 (0.45 ms)
+        // what the remainder costs on its own (us; AUTO's choice for that many windows, below): the latency plan up to 32 windows
+        // (measured 163 / 177 / 201 / 282 / 372 us for 1 / 8 / 16 / 32 / 44), the window-split encoder up to #CUs / 4 (0.305 ms) and
+        // #CUs / 2 (0.45 ms)
         long long rem = -1;
-        if (r >= 1 && r <= 48 && latency_supported(d, r, T)) rem = r <= 8 ? 162 + 2 * r : 178 + (long long)(6.6 * (r - 8));
-        else if (r >= 1 && fused2_supported(d, T) && fused1s_fits(r, cus)) rem = 452;
+        const bool quad = fused2_supported(d, T) && h->f1s_parts != 2 && fused1s_quad_fits(r, cus);
+        if (r >= 1 && r <= (quad ? 32 : 48) && latency_supported(d, r, T)) rem = r <= 8 ? 162 + 2 * r : 178 + (long long)(6.6 * (r - 8));
+        else if (r >= 1 && fused2_supported(d, T) && fused1s_fits(r, cus)) rem = quad ? 305 : 452;
         else if (r >= 1 && latency_supported(d, r, T)) rem = 178 + (long long)(6.6 * (r - 8));
         if (split_on && rem >= 0) {
             auto single = [&](long long b) {   // encoder rounds of the cheaper of the two fused kernels + recurrence / projection rounds
@@ -767,11 +774,12 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         // (TIP_PLAN_LATENCY1, the same chain as one persistent kernel, is opt-in: measured 181-207 us against the chain's 176 at B = 1 —
         // the stage bodies, not the kernel boundaries, bound the chain; CHANGELOG.md, round 4.  TIP_LAT1=1 makes AUTO take it: measurement.)
         static const bool lat1 = getenv("TIP_LAT1") && getenv("TIP_LAT1")[0] == '1';
-        // few streams: the latency plan up to 48 windows (0.18-0.4 ms), then ONE window on TWO CUs while half of the CUs would idle
-        // otherwise (window-split encoder, 0.45 ms per step against 0.60 for one window per CU; T = 40 only), the latency plan again
-        // where that does not apply (49-64 windows of a shorter window)
+        // few streams: the latency plan up to 32 windows (0.17-0.28 ms), then ONE window on FOUR CUs up to #CUs / 4 windows (0.30 ms
+        // per step; the latency plan takes 0.36 ms for 40 windows) and on TWO up to #CUs / 2 (0.45 ms against 0.60 for one window
+        // per CU) — the window-split encoder, T = 40 only; the latency plan again where that does not apply (<= 64 shorter windows)
+        const bool f1s4 = fused2_supported(d, T) && h->f1s_parts != 2 && fused1s_quad_fits(B, cus);
         if (!h->demoted && lat1 && cus == h->num_cus && latency1_supported(d, B, T)) plan = TIP_PLAN_LATENCY1;
-        else if (!h->demoted && B <= 48 && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;
+        else if (!h->demoted && B <= (f1s4 ? 32 : 48) && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;
         else if (!h->demoted && fused2_supported(d, T) && fused1s_fits(B, cus)) plan = TIP_PLAN_FUSED1S;
         else if (!h->demoted && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;   // <= 64 streams: spread each window over many CUs
         else plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
@@ -789,7 +797,8 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if ((plan == TIP_PLAN_FUSED || plan == TIP_PLAN_FUSEDH) && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2S && !(fused2_supported(d, T) && fused2s_fits(B, cus) && B <= 1024)) return TIP_ERR_UNSUPPORTED_CONFIG;
-    if (plan == TIP_PLAN_FUSED1S && !(fused2_supported(d, T) && fused1s_fits(B, cus))) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (plan == TIP_PLAN_FUSED1S && !(fused2_supported(d, T) && fused1s_fits(B, cus) && (h->f1s_parts != 4 || fused1s_quad_fits(B, cus))))
+        return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY1 && !latency1_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED16 && !(s16_supported(d, T) && L.s16_floats)) return TIP_ERR_UNSUPPORTED_CONFIG;
@@ -836,7 +845,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         ih_done = true;
         hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
         TIP_TRY(launch_fused_encoder1s(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr,
-                                       W0 + ws.xchg, B, cus, gd, s), "fused_encoder1s");
+                                       W0 + ws.xchg, B, cus, h->f1s_parts, gd, s), "fused_encoder1s");
     } else if (plan == TIP_PLAN_FUSED2S) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = true;

@@ -13,6 +13,7 @@
 // row blocks 0-2, waves 4-7 row blocks 3-4), attention (wave = head x window), out-projection partial } ->
 // LayerNorm1 -> 8 x { linear1 chunk + ReLU, linear2 partial } -> LayerNorm2.
 #include <string.h>
+#include <algorithm>
 
 #include "tip_internal.h"
 #include "tip_attention.h"
@@ -452,13 +453,17 @@ constexpr int PAIR_FLAG_WORDS = 32;                  // per pair, behind ALL ima
 size_t fused2s_xchg_floats(int B) {
     const size_t pair = (size_t)((B + 1) / 2) * (f2::PAIR_IMG_FLOATS + f2::PAIR_FLAG_WORDS);
     const size_t one = B <= 128 ? (size_t)B * (4 * 48 * f2::D + f2::PAIR_FLAG_WORDS) : 0;
-    return pair > one ? pair : one;
+    const size_t four = B <= 64 ? (size_t)B * (8 * 48 * f2::D + f2::PAIR_FLAG_WORDS) : 0;   // one window on four workgroups
+    return std::max(pair, std::max(one, four));
 }
 
 // NWIN = 2: a window PAIR on two workgroups (80 rows = 5 row blocks, no padding).  NWIN = 1 (round 4): ONE window on two workgroups
 // (48 rows = 3 row blocks, 8 of them pad): the same column split and hand-offs, 3/5 of the matrix work per workgroup — for batches
 // that leave at least half of the CUs idle (64 < B <= #CUs / 2), where a window's latency, not the round count, is what a step costs.
-template <int NWIN>
+// NPART = 4 (round 4, NWIN = 1 only): ONE window on FOUR workgroups of one XCD — part p owns heads 4 p .. 4 p + 3 (one quad), hidden
+// units 256 p .., columns 128 p .. of the RNN input projection; the partial sums of out-proj / linear2 meet as p0 + p1 + p2 + p3 in
+// every partner (same order: bit-identical rows whichever partner stores them).  For batches that leave three quarters of the CUs idle.
+template <int NWIN, int NPART = 2>
 __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
     const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ ih_out, unsigned* __restrict__ hall_sentinel,
@@ -466,7 +471,8 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     using namespace f2;
     constexpr int RBK = NWIN == 2 ? 5 : 3;                     // 16-row blocks a workgroup carries
     constexpr int IMG = RBK * 16 * D;                          // one partial-sum image: 8 waves x 2 RBK tiles x 64 lanes x 4
-    constexpr int PAIR_IMG = 4 * IMG;                          // per pair: [slot 2][half 2] images
+    constexpr int PAIR_IMG = 2 * NPART * IMG;                  // per pair: [slot 2][part NPART] images
+    static_assert(NPART == 2 || (NPART == 4 && NWIN == 1), "two partners, or four for a single window");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int s_same_xcd;
     __shared__ int s_poison;   // a hand-off wait gave up: the partner's partial sums count as NaN from here on (and no wait spins again)
@@ -485,8 +491,8 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     // workgroup -> (pair, half): the two halves of a pair are 8 workgroup ids apart, i.e. on the same XCD when ids go
     // round-robin over the 8 XCDs (checked below, never assumed)
     const int xslot = blockIdx.x & 7, jj = blockIdx.x >> 3;
-    const int half = jj & 1;
-    const int pair = (jj >> 1) * 8 + xslot;
+    const int half = jj % NPART;                           // this workgroup's part (0 .. NPART-1; "half" when NPART = 2)
+    const int pair = (jj / NPART) * 8 + xslot;
     if (pair >= npairs) return;                           // (both halves of a surplus pair leave together)
     if ((gd.fault & 1) && pair == 0 && half == 1) return; // TIP_OPT_FAULT_INJECT: this partner never arrives
     float* px = xchg + (size_t)pair * PAIR_IMG;
@@ -516,28 +522,33 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     // no workgroup barrier inside the hand-off — measured SLOWER: 0.787 vs 0.768 ms per step.)
     auto exchange_add = [&](f32x4 (&acc)[RBK][2], const float* bias) {
         if (tid == 0 && s_same_xcd < 0) {                  // first hand-off: are the partners on one XCD?
-            unsigned mine = 0, theirs = 0;
+            unsigned mine = 0;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(mine));
             mine = (mine & 0xf) + 1u;
             const unsigned lim0 = guard_spin_limit(gd.fault, 1u << 22);
-            for (unsigned spins = 0; spins < lim0; ++spins) {
-                theirs = __hip_atomic_load(pflag + 16 + (1 - half), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (theirs) break;
-                __builtin_amdgcn_s_sleep(1);
+            bool same = true;
+            for (int pp = 0; pp < NPART; ++pp) {
+                if (pp == half) continue;
+                unsigned theirs = 0;
+                for (unsigned spins = 0; spins < lim0; ++spins) {
+                    theirs = __hip_atomic_load(pflag + 16 + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (theirs) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!theirs) {                             // a partner is not there at all: poison now, never wait again
+                    if (!s_poison) note_spin_timeout(gd.err);
+                    s_poison = 1;
+                }
+                if (theirs != mine) atomicAdd(&g_f2s_cross_xcd, 1u);   // (measurement: pairs that straddle XCDs)
+                same &= theirs == mine;
             }
-            if (!theirs) {                                 // the partner is not there at all: poison now, never wait again
-                note_spin_timeout(gd.err);
-                s_poison = 1;
-            }
-            if (theirs != mine) atomicAdd(&g_f2s_cross_xcd, 1u);   // (measurement: pairs that straddle XCDs)
-            s_same_xcd = theirs == mine ? 1 : 0;
+            s_same_xcd = same ? 1 : 0;
         }
         __syncthreads();
         if (blockIdx.x == 0 && tid == 0 && handoff < 8) g_f2s_trace[handoff * 4 + 0] = __builtin_amdgcn_s_memtime();
         const bool same = s_same_xcd == 1;
         const int slot = handoff & 1;
-        float* mine_img = px + (size_t)(slot * 2 + half) * IMG;
-        const int their_off_b = px_off_b + (slot * 2 + (1 - half)) * IMG * 4;
+        float* mine_img = px + (size_t)(slot * NPART + half) * IMG;
         // image: [wave][r * 2 + n][lane] float4
 #pragma unroll
         for (int r = 0; r < RBK; ++r)
@@ -558,27 +569,44 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
             __hip_atomic_store(pflag + half, (unsigned)(handoff + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!s_poison) {
                 const unsigned lim = guard_spin_limit(gd.fault, 1u << 22);
-                unsigned spins = 0;
-                for (; spins < lim; ++spins) {
-                    if (__hip_atomic_load(pflag + (1 - half), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(handoff + 1)) break;
-                    if (!same) __builtin_amdgcn_s_sleep(1);
-                }
-                if (spins == lim) {
-                    note_spin_timeout(gd.err);
-                    s_poison = 1;
+                for (int pp = 0; pp < NPART && !s_poison; ++pp) {
+                    if (pp == half) continue;
+                    unsigned spins = 0;
+                    for (; spins < lim; ++spins) {
+                        if (__hip_atomic_load(pflag + pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(handoff + 1)) break;
+                        if (!same) __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (spins == lim) {
+                        note_spin_timeout(gd.err);
+                        s_poison = 1;
+                    }
                 }
             }
         }
         __syncthreads();
         const bool poisoned = s_poison != 0;
         if (blockIdx.x == 0 && tid == 0 && handoff < 8) g_f2s_trace[handoff * 4 + 2] = __builtin_amdgcn_s_memtime();
-        f32x4 other[RBK][2];
+        // the partners' images (sc1: not from L1), summed in part order p0 + p1 (+ p2 + p3) — the same order in every partner
+        f32x4 sum[RBK][2];
 #pragma unroll
         for (int r = 0; r < RBK; ++r)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
-                other[r][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                  xrs, lane * 16, their_off_b + (wave * (RBK * 2) + r * 2 + n) * 1024, 16));   // sc1: not from L1
+            for (int n = 0; n < 2; ++n) sum[r][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pp = 0; pp < NPART; ++pp) {
+            const int off_b = px_off_b + (slot * NPART + pp) * IMG * 4;
+#pragma unroll
+            for (int r = 0; r < RBK; ++r)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    f32x4 v = acc[r][n];
+                    if (pp != half) {
+                        v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, lane * 16, off_b + (wave * (RBK * 2) + r * 2 + n) * 1024, 16));
+                        if (poisoned) v = (f32x4){__uint_as_float(kPoisonBits), __uint_as_float(kPoisonBits), __uint_as_float(kPoisonBits), __uint_as_float(kPoisonBits)};
+                    }
+                    sum[r][n] = pp == 0 ? v : sum[r][n] + v;
+                }
+        }
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int col = (wave * 2 + n) * 16 + l15;
@@ -586,12 +614,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
 #pragma unroll
             for (int r = 0; r < RBK; ++r)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float oth = poisoned ? __uint_as_float(kPoisonBits) : other[r][n][e];
-                    const float p0 = half == 0 ? acc[r][n][e] : oth;
-                    const float p1 = half == 0 ? oth : acc[r][n][e];
-                    X[(r * 16 + lg * 4 + e) * LDX + col] += (p0 + p1) + bv;
-                }
+                for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] += sum[r][n][e] + bv;
         }
         if (blockIdx.x == 0 && tid == 0 && handoff < 8) g_f2s_trace[handoff * 4 + 3] = __builtin_amdgcn_s_memtime();
         ++handoff;
@@ -641,7 +664,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     __syncthreads();
 
     WRing2<1> g_q;   // Q|K projection ring of the next quad: primed one phase ahead (here for layer 0, quad 2 * half)
-    ring2_prefetch<1>(g_q, rsrc, voff, (int)(LAYER0 * 4) + (int)(QKV_W * 4) + ((wave >> 2) * 16 + half * 8 + (wave & 3)) * 16 * 1024, 0);
+    ring2_prefetch<1>(g_q, rsrc, voff, (int)(LAYER0 * 4) + (int)(QKV_W * 4) + ((wave >> 2) * 16 + half * (16 / NPART) + (wave & 3)) * 16 * 1024, 0);
 #pragma unroll 1
     for (int layer = 0; layer < L; ++layer) {
         const float* LW = wts + LAYER0 + (size_t)layer * LAYER_FLOATS;
@@ -650,9 +673,10 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         zero_acc2<RBK, 2>(acc_o);
         WRing2<2> g_o, g_f2r;
         WRing2<1> g_v, g_f1;
+        constexpr int NQ = 4 / NPART;                  // quads of four heads per part
 #pragma unroll 1
-        for (int qq = 0; qq < 2; ++qq) {
-            const int q = half * 2 + qq;              // this half's quads
+        for (int qq = 0; qq < NQ; ++qq) {
+            const int q = half * NQ + qq;             // this part's quads
             const int hl = wave & 3;
             const int head = q * 4 + hl;
             {
@@ -713,11 +737,11 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
                     attention_head_mfma<LDQ, LDV>(Qp + w * 48 * LDQ, Kp + w * 48 * LDQ, Vt + w * 48, hl * 16, lane, T);
             }
             __syncthreads();
-            if (qq == 0)
+            if (qq + 1 < NQ)
                 ring2_prefetch<1>(g_q, rsrc, voff,
                                   lbase + (int)(QKV_W * 4) + ((wave >> 2) * 16 + (q + 1) * 4 + (wave & 3)) * 16 * 1024, 0);
             else
-                ring2_prefetch<1>(g_f1, rsrc, voff, lbase + (int)(W1_W * 4) + (half * 32 + wave) * 16 * 1024, 0);
+                ring2_prefetch<1>(g_f1, rsrc, voff, lbase + (int)(W1_W * 4) + (half * (64 / NPART) + wave) * 16 * 1024, 0);
             {
                 const int osoff = lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + q * 4) * 1024;
                 int ao[RBK];
@@ -735,9 +759,10 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         float* Hc = C;
         f32x4 acc_f[RBK][2];
         zero_acc2<RBK, 2>(acc_f);
+        constexpr int NF = 8 / NPART;                  // hidden chunks of 128 per part
 #pragma unroll 1
-        for (int ff = 0; ff < 4; ++ff) {
-            const int f = half * 4 + ff;
+        for (int ff = 0; ff < NF; ++ff) {
+            const int f = half * NF + ff;
             {
                 f32x4 acc[RBK][1];
                 zero_acc2<RBK, 1>(acc);
@@ -755,7 +780,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
             }
             __syncthreads();
             {
-                if (ff < 3) ring2_prefetch<1>(g_f1, rsrc, voff, lbase + (int)(W1_W * 4) + ((f + 1) * 8 + wave) * 16 * 1024, 0);
+                if (ff + 1 < NF) ring2_prefetch<1>(g_f1, rsrc, voff, lbase + (int)(W1_W * 4) + ((f + 1) * 8 + wave) * 16 * 1024, 0);
                 const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 8) * 1024;
                 int ah[RBK];
                 rows_off(ah, X_FLOATS, LDH);
@@ -765,39 +790,41 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         }
         if (layer + 1 < L)                              // next layer's first Q|K ring flies during the hand-off and LayerNorm2
             ring2_prefetch<1>(g_q, rsrc, voff, lbase + (int)(LAYER_FLOATS * 4) + (int)(QKV_W * 4) +
-                                                   ((wave >> 2) * 16 + half * 8 + (wave & 3)) * 16 * 1024, 0);
+                                                   ((wave >> 2) * 16 + half * (16 / NPART) + (wave & 3)) * 16 * 1024, 0);
         exchange_add(acc_f, LW + W2_B);               // X += linear2 (both halves' hidden units) + bias
         __syncthreads();
         layernorm_rows16<RBK * 16, f2::LDX>(X, LW + G2, LW + BE2, wave, lane);
         __syncthreads();
     }
-    // ---- RNN input projection, columns 256 * half ..: IH = X W_ih^T + (b_ih + b_hh) -> HBM ------------------------------------
+    // ---- RNN input projection, columns (512 / NPART) * part ..: IH = X W_ih^T + (b_ih + b_hh) -> HBM -----------------------------
     {
-        f32x4 acc[RBK][2];
-        zero_acc2<RBK, 2>(acc);
-        const int isoff = ih_off_b + (half * 16 + wave * 2) * 16 * 1024;
-        WRing2<2> g_ih;
-        ring2_prefetch<2>(g_ih, rsrc, voff, isoff, 16 * 1024);
+        constexpr int NBI = 4 / NPART;                 // 16-column blocks per wave: 2 (halves) or 1 (quarters)
+        f32x4 acc[RBK][NBI];
+        zero_acc2<RBK, NBI>(acc);
+        const int nb0 = half * (32 / NPART) + wave * NBI;
+        const int isoff = ih_off_b + nb0 * 16 * 1024;
+        WRing2<NBI> g_ih;
+        ring2_prefetch<NBI>(g_ih, rsrc, voff, isoff, 16 * 1024);
         int ax[RBK];
         rows_off(ax, 0, LDX);
         // (transposed tiles, 16-byte buffer stores bounded to the pair's real rows, biases first: as in fused_encoder2_kernel)
-        gemm_phase2<RBK, 2, 16, true>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
+        gemm_phase2<RBK, NBI, 16, true>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
         const int nrows = nwin * T;
         const __amdgpu_buffer_rsrc_t io_rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ih_out + (size_t)win0 * T * R), 0,
                                                                                 __builtin_amdgcn_readfirstlane(nrows * R * 4), 0x00020000);
-        f32x4 bv4[2];
+        f32x4 bv4[NBI];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) bv4[n] = *reinterpret_cast<const f32x4*>(wts + ih_off_b / 4 + R * D + (half * 16 + wave * 2 + n) * 16 + lg * 4);
+        for (int n = 0; n < NBI; ++n) bv4[n] = *reinterpret_cast<const f32x4*>(wts + ih_off_b / 4 + R * D + (nb0 + n) * 16 + lg * 4);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NBI; ++n)
 #pragma unroll
             for (int r = 0; r < RBK; ++r)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_f2, acc[r][n] + bv4[n]), io_rs,
-                                                       ((r * 16 + l15) * R + (half * 16 + wave * 2 + n) * 16 + lg * 4) * 4, 0, 0);
+                                                       ((r * 16 + l15) * R + (nb0 + n) * 16 + lg * 4) * 4, 0, 0);
     }
-    if (hall_sentinel) {   // each half arms half of the pair's HALL rows
+    if (hall_sentinel) {   // each part arms its share of the pair's HALL rows
         uint4* hp = reinterpret_cast<uint4*>(hall_sentinel + (size_t)win0 * T * R);
-        const int n4 = nwin * T * (R / 4), h0 = half * (n4 / 2), h1 = half ? n4 : n4 / 2;
+        const int n4 = nwin * T * (R / 4), h0 = half * (n4 / NPART), h1 = half == NPART - 1 ? n4 : (half + 1) * (n4 / NPART);
         for (int i = h0 + tid; i < h1; i += THREADS) hp[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     }
 }
@@ -834,39 +861,42 @@ hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const floa
 
 bool fused2s_fits(int B, int num_cus) { return B >= 1 && 2 * ((B + 1) / 2) <= num_cus; }
 bool fused1s_fits(int B, int num_cus) { return B >= 1 && 2 * B <= num_cus && B <= 128; }
+// one window on FOUR workgroups (the fused1s plan takes this form when it fits; TIP_OPT_F1S_PARTS = 2 keeps two)
+bool fused1s_quad_fits(int B, int num_cus) { return B >= 1 && 4 * B <= num_cus && B <= 64; }
 
 // nwin = 2: a window pair per two workgroups (TIP_PLAN_FUSED2S); nwin = 1: ONE window per two workgroups (TIP_PLAN_FUSED1S)
-template <int NWIN>
+template <int NWIN, int NPART = 2>
 static hipError_t launch_fused_encoder_split(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                              const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
                                              int B, int num_cus, const Guard& gd, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (!(NWIN == 2 ? fused2s_fits(B, num_cus) : fused1s_fits(B, num_cus))) return hipErrorInvalidValue;   // every workgroup must be resident: partners wait for each other
+    if (!(NWIN == 2 ? fused2s_fits(B, num_cus) : NPART == 4 ? fused1s_quad_fits(B, num_cus) : fused1s_fits(B, num_cus))) return hipErrorInvalidValue;   // every workgroup must be resident: partners wait for each other
     static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder2s_kernel<NWIN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder2s_kernel<NWIN, NPART>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, f2::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     constexpr int RBK = NWIN == 2 ? 5 : 3;
-    constexpr size_t PAIR_IMG = (size_t)4 * RBK * 16 * f2::D;
+    constexpr size_t PAIR_IMG = (size_t)2 * NPART * RBK * 16 * f2::D;
     const int npairs = (B + NWIN - 1) / NWIN;
     const size_t xbytes = (size_t)npairs * (PAIR_IMG + f2::PAIR_FLAG_WORDS) * sizeof(float);
     if (xbytes > 0x7fffffffull || xbytes > fused2s_xchg_floats(B) * sizeof(float)) return hipErrorInvalidValue;
     // hand-off counters and XCC words (behind all images) start from zero every forward
     hipError_t e = hipMemsetAsync(xchg + (size_t)npairs * PAIR_IMG, 0, (size_t)npairs * f2::PAIR_FLAG_WORDS * 4, s);
     if (e != hipSuccess) return e;
-    const int grid = (2 * npairs + 15) / 16 * 16;                      // whole (xcd, j) blocks of the id -> (pair, half) map
+    constexpr int BLK = 8 * NPART;
+    const int grid = (NPART * npairs + BLK - 1) / BLK * BLK;           // whole (xcd, j) blocks of the id -> (pair, part) map
     {
         // the runtime's own answer to "how many of these workgroups fit on a CU" (what a cooperative launch would check): the
         // 2 * npairs working ones must all be resident (surplus ids leave at once)
         static PerDeviceInt occ_dev; int& occ = occ_dev.cur();
-        hipError_t ce = check_coresident(fused_encoder2s_kernel<NWIN>, f2::THREADS, (size_t)f2::LDS_BYTES, 2 * npairs, num_cus, &occ);
+        hipError_t ce = check_coresident(fused_encoder2s_kernel<NWIN, NPART>, f2::THREADS, (size_t)f2::LDS_BYTES, NPART * npairs, num_cus, &occ);
         if (ce != hipSuccess) return ce;
     }
     const size_t ih_off = f2::LAYER0 + (size_t)d.L * f2::LAYER_FLOATS;
-    hipLaunchKernelGGL(fused_encoder2s_kernel<NWIN>, dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+    hipLaunchKernelGGL((fused_encoder2s_kernel<NWIN, NPART>), dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
                        keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), xchg, (int)xbytes, B, d.n_imu_total, d.S, d.L,
                        (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4), gd);
     return hipGetLastError();
@@ -879,7 +909,10 @@ hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const flo
 }
 hipError_t launch_fused_encoder1s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                   const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
-                                  int B, int num_cus, const Guard& gd, hipStream_t s) {
+                                  int B, int num_cus, int parts, const Guard& gd, hipStream_t s) {
+    if (parts == 4 && !fused1s_quad_fits(B, num_cus)) return hipErrorInvalidValue;
+    if (parts != 2 && fused1s_quad_fits(B, num_cus))
+        return launch_fused_encoder_split<1, 4>(d, fused_w, x_imu, x_s, keep_mask, keep_scale, ih_out, hall_sentinel, xchg, B, num_cus, gd, s);
     return launch_fused_encoder_split<1>(d, fused_w, x_imu, x_s, keep_mask, keep_scale, ih_out, hall_sentinel, xchg, B, num_cus, gd, s);
 }
 

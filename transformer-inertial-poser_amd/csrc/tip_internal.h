@@ -278,6 +278,7 @@ struct tip_handle {
     int fuse_head = 0;              // TIP_OPT_FUSE_HEAD
     int pack_split16 = 0;           // TIP_OPT_PACK_SPLIT16: which exploratory split-fp16 sections the packed image carries
     int auto_demote = 1;            // TIP_OPT_AUTO_DEMOTE
+    int f1s_parts = 0;              // TIP_OPT_F1S_PARTS: 0 = auto, 2, 4
     int sync_dirty = 0;             // a hand-off failed since the sync words of the packed image were last known clean: re-zero them before the next persistent launch
     int demoted = 0;                // TIP_OPT_DEMOTED: set by tip_demote after a lost hand-off: AUTO then avoids every cooperating kernel
     tip::Guard guard() const { return tip::Guard{err_dev, fault_inject}; }
@@ -473,8 +474,11 @@ hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const floa
                                  int num_cus, hipStream_t s);
 // window-split form: ONE window on two co-resident workgroups (columns split, 48 rows each), for 2 B <= #CUs, B <= 128
 bool fused1s_fits(int B, int num_cus);
+// ... or on FOUR (round 4: quads of heads, quarters of the hidden units and of the RNN input projection), for 4 B <= #CUs, B <= 64
+bool fused1s_quad_fits(int B, int num_cus);
+// parts: 2, 4, or 0 = four when they fit
 hipError_t launch_fused_encoder1s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                   const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
-                                  int B, int num_cus, const Guard& gd, hipStream_t s);
+                                  int B, int num_cus, int parts, const Guard& gd, hipStream_t s);
 
 }  // namespace tip

@@ -21,7 +21,7 @@ TIP_PLAN_FUSED16 = 7   # exploratory: fp32 operands emulated as split fp16 on th
 TIP_SAVED_QKV, TIP_SAVED_ATT, TIP_SAVED_X1, TIP_SAVED_HID, TIP_SAVED_XOUT, TIP_SAVED_HALL = range(6)
 TIP_STREAM_FRAME_AUTO = -1   # tip_stream_ingest / tip_stream_consume: continue from the counter in the state buffer (HIP graphs)
 TIP_OPT_PLAN, TIP_OPT_PROFILE, TIP_OPT_RNN_CLUSTER, TIP_OPT_FAULT_INJECT, TIP_OPT_FUSE_HEAD = 1, 2, 3, 4, 5
-TIP_OPT_PACK_SPLIT16, TIP_OPT_AUTO_DEMOTE, TIP_OPT_DEMOTED = 6, 7, 8
+TIP_OPT_PACK_SPLIT16, TIP_OPT_AUTO_DEMOTE, TIP_OPT_DEMOTED, TIP_OPT_F1S_PARTS = 6, 7, 8, 9
 TIP_PACK_SPLIT16_FUSED, TIP_PACK_SPLIT16_GENERAL = 1, 2
 TIP_ABI_VERSION = 2
 TIP_RNN_CLUSTER_ROWS4 = 0x44   # TIP_OPT_RNN_CLUSTER value: 4-window tiles on 4-workgroup clusters (AUTO's choice for rnn_hidden 512)

@@ -319,7 +319,9 @@ class TF_RNN_Past_State(nn.Module):
         if want and not (have & want):
             h.set_option(_lib.TIP_OPT_PACK_SPLIT16, have | want)    # new image layout: detach, re-pack on the next forward
             self._packed_dev, self._packed_key = None, None
-        h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fused2s": 5, "fusedh": 6, "fused16": 7, "general16": 8, "latency1": 9, "fused1s": 10}[plan])
+        # "fused1s": one window on four workgroups while 4 B <= #CUs, on two otherwise; "fused1s2" / "fused1s4" pin the form
+        h.set_option(_lib.TIP_OPT_F1S_PARTS, {"fused1s2": 2, "fused1s4": 4}.get(plan, 0))
+        h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fused2s": 5, "fusedh": 6, "fused16": 7, "general16": 8, "latency1": 9, "fused1s": 10, "fused1s2": 10, "fused1s4": 10}[plan])
         h.set_option(_lib.TIP_OPT_RNN_CLUSTER, int(rnn_cluster))
         h.set_option(_lib.TIP_OPT_PROFILE, int(profile))
 
