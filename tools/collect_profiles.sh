@@ -98,5 +98,6 @@ timeout 300 python tools/f1s_bench.py 2> /dev/null | grep "^B=\|fused1s vs" > "$
 timeout 300 python tools/f1s_parts.py 2> /dev/null | grep "^B=" > "$OUT/f1s_parts.txt"
 { echo "8-wave members"; TIP_RNN_W4=0 timeout 200 python tools/rnn_ab.py 2> /dev/null | grep "^B="; echo "4-wave members (TIP_RNN_W4=1)"; TIP_RNN_W4=1 timeout 200 python tools/rnn_ab.py 2> /dev/null | grep "^B="; } > "$OUT/rnn_w4.txt"
 timeout 300 python tools/plan_bench.py 257 272 300 356 1000 2> /dev/null | grep "^B=" > "$OUT/plan_bench_split.txt"
+timeout 300 python tools/f64_bench.py 2> /dev/null | grep "^{" > "$OUT/f64_bench_n1.json"
 for p in mfma4x4_probe hop_probe permlane_probe launch_probe ffn_split16_probe mfma_f64_probe imul_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
 ls -la "$OUT"

@@ -17,7 +17,8 @@ m.load_state_dict({k: torch.tensor(v) for k, v in synth.make_weights(cfg, seed=0
 m = m.cuda().eval()
 cl = int(sys.argv[sys.argv.index("--cluster") + 1], 0) if "--cluster" in sys.argv else 0
 m.set_plan("fused", rnn_cluster=cl)
-x_imu, x_s = synth.make_inputs(cfg, 256, 40)
+NB = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 256
+x_imu, x_s = synth.make_inputs(cfg, NB, 40)
 xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
 with torch.no_grad():
     for _ in range(5):

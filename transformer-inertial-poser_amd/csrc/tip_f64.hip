@@ -5,8 +5,11 @@
 // the parameters are read RAW (fp64 device tensors in state-dict order, as tip_train_forward reads its fp32 ones — nothing is
 // packed), the big products run on the fp64 matrix cores (v_mfma_f64_16x16x4_f64, 64x64 tiles staged through LDS), softmax /
 // LayerNorm / tanh use the double-precision device math library.  `--double` is a debugging switch of the training script, so
-// this path is built for exactness and any configuration, not for the roofline: layer-by-layer kernels, one workgroup per window
-// for the recurrence (W_hh^T streamed from L2 every step).  It is also the on-device high-precision check of the fp32 plans at sizes the CPU
+// this path is built for exactness and any configuration, layer by layer.  Round 4 took the obvious costs out (the recurrence as
+// one fp64-MFMA launch per time step over all windows instead of one workgroup per window, attention per (window, head) in LDS,
+// parallel column sums, GEMM operand loads under the MFMAs): forward 5.55 -> 2.69 ms, forward + backward 17.4 -> 8.9 ms at B = 256,
+// T = 40 — 1.7x / 3.5x faster than the same module on stock PyTorch-ROCm fp64 ops (tools/f64_bench.py); the GEMMs sit at ~58 % of
+// the fp64 matrix peak and are what is left.  It is also the on-device high-precision check of the fp32 plans at sizes the CPU
 // oracle does not finish in seconds (tests/test_f64_gpu.py).
 #include <hip/hip_runtime.h>
 #include <string>
@@ -59,14 +62,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const double* __restrict__ A,
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
     const int lr = tid >> 2, lk = (tid & 3) * 4;   // this thread stages 4 consecutive k of row lr of both operands
-    for (int k0 = 0; k0 < K; k0 += KC) {
-        double av[4], wv[4];
+    double av[4], wv[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int k = k0 + lk + q;
             av[q] = (row0 + lr < M && k < K) ? A[(row0 + lr) * lda + k] : 0.0;
             wv[q] = (col0 + lr < N && k < K) ? W[(long long)(col0 + lr) * K + k] : 0.0;
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += KC) {
         __syncthreads();   // the previous chunk's fragments have been read
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -74,6 +80,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const double* __restrict__ A,
             Ws[lr * LDS_LD + lk + q] = wv[q];
         }
         __syncthreads();
+        if (k0 + KC < K) fetch(k0 + KC);   // the next chunk's operands travel during this chunk's MFMAs (round 4)
 #pragma unroll
         for (int s = 0; s < KC / 4; ++s) {
             double a[2], b[2];
@@ -178,25 +185,181 @@ __global__ void transpose_kernel(const double* __restrict__ W, double* __restric
 }
 
 // :98-99 nn.RNN tanh, h0 = 0: h_t = tanh((W_ih x_t + b_ih) + (W_hh h_{t-1} + b_hh)); IH = the first bracket for every row.
-// One workgroup per window; thread c owns output channels c, c + blockDim.x, ...; W_hh^T rows are read coalesced.
-__global__ void rnn_kernel(const double* __restrict__ IH, const double* __restrict__ WhhT, const double* __restrict__ bhh,
-                           double* __restrict__ HALL, int T, int R) {
-    extern __shared__ double hbuf[];   // [2][R]
-    const long long b = blockIdx.x;
-    for (int c = threadIdx.x; c < R; c += blockDim.x) hbuf[c] = 0.0;
-    __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        const double* h = hbuf + (t & 1) * R;
-        double* hn = hbuf + ((t + 1) & 1) * R;
-        for (int c = threadIdx.x; c < R; c += blockDim.x) {
-            double a = bhh[c];
-            for (int k = 0; k < R; ++k) a += h[k] * WhhT[(long long)k * R + c];
-            const double v = tanh(IH[(b * T + t) * R + c] + a);
-            hn[c] = v;
-            HALL[(b * T + t) * R + c] = v;
-        }
-        __syncthreads();
+struct DropD {
+    unsigned key, thresh;
+    double scale;
+};
+static DropD make_drop_d(float p, unsigned long long seed, unsigned site) {
+    DropD d;
+    d.key = tip_drop_key(seed, site);
+    if (p <= 0.f) { d.thresh = 0; d.scale = 1.0; return d; }
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    d.thresh = (unsigned)t;
+    if (d.thresh == 0) d.thresh = 1;
+    d.scale = (double)(1.0f / (1.0f - p));
+    return d;
+}
+__device__ __forceinline__ double drop_factor(const DropD& d, unsigned long long idx) {
+    if (!d.thresh) return 1.0;
+    return tip_drop_hash_k(d.key, (unsigned)idx) >= d.thresh ? d.scale : 0.0;
+}
+
+// Round 4: forward attention with one workgroup per (window, head): q | k | v of the head staged in LDS (odd row strides: a thread per
+// query row walks its row without bank conflicts, every thread of an iteration reads the same key row: broadcast), thread i the
+// softmax of query i over keys 0 .. i, then thread (row, channel) the P V sum.  Same expressions, same order per element as the
+// wave-per-query kernels it replaces where it fits (the row's denominator is summed in key order instead of by a wave butterfly);
+// 330 us -> ~25 us per layer at B = 256, T = 40.  DROP: dropout on the probabilities (site 4 l), the training forward.
+template <bool DROP>
+__global__ __launch_bounds__(256) void attention_wg_kernel(const double* __restrict__ qkv, double* __restrict__ att, int T, int D, int H, int dh,
+                                                           double scale, DropD dr) {
+    extern __shared__ double sm[];
+    const int ldq = dh | 1, ldp = T | 1;
+    double* qs = sm;
+    double* ks = qs + T * ldq;
+    double* vs = ks + T * ldq;
+    double* P = vs + T * ldq;
+    double* rmx = P + T * ldp;     // [T] row maximum, then 1 / row sum
+    const int hd = blockIdx.x % H;
+    const long long b = blockIdx.x / H;
+    const double* base = qkv + b * T * 3 * D;
+    for (int i = threadIdx.x; i < T * dh; i += blockDim.x) {
+        const int r = i / dh, e = i - r * dh;
+        qs[r * ldq + e] = base[(long long)r * 3 * D + hd * dh + e] * scale;
+        ks[r * ldq + e] = base[(long long)r * 3 * D + D + hd * dh + e];
+        vs[r * ldq + e] = base[(long long)r * 3 * D + 2 * D + hd * dh + e];
     }
+    __syncthreads();
+    // scores of the lower triangle, one element per thread and pass (the expensive parts — dot product, exp, division, dropout hash —
+    // are spread over the whole workgroup; only the order-sensitive row maximum / row sum are walked by one thread per row)
+    for (int idx = threadIdx.x; idx < T * T; idx += blockDim.x) {
+        const int i = idx / T, j = idx - i * T;
+        if (j > i) continue;
+        double sc = 0.0;
+        for (int e = 0; e < dh; ++e) sc += qs[i * ldq + e] * ks[j * ldq + e];
+        P[i * ldp + j] = sc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+        double mx = -INFINITY;
+        for (int j = 0; j <= i; ++j) { const double sc = P[i * ldp + j]; mx = sc > mx ? sc : mx; }
+        rmx[i] = mx;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < T * T; idx += blockDim.x) {
+        const int i = idx / T, j = idx - i * T;
+        if (j > i) continue;
+        P[i * ldp + j] = exp(P[i * ldp + j] - rmx[i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+        double den = 0.0;
+        for (int j = 0; j <= i; ++j) den += P[i * ldp + j];
+        rmx[i] = den;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < T * T; idx += blockDim.x) {
+        const int i = idx / T, j = idx - i * T;
+        if (j > i) continue;
+        double pv = P[i * ldp + j] / rmx[i];
+        if (DROP) pv *= drop_factor(dr, (unsigned long long)((b * H + hd) * T + i) * T + j);
+        P[i * ldp + j] = pv;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T * dh; i += blockDim.x) {
+        const int r = i / dh, e = i - r * dh;
+        double o = 0.0;
+        for (int j = 0; j <= r; ++j) o += P[r * ldp + j] * vs[j * ldq + e];
+        att[(b * T + r) * D + hd * dh + e] = o;
+    }
+}
+static size_t attention_wg_smem(int T, int dh) { return (size_t)(3 * T * (dh | 1) + T * (T | 1) + T) * sizeof(double); }
+static bool attention_wg_ok(int T, int dh) { return T <= 128 && attention_wg_smem(T, dh) <= 64 * 1024; }
+
+// Round 4: the recurrence as ONE LAUNCH PER TIME STEP over all windows — H_t = tanh(IH_t + (H_{t-1} W_hh^T + b_hh)) is a
+// [B x R] x [R x R] product, 16-window x 32-channel tiles on the fp64 matrix cores, operands straight from L2 (32-byte row segments
+// per lane, a whole k-quarter's loads in flight at once), the four k-quarters of a tile on four waves and summed through LDS in a fixed order.  (Until round 4: one
+// workgroup per window, W_hh^T — 2 MB at R = 512 — streamed through every CU at every step, R dependent FMAs per thread: 2.28 ms at
+// B = 256, T = 40 against 0.58 ms for 40 of these launches.)  BWD: delta_t = (dH_t + delta_{t+1} W_hh) (1 - h_t^2), Wm = W_hh^T, and the
+// h_{t-1} rows are copied next to it (dW_hh's operand).  R % 64 == 0: tip_create admits nothing else.  `add` / `side` may alias (the backward writes h_{t-1} where it just read dH_t): no __restrict__ there.
+template <bool BWD>
+__global__ __launch_bounds__(512) void rnn_step_kernel(const double* prev, const double* __restrict__ Wm, const double* __restrict__ bias,
+                                                       const double* add, const double* __restrict__ hcur, const double* __restrict__ hprev_src,
+                                                       double* out, double* side, long long ld, int B, int R, int first) {
+    __shared__ double red[3 * 2 * 64 * 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int ct = wave & 1, kq = wave >> 1;                  // channel tile, k-quarter
+    const int w0 = blockIdx.y * 16, c0 = blockIdx.x * 32 + ct * 16;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    if (!first) {
+        const int nkb = R / 64;                              // 16-wide k-blocks of this wave's quarter
+        const int wrow = w0 + l15 < B ? w0 + l15 : B - 1;    // (padded rows of a ragged last tile re-read the last window: never stored)
+        const double* pa = prev + (long long)wrow * ld + kq * (R / 4) + lg * 4;
+        const double* pb = Wm + (long long)(c0 + l15) * R + kq * (R / 4) + lg * 4;
+        constexpr int G = 8;                                 // k-blocks whose operands are in flight together (R = 512: the whole quarter)
+        for (int kb0 = 0; kb0 < nkb; kb0 += G) {
+            d4 a[G], b[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int kb = kb0 + j < nkb ? kb0 + j : nkb - 1;
+                a[j] = *reinterpret_cast<const d4*>(pa + kb * 16);
+                b[j] = *reinterpret_cast<const d4*>(pb + kb * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                if (kb0 + j < nkb) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j][q], b[j][q], acc, 0, 0, 0);
+                }
+        }
+    }
+    if (kq > 0) *reinterpret_cast<d4*>(red + (((kq - 1) * 2 + ct) * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (kq > 0) return;
+    {   // (q0 + q1) + (q2 + q3)
+        const d4 p1 = *reinterpret_cast<const d4*>(red + ((0 * 2 + ct) * 64 + lane) * 4);
+        const d4 p2 = *reinterpret_cast<const d4*>(red + ((1 * 2 + ct) * 64 + lane) * 4);
+        const d4 p3 = *reinterpret_cast<const d4*>(red + ((2 * 2 + ct) * 64 + lane) * 4);
+        acc = (acc + p1) + (p2 + p3);
+    }
+    const int c = c0 + l15;
+    const double bv = BWD ? 0.0 : bias[c];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int w = w0 + 4 * e + lg;                       // fp64 16x16x4 accumulator: register e = row 4 e + lg, column l15
+        if (w >= B) continue;
+        const long long i = (long long)w * ld + c;
+        if (BWD) {
+            const double h = hcur[i];
+            const double v = (add[i] + acc[e]) * (1.0 - h * h);
+            out[i] = v;
+            side[i] = hprev_src ? hprev_src[i] : 0.0;
+        } else {
+            out[i] = tanh(add[i] + (acc[e] + bv));
+        }
+    }
+}
+// forward: HALL[:, t] for t = 0 .. T-1 (IH, HALL: [B][T][R])
+static hipError_t rnn_steps_fwd(const double* IH, const double* Whh, const double* bhh, double* HALL, int B, int T, int R, hipStream_t s) {
+    const dim3 grid(R / 32, (B + 15) / 16);
+    const long long ld = (long long)T * R;
+    for (int t = 0; t < T; ++t)
+        hipLaunchKernelGGL(rnn_step_kernel<false>, grid, dim3(512), 0, s, t ? HALL + (size_t)(t - 1) * R : HALL, Whh, bhh, IH + (size_t)t * R,
+                           (const double*)nullptr, (const double*)nullptr, HALL + (size_t)t * R, (double*)nullptr, ld, B, R, t == 0 ? 1 : 0);
+    return hipGetLastError();
+}
+// backward: delta[:, t] for t = T-1 .. 0; hprev lands in dH's place (dH[:, t] is read before it is overwritten, same thread)
+static hipError_t rnn_steps_bwd(double* dH, const double* WhhT, const double* HALL, double* delta, int B, int T, int R, hipStream_t s) {
+    const dim3 grid(R / 32, (B + 15) / 16);
+    const long long ld = (long long)T * R;
+    for (int t = T - 1; t >= 0; --t)
+        hipLaunchKernelGGL(rnn_step_kernel<true>, grid, dim3(512), 0, s, t + 1 < T ? delta + (size_t)(t + 1) * R : delta, WhhT, (const double*)nullptr,
+                           dH + (size_t)t * R, HALL + (size_t)t * R, t ? HALL + (size_t)(t - 1) * R : (const double*)nullptr, delta + (size_t)t * R,
+                           dH + (size_t)t * R, ld, B, R, t == T - 1 ? 1 : 0);
+    return hipGetLastError();
 }
 
 struct Layout {
@@ -215,7 +378,8 @@ static Layout layout(const Dims& d, int B, int T) {
     L.HID = o;  o += al(M * d.F);
     L.IH = o;   o += al(d.with_rnn ? M * d.R : 0);
     L.HALL = o; o += al(d.with_rnn ? M * d.R : 0);
-    L.WT = o;   o += al(d.with_rnn ? (size_t)d.R * d.R : 0);
+    L.WT = o;   // (unused since the per-step recurrence reads W_hh as it is; kept so that the workspace size is unchanged)
+    o += al(d.with_rnn ? (size_t)d.R * d.R : 0);
     L.total = o;
     return L;
 }
@@ -286,8 +450,12 @@ int tip_forward_f64(tip_handle* h, const double* const* params, int n_params, co
     for (int l = 0; l < d.L; ++l) {
         const double* const* lp = params + 2 + 12 * l;
         TF(f64::gemm(0, W + L.Z, d.D, lp[0], lp[1], nullptr, 0, W + L.QKV, 3 * d.D, M, 3 * d.D, d.D, 0, 1, s), "f64 in_proj");
-        hipLaunchKernelGGL(f64::attention_kernel, dim3((unsigned)(M * d.H)), dim3(64), (size_t)T * sizeof(double), s, W + L.QKV,
-                           W + L.ATT, T, d.D, d.H, d.dh, scale);
+        if (f64::attention_wg_ok(T, d.dh))
+            hipLaunchKernelGGL(f64::attention_wg_kernel<false>, dim3((unsigned)(B * d.H)), dim3(256), f64::attention_wg_smem(T, d.dh), s, W + L.QKV,
+                               W + L.ATT, T, d.D, d.H, d.dh, scale, f64::DropD{0u, 0u, 1.0});
+        else
+            hipLaunchKernelGGL(f64::attention_kernel, dim3((unsigned)(M * d.H)), dim3(64), (size_t)T * sizeof(double), s, W + L.QKV,
+                               W + L.ATT, T, d.D, d.H, d.dh, scale);
         TF(hipGetLastError(), "f64 attention");
         TF(f64::gemm(2, W + L.ATT, d.D, lp[2], lp[3], W + L.Z, d.D, W + L.Z, d.D, M, d.D, d.D, 0, 1, s), "f64 out_proj");
         hipLaunchKernelGGL(f64::layernorm_kernel, dim3((unsigned)M), dim3(64), 0, s, W + L.Z, lp[8], lp[9], d.D);
@@ -302,13 +470,8 @@ int tip_forward_f64(tip_handle* h, const double* const* params, int n_params, co
     int fw = d.D;
     if (d.with_rnn) {
         TF(f64::gemm(0, W + L.Z, d.D, tw[0], tw[2], nullptr, 0, W + L.IH, d.R, M, d.R, d.D, 0, 1, s), "f64 rnn W_ih");
-        const long long n = (long long)d.R * d.R;
-        hipLaunchKernelGGL(f64::transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, tw[1], W + L.WT, d.R);
-        TF(hipGetLastError(), "f64 W_hh transpose");
-        const int threads = d.R < 1024 ? ((d.R + 63) / 64) * 64 : 1024;
-        hipLaunchKernelGGL(f64::rnn_kernel, dim3(B), dim3(threads), 2 * (size_t)d.R * sizeof(double), s, W + L.IH, W + L.WT, tw[3],
-                           W + L.HALL, T, d.R);
-        TF(hipGetLastError(), "f64 rnn");
+        if (d.R % 64) return TIP_ERR_UNSUPPORTED_CONFIG;   // (tip_create admits multiples of 64 only)
+        TF(f64::rnn_steps_fwd(W + L.IH, tw[1], tw[3], W + L.HALL, B, T, d.R, s), "f64 rnn steps");
         feat = W + L.HALL;
         fw = d.R;
         tw += 4;
@@ -334,26 +497,6 @@ int tip_forward_f64(tip_handle* h, const double* const* params, int n_params, co
 // =====================================================================================================================
 namespace tip {
 namespace f64 {
-
-struct DropD {
-    unsigned key, thresh;
-    double scale;
-};
-static DropD make_drop_d(float p, unsigned long long seed, unsigned site) {
-    DropD d;
-    d.key = tip_drop_key(seed, site);
-    if (p <= 0.f) { d.thresh = 0; d.scale = 1.0; return d; }
-    double t = (double)p * 4294967296.0;
-    if (t > 4294967295.0) t = 4294967295.0;
-    d.thresh = (unsigned)t;
-    if (d.thresh == 0) d.thresh = 1;
-    d.scale = (double)(1.0f / (1.0f - p));
-    return d;
-}
-__device__ __forceinline__ double drop_factor(const DropD& d, unsigned long long idx) {
-    if (!d.thresh) return 1.0;
-    return tip_drop_hash_k(d.key, (unsigned)idx) >= d.thresh ? d.scale : 0.0;
-}
 
 // y[i] = (res ? res[i] : 0) + x[i] * keep(i)   (dropout sites 1 / 3 with their residual; site 2 in place with res = null)
 __global__ void drop_res_kernel(const double* __restrict__ x, const double* __restrict__ res, double* __restrict__ y, long long n, DropD d) {
@@ -401,66 +544,95 @@ __global__ __launch_bounds__(64) void attention_train_kernel(const double* __res
 // attention backward: one workgroup per (window, head).  dqkv rows of this head <- d(att) of this head.
 //   P_ij = softmax_j(q_i k_j * scale), Pd = P * keep; O = Pd V;  dPd_ij = dO_i . v_j;  dV_j = sum_i Pd_ij dO_i;
 //   dP = dPd * keep;  dS_ij = P_ij (dP_ij - sum_k dP_ik P_ik);  dq_i = scale sum_j dS_ij k_j;  dk_j = scale sum_i dS_ij q_i
-__global__ __launch_bounds__(128) void attention_bwd_kernel(const double* __restrict__ qkv, const double* __restrict__ datt, double* __restrict__ dqkv,
+__global__ __launch_bounds__(256) void attention_bwd_kernel(const double* __restrict__ qkv, const double* __restrict__ datt, double* __restrict__ dqkv,
                                                             int T, int D, int H, int dh, double scale, DropD dr) {
-    extern __shared__ double sm[];   // q, k, v, do: [T][dh] each; P, dS: [T][T]
+    // q, k, v, do: [T][dh | 1] each; P, dS: [T][T | 1].  Odd row strides (round 4): thread i walks row i of q / do / P / dS, and with
+    // the even strides dh and T all threads of a wave sat on two LDS banks.
+    extern __shared__ double sm[];
+    const int ldq = dh | 1, ldp = T | 1;
     double* qs = sm;
-    double* ks = qs + T * dh;
-    double* vs = ks + T * dh;
-    double* dos = vs + T * dh;
-    double* P = dos + T * dh;
-    double* dS = P + T * T;
+    double* ks = qs + T * ldq;
+    double* vs = ks + T * ldq;
+    double* dos = vs + T * ldq;
+    double* P = dos + T * ldq;
+    double* dS = P + T * ldp;
     const int hd = blockIdx.x % H;
     const long long b = blockIdx.x / H;
     const double* base = qkv + b * T * 3 * D;
     for (int i = threadIdx.x; i < T * dh; i += blockDim.x) {
         const int r = i / dh, e = i - r * dh;
-        qs[i] = base[(long long)r * 3 * D + hd * dh + e];
-        ks[i] = base[(long long)r * 3 * D + D + hd * dh + e];
-        vs[i] = base[(long long)r * 3 * D + 2 * D + hd * dh + e];
-        dos[i] = datt[(b * T + r) * D + hd * dh + e];
+        qs[r * ldq + e] = base[(long long)r * 3 * D + hd * dh + e];
+        ks[r * ldq + e] = base[(long long)r * 3 * D + D + hd * dh + e];
+        vs[r * ldq + e] = base[(long long)r * 3 * D + 2 * D + hd * dh + e];
+        dos[r * ldq + e] = datt[(b * T + r) * D + hd * dh + e];
     }
     __syncthreads();
-    // one thread per query row: softmax, then dS of the row
+    // Element-wise passes over the lower triangle with the whole workgroup (dot products, exp, division, dropout hash), one thread per
+    // row only for the order-sensitive row maximum / row sum / sum_k dP_ik P_ik.  P is left as P * keep (dV's operand).
+    double* rmx = dS + T * ldp;    // [T] row maximum, then row sum, then the row's dot
+    for (int idx = threadIdx.x; idx < T * T; idx += blockDim.x) {
+        const int i = idx / T, j = idx - i * T;
+        if (j > i) { P[i * ldp + j] = 0.0; dS[i * ldp + j] = 0.0; continue; }
+        double sc = 0.0, dpd = 0.0;
+        for (int e = 0; e < dh; ++e) {
+            sc += (qs[i * ldq + e] * scale) * ks[j * ldq + e];
+            dpd += dos[i * ldq + e] * vs[j * ldq + e];
+        }
+        P[i * ldp + j] = sc;
+        dS[i * ldp + j] = dpd * drop_factor(dr, (unsigned long long)((b * H + hd) * T + i) * T + j);   // dP
+    }
+    __syncthreads();
     for (int i = threadIdx.x; i < T; i += blockDim.x) {
         double mx = -INFINITY;
-        for (int j = 0; j <= i; ++j) {
-            double s = 0.0;
-            for (int e = 0; e < dh; ++e) s += (qs[i * dh + e] * scale) * ks[j * dh + e];
-            P[i * T + j] = s;
-            mx = s > mx ? s : mx;
-        }
+        for (int j = 0; j <= i; ++j) { const double sc = P[i * ldp + j]; mx = sc > mx ? sc : mx; }
+        rmx[i] = mx;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < T * T; idx += blockDim.x) {
+        const int i = idx / T, j = idx - i * T;
+        if (j <= i) P[i * ldp + j] = exp(P[i * ldp + j] - rmx[i]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
         double den = 0.0;
-        for (int j = 0; j <= i; ++j) { const double e_ = exp(P[i * T + j] - mx); P[i * T + j] = e_; den += e_; }
+        for (int j = 0; j <= i; ++j) den += P[i * ldp + j];
+        rmx[i] = den;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < T * T; idx += blockDim.x) {
+        const int i = idx / T, j = idx - i * T;
+        if (j <= i) P[i * ldp + j] = P[i * ldp + j] / rmx[i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
         double dot = 0.0;
-        for (int j = 0; j <= i; ++j) {
-            const double pij = P[i * T + j] / den;
-            const double kf = drop_factor(dr, (unsigned long long)((b * H + hd) * T + i) * T + j);
-            double dpd = 0.0;
-            for (int e = 0; e < dh; ++e) dpd += dos[i * dh + e] * vs[j * dh + e];
-            const double dp = dpd * kf;
-            P[i * T + j] = pij;
-            dS[i * T + j] = dp;           // dP for now
-            dot += dp * pij;
-        }
-        for (int j = 0; j <= i; ++j) dS[i * T + j] = P[i * T + j] * (dS[i * T + j] - dot);
-        for (int j = i + 1; j < T; ++j) { P[i * T + j] = 0.0; dS[i * T + j] = 0.0; }
+        for (int j = 0; j <= i; ++j) dot += dS[i * ldp + j] * P[i * ldp + j];
+        rmx[i] = dot;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < T * T; idx += blockDim.x) {
+        const int i = idx / T, j = idx - i * T;
+        if (j > i) continue;
+        const double pij = P[i * ldp + j];
+        dS[i * ldp + j] = pij * (dS[i * ldp + j] - rmx[i]);
+        P[i * ldp + j] = pij * drop_factor(dr, (unsigned long long)((b * H + hd) * T + i) * T + j);
     }
     __syncthreads();
     double* out = dqkv + b * T * 3 * D;
     for (int i = threadIdx.x; i < T * dh; i += blockDim.x) {
         const int r = i / dh, e = i - r * dh;
         double dq = 0.0, dk = 0.0, dv = 0.0;
-        for (int j = 0; j <= r; ++j) dq += dS[r * T + j] * ks[j * dh + e];
+        for (int j = 0; j <= r; ++j) dq += dS[r * ldp + j] * ks[j * ldq + e];
         for (int ii = r; ii < T; ++ii) {
-            dk += dS[ii * T + r] * qs[ii * dh + e];
-            dv += P[ii * T + r] * drop_factor(dr, (unsigned long long)((b * H + hd) * T + ii) * T + r) * dos[ii * dh + e];
+            dk += dS[ii * ldp + r] * qs[ii * ldq + e];
+            dv += P[ii * ldp + r] * dos[ii * ldq + e];
         }
         out[(long long)r * 3 * D + hd * dh + e] = dq * scale;
         out[(long long)r * 3 * D + D + hd * dh + e] = dk * scale;
         out[(long long)r * 3 * D + 2 * D + hd * dh + e] = dv;
     }
 }
+static size_t attention_bwd_smem(int T, int dh) { return (size_t)(4 * T * (dh | 1) + 2 * T * (T | 1) + T) * sizeof(double); }
 
 // LayerNorm forward into a separate output (the pre-norm sum is kept for the backward)
 __global__ __launch_bounds__(64) void ln_fwd_kernel(const double* __restrict__ Z, const double* __restrict__ g, const double* __restrict__ be,
@@ -504,26 +676,37 @@ __global__ __launch_bounds__(64) void ln_bwd_kernel(const double* __restrict__ Z
     }
 }
 
-// out[c] (+= when acc) = sum over rows of x[r][c]: 256 rows per block in a fixed order, then a fixed-order pass over the blocks
+// out[c] (+= when acc) = sum over rows of x[r][c]: kColRows rows per block in a fixed order, then a fixed-order pass over the blocks
+// (32 rows, round 4: with 256 a [10240 x 256] sum was 40 workgroups of 256 dependent loads each — 65 us, 35 times per step)
+constexpr int kColRows = 32;
 __global__ __launch_bounds__(256) void colsum_part_kernel(const double* __restrict__ x, int ld, long long M, int N, double* __restrict__ part) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= N) return;
-    const long long r0 = (long long)blockIdx.y * 256, r1 = r0 + 256 < M ? r0 + 256 : M;
+    const long long r0 = (long long)blockIdx.y * kColRows, r1 = r0 + kColRows < M ? r0 + kColRows : M;
     double s = 0.0;
     for (long long r = r0; r < r1; ++r) s += x[r * ld + c];
     part[(long long)blockIdx.y * N + c] = s;
 }
+// 16 columns per block; thread (pl, c) sums parts pl, pl + 16, ... in order, then the 16 lanes of a column meet in LDS in a fixed order
 __global__ __launch_bounds__(256) void colsum_final_kernel(const double* __restrict__ part, int nparts, int N, double* __restrict__ out, double* __restrict__ out2) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+    __shared__ double red[16][17];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s = 0.0;
-    for (int p_ = 0; p_ < nparts; ++p_) s += part[(long long)p_ * N + c];
-    out[c] = s;
-    if (out2) out2[c] = s;
+    if (c < N)
+        for (int p_ = pl; p_ < nparts; p_ += 16) s += part[(long long)p_ * N + c];
+    red[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && c < N) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][cl];
+        out[c] = t;
+        if (out2) out2[c] = t;
+    }
 }
 
 // dW[N][K] partials: part[z][n][k] = sum over the rows of slice z of dY[m][n] X[m][k]  (64 x 64 tiles, fp64 matrix cores)
-constexpr int TNS = 64;   // rows of a split
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const double* __restrict__ dY, int ldy, const double* __restrict__ X, int ldx, long long M,
                                                       int N, int K, long long rows_per_split, double* __restrict__ part) {
     __shared__ double Ys[KC * (TM + 1)], Xs[KC * (TN + 1)];   // [m][n], [m][k]
@@ -538,14 +721,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const double* __restrict__
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
     const int lm = tid >> 4, lc = (tid & 15) * 4;   // this thread stages 4 consecutive columns of row lm of both operands
-    for (long long mm = m0; mm < m1; mm += KC) {
-        double yv[4], xv[4];
+    double yv[4], xv[4];
+    auto fetch = [&](long long mm) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long long m = mm + lm;
             yv[q] = (m < m1 && n0 + lc + q < N) ? dY[m * ldy + n0 + lc + q] : 0.0;
             xv[q] = (m < m1 && k0 + lc + q < K) ? X[m * ldx + k0 + lc + q] : 0.0;
         }
+    };
+    fetch(m0);
+    for (long long mm = m0; mm < m1; mm += KC) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -553,6 +739,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const double* __restrict__
             Xs[lm * (TN + 1) + lc + q] = xv[q];
         }
         __syncthreads();
+        if (mm + KC < m1) fetch(mm + KC);   // the next rows travel during this chunk's MFMAs (round 4)
 #pragma unroll
         for (int s = 0; s < KC / 4; ++s) {
             double a[2], b[2];
@@ -617,32 +804,6 @@ __global__ void add_kernel(const double* __restrict__ a, const double* __restric
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = a[i] + b[i];
 }
 
-// backward recurrence: delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2); one workgroup per window; also hprev[t] = h[t-1]
-// (dH and hprev may be the SAME buffer: a thread reads dH[b,t,c] before it writes hprev[b,t,c]; hence no __restrict__ on the two)
-__global__ void rnn_bwd_kernel(const double* dH, const double* __restrict__ Whh, const double* __restrict__ HALL,
-                               double* __restrict__ delta, double* hprev, int T, int R) {
-    extern __shared__ double dbuf[];   // [2][R]
-    const long long b = blockIdx.x;
-    for (int c = threadIdx.x; c < R; c += blockDim.x) dbuf[c] = 0.0;
-    __syncthreads();
-    for (int st = 0; st < T; ++st) {
-        const int t = T - 1 - st;
-        const double* dn = dbuf + (st & 1) * R;
-        double* dc = dbuf + ((st + 1) & 1) * R;
-        for (int c = threadIdx.x; c < R; c += blockDim.x) {
-            double a = 0.0;
-            if (st > 0)
-                for (int k = 0; k < R; ++k) a += dn[k] * Whh[(long long)k * R + c];   // (delta_{t+1} W_hh)[c]
-            const double h = HALL[(b * T + t) * R + c];
-            const double v = (dH[(b * T + t) * R + c] + a) * (1.0 - h * h);
-            dc[c] = v;
-            delta[(b * T + t) * R + c] = v;
-            hprev[(b * T + t) * R + c] = t > 0 ? HALL[(b * T + t - 1) * R + c] : 0.0;
-        }
-        __syncthreads();
-    }
-}
-
 struct TrainLay {
     // saved (doubles)
     size_t U, X0, IH, HALL, WT, total_saved;
@@ -672,7 +833,7 @@ static TrainLay train_layout(const Dims& d, int B, int T) {
     }
     L.IH = o; o += al(d.with_rnn ? M * d.R : 0);
     L.HALL = o; o += al(d.with_rnn ? M * d.R : 0);
-    L.WT = o; o += al(d.with_rnn ? (size_t)d.R * d.R : 0);   // W_hh^T for the forward recurrence
+    L.WT = o; o += al(d.with_rnn ? (size_t)d.R * d.R : 0);   // W_hh^T: the backward recurrence's operand
     L.total_saved = o;
     o = 0;
     size_t wide = 3 * (size_t)d.D;
@@ -692,7 +853,7 @@ static TrainLay train_layout(const Dims& d, int B, int T) {
     L.nsplit = (int)((M + L.rows_per_split - 1) / L.rows_per_split);
     if (L.nsplit > 64) { L.nsplit = 64; L.rows_per_split = (long long)((M + 63) / 64); L.rows_per_split = (L.rows_per_split + KC - 1) / KC * KC; L.nsplit = (int)((M + L.rows_per_split - 1) / L.rows_per_split); }
     L.part = o; o += al(wmax * L.nsplit);
-    L.colpart = o; o += al(((M + 255) / 256) * wide);
+    L.colpart = o; o += al(((M + kColRows - 1) / kColRows) * wide);
     L.dwin = o; o += al((size_t)d.D * d.In);
     L.dbin = o; o += al(d.D);
     L.total_scratch = o;
@@ -711,8 +872,8 @@ int tip_train_bytes_f64(const tip_handle* h, int B, int T, size_t* saved_bytes, 
     const Dims& d = h->d;
     if (d.L > f64::kMaxLayersF64 || T > 128) return TIP_ERR_UNSUPPORTED_CONFIG;   // attention backward keeps two T x T tiles in LDS
     const long long M = (long long)B * T;
-    if (M * (long long)(3 * d.D > d.F ? 3 * d.D : d.F) > 0x7fffffffLL || M * d.H > 0x7fffffffLL || M > 65535LL * f64::TM) return TIP_ERR_UNSUPPORTED_CONFIG;
-    if ((size_t)(4 * T * d.dh + 2 * T * T) * sizeof(double) > 160 * 1024) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (M * (long long)(3 * d.D > d.F ? 3 * d.D : d.F) > 0x7fffffffLL || M * d.H > 0x7fffffffLL || M > 65535LL * f64::kColRows) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (f64::attention_bwd_smem(T, d.dh) > 160 * 1024) return TIP_ERR_UNSUPPORTED_CONFIG;
     const f64::TrainLay L = f64::train_layout(d, B > 0 ? B : 1, T > 0 ? T : 1);
     if (saved_bytes) *saved_bytes = L.total_saved * sizeof(double) + 256;
     if (scratch_bytes) *scratch_bytes = L.total_scratch * sizeof(double) + 256;
@@ -751,8 +912,12 @@ int tip_train_forward_f64(tip_handle* h, const double* const* params, int n_para
     for (int l = 0; l < d.L; ++l) {
         const double* const* lp = params + 2 + 12 * l;
         TF(f64::gemm(0, x, d.D, lp[0], lp[1], nullptr, 0, W + L.qkv[l], 3 * d.D, M, 3 * d.D, d.D, 0, 1, s), "f64 train in_proj");
-        hipLaunchKernelGGL(f64::attention_train_kernel, dim3((unsigned)(M * d.H)), dim3(64), (size_t)T * sizeof(double), s, W + L.qkv[l],
-                           W + L.att[l], T, d.D, d.H, d.dh, scale, f64::make_drop_d(p_drop, seed, 4 * l + 0));
+        if (f64::attention_wg_ok(T, d.dh))
+            hipLaunchKernelGGL(f64::attention_wg_kernel<true>, dim3((unsigned)(B * d.H)), dim3(256), f64::attention_wg_smem(T, d.dh), s, W + L.qkv[l],
+                               W + L.att[l], T, d.D, d.H, d.dh, scale, f64::make_drop_d(p_drop, seed, 4 * l + 0));
+        else
+            hipLaunchKernelGGL(f64::attention_train_kernel, dim3((unsigned)(M * d.H)), dim3(64), (size_t)T * sizeof(double), s, W + L.qkv[l],
+                               W + L.att[l], T, d.D, d.H, d.dh, scale, f64::make_drop_d(p_drop, seed, 4 * l + 0));
         TF(hipGetLastError(), "f64 train attention");
         // z1 = x + drop1(att Wo^T + bo): the product lands in z1, then the dropout / residual pass rewrites it in place
         TF(f64::gemm(0, W + L.att[l], d.D, lp[2], lp[3], nullptr, 0, W + L.z1[l], d.D, M, d.D, d.D, 0, 1, s), "f64 train out_proj");
@@ -775,9 +940,8 @@ int tip_train_forward_f64(tip_handle* h, const double* const* params, int n_para
     if (d.with_rnn) {
         TF(f64::gemm(0, x, d.D, tw[0], tw[2], nullptr, 0, W + L.IH, d.R, M, d.R, d.D, 0, 1, s), "f64 train rnn W_ih");
         hipLaunchKernelGGL(f64::transpose_kernel, dim3(f64::grid_n((long long)d.R * d.R)), dim3(256), 0, s, tw[1], W + L.WT, d.R);
-        const int threads = d.R < 1024 ? ((d.R + 63) / 64) * 64 : 1024;
-        hipLaunchKernelGGL(f64::rnn_kernel, dim3(B), dim3(threads), 2 * (size_t)d.R * sizeof(double), s, W + L.IH, W + L.WT, tw[3], W + L.HALL, T, d.R);
-        TF(hipGetLastError(), "f64 train rnn");
+        if (d.R % 64) return TIP_ERR_UNSUPPORTED_CONFIG;
+        TF(f64::rnn_steps_fwd(W + L.IH, tw[1], tw[3], W + L.HALL, B, T, d.R, s), "f64 train rnn steps");   // (W_hh^T above is the backward's operand)
         feat = W + L.HALL;
         fw = d.R;
         tw += 4;
@@ -827,9 +991,9 @@ int tip_train_backward_f64(tip_handle* h, const double* const* params, int n_par
         return hipGetLastError();
     };
     auto col_sum = [&](const double* x, int ld, int N, double* out, double* out2 = nullptr) -> hipError_t {
-        const int nparts = (int)((M + 255) / 256);
+        const int nparts = (int)((M + f64::kColRows - 1) / f64::kColRows);
         hipLaunchKernelGGL(f64::colsum_part_kernel, dim3((N + 255) / 256, nparts), dim3(256), 0, s, x, ld, M, N, X + L.colpart);
-        hipLaunchKernelGGL(f64::colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, X + L.colpart, nparts, N, out, out2);
+        hipLaunchKernelGGL(f64::colsum_final_kernel, dim3((N + 15) / 16), dim3(256), 0, s, X + L.colpart, nparts, N, out, out2);
         return hipGetLastError();
     };
     // dX[M][K] = dY[M][N] W[N][K]: the NT GEMM on a transposed copy of the weight
@@ -853,9 +1017,7 @@ int tip_train_backward_f64(tip_handle* h, const double* const* params, int n_par
         TF(grad_x(dy, d.S, params[g_lin_w], d.S, d.R, dH, nullptr), "f64 bwd dH");
         // ---- recurrence (:98-99), time reversed; hprev lands in dH's place afterwards (dH is dead once delta exists) — not in
         //      place: the kernel reads dH[t] and writes hprev[t] at the same index in the same thread, after the read
-        const int threads = d.R < 1024 ? ((d.R + 63) / 64) * 64 : 1024;
-        hipLaunchKernelGGL(f64::rnn_bwd_kernel, dim3(B), dim3(threads), 2 * (size_t)d.R * sizeof(double), s, dH, params[rbase + 1], W + L.HALL, delta, dH, T, d.R);
-        TF(hipGetLastError(), "f64 bwd rnn");
+        TF(f64::rnn_steps_bwd(dH, W + L.WT, W + L.HALL, delta, B, T, d.R, s), "f64 bwd rnn steps");
         TF(col_sum(delta, d.R, d.R, grads + goff[rbase + 2], grads + goff[rbase + 3]), "f64 bwd db_rnn");
         TF(grad_w(delta, d.R, dH /* = hprev */, d.R, d.R, d.R, grads + goff[rbase + 1]), "f64 bwd dW_hh");
         TF(grad_w(delta, d.R, enc, d.D, d.R, d.D, grads + goff[rbase + 0]), "f64 bwd dW_ih");
@@ -865,7 +1027,7 @@ int tip_train_backward_f64(tip_handle* h, const double* const* params, int n_par
     }
     // ---- encoder layers, last to first -----------------------------------------------------------------------------------
     const double qs = 1.0 / sqrt((double)d.dh);
-    const size_t att_smem = (size_t)(4 * T * d.dh + 2 * T * T) * sizeof(double);
+    const size_t att_smem = f64::attention_bwd_smem(T, d.dh);
     if (att_smem > 64 * 1024)   // (per call: cheap, and correct for every device the process drives)
         TF(hipFuncSetAttribute(reinterpret_cast<const void*>(f64::attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)att_smem),
            "f64 attention_bwd LDS");
@@ -904,7 +1066,7 @@ int tip_train_backward_f64(tip_handle* h, const double* const* params, int n_par
         TF(grad_w(dout, d.D, W + L.att[l], d.D, d.D, d.D, grads + goff[pb + 2]), "f64 bwd dWo");
         double* datt = gx;            // gx is free until dx_in is formed
         TF(grad_x(dout, d.D, lp[2], d.D, d.D, datt, nullptr), "f64 bwd datt");
-        hipLaunchKernelGGL(f64::attention_bwd_kernel, dim3((unsigned)(B * d.H)), dim3(128), att_smem, s,
+        hipLaunchKernelGGL(f64::attention_bwd_kernel, dim3((unsigned)(B * d.H)), dim3(256), att_smem, s,
                            W + L.qkv[l], datt, big2, T, d.D, d.H, d.dh, qs, f64::make_drop_d(p_drop, seed, 4 * l + 0));
         TF(hipGetLastError(), "f64 bwd attention");
         TF(col_sum(big2, 3 * d.D, 3 * d.D, grads + goff[pb + 1]), "f64 bwd dbqkv");

@@ -692,7 +692,7 @@ constexpr unsigned kRnnSentinel = 0xFFFFFFFFu;
 
 // measurement only (TIP_RNN_TRACE=1): per-step s_memtime stamps of workgroup 0 — after the pull, after the MFMAs,
 // after the reduce+tanh+stores — read back with tip_debug_read_rnn_trace().
-__device__ unsigned long long g_rnn_trace[64 * 4];
+__device__ unsigned long long g_rnn_trace[2048];   // [0, 256): step stamps of workgroup 0; [1024, 1536): HW_ID | XCC_ID << 32 per workgroup (tools/rnn_hwid.py)
 
 // BWD = true runs the backward recurrence of the training step on the same machinery (tip_train.hip):
 //   delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2),  t = T-1 .. 0
@@ -1161,6 +1161,12 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_rows4_kernel(const float* __re
     const int aoff = (lane & 3) * LD + lg * 4;                    // this lane's A operand: row lane & 3, k = 16 kb + 4 lg ..
     const int lds_w = prow * LD + pcol;                            // where this thread's 16 bytes of a pulled tile go
     bool poisoned = false;                                         // (wave-uniform)
+    if (TRACE && tid == 0 && blockIdx.x < 512) {                   // which workgroups share a CU (tools/rnn_hwid.py: ids j and j + 32 of an XCD)
+        unsigned hwid, xccid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xccid));
+        g_rnn_trace[1024 + blockIdx.x] = (unsigned long long)hwid | ((unsigned long long)(xccid & 0xf) << 32);
+    }
 
     for (int q0 = dead ? tpg : 0; q0 < tpg; q0 += NT) {
         if (q0 > 0) {
@@ -1572,7 +1578,7 @@ hipError_t read_spin_timeouts_general(unsigned* out) {
 }  // namespace tip
 
 extern "C" int tip_debug_read_rnn_trace(unsigned long long* out, int n) {
-    if (!out || n < 0 || n > 64 * 4) return -1;
+    if (!out || n < 0 || n > 2048) return -1;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(tip::g_rnn_trace), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -5;
 }
 
