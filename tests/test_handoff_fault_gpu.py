@@ -163,3 +163,35 @@ def test_cu_masked_stream_is_exact(ncus_enabled):
     finally:
         torch.cuda.synchronize()
         hip.hipStreamDestroy(stream)
+
+
+@pytest.mark.parametrize("plan,B", [("auto", 60), ("fused1s4", 30), ("fused1s2", 64)])
+def test_cu_masked_stream_window_split(plan, B):
+    """The window-split encoder (one window on two / four workgroups) on a stream limited to 128 CUs: the partners of a window must
+    all be resident (the launchers size the check for the stream's CUs) and are not necessarily on one XCD any more (checked at run
+    time: the cross-XCD path then carries the partial sums) — bit-identical to the unmasked run either way.  AUTO at 60 windows:
+    four workgroups per window do not fit 128 CUs, two do."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    if torch.cuda.get_device_properties(0).multi_processor_count < 256:
+        pytest.skip("written for the 256-CU part")
+    stream = _masked_stream(hip, 128)
+    try:
+        m = _model()
+        x_imu, x_s = synth.make_inputs(synth.PAPER, B, 40, seed=18)
+        xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+        with torch.no_grad():
+            m.set_plan("fused1s2" if plan == "auto" else plan)
+            ref = m(xi, xs)
+            torch.cuda.synchronize()
+            m.set_plan(plan)
+            ext = torch.cuda.ExternalStream(stream.value)
+            for _ in range(3):
+                with torch.cuda.stream(ext):
+                    y = m(xi, xs)
+                ext.synchronize()
+                assert bool(torch.isfinite(y).all())
+                assert torch.equal(y, ref)
+            m.check_handoffs()
+    finally:
+        torch.cuda.synchronize()
+        hip.hipStreamDestroy(stream)

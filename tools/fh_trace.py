@@ -12,14 +12,24 @@ with contextlib.redirect_stdout(sys.stderr):
     m = tip_amd.TF_RNN_Past_State(72, 131, rnn_hid_size=512, tf_hid_size=1024, tf_in_dim=256, n_heads=16, tf_layers=4,
                                   dropout=0.0, in_dropout=0.0, past_state_dropout=0.0, with_acc_sum=True)
 m.load_state_dict({k: torch.tensor(v) for k, v in synth.make_weights(cfg, seed=0).items()})
-m = m.cuda().eval()
-m.set_plan("fusedh")
+TRAIN = "--train" in sys.argv     # the training forward (stash + the four dropout sites, p = 0.1) instead of the inference kernel
+m = m.cuda().train() if TRAIN else m.cuda().eval()
+if TRAIN:
+    m.ENCODER_DROPOUT = 0.1
+else:
+    m.set_plan("fusedh")
 x_imu, x_s = synth.make_inputs(cfg, 256, 40)
-xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
-with torch.no_grad():
-    for _ in range(300):        # long enough for the clocks to settle
-        m(xi, xs)
+xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(np.nan_to_num(x_s)).cuda()
+if TRAIN:
+    for _ in range(60):
+        y = m(xi, xs)
+        del y
     torch.cuda.synchronize()
+else:
+    with torch.no_grad():
+        for _ in range(300):        # long enough for the clocks to settle
+            m(xi, xs)
+        torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 64)()
 assert tlib.load().tip_debug_read_fh_trace(buf, 64) == 0
 t = np.array(buf[:], dtype=np.float64)

@@ -1209,12 +1209,21 @@ hipError_t launch_fused_train_h(const Dims& d, const float* fused_w, const float
     if (!fused_supported(d, T) || !fused_has_rnn_ih(d)) return hipErrorInvalidValue;
     static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder_h_kernel<false, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
-        if (e != hipSuccess) return e;
+        for (const void* f : {reinterpret_cast<const void*>(fused_encoder_h_kernel<false, true>), reinterpret_cast<const void*>(fused_encoder_h_kernel<true, true>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, fz::LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
     const int grid = B < num_cus ? B : num_cus;
+    static int trace = -1;
+    if (trace < 0) trace = getenv("TIP_FUSEDH_TRACE") ? 1 : 0;
+    if (trace) {   // measurement: the same phase stamps as the inference kernel (tools/fh_trace.py --train)
+        hipLaunchKernelGGL((fused_encoder_h_kernel<true, true>), dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s,
+                           keep_mask, keep_scale, (float*)nullptr, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total,
+                           d.S, d.L, (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4), tr);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((fused_encoder_h_kernel<false, true>), dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s,
                        keep_mask, keep_scale, (float*)nullptr, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total,
                        d.S, d.L, (int)(fused_packed_floats(d) * 4), (int)(fused_ih_off(d) * 4), tr);
