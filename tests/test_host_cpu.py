@@ -129,6 +129,16 @@ def test_max_batch_and_pack_options_without_a_gpu():
     # set_plan("fused16") asks for the section and invalidates the attached image
     m.set_plan("fused16")
     assert h.get_option(tlib.TIP_OPT_PACK_SPLIT16) == tlib.TIP_PACK_SPLIT16_FUSED and m._packed_dev is None
+    # TIP_OPT_F1S_PARTS: workgroups per window of the window-split plan (0 = the library's choice); the plan names pin it
+    assert h.get_option(tlib.TIP_OPT_F1S_PARTS) == 0
+    m.set_plan("fused1s4")
+    assert h.get_option(tlib.TIP_OPT_F1S_PARTS) == 4 and h.get_option(tlib.TIP_OPT_PLAN) == tlib.TIP_PLAN_FUSED1S
+    m.set_plan("fused1s2")
+    assert h.get_option(tlib.TIP_OPT_F1S_PARTS) == 2
+    m.set_plan("auto")
+    assert h.get_option(tlib.TIP_OPT_F1S_PARTS) == 0
+    with pytest.raises(tlib.TipStatusError):
+        h.set_option(tlib.TIP_OPT_F1S_PARTS, 3)
 
 
 def test_handle_table_status_and_errors():
