@@ -344,11 +344,12 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
                     "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(cfg, T, Bx / (ms * 1e-3)),
                     "headroom_vs_60fps": (1000.0 / ms) / 60.0}
         del bi, bs
-    # -- batches that are not whole rounds of 256 windows: AUTO runs whole rounds + a small remainder as two launch
-    #    sequences when that is cheaper than one more full round; a 300-window batch still pays most of a second round
+    # -- batches that are not whole rounds of 256 windows: below a round AUTO spreads ONE window over four
+    #    (33-64 windows) or two (65-128) CUs; above, it runs whole rounds + a remainder as two launch sequences when that is cheaper
+    #    than one more full round
     try:
         rem = {}
-        for Bx in (272, 300, 1000):
+        for Bx in (48, 64, 128, 272, 300, 1000):
             reps = (Bx + xi.shape[0] - 1) // xi.shape[0]
             bi, bs = xi.repeat(reps, 1, 1)[:Bx].contiguous(), xs.repeat(reps, 1, 1)[:Bx].contiguous()
             for _ in range(3):

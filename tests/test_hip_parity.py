@@ -199,7 +199,7 @@ def test_two_window_plan_golden_and_auto_selection(golden):
     for B, picked, rem in ((ncu + 200, "fused2", 0), (2 * ncu + 200, "fusedh", 0), (3 * ncu + 205, "fused2", 0), (ncu - 1, "fusedh", 0),
                            (65, "fused1s", 0), (ncu // 2, "fused1s", 0), (ncu // 2 + 1, "fusedh", 0), (49, "fused1s", 0), (33, "fused1s", 0), (32, "latency", 0),
                            (ncu + 3, "fusedh", 3), (2 * ncu + 3, "fused2", 3), (3 * ncu + 5, "fusedh", 5), (ncu + 100, "fusedh", 100),
-                           (ncu + 40, "fusedh", 40)):
+                           (ncu + 40, "fusedh", 40), (4 * ncu + 40, "fused2", 40)):
         x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=77)
         m.set_plan("auto")
         ya = _run(m, x_imu, x_s)

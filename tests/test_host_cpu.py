@@ -383,3 +383,19 @@ def test_f64_training_and_loss_entry_points_check_their_arguments_without_a_gpu(
     assert lib.tip_loss_forward_f64(vp(8), 131, vp(8), 131, 2, 5, 108, 2, 5, 7, vp(8), vp(8), 512, None) == -1     # n_vel must be 0 or 3
     assert lib.tip_loss_forward_f64(vp(8), 131, vp(8), 131, 2, 5, 108, 3, 5, 7, vp(8), vp(8), 8, None) == -4       # workspace too small
     assert lib.tip_loss_backward_f64(vp(8), 131, vp(8), 131, 2, 5, 108, 3, 5, 7, vp(8), None, vp(8), 100, None) == -1   # ld_dpred < W
+
+
+def test_workspace_of_a_part_never_exceeds_the_whole():
+    """AUTO runs a batch of whole rounds of 256 windows + a remainder as two forwards over the SAME workspace: every part's
+    tip_workspace_bytes must fit the whole's (round 4: the exchange section of the window-split plans was sized for B <= 1024 and
+    absent above, so the 1024-window part of a 1064-window batch asked for more than the whole — TIP_ERR_WORKSPACE)."""
+    m = make_model(synth.PAPER)
+    h = m._ensure_handle()
+    for T in (40, 17):
+        sizes = {B: h.workspace_bytes(B, T) for B in list(range(1, 300)) + list(range(300, 2400, 7)) + [1024, 1025, 1064, 1279, 1280, 2048, 4096, 8192]}
+        for B, total in sizes.items():
+            r = B % 256
+            if B > 256 and r:
+                assert h.workspace_bytes(B - r, T) <= total and h.workspace_bytes(r, T) <= total, (B, T)
+        big = [sizes[B] for B in sorted(sizes) if B >= 256]
+        assert all(a <= b for a, b in zip(big, big[1:])), "monotone from one round up"

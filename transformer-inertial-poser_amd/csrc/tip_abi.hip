@@ -152,8 +152,12 @@ Workspace carve_workspace(const Dims& d, int B, int T) {
     w.hall = take(Mp * (d.with_rnn ? d.R : 1));
     w.flags = take(rnn_flag_words(B, T) + 64);
     w.lat = take(latency_supported(d, B, T) ? latency_workspace_floats(B, T) : 0);   // (the persistent variant uses the same buffers)
-    // pair-split plan: partial-sum images two partner workgroups exchange (only batches that can be co-resident use it)
-    w.xchg = take(fused2_supported(d, T) && B <= 1024 ? fused2s_xchg_floats(B) : 0);
+    // window-split / pair-split plans: partial-sum images the partner workgroups exchange.  Only batches whose workgroups can all be
+    // resident use them (2 x ceil(B / 2) <= #CUs <= 256), so the section stops growing at 256 windows — and does not shrink beyond:
+    // AUTO runs a batch of whole rounds + a remainder as two forwards over the SAME workspace, and a part must never need more than
+    // the whole (until round 4 the section was sized for B <= 1024, 168 MB at B = 1024, and absent above: a 1064-window batch
+    // whose 1024-window part asked for more than the whole got TIP_ERR_WORKSPACE).
+    w.xchg = take(fused2_supported(d, T) ? fused2s_xchg_floats(B < 256 ? B : 256) : 0);
     w.total_bytes = off * sizeof(float);
     return w;
 }
@@ -796,7 +800,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     }
     if ((plan == TIP_PLAN_FUSED || plan == TIP_PLAN_FUSEDH) && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
-    if (plan == TIP_PLAN_FUSED2S && !(fused2_supported(d, T) && fused2s_fits(B, cus) && B <= 1024)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (plan == TIP_PLAN_FUSED2S && !(fused2_supported(d, T) && fused2s_fits(B, cus) && B <= 256)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED1S && !(fused2_supported(d, T) && fused1s_fits(B, cus) && (h->f1s_parts != 4 || fused1s_quad_fits(B, cus))))
         return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
