@@ -161,3 +161,34 @@ def test_auto_splits_whole_rounds_and_a_small_remainder(B):
     yo = oracle.forward(synth.PAPER, w, x_imu[sel], x_s[sel], dtype=np.float64)
     assert np.abs(y[torch.tensor(sel).cuda()].cpu().numpy() - yo).max() < TOL_TIGHT
     m.check_handoffs()
+
+
+def test_auto_over_a_batch_sweep_matches_the_one_window_plan():
+    """Every AUTO decision boundary in one sweep (latency plan / one window on four CUs / on two / one or two windows per CU / whole
+    rounds + remainder on each of the few-stream plans, below and above the 1024-window mark where the workspace layout used to
+    change): finite, hand-offs clean, within summation-order distance of the explicit one-window plan, and — the caller's workspace
+    being sized by tip_workspace_bytes of the WHOLE batch — no part ever short of workspace (round 4: B = 1064 was)."""
+    m, _ = _gpu_model(0)
+    x_imu, x_s = synth.make_inputs(synth.PAPER, 256, 40, seed=4242)
+    sizes = sorted(set([1, 2, 8, 9, 31, 32, 33, 47, 48, 49, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 257, 258, 287, 288, 289, 300, 319, 320, 321,
+                        383, 384, 385, 400, 511, 512, 513, 545, 600, 767, 768, 769, 801, 1000, 1023, 1024, 1025, 1056, 1057, 1064, 1088, 1089,
+                        1152, 1153, 1279, 1280, 1281, 1500, 2047, 2048, 2049, 2081, 2112, 2113, 2200]))
+    with torch.no_grad():
+        for B in sizes:
+            reps = (B + 255) // 256
+            xi = torch.tensor(np.tile(x_imu, (reps, 1, 1))[:B]).cuda()
+            xs = torch.tensor(np.tile(x_s, (reps, 1, 1))[:B]).cuda()
+            m.set_plan("auto")
+            n0 = m.hip_forward_count()
+            y = m(xi, xs)
+            torch.cuda.synchronize()
+            assert m.hip_forward_count() == n0 + 1, B
+            assert bool(torch.isfinite(y).all()), B
+            m.set_plan("fusedh")
+            ref = m(xi, xs)
+            assert float((y - ref).abs().max()) < 5e-6, B
+            yl = None
+            m.set_plan("auto")
+            yl = m.forward_last(xi, xs)
+            assert torch.equal(yl, y[:, -1]), B
+    m.check_handoffs()

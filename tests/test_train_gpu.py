@@ -350,3 +350,25 @@ def test_demoted_handle_trains_without_cooperating_recurrences():
     print("worst tensor", _check_grads(g, go))
     h.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)
     m.check_handoffs()
+
+
+def test_training_step_over_a_batch_sweep():
+    """Every batch-size regime of the training step in one sweep (tile remainders of the 4- / 16-window recurrences, one window per CU
+    below a round, several rounds, non-multiples of everything), encoder dropout off so that the step can be compared with the
+    INFERENCE forward of the same module: y within summation-order distance, every gradient finite, and the step deterministic."""
+    cfg = synth.PAPER
+    m, _ = _train_model(cfg, 3, 0.0)
+    x_imu, x_s = synth.make_inputs(cfg, 256, 40, seed=777)
+    cot = synth.normal(5, "cot", 256 * 40 * cfg["size_s"]).reshape(256, 40, -1).astype(np.float32)
+    for B in (1, 2, 3, 4, 5, 7, 15, 16, 17, 33, 63, 64, 65, 100, 127, 128, 129, 255, 256, 257, 300, 511, 513, 777):
+        reps = (B + 255) // 256
+        xi, xs, ct = (np.tile(a, (reps, 1, 1))[:B] for a in (x_imu, np.nan_to_num(x_s), cot))
+        y, g, _ = _hip_step(m, xi, xs, ct)
+        assert np.isfinite(y).all() and all(np.isfinite(v).all() for v in g.values()), B
+        y2, g2, _ = _hip_step(m, xi, xs, ct)
+        assert np.array_equal(y, y2) and all(np.array_equal(g[n], g2[n]) for n in g), B
+        m.eval()
+        with torch.no_grad():
+            ye = m(torch.tensor(xi).cuda(), torch.tensor(xs).cuda()).cpu().numpy()
+        m.train()
+        assert np.abs(y - ye).max() < 5e-6, (B, np.abs(y - ye).max())
