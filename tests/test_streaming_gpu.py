@@ -212,7 +212,7 @@ def test_rotation_branches_against_scipy_conventions():
     print("rotation-branch worst |axis-angle - scipy| =", worst)
 
 
-@pytest.mark.parametrize("B", [1, 3, 100])
+@pytest.mark.parametrize("B", [1, 3, 40, 100, 300])   # latency plan; one window on four / two CUs; whole round + remainder (two launch sequences)
 def test_graph_mode_equals_launch_by_launch(B):
     """StreamingEngine(use_graph=True): from frame 44 on (T = 40) a frame is one HIP-graph launch — ingest / forward_last / consume
     captured once, frame and call indices read from the counter the ingest kernel keeps in the state buffer
