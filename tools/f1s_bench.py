@@ -1,5 +1,7 @@
-import contextlib, sys
-sys.path.insert(0, "/root/repo")
+"""The window-split encoder (plan fused1s) against the one-window hybrid kernel (fusedh) at B = 1 .. 128: step time, encoder and
+recurrence stage times, error against the fp64 oracle, and the distance between the two plans (summation order only)."""
+import contextlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import tip_amd
 from tip_amd import synth

@@ -1,7 +1,7 @@
 """The window-split encoder with one window on 2 or 4 workgroups ("fused1s2" / "fused1s4": TIP_OPT_F1S_PARTS) against the
    latency plan, 1 <= B <= 64 (best of 3 x 100 forwards; encoder time from the in-library stage timers)."""
-import contextlib, sys
-sys.path.insert(0, "/root/repo")
+import contextlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import tip_amd
 from tip_amd import synth

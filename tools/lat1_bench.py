@@ -1,7 +1,7 @@
 """B = 1 .. 8 forward latency: the latency launch chain vs the persistent kernel (plan latency1); run on the GPU box.
 TIP_LAT1_SPREAD=1 in the environment selects the all-XCD worker placement."""
 import contextlib, os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import tip_amd
 from tip_amd import synth

@@ -2,7 +2,7 @@
 exit.  Run on the GPU box with TIP_LAT1_TRACE=1."""
 import contextlib, ctypes, os, sys
 os.environ["TIP_LAT1_TRACE"] = "1"
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import tip_amd
 from tip_amd import synth, lib as tlib

@@ -1,5 +1,7 @@
+"""Every explicit plan and AUTO at the given batch sizes: step time and the encoder / recurrence / projection stage times
+(in-library HIP events).  usage: python tools/plan_bench.py 256 300 512 1024"""
 import contextlib, os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import tip_amd
 from tip_amd import synth

@@ -1,5 +1,6 @@
+"""Measurement only: recurrence stage time against the row stride of its state buffer (round 3: does the HALL layout alias in L2?)."""
 import contextlib, os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import tip_amd
 from tip_amd import synth
