@@ -20,7 +20,7 @@ with contextlib.redirect_stdout(sys.stderr):
 w = synth.make_weights(cfg, seed=1)
 m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
 m = m.cuda().eval()
-BS = [1, 2, 3, 5, 8, 31, 32, 33, 63, 64, 65, 66, 127, 128, 129, 255, 256, 257, 258, 300, 511, 512, 513, 600, 767, 768, 769, 1000, 1023, 1024, 1025, 1100, 1537, 2049]
+BS = [1, 2, 3, 5, 8, 31, 32, 33, 40, 48, 49, 63, 64, 65, 66, 100, 127, 128, 129, 255, 256, 257, 258, 288, 289, 300, 320, 321, 384, 511, 512, 513, 600, 767, 768, 769, 1000, 1023, 1024, 1025, 1064, 1100, 1537, 2049]
 cases = worst = 0
 unsupported = set()
 worst_case = None
@@ -34,6 +34,9 @@ while time.time() < t_end:
         plans += ["fusedh", "fused"]
         if T == 40: plans.append("fused2")
     if B <= 64: plans.append("latency")
+    if T == 40 and B <= 128: plans += ["fused1s", "fused1s2"]       # one window on several workgroups (round 4)
+    if T == 40 and B <= 64: plans.append("fused1s4")
+    if T == 40 and B <= 256: plans.append("fused2s")
     plan = str(rng.choice(plans))
     cluster = int(rng.choice([0, 0, 0, 1, 2, 4, 8, 16])) if plan in ("fusedh", "fused", "general") else 0
     last = bool(rng.rand() < 0.3)
