@@ -488,12 +488,12 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xchg, 0, xchg_bytes, 0x00020000);
     const int voff = lane * 16;
     const int npairs = (B + NWIN - 1) / NWIN;                  // "pair" = the NWIN windows two partner workgroups share
-    // workgroup -> (pair, half): the two halves of a pair are 8 workgroup ids apart, i.e. on the same XCD when ids go
+    // workgroup -> (pair, part): the parts of a pair (called `half` below: two of them, or four) are 8 workgroup ids apart, i.e. on the same XCD when ids go
     // round-robin over the 8 XCDs (checked below, never assumed)
     const int xslot = blockIdx.x & 7, jj = blockIdx.x >> 3;
     const int half = jj % NPART;                           // this workgroup's part (0 .. NPART-1; "half" when NPART = 2)
     const int pair = (jj / NPART) * 8 + xslot;
-    if (pair >= npairs) return;                           // (both halves of a surplus pair leave together)
+    if (pair >= npairs) return;                           // (all parts of a surplus pair leave together)
     if ((gd.fault & 1) && pair == 0 && half == 1) return; // TIP_OPT_FAULT_INJECT: this partner never arrives
     float* px = xchg + (size_t)pair * PAIR_IMG;
     unsigned* pflag = reinterpret_cast<unsigned*>(xchg + (size_t)npairs * PAIR_IMG) + pair * PAIR_FLAG_WORDS;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
     const int nwin = (NWIN == 2 && win0 + 1 < B) ? 2 : 1;
     int handoff = 0;                                      // hand-offs done so far (uniform)
 
-    // X[:, all columns] += (partial of half 0 + partial of half 1) + bias: acc holds THIS half's partial.
+    // X[:, all columns] += (partial of part 0 + part 1 (+ part 2 + part 3)) + bias: acc holds THIS part's partial.
     // (A wave-to-wave variant — every wave publishing its own 10 tiles under its own counter and waiting only for its twin,
     // no workgroup barrier inside the hand-off — measured SLOWER: 0.787 vs 0.768 ms per step.)
     auto exchange_add = [&](f32x4 (&acc)[RBK][2], const float* bias) {
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         const int in_soff = (int)(IN_W * 4) + (wave * 2) * (KIN / 16) * 1024;
         WRing2<2> g_in;
         ring2_prefetch<2>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
-        // ---- prologue (:63-78) for both windows (carried by both halves) -------------------------------------------------
+        // ---- prologue (:63-78) for the pair's windows (carried by every part) --------------------------------------------
         float* U = C;
         for (int i = tid; i < ROWS * LDU; i += THREADS) U[i] = 0.f;
         __syncthreads();
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
             }
         }
         __syncthreads();
-        // ---- in_linear (:79) + channel shuffle (folded), all 256 columns on both halves ----------------------------------
+        // ---- in_linear (:79) + channel shuffle (folded), all 256 columns on every part -----------------------------------
         f32x4 acc[RBK][2];
         zero_acc2<RBK, 2>(acc);
         int au[RBK];
@@ -751,11 +751,11 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
             }
             __syncthreads();
         }
-        exchange_add(acc_o, LW + WO_B);               // X += out-projection (both halves' heads) + bias
+        exchange_add(acc_o, LW + WO_B);               // X += out-projection (every part's heads) + bias
         __syncthreads();
         layernorm_rows16<RBK * 16, f2::LDX>(X, LW + G1, LW + BE1, wave, lane);
         __syncthreads();
-        // ---- feed-forward: this half's 4 hidden chunks of 128; its K-half of linear2 accumulates in registers ---------------
+        // ---- feed-forward: this part's 8 / NPART hidden chunks of 128; its K-slice of linear2 accumulates in registers ------
         float* Hc = C;
         f32x4 acc_f[RBK][2];
         zero_acc2<RBK, 2>(acc_f);
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
         if (layer + 1 < L)                              // next layer's first Q|K ring flies during the hand-off and LayerNorm2
             ring2_prefetch<1>(g_q, rsrc, voff, lbase + (int)(LAYER_FLOATS * 4) + (int)(QKV_W * 4) +
                                                    ((wave >> 2) * 16 + half * (16 / NPART) + (wave & 3)) * 16 * 1024, 0);
-        exchange_add(acc_f, LW + W2_B);               // X += linear2 (both halves' hidden units) + bias
+        exchange_add(acc_f, LW + W2_B);               // X += linear2 (every part's hidden units) + bias
         __syncthreads();
         layernorm_rows16<RBK * 16, f2::LDX>(X, LW + G2, LW + BE2, wave, lane);
         __syncthreads();
