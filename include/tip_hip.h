@@ -112,7 +112,10 @@ typedef enum tip_status {
 #define TIP_OPT_FAULT_INJECT 4 /* TESTS ONLY.  Bit 0: the pair-split encoder drops one workgroup of pair 0; bit 1: the clustered
                                  RNN drops member 1 of its first cluster; bit 2: the latency plan's GEMV RNN drops member 1 of
                                  stream 0.  The partners' waits then MUST give up (after a shortened spin): the error path of
-                                 tip_check is exercised deterministically.  0 = off (default). */
+                                 tip_check is exercised deterministically.  Bit 3: nobody is dropped, but every cooperating kernel
+                                 treats its partners as sitting on DIFFERENT XCDs (agent-scope stores, L1-bypassing loads, paced
+                                 polls) wherever they really are: the path a placement across XCDs takes, bit-identical results.
+                                 0 = off (default). */
 
 #define TIP_OPT_FUSE_HEAD 5 /* 1: the output projection (:102) runs as the epilogue of the four-window recurrence kernel instead of as a
                                launch of its own, when the launch qualifies (T = 40, full output, one tile per cluster, i.e. B <= 256 on

@@ -195,3 +195,33 @@ def test_cu_masked_stream_window_split(plan, B):
     finally:
         torch.cuda.synchronize()
         hip.hipStreamDestroy(stream)
+
+
+@pytest.mark.parametrize("plan,B,cluster", [("fused1s4", 20, 0), ("fused1s2", 40, 0), ("fused2s", 60, 0), ("fusedh", 256, 0), ("fusedh", 100, 0),
+                                            ("fused", 64, 16), ("fused", 64, 4), ("latency", 5, 0)])
+def test_cross_xcd_paths_are_bit_identical(plan, B, cluster):
+    """TIP_OPT_FAULT_INJECT bit 3: every cooperating kernel (window-split / pair-split encoder, four-window and 16-window recurrence
+    clusters, the latency plan's GEMV cluster) treats its partners as sitting on different XCDs — agent-scope stores, L1-bypassing loads,
+    paced polls — wherever they really are.  That is the path a placement across XCDs takes (a CU-masked stream, a partitioned part);
+    on an idle full part the dispatcher never produces it, so it is forced here: bit-identical results, no time-out."""
+    m = _model()
+    h = m._ensure_handle()
+    x_imu, x_s = synth.make_inputs(synth.PAPER, B, 40, seed=28)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    t0 = tlib.spin_timeouts()
+    with torch.no_grad():
+        m.set_plan(plan, rnn_cluster=cluster)
+        ref = m(xi, xs)
+        refl = m.forward_last(xi, xs)
+        torch.cuda.synchronize()
+        h.set_option(tlib.TIP_OPT_FAULT_INJECT, 8)
+        try:
+            for _ in range(3):
+                y = m(xi, xs)
+                yl = m.forward_last(xi, xs)
+                torch.cuda.synchronize()
+                assert torch.equal(y, ref) and torch.equal(yl, refl)
+        finally:
+            h.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)
+    assert tlib.spin_timeouts() == t0
+    m.check_handoffs()

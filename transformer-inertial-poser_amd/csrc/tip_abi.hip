@@ -370,7 +370,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
             h->rnn_cluster = value;
             return TIP_OK;
         case TIP_OPT_FAULT_INJECT:
-            if (value < 0 || value > 7) return TIP_ERR_INVALID_ARG;
+            if (value < 0 || value > 15) return TIP_ERR_INVALID_ARG;
             h->fault_inject = value;
             return TIP_OK;
         case TIP_OPT_FUSE_HEAD:

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
                 if (theirs != mine) atomicAdd(&g_f2s_cross_xcd, 1u);   // (measurement: pairs that straddle XCDs)
                 same &= theirs == mine;
             }
-            s_same_xcd = same ? 1 : 0;
+            s_same_xcd = (same && !(gd.fault & 8)) ? 1 : 0;   // (fault bit 3: take the cross-XCD path wherever the partners sit)
         }
         __syncthreads();
         if (blockIdx.x == 0 && tid == 0 && handoff < 8) g_f2s_trace[handoff * 4 + 0] = __builtin_amdgcn_s_memtime();

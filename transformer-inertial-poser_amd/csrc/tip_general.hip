@@ -768,7 +768,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_resident_kernel(const float* _
                 if (!here) note_spin_timeout(gd.err);   // (the step loop below will time out on this member too, and poison)
                 same &= (v == mine);
             }
-            s_same_xcd = same ? 1 : 0;
+            s_same_xcd = (same && !(gd.fault & 8)) ? 1 : 0;
         }
         __syncthreads();
     }
@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_rows4_kernel(const float* __re
             if (!here) note_spin_timeout(gd.err);
             same &= (v == mine);
         }
-        s_same_xcd = same ? 1 : 0;
+        s_same_xcd = (same && !(gd.fault & 8)) ? 1 : 0;
     }
     __syncthreads();
     const bool same_xcd = s_same_xcd != 0;

@@ -172,7 +172,7 @@ struct Guard {
     int fault = 0;
 };
 constexpr unsigned kPoisonBits = 0x7FC00000u;   // canonical quiet NaN (NOT the all-ones RNN sentinel)
-__device__ __forceinline__ unsigned guard_spin_limit(int fault, unsigned normal) { return fault ? (1u << 14) : normal; }
+__device__ __forceinline__ unsigned guard_spin_limit(int fault, unsigned normal) { return (fault & 7) ? (1u << 14) : normal; }   // (bit 3 drops no member: full waits)
 __device__ __forceinline__ void guard_report(unsigned* err) {
     if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

@@ -497,7 +497,7 @@ __global__ __launch_bounds__(512) void rnn_gemv_kernel(const float* __restrict__
             }
             same &= (v == xcc + 1u);
         }
-        s_same_xcd = same ? 1 : 0;
+        s_same_xcd = (same && !(gd.fault & 8)) ? 1 : 0;
     }
     __syncthreads();
     const bool same_xcd = s_same_xcd != 0;
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(l1::THREADS) void lat1_kernel(Lat1Args a) {
     const unsigned tagbase = epoch * 32u;
     const unsigned spin_lim = guard_spin_limit(a.gd.fault, 1u << 22);
     // (grid barriers outlast a recurrence whose members each sit out one shortened granule wait)
-    const unsigned bar_lim = a.gd.fault ? (1u << 19) : (1u << 22);
+    const unsigned bar_lim = (a.gd.fault & 7) ? (1u << 19) : (1u << 22);
     if (tid == 0) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
