@@ -125,3 +125,39 @@ def test_graph_mode_streaming_engine_polls_the_handoff_word():
     assert out is not None and bool(torch.isfinite(out["y_last"]).all()) and eng._graph is not None
     m.check_handoffs()
     h.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)
+
+
+@pytest.mark.handoff_fault
+def test_launch_by_launch_streaming_engine_raises_and_reprimes_after_a_lost_frame():
+    """in the launch-by-launch engine the frame that lost a hand-off has already been consumed (its NaN y_last
+    is in the history ring) when the NEXT forward's entry check demotes the model and serves the call.  step() must not carry on on
+    top of that row: it resets the engine and raises, like the graph path; the stream then runs on demoted, finite."""
+    m, _ = _model()
+    h = m._ensure_handle()
+    n = 2
+    rng = np.random.RandomState(5)
+    eng = streaming.StreamingEngine(m, torch.zeros(n, 114), use_graph=False)
+
+    def frame():
+        R = np.tile(np.eye(3).reshape(-1), (n, 6)).astype(np.float32)
+        return torch.tensor(np.concatenate([R, rng.randn(n, 18).astype(np.float32)], axis=1)).cuda()
+
+    for _ in range(50):
+        out = eng.step(frame())
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out["y_last"]).all()) and not m.is_demoted()
+    h.set_option(tlib.TIP_OPT_FAULT_INJECT, 4)                # latency plan's GEMV recurrence (B = 2): this frame is lost
+    out = eng.step(frame())
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out["y_last"]).any())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with pytest.raises(tlib.TipHandoffError):
+            eng.step(frame())                                  # entry check trips, the model demotes, the engine re-primes and raises
+    assert eng.frame == 0 and m.is_demoted() and m.demotions == 1
+    for _ in range(60):                                        # fault still injected: the demoted plans do not care
+        out = eng.step(frame())
+    torch.cuda.synchronize()
+    assert out is not None and out["T"] == 40 and bool(torch.isfinite(out["y_last"]).all())
+    m.check_handoffs()
+    h.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)

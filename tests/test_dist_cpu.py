@@ -73,3 +73,17 @@ def test_shard_range_partitions():
             assert all(rs[i][1] == rs[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in rs]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_plain_bench_command_refuses_without_the_gpus():
+    """`python bench.py --gpus 8` where 8 GPUs are not there (here: none) exits non-zero without a JSON line — the driver's plain
+    invocation can never be answered with a silent N = 1 measurement."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TIP_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode != 0
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")], res.stdout
+    assert "refusing" in res.stderr

@@ -93,3 +93,43 @@ def test_two_ranks_one_gpu_shards_equal_single_process(tmp_path):
         yl = m.forward_last(torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()).cpu().numpy()
     assert np.array_equal(np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(2)]), y)
     assert np.array_equal(np.concatenate([np.load(tmp_path / f"yl{r}.npy") for r in range(2)]), yl)
+
+
+def test_plain_bench_command_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (the driver's invocation): bench.py re-runs itself under torch.distributed.run
+    with two ranks; here both share cuda:0 over gloo.  The line must say n_gpus == world_size == 2."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TIP_BENCH_SHARE_GPU="1", TIP_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--plan", "fusedh",
+           "--rnn-cluster", "1", "--no-cpu-baseline", "--no-extra", "--prewarm-s", "0.05"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and len(d["per_rank_ms_per_step"]["all"]) == 2
+    assert d["config"]["global_batch"] == 512 and d["ranks_output_identical"] is True
+
+
+def test_plain_bench_command_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus 8` on a box with fewer GPUs fails loudly: no N = 1 line, non-zero exit."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("an 8-GPU node: the command is legitimate here")
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TIP_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode != 0
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")], res.stdout
+    assert "refusing" in res.stderr
+
+
+def test_world_size_mismatch_is_an_error():
+    """One rank under the launcher but --gpus 2: a hard error, not an N = 1 line."""
+    res = _torchrun(1, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extra",
+                        "--no-cpu-baseline"], {})
+    assert res.returncode != 0
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")], res.stdout

@@ -22,7 +22,8 @@ buffers.  A captured forward is outside the library's cross-stream serialisation
 the device's other forwards use, or when none is in flight.  Every replayed frame polls the handle's hand-off word (a pinned
 host word, no synchronisation): a lost hand-off of an earlier replay — its y_last was NaN and went into the history ring —
 re-primes the engine (reset()), demotes the handle to the non-cooperating plans when TIP_OPT_AUTO_DEMOTE allows, and raises
-TipHandoffError, exactly as the launch-by-launch engine's next forward would have.
+TipHandoffError.  The launch-by-launch engine does the same: when the model's forward reports that it demoted itself because
+of an earlier frame's loss, step() resets the engine and raises instead of consuming on top of a NaN history row.
 """
 from __future__ import annotations
 
@@ -115,7 +116,11 @@ class StreamingEngine:
                     if self._graph_ws is None:
                         self._graph_ws = torch.empty(self.model.workspace_bytes(self.n, 40), dtype=torch.uint8, device=self.device)
                         self._graph_y = torch.empty((self.n, self.model.size_s), dtype=torch.float32, device=self.device)
-                    self.model.forward_last(self.x_imu, self.x_s, workspace=self._graph_ws, out=self._graph_y)   # packs / attaches outside the capture
+                    # packs / attaches outside the capture.  The device RNG is put back afterwards: with past_state_dropout or
+                    # in_dropout live this warm-up would otherwise draw once more than the launch-by-launch loop does
+                    rng = torch.cuda.get_rng_state(self.device)
+                    self.model.forward_last(self.x_imu, self.x_s, workspace=self._graph_ws, out=self._graph_y)
+                    torch.cuda.set_rng_state(rng, self.device)
                     torch.cuda.current_stream(self.device).synchronize()
                     self._poll_handoff()
                     g = torch.cuda.CUDAGraph()
@@ -140,7 +145,15 @@ class StreamingEngine:
                 return None
             x_imu = self.x_imu.view(-1)[: self.n * T * 90].view(self.n, T, 90)
             x_s = self.x_s.view(-1)[: self.n * T * 131].view(self.n, T, 131)
+            demotions = self.model.demotions
             y_last = self.model.forward_last(x_imu, x_s)
+            if self.model.demotions != demotions:
+                # tip_forward's entry check found that an EARLIER frame lost a hand-off: the model demoted itself and served this
+                # call, but that frame's NaN row already went into the history ring (the prologue would scrub it to 0 for the
+                # next 40 windows: finite, degraded poses).  Same contract as the graph path: re-prime and raise.
+                self.reset()
+                raise _lib.TipHandoffError(_lib.TIP_ERR_HANDOFF, "an earlier frame of this engine lost an inter-workgroup hand-off; "
+                                           "the model now runs the non-cooperating plans and the engine was reset (re-prime it)")
             self._check(self.lib.tip_stream_consume(self.state.data_ptr(), y_last.data_ptr(), self.n, f - 5,
                                                     self.s_rest.data_ptr(), self.c_t.data_ptr(), self._stream()))
         return {"s_rest": self.s_rest, "c_t": self.c_t, "y_last": y_last, "T": T}
