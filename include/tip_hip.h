@@ -117,10 +117,14 @@ typedef enum tip_status {
                                  polls) wherever they really are: the path a placement across XCDs takes, bit-identical results.
                                  0 = off (default). */
 
-#define TIP_OPT_FUSE_HEAD 5 /* 1: the output projection (:102) runs as the epilogue of the four-window recurrence kernel instead of as a
-                               launch of its own, when the launch qualifies (T = 40, full output, one tile per cluster, i.e. B <= 256 on
-                               a full part); bit-identical results.  0 (default): separate launch.  Measured neutral to -1.2 us per
-                               step; kept selectable (CHANGELOG.md, round 3).  Environment TIP_RNN_HEAD=1 makes 1 the default. */
+#define TIP_OPT_FUSE_HEAD 5 /* 1 (default): with rnn_hidden 512 and 128 < size_s <= 132 the four-window cluster recurrence computes the
+                               output projection (:102) INSIDE its hop wait (rnn_head_kernel, csrc/tip_rnnh.hip): y_{t-1} is multiplied out
+                               between a member's store of its slice of h_t and the arrival of its partners' slices, the state travels
+                               through an L2-resident ring of {value, tag} granules in the workspace instead of HALL, and no projection
+                               kernel is launched.  Any batch size and window length, full and last-row output (bit-identical last rows).
+                               The recurrence's arithmetic is unchanged; the projection's summation order differs from the stand-alone
+                               kernels' (outputs agree to ~1e-6).  0: recurrence and projection as separate launches (rnn_rows4_kernel +
+                               head_ksplit_kernel), as until round 4.  Ignored on a demoted handle (a cooperating kernel). */
 
 #define TIP_OPT_PACK_SPLIT16 6 /* which EXPLORATORY split-fp16 weight copies the packed image carries (default 0: none).  Bit 0
                                  (TIP_PACK_SPLIT16_FUSED): the fused section's, for TIP_PLAN_FUSED16 (+15 MB for the paper configuration);

@@ -7,6 +7,7 @@
 
 #include <mutex>
 #include "tip_internal.h"
+#include "tip_rnnh.h"
 
 using namespace tip;
 
@@ -158,6 +159,8 @@ Workspace carve_workspace(const Dims& d, int B, int T) {
     // the whole (until round 4 the section was sized for B <= 1024, 168 MB at B = 1024, and absent above: a 1064-window batch
     // whose 1024-window part asked for more than the whole got TIP_ERR_WORKSPACE).
     w.xchg = take(fused2_supported(d, T) ? fused2s_xchg_floats(B < 256 ? B : 256) : 0);
+    // hand-off ring of the recurrence-with-projection kernel (tip_rnnh.hip): two 16-KB slots per four-window cluster in flight
+    w.ring = take(d.with_rnn ? rnnh_ring_bytes(B) / sizeof(float) : 0);
     w.total_bytes = off * sizeof(float);
     return w;
 }
@@ -312,7 +315,7 @@ int tip_create(const tip_config* cfg, tip_handle** out) {
     h->d = d;
     build_tensor_table(h);
     build_layout(h);
-    h->fuse_head = (getenv("TIP_RNN_HEAD") && getenv("TIP_RNN_HEAD")[0] == '1') ? 1 : 0;   // TIP_OPT_FUSE_HEAD's default
+    h->fuse_head = 1;   // TIP_OPT_FUSE_HEAD's default
     int dev = -1;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0) {
         h->device = dev;
@@ -685,11 +688,11 @@ int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches
 
 int tip_spin_timeouts(unsigned* count) {
     if (!count) return TIP_ERR_INVALID_ARG;
-    unsigned a = 0, b = 0, c = 0;
+    unsigned a = 0, b = 0, c = 0, e = 0;
     if (read_spin_timeouts_general(&a) != hipSuccess || read_spin_timeouts_latency(&b) != hipSuccess ||
-        read_spin_timeouts_fused2(&c) != hipSuccess)
+        read_spin_timeouts_fused2(&c) != hipSuccess || read_spin_timeouts_rnnh(&e) != hipSuccess)
         return TIP_ERR_HIP;
-    *count = a + b + c;
+    *count = a + b + c + e;
     return TIP_OK;
 }
 
@@ -827,6 +830,12 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         if (rows4 && d.R == 512) rnn_cluster = kRnnRows4;
     }
     bool head_done = false;
+    // TIP_OPT_FUSE_HEAD (default): the four-window cluster recurrence computes the output projection inside its hop wait and hands
+    // its state over through an L2-resident ring (tip_rnnh.hip) — no HALL traffic, no projection launch.  A cooperating kernel:
+    // never on a demoted handle.
+    const bool use_rnnh = d.with_rnn && h->fuse_head && !h->demoted && rnn_cluster == kRnnRows4 && rnnh_supported(d, T) &&
+                          plan != TIP_PLAN_LATENCY && plan != TIP_PLAN_LATENCY1;
+    auto arm_hall = [&]() { return !use_rnnh && rnn_uses_sentinel(d, B, T, rnn_cluster); };
     if (plan == TIP_PLAN_LATENCY1) {
         StageScope sc(h, s, "latency_chain");
         unsigned* sync = reinterpret_cast<unsigned*>(const_cast<float*>(P + L.sync_off));
@@ -847,38 +856,38 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     } else if (plan == TIP_PLAN_FUSED1S) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = true;
-        hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
+        hall_armed = arm_hall();
         TIP_TRY(launch_fused_encoder1s(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr,
                                        W0 + ws.xchg, B, cus, h->f1s_parts, gd, s), "fused_encoder1s");
     } else if (plan == TIP_PLAN_FUSED2S) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = true;
-        hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
+        hall_armed = arm_hall();
         TIP_TRY(launch_fused_encoder2s(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr,
                                        W0 + ws.xchg, B, cus, gd, s), "fused_encoder2s");
     } else if (plan == TIP_PLAN_FUSED2) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = true;
-        hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
+        hall_armed = arm_hall();
         TIP_TRY(launch_fused_encoder2(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr, B,
                                       cus, s), "fused_encoder2");
     } else if (plan == TIP_PLAN_FUSED16) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = true;
-        hall_armed = rnn_uses_sentinel(d, B, T, rnn_cluster);
+        hall_armed = arm_hall();
         TIP_TRY(launch_fused_encoder_s16(d, P + L.fused_off, P + L.s16_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr,
                                          B, T, cus, s), "fused_encoder_s16");
     } else if (plan == TIP_PLAN_FUSEDH) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = fused_has_rnn_ih(d);
-        hall_armed = ih_done && rnn_uses_sentinel(d, B, T, rnn_cluster);
+        hall_armed = ih_done && arm_hall();
         TIP_TRY(launch_fused_encoder_h(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, ih_done ? nullptr : xa,
                                        ih_done ? big : nullptr, hall_armed ? hall : nullptr, B, T, cus, s),
                 "fused_encoder_h");
     } else if (plan == TIP_PLAN_FUSED) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = fused_has_rnn_ih(d);
-        hall_armed = ih_done && rnn_uses_sentinel(d, B, T, rnn_cluster);   // the encoder pre-fills its HALL rows
+        hall_armed = ih_done && arm_hall();   // the encoder pre-fills its HALL rows
         TIP_TRY(launch_fused_encoder(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, ih_done ? nullptr : xa,
                                      ih_done ? big : nullptr, hall_armed ? hall : nullptr, B, T, cus, s),
                 "fused_encoder");
@@ -939,15 +948,13 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         }
         {
             StageScope sc(h, s, "rnn_recurrence");
-            // TIP_OPT_FUSE_HEAD: the output projection rides as the recurrence's epilogue when the launch qualifies
-            // (rnn_rows4_kernel<.., HEAD>)
-            const bool fuse_head = h->fuse_head && !(getenv("TIP_HEAD") && getenv("TIP_HEAD")[0] == 'o');
-            HeadFuse hf;
-            hf.wfrag = P + L.out_frag_off; hf.bias = P + L.out_lin.b_off; hf.y = y; hf.ldy = d.S; hf.N = d.S;
-            const bool can_fuse = fuse_head && !last_only && plan != TIP_PLAN_LATENCY && d.R == 512 && d.S > 128 && d.S <= 144 &&
-                                  (long long)M * d.S * 4 <= 0x7fffffffLL;
-            TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, rnn_cluster, cus, hall_armed, gd, s,
-                               can_fuse ? &hf : nullptr, &head_done), "rnn_recurrence");
+            if (use_rnnh) {
+                TIP_TRY(launch_rnn_head(d, big, P + L.whh_frag_off, P + L.out_lin.w_off, P + L.out_lin.b_off, y, W0 + ws.ring, rflags, B, T,
+                                        last_only, false, cus, next_rnn_launch_tag(), gd, s), "rnn_recurrence");
+                head_done = true;
+            } else {
+                TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, rnn_cluster, cus, hall_armed, gd, s), "rnn_recurrence");
+            }
         }
         head_in = hall;
         head_ld = d.R;

@@ -1041,23 +1041,19 @@ constexpr int kQ4Rows = 4, kQ4Cluster = 4, kQ4Tiles = 4, kQ4LD = 512 + 16;
 //     >= hall_bytes, so the descriptor's range check returns zeros for their loads and drops their stores (the scalar offset is
 //     not part of that check: the row term alone decides); such tiles multiply zeros;
 //   * the poll loop is per WAVE: all its lanes re-ask until none of them sees a sentinel.
-// HEAD (NT = 1, forward, one tile per cluster, T = 40): the output projection y = h W_out^T + b (:102) runs as the kernel's epilogue
-// — head_ksplit_body (tip_head.h), member `cid` of a cluster taking window 4 tile + cid — instead of as a launch of its own: the
-// weight loads go out while the last step's stores travel, and the launch boundary (fixed cost + ramp, ~3 us) disappears.
 // WAVES = 4 (round 4): a member is a 4-wave workgroup owning 64 columns, a cluster EIGHT members, and TWO workgroups — members of
 // different clusters, i.e. different tiles — share a CU: the matrix work per CU is what it was, but while one workgroup sits in its
 // hand-off (pull, LDS, barrier: 0.7 us of a 1.9-us step) the other one's MFMAs have the pipe.  Same fragments per wave (16 columns x
 // all k), same accumulation order: bit-identical to WAVES = 8.
-template <int NT, bool TRACE, bool BWD, bool HEAD = false, int WAVES = 8>
+template <int NT, bool TRACE, bool BWD, int WAVES = 8>
 __global__ __launch_bounds__(WAVES * 64) void rnn_rows4_kernel(const float* __restrict__ ih, const float* __restrict__ whh_frag,
                                                         float* __restrict__ hall, unsigned* __restrict__ flags, int B, int T,
                                                         int ntiles, int hall_bytes, const float* __restrict__ gate, Guard gd,
-                                                        unsigned etag, int abl, int ngroups, HeadFuse hf) {
+                                                        unsigned etag, int abl, int ngroups) {
     // abl: MEASUREMENT-ONLY ablations (wrong results), TIP_RNN_ABLATE: 1 = polls never wait, 2 = no MFMAs
     constexpr int R = 512, KB = R / 16, CLUSTER = 32 / WAVES, LD = kQ4LD;
     constexpr int THREADS = WAVES * 64, PL = 8 / WAVES;            // 16-byte pieces of a pulled tile per thread: 1 (8 waves) or 2 (4 waves)
     static_assert(WAVES == 8 || WAVES == 4, "cluster of 4 or 8 members");
-    static_assert(!HEAD || WAVES == 8, "the projection epilogue is written for 8-wave members");
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [2 buffers][NT tiles][4 rows][LD]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1071,10 +1067,9 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_rows4_kernel(const float* __re
     const __amdgpu_buffer_rsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(hall, 0, hall_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ih), 0, hall_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BWD ? gate : ih), 0, hall_bytes, 0x00020000);
-    // TIP_OPT_FAULT_INJECT: this member never arrives.  (HEAD: it still runs the epilogue for its window — over state columns that
-    // stay sentinel words, i.e. NaN — so that what a dead member owed is NaN in y too, never stale memory.)
+    // TIP_OPT_FAULT_INJECT: this member never arrives
     const bool dead = (gd.fault & 2) && group == 0 && cid == 1;
-    if (dead && !HEAD) return;
+    if (dead) return;
     const unsigned spin_big = guard_spin_limit(gd.fault, 1u << 22), spin_pull = guard_spin_limit(gd.fault, 1u << 20);
 
     // this thread's 16-byte pieces of a pulled tile: row prow, columns pcol + 4 i (i < PL)
@@ -1285,42 +1280,39 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_rows4_kernel(const float* __re
                 else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), hrs, vout[n], so_out, 16);
             }
             if (TRACE && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 2] = __builtin_amdgcn_s_memtime();
+            if (abl & 48) {
+                // MEASUREMENT ONLY (round 5 probe): matrix work placed in the hop wait — 16: 64 MFMAs per wave with their B operand
+                // read from LDS (what the input projection of step t + 1 would cost there), 32: 32 MFMAs per wave on registers
+                // (the output projection of step t - 1).  Results are discarded.
+                f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0, d3 = d0;
+                if (abl & 16) {
+                    const float* bp = smem + (lane * 4);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const float4 bv = *reinterpret_cast<const float4*>(bp + (k & 7) * 256);
+                        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].x, bv.x, d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].y, bv.y, d1, 0, 0, 0);
+                        d2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].z, bv.z, d2, 0, 0, 0);
+                        d3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].w, bv.w, d3, 0, 0, 0);
+                    }
+                }
+                if (abl & 32) {
+#pragma unroll
+                    for (int k = 16; k < 24; ++k) {
+                        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].x, wreg[k].y, d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].y, wreg[k].z, d1, 0, 0, 0);
+                        d2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].z, wreg[k].w, d2, 0, 0, 0);
+                        d3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].w, wreg[k].x, d3, 0, 0, 0);
+                    }
+                }
+                asm volatile("" :: "v"(d0), "v"(d1), "v"(d2), "v"(d3));
+            }
         }
         retire_touch();
         __syncthreads();   // the next batch's second step rewrites the buffer the last step of this one may still be reading
     }
     // leave the XCC-exchange word cleared for a replay of this launch from a HIP graph (same tag): see rnn_resident_kernel
     if (T >= 2 && tid == 0 && !dead) __hip_atomic_store(flags + group * CLUSTER + cid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if constexpr (HEAD) {
-        // one tile per cluster (host-side condition): this member projects window 4 * group + cid.  Rows 0 .. T-2 of the tile were
-        // pulled complete by this workgroup in the steps above; row T-1 is awaited below, behind the weight loads.
-        const int win = group * kQ4Rows + cid;
-        if (win >= B) return;
-        struct Ctl {
-            int win, nwin, vpull, so, same_xcd, spin_pull, poisoned;
-            __amdgpu_buffer_rsrc_t hrs;
-            unsigned* err;
-            __device__ __forceinline__ int first() const { return win; }
-            __device__ __forceinline__ int stride() const { return nwin; }
-            __device__ __forceinline__ void after_weights() const {
-                bool gave_up = true;
-                const unsigned lim = poisoned ? 1u : (unsigned)spin_pull;
-                for (unsigned spins = 0; spins < lim; ++spins) {
-                    asm volatile("" ::: "memory");
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(hrs, vpull, so, 16);
-                    const bool pend = v.x == kRnnSentinel || v.y == kRnnSentinel || v.z == kRnnSentinel || v.w == kRnnSentinel;
-                    if (__builtin_amdgcn_ballot_w64(pend) == 0) { gave_up = false; break; }
-                    if (!same_xcd) __builtin_amdgcn_s_sleep(2);
-                }
-                if (gave_up && !poisoned && (threadIdx.x & 63) == 0) note_spin_timeout(err);   // the rows stay sentinel = NaN: y is NaN there
-                __syncthreads();
-            }
-        };
-        const unsigned rowbytes_h = (unsigned)T * R * 4;
-        Ctl ctl{win, B, (int)((unsigned)(group * kQ4Rows + prow) * rowbytes_h + (unsigned)pcol * 4u), (T - 1) * (R * 4),
-                same_xcd ? 1 : 0, (int)spin_pull, poisoned ? 1 : 0, hrs, gd.err};
-        head_ksplit_body<0, false, 16>(hall, (unsigned)(R * 4), (unsigned)hall_bytes, hf.wfrag, hf.bias, hf.y, hf.ldy, B * T, hf.N, B, ctl);
-    }
 }
 
 size_t rnn_flag_words(int B, int T) { return (size_t)((B + kRnnTile - 1) / kRnnTile) * (size_t)T + 1024; }
@@ -1328,7 +1320,7 @@ size_t rnn_flag_words(int B, int T) { return (size_t)((B + kRnnTile - 1) / kRnnT
 // ONE process-wide launch tag for every kernel family that tags the XCC-exchange words of a workspace (rnn_resident_kernel and
 // rnn_rows4_kernel write the same `flags` words): with a counter each, a stale word left by one family could match the other's
 // tag and a wait would be satisfied by a stale XCC id.
-static unsigned next_rnn_launch_tag() {
+unsigned next_rnn_launch_tag() {
     static std::atomic<unsigned> launch_tag{[] { std::random_device rd; return (unsigned)rd(); }()};
     return launch_tag.fetch_add(1u) & 0x7FFFFFu;   // 23 bits: fits the int kernel argument above the option bits
 }
@@ -1405,61 +1397,38 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
 // (rnn_rows4_kernel); sentinel hand-off only
 template <int NT, int WAVES>
 static hipError_t launch_rnn_rows4_nt(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T, int ntiles,
-                                      int groups, long long hb, const Guard& gd, hipStream_t s, const float* gate, unsigned etag, int num_cus,
-                                      const HeadFuse* hf = nullptr, bool* head_done = nullptr) {
+                                      int groups, long long hb, const Guard& gd, hipStream_t s, const float* gate, unsigned etag, int num_cus) {
     constexpr int smem = 2 * NT * kQ4Rows * kQ4LD * (int)sizeof(float);
     constexpr int CLUSTER = 32 / WAVES, THREADS = WAVES * 64;
     static int trace = -1, abl = -1;
     if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
     if (abl < 0) abl = getenv("TIP_RNN_ABLATE") ? atoi(getenv("TIP_RNN_ABLATE")) : 0;   // measurement only (profiles/): never set in production
-    if constexpr (NT == 1 && WAVES == 8) {
-        // output projection fused as the kernel's epilogue (see the kernel): one tile per cluster, T = 40, forward, no tracing
-        if (hf && !gate && !trace && !abl && T == 40 && ntiles <= groups) {
-            constexpr int smem_h = smem > hd::LDS_BYTES ? smem : hd::LDS_BYTES;
-            static PerDeviceFlag attr_h; bool& set_h = attr_h.cur();
-            if (!set_h) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rnn_rows4_kernel<1, false, false, true>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem_h);
-                if (e != hipSuccess) return e;
-                set_h = true;
-            }
-            static PerDeviceInt occ_h; int& occh = occ_h.cur();
-            hipError_t ce = check_coresident(rnn_rows4_kernel<1, false, false, true>, 512, smem_h, groups * kQ4Cluster, num_cus, &occh);
-            if (ce != hipSuccess) return ce;
-            const dim3 gridh((groups + 7) / 8 * 8 * kQ4Cluster), blockh(512);
-            hipLaunchKernelGGL((rnn_rows4_kernel<1, false, false, true>), gridh, blockh, smem_h, s, ih, whh_frag, hall, flags, B, T, ntiles,
-                               (int)hb, gate, gd, etag, abl, groups, *hf);
-            if (head_done) *head_done = true;
-            return hipGetLastError();
-        }
-    }
     static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
-        for (const void* f : {reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, false, false, WAVES>), reinterpret_cast<const void*>(rnn_rows4_kernel<NT, true, false, false, WAVES>),
-                              reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, true, false, WAVES>)}) {
+        for (const void* f : {reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, false, WAVES>), reinterpret_cast<const void*>(rnn_rows4_kernel<NT, true, false, WAVES>),
+                              reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, true, WAVES>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return e;
         }
         attr_set = true;
     }
     static PerDeviceInt occ_dev; int& occ = occ_dev.cur();   // every member of a cluster must be resident while its partners wait for it: ask the runtime
-    hipError_t ce = check_coresident(rnn_rows4_kernel<NT, false, false, false, WAVES>, THREADS, smem, groups * CLUSTER, num_cus, &occ);
+    hipError_t ce = check_coresident(rnn_rows4_kernel<NT, false, false, WAVES>, THREADS, smem, groups * CLUSTER, num_cus, &occ);
     if (ce != hipSuccess) return ce;
     // Members of a cluster are taken 8 workgroup ids apart (one XCD); that needs a grid of whole rounds of 8 clusters.  The
     // workgroups of the clusters that pad the last round exit at once (they hold no resources anybody waits for).
     const dim3 grid((groups + 7) / 8 * 8 * CLUSTER), block(THREADS);
     if (gate)
-        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, true, false, WAVES>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups, HeadFuse{});
+        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, true, WAVES>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups);
     else if (trace)
-        hipLaunchKernelGGL((rnn_rows4_kernel<NT, true, false, false, WAVES>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups, HeadFuse{});
+        hipLaunchKernelGGL((rnn_rows4_kernel<NT, true, false, WAVES>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups);
     else
-        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, false, false, WAVES>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups, HeadFuse{});
+        hipLaunchKernelGGL((rnn_rows4_kernel<NT, false, false, WAVES>), grid, block, smem, s, ih, whh_frag, hall, flags, B, T, ntiles, (int)hb, gate, gd, etag, abl, groups);
     return hipGetLastError();
 }
 
 static hipError_t launch_rnn_rows4(const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B, int T, int num_cus,
-                                   bool hall_armed, const Guard& gd, hipStream_t s, const float* gate = nullptr,
-                                   const HeadFuse* hf = nullptr, bool* head_done = nullptr) {
+                                   bool hall_armed, const Guard& gd, hipStream_t s, const float* gate = nullptr) {
     const int ntiles = (B + kQ4Rows - 1) / kQ4Rows;
     // 4-wave members, 8 per cluster: when the batch leaves CUs idle (tiles x 8 <= #CUs, i.e. B <= 128 on a full part) every member
     // gets a CU of its own with half the matrix work per step: 62 vs 76 us at B = 100.  With two members per CU (B = 256) the hoped-for
@@ -1467,7 +1436,7 @@ static hipError_t launch_rnn_rows4(const float* ih, const float* whh_frag, float
     // stay there.  Bit-identical either way.  TIP_RNN_W4=0 / 1 forces one (measurement).
     static int w4 = -2;
     if (w4 == -2) w4 = getenv("TIP_RNN_W4") ? (getenv("TIP_RNN_W4")[0] == '1' ? 1 : 0) : -1;
-    const bool use_w4 = (w4 == 1 || (w4 == -1 && ntiles * 8 <= num_cus)) && !(hf && !gate);   // (the fused output projection exists for 8-wave members)
+    const bool use_w4 = (w4 == 1 || (w4 == -1 && ntiles * 8 <= num_cus));
     int groups = ntiles;
     const int maxg = num_cus / kQ4Cluster > 0 ? num_cus / kQ4Cluster : 1;   // keep every cluster co-resident (W4: 8 members, two per CU: the same count)
     if (groups > maxg) groups = maxg;
@@ -1488,7 +1457,7 @@ static hipError_t launch_rnn_rows4(const float* ih, const float* whh_frag, float
         if (tpg == 2) return launch_rnn_rows4_nt<2, 4>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
         return launch_rnn_rows4_nt<kQ4Tiles, 4>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
     }
-    if (tpg <= 1) return launch_rnn_rows4_nt<1, 8>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus, hf, head_done);
+    if (tpg <= 1) return launch_rnn_rows4_nt<1, 8>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
     if (tpg == 2) return launch_rnn_rows4_nt<2, 8>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
     return launch_rnn_rows4_nt<kQ4Tiles, 8>(ih, whh_frag, hall, flags, B, T, ntiles, groups, hb, gd, s, gate, etag, num_cus);
 }
@@ -1544,14 +1513,14 @@ hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_fra
 }
 
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
-                      int T, int cluster, int num_cus, bool hall_armed, const Guard& gd, hipStream_t s, const HeadFuse* hf, bool* head_done) {
+                      int T, int cluster, int num_cus, bool hall_armed, const Guard& gd, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     const int R = d.R;
     const int ntiles = (B + kRnnTile - 1) / kRnnTile;
     if (cluster < 1) cluster = 1;
     if (R == 512 && (long long)B * T * 512 * 4 <= 0x7fffffffLL) {
         if (cluster == kRnnRows4) {
-            if (rnn_handoff_mode() == 1) return launch_rnn_rows4(ih, whh_frag, hall, flags, B, T, num_cus, hall_armed, gd, s, nullptr, hf, head_done);
+            if (rnn_handoff_mode() == 1) return launch_rnn_rows4(ih, whh_frag, hall, flags, B, T, num_cus, hall_armed, gd, s, nullptr);
             cluster = 16;   // (TIP_RNN_HANDOFF=0, measurement: the counter protocol exists for the 16-row kernels only)
         }
         // register-resident clustered kernel: W_hh slice lives in VGPRs, 4/8/16 workgroups per window tile

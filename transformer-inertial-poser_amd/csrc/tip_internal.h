@@ -148,7 +148,7 @@ struct PackBatch {
 
 // Workspace carve-up for the general plan (float offsets), M = B*T rows.
 struct Workspace {
-    size_t xa, xb, big, att, hall, flags, lat, xchg;  // float offsets
+    size_t xa, xb, big, att, hall, flags, lat, xchg, ring;  // float offsets
     size_t total_bytes;
 };
 
@@ -304,18 +304,10 @@ hipError_t launch_mattn_fwd(const float* qkv, float* out, float* ast, int B, int
 hipError_t launch_mattn_bwd(const float* qkv, const float* o_saved, const float* ast, const float* d_o, float* dqkv, int B, int T,
                             int H, int dh, float q_scale, AttnDrop drop, hipStream_t s);
 hipError_t launch_layernorm(float* x, const float* g, const float* b, int M, int D, hipStream_t s);
-// Output projection as the recurrence's epilogue (rnn_rows4_kernel<1, .., HEAD>): when `hf` is given and the launch qualifies (four-
-// window tiles, one tile per cluster, T = 40) the kernel also writes y = h W_out^T + b and *head_done is set; otherwise the caller
-// launches the projection itself.
-struct HeadFuse {
-    const float* wfrag = nullptr;   // W_out in B-fragment order (PackedLayout::out_frag_off)
-    const float* bias = nullptr;
-    float* y = nullptr;             // [B * T][ldy]
-    int ldy = 0, N = 0;
-};
 hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, float* hall, unsigned* flags, int B,
-                      int T, int cluster, int num_cus, bool hall_armed, const Guard& gd, hipStream_t s,
-                      const HeadFuse* hf = nullptr, bool* head_done = nullptr);
+                      int T, int cluster, int num_cus, bool hall_armed, const Guard& gd, hipStream_t s);
+// one process-wide launch tag for every kernel family that tags the XCC-exchange words of a workspace (tip_general.hip)
+unsigned next_rnn_launch_tag();
 size_t rnn_flag_words(int B, int T);
 // training step, backward recurrence: delta_t = (dH_t + delta_{t+1} W_hh) * (1 - h_t^2) (tip_train.hip)
 hipError_t launch_rnn_bwd(const Dims& d, const float* dH, const float* whh_t_frag, const float* h_fwd, float* delta,
