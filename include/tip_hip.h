@@ -117,14 +117,9 @@ typedef enum tip_status {
                                  polls) wherever they really are: the path a placement across XCDs takes, bit-identical results.
                                  0 = off (default). */
 
-#define TIP_OPT_FUSE_HEAD 5 /* 1 (default): with rnn_hidden 512 and 128 < size_s <= 132 the four-window cluster recurrence computes the
-                               output projection (:102) INSIDE its hop wait (rnn_head_kernel, csrc/tip_rnnh.hip): y_{t-1} is multiplied out
-                               between a member's store of its slice of h_t and the arrival of its partners' slices, the state travels
-                               through an L2-resident ring of {value, tag} granules in the workspace instead of HALL, and no projection
-                               kernel is launched.  Any batch size and window length, full and last-row output (bit-identical last rows).
-                               The recurrence's arithmetic is unchanged; the projection's summation order differs from the stand-alone
-                               kernels' (outputs agree to ~1e-6).  0: recurrence and projection as separate launches (rnn_rows4_kernel +
-                               head_ksplit_kernel), as until round 4.  Ignored on a demoted handle (a cooperating kernel). */
+#define TIP_OPT_FUSE_HEAD 5 /* RESERVED: accepted (0 / 1) and ignored.  Rounds 3-4: the output projection as the epilogue of the recurrence
+                               kernel (measured neutral, removed in round 5); round 5: the projection inside the recurrence's hop wait
+                               with an L2-ring hand-off (correct, measured slower than the separate kernels: CHANGELOG.md). */
 
 #define TIP_OPT_PACK_SPLIT16 6 /* which EXPLORATORY split-fp16 weight copies the packed image carries (default 0: none).  Bit 0
                                  (TIP_PACK_SPLIT16_FUSED): the fused section's, for TIP_PLAN_FUSED16 (+15 MB for the paper configuration);

@@ -25,7 +25,6 @@ TIP_API int tip_debug_read_head_wg(unsigned long long* out, int n);    /* output
 TIP_API int tip_debug_read_head_trace(unsigned long long* out, int n); /* output projection: tile stamps */
 TIP_API int tip_debug_read_lat1_trace(unsigned long long* out, int n); /* persistent latency kernel: [0] = count, then worker 0's stage / barrier stamps (tools/lat1_trace.py) */
 TIP_API int tip_debug_read_s16_trace(unsigned long long* out, int n);  /* split-fp16 encoder phase stamps (tools/s16_trace.py) */
-TIP_API int tip_debug_read_rnnh_trace(unsigned long long* out, int n); /* recurrence-with-projection kernel: 12 stamps per step of workgroup 0 (tools/rnnh_trace.py) */
 
 #ifdef __cplusplus
 }

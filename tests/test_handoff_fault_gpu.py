@@ -36,8 +36,7 @@ def _fault(m, bits):
 @pytest.mark.handoff_fault
 @pytest.mark.parametrize("plan,B,bits,hit,cluster", [
     ("fused2s", 64, 1, "pair0", 0),     # pair-split encoder: workgroup (pair 0, half 1) never arrives
-    ("fused", 40, 2, "tile0", 0),       # RNN clusters (AUTO: 4 workgroups per 4-window tile, projection inside: rnn_head_kernel): member 1 of cluster 0 never arrives
-    ("fused-head", 40, 2, "tile0", 0),  # the same with TIP_OPT_FUSE_HEAD = 0: rnn_rows4_kernel + the stand-alone projection
+    ("fused", 40, 2, "tile0", 0),       # RNN clusters (AUTO: 4 workgroups per 4-window tile): member 1 of cluster 0 never arrives
     ("fusedh", 40, 2, "tile0", 16),     # the 16-workgroup clusters on 16-window tiles (sentinel hand-off)
     ("general", 37, 2, "tile0", 0),     # AUTO through the general plan
     ("general", 37, 2, "tile0", 8),     # 8-workgroup clusters
@@ -48,9 +47,6 @@ def test_lost_handoff_poisons_and_raises(plan, B, bits, hit, cluster):
     if plan == "fused2s" and 2 * ((B + 1) // 2) > ncu:
         pytest.skip("needs every workgroup resident")
     m = _model()
-    if plan.endswith("-head"):
-        plan = plan[:-5]
-        m._ensure_handle().set_option(tlib.TIP_OPT_FUSE_HEAD, 0)
     m.set_plan(plan, rnn_cluster=cluster)
     x_imu, x_s = synth.make_inputs(synth.PAPER, B, 40, seed=5)
     xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()

@@ -189,12 +189,12 @@ def test_new_entry_points_check_their_arguments_without_a_gpu():
         h.forward_f64(ptrs, 8, 8, 8, 1, 40, 0, None, 1.0, 264, 1 << 30, 0)
     assert ei.value.status == -4
     # options
+    assert h.get_option(tlib.TIP_OPT_FUSE_HEAD) == 0   # reserved since round 5: accepted, without effect
+    h.set_option(tlib.TIP_OPT_FUSE_HEAD, 1)
     assert h.get_option(tlib.TIP_OPT_FUSE_HEAD) == 1
-    h.set_option(tlib.TIP_OPT_FUSE_HEAD, 0)
-    assert h.get_option(tlib.TIP_OPT_FUSE_HEAD) == 0
     with pytest.raises(tlib.TipStatusError):
         h.set_option(tlib.TIP_OPT_FUSE_HEAD, 2)
-    h.set_option(tlib.TIP_OPT_FUSE_HEAD, 1)
+    h.set_option(tlib.TIP_OPT_FUSE_HEAD, 0)
     # streaming: AUTO is -1, anything below is refused; zero streams is a no-op
     assert tlib.TIP_STREAM_FRAME_AUTO == -1
     assert lib.tip_stream_ingest(ctypes.c_void_p(8), ctypes.c_void_p(8), 0, -1, ctypes.c_void_p(8), ctypes.c_void_p(8), None) == 0

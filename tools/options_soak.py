@@ -1,9 +1,7 @@
 #!/usr/bin/env python3
-"""Race screen for the round-3 options that touch cooperating kernels: (a) TIP_OPT_FUSE_HEAD (output projection as the epilogue of
-the four-window recurrence: its last-row wait runs once per forward) — many forwards, every result compared bit for bit with the
-stand-alone projection's; (b) the streaming engine's HIP-graph mode — a long closed loop, graph engine vs launch-by-launch engine,
-every frame compared bit for bit; no hand-off time-out allowed anywhere.
-usage: python tools/options_soak.py [forwards per batch size = 2000] [frames = 3000]"""
+"""Race screen for the streaming engine's HIP-graph mode — a long closed loop, graph engine vs launch-by-launch engine, every frame
+compared bit for bit; no hand-off time-out allowed anywhere.  (Until round 4 also TIP_OPT_FUSE_HEAD, since removed.)
+usage: python tools/options_soak.py [unused] [frames = 3000]"""
 import contextlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,22 +18,6 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
 t0 = tlib.spin_timeouts()
 h = m._ensure_handle()
-for B in (65, 130, 200, 256):
-    x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=B)
-    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
-    with torch.no_grad():
-        h.set_option(tlib.TIP_OPT_FUSE_HEAD, 0)
-        ref = m(xi, xs).clone()
-        h.set_option(tlib.TIP_OPT_FUSE_HEAD, 1)
-        bad = 0
-        for i in range(iters):
-            if not torch.equal(m(xi, xs), ref):
-                bad += 1
-        torch.cuda.synchronize()
-    m.check_handoffs()
-    print(f"fuse_head B={B:4d}: {iters} forwards, {bad} differing from the stand-alone projection", flush=True)
-h.set_option(tlib.TIP_OPT_FUSE_HEAD, 0)
-
 from scipy.spatial.transform import Rotation
 for n in (1, 8, 64):
     rng = np.random.RandomState(n)

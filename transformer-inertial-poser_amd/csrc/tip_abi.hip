@@ -7,7 +7,6 @@
 
 #include <mutex>
 #include "tip_internal.h"
-#include "tip_rnnh.h"
 
 using namespace tip;
 
@@ -159,8 +158,6 @@ Workspace carve_workspace(const Dims& d, int B, int T) {
     // the whole (until round 4 the section was sized for B <= 1024, 168 MB at B = 1024, and absent above: a 1064-window batch
     // whose 1024-window part asked for more than the whole got TIP_ERR_WORKSPACE).
     w.xchg = take(fused2_supported(d, T) ? fused2s_xchg_floats(B < 256 ? B : 256) : 0);
-    // hand-off ring of the recurrence-with-projection kernel (tip_rnnh.hip): two 16-KB slots per four-window cluster in flight
-    w.ring = take(d.with_rnn ? rnnh_ring_bytes(B) / sizeof(float) : 0);
     w.total_bytes = off * sizeof(float);
     return w;
 }
@@ -315,7 +312,7 @@ int tip_create(const tip_config* cfg, tip_handle** out) {
     h->d = d;
     build_tensor_table(h);
     build_layout(h);
-    h->fuse_head = 1;   // TIP_OPT_FUSE_HEAD's default
+    h->fuse_head = 0;   // TIP_OPT_FUSE_HEAD: reserved (accepted, no effect)
     int dev = -1;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0) {
         h->device = dev;
@@ -688,11 +685,11 @@ int tip_profile_read(tip_handle* h, const char** names, float* ms, int* launches
 
 int tip_spin_timeouts(unsigned* count) {
     if (!count) return TIP_ERR_INVALID_ARG;
-    unsigned a = 0, b = 0, c = 0, e = 0;
+    unsigned a = 0, b = 0, c = 0;
     if (read_spin_timeouts_general(&a) != hipSuccess || read_spin_timeouts_latency(&b) != hipSuccess ||
-        read_spin_timeouts_fused2(&c) != hipSuccess || read_spin_timeouts_rnnh(&e) != hipSuccess)
+        read_spin_timeouts_fused2(&c) != hipSuccess)
         return TIP_ERR_HIP;
-    *count = a + b + c + e;
+    *count = a + b + c;
     return TIP_OK;
 }
 
@@ -830,12 +827,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         if (rows4 && d.R == 512) rnn_cluster = kRnnRows4;
     }
     bool head_done = false;
-    // TIP_OPT_FUSE_HEAD (default): the four-window cluster recurrence computes the output projection inside its hop wait and hands
-    // its state over through an L2-resident ring (tip_rnnh.hip) — no HALL traffic, no projection launch.  A cooperating kernel:
-    // never on a demoted handle.
-    const bool use_rnnh = d.with_rnn && h->fuse_head && !h->demoted && rnn_cluster == kRnnRows4 && rnnh_supported(d, T) &&
-                          plan != TIP_PLAN_LATENCY && plan != TIP_PLAN_LATENCY1;
-    auto arm_hall = [&]() { return !use_rnnh && rnn_uses_sentinel(d, B, T, rnn_cluster); };
+    auto arm_hall = [&]() { return rnn_uses_sentinel(d, B, T, rnn_cluster); };
     if (plan == TIP_PLAN_LATENCY1) {
         StageScope sc(h, s, "latency_chain");
         unsigned* sync = reinterpret_cast<unsigned*>(const_cast<float*>(P + L.sync_off));
@@ -948,13 +940,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         }
         {
             StageScope sc(h, s, "rnn_recurrence");
-            if (use_rnnh) {
-                TIP_TRY(launch_rnn_head(d, big, P + L.whh_frag_off, P + L.out_lin.w_off, P + L.out_lin.b_off, y, W0 + ws.ring, rflags, B, T,
-                                        last_only, false, cus, next_rnn_launch_tag(), gd, s), "rnn_recurrence");
-                head_done = true;
-            } else {
-                TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, rnn_cluster, cus, hall_armed, gd, s), "rnn_recurrence");
-            }
+            TIP_TRY(launch_rnn(d, big, P + L.whh_frag_off, hall, rflags, B, T, rnn_cluster, cus, hall_armed, gd, s), "rnn_recurrence");
         }
         head_in = hall;
         head_ld = d.R;

@@ -1280,33 +1280,6 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_rows4_kernel(const float* __re
                 else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), hrs, vout[n], so_out, 16);
             }
             if (TRACE && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 2] = __builtin_amdgcn_s_memtime();
-            if (abl & 48) {
-                // MEASUREMENT ONLY (round 5 probe): matrix work placed in the hop wait — 16: 64 MFMAs per wave with their B operand
-                // read from LDS (what the input projection of step t + 1 would cost there), 32: 32 MFMAs per wave on registers
-                // (the output projection of step t - 1).  Results are discarded.
-                f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0, d2 = d0, d3 = d0;
-                if (abl & 16) {
-                    const float* bp = smem + (lane * 4);
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const float4 bv = *reinterpret_cast<const float4*>(bp + (k & 7) * 256);
-                        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].x, bv.x, d0, 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].y, bv.y, d1, 0, 0, 0);
-                        d2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].z, bv.z, d2, 0, 0, 0);
-                        d3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].w, bv.w, d3, 0, 0, 0);
-                    }
-                }
-                if (abl & 32) {
-#pragma unroll
-                    for (int k = 16; k < 24; ++k) {
-                        d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].x, wreg[k].y, d0, 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].y, wreg[k].z, d1, 0, 0, 0);
-                        d2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].z, wreg[k].w, d2, 0, 0, 0);
-                        d3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[k].w, wreg[k].x, d3, 0, 0, 0);
-                    }
-                }
-                asm volatile("" :: "v"(d0), "v"(d1), "v"(d2), "v"(d3));
-            }
         }
         retire_touch();
         __syncthreads();   // the next batch's second step rewrites the buffer the last step of this one may still be reading

@@ -148,7 +148,7 @@ struct PackBatch {
 
 // Workspace carve-up for the general plan (float offsets), M = B*T rows.
 struct Workspace {
-    size_t xa, xb, big, att, hall, flags, lat, xchg, ring;  // float offsets
+    size_t xa, xb, big, att, hall, flags, lat, xchg;  // float offsets
     size_t total_bytes;
 };
 
