@@ -23,8 +23,10 @@
 extern "C" {
 #endif
 
-#define TIP_ABI_VERSION 2 /* 2: packed image without the exploratory split-fp16 section unless asked for (TIP_CREATE_S16, tip_create_ex);
-                             tip_max_batch; export list = this header (+ tip_hip_debug.h), everything else hidden */
+#define TIP_ABI_VERSION 3 /* 2: packed image without the exploratory split-fp16 section unless asked for (TIP_CREATE_S16, tip_create_ex);
+                             tip_max_batch; export list = this header (+ tip_hip_debug.h), everything else hidden
+                             3: tip_forward_dropout; plan 9 (persistent latency kernel) and its 1 KiB of sync words in the packed image
+                             removed; TIP_OPT_FUSE_HEAD reserved */
 
 /* The library is built with -fvisibility=hidden: the functions declared here (and the measurement hooks of
  * tip_hip_debug.h) are its whole dynamic symbol table (tests/test_host_cpu.py compares `nm -D` with the two headers). */
@@ -97,12 +99,8 @@ typedef enum tip_status {
                                in every partner; TIP_OPT_F1S_PARTS pins the form) — the two forms differ in summation order, each is
                                deterministic.  AUTO picks it for 32 < B <= #CUs / 2 at T = 40 and for remainders of 33-128 windows behind
                                whole rounds. */
-#define TIP_PLAN_LATENCY1 9 /* TIP_PLAN_LATENCY as ONE persistent kernel (B <= 8): the same stages separated by grid barriers instead of
-                               kernel boundaries, recurrence and output projection as its tail; bit-identical to TIP_PLAN_LATENCY.  32
-                               co-resident workgroups (one XCD).  Its hand-off flags live in the last 1 KiB of the packed weight image
-                               (zero after packing; the only part of the image a forward writes).  OPT-IN, never AUTO's choice: measured no
-                               faster than the launch chain (181-207 us against 176 at B = 1: the stage bodies, not the kernel boundaries,
-                               bound it); kept as the single-kernel, HIP-graph-replayable form of the few-stream forward. */
+/* plan value 9 is RESERVED (rounds 4: TIP_PLAN_LATENCY1, the latency chain as one persistent kernel — bit-identical, measured slower
+   than the launch chain at every batch size, removed in round 5): tip_set_option rejects it */
 
 #define TIP_OPT_PLAN        1
 #define TIP_OPT_PROFILE     2 /* 0 off; 1: bracket every stage with a HIP event pair; 2: only the dominant stage
@@ -178,6 +176,18 @@ TIP_API int tip_max_batch(const tip_handle* h, int T, int fp64, int* max_batch);
 TIP_API int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
                 const float* keep_mask, float keep_scale, void* workspace, size_t workspace_bytes,
                 tip_stream_t stream);
+
+/* The forward WITH the training step's encoder dropout and WITHOUT its activation stash: what a `.train()`-mode module computes when
+ * nobody differentiates it — the unedited reference runner (offline_testing_simple.py:98 never calls .eval();
+ * real_time_runner_minimal.py:149).  Few streams only: the configurations TIP_PLAN_LATENCY serves (paper configuration, B <= 64,
+ * T <= 40), on that plan's kernels with the four dropout sites of every encoder layer live; TIP_ERR_UNSUPPORTED_CONFIG otherwise
+ * (and on a demoted handle): the caller then takes tip_train_forward.  The keep decisions are tip_train_forward's for the same
+ * (p_drop, seed) — same hash, same element indices — so a later tip_train_forward(same arguments) + tip_train_backward differentiates
+ * exactly the function evaluated here (the Python module does that when .backward() is called after all).  Uses the ATTACHED packed
+ * image like tip_forward; flags / keep_mask / workspace as tip_forward. */
+TIP_API int tip_forward_dropout(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
+                        const float* keep_mask, float keep_scale, float p_drop, unsigned long long seed, void* workspace,
+                        size_t workspace_bytes, tip_stream_t stream);
 
 /* ---- forward in fp64: the module built under `--double` (train_model.py:62-63,84-85: torch.set_default_dtype(float64), fp64
  *      windows :161-164).  Same function as tip_forward (simple_transformer_with_state.py:60-102) with every operation in IEEE

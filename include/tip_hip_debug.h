@@ -23,7 +23,6 @@ TIP_API int tip_debug_read_rnn_trace(unsigned long long* out, int n);  /* cluste
 TIP_API int tip_debug_clock_probe(unsigned long long* dev_out, void* stream); /* s_memtime / s_memrealtime pair (bench.py: clock under load) */
 TIP_API int tip_debug_read_head_wg(unsigned long long* out, int n);    /* output projection: per-workgroup lifetimes (tools/head_trace.py) */
 TIP_API int tip_debug_read_head_trace(unsigned long long* out, int n); /* output projection: tile stamps */
-TIP_API int tip_debug_read_lat1_trace(unsigned long long* out, int n); /* persistent latency kernel: [0] = count, then worker 0's stage / barrier stamps (tools/lat1_trace.py) */
 TIP_API int tip_debug_read_s16_trace(unsigned long long* out, int n);  /* split-fp16 encoder phase stamps (tools/s16_trace.py) */
 
 #ifdef __cplusplus

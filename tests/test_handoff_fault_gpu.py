@@ -90,7 +90,7 @@ def test_lost_handoff_poisons_and_raises(plan, B, bits, hit, cluster):
 def test_training_step_reports_a_lost_handoff():
     """tip_train_forward shares the clustered RNN: a lost hand-off there poisons y and makes the next step raise."""
     m = _model().train()
-    x_imu, x_s = synth.make_inputs(synth.PAPER, 32, 40, seed=6)
+    x_imu, x_s = synth.make_inputs(synth.PAPER, 36, 40, seed=6)   # (> LAZY_STASH_MAX_BATCH: fewer windows take tip_forward_dropout)
     xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
     _fault(m, 2)
     y = m(xi, xs)

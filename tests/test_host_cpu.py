@@ -87,15 +87,15 @@ def test_c_abi_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(tip_[a-z0-9_]+)\s*\(", hdr)) - {"tip_stream_t"}
     assert declared == set(tlib.EXPORTS), declared ^ set(tlib.EXPORTS)
     dbg = set(re.findall(r"\b(tip_debug_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "tip_hip_debug.h")).read()))
-    assert len(dbg) == 13
+    assert len(dbg) == 12
     lib = ctypes.CDLL(tlib.LIB_PATH)
     for name in declared | dbg:
         assert hasattr(lib, name), name
     out = subprocess.run(["nm", "-D", "--defined-only", tlib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
     assert exported == declared | dbg, exported ^ (declared | dbg)
-    assert tlib.load().tip_abi_version() == tlib.TIP_ABI_VERSION == 2
-    assert int(re.search(r"#define TIP_ABI_VERSION (\d+)", hdr).group(1)) == 2
+    assert tlib.load().tip_abi_version() == tlib.TIP_ABI_VERSION == 3
+    assert int(re.search(r"#define TIP_ABI_VERSION (\d+)", hdr).group(1)) == 3
 
 
 def test_max_batch_and_pack_options_without_a_gpu():
@@ -259,13 +259,11 @@ def test_packed_image_split_fp16_section():
     plain = m.pack_host().numpy()
     m.set_plan("fused16")                               # TIP_OPT_PACK_SPLIT16 bit 0: the image now carries the split copy
     img = m.pack_host().numpy()
-    SYNC = 256                                          # the persistent latency kernel's flag words close every image (zero after packing)
-    assert img.size == plain.size + 3352320 * 4 and np.array_equal(img[:plain.size - SYNC * 4], plain[:-SYNC * 4])
-    assert not plain[-SYNC * 4:].any() and not img[-SYNC * 4:].any()
+    assert img.size == plain.size + 3352320 * 4 and np.array_equal(img[:plain.size], plain)
     f32 = img.view(np.float32)
     NF = 3352320                                        # fused_packed_floats of the paper configuration (64-float aligned)
-    assert f32.size >= 2 * NF + SYNC
-    fused, s16 = f32[-(2 * NF + SYNC):-(NF + SYNC)], f32[-(NF + SYNC):-SYNC].view(np.float16)
+    assert f32.size >= 2 * NF
+    fused, s16 = f32[-(2 * NF):-NF], f32[-NF:].view(np.float16)   # (ABI 3: nothing behind the split copy any more)
     LAYER0, LAYER_FLOATS = 57600, 789760
     W1_W = 3 * 256 * 256 + 3 * 256 + 256 * 256 + 256
     for (off, N, K) in ((0, 256, 224), (LAYER0, 768, 256), (LAYER0 + 2 * LAYER_FLOATS + W1_W, 1024, 256),

@@ -372,3 +372,49 @@ def test_training_step_over_a_batch_sweep():
             ye = m(torch.tensor(xi).cuda(), torch.tensor(xs).cuda()).cpu().numpy()
         m.train()
         assert np.abs(y - ye).max() < 5e-6, (B, np.abs(y - ye).max())
+
+
+@pytest.mark.parametrize("B,T", [(1, 40), (1, 1), (1, 7), (3, 40), (8, 33), (32, 40)])
+def test_few_window_train_mode_forward_runs_without_a_stash(B, T):
+    """The unedited runner's call (real_time_runner_minimal.py:149 on a module that never left .train() mode,
+    offline_testing_simple.py:98): up to LAZY_STASH_MAX_BATCH windows go through tip_forward_dropout — the few-stream kernels
+    with the four dropout sites live and NO activation stash.  Same keep decisions as tip_train_forward for the same seed (a
+    single differing decision would show as an O(0.1) difference), and a .backward() after all produces the stash then: gradients
+    bit-identical to the stash path's."""
+    cfg = synth.PAPER
+    m = make_model(cfg, p_state=0.8)
+    load_synth(m, cfg, 0)
+    m = m.cuda().train()
+    m.ENCODER_DROPOUT = 0.1
+    x_imu, x_s = synth.make_inputs(cfg, B, T, seed=77 + B + T, nan_frac=0.02)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    cot = torch.randn(B, T, cfg["size_s"], generator=torch.Generator().manual_seed(3)).cuda()
+
+    def run(lazy_max):
+        m.LAZY_STASH_MAX_BATCH = lazy_max
+        torch.manual_seed(1234)                      # the keep mask (device generator) and the dropout seed (CPU generator)
+        m.zero_grad(set_to_none=True)
+        n0 = m.hip_forward_count()
+        y = m(xi, xs)
+        nf = m.hip_forward_count() - n0
+        assert type(y.grad_fn).__name__.startswith("_HipTrainFunction")
+        lazy = y.grad_fn.lazy_inputs is not None
+        (y * cot).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach().cpu().numpy(), {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters()}, lazy, nf
+
+    y_fast, g_fast, lazy_fast, nf = run(32)
+    y_stash, g_stash, lazy_stash, _ = run(0)
+    assert lazy_fast and not lazy_stash and nf == 1
+    assert np.isfinite(y_fast).all()
+    # same function, same dropout decisions, other kernels (summation order): 1e-5 (a flipped decision moves outputs by >= 1e-2)
+    assert np.abs(y_fast - y_stash).max() < 2e-5, np.abs(y_fast - y_stash).max()
+    for n in g_stash:
+        assert np.array_equal(g_fast[n], g_stash[n]), n
+    # dropout really is live: two calls with different seeds differ
+    torch.manual_seed(99)
+    m.LAZY_STASH_MAX_BATCH = 32
+    with torch.no_grad():
+        y2 = m(xi, xs).cpu().numpy()
+    assert np.abs(y2 - y_fast).max() > 1e-3
+    m.check_handoffs()

@@ -92,8 +92,6 @@ t=$(find $d -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python tools/ks
 timeout 300 python bench.py --plan fused16 --no-cpu-baseline --no-extra --steps 300 --warmup 20 > "$OUT/bench_fused16_n1.json" 2> /dev/null
 # round 4: AUTO over a batch sweep against the round-3 selection (remainder split, window-split plan), the persistent latency kernel
 { echo "AUTO (round 4)"; timeout 300 python tools/auto_sweep.py 2> /dev/null; echo "round-3 selection (TIP_PLAN_BASE=1)"; TIP_PLAN_BASE=1 timeout 300 python tools/auto_sweep.py 2> /dev/null; } > "$OUT/auto_sweep.txt"
-timeout 300 python tools/lat1_bench.py 2> /dev/null | grep "^B=" > "$OUT/lat1_bench.txt"
-TIP_LAT1_TRACE=1 timeout 120 python tools/lat1_trace.py 1 2> /dev/null | grep -v "^model\|^number" > "$OUT/lat1_trace_B1.txt"
 timeout 300 python tools/f1s_bench.py 2> /dev/null | grep "^B=\|fused1s vs" > "$OUT/f1s_bench.txt"
 timeout 300 python tools/f1s_parts.py 2> /dev/null | grep "^B=" > "$OUT/f1s_parts.txt"
 { echo "8-wave members"; TIP_RNN_W4=0 timeout 200 python tools/rnn_ab.py 2> /dev/null | grep "^B="; echo "4-wave members (TIP_RNN_W4=1)"; TIP_RNN_W4=1 timeout 200 python tools/rnn_ab.py 2> /dev/null | grep "^B="; } > "$OUT/rnn_w4.txt"

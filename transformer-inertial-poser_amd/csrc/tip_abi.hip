@@ -87,7 +87,6 @@ void build_layout(tip_handle* h) {
     // exploratory TIP_PLAN_FUSED16: split-fp16 copy of the fused section, only on request (TIP_OPT_PACK_SPLIT16)
     L.s16_floats = (h->pack_split16 & TIP_PACK_SPLIT16_FUSED) ? s16_packed_floats(d) : 0;
     L.s16_off = L.s16_floats ? c.take(L.s16_floats) : 0;
-    L.sync_off = c.take(kLat1SyncWords);
     L.total_floats = c.off;
 }
 
@@ -356,7 +355,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
     if (!h) return TIP_ERR_INVALID_ARG;
     switch (option) {
         case TIP_OPT_PLAN:
-            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED1S) return TIP_ERR_INVALID_ARG;
+            if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED1S || value == 9 /* reserved */) return TIP_ERR_INVALID_ARG;
             h->plan = value;
             return TIP_OK;
         case TIP_OPT_PROFILE:
@@ -407,7 +406,6 @@ int tip_check(tip_handle* h, int clear) {
     if (!h->err_host) return TIP_OK;
     const unsigned v = *const_cast<volatile unsigned*>(h->err_host);
     if (clear) *const_cast<volatile unsigned*>(h->err_host) = 0u;
-    if (v) h->sync_dirty = 1;   // the persistent kernel's flag words may have been left mid-protocol
     return v ? TIP_ERR_HANDOFF : TIP_OK;
 }
 
@@ -775,15 +773,11 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     int plan = h->plan;
     if (plan == TIP_PLAN_AUTO) {
         // (a demoted handle — TIP_OPT_DEMOTED, after a lost hand-off — takes no cooperating kernel: the latency plan's GEMV recurrence is one)
-        // (TIP_PLAN_LATENCY1, the same chain as one persistent kernel, is opt-in: measured 181-207 us against the chain's 176 at B = 1 —
-        // the stage bodies, not the kernel boundaries, bound the chain; CHANGELOG.md, round 4.  TIP_LAT1=1 makes AUTO take it: measurement.)
-        static const bool lat1 = getenv("TIP_LAT1") && getenv("TIP_LAT1")[0] == '1';
         // few streams: the latency plan up to 32 windows (0.17-0.28 ms), then ONE window on FOUR CUs up to #CUs / 4 windows (0.30 ms
         // per step; the latency plan takes 0.36 ms for 40 windows) and on TWO up to #CUs / 2 (0.45 ms against 0.60 for one window
         // per CU) — the window-split encoder, T = 40 only; the latency plan again where that does not apply (<= 64 shorter windows)
         const bool f1s4 = fused2_supported(d, T) && h->f1s_parts != 2 && fused1s_quad_fits(B, cus);
-        if (!h->demoted && lat1 && cus == h->num_cus && latency1_supported(d, B, T)) plan = TIP_PLAN_LATENCY1;
-        else if (!h->demoted && B <= (f1s4 ? 32 : 48) && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;
+        if (!h->demoted && B <= (f1s4 ? 32 : 48) && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;
         else if (!h->demoted && fused2_supported(d, T) && fused1s_fits(B, cus)) plan = TIP_PLAN_FUSED1S;
         else if (!h->demoted && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;   // <= 64 streams: spread each window over many CUs
         else plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
@@ -804,7 +798,6 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     if (plan == TIP_PLAN_FUSED1S && !(fused2_supported(d, T) && fused1s_fits(B, cus) && (h->f1s_parts != 4 || fused1s_quad_fits(B, cus))))
         return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
-    if (plan == TIP_PLAN_LATENCY1 && !latency1_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED16 && !(s16_supported(d, T) && L.s16_floats)) return TIP_ERR_UNSUPPORTED_CONFIG;
 
     const bool g16 = plan == TIP_PLAN_GENERAL16;   // exploratory: the general plan with split-fp16 panel GEMMs
@@ -828,19 +821,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     }
     bool head_done = false;
     auto arm_hall = [&]() { return rnn_uses_sentinel(d, B, T, rnn_cluster); };
-    if (plan == TIP_PLAN_LATENCY1) {
-        StageScope sc(h, s, "latency_chain");
-        unsigned* sync = reinterpret_cast<unsigned*>(const_cast<float*>(P + L.sync_off));
-        if (h->sync_dirty) {   // a hand-off failed earlier: the flag words may have been left mid-protocol
-            TIP_TRY(hipMemsetAsync(sync, 0, kLat1SyncWords * sizeof(unsigned), s), "latency1 sync reset");
-            h->sync_dirty = 0;
-        }
-        TIP_TRY(launch_latency1_plan(d, P + L.fused_off, P + L.whh_frag_off, P + L.out_frag_off, P + L.out_lin.b_off, x_imu, x_s, mask,
-                                     keep_scale, W0, ws.total_bytes, ws.lat, ws.hall, sync, y, (flags & TIP_FWD_LAST_ROW_ONLY) != 0, B, T,
-                                     cus, gd, s), "latency1");
-        rnn_done = true;
-        head_done = true;
-    } else if (plan == TIP_PLAN_LATENCY) {
+    if (plan == TIP_PLAN_LATENCY) {
         StageScope sc(h, s, "latency_chain");
         TIP_TRY(launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall,
                                     B, T, cus, gd, s), "latency_chain");
@@ -967,6 +948,51 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         }
     }
 #undef TIP_TRY
+    h->forward_count++;
+    return TIP_OK;
+}
+
+int tip_forward_dropout(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
+                        const float* keep_mask, float keep_scale, float p_drop, unsigned long long seed, void* workspace,
+                        size_t workspace_bytes, tip_stream_t stream) {
+    if (!h || !x_imu || !x_s || !y || B < 0 || T < 1) return TIP_ERR_INVALID_ARG;
+    if (p_drop < 0.f || p_drop >= 1.f) return TIP_ERR_INVALID_ARG;
+    if ((flags & TIP_FWD_KEEP_MASK) && !keep_mask) return TIP_ERR_INVALID_ARG;
+    if (!h->packed_dev) return TIP_ERR_NOT_READY;
+    if (tip_check(h, 0) != TIP_OK) return TIP_ERR_HANDOFF;
+    if (B == 0) return TIP_OK;
+    const Dims& d = h->d;
+    // the few-stream latency plan is the only one with the dropout sites; a demoted handle takes no cooperating kernel (its GEMV
+    // recurrence is one): the caller falls back to tip_train_forward
+    if (h->demoted || !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    const Workspace ws = carve_workspace(d, B, T);
+    if (!workspace || reinterpret_cast<uintptr_t>(workspace) % 256 || workspace_bytes < ws.total_bytes) return TIP_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int cus = effective_cus(h->num_cus, s);
+    CoopSerial serial(h->device, s);
+    if (serial.status != hipSuccess) return fail_hip(h, serial.status, "stream serialisation");
+    const float* P = h->packed_dev;
+    const PackedLayout& L = h->lay;
+    float* W0 = static_cast<float*>(workspace);
+    float* hall = W0 + ws.hall;
+    const float* mask = (flags & TIP_FWD_KEEP_MASK) ? keep_mask : nullptr;
+    if (!mask) keep_scale = 1.f;
+    const TrainDropout td = make_train_dropout(p_drop, seed);
+    hipError_t e;
+    {
+        StageScope sc(h, s, "latency_chain");
+        e = launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall, B, T, cus,
+                                h->guard(), s, &td);
+        if (e != hipSuccess) return fail_hip(h, e, "latency_chain");
+    }
+    {
+        StageScope sc(h, s, "out_linear");
+        const bool last_only = (flags & TIP_FWD_LAST_ROW_ONLY) != 0;
+        const float* hA = last_only ? hall + (size_t)(T - 1) * d.R : hall;
+        const long long hlda = last_only ? (long long)T * d.R : d.R;
+        e = launch_latency_head(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, last_only ? B : B * T, d.S, s);
+        if (e != hipSuccess) return fail_hip(h, e, "out_linear");
+    }
     h->forward_count++;
     return TIP_OK;
 }

@@ -17,8 +17,12 @@ typedef float f32x4_att __attribute__((ext_vector_type(4)));
 //                1/rowsum of its queries by shuffle from the lanes that own them.
 // Q/K planes hold the head at column c0; output overwrites the head's Q columns (out-projection A operand); rows at or
 // beyond row_limit are not written (the two-window kernel packs another window's rows right behind).
-template <int LDC, int LDV>
-__device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const float* Vt, int c0, int lane, int row_limit = 48) {
+// DROP (the training step's dropout on the probabilities, as attention_head_regs<.., TRAIN> below): keep = hash(dkey, (bh * T + query) *
+// T + key) >= thresh, kept probabilities times dscale; thresh 0 = off.
+template <int LDC, int LDV, bool DROP = false>
+__device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const float* Vt, int c0, int lane, int row_limit = 48,
+                                                    unsigned dkey = 0, unsigned thresh = 0, float dscale = 1.f,
+                                                    unsigned long long bh = 0, int T = 0) {
     constexpr int RB = 3;   // 48 padded rows
     const int l15 = lane & 15, lg = lane >> 4;
     float4 qf[RB], kf[RB];
@@ -76,6 +80,17 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
     for (int r = 0; r < RB; ++r) rsum[r] = lg4_sum(rsum[r]);
 #pragma unroll
     for (int r = 0; r < RB; ++r) rsum[r] = 1.0f / rsum[r];
+    if (DROP && thresh) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const unsigned pb = (unsigned)((bh * T + (r * 16 + l15)) * T);
+#pragma unroll
+            for (int cb = 0; cb <= r; ++cb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    S[r][cb][e] = tip_drop_hash_k(dkey, pb + cb * 16 + lg * 4 + e) >= thresh ? S[r][cb][e] * dscale : 0.f;
+        }
+    }
     // P V per query block: A = P tiles from registers, B = V^T fragments
 #pragma unroll
     for (int r = 0; r < RB; ++r) {

@@ -119,9 +119,6 @@ struct PackedLayout {
     // split-fp16 copy of the fused section's weight matrices (tip_s16.hip, TIP_PLAN_FUSED16): same float offsets, hi | lo halfs
     size_t s16_off = 0;
     size_t s16_floats = 0;
-    // 256 words of hand-off flags the persistent latency kernel owns (tip_latency.hip, lat1_kernel): zero after packing, written only
-    // by that kernel — the one part of the image that is not read-only
-    size_t sync_off = 0;
     size_t total_floats;
 };
 
@@ -279,7 +276,6 @@ struct tip_handle {
     int pack_split16 = 0;           // TIP_OPT_PACK_SPLIT16: which exploratory split-fp16 sections the packed image carries
     int auto_demote = 1;            // TIP_OPT_AUTO_DEMOTE
     int f1s_parts = 0;              // TIP_OPT_F1S_PARTS: 0 = auto, 2, 4
-    int sync_dirty = 0;             // a hand-off failed since the sync words of the packed image were last known clean: re-zero them before the next persistent launch
     int demoted = 0;                // TIP_OPT_DEMOTED: set by tip_demote after a lost hand-off: AUTO then avoids every cooperating kernel
     tip::Guard guard() const { return tip::Guard{err_dev, fault_inject}; }
 };
@@ -433,24 +429,22 @@ hipError_t launch_fused_encoder_s16(const Dims& d, const float* fused_w, const f
 // ---- latency plan (tip_latency.hip): one window spread over many CUs, for few concurrent streams ----
 bool latency_supported(const Dims& d, int B, int T);
 size_t latency_workspace_floats(int B, int T);
+// td (nullable): the training step's encoder dropout (tip_forward_dropout) — seed / thresh / scale as make_drop (tip_train.hip) derives them
+struct TrainDropout {
+    unsigned long long seed;
+    unsigned thresh;
+    float scale;
+};
+TrainDropout make_train_dropout(float p, unsigned long long seed);
 hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float* whh_frag, const float* x_imu,
                                const float* x_s, const float* keep_mask, float keep_scale, float* ws, float* hall, int B,
-                               int T, int num_cus, const Guard& gd, hipStream_t s);
+                               int T, int num_cus, const Guard& gd, hipStream_t s, const TrainDropout* td = nullptr);
 
 hipError_t launch_latency_head(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy,
                                int M, int N, hipStream_t s);
 
 hipError_t read_spin_timeouts_general(unsigned* out);
 hipError_t read_spin_timeouts_latency(unsigned* out);
-// the same chain as ONE persistent kernel (B <= 8): grid barriers instead of kernel boundaries, recurrence and output projection
-// as its tail.  ws_base / ws_bytes: the forward's whole workspace (one buffer descriptor); lat_off / hall_off: float offsets of the
-// latency buffers and of HALL inside it; sync: 256 zero-initialised words the kernel owns (PackedLayout::sync_off)
-constexpr int kLat1SyncWords = 256;
-bool latency1_supported(const Dims& d, int B, int T);
-hipError_t launch_latency1_plan(const Dims& d, const float* fused_w, const float* whh_frag, const float* out_frag, const float* out_bias,
-                                const float* x_imu, const float* x_s, const float* keep_mask, float keep_scale, float* ws_base,
-                                size_t ws_bytes, size_t lat_off, size_t hall_off, unsigned* sync, float* y, bool last_only, int B, int T,
-                                int num_cus, const Guard& gd, hipStream_t s);
 hipError_t read_spin_timeouts_fused2(unsigned* out);
 
 // ---- two-window fused encoder (tip_fused2.hip): 80 rows = 5 MFMA row blocks, no padding; for >= 2 windows per CU ----

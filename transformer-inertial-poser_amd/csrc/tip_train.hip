@@ -56,6 +56,12 @@ static Drop make_drop(float p, unsigned long long seed, unsigned site) {
     return d;
 }
 
+// the encoder dropout of a step as the other translation units see it (tip_forward_dropout: the same thresh / scale as the kernels here)
+TrainDropout make_train_dropout(float p, unsigned long long seed) {
+    const Drop d = make_drop(p, seed, 0);
+    return TrainDropout{seed, d.thresh, d.scale};
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // tgemm: C[i][j] = epi( sum_k A(i,k) * B(j,k) ),  128x128x16 block tile, 32x32x2 fp32 MFMA, 4 waves as 2x2.
 //   operand mode 0: element (r,k) at P[r*ld + k]  (k contiguous: activations, weights as stored)

@@ -15,7 +15,6 @@ TIP_FWD_LAST_ROW_ONLY = 0x1
 TIP_FWD_KEEP_MASK = 0x2
 TIP_PLAN_AUTO, TIP_PLAN_GENERAL, TIP_PLAN_FUSED, TIP_PLAN_LATENCY, TIP_PLAN_FUSED2, TIP_PLAN_FUSED2S, TIP_PLAN_FUSEDH = 0, 1, 2, 3, 4, 5, 6
 TIP_PLAN_FUSED1S = 10   # one window on two co-resident workgroups (64 < B <= 128)
-TIP_PLAN_LATENCY1 = 9   # the latency plan as one persistent kernel (B <= 8)
 TIP_PLAN_GENERAL16 = 8  # exploratory: general plan with split-fp16 panel GEMMs (needs TIP_OPT_PACK_SPLIT16 bit 1 before packing)
 TIP_PLAN_FUSED16 = 7   # exploratory: fp32 operands emulated as split fp16 on the f16 matrix cores (csrc/tip_s16.hip); opt-in only
 TIP_SAVED_QKV, TIP_SAVED_ATT, TIP_SAVED_X1, TIP_SAVED_HID, TIP_SAVED_XOUT, TIP_SAVED_HALL = range(6)
@@ -23,16 +22,17 @@ TIP_STREAM_FRAME_AUTO = -1   # tip_stream_ingest / tip_stream_consume: continue 
 TIP_OPT_PLAN, TIP_OPT_PROFILE, TIP_OPT_RNN_CLUSTER, TIP_OPT_FAULT_INJECT, TIP_OPT_FUSE_HEAD = 1, 2, 3, 4, 5
 TIP_OPT_PACK_SPLIT16, TIP_OPT_AUTO_DEMOTE, TIP_OPT_DEMOTED, TIP_OPT_F1S_PARTS = 6, 7, 8, 9
 TIP_PACK_SPLIT16_FUSED, TIP_PACK_SPLIT16_GENERAL = 1, 2
-TIP_ABI_VERSION = 2
+TIP_ABI_VERSION = 3
 TIP_RNN_CLUSTER_ROWS4 = 0x44   # TIP_OPT_RNN_CLUSTER value: 4-window tiles on 4-workgroup clusters (AUTO's choice for rnn_hidden 512)
 TIP_ERR_HANDOFF = -8
+TIP_ERR_UNSUPPORTED_CONFIG = -2
 TIP_LOSS_Q, TIP_LOSS_C, TIP_LOSS_J, TIP_LOSS_STATS = 1, 2, 4, 16
 
 # every symbol include/tip_hip.h declares (tests check that the .so exports exactly these + the hooks of tip_hip_debug.h)
 EXPORTS = (
     "tip_abi_version", "tip_create", "tip_destroy", "tip_strerror", "tip_last_hip_error", "tip_set_option",
     "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
-    "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_max_batch", "tip_forward", "tip_forward_f64_bytes", "tip_forward_f64", "tip_forward_count", "tip_profile_read",
+    "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_max_batch", "tip_forward", "tip_forward_dropout", "tip_forward_f64_bytes", "tip_forward_f64", "tip_forward_count", "tip_profile_read",
     "tip_spin_timeouts", "tip_check", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
     "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward",
     "tip_train_bytes_f64", "tip_train_forward_f64", "tip_train_backward_f64",
@@ -111,6 +111,7 @@ def load() -> ctypes.CDLL:
     lib.tip_workspace_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
     lib.tip_max_batch.argtypes = [vp, i32, i32, ctypes.POINTER(i32)]
     lib.tip_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, ctypes.c_float, vp, sz, vp]
+    lib.tip_forward_dropout.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, vp, sz, vp]
     lib.tip_forward_f64_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
     lib.tip_forward_f64.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, vp, i32, i32, i32, vp, ctypes.c_double, vp, sz, vp]
     lib.tip_forward_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
@@ -225,6 +226,12 @@ class Handle:
                 keep_scale: float, workspace: int, workspace_bytes: int, stream: int):
         self._check(self.lib.tip_forward(self._h, x_imu, x_s, y, B, T, flags, keep_mask, keep_scale, workspace,
                                          workspace_bytes, stream))
+
+    def forward_dropout(self, x_imu: int, x_s: int, y: int, B: int, T: int, flags: int, keep_mask: Optional[int], keep_scale: float,
+                        p_drop: float, seed: int, workspace: int, workspace_bytes: int, stream: int):
+        """tip_forward_dropout: the few-stream forward with the training step's encoder dropout and no activation stash."""
+        self._check(self.lib.tip_forward_dropout(self._h, x_imu, x_s, y, B, T, flags, keep_mask, keep_scale, p_drop, seed, workspace,
+                                                 workspace_bytes, stream))
 
     # -- training step (train_model.py:171-196) -------------------------------------------------------
     def train_bytes(self, B: int, T: int, fp64: bool = False) -> Tuple[int, int]:

@@ -126,6 +126,9 @@ class TF_RNN_Past_State(nn.Module):
         self.last_train_stash = None
         self.demotions = 0               # times a lost hand-off switched the handle to the non-cooperating plans (_forward_hip)
         self.t_max = 80                  # sizing hint handed to the handle; any window length is served (general plan beyond T = 40)
+        self._plist_cache = None         # list(self.parameters()): nn.Module.parameters() walks the module tree on every call (~0.6 us per
+                                         # parameter and call site; the forward asks several times per frame), see _plist()
+        self._train_ok_cache = {}
 
     # ------------------------------------------------------------------------------------------
     # initialisation: same distributions torch's nn.Linear / nn.MultiheadAttention / nn.LayerNorm / nn.RNN use
@@ -182,9 +185,23 @@ class TF_RNN_Past_State(nn.Module):
     def workspace_bytes(self, B: int, T: int) -> int:
         return self._ensure_handle().workspace_bytes(int(B), int(T))
 
+    def _plist(self):
+        """The module's parameters as a cached list (state-dict order).  Parameters are created in the constructor only; conversions
+        (.cuda(), .double(), ...) go through _apply, which drops the cache."""
+        pl = self._plist_cache
+        if pl is None:
+            pl = self._plist_cache = list(self.parameters())
+        return pl
+
+    def _apply(self, fn, *args, **kwargs):
+        self._plist_cache = None
+        self._train_ok_cache = {}
+        return super()._apply(fn, *args, **kwargs)
+
     def _dispatch(self, x_imu, x_s, last_row_only: bool):
+        plist = self._plist()
         needs_grad = torch.is_grad_enabled() and (x_imu.requires_grad or x_s.requires_grad or
-                                                  any(p.requires_grad for p in self.parameters()))
+                                                  any([p.requires_grad for p in plist]))
         # .train() mode draws the encoder's dropout whether or not autograd records (nn.TransformerEncoderLayer p = 0.1): with
         # gradients wanted, or with dropout to apply, the call goes to the training kernels; .train() + no_grad + p = 0 is the
         # same function as .eval() and takes the inference kernels below
@@ -198,7 +215,7 @@ class TF_RNN_Past_State(nn.Module):
             xi = F.dropout(x_imu, self.in_dropout, training=True) if self.in_dropout > 0.0 else x_imu   # :73
             mask = self._draw_keep_mask(x_s)                                                            # :77
             seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())     # CPU generator: no device sync
-            y = _HipTrainFunction.apply(self, xi, x_s, mask, float(self.ENCODER_DROPOUT), seed, *self.parameters())
+            y = _HipTrainFunction.apply(self, xi, x_s, mask, float(self.ENCODER_DROPOUT), seed, *plist)
             return y[:, -1] if last_row_only else y
         if (needs_grad and (self.training or not x_imu.is_cuda)) or (self.training and self.ENCODER_DROPOUT > 0.0 and x_imu.is_cuda):
             # not covered by the HIP training step: the torch-op composite, with the encoder dropout .train() implies
@@ -215,7 +232,27 @@ class TF_RNN_Past_State(nn.Module):
         # eval mode, autograd on: HIP forward, torch-op recompute in backward
         xi = F.dropout(x_imu, self.in_dropout, training=True) if self.in_dropout > 0.0 else x_imu   # :73
         mask = self._draw_keep_mask(x_s)
-        return _HipForwardTorchBackward.apply(self, last_row_only, xi, x_s, mask, *self.parameters())
+        return _HipForwardTorchBackward.apply(self, last_row_only, xi, x_s, mask, *plist)
+
+    LAZY_STASH_MAX_BATCH = 32   # .train()-mode calls of up to this many windows run without an activation stash (see _HipTrainFunction)
+
+    def _forward_dropout_hip(self, h, xi, xs, y, B, T, mask_ptr, scale, p_drop, seed, stream) -> bool:
+        """tip_forward_dropout into `y`; False when the library does not serve this call that way (configuration, window length,
+        demoted handle): the caller then runs tip_train_forward."""
+        dev = xi.device
+        if self._packed_dev is None or self._packed_dev.device != dev or (not self._frozen and self._packed_key != self._param_key(dev)):
+            self.refresh_packed(dev)
+        try:
+            ws = self._stream_buffer(self._workspace, dev, stream, h.workspace_bytes(B, T))
+            h.forward_dropout(xi.data_ptr(), xs.data_ptr(), y.data_ptr(), B, T, _lib.TIP_FWD_KEEP_MASK if mask_ptr else 0, mask_ptr,
+                              scale, p_drop, seed, ws.data_ptr(), ws.numel(), stream)
+        except _lib.TipHandoffError:
+            raise
+        except _lib.TipStatusError as e:
+            if e.status == _lib.TIP_ERR_UNSUPPORTED_CONFIG:
+                return False
+            raise
+        return True
 
     def _hip_train_ok(self, x_imu, x_s) -> bool:
         """True when the HIP training step (libtip_hip tip_train_*, or tip_train_*_f64 for a module built under --double) covers
@@ -230,13 +267,21 @@ class TF_RNN_Past_State(nn.Module):
             return False
         if x_imu.dim() != 3 or x_s.dim() != 3 or x_imu.shape[:2] != x_s.shape[:2]:
             return False
-        if any(p.dtype != pdt or not p.is_cuda for p in self.parameters()):
+        plist = self._plist()
+        if any([p.dtype != pdt or not p.is_cuda for p in plist]):
             return False
-        try:
-            self._ensure_handle().train_bytes(int(x_imu.shape[0]), int(x_imu.shape[1]), fp64=pdt == torch.float64)
-        except _lib.TipStatusError:
-            return False
-        return True
+        key = (int(x_imu.shape[0]), int(x_imu.shape[1]), pdt)
+        ok = self._train_ok_cache.get(key)
+        if ok is None:
+            try:
+                self._ensure_handle().train_bytes(key[0], key[1], fp64=pdt == torch.float64)
+                ok = True
+            except _lib.TipStatusError:
+                ok = False
+            if len(self._train_ok_cache) > 256:
+                self._train_ok_cache.clear()
+            self._train_ok_cache[key] = ok
+        return ok
 
     def train_activation(self, what: int, layer: int = 0) -> torch.Tensor:
         """One stashed activation of the last HIP training forward (needs keep_train_stash = True): `what` is one of
@@ -266,7 +311,8 @@ class TF_RNN_Past_State(nn.Module):
         return self._handle
 
     def _param_key(self, device):
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        plist = self._plist()
+        return (str(device), [p.data_ptr() for p in plist], [p._version for p in plist])
 
     def pack_host(self) -> torch.Tensor:
         """Build the packed weight image (uint8 CPU tensor) from the current parameters."""
@@ -298,7 +344,7 @@ class TF_RNN_Past_State(nn.Module):
 
     def refresh_packed(self, device=None):
         device = torch.device(device) if device is not None else next(self.parameters()).device
-        if device.type == "cuda" and all(p.is_cuda for p in self.parameters()):
+        if device.type == "cuda" and all([p.is_cuda for p in self._plist()]):
             self.attach_packed(self.pack_device(device))          # parameters already live on the GPU: pack there
         else:
             self.attach_packed(self.pack_host().to(device, non_blocking=False))
@@ -321,7 +367,7 @@ class TF_RNN_Past_State(nn.Module):
             self._packed_dev, self._packed_key = None, None
         # "fused1s": one window on four workgroups while 4 B <= #CUs, on two otherwise; "fused1s2" / "fused1s4" pin the form
         h.set_option(_lib.TIP_OPT_F1S_PARTS, {"fused1s2": 2, "fused1s4": 4}.get(plan, 0))
-        h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fused2s": 5, "fusedh": 6, "fused16": 7, "general16": 8, "latency1": 9, "fused1s": 10, "fused1s2": 10, "fused1s4": 10}[plan])
+        h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fused2s": 5, "fusedh": 6, "fused16": 7, "general16": 8, "fused1s": 10, "fused1s2": 10, "fused1s4": 10}[plan])
         h.set_option(_lib.TIP_OPT_RNN_CLUSTER, int(rnn_cluster))
         h.set_option(_lib.TIP_OPT_PROFILE, int(profile))
 
@@ -533,20 +579,29 @@ class _HipTrainFunction(torch.autograd.Function):
         pdt = x_imu.dtype                                  # fp32, or fp64 for a module built under --double (_hip_train_ok: no mixes)
         f64 = pdt == torch.float64
         with torch.cuda.device(dev):
-            saved_bytes, _ = h.train_bytes(B, T, fp64=f64)
-            saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
             xi, xs = x_imu.contiguous(), x_s.contiguous()
-            pc = [p.detach().contiguous() for p in params]
             mask_ptr, scale = None, 1.0
             if mask is not None:
                 pd = module.past_state_dropout
                 mask = mask.to(pdt).contiguous()
                 mask_ptr, scale = mask.data_ptr(), (1.0 / (1.0 - pd) if pd < 1.0 else 0.0)
             y = torch.empty((B, T, module.size_s), dtype=pdt, device=dev)
-            h.train_forward([p.data_ptr() for p in pc], xi.data_ptr(), xs.data_ptr(), mask_ptr, scale, p_drop, seed,
-                            y.data_ptr(), saved.data_ptr(), saved.numel(), B, T, torch.cuda.current_stream(dev).cuda_stream, fp64=f64)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            saved = None
+            # A few windows (the unedited runner's B = 1 call, real_time_runner_minimal.py:149, on a module that never left .train()
+            # mode): the same function on the few-stream kernels (tip_forward_dropout: same dropout decisions, no activation stash,
+            # ~0.2 ms instead of ~0.8 at one window per CU).  If .backward() is called after all, the stash is produced then.
+            lazy = (not f64 and B <= module.LAZY_STASH_MAX_BATCH and not module.keep_train_stash
+                    and module._forward_dropout_hip(h, xi, xs, y, B, T, mask_ptr, scale, p_drop, seed, stream))
+            if not lazy:
+                saved_bytes, _ = h.train_bytes(B, T, fp64=f64)
+                saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+                pc = [p.detach().contiguous() for p in params]
+                h.train_forward([p.data_ptr() for p in pc], xi.data_ptr(), xs.data_ptr(), mask_ptr, scale, p_drop, seed,
+                                y.data_ptr(), saved.data_ptr(), saved.numel(), B, T, stream, fp64=f64)
         ctx.module, ctx.dims, ctx.p_drop, ctx.seed, ctx.f64 = module, (B, T), p_drop, seed, f64
         ctx.saved_stash = saved
+        ctx.lazy_inputs = (xi, xs, mask, scale) if lazy else None
         if module.keep_train_stash:
             module.last_train_stash = (saved, B, T)
         ctx.save_for_backward(*params)
@@ -560,14 +615,25 @@ class _HipTrainFunction(torch.autograd.Function):
         dev = gy.device
         with torch.cuda.device(dev):
             saved = ctx.saved_stash
+            f64 = ctx.f64
+            pdt = torch.float64 if f64 else torch.float32
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if saved is None and ctx.lazy_inputs is not None:
+                # the forward ran without a stash (few windows, tip_forward_dropout): produce it now — tip_train_forward with the same
+                # inputs, keep mask, dropout probability and seed evaluates the same function with the same keep decisions
+                xi, xs, mask, scale = ctx.lazy_inputs
+                saved_bytes, _ = h.train_bytes(B, T, fp64=f64)
+                saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+                y2 = torch.empty((B, T, module.size_s), dtype=pdt, device=dev)
+                pc0 = [p.detach().contiguous() for p in params]
+                h.train_forward([p.data_ptr() for p in pc0], xi.data_ptr(), xs.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                scale, ctx.p_drop, ctx.seed, y2.data_ptr(), saved.data_ptr(), saved.numel(), B, T, stream, fp64=f64)
+                ctx.lazy_inputs = None
             if saved is None:
                 raise RuntimeError("tip_amd: backward through the HIP training step a second time — the activation stash "
                                    "is released after the first backward (retain_graph=True is not supported; run the "
                                    "forward again)")
-            f64 = ctx.f64
-            pdt = torch.float64 if f64 else torch.float32
             _, scratch_bytes = h.train_bytes(B, T, fp64=f64)
-            stream = torch.cuda.current_stream(dev).cuda_stream
             scratch = module._stream_buffer(module._train_scratch, dev, stream, scratch_bytes)
             total = sum(p.numel() for p in params)
             flat = torch.empty(total, dtype=pdt, device=dev)
