@@ -25,7 +25,7 @@ extern "C" {
 
 #define TIP_ABI_VERSION 3 /* 2: packed image without the exploratory split-fp16 section unless asked for (TIP_CREATE_S16, tip_create_ex);
                              tip_max_batch; export list = this header (+ tip_hip_debug.h), everything else hidden
-                             3: tip_forward_dropout; plan 9 (persistent latency kernel) and its 1 KiB of sync words in the packed image
+                             3: tip_forward_dropout, tip_draw_keep_mask; plan 9 (persistent latency kernel) and its 1 KiB of sync words in the packed image
                              removed; TIP_OPT_FUSE_HEAD reserved */
 
 /* The library is built with -fvisibility=hidden: the functions declared here (and the measurement hooks of
@@ -184,10 +184,15 @@ TIP_API int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, flo
  * (and on a demoted handle): the caller then takes tip_train_forward.  The keep decisions are tip_train_forward's for the same
  * (p_drop, seed) — same hash, same element indices — so a later tip_train_forward(same arguments) + tip_train_backward differentiates
  * exactly the function evaluated here (the Python module does that when .backward() is called after all).  Uses the ATTACHED packed
- * image like tip_forward; flags / keep_mask / workspace as tip_forward. */
+ * image like tip_forward; flags / workspace as tip_forward.  Past-state dropout (:77): an explicit keep_mask (TIP_FWD_KEEP_MASK), or
+ * p_state > 0 with keep_mask NULL — the mask is then drawn inside the first kernel from (p_state, state_seed), the same decisions
+ * tip_draw_keep_mask(p_state, state_seed, ...) writes out as a [B,T,size_s] tensor of 0 / 1 (for the tip_train_forward that a later
+ * backward needs); kept values are scaled by keep_scale either way. */
 TIP_API int tip_forward_dropout(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
-                        const float* keep_mask, float keep_scale, float p_drop, unsigned long long seed, void* workspace,
-                        size_t workspace_bytes, tip_stream_t stream);
+                        const float* keep_mask, float keep_scale, float p_state, unsigned long long state_seed, float p_drop,
+                        unsigned long long seed, void* workspace, size_t workspace_bytes, tip_stream_t stream);
+/* mask[i] = 1 (keep) or 0 for i < n: the counter-based hash of the training step at site 0xFFFFFFF0, drop probability p_state in [0, 1) */
+TIP_API int tip_draw_keep_mask(float p_state, unsigned long long state_seed, float* mask, size_t n, tip_stream_t stream);
 
 /* ---- forward in fp64: the module built under `--double` (train_model.py:62-63,84-85: torch.set_default_dtype(float64), fp64
  *      windows :161-164).  Same function as tip_forward (simple_transformer_with_state.py:60-102) with every operation in IEEE

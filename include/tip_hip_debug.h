@@ -2,7 +2,19 @@
  * in-kernel time stamps and launch counters that the profiling scripts under tools/ and two launch-path assertions in tests/
  * use.  They are exported so that those scripts can reach them through ctypes; nothing in the product path calls them.
  * Every reader copies `n` 64-bit words from a __device__ trace array (filled only when the matching TIP_*_TRACE environment
- * switch was set at launch) and returns 0, -1 for a bad `n`, -5 for a HIP error. */
+ * switch was set at launch) and returns 0, -1 for a bad `n`, -5 for a HIP error.
+ *
+ * Environment switches of the MEASUREMENT BUILD (csrc: `make measure` -> libtip_hip_measure.so, -DTIP_MEASURE; the default library
+ * reads none of them — its kernel selection depends on tip_set_option only):
+ *   traces (fill the arrays the readers below copy): TIP_FUSEDH_TRACE, TIP_FUSED2_TRACE, TIP_BWD_TRACE, TIP_RNN_TRACE, TIP_HEAD_TRACE,
+ *     TIP_S16_TRACE
+ *   ablations (wrong results, timing only): TIP_FUSED_ABLATE, TIP_RNN_ABLATE
+ *   A/B selections: TIP_AUTO_SPLIT=0 (no rounds + remainder split), TIP_RNN_ROWS4=0 / TIP_RNN_W4=0|1 / TIP_RNN_C16=4 / TIP_RNN_HANDOFF=0 /
+ *     TIP_RNN_PREPOLL=0 / TIP_RNN_ROTATE=0 (recurrence variants), TIP_HEAD=old (streaming projection kernel), TIP_GENERAL_PGEMM=0 /
+ *     TIP_GENERAL_GEMM=32 / TIP_GENERAL_ATTN=v (general plan), TIP_TRAIN_FUSED=0 / TIP_TRAIN_FUSED_BWD=0 / TIP_TRAIN_FWD_PADDED /
+ *     TIP_TRAIN_WIN_GEMM=0 / TIP_TRAIN_PGEMM=0 / TIP_TGEMM_TILE / TIP_TGEMM16_TILE / TIP_DW_KERNEL / TIP_DW_SPLITS / TIP_DW_SPLITDIV /
+ *     TIP_DW_GROUP / TIP_DW_NB (training step)
+ */
 #ifndef TIP_HIP_DEBUG_H
 #define TIP_HIP_DEBUG_H
 

@@ -397,3 +397,21 @@ def test_workspace_of_a_part_never_exceeds_the_whole():
                 assert h.workspace_bytes(B - r, T) <= total and h.workspace_bytes(r, T) <= total, (B, T)
         big = [sizes[B] for B in sorted(sizes) if B >= 256]
         assert all(a <= b for a, b in zip(big, big[1:])), "monotone from one round up"
+
+
+def test_default_library_does_not_read_the_environment():
+    """kernel selection of a production handle must not depend on the process environment.  The launchers'
+    TIP_* measurement switches go through tip_env() (csrc/tip_internal.h), which is a constant nullptr unless the library is built
+    with -DTIP_MEASURE (`make measure` -> libtip_hip_measure.so): the default library does not even import getenv."""
+    import glob
+    import subprocess
+    und = subprocess.run(["nm", "-D", "--undefined-only", tlib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert os.path.basename(tlib.LIB_PATH) == "libtip_hip.so"
+    assert "getenv" not in und
+    hits = []
+    for f in glob.glob(os.path.join(ROOT, "transformer-inertial-poser_amd", "csrc", "*.hip")) + \
+            glob.glob(os.path.join(ROOT, "transformer-inertial-poser_amd", "csrc", "*.h")):
+        n = len(re.findall(r"\bgetenv\s*\(", open(f).read()))
+        if n:
+            hits.append((os.path.basename(f), n))
+    assert hits == [("tip_internal.h", 1)], hits

@@ -3,6 +3,7 @@ TIP_AUTO_SPLIT=0 TIP_PLAN_BASE=1 reproduces the round-3 selection (no remainder 
 import contextlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+os.environ.setdefault("TIP_LIB", "measure")   # the launchers' TIP_* switches exist in the measurement build only (csrc: make measure)
 import tip_amd
 from tip_amd import synth
 cfg = synth.PAPER

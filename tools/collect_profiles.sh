@@ -8,6 +8,9 @@ ROUND=${1:-r03}
 OUT=$PWD/gpurun_out/$ROUND
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+# the trace / A-B scripts below load the MEASUREMENT build (TIP_LIB=measure, set by the scripts themselves): the launchers' TIP_*
+# environment switches exist only there.  bench.py and the rocprofv3 passes run the default library.
+[ -f transformer-inertial-poser_amd/csrc/libtip_hip_measure.so ] || make -C transformer-inertial-poser_amd/csrc -j8 measure > /dev/null
 BENCH="python $PWD/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extra"
 
 # 1. the default bench line (with cpu_baseline) and the same command under rocprofv3 --kernel-trace --stats

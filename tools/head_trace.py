@@ -5,6 +5,7 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np, torch
+os.environ.setdefault("TIP_LIB", "measure")   # the launchers' TIP_* switches exist in the measurement build only (csrc: make measure)
 from tip_amd import synth, lib as tlib
 from sweep import model_for
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256

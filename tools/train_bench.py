@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+os.environ.setdefault("TIP_LIB", "measure")   # the launchers' TIP_* switches exist in the measurement build only (csrc: make measure)
 import tip_amd  # noqa: E402
 from tip_amd import synth  # noqa: E402
 

@@ -211,7 +211,7 @@ static hipError_t linear_gemm(const float* P, const tip::PackedLinear& p, const 
     if (s16 && p.s_off && tip::pgemm16_shape_ok(M, p.N, p.K))   // TIP_PLAN_GENERAL16 (exploratory): split-fp16 operands
         return tip::launch_pgemm16(A, lda, P + p.s_off, (size_t)p.N * p.K, P + p.b_off, res, ldres, C, ldc, M, p.N, p.K, flags, s);
     static int use_pg = -1;   // TIP_GENERAL_PGEMM=0 keeps the LDS-tiled kernel (measurement)
-    if (use_pg < 0) use_pg = (getenv("TIP_GENERAL_PGEMM") && getenv("TIP_GENERAL_PGEMM")[0] == '0') ? 0 : 1;
+    if (use_pg < 0) use_pg = (tip_env("TIP_GENERAL_PGEMM") && tip_env("TIP_GENERAL_PGEMM")[0] == '0') ? 0 : 1;
     // (the panel kernel's epilogue moves 16 bytes per lane: bias / residual / output rows must be 16-byte aligned — they are for
     //  every buffer the library carves out itself)
     auto al16 = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0; };
@@ -718,7 +718,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     // Costs in us from profiles/r04/plan_bench_split.txt (B = 256 step 0.625 ms; the remainder's latency-plan forward measured
     // 163 / 177 / 201 / 282 / 372 us for 1 / 8 / 16 / 32 / 44 windows behind it); TIP_AUTO_SPLIT=0 disables (measurement).
     if (h->plan == TIP_PLAN_AUTO && !h->demoted && cus == h->num_cus && B > cus && fused_supported(d, T) && fused_has_rnn_ih(d)) {
-        static const bool split_on = !(getenv("TIP_AUTO_SPLIT") && getenv("TIP_AUTO_SPLIT")[0] == '0');
+        static const bool split_on = !(tip_env("TIP_AUTO_SPLIT") && tip_env("TIP_AUTO_SPLIT")[0] == '0');
         const int r = B % cus, bm = B - r;
         // what the remainder costs on its own (us; AUTO's choice for that many windows, below): the latency plan up to 32 windows
         // (measured 163 / 177 / 201 / 282 / 372 us for 1 / 8 / 16 / 32 / 44), the window-split encoder up to #CUs / 4 (0.305 ms) and
@@ -816,7 +816,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         while (rnn_cluster > 1 && ntiles * rnn_cluster > cus) rnn_cluster >>= 1;
         // rnn_hidden 512: four-row tiles on 4-workgroup clusters at every batch size (76 us at B = 256 against 114 for the best
         // 16-row variant; tools/rnn_variants2.py).  TIP_RNN_ROWS4=0 keeps the 16-row kernels (measurement).
-        static const bool rows4 = !(getenv("TIP_RNN_ROWS4") && getenv("TIP_RNN_ROWS4")[0] == '0');
+        static const bool rows4 = !(tip_env("TIP_RNN_ROWS4") && tip_env("TIP_RNN_ROWS4")[0] == '0');
         if (rows4 && d.R == 512) rnn_cluster = kRnnRows4;
     }
     bool head_done = false;
@@ -938,7 +938,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         } else {
             // window lengths that are multiples of 40 (the paper's and the scaled configuration's): the register-resident
             // kernel for both forms of the output (bit-identical last rows); everything else: head_gemm_kernel for both
-            static const bool ksplit = !(getenv("TIP_HEAD") && getenv("TIP_HEAD")[0] == 'o');   // TIP_HEAD=old: measurement
+            static const bool ksplit = !(tip_env("TIP_HEAD") && tip_env("TIP_HEAD")[0] == 'o');   // TIP_HEAD=old: measurement
             hipError_t he = hipErrorInvalidValue;
             if (ksplit && T % 40 == 0)
                 he = launch_head_ksplit(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, hM, d.S, Kh, last_only, cus, s);
@@ -952,11 +952,19 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     return TIP_OK;
 }
 
+int tip_draw_keep_mask(float p_state, unsigned long long state_seed, float* mask, size_t n, tip_stream_t stream) {
+    unsigned key = 0, thresh = 0;
+    if ((!mask && n) || !state_mask_params(p_state, state_seed, &key, &thresh)) return TIP_ERR_INVALID_ARG;
+    return launch_keep_mask(mask, n, key, thresh, static_cast<hipStream_t>(stream)) == hipSuccess ? TIP_OK : TIP_ERR_HIP;
+}
+
 int tip_forward_dropout(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
-                        const float* keep_mask, float keep_scale, float p_drop, unsigned long long seed, void* workspace,
-                        size_t workspace_bytes, tip_stream_t stream) {
+                        const float* keep_mask, float keep_scale, float p_state, unsigned long long state_seed, float p_drop,
+                        unsigned long long seed, void* workspace, size_t workspace_bytes, tip_stream_t stream) {
     if (!h || !x_imu || !x_s || !y || B < 0 || T < 1) return TIP_ERR_INVALID_ARG;
     if (p_drop < 0.f || p_drop >= 1.f) return TIP_ERR_INVALID_ARG;
+    unsigned mkey = 0, mthresh = 0;
+    if (!(flags & TIP_FWD_KEEP_MASK) && p_state > 0.f && !state_mask_params(p_state, state_seed, &mkey, &mthresh)) return TIP_ERR_INVALID_ARG;
     if ((flags & TIP_FWD_KEEP_MASK) && !keep_mask) return TIP_ERR_INVALID_ARG;
     if (!h->packed_dev) return TIP_ERR_NOT_READY;
     if (tip_check(h, 0) != TIP_OK) return TIP_ERR_HANDOFF;
@@ -976,8 +984,10 @@ int tip_forward_dropout(tip_handle* h, const float* x_imu, const float* x_s, flo
     float* W0 = static_cast<float*>(workspace);
     float* hall = W0 + ws.hall;
     const float* mask = (flags & TIP_FWD_KEEP_MASK) ? keep_mask : nullptr;
-    if (!mask) keep_scale = 1.f;
-    const TrainDropout td = make_train_dropout(p_drop, seed);
+    if (!mask && !mthresh) keep_scale = 1.f;
+    TrainDropout td = make_train_dropout(p_drop, seed);
+    td.mkey = mkey;
+    td.mthresh = mthresh;
     hipError_t e;
     {
         StageScope sc(h, s, "latency_chain");

@@ -571,7 +571,7 @@ hipError_t launch_fused_encoder(const Dims& d, const float* fused_w, const float
     if (B <= 0) return hipSuccess;
     static int abl = -1;
     if (abl < 0) {
-        const char* e = getenv("TIP_FUSED_ABLATE");   // measurement-only (profiles/): never set in production
+        const char* e = tip_env("TIP_FUSED_ABLATE");   // measurement-only (profiles/): never set in production
         abl = e ? atoi(e) : 0;
     }
     const int grid = B < num_cus ? B : num_cus;
@@ -1187,7 +1187,7 @@ hipError_t launch_fused_encoder_h(const Dims& d, const float* fused_w, const flo
         attr_set = true;
     }
     static int trace = -1;
-    if (trace < 0) trace = getenv("TIP_FUSEDH_TRACE") ? 1 : 0;
+    if (trace < 0) trace = tip_env("TIP_FUSEDH_TRACE") ? 1 : 0;
     const int grid = B < num_cus ? B : num_cus;
     float* iho = fused_has_rnn_ih(d) ? ih_out : nullptr;
     if (trace)
@@ -1217,7 +1217,7 @@ hipError_t launch_fused_train_h(const Dims& d, const float* fused_w, const float
     }
     const int grid = B < num_cus ? B : num_cus;
     static int trace = -1;
-    if (trace < 0) trace = getenv("TIP_FUSEDH_TRACE") ? 1 : 0;
+    if (trace < 0) trace = tip_env("TIP_FUSEDH_TRACE") ? 1 : 0;
     if (trace) {   // measurement: the same phase stamps as the inference kernel (tools/fh_trace.py --train)
         hipLaunchKernelGGL((fused_encoder_h_kernel<true, true>), dim3(grid), dim3(fz::THREADS), fz::LDS_BYTES, s, fused_w, x_imu, x_s,
                            keep_mask, keep_scale, (float*)nullptr, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total,
@@ -1489,7 +1489,7 @@ hipError_t launch_ffn_bwd(const Dims& d, const FfnBwdArgs& a, int B, int T, int 
     FfnBwdArgs aa = a;
     aa.hid_bytes = (int)((long long)B * T * d.F * 4);
     static int trace = -1;
-    if (trace < 0) trace = getenv("TIP_BWD_TRACE") ? 1 : 0;
+    if (trace < 0) trace = tip_env("TIP_BWD_TRACE") ? 1 : 0;
     aa.trace = trace;
     hipLaunchKernelGGL(ffn_bwd_kernel, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
     return hipGetLastError();
@@ -1842,7 +1842,7 @@ hipError_t launch_attn_bwd(const Dims& d, const AttnBwdArgs& a, int B, int T, in
     AttnBwdArgs aa = a;
     aa.dqkv_bytes = (int)((long long)B * T * 3 * d.D * 4);
     static int trace = -1;
-    if (trace < 0) trace = getenv("TIP_BWD_TRACE") ? 1 : 0;
+    if (trace < 0) trace = tip_env("TIP_BWD_TRACE") ? 1 : 0;
     aa.trace = trace;
     if (aa.thresh) hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
     else hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);

@@ -844,7 +844,7 @@ hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const floa
         attr_set = true;
     }
     static int trace = -1;
-    if (trace < 0) trace = getenv("TIP_FUSED2_TRACE") ? 1 : 0;
+    if (trace < 0) trace = tip_env("TIP_FUSED2_TRACE") ? 1 : 0;
     const int npairs = (B + 1) / 2;
     const int grid = npairs < num_cus ? npairs : num_cus;
     const size_t ih_off = f2::LAYER0 + (size_t)d.L * f2::LAYER_FLOATS;

@@ -180,7 +180,7 @@ hipError_t launch_gemm(const float* A, int lda, const float* W, int Kpad, const 
     // default: the 16x16x4 / 64x64-tile kernel of tip_train.hip (measured: paper B=256 general plan 1.27 vs 1.59 ms, scaled
     // B=128 32.3 vs 35.5 ms, scaled B=512 equal); TIP_GENERAL_GEMM=32 selects the 128x128 32x32x2 kernel below
     static int use16 = -1;
-    if (use16 < 0) use16 = (getenv("TIP_GENERAL_GEMM") && atoi(getenv("TIP_GENERAL_GEMM")) == 32) ? 0 : 1;
+    if (use16 < 0) use16 = (tip_env("TIP_GENERAL_GEMM") && atoi(tip_env("TIP_GENERAL_GEMM")) == 32) ? 0 : 1;
     if (use16) return launch_gemm16(A, lda, W, Kpad, bias, res, ldres, C, ldc, M, N, Kpad, flags, s);
     dim3 grid(Npad / kGemmBN, (M + kGemmBM - 1) / kGemmBM);
     dim3 block(256);
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 
 hipError_t launch_attention(const Dims& d, const float* qkv, float* out, int B, int T, hipStream_t s) {
     static int valu = -1;   // TIP_GENERAL_ATTN=valu keeps the one-thread-per-query kernel below (measurement / fallback)
-    if (valu < 0) valu = (getenv("TIP_GENERAL_ATTN") && getenv("TIP_GENERAL_ATTN")[0] == 'v') ? 1 : 0;
+    if (valu < 0) valu = (tip_env("TIP_GENERAL_ATTN") && tip_env("TIP_GENERAL_ATTN")[0] == 'v') ? 1 : 0;
     if (!valu && mattn_supported(d.dh, T)) {
         Drop off;
         off.seed = 0; off.site = 0; off.thresh = 0; off.scale = 1.f;
@@ -1301,7 +1301,7 @@ unsigned next_rnn_launch_tag() {
 static int rnn_handoff_mode() {
     static int handoff = -1;
     if (handoff < 0) {
-        const char* e = getenv("TIP_RNN_HANDOFF");   // 0 = arrival counter, 1 = sentinel polling (default)
+        const char* e = tip_env("TIP_RNN_HANDOFF");   // 0 = arrival counter, 1 = sentinel polling (default)
         handoff = e ? atoi(e) : 1;
     }
     return handoff;
@@ -1347,11 +1347,11 @@ static hipError_t launch_rnn_resident(const float* ih, const float* whh_frag, fl
         // XCC-id exchange words: tagged with a per-launch number instead of being zeroed (see the kernel)
         const unsigned etag = next_rnn_launch_tag();
         static int trace = -1;
-        if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
+        if (trace < 0) trace = tip_env("TIP_RNN_TRACE") ? 1 : 0;
         static int prepoll_env = -1;   // TIP_RNN_PREPOLL=0: no arrival probe before the tile pull (measurement)
-        if (prepoll_env < 0) prepoll_env = (getenv("TIP_RNN_PREPOLL") && getenv("TIP_RNN_PREPOLL")[0] == '0') ? 0 : 1;
+        if (prepoll_env < 0) prepoll_env = (tip_env("TIP_RNN_PREPOLL") && tip_env("TIP_RNN_PREPOLL")[0] == '0') ? 0 : 1;
         static int rot_env = -1;       // TIP_RNN_ROTATE=0: every member sweeps the tile from row 0 (measurement)
-        if (rot_env < 0) rot_env = (getenv("TIP_RNN_ROTATE") && getenv("TIP_RNN_ROTATE")[0] == '0') ? 0 : 2;
+        if (rot_env < 0) rot_env = (tip_env("TIP_RNN_ROTATE") && tip_env("TIP_RNN_ROTATE")[0] == '0') ? 0 : 2;
         const int prepoll = prepoll_env | rot_env | (int)(etag << 8);
         if (gate)
             hipLaunchKernelGGL((rnn_resident_kernel<WAVES, KSPLIT, 1, false, true>), dim3(groups * CLUSTER), dim3(WAVES * 64), smem,
@@ -1374,8 +1374,8 @@ static hipError_t launch_rnn_rows4_nt(const float* ih, const float* whh_frag, fl
     constexpr int smem = 2 * NT * kQ4Rows * kQ4LD * (int)sizeof(float);
     constexpr int CLUSTER = 32 / WAVES, THREADS = WAVES * 64;
     static int trace = -1, abl = -1;
-    if (trace < 0) trace = getenv("TIP_RNN_TRACE") ? 1 : 0;
-    if (abl < 0) abl = getenv("TIP_RNN_ABLATE") ? atoi(getenv("TIP_RNN_ABLATE")) : 0;   // measurement only (profiles/): never set in production
+    if (trace < 0) trace = tip_env("TIP_RNN_TRACE") ? 1 : 0;
+    if (abl < 0) abl = tip_env("TIP_RNN_ABLATE") ? atoi(tip_env("TIP_RNN_ABLATE")) : 0;   // measurement only (profiles/): never set in production
     static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         for (const void* f : {reinterpret_cast<const void*>(rnn_rows4_kernel<NT, false, false, WAVES>), reinterpret_cast<const void*>(rnn_rows4_kernel<NT, true, false, WAVES>),
@@ -1408,7 +1408,7 @@ static hipError_t launch_rnn_rows4(const float* ih, const float* whh_frag, float
     // overlap of one's hand-off with the other's MFMAs does not happen: 84 vs 78 us (profiles/r04/rnn_w4.txt), so the 8-wave members
     // stay there.  Bit-identical either way.  TIP_RNN_W4=0 / 1 forces one (measurement).
     static int w4 = -2;
-    if (w4 == -2) w4 = getenv("TIP_RNN_W4") ? (getenv("TIP_RNN_W4")[0] == '1' ? 1 : 0) : -1;
+    if (w4 == -2) w4 = tip_env("TIP_RNN_W4") ? (tip_env("TIP_RNN_W4")[0] == '1' ? 1 : 0) : -1;
     const bool use_w4 = (w4 == 1 || (w4 == -1 && ntiles * 8 <= num_cus));
     int groups = ntiles;
     const int maxg = num_cus / kQ4Cluster > 0 ? num_cus / kQ4Cluster : 1;   // keep every cluster co-resident (W4: 8 members, two per CU: the same count)
@@ -1501,7 +1501,7 @@ hipError_t launch_rnn(const Dims& d, const float* ih, const float* whh_frag, flo
             return launch_rnn_resident<4, 4>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, gd, s, nullptr, 2);
         if (cluster >= 16) {
             static int w8 = -1;   // TIP_RNN_C16=4 selects the 4-wave variant (measurement)
-            if (w8 < 0) w8 = (getenv("TIP_RNN_C16") && getenv("TIP_RNN_C16")[0] == '4') ? 0 : 1;
+            if (w8 < 0) w8 = (tip_env("TIP_RNN_C16") && tip_env("TIP_RNN_C16")[0] == '4') ? 0 : 1;
             return w8 ? launch_rnn_resident<8, 4>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, gd, s)
                       : launch_rnn_resident<4, 2>(ih, whh_frag, hall, flags, B, T, ntiles, num_cus, hall_armed, gd, s);
         }

@@ -67,7 +67,7 @@ hipError_t launch_head_ksplit(const float* A, long long lda, const float* wfrag,
         if (e2 == hipSuccess) done = true;
         return e2;
     };
-    static const bool trace = getenv("TIP_HEAD_TRACE") && getenv("TIP_HEAD_TRACE")[0] == '1';
+    static const bool trace = tip_env("TIP_HEAD_TRACE") && tip_env("TIP_HEAD_TRACE")[0] == '1';
     if (trace && !last_only && M % 40 == 0) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_ksplit_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, hd::LDS_BYTES);
         if (e != hipSuccess) return e;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <string>
 #include <type_traits>
@@ -12,6 +13,19 @@
 #include "../../include/tip_hip_debug.h"
 
 namespace tip {
+
+// Measurement switches.  The launchers' A/B selections, in-kernel traces and ablations are driven by TIP_* environment variables —
+// in a build with -DTIP_MEASURE only (`make MEASURE=1` -> libtip_hip_measure.so, loaded by the tools under tools/ through
+// TIP_LIB=measure).  In the default build tip_env() is a constant nullptr: every switch sits at its default and the kernels a handle
+// launches depend on tip_set_option alone, never on the process environment.  The switches are listed in include/tip_hip_debug.h.
+inline const char* tip_env(const char* name) {
+#ifdef TIP_MEASURE
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // tanh for the recurrence: sign(x) * (1 - e) / (1 + e), e = exp(-2|x|) on the hardware exp2 path.  No overflow, abs error
 // ~2e-7 (the accurate libm tanhf costs ~1 us per step on the serial chain).  Every RNN kernel uses this one function,
@@ -434,8 +448,13 @@ struct TrainDropout {
     unsigned long long seed;
     unsigned thresh;
     float scale;
+    unsigned mkey = 0, mthresh = 0;   // past-state keep mask drawn in the kernel (mthresh 0: not): see tip_draw_keep_mask
 };
 TrainDropout make_train_dropout(float p, unsigned long long seed);
+constexpr unsigned kStateMaskSite = 0xFFFFFFF0u;   // hash site of the past-state keep mask (encoder sites are 4 * layer + k)
+// (key, thresh) of a keep mask with drop probability p under `seed`; false for p outside [0, 1)
+bool state_mask_params(float p, unsigned long long seed, unsigned* key, unsigned* thresh);
+hipError_t launch_keep_mask(float* mask, size_t n, unsigned key, unsigned thresh, hipStream_t s);
 hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float* whh_frag, const float* x_imu,
                                const float* x_s, const float* keep_mask, float keep_scale, float* ws, float* hall, int B,
                                int T, int num_cus, const Guard& gd, hipStream_t s, const TrainDropout* td = nullptr);

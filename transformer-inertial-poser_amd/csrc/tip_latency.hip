@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void lat_in_kernel(const float* __restrict__ w
                                                      const float* __restrict__ x_s, const float* __restrict__ keep_mask,
                                                      float keep_scale, float* __restrict__ xpre, int T, int NI, int S,
                                                      int in_w_off_b, int in_b_off, unsigned long long* __restrict__ gran,
-                                                     unsigned* __restrict__ xcc_words) {
+                                                     unsigned* __restrict__ xcc_words, unsigned mkey, unsigned mthresh) {
     using namespace lz;
     __shared__ __attribute__((aligned(16))) float U[RP * LDU];
     __shared__ __attribute__((aligned(16))) float red[4 * 3 * 256];
@@ -203,7 +203,10 @@ __global__ __launch_bounds__(256) void lat_in_kernel(const float* __restrict__ w
                 const float x = *pa;
                 float kv = 1.f;
                 if (km) kv = *(imu ? pa : km + (size_t)rc * S + cs);                  // :77 (km: wave-uniform; IMU lanes read a dummy)
-                const float xs_v = (x != x ? 0.f : x) * kv * (km ? keep_scale : 1.f); // :65, then (x * mask) * scale as before
+                // ... or the keep decision drawn here (tip_forward_dropout with a state seed): element index of x_s [B][T][S], the
+                // same decisions tip_draw_keep_mask writes out
+                if (mthresh) kv = tip_drop_hash_k(mkey, (unsigned)(((size_t)win * T + rc) * S + cs)) >= mthresh ? 1.f : 0.f;
+                const float xs_v = (x != x ? 0.f : x) * kv * ((km || mthresh) ? keep_scale : 1.f); // :65, then (x * mask) * scale as before
                 v[i][ch] = (row < T && c < NI + S) ? (imu ? x : xs_v) : 0.f;
             }
         }
@@ -632,7 +635,7 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
     constexpr size_t W1_W = WO_B + D, W1_B = W1_W + (size_t)F * D, W2_W = W1_B + F, W2_B = W2_W + (size_t)D * F;
     constexpr size_t G1 = W2_B + D, BE1 = G1 + D, G2 = BE1 + D, BE2 = G2 + D, LAYER_FLOATS = BE2 + D;
     hipLaunchKernelGGL(lat_in_kernel, dim3(16, B), dim3(256), 0, s, fused_w, wbytes, x_imu, x_s, keep_mask, keep_scale, xa, T,
-                       d.n_imu_total, d.S, (int)(IN_W * 4), (int)IN_B, gran, xccw);
+                       d.n_imu_total, d.S, (int)(IN_W * 4), (int)IN_B, gran, xccw, td ? td->mkey : 0u, td && !keep_mask ? td->mthresh : 0u);
     const float* pg = nullptr;   // LayerNorm pending on the residual stream (norm2 of the previous layer)
     const float* pb = nullptr;
     for (int l = 0; l < d.L; ++l) {
@@ -674,6 +677,19 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
         if (ce != hipSuccess) return ce;
     }
     hipLaunchKernelGGL(rnn_gemv_kernel, dim3(32 * ((B + 7) / 8)), dim3(512), 0, s, ihb, whh_frag, hall, gran, xccw, B, T, gd);
+    return hipGetLastError();
+}
+
+// The past-state keep mask (:77) as a tensor: mask[i] = hash(key, i) >= thresh ? 1 : 0 over the elements of x_s — the decisions
+// lat_in_kernel draws in place when tip_forward_dropout is given the seed instead of a mask.
+__global__ void keep_mask_kernel(float* __restrict__ mask, size_t n, unsigned key, unsigned thresh) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        mask[i] = tip_drop_hash_k(key, (unsigned)i) >= thresh ? 1.f : 0.f;
+}
+hipError_t launch_keep_mask(float* mask, size_t n, unsigned key, unsigned thresh, hipStream_t s) {
+    if (!n) return hipSuccess;
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(keep_mask_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, s, mask, n, key, thresh);
     return hipGetLastError();
 }
 

@@ -639,7 +639,7 @@ hipError_t launch_fused_encoder_s16(const Dims& d, const float* fused_w, const f
         attr_set = true;
     }
     const int grid = B < num_cus ? B : num_cus;
-    static const bool trace = getenv("TIP_S16_TRACE") && getenv("TIP_S16_TRACE")[0] == '1';
+    static const bool trace = tip_env("TIP_S16_TRACE") && tip_env("TIP_S16_TRACE")[0] == '1';
     if (trace) {
         hipLaunchKernelGGL(fused_encoder_s16_kernel<true>, dim3(grid), dim3(sz::THREADS), sz::LDS_BYTES, s, fused_w, s16_w, x_imu, x_s, keep_mask,
                            keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, T, d.n_imu_total, d.S, d.L,

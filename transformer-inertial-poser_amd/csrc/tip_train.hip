@@ -61,6 +61,13 @@ TrainDropout make_train_dropout(float p, unsigned long long seed) {
     const Drop d = make_drop(p, seed, 0);
     return TrainDropout{seed, d.thresh, d.scale};
 }
+bool state_mask_params(float p, unsigned long long seed, unsigned* key, unsigned* thresh) {
+    if (!(p >= 0.f) || p >= 1.f) return false;
+    const Drop d = make_drop(p, seed, kStateMaskSite);
+    *key = d.key;
+    *thresh = d.thresh;
+    return true;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // tgemm: C[i][j] = epi( sum_k A(i,k) * B(j,k) ),  128x128x16 block tile, 32x32x2 fp32 MFMA, 4 waves as 2x2.
@@ -375,7 +382,7 @@ static thread_local int g_tgemm_cus = 256;   // set from the handle at every ent
 static hipError_t tgemm16_launch(TG g, hipStream_t s) {
     g.kk = round_up(g.kk, 32);
     static int force = -1;
-    if (force < 0) force = getenv("TIP_TGEMM16_TILE") ? atoi(getenv("TIP_TGEMM16_TILE")) : 0;
+    if (force < 0) force = tip_env("TIP_TGEMM16_TILE") ? atoi(tip_env("TIP_TGEMM16_TILE")) : 0;
     if (force == 3) {   // 8-wave 128 x 128 (measured: no gain over 64 x 64 even at N, K in the thousands: 112 vs 110 TFLOP/s)
         hipLaunchKernelGGL((tgemm16_kernel<128, 128, 4, 2>), dim3((g.nn + 127) / 128, (g.mm + 127) / 128), dim3(512), 0, s, g);
     } else if (force == 1) {
@@ -433,7 +440,7 @@ static bool panel_ok(int M, int N, int K) {
 
 static hipError_t lin_launch(const TG& g, const float* wfrag, hipStream_t s) {
     static int use_pg = -1;   // TIP_TRAIN_PGEMM=0: LDS-tiled kernel everywhere (measurement)
-    if (use_pg < 0) use_pg = (getenv("TIP_TRAIN_PGEMM") && getenv("TIP_TRAIN_PGEMM")[0] == '0') ? 0 : 1;
+    if (use_pg < 0) use_pg = (tip_env("TIP_TRAIN_PGEMM") && tip_env("TIP_TRAIN_PGEMM")[0] == '0') ? 0 : 1;
     auto al16 = [](const void* q, long long ld) { return !q || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld & 3) == 0); };
     if (!use_pg || !wfrag || !panel_ok(g.mm, g.nn, g.kva) || g.kva != g.kvb || (long long)g.nn * g.kva * 4 > 0x7fffffffLL ||
         !al16(g.bias, 0) || !al16(g.C, g.ldc) || !al16(g.res, g.ldres) || !al16(g.gate, g.ldgate))   // 16-byte epilogue accesses
@@ -455,7 +462,7 @@ static hipError_t tgemm_launch(const TG& g, int splits, hipStream_t s) {
     auto blocks = [&](int ti, int tj) { return (long long)((g.mm + ti - 1) / ti) * ((g.nn + tj - 1) / tj) * splits; };
     const long long want = 2LL * g_tgemm_cus;
     static int force = -1;   // measurement only: TIP_TGEMM_TILE = 1 (128x128) / 2 (64x128) / 3 (64x64)
-    if (force < 0) force = getenv("TIP_TGEMM_TILE") ? atoi(getenv("TIP_TGEMM_TILE")) : 0;
+    if (force < 0) force = tip_env("TIP_TGEMM_TILE") ? atoi(tip_env("TIP_TGEMM_TILE")) : 0;
     if (force == 1 || (force == 0 && blocks(128, 128) >= want)) {
         hipLaunchKernelGGL((tgemm_kernel<AM, BM, 128, 128>), dim3((g.nn + 127) / 128, (g.mm + 127) / 128, splits), dim3(256), 0, s, g);
     } else if (force == 2 || (force == 0 && blocks(64, 128) >= want)) {
@@ -715,7 +722,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_batch_kernel(ReduceBatch r)
 
 static bool dwgemm_ok(long long ldy, long long ldx, int n_rows_pad, int n_store, int K, int M) {
     static int off = -1;   // TIP_DW_KERNEL=tgemm: the LDS-tiled 32x32x2 kernel for every shape (measurement)
-    if (off < 0) off = getenv("TIP_DW_KERNEL") && !strcmp(getenv("TIP_DW_KERNEL"), "tgemm");
+    if (off < 0) off = tip_env("TIP_DW_KERNEL") && !strcmp(tip_env("TIP_DW_KERNEL"), "tgemm");
     return !off && n_store == n_rows_pad && n_store % 128 == 0 && K % 64 == 0 && M % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0;
 }
 
@@ -723,7 +730,7 @@ static bool dwgemm_ok(long long ldy, long long ldx, int n_rows_pad, int n_store,
 // pipeline fill, LDS reduction, 32-KB store ~ the time of 96 rows), plus the second-stage reduce when the reduction is split
 static int dw_choose_splits(int tiles, int slots, int M, long long per_total, size_t part_floats, int tile_floats) {
     static int force = -1;   // TIP_DW_SPLITS: fixed split count (measurement)
-    if (force < 0) force = getenv("TIP_DW_SPLITS") ? atoi(getenv("TIP_DW_SPLITS")) : 0;
+    if (force < 0) force = tip_env("TIP_DW_SPLITS") ? atoi(tip_env("TIP_DW_SPLITS")) : 0;
     const int smax = std::max(1, (int)std::min<long long>(std::max(1, M / 128), (long long)part_floats / per_total));
     if (force > 0) return std::min(force, smax);
     int best = 1;
@@ -763,14 +770,14 @@ struct DwProb {
 // eligible (caller then issues them one by one).
 static bool grad_weight_batch(const DwProb* pr, int n, int M, float* part, size_t part_floats, int num_cus, hipStream_t s, hipError_t* err) {
     static int on = -1;   // TIP_DW_GROUP=0: one launch per gradient (measurement)
-    if (on < 0) on = !(getenv("TIP_DW_GROUP") && atoi(getenv("TIP_DW_GROUP")) == 0);
+    if (on < 0) on = !(tip_env("TIP_DW_GROUP") && atoi(tip_env("TIP_DW_GROUP")) == 0);
     if (!on || n < 1 || n > kDwBatchMax) return false;
     long long per_total = 0;
     DwBatch b;
     b.n = n;
     b.tile0[0] = 0;
     static int nbsel = -1;   // TIP_DW_NB=2: 128 x 128 per wave in the batched launch too (measurement)
-    if (nbsel < 0) nbsel = getenv("TIP_DW_NB") ? atoi(getenv("TIP_DW_NB")) : 0;
+    if (nbsel < 0) nbsel = tip_env("TIP_DW_NB") ? atoi(tip_env("TIP_DW_NB")) : 0;
     int NB = nbsel == 2 ? 2 : 1;
     for (int i = 0; i < n; ++i) {
         if (!dwgemm_ok(pr[i].ldy, pr[i].ldx, pr[i].n_out, pr[i].n_out, pr[i].K, M)) return false;
@@ -812,7 +819,7 @@ static hipError_t grad_weight(const float* dY, long long ldy, int n_rows_pad, in
                               int M, float* part, size_t part_floats, float* out, int num_cus, hipStream_t s) {
     if (dwgemm_ok(ldy, ldx, n_rows_pad, n_store, K, M)) {
         static int nbsel = -1;   // TIP_DW_NB: 1 / 2 = X blocks per wave for every shape (measurement)
-        if (nbsel < 0) nbsel = getenv("TIP_DW_NB") ? atoi(getenv("TIP_DW_NB")) : 0;
+        if (nbsel < 0) nbsel = tip_env("TIP_DW_NB") ? atoi(tip_env("TIP_DW_NB")) : 0;
         // 128 x 128 per wave once such tiles alone fill the chip (big layers: operand traffic is what binds there, +7 %);
         // 128 x 64 with two waves per SIMD otherwise (more, smaller workgroups; better at the paper model's shapes)
         const bool big = K % 128 == 0 && (n_store / 128) * (K / 128) >= num_cus;
@@ -836,7 +843,7 @@ static hipError_t grad_weight(const float* dY, long long ldy, int n_rows_pad, in
     g.c_rows = n_store;
     const int tiles = ((K + 127) / 128) * ((n_rows_pad + 127) / 128);
     static int sdiv = -1;   // TIP_DW_SPLITDIV: fewer splits (smaller partial volume), tgemm_launch then picks smaller tiles
-    if (sdiv < 0) sdiv = getenv("TIP_DW_SPLITDIV") ? atoi(getenv("TIP_DW_SPLITDIV")) : 2;   // measured: 2 is the sweet spot (1: more reduce traffic, 4+: tiles too small)
+    if (sdiv < 0) sdiv = tip_env("TIP_DW_SPLITDIV") ? atoi(tip_env("TIP_DW_SPLITDIV")) : 2;   // measured: 2 is the sweet spot (1: more reduce traffic, 4+: tiles too small)
     int splits = ((2 * num_cus + tiles - 1) / tiles + sdiv - 1) / sdiv;
     const long long per = (long long)n_store * K;
     const long long stride = (per + 3) / 4 * 4;
@@ -1462,7 +1469,7 @@ static int auto_cluster(const Dims& d, int B, int num_cus, bool demoted) {
         while (c > 1 && (ntiles * c > num_cus || (d.R / 16) % (4 * c))) c >>= 1;
         return c;
     }
-    static const bool rows4 = !(getenv("TIP_RNN_ROWS4") && getenv("TIP_RNN_ROWS4")[0] == '0');
+    static const bool rows4 = !(tip_env("TIP_RNN_ROWS4") && tip_env("TIP_RNN_ROWS4")[0] == '0');
     if (rows4) return kRnnRows4;
     int c = 16;
     while (c > 4 && ntiles * c > num_cus) c >>= 1;
@@ -1487,9 +1494,9 @@ static int train_fail(tip_handle* h, hipError_t e, const char* what) {
 // only then do the fragment copies the per-window kernels of the backward read (wih_tf, wout_tf) exist in `saved`
 static bool train_fused_prep(const Dims& d, int T) {
     static int use_fused_prep = -1;
-    if (use_fused_prep < 0) use_fused_prep = (getenv("TIP_TRAIN_FUSED") && getenv("TIP_TRAIN_FUSED")[0] == '0') ? 0 : 1;
+    if (use_fused_prep < 0) use_fused_prep = (tip_env("TIP_TRAIN_FUSED") && tip_env("TIP_TRAIN_FUSED")[0] == '0') ? 0 : 1;
     return use_fused_prep && fused_supported(d, T) && fused_has_rnn_ih(d) && fused_packed_floats(d) > 0 &&
-           fused_bwd_image_floats(d) > 0 && !(getenv("TIP_TRAIN_FUSED_BWD") && getenv("TIP_TRAIN_FUSED_BWD")[0] == '0');
+           fused_bwd_image_floats(d) > 0 && !(tip_env("TIP_TRAIN_FUSED_BWD") && tip_env("TIP_TRAIN_FUSED_BWD")[0] == '0');
 }
 
 #define TT(expr, what)                                   \
@@ -1589,14 +1596,14 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     }
     TT(hipGetLastError(), "train_prep");
     // (the hybrid fused forward stashes U itself: FusedTrain::u)
-    static const bool padded_fwd = getenv("TIP_TRAIN_FWD_PADDED") != nullptr;
+    static const bool padded_fwd = tip_env("TIP_TRAIN_FWD_PADDED") != nullptr;
     const bool u_in_kernel = fused_prep && !padded_fwd && d.InPad == 224;
     if (!u_in_kernel) TT(launch_prologue(d, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f, W + L.U, M, s), "train_prologue");
     // Paper configuration: the encoder runs as ONE kernel — the fused inference kernel with its activations stashed and the
     // dropout sites live (tip_fused.hip, fused_encoder_kernel<8>) — on a weight image packed on the GPU from the live
     // parameters.  Any other supported configuration takes the layer-by-layer path below.
     static int use_fused = -1;   // TIP_TRAIN_FUSED=0: layer-by-layer forward (measurement)
-    if (use_fused < 0) use_fused = (getenv("TIP_TRAIN_FUSED") && getenv("TIP_TRAIN_FUSED")[0] == '0') ? 0 : 1;
+    if (use_fused < 0) use_fused = (tip_env("TIP_TRAIN_FUSED") && tip_env("TIP_TRAIN_FUSED")[0] == '0') ? 0 : 1;
     const bool fused = use_fused && fused_supported(d, T) && fused_has_rnn_ih(d) && fused_packed_floats(d) > 0;
     bool hall_armed = false;
     if (fused) {
@@ -1633,7 +1640,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
         tr.seed = seed; tr.thresh = dr.thresh; tr.scale = dr.scale;
         // the encoder also pre-fills its windows' HALL rows with the recurrence's hand-off sentinel (saves a 21-MB memset)
         hall_armed = rnn_uses_sentinel(d, B, T, auto_cluster(d, B, ecus, h->demoted != 0));
-        static const bool padded = getenv("TIP_TRAIN_FWD_PADDED") != nullptr;   // A/B runs only (tools/train_bench.py)
+        static const bool padded = tip_env("TIP_TRAIN_FWD_PADDED") != nullptr;   // A/B runs only (tools/train_bench.py)
         TT((padded ? launch_fused_train : launch_fused_train_h)(d, W + L.fused_img, x_imu, x_s, keep_mask, keep_mask ? keep_scale : 1.f,
                                                                  W + L.ih, hall_armed ? W + L.hall : nullptr, tr, B, T, ecus, s),
            "train_fused_encoder");
@@ -1746,7 +1753,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     {
         // fused path, windows of 40 frames: the register-resident projection of the inference path (tip_head.hip) on fragments
         // packed from the live W_out (27 -> 17 us at B = 256); otherwise the LDS-tiled GEMM
-        static const bool win_k = !(getenv("TIP_TRAIN_WIN_GEMM") && getenv("TIP_TRAIN_WIN_GEMM")[0] == '0');
+        static const bool win_k = !(tip_env("TIP_TRAIN_WIN_GEMM") && tip_env("TIP_TRAIN_WIN_GEMM")[0] == '0');
         hipError_t he = hipErrorInvalidValue;
         if (win_k && fused && fused_prep && L.wout_f && T % 40 == 0)
             he = launch_head_ksplit(W + L.hall, d.R, W + L.wout_f, lin_b, y, d.S, M, d.S, d.R, false, ecus, s);
@@ -1802,7 +1809,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
 
     // paper configuration: the feed-forward half of every layer's backward runs as one fused kernel per window
     static int use_fbwd = -1;   // TIP_TRAIN_FUSED_BWD=0: layer-by-layer (measurement)
-    if (use_fbwd < 0) use_fbwd = (getenv("TIP_TRAIN_FUSED_BWD") && getenv("TIP_TRAIN_FUSED_BWD")[0] == '0') ? 0 : 1;
+    if (use_fbwd < 0) use_fbwd = (tip_env("TIP_TRAIN_FUSED_BWD") && tip_env("TIP_TRAIN_FUSED_BWD")[0] == '0') ? 0 : 1;
     const bool fbwd = use_fbwd && fused_supported(d, T) && fused_bwd_image_floats(d) > 0;
     if (fbwd) {
         std::vector<PackOp> ops;
@@ -1824,7 +1831,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
     }
     TT(grad_weight(X + S.dyp, Sp, Sp, d.S, head_in, Kout, Kout, M, part, S.part_floats, grads + goff[g_lin_w], ncu, s),
        "bwd_dW_out");
-    static const bool win_k = !(getenv("TIP_TRAIN_WIN_GEMM") && getenv("TIP_TRAIN_WIN_GEMM")[0] == '0');   // TIP_TRAIN_WIN_GEMM=0: measurement
+    static const bool win_k = !(tip_env("TIP_TRAIN_WIN_GEMM") && tip_env("TIP_TRAIN_WIN_GEMM")[0] == '0');   // TIP_TRAIN_WIN_GEMM=0: measurement
     const bool win_g = win_k && fbwd && train_fused_prep(d, T) && L.wout_tf && T <= 40 && Sp <= 160 && Sp % 4 == 0;
     float* gx = X + S.ga;     // gradient w.r.t. the current layer's output
     float* galt = X + S.gb;

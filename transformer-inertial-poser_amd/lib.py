@@ -9,7 +9,10 @@ from typing import List, Optional, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libtip_hip.so")
+# TIP_LIB=measure (a PYTHON-side switch, for the scripts under tools/): load the measurement build, in which the launchers' TIP_*
+# environment switches are alive (csrc/Makefile: `make measure`); the default library ignores the environment.
+MEASURE = os.environ.get("TIP_LIB", "") == "measure"
+LIB_PATH = os.path.join(CSRC, "libtip_hip_measure.so" if MEASURE else "libtip_hip.so")
 
 TIP_FWD_LAST_ROW_ONLY = 0x1
 TIP_FWD_KEEP_MASK = 0x2
@@ -32,7 +35,7 @@ TIP_LOSS_Q, TIP_LOSS_C, TIP_LOSS_J, TIP_LOSS_STATS = 1, 2, 4, 16
 EXPORTS = (
     "tip_abi_version", "tip_create", "tip_destroy", "tip_strerror", "tip_last_hip_error", "tip_set_option",
     "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
-    "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_max_batch", "tip_forward", "tip_forward_dropout", "tip_forward_f64_bytes", "tip_forward_f64", "tip_forward_count", "tip_profile_read",
+    "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_max_batch", "tip_forward", "tip_forward_dropout", "tip_draw_keep_mask", "tip_forward_f64_bytes", "tip_forward_f64", "tip_forward_count", "tip_profile_read",
     "tip_spin_timeouts", "tip_check", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
     "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward",
     "tip_train_bytes_f64", "tip_train_forward_f64", "tip_train_backward_f64",
@@ -64,7 +67,7 @@ class TipConfig(ctypes.Structure):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into csrc/libtip_hip.so (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else []) + ["libtip_hip.so"]
+    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else []) + [os.path.basename(LIB_PATH)]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)
@@ -111,7 +114,9 @@ def load() -> ctypes.CDLL:
     lib.tip_workspace_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
     lib.tip_max_batch.argtypes = [vp, i32, i32, ctypes.POINTER(i32)]
     lib.tip_forward.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, ctypes.c_float, vp, sz, vp]
-    lib.tip_forward_dropout.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, vp, sz, vp]
+    lib.tip_forward_dropout.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, ctypes.c_float,
+                                        ctypes.c_uint64, vp, sz, vp]
+    lib.tip_draw_keep_mask.argtypes = [ctypes.c_float, ctypes.c_uint64, vp, sz, vp]
     lib.tip_forward_f64_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
     lib.tip_forward_f64.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, vp, i32, i32, i32, vp, ctypes.c_double, vp, sz, vp]
     lib.tip_forward_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
@@ -228,10 +233,10 @@ class Handle:
                                          workspace_bytes, stream))
 
     def forward_dropout(self, x_imu: int, x_s: int, y: int, B: int, T: int, flags: int, keep_mask: Optional[int], keep_scale: float,
-                        p_drop: float, seed: int, workspace: int, workspace_bytes: int, stream: int):
+                        p_state: float, state_seed: int, p_drop: float, seed: int, workspace: int, workspace_bytes: int, stream: int):
         """tip_forward_dropout: the few-stream forward with the training step's encoder dropout and no activation stash."""
-        self._check(self.lib.tip_forward_dropout(self._h, x_imu, x_s, y, B, T, flags, keep_mask, keep_scale, p_drop, seed, workspace,
-                                                 workspace_bytes, stream))
+        self._check(self.lib.tip_forward_dropout(self._h, x_imu, x_s, y, B, T, flags, keep_mask, keep_scale, p_state, state_seed, p_drop,
+                                                 seed, workspace, workspace_bytes, stream))
 
     # -- training step (train_model.py:171-196) -------------------------------------------------------
     def train_bytes(self, B: int, T: int, fp64: bool = False) -> Tuple[int, int]:
@@ -302,6 +307,13 @@ class Handle:
         launches = (ctypes.c_int * cap)()
         n = self._check(self.lib.tip_profile_read(self._h, names, ms, launches, cap))
         return [(names[i].decode(), float(ms[i]), int(launches[i])) for i in range(n)]
+
+
+def draw_keep_mask(p_state: float, state_seed: int, mask_ptr: int, n: int, stream: int):
+    """tip_draw_keep_mask: the past-state keep decisions of (p_state, state_seed) as n floats (0 / 1) at device pointer mask_ptr."""
+    st = load().tip_draw_keep_mask(p_state, state_seed, mask_ptr, n, stream)
+    if st < 0:
+        raise TipStatusError(st, load().tip_strerror(st).decode())
 
 
 def spin_timeouts() -> int:

@@ -129,6 +129,8 @@ class TF_RNN_Past_State(nn.Module):
         self._plist_cache = None         # list(self.parameters()): nn.Module.parameters() walks the module tree on every call (~0.6 us per
                                          # parameter and call site; the forward asks several times per frame), see _plist()
         self._train_ok_cache = {}
+        self._params_sig = None
+        self._ws_bytes_cache = {}
 
     # ------------------------------------------------------------------------------------------
     # initialisation: same distributions torch's nn.Linear / nn.MultiheadAttention / nn.LayerNorm / nn.RNN use
@@ -195,6 +197,7 @@ class TF_RNN_Past_State(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self._plist_cache = None
+        self._params_sig = None
         self._train_ok_cache = {}
         return super()._apply(fn, *args, **kwargs)
 
@@ -213,9 +216,12 @@ class TF_RNN_Past_State(nn.Module):
                               "is never called (offline_testing_simple.py:98); call .eval() for the deterministic inference kernels")
                 self._warned_train_nograd = True
             xi = F.dropout(x_imu, self.in_dropout, training=True) if self.in_dropout > 0.0 else x_imu   # :73
-            mask = self._draw_keep_mask(x_s)                                                            # :77
-            seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())     # CPU generator: no device sync
-            y = _HipTrainFunction.apply(self, xi, x_s, mask, float(self.ENCODER_DROPOUT), seed, *plist)
+            # :77 and the encoder's dropout: two seeds from torch's CPU generator (torch.manual_seed governs them; no device sync).
+            # The past-state keep mask is a function of (p, seed) — the library's counter-based hash — drawn inside the first kernel
+            # (few windows) or written out by tip_draw_keep_mask (_hash_keep_mask), never by three torch kernels per call.
+            seeds = torch.randint(0, 2 ** 62, (2,), dtype=torch.int64).tolist()
+            mask = seeds[1] if 0.0 < self.past_state_dropout < 1.0 else self._draw_keep_mask(x_s)
+            y = _HipTrainFunction.apply(self, xi, x_s, mask, float(self.ENCODER_DROPOUT), seeds[0], *plist)
             return y[:, -1] if last_row_only else y
         if (needs_grad and (self.training or not x_imu.is_cuda)) or (self.training and self.ENCODER_DROPOUT > 0.0 and x_imu.is_cuda):
             # not covered by the HIP training step: the torch-op composite, with the encoder dropout .train() implies
@@ -236,16 +242,19 @@ class TF_RNN_Past_State(nn.Module):
 
     LAZY_STASH_MAX_BATCH = 32   # .train()-mode calls of up to this many windows run without an activation stash (see _HipTrainFunction)
 
-    def _forward_dropout_hip(self, h, xi, xs, y, B, T, mask_ptr, scale, p_drop, seed, stream) -> bool:
+    def _forward_dropout_hip(self, h, xi, xs, y, B, T, mask_ptr, scale, p_state, state_seed, p_drop, seed, stream) -> bool:
         """tip_forward_dropout into `y`; False when the library does not serve this call that way (configuration, window length,
         demoted handle): the caller then runs tip_train_forward."""
         dev = xi.device
         if self._packed_dev is None or self._packed_dev.device != dev or (not self._frozen and self._packed_key != self._param_key(dev)):
             self.refresh_packed(dev)
         try:
-            ws = self._stream_buffer(self._workspace, dev, stream, h.workspace_bytes(B, T))
+            need = self._ws_bytes_cache.get((B, T))
+            if need is None:
+                need = self._ws_bytes_cache[(B, T)] = h.workspace_bytes(B, T)
+            ws = self._stream_buffer(self._workspace, dev, stream, need)
             h.forward_dropout(xi.data_ptr(), xs.data_ptr(), y.data_ptr(), B, T, _lib.TIP_FWD_KEEP_MASK if mask_ptr else 0, mask_ptr,
-                              scale, p_drop, seed, ws.data_ptr(), ws.numel(), stream)
+                              scale, p_state, state_seed, p_drop, seed, ws.data_ptr(), ws.numel(), stream)
         except _lib.TipHandoffError:
             raise
         except _lib.TipStatusError as e:
@@ -267,8 +276,12 @@ class TF_RNN_Past_State(nn.Module):
             return False
         if x_imu.dim() != 3 or x_s.dim() != 3 or x_imu.shape[:2] != x_s.shape[:2]:
             return False
-        plist = self._plist()
-        if any([p.dtype != pdt or not p.is_cuda for p in plist]):
+        sig = self._params_sig
+        if sig is None:   # (dtype, every parameter of that dtype on the GPU): recomputed after every _apply (.cuda(), .double(), ...)
+            plist = self._plist()
+            d0 = plist[0].dtype
+            sig = self._params_sig = (d0, all([p.dtype == d0 and p.is_cuda for p in plist]))
+        if not sig[1] or sig[0] != pdt or not self.in_linear.weight.is_cuda:
             return False
         key = (int(x_imu.shape[0]), int(x_imu.shape[1]), pdt)
         ok = self._train_ok_cache.get(key)
@@ -289,6 +302,13 @@ class TF_RNN_Past_State(nn.Module):
         saved, B, T = self.last_train_stash
         off, n = self._ensure_handle().train_saved_view(B, T, what, layer)
         return saved.view(torch.float32)[off:off + n].view(B * T, -1)
+
+    def _hash_keep_mask(self, x_s, state_seed: int):
+        """The past-state keep mask (:77) of (past_state_dropout, state_seed) as a tensor like x_s: tip_draw_keep_mask."""
+        m = torch.empty(x_s.shape, dtype=torch.float32, device=x_s.device)
+        with torch.cuda.device(x_s.device):
+            _lib.draw_keep_mask(self.past_state_dropout, state_seed, m.data_ptr(), m.numel(), torch.cuda.current_stream(x_s.device).cuda_stream)
+        return m if x_s.dtype == torch.float32 else m.to(x_s.dtype)
 
     def _draw_keep_mask(self, x_s):
         """Bernoulli keep-mask of the always-on past-state dropout (:77); None when p == 0."""
@@ -580,11 +600,14 @@ class _HipTrainFunction(torch.autograd.Function):
         f64 = pdt == torch.float64
         with torch.cuda.device(dev):
             xi, xs = x_imu.contiguous(), x_s.contiguous()
-            mask_ptr, scale = None, 1.0
-            if mask is not None:
-                pd = module.past_state_dropout
+            pd = module.past_state_dropout
+            mask_ptr, scale = None, (1.0 / (1.0 - pd) if pd < 1.0 else 0.0) if mask is not None else 1.0
+            state_seed = mask if isinstance(mask, int) else None     # the keep mask as (p, seed): drawn by the library
+            if state_seed is not None:
+                mask = None
+            elif mask is not None:
                 mask = mask.to(pdt).contiguous()
-                mask_ptr, scale = mask.data_ptr(), (1.0 / (1.0 - pd) if pd < 1.0 else 0.0)
+                mask_ptr = mask.data_ptr()
             y = torch.empty((B, T, module.size_s), dtype=pdt, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             saved = None
@@ -592,8 +615,12 @@ class _HipTrainFunction(torch.autograd.Function):
             # mode): the same function on the few-stream kernels (tip_forward_dropout: same dropout decisions, no activation stash,
             # ~0.2 ms instead of ~0.8 at one window per CU).  If .backward() is called after all, the stash is produced then.
             lazy = (not f64 and B <= module.LAZY_STASH_MAX_BATCH and not module.keep_train_stash
-                    and module._forward_dropout_hip(h, xi, xs, y, B, T, mask_ptr, scale, p_drop, seed, stream))
+                    and module._forward_dropout_hip(h, xi, xs, y, B, T, mask_ptr, scale, pd if state_seed is not None else 0.0,
+                                                    state_seed or 0, p_drop, seed, stream))
             if not lazy:
+                if state_seed is not None:
+                    mask = module._hash_keep_mask(xs, state_seed)
+                    mask_ptr = mask.data_ptr()
                 saved_bytes, _ = h.train_bytes(B, T, fp64=f64)
                 saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
                 pc = [p.detach().contiguous() for p in params]
@@ -601,7 +628,7 @@ class _HipTrainFunction(torch.autograd.Function):
                                 y.data_ptr(), saved.data_ptr(), saved.numel(), B, T, stream, fp64=f64)
         ctx.module, ctx.dims, ctx.p_drop, ctx.seed, ctx.f64 = module, (B, T), p_drop, seed, f64
         ctx.saved_stash = saved
-        ctx.lazy_inputs = (xi, xs, mask, scale) if lazy else None
+        ctx.lazy_inputs = (xi, xs, mask if state_seed is None else state_seed, scale) if lazy else None
         if module.keep_train_stash:
             module.last_train_stash = (saved, B, T)
         ctx.save_for_backward(*params)
@@ -622,6 +649,8 @@ class _HipTrainFunction(torch.autograd.Function):
                 # the forward ran without a stash (few windows, tip_forward_dropout): produce it now — tip_train_forward with the same
                 # inputs, keep mask, dropout probability and seed evaluates the same function with the same keep decisions
                 xi, xs, mask, scale = ctx.lazy_inputs
+                if isinstance(mask, int):
+                    mask = module._hash_keep_mask(xs, mask)
                 saved_bytes, _ = h.train_bytes(B, T, fp64=f64)
                 saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
                 y2 = torch.empty((B, T, module.size_s), dtype=pdt, device=dev)
