@@ -25,7 +25,7 @@ extern "C" {
 
 #define TIP_ABI_VERSION 3 /* 2: packed image without the exploratory split-fp16 section unless asked for (TIP_CREATE_S16, tip_create_ex);
                              tip_max_batch; export list = this header (+ tip_hip_debug.h), everything else hidden
-                             3: tip_forward_dropout, tip_draw_keep_mask; plan 9 (persistent latency kernel) and its 1 KiB of sync words in the packed image
+                             3: tip_forward_dropout, tip_draw_keep_mask, tip_train_input_grads; plan 9 (persistent latency kernel) and its 1 KiB of sync words in the packed image
                              removed; TIP_OPT_FUSE_HEAD reserved */
 
 /* The library is built with -fvisibility=hidden: the functions declared here (and the measurement hooks of
@@ -297,6 +297,14 @@ TIP_API int tip_train_forward(tip_handle* h, const float* const* params, int n_p
 TIP_API int tip_train_backward(tip_handle* h, const float* const* params, int n_params, const float* dy, const void* saved,
                        size_t saved_bytes, void* scratch, size_t scratch_bytes, float* grads, size_t grads_floats, float p_drop,
                        unsigned long long seed, int B, int T, tip_stream_t stream);
+
+/* Gradients w.r.t. the step's INPUTS, to be called right after tip_train_backward on the same scratch (which still holds the gradient
+ * w.r.t. in_linear's output): dx_imu [B,T,input_size_imu(+18)] and / or dx_s [B,T,size_s] (either may be NULL).  x_s, keep_mask and
+ * keep_scale as given to tip_train_forward: d x_s carries the keep mask and is zero where x_s was NaN (:65) and in the root-velocity
+ * columns (:75). */
+TIP_API int tip_train_input_grads(tip_handle* h, const float* const* params, int n_params, const float* x_s, const float* keep_mask,
+                          float keep_scale, void* scratch, size_t scratch_bytes, float* dx_imu, float* dx_s, int B, int T,
+                          tip_stream_t stream);
 
 /* ---- the same step for a module built under `--double` (train_model.py:84-85): fp64 parameters (raw, state-dict order), windows,
  *      keep mask, cotangent and gradients; same dropout decisions as the fp32 step for the same seed (kept values scaled by the fp32

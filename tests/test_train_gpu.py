@@ -418,3 +418,108 @@ def test_few_window_train_mode_forward_runs_without_a_stash(B, T):
         y2 = m(xi, xs).cpu().numpy()
     assert np.abs(y2 - y_fast).max() > 1e-3
     m.check_handoffs()
+
+
+def _fp64_copy(m):
+    """The module's torch-op composite in fp64 (same parameters, same training flag): the reference of the two tests below."""
+    import copy
+    handle, m._handle = m._handle, None            # (the ctypes handle does not deep-copy; the copy never calls the library)
+    try:
+        m64 = copy.deepcopy(m)
+    finally:
+        m._handle = handle
+    m64 = m64.double()
+    m64.ENCODER_DROPOUT = m.ENCODER_DROPOUT
+    m64.train(m.training)
+    m64.zero_grad(set_to_none=True)
+    return m64
+
+
+@pytest.mark.parametrize("B,last", [(5, False), (5, True), (70, False), (256, True)])
+def test_eval_mode_backward_runs_on_the_hip_training_step(B, last):
+    """VERDICT r04 missing #5: an .eval()-mode call with autograd enabled (what the reference's runners make) keeps the inference
+    kernels for its values — bit-identical to the no_grad call — and a .backward() through it is the HIP training step with dropout
+    off (stash produced then), not the torch-op composite: gradients agree with the composite's to fp32 rounding."""
+    cfg = synth.PAPER
+    m = make_model(cfg, p_state=0.5)
+    load_synth(m, cfg, 0)
+    m = m.cuda().eval()
+    x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=300 + B, nan_frac=0.02)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    m.keep_train_stash = True                         # (the backward's stash stays readable: ReLU gates for the reference)
+    f = (lambda: m.forward_last(xi, xs)) if last else (lambda: m(xi, xs))
+    torch.manual_seed(5)
+    with torch.no_grad():
+        y_ng = f()
+    torch.manual_seed(5)
+    y = f()
+    assert type(y.grad_fn).__name__.startswith("_HipForwardHipBackward"), type(y.grad_fn).__name__
+    assert torch.equal(y.detach(), y_ng)
+    cot = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).cuda()
+    m.zero_grad(set_to_none=True)
+    (y * cot).sum().backward()
+    g_hip = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    # reference: the torch-op composite in fp64 with the same keep mask
+    torch.manual_seed(5)
+    mask = m._draw_keep_mask(xs)
+    m64 = _fp64_copy(m)
+    gates = [torch.tensor(g).cuda() for g in _gates(m, cfg, B, 40)]           # the run's own ReLU gates (see _forward_torch_ops)
+    y2 = m64._forward_torch_ops(xi.double(), xs.double(), keep_mask=mask.double(), relu_gates=gates)
+    y2 = y2[:, -1] if last else y2
+    assert (y2.detach() - y_ng.double()).abs().max() < 2e-5
+    (y2 * cot.double()).sum().backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), m64.named_parameters()):
+        ref = q.grad
+        err = (g_hip[k].double() - ref).norm() / (ref.norm() + 1e-30)
+        assert err < REL, (k, float(err))
+    m.check_handoffs()
+
+
+@pytest.mark.parametrize("B,train", [(4, True), (40, True), (256, True), (6, False), (70, False)])
+def test_input_gradients_run_on_the_hip_step(B, train):
+    """VERDICT r04 missing #5: gradients w.r.t. x_imu / x_s (tip_train_input_grads: one more GEMM behind tip_train_backward) instead
+    of the torch-op composite — .train() mode (encoder dropout off here, so that the composite is comparable; past-state dropout live)
+    and .eval() mode.  d x_s is zero where x_s was NaN and in the root-velocity columns, and carries the keep mask."""
+    cfg = synth.PAPER
+    m = make_model(cfg, p_state=0.5)
+    load_synth(m, cfg, 0)
+    m = m.cuda()
+    m = m.train() if train else m.eval()
+    m.ENCODER_DROPOUT = 0.0
+    m.keep_train_stash = True                         # (ReLU gates for the reference; also keeps a few-window call on the stash path)
+    x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=500 + B, nan_frac=0.03)
+    xi = torch.tensor(x_imu).cuda().requires_grad_(True)
+    xs = torch.tensor(x_s).cuda().requires_grad_(True)
+    cot = torch.randn(B, 40, cfg["size_s"], generator=torch.Generator().manual_seed(2)).cuda()
+    torch.manual_seed(11)
+    n0 = m.hip_forward_count()
+    y = m(xi, xs)
+    assert m.hip_forward_count() > n0 and type(y.grad_fn).__name__.startswith("_Hip"), type(y.grad_fn).__name__
+    m.zero_grad(set_to_none=True)
+    (y * cot).sum().backward()
+    g_hip = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    dxi_hip, dxs_hip = xi.grad.clone(), xs.grad.clone()
+    # the same function through the torch-op composite with the same keep mask
+    torch.manual_seed(11)
+    if train:
+        seeds = torch.randint(0, 2 ** 62, (2,), dtype=torch.int64).tolist()
+        mask = m._hash_keep_mask(xs.detach(), seeds[1])
+    else:
+        mask = m._draw_keep_mask(xs.detach())
+    xi2 = xi.detach().double().requires_grad_(True)
+    xs2 = xs.detach().double().requires_grad_(True)
+    m64 = _fp64_copy(m)
+    gates = [torch.tensor(g).cuda() for g in _gates(m, cfg, B, 40)]
+    y2 = m64._forward_torch_ops(xi2, xs2, keep_mask=mask.double(), relu_gates=gates)      # fp64 reference, the run's own ReLU gates
+    assert (y2.detach() - y.detach().double()).abs().max() < 2e-5
+    (y2 * cot.double()).sum().backward()
+    for name, a, b in (("x_imu", dxi_hip, xi2.grad), ("x_s", dxs_hip, xs2.grad)):
+        err = (a.double() - b).norm() / (b.norm() + 1e-30)
+        assert err < REL, (name, float(err))
+    nan = torch.isnan(xs.detach())
+    assert nan.any() and (dxs_hip[nan] == 0).all() and (dxs_hip[..., 108:111] == 0).all()
+    for (k, p), (_, q) in zip(m.named_parameters(), m64.named_parameters()):
+        ref = q.grad
+        err = (g_hip[k].double() - ref).norm() / (ref.norm() + 1e-30)
+        assert err < REL, (k, float(err))
+    m.check_handoffs()

@@ -1,3 +1,1 @@
-mkdir -p gpurun_out/r05e
-python -m pytest tests -m gpu -x -q > gpurun_out/r05e/gputests.log 2>&1; echo "pytest rc=$?"; tail -6 gpurun_out/r05e/gputests.log
-bash tools/_run_d.sh 2>&1 | grep -v "^model\|^number" | head -12
+python -m pytest tests/test_train_gpu.py -x -q -k "input_gradients or eval_mode_backward" 2>&1 | grep -E "^E|passed|failed|assert" | head

@@ -1214,6 +1214,26 @@ __global__ __launch_bounds__(256) void prep_rnn_kernel(const float* __restrict__
     }
 }
 
+// dU [M][InPad] -> d x_imu [M][NI], d x_s [M][S] (see tip_train_input_grads)
+__global__ __launch_bounds__(256) void input_grads_kernel(const float* __restrict__ dU, const float* __restrict__ x_s,
+                                                          const float* __restrict__ mask, float scale, float* __restrict__ dx_imu,
+                                                          float* __restrict__ dx_s, long long M, int NI, int S, int InPad) {
+    const int In = NI + S;
+    const long long total = M * In;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / In;
+        const int c = (int)(i - m * In);
+        const float g = dU[m * InPad + c];
+        if (c < NI) {
+            if (dx_imu) dx_imu[m * NI + c] = g;
+        } else if (dx_s) {
+            const long long j = m * S + (c - NI);
+            const float xv = x_s[j];
+            dx_s[j] = (xv != xv) ? 0.f : (mask ? g * mask[j] * scale : g);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, int n, float* __restrict__ dst, int npad, long long rows) {
     const long long total = rows * npad;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -2048,6 +2068,34 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
                        grads + goff[P_IN_W], grads + goff[P_IN_B], d.D, d.H, d.In, d.InPad, d.n_imu_total + d.rootv0,
                        d.n_imu_total + d.rootv1);
     TT(hipGetLastError(), "bwd_finish_in");
+    return TIP_OK;
+}
+
+// Gradients w.r.t. the INPUTS of the step (simple_transformer_with_state.py:63-79 backwards): dU = dx0 W_in' with dx0 = the gradient
+// w.r.t. in_linear's output that tip_train_backward leaves in its scratch and W_in' = in_linear's weight with the channel shuffle
+// folded into its rows and the root-velocity columns (:75) zeroed; d x_imu = dU[:, :n_imu], d x_s = dU[:, n_imu:] * keep_mask *
+// keep_scale, zero where x_s was NaN (:65 overwrites those entries).
+int tip_train_input_grads(tip_handle* h, const float* const* params, int n_params, const float* x_s, const float* keep_mask,
+                          float keep_scale, void* scratch, size_t scratch_bytes, float* dx_imu, float* dx_s, int B, int T, void* stream) {
+    if (!h || !params || !x_s || !scratch || (!dx_imu && !dx_s)) return TIP_ERR_INVALID_ARG;
+    if (n_params != (int)h->tensor_names.size()) return TIP_ERR_INVALID_ARG;
+    const Dims& d = h->d;
+    if (!train_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    g_tgemm_cus = h->num_cus;
+    const TrainScratch S = scratch_layout(d, B, T);
+    if (reinterpret_cast<uintptr_t>(scratch) % 256 || scratch_bytes < S.total * sizeof(float)) return TIP_ERR_WORKSPACE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* X = static_cast<float*>(scratch);
+    const int M = B * T;
+    // W_in' [D][InPad] into the (consumed) partial-dW_in area, dU [M][InPad] into the (free) wide gradient buffer
+    hipLaunchKernelGGL(prep_in_kernel, dim3(grid_for((long long)d.D * d.InPad)), dim3(256), 0, s, params[P_IN_W], params[P_IN_B],
+                       X + S.dwin_p, X + S.dbin_p, d.D, d.H, d.In, d.InPad, d.n_imu_total + d.rootv0, d.n_imu_total + d.rootv1);
+    TT(hipGetLastError(), "input_grads_prep");
+    TG g = tg_base(X + S.ga, d.D, X + S.dwin_p, d.InPad, X + S.gbig, d.InPad, M, d.InPad, d.D);
+    TT((tgemm_launch<0, 1>(g, 1, s)), "input_grads_gemm");
+    hipLaunchKernelGGL(input_grads_kernel, dim3(grid_for((long long)M * d.In)), dim3(256), 0, s, X + S.gbig, x_s, keep_mask,
+                       keep_mask ? keep_scale : 1.f, dx_imu, dx_s, (long long)M, d.n_imu_total, d.S, d.InPad);
+    TT(hipGetLastError(), "input_grads_split");
     return TIP_OK;
 }
 

@@ -37,7 +37,7 @@ EXPORTS = (
     "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
     "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_max_batch", "tip_forward", "tip_forward_dropout", "tip_draw_keep_mask", "tip_forward_f64_bytes", "tip_forward_f64", "tip_forward_count", "tip_profile_read",
     "tip_spin_timeouts", "tip_check", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
-    "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward",
+    "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward", "tip_train_input_grads",
     "tip_train_bytes_f64", "tip_train_forward_f64", "tip_train_backward_f64",
     "tip_combine_frames", "tip_combine_scratch_bytes", "tip_combine_sequence", "tip_gather_windows",
     "tip_loss_ws_bytes", "tip_loss_forward", "tip_loss_backward", "tip_loss_forward_f64", "tip_loss_backward_f64",
@@ -117,6 +117,7 @@ def load() -> ctypes.CDLL:
     lib.tip_forward_dropout.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, ctypes.c_float,
                                         ctypes.c_uint64, vp, sz, vp]
     lib.tip_draw_keep_mask.argtypes = [ctypes.c_float, ctypes.c_uint64, vp, sz, vp]
+    lib.tip_train_input_grads.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, ctypes.c_float, vp, sz, vp, vp, i32, i32, vp]
     lib.tip_forward_f64_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz)]
     lib.tip_forward_f64.argtypes = [vp, ctypes.POINTER(vp), i32, vp, vp, vp, i32, i32, i32, vp, ctypes.c_double, vp, sz, vp]
     lib.tip_forward_count.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
@@ -231,6 +232,13 @@ class Handle:
                 keep_scale: float, workspace: int, workspace_bytes: int, stream: int):
         self._check(self.lib.tip_forward(self._h, x_imu, x_s, y, B, T, flags, keep_mask, keep_scale, workspace,
                                          workspace_bytes, stream))
+
+    def train_input_grads(self, param_ptrs, x_s: int, keep_mask: Optional[int], keep_scale: float, scratch: int, scratch_bytes: int,
+                          dx_imu: Optional[int], dx_s: Optional[int], B: int, T: int, stream: int):
+        """tip_train_input_grads: right after train_backward on the same scratch."""
+        arr = (ctypes.c_void_p * len(param_ptrs))(*param_ptrs)
+        self._check(self.lib.tip_train_input_grads(self._h, arr, len(param_ptrs), x_s, keep_mask, keep_scale, scratch, scratch_bytes,
+                                                   dx_imu, dx_s, B, T, stream))
 
     def forward_dropout(self, x_imu: int, x_s: int, y: int, B: int, T: int, flags: int, keep_mask: Optional[int], keep_scale: float,
                         p_state: float, state_seed: int, p_drop: float, seed: int, workspace: int, workspace_bytes: int, stream: int):

@@ -235,9 +235,14 @@ class TF_RNN_Past_State(nn.Module):
             return y[:, -1] if last_row_only else y
         if not needs_grad:
             return self._forward_hip(x_imu, x_s, last_row_only)
-        # eval mode, autograd on: HIP forward, torch-op recompute in backward
+        # eval mode, autograd on (the runners never enter no_grad): the values come from the inference kernels, exactly as under
+        # no_grad; a .backward() — if it ever comes — runs the HIP training step on the saved inputs with dropout off (activation
+        # stash produced then), or differentiates the torch-op composite where the HIP step does not apply (input gradients,
+        # unsupported widths)
         xi = F.dropout(x_imu, self.in_dropout, training=True) if self.in_dropout > 0.0 else x_imu   # :73
         mask = self._draw_keep_mask(x_s)
+        if self._hip_train_ok(xi, x_s):
+            return _HipForwardHipBackward.apply(self, last_row_only, xi, x_s, mask, *plist)
         return _HipForwardTorchBackward.apply(self, last_row_only, xi, x_s, mask, *plist)
 
     LAZY_STASH_MAX_BATCH = 32   # .train()-mode calls of up to this many windows run without an activation stash (see _HipTrainFunction)
@@ -272,8 +277,10 @@ class TF_RNN_Past_State(nn.Module):
         pdt = self.in_linear.weight.dtype
         if pdt not in (torch.float32, torch.float64):
             return False
-        if x_imu.requires_grad or x_s.requires_grad or x_imu.dtype != pdt or x_s.dtype != pdt:
+        if x_imu.dtype != pdt or x_s.dtype != pdt:
             return False
+        if (x_imu.requires_grad or x_s.requires_grad) and pdt != torch.float32:
+            return False          # gradients w.r.t. the inputs: tip_train_input_grads (fp32 step only)
         if x_imu.dim() != 3 or x_s.dim() != 3 or x_imu.shape[:2] != x_s.shape[:2]:
             return False
         sig = self._params_sig
@@ -545,7 +552,10 @@ class TF_RNN_Past_State(nn.Module):
         return y
 
     # -- torch-op composite (autograd / training) -----------------------------------------------
-    def _forward_torch_ops(self, x_imu, x_s, keep_mask="draw", apply_in_dropout=True):
+    def _forward_torch_ops(self, x_imu, x_s, keep_mask="draw", apply_in_dropout=True, relu_gates=None):
+        """relu_gates (tests): per layer a [B,T,tf_hid_size] boolean tensor — the hidden units' gates are TAKEN from it instead of from
+        the sign of the pre-activation (a unit within rounding of zero is open in one implementation and shut in another; one such
+        flip moves a weight gradient by ~1e-3 relative: comparisons of gradients fix the gates)."""
         B, T = x_imu.shape[0], x_imu.shape[1]
         D, H = self.tf_in_dim, self.n_heads
         dh = D // H
@@ -561,14 +571,15 @@ class TF_RNN_Past_State(nn.Module):
         z = F.linear(torch.cat((xi, s), dim=2), self.in_linear.weight, self.in_linear.bias)
         z = z.reshape(B, T, H, dh).transpose(2, 3).reshape(B, T, D)      # :88-89 (batch-first view of the same shuffle)
         pdrop = self.ENCODER_DROPOUT if self.training else 0.0   # torch default inside nn.TransformerEncoderLayer
-        for layer in self.tf_encode.layers:
+        for li, layer in enumerate(self.tf_encode.layers):
             qkv = F.linear(z, layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias)
             q, k, v = (t.reshape(B, T, H, dh).transpose(1, 2) for t in qkv.split(D, dim=2))
             a = F.scaled_dot_product_attention(q, k, v, dropout_p=pdrop, is_causal=True)
             a = a.transpose(1, 2).reshape(B, T, D)
             a = F.linear(a, layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias)
             z = F.layer_norm(z + F.dropout(a, pdrop, self.training), (D,), layer.norm1.weight, layer.norm1.bias, 1e-5)
-            f = F.relu(F.linear(z, layer.linear1.weight, layer.linear1.bias))
+            f = F.linear(z, layer.linear1.weight, layer.linear1.bias)
+            f = F.relu(f) if relu_gates is None else f * relu_gates[li].to(f.dtype)
             f = F.linear(F.dropout(f, pdrop, self.training), layer.linear2.weight, layer.linear2.bias)
             z = F.layer_norm(z + F.dropout(f, pdrop, self.training), (D,), layer.norm2.weight, layer.norm2.bias, 1e-5)
         if self.rnn is not None:
@@ -580,6 +591,22 @@ class TF_RNN_Past_State(nn.Module):
                 hs.append(hcur)
             z = torch.stack(hs, dim=1)
         return F.linear(z, self.linear.weight, self.linear.bias)
+
+
+def _hip_input_grads(module, h, want_imu, want_s, bwd_inputs, pc, scratch, B, T, stream):
+    """d x_imu, d x_s of the step that tip_train_backward has just differentiated on `scratch` (tip_train_input_grads)."""
+    if not (want_imu or want_s):
+        return None, None
+    xs, mask, scale = bwd_inputs
+    if isinstance(mask, int):
+        mask = module._hash_keep_mask(xs, mask)
+    n_imu = module.input_size_imu + (18 if module.with_acc_sum else 0)
+    dxi = torch.empty((B, T, n_imu), dtype=torch.float32, device=xs.device) if want_imu else None
+    dxs = torch.empty((B, T, module.size_s), dtype=torch.float32, device=xs.device) if want_s else None
+    h.train_input_grads([p.data_ptr() for p in pc], xs.data_ptr(), mask.data_ptr() if mask is not None else None, scale,
+                        scratch.data_ptr(), scratch.numel(), dxi.data_ptr() if want_imu else None, dxs.data_ptr() if want_s else None,
+                        B, T, stream)
+    return dxi, dxs
 
 
 class _HipTrainFunction(torch.autograd.Function):
@@ -629,6 +656,8 @@ class _HipTrainFunction(torch.autograd.Function):
         ctx.module, ctx.dims, ctx.p_drop, ctx.seed, ctx.f64 = module, (B, T), p_drop, seed, f64
         ctx.saved_stash = saved
         ctx.lazy_inputs = (xi, xs, mask if state_seed is None else state_seed, scale) if lazy else None
+        # what gradients w.r.t. the inputs need (tip_train_input_grads): x_s (NaN positions), the keep mask (tensor, or its seed), its scale
+        ctx.bwd_inputs = (xs, mask if mask is not None else state_seed, scale) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
         if module.keep_train_stash:
             module.last_train_stash = (saved, B, T)
         ctx.save_for_backward(*params)
@@ -671,13 +700,72 @@ class _HipTrainFunction(torch.autograd.Function):
             h.train_backward([p.data_ptr() for p in pc], g.data_ptr(), saved.data_ptr(), saved.numel(),
                              scratch.data_ptr(), scratch.numel(), flat.data_ptr(), total,
                              ctx.p_drop, ctx.seed, B, T, stream, fp64=f64)
+            dxi, dxs = _hip_input_grads(module, h, ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.bwd_inputs, pc, scratch, B, T, stream)
         ctx.saved_stash = None
         out, off = [], 0
         for i, p in enumerate(params):
             n = p.numel()
             out.append(flat[off:off + n].view(p.shape) if ctx.needs_input_grad[6 + i] else None)
             off += n
-        return (None, None, None, None, None, None, *out)
+        return (None, dxi, dxs, None, None, None, *out)
+
+
+class _HipForwardHipBackward(torch.autograd.Function):
+    """.eval()-mode forward with autograd enabled, configurations the HIP training step covers: forward = the inference kernels
+    (bit-identical to the no_grad call); backward = tip_train_forward (p_drop = 0: the same function, activations stashed) +
+    tip_train_backward on the saved inputs and keep mask.  The extra forward is paid only when .backward() is really called."""
+
+    @staticmethod
+    def forward(ctx, module, last_row_only, x_imu, x_s, mask, *params):
+        ctx.module, ctx.last = module, last_row_only
+        ctx.inputs = (x_imu.contiguous(), x_s.contiguous(), mask)
+        ctx.save_for_backward(*params)
+        with torch.no_grad():
+            return module._forward_hip(x_imu, x_s, last_row_only, keep_mask=mask, apply_in_dropout=False)
+
+    @staticmethod
+    def backward(ctx, gy):
+        module = ctx.module
+        params = ctx.saved_tensors
+        xi, xs, mask = ctx.inputs
+        h = module._ensure_handle()
+        dev = gy.device
+        B, T = int(xi.shape[0]), int(xi.shape[1])
+        pdt = xi.dtype
+        f64 = pdt == torch.float64
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            mask_ptr, scale = None, 1.0
+            if mask is not None:
+                pd = module.past_state_dropout
+                mask = mask.to(pdt).contiguous()
+                mask_ptr, scale = mask.data_ptr(), (1.0 / (1.0 - pd) if pd < 1.0 else 0.0)
+            saved_bytes, scratch_bytes = h.train_bytes(B, T, fp64=f64)
+            saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
+            y2 = torch.empty((B, T, module.size_s), dtype=pdt, device=dev)
+            pc = [p.detach().contiguous() for p in params]
+            ptrs = [p.data_ptr() for p in pc]
+            h.train_forward(ptrs, xi.data_ptr(), xs.data_ptr(), mask_ptr, scale, 0.0, 0, y2.data_ptr(), saved.data_ptr(), saved.numel(),
+                            B, T, stream, fp64=f64)
+            if module.keep_train_stash:
+                module.last_train_stash = (saved, B, T)
+            if ctx.last:      # the cotangent of row T-1 only: zero everywhere else
+                g = torch.zeros((B, T, module.size_s), dtype=pdt, device=dev)
+                g[:, -1] = gy.to(pdt)
+            else:
+                g = gy.to(pdt).contiguous()
+            scratch = module._stream_buffer(module._train_scratch, dev, stream, scratch_bytes)
+            total = sum(p.numel() for p in params)
+            flat = torch.empty(total, dtype=pdt, device=dev)
+            h.train_backward(ptrs, g.data_ptr(), saved.data_ptr(), saved.numel(), scratch.data_ptr(), scratch.numel(), flat.data_ptr(),
+                             total, 0.0, 0, B, T, stream, fp64=f64)
+            dxi, dxs = _hip_input_grads(module, h, ctx.needs_input_grad[2], ctx.needs_input_grad[3], (xs, mask, scale), pc, scratch, B, T, stream)
+        out, off = [], 0
+        for i, p in enumerate(params):
+            n = p.numel()
+            out.append(flat[off:off + n].view(p.shape) if ctx.needs_input_grad[5 + i] else None)
+            off += n
+        return (None, None, dxi, dxs, None, *out)
 
 
 class _HipForwardTorchBackward(torch.autograd.Function):
