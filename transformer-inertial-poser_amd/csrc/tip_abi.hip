@@ -225,7 +225,7 @@ namespace {
 struct DevSerialState {
     std::mutex mu;
     hipStream_t last = nullptr;
-    bool have = false, multi = false;
+    bool have = false;
     hipEvent_t ev = nullptr;
 };
 DevSerialState g_serial[kMaxDevices];
@@ -236,29 +236,21 @@ CoopSerial::CoopSerial(int device, hipStream_t s)
     DevSerialState& st = g_serial[dev];
     st.mu.lock();
     if (capturing) return;   // see stream_is_capturing (tip_internal.h)
-    if (st.have && st.last != s) {
-        if (!st.ev) status = hipEventCreateWithFlags(&st.ev, hipEventDisableTiming);
-        if (status == hipSuccess && !st.multi) {
-            // first stream switch on this device: put an event behind the previous stream's work now (nothing was recorded while
-            // the process used one stream).  No device-wide drain: hipDeviceSynchronize fails — and invalidates the capture —
-            // when any other stream is mid-capture.  If the previous stream no longer exists, its handle is dead: drain instead.
-            if (hipEventRecord(st.ev, st.last) != hipSuccess) {
-                (void)hipGetLastError();
-                status = hipDeviceSynchronize();
-            } else {
-                status = hipStreamWaitEvent(s, st.ev, 0);
-            }
-            if (status == hipSuccess) st.multi = true;
-        } else if (status == hipSuccess) {
-            status = hipStreamWaitEvent(s, st.ev, 0);
-        }
-    }
+    // The event is recorded at the END of every forward (destructor), on the stream that forward ran on — known to be alive then.  A
+    // stream switch therefore only waits on the event: it never touches the previous stream's handle, which may have been destroyed
+    // (or recycled) by now (hipEventRecord on a dangling hipStream_t is undefined behaviour), and it cannot pull this
+    // stream into another stream's capture.
+    if (st.have && st.last != s && st.ev) status = hipStreamWaitEvent(s, st.ev, 0);
 }
 
 CoopSerial::~CoopSerial() {
     DevSerialState& st = g_serial[dev];
     if (!capturing) {
-        if (st.multi) (void)hipEventRecord(st.ev, stream);
+        if (!st.ev && hipEventCreateWithFlags(&st.ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            st.ev = nullptr;
+        }
+        if (st.ev) (void)hipEventRecord(st.ev, stream);
         st.last = stream;
         st.have = true;
     }
@@ -717,7 +709,9 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     // window's result is bit-identical to what its part's plan gives on its own (tests/test_benchmarked_shapes_gpu.py).
     // Costs in us from profiles/r04/plan_bench_split.txt (B = 256 step 0.625 ms; the remainder's latency-plan forward measured
     // 163 / 177 / 201 / 282 / 372 us for 1 / 8 / 16 / 32 / 44 windows behind it); TIP_AUTO_SPLIT=0 disables (measurement).
-    if (h->plan == TIP_PLAN_AUTO && !h->demoted && cus == h->num_cus && B > cus && fused_supported(d, T) && fused_has_rnn_ih(d)) {
+    // (the cost model below is calibrated at T = 40 — the only window length the window-split plans serve — and its constants scale
+    // with the CU count only through `cus`, which is the device's: other window lengths take whole rounds)
+    if (h->plan == TIP_PLAN_AUTO && !h->demoted && cus == h->num_cus && B > cus && T == 40 && fused_supported(d, T) && fused_has_rnn_ih(d)) {
         static const bool split_on = !(tip_env("TIP_AUTO_SPLIT") && tip_env("TIP_AUTO_SPLIT")[0] == '0');
         const int r = B % cus, bm = B - r;
         // what the remainder costs on its own (us; AUTO's choice for that many windows, below): the latency plan up to 32 windows
@@ -734,7 +728,10 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
                 const long long enc = (fused2_supported(d, T) && r2 * 1049 < rh * 527) ? r2 * 1049 : rh * 527;
                 return enc + 96 * rh;
             };
-            if (single(bm) + rem < single(B)) {
+            // (a part never needs more workspace than the whole — carve_workspace is monotone, tests/test_host_cpu.py — but a caller's
+            // buffer sized by an older library must fall through to the single launch sequence, not fail)
+            if (single(bm) + rem < single(B) && carve_workspace(d, bm, T).total_bytes <= workspace_bytes &&
+                carve_workspace(d, r, T).total_bytes <= workspace_bytes) {
                 const size_t row_i = (size_t)T * d.n_imu_total, row_s = (size_t)T * d.S;
                 const size_t row_y = (flags & TIP_FWD_LAST_ROW_ONLY) ? (size_t)d.S : row_s;
                 const uint64_t count0 = h->forward_count;

@@ -102,13 +102,11 @@ class TrainSubDataset(torch.utils.data.Dataset):
         self._setup(seq_length, infos, with_acc_sum)
         self.IMU_c = self.S_c = self.SUM_c = None
         self.device = torch.device(device) if device is not None else None
-        if self.device is not None:
-            if self.device.type != "cuda":
-                raise RuntimeError("tip_amd.data.TrainSubDataset: device must be a GPU (or None for the host item protocol only)")
-            up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
-            self.IMU_c, self.S_c = up(IMU_c), up(S_c)
-            self.SUM_c = up(SUM_c) if SUM_c is not None else None
-            self.ends = self.ends.to(self.device)
+        if self.device is not None and self.device.type != "cuda":
+            raise RuntimeError("tip_amd.data.TrainSubDataset: device must be a GPU (or None for the host item protocol only)")
+        # The combined arrays go to HBM on the FIRST batch() call, not here: the unedited DataLoader loop of
+        # train_model.py builds one dataset per epoch and only ever uses the host item protocol (__getitem__ on the memory maps) — an
+        # eager upload was a full read of the files, an H2D copy and several GB of HBM per epoch for nothing.
         # the reference prints the shapes of the windows it materialised (:67-70); same lines, nothing materialised
         n, T = self.size
         print("load time", time.time() - start_time)
@@ -154,6 +152,12 @@ class TrainSubDataset(torch.utils.data.Dataset):
 
     def batch(self, index) -> "tuple[torch.Tensor, torch.Tensor, torch.Tensor]":
         """(x_imu [n,T,72(+18)], x_s [n,T,131], y [n,T,131]) for a list / tensor of sample indices: one gather kernel."""
+        if self.IMU_c is None and self._host is not None and self.device is not None:
+            IMU_c, SUM_c, S_c = self._host     # first use: upload the memory-mapped arrays once
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)   # noqa: E731
+            self.IMU_c, self.S_c = up(IMU_c), up(S_c)
+            self.SUM_c = up(SUM_c) if SUM_c is not None else None
+            self.ends = self.ends.to(self.device)
         if self.IMU_c is None:
             raise RuntimeError("tip_amd.data.TrainSubDataset.batch: the combined arrays are not in HBM (constructed with "
                                "device=None or without a GPU); there is no CPU gather")
