@@ -696,7 +696,9 @@ def main():
             torch.cuda.synchronize()
         for _ in range(args.warmup):
             y = step()
-        model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=2)   # event pair around the dominant kernel
+        # event pair around the dominant kernel of every FOURTH step (TIP_OPT_PROFILE = 3): a pair on every launch costs ~7 us of
+        # queue barriers per step (0.624 vs 0.631 ms, profiles/r05), which is measurement overhead, not forward time
+        model.set_plan(args.plan, rnn_cluster=args.rnn_cluster, profile=3)
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -744,7 +746,8 @@ def main():
                         # tools/collect_profiles.sh's last collection (same kernel, same batch)
                         "traffic_source": "profiles/traffic.json (stored: rocprofv3 PMC passes of tools/collect_profiles.sh, not measured by this run)"
                         if traffic is not None else None,
-                        "avg_launch_ms": avg_ms, "launches_timed": launches, "flops_per_launch": fl}
+                        "avg_launch_ms": avg_ms, "launches_timed": launches, "flops_per_launch": fl,
+                        "sampling": "HIP event pair around every 4th launch of the kernel inside the timed region"}
 
     extra = {}
     if args.config == "paper256" and not args.no_extra:

@@ -103,8 +103,9 @@ typedef enum tip_status {
    than the launch chain at every batch size, removed in round 5): tip_set_option rejects it */
 
 #define TIP_OPT_PLAN        1
-#define TIP_OPT_PROFILE     2 /* 0 off; 1: bracket every stage with a HIP event pair; 2: only the dominant stage
-                                 (cheap enough for a timed region).  Setting it resets the accumulated times. */
+#define TIP_OPT_PROFILE     2 /* 0 off; 1: bracket every stage with a HIP event pair; 2: only the dominant stage; 3: the dominant
+                                 stage of every fourth forward (a pair costs ~7 us of queue barriers per step at B = 256: this is
+                                 the form a timed region carries).  Setting it resets the accumulated times. */
 #define TIP_OPT_RNN_CLUSTER 3 /* workgroups cooperating on one RNN window-tile (1,2,4,8,16); 0 = auto */
 #define TIP_RNN_CLUSTER_ROWS4 0x44 /* TIP_OPT_RNN_CLUSTER value: 4-window tiles on 4-workgroup clusters (4x4x1 MFMAs; rnn_hidden 512 only) */
 #define TIP_OPT_FAULT_INJECT 4 /* TESTS ONLY.  Bit 0: the pair-split encoder drops one workgroup of pair 0; bit 1: the clustered
