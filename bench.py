@@ -471,34 +471,6 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
                                                         "one graph launch per frame; bit-identical outputs (tests/test_streaming_gpu.py)")
     except Exception as e:
         out["stream1_closed_loop"] = {"error": f"{type(e).__name__}: {e}"}
-    # -- EXPLORATORY, never the headline: plan "fused16" (csrc/tip_s16.hip) — the same forward with every GEMM's fp32 operands
-    #    emulated on the fp16 matrix cores (operands split hi + lo * 2^-11 = 22 significant bits, three f16 MFMAs per product, fp32
-    #    accumulation; attention core / LayerNorm / residual stream in fp32).  Reported with its own dtype label, its error against
-    #    the fp64 oracle next to the fp32-MFMA plan's on the same windows, and the timing of both on this run's clock.
-    try:
-        from oracle import oracle as _oracle
-        x256i, x256s = xi[:256].contiguous(), xs[:256].contiguous()
-        res = {"dtype": "f32 emulated as split fp16 (hi + lo * 2^-11: 22-bit operands), fp32 accumulate; attention / LayerNorm / residual fp32",
-               "batch": int(x256i.shape[0]), "T": T, "status": "opt-in plan (set_plan('fused16')), never chosen by AUTO"}
-        w_np = synth.make_weights(cfg, seed=0)
-        nref = 4
-        yo = _oracle.forward(cfg, w_np, x256i[:nref].cpu().numpy(), x256s[:nref].cpu().numpy(), dtype=np.float64)
-        for plan_name in ("fusedh", "fused16"):
-            model.set_plan(plan_name)
-            for _ in range(20):
-                model(x256i, x256s)
-            torch.cuda.synchronize()
-            ms = timed_loop(lambda: model(x256i, x256s), 200)
-            err = float(np.abs(model(x256i[:nref], x256s[:nref]).cpu().numpy() - yo).max())
-            key = "fp32_mfma_plan_fusedh" if plan_name == "fusedh" else "split_fp16_plan_fused16"
-            res[key] = {"ms_per_step": ms, "frames_per_s": x256i.shape[0] / (ms * 1e-3), "max_abs_err_vs_fp64_oracle": err}
-        res["speedup_vs_fp32_mfma_plan"] = res["fp32_mfma_plan_fusedh"]["ms_per_step"] / res["split_fp16_plan_fused16"]["ms_per_step"]
-        res["fp32_equivalent_tflops"] = res["split_fp16_plan_fused16"]["frames_per_s"] * fpw / 1e12
-        model.set_plan("auto")
-        out["exploratory_fused16"] = res
-    except Exception as e:
-        model.set_plan("auto")
-        out["exploratory_fused16"] = {"error": f"{type(e).__name__}: {e}"}
     # -- self-check: EVERY window of the headline batch against the same forward in fp64 ON THE DEVICE (tip_forward_f64: the module
     #    as train_model.py --double builds it; itself held to 1e-11 of the reference's fp64 outputs by tests/test_f64_gpu.py)
     try:
@@ -538,21 +510,6 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
         out["scaled_b512_t80"] = {"batch": Bs, "T": Ts, "ms_per_step": ms, "frames_per_s": Bs / (ms * 1e-3),
                                   "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(sc, Ts, Bs / (ms * 1e-3)),
                                   "tflops": Bs / (ms * 1e-3) * synth.flops_per_window(sc, Ts) / 1e12}
-        # EXPLORATORY, never the headline: the same forward with the big linears on split-fp16 operands (plan "general16")
-        try:
-            y32 = ms_model(si[:8], ss[:8])
-            ms_model.set_plan("general16")
-            ms_model(si, ss)
-            ms16 = timed_loop(lambda: ms_model(si, ss), 3)
-            y16 = ms_model(si[:8], ss[:8])
-            out["scaled_b512_t80"]["exploratory_general16"] = {
-                "dtype": "big linears: f32 emulated as split fp16 (22-bit operands), fp32 accumulate; everything else fp32",
-                "ms_per_step": ms16, "frames_per_s": Bs / (ms16 * 1e-3), "speedup_vs_fp32_mfma_plan": ms / ms16,
-                "fp32_equivalent_tflops": Bs / (ms16 * 1e-3) * synth.flops_per_window(sc, Ts) / 1e12,
-                "max_abs_diff_vs_fp32_plan_8_windows": float((y16 - y32).abs().max().item()), "max_abs_y": float(y32.abs().max().item())}
-            ms_model.set_plan("auto")
-        except Exception as e2:
-            out["scaled_b512_t80"]["exploratory_general16"] = {"error": f"{type(e2).__name__}: {e2}"}
         # -- configs[4] at its own batch on ONE GPU: B = 4096 as one call (the host runs it in chunks of at most tip_max_batch
         #    windows: 32-bit buffer offsets) — the absolute single-GPU number next to the 512-window per-GPU share
         try:
@@ -608,7 +565,8 @@ def main():
     ap.add_argument("--config", default="paper256", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="windows (IMU streams) per GPU; 0 = the configuration's own")
     ap.add_argument("--seq-len", type=int, default=0)
-    ap.add_argument("--plan", default="auto", choices=["auto", "general", "fused", "latency", "fused2", "fused2s", "fusedh", "fused16"])
+    ap.add_argument("--plan", default="auto", choices=["auto", "general", "fused", "latency", "fused2", "fused2s", "fusedh", "fused16"],
+                    help="fused16: exploratory, measurement build only (TIP_LIB=measure)")
     ap.add_argument("--rnn-cluster", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.configs / extra.sustained (headline line only)")

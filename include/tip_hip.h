@@ -81,10 +81,10 @@ typedef enum tip_status {
 #define TIP_PLAN_FUSEDH  6 /* TIP_PLAN_FUSED with a hybrid row tiling: rows 0-31 on 16x16x4 MFMAs, rows 32-39 on 4x4x1 MFMAs fed by the
                               same weight fragments — no matrix-core work on the pad rows 40-47 outside the QKV projection.  No
                               inter-workgroup hand-off in the encoder.  Rows 0-31 bit-identical to TIP_PLAN_FUSED. */
-#define TIP_PLAN_FUSED16 7 /* EXPLORATORY, opt-in only (never AUTO's choice; needs TIP_OPT_PACK_SPLIT16 bit 0 set before packing): TIP_PLAN_FUSED with every GEMM's fp32 operands emulated on the
+#define TIP_PLAN_FUSED16 7 /* EXPLORATORY, MEASUREMENT BUILD ONLY (csrc: `make measure`; the default library answers TIP_ERR_UNSUPPORTED_CONFIG — round 5), opt-in (never AUTO's choice; needs TIP_OPT_PACK_SPLIT16 bit 0 set before packing): TIP_PLAN_FUSED with every GEMM's fp32 operands emulated on the
                               fp16 matrix cores — operands split hi + lo * 2^-11 (22 significant bits), three f16 MFMAs per product,
                               fp32 accumulation; attention core, LayerNorm, residual stream and epilogues in fp32 (csrc/tip_s16.hip) */
-#define TIP_PLAN_GENERAL16 8 /* EXPLORATORY, opt-in only: TIP_PLAN_GENERAL with the big linears (panel GEMM shapes) on split-fp16 operands as in
+#define TIP_PLAN_GENERAL16 8 /* EXPLORATORY, MEASUREMENT BUILD ONLY, opt-in: TIP_PLAN_GENERAL with the big linears (panel GEMM shapes) on split-fp16 operands as in
                                TIP_PLAN_FUSED16; needs TIP_OPT_PACK_SPLIT16 bit 1 set before packing (the split weight copies double the
                                packed image of a big model, so they are not packed by default) */
 #define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);

@@ -42,7 +42,7 @@ def _run(m, x_imu, x_s, last=False):
 
 
 PLANS = ["general", "fused"]
-ALL_PLANS = ["general", "fused", "latency", "fusedh", "fused16"]   # fused16: exploratory split-fp16 plan, same tolerances
+ALL_PLANS = ["general", "fused", "latency", "fusedh"] + (["fused16"] if tlib.MEASURE else [])   # fused16: exploratory split-fp16 plan (measurement build), same tolerances
 
 
 @pytest.mark.parametrize("plan", ALL_PLANS + ["fused2s"])

@@ -112,13 +112,26 @@ def test_max_batch_and_pack_options_without_a_gpu():
     assert hs.max_batch(80) == (2 ** 31 - 1) // (4 * 4096 * 80) == 1638            # BASELINE config 5 (B = 4096) runs as >= 3 chunks
     base = h.packed_bytes()
     assert h.get_option(tlib.TIP_OPT_PACK_SPLIT16) == 0
-    h.set_option(tlib.TIP_OPT_PACK_SPLIT16, tlib.TIP_PACK_SPLIT16_FUSED)
-    assert h.packed_bytes() == base + 3352320 * 4                                    # + the fused section's split copy
-    h.set_option(tlib.TIP_OPT_PACK_SPLIT16, 0)
-    assert h.packed_bytes() == base
-    b0 = hs.packed_bytes()
-    hs.set_option(tlib.TIP_OPT_PACK_SPLIT16, tlib.TIP_PACK_SPLIT16_GENERAL)
-    assert hs.packed_bytes() > b0 + 12 * (3 * 1024 * 1024 + 1024 * 1024 + 2 * 4096 * 1024) * 4 * 0.99
+    if tlib.MEASURE:     # the exploratory split-fp16 sections exist in the measurement build only (round 5)
+        h.set_option(tlib.TIP_OPT_PACK_SPLIT16, tlib.TIP_PACK_SPLIT16_FUSED)
+        assert h.packed_bytes() == base + 3352320 * 4                                    # + the fused section's split copy
+        h.set_option(tlib.TIP_OPT_PACK_SPLIT16, 0)
+        assert h.packed_bytes() == base
+        b0 = hs.packed_bytes()
+        hs.set_option(tlib.TIP_OPT_PACK_SPLIT16, tlib.TIP_PACK_SPLIT16_GENERAL)
+        assert hs.packed_bytes() > b0 + 12 * (3 * 1024 * 1024 + 1024 * 1024 + 2 * 4096 * 1024) * 4 * 0.99
+    else:                # the default library: unsupported configuration, image unchanged, and no such plan
+        for v in (tlib.TIP_PACK_SPLIT16_FUSED, tlib.TIP_PACK_SPLIT16_GENERAL):
+            with pytest.raises(tlib.TipStatusError) as ei:
+                h.set_option(tlib.TIP_OPT_PACK_SPLIT16, v)
+            assert ei.value.status == tlib.TIP_ERR_UNSUPPORTED_CONFIG
+        for pl in (tlib.TIP_PLAN_FUSED16, tlib.TIP_PLAN_GENERAL16):
+            with pytest.raises(tlib.TipStatusError) as ei:
+                h.set_option(tlib.TIP_OPT_PLAN, pl)
+            assert ei.value.status == tlib.TIP_ERR_UNSUPPORTED_CONFIG
+        assert h.packed_bytes() == base and h.get_option(tlib.TIP_OPT_PACK_SPLIT16) == 0
+        with pytest.raises(RuntimeError, match="measurement build"):
+            m.set_plan("fused16")
     with pytest.raises(tlib.TipStatusError):
         hs.set_option(tlib.TIP_OPT_PACK_SPLIT16, 4)
     assert h.get_option(tlib.TIP_OPT_AUTO_DEMOTE) == 1 and h.get_option(tlib.TIP_OPT_DEMOTED) == 0
@@ -126,9 +139,9 @@ def test_max_batch_and_pack_options_without_a_gpu():
     assert m.is_demoted()
     m.undemote()
     assert not m.is_demoted()
-    # set_plan("fused16") asks for the section and invalidates the attached image
-    m.set_plan("fused16")
-    assert h.get_option(tlib.TIP_OPT_PACK_SPLIT16) == tlib.TIP_PACK_SPLIT16_FUSED and m._packed_dev is None
+    if tlib.MEASURE:     # set_plan("fused16") asks for the section and invalidates the attached image
+        m.set_plan("fused16")
+        assert h.get_option(tlib.TIP_OPT_PACK_SPLIT16) == tlib.TIP_PACK_SPLIT16_FUSED and m._packed_dev is None
     # TIP_OPT_F1S_PARTS: workgroups per window of the window-split plan (0 = the library's choice); the plan names pin it
     assert h.get_option(tlib.TIP_OPT_F1S_PARTS) == 0
     m.set_plan("fused1s4")
@@ -248,6 +261,7 @@ def test_packed_image_folds():
     assert np.array_equal(blk, exp)
 
 
+@pytest.mark.skipif(not tlib.MEASURE, reason="exploratory plans: measurement build only (tests/test_exploratory_build.py re-runs this under TIP_LIB=measure)")
 def test_packed_image_split_fp16_section():
     """The exploratory split-fp16 copy of the fused section (csrc/tip_s16.hip, plan "fused16"): the last section of the packed
     image holds, at the fused section's own float offsets, every weight matrix as [column block][32-k block][hi | lo][64 lanes][8

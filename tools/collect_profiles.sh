@@ -90,9 +90,9 @@ TIP_HEAD_TRACE=1 timeout 300 python tools/head_trace.py 1024 2> /dev/null | grep
 TIP_S16_TRACE=1 timeout 300 python tools/s16_trace.py 2> /dev/null | grep -v "^model\|^number" > "$OUT/s16_trace_B256.txt"
 timeout 300 python tools/stream_latency.py 1 400 2> /dev/null | grep "^{" > "$OUT/stream_latency_n1.json"
 d=/tmp/prof_f16; rm -rf $d
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $d -- $BENCH --plan fused16 > "$OUT/bench_fused16_under_rocprof.json" 2> /dev/null)
+(cd /tmp && TIP_LIB=measure timeout 600 rocprofv3 --kernel-trace --output-format csv -d $d -- $BENCH --plan fused16 > "$OUT/bench_fused16_under_rocprof.json" 2> /dev/null)
 t=$(find $d -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python tools/kstats_table.py "$t" > "$OUT/kernel_medians_bench_fused16_B256_T40.txt"
-timeout 300 python bench.py --plan fused16 --no-cpu-baseline --no-extra --steps 300 --warmup 20 > "$OUT/bench_fused16_n1.json" 2> /dev/null
+TIP_LIB=measure timeout 300 python bench.py --plan fused16 --no-cpu-baseline --no-extra --steps 300 --warmup 20 > "$OUT/bench_fused16_n1.json" 2> /dev/null
 # round 4: AUTO over a batch sweep against the round-3 selection (remainder split, window-split plan), the persistent latency kernel
 { echo "AUTO (round 4)"; timeout 300 python tools/auto_sweep.py 2> /dev/null; echo "round-3 selection (TIP_PLAN_BASE=1)"; TIP_PLAN_BASE=1 timeout 300 python tools/auto_sweep.py 2> /dev/null; } > "$OUT/auto_sweep.txt"
 timeout 300 python tools/f1s_bench.py 2> /dev/null | grep "^B=\|fused1s vs" > "$OUT/f1s_bench.txt"

@@ -351,6 +351,9 @@ int tip_set_option(tip_handle* h, int option, int value) {
     switch (option) {
         case TIP_OPT_PLAN:
             if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED1S || value == 9 /* reserved */) return TIP_ERR_INVALID_ARG;
+#ifndef TIP_EXPLORATORY
+            if (value == TIP_PLAN_FUSED16 || value == TIP_PLAN_GENERAL16) return TIP_ERR_UNSUPPORTED_CONFIG;   // measurement build only
+#endif
             h->plan = value;
             return TIP_OK;
         case TIP_OPT_PROFILE:
@@ -373,6 +376,9 @@ int tip_set_option(tip_handle* h, int option, int value) {
             return TIP_OK;
         case TIP_OPT_PACK_SPLIT16:
             if (value < 0 || value > (TIP_PACK_SPLIT16_FUSED | TIP_PACK_SPLIT16_GENERAL)) return TIP_ERR_INVALID_ARG;
+#ifndef TIP_EXPLORATORY
+            if (value != 0) return TIP_ERR_UNSUPPORTED_CONFIG;   // the split-fp16 sections exist in the measurement build only
+#endif
             if (value != h->pack_split16) {
                 // the layout of the packed image changes: whatever was attached no longer matches it
                 h->pack_split16 = value;

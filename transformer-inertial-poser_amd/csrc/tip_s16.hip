@@ -29,6 +29,26 @@
 #include "tip_internal.h"
 #include "tip_layernorm.h"
 
+// The exploratory plans are compiled into the MEASUREMENT build only (csrc/Makefile: `make measure`, -DTIP_EXPLORATORY).  In the
+// default library every entry point of this file is a stub that says "not served": tip_set_option refuses TIP_PLAN_FUSED16 /
+// TIP_PLAN_GENERAL16 and a non-zero TIP_OPT_PACK_SPLIT16 with TIP_ERR_UNSUPPORTED_CONFIG.
+#ifndef TIP_EXPLORATORY
+namespace tip {
+bool pgemm16_shape_ok(int, int, int) { return false; }
+hipError_t launch_pgemm16(const float*, int, const float*, size_t, const float*, const float*, int, float*, int, int, int, int, int,
+                          hipStream_t) { return hipErrorInvalidValue; }
+void s16_convert_host(const float*, float*, int, int) {}
+hipError_t launch_s16_convert(const float*, float*, int, int, hipStream_t) { return hipErrorInvalidValue; }
+bool s16_supported(const Dims&, int) { return false; }
+size_t s16_packed_floats(const Dims&) { return 0; }
+void s16_pack_host(const Dims&, const float*, float*) {}
+hipError_t launch_s16_repack(const Dims&, const float*, float*, hipStream_t) { return hipErrorInvalidValue; }
+hipError_t launch_fused_encoder_s16(const Dims&, const float*, const float*, const float*, const float*, const float*, float, float*,
+                                    float*, int, int, int, hipStream_t) { return hipErrorInvalidValue; }
+}  // namespace tip
+extern "C" int tip_debug_read_s16_trace(unsigned long long*, int) { return -1; }
+#else
+
 namespace tip {
 
 typedef _Float16 s16h8 __attribute__((ext_vector_type(8)));
@@ -799,3 +819,4 @@ hipError_t launch_s16_convert(const float* src_frag, float* dst, int N, int K, h
 }
 
 }  // namespace tip
+#endif  // TIP_EXPLORATORY

@@ -76,6 +76,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def build_measure(verbose: bool = False) -> str:
+    """Compile the measurement build (csrc/libtip_hip_measure.so: TIP_* environment switches alive, exploratory plans compiled in)."""
+    cmd = ["make", "-C", CSRC, "-j4", "libtip_hip_measure.so"]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        raise TipLibraryError("building libtip_hip_measure.so failed:\n" + res.stdout[-4000:])
+    if verbose:
+        print(res.stdout)
+    return os.path.join(CSRC, "libtip_hip_measure.so")
+
+
 _lib = None
 
 
