@@ -30,7 +30,7 @@ namespace tip {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace lz {
-constexpr int D = 256, DH = 16, F = 1024, R = 512, RP = 48, RB = 3, TMAX = 40, KIN = 224;
+constexpr int D = 256, DH = 16, F = 1024, R = 512, RP = 48, RB = 3, KIN = 224;
 constexpr int LDX = D + 4, LDU = KIN + 4;
 }  // namespace lz
 
