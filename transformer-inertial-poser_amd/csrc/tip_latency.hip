@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256) void lat_in_kernel(const float* __restrict__ w
                 if (km) kv = *(imu ? pa : km + (size_t)rc * S + cs);                  // :77 (km: wave-uniform; IMU lanes read a dummy)
                 // ... or the keep decision drawn here (tip_forward_dropout with a state seed): element index of x_s [B][T][S], the
                 // same decisions tip_draw_keep_mask writes out
-                if (mthresh) kv = tip_drop_hash_k(mkey, (unsigned)(((size_t)win * T + rc) * S + cs)) >= mthresh ? 1.f : 0.f;
+                // (32-bit index arithmetic: the hash takes the index mod 2^32 anyway; chunks that hold IMU columns only — NI >= 64 — skip it)
+                if (mthresh && (ch + 1) * 64 > NI)
+                    kv = tip_drop_hash_k(mkey, ((unsigned)win * (unsigned)T + (unsigned)rc) * (unsigned)S + (unsigned)cs) >= mthresh ? 1.f : 0.f;
                 const float xs_v = (x != x ? 0.f : x) * kv * ((km || mthresh) ? keep_scale : 1.f); // :65, then (x * mask) * scale as before
                 v[i][ch] = (row < T && c < NI + S) ? (imu ? x : xs_v) : 0.f;
             }
