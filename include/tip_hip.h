@@ -75,9 +75,11 @@ typedef enum tip_status {
 #define TIP_PLAN_FUSED   2 /* one workgroup = one window through all encoder layers (paper configuration) */
 #define TIP_PLAN_FUSED2  4 /* two windows per workgroup (80 rows = 5 MFMA row blocks, no padding); AUTO picks it for
                               B >= 2 x CUs; bit-identical results to TIP_PLAN_FUSED */
-#define TIP_PLAN_FUSED2S 5 /* pair-split: a window pair on TWO co-resident workgroups, columns split, partial sums exchanged
-                              twice per layer (80 rows x half the columns per CU: no row padding at B <= #CUs);
-                              needs 2*ceil(B/2) <= #CUs; AUTO picks it for 64 < B <= #CUs */
+#define TIP_PLAN_FUSED2S 5 /* MEASUREMENT BUILD ONLY since round 5 (csrc: `make measure`; the default library answers
+                              TIP_ERR_UNSUPPORTED_CONFIG): pair-split, a window pair on TWO co-resident workgroups, columns split,
+                              partial sums exchanged twice per layer; needs 2*ceil(B/2) <= #CUs.  Round 1's choice for
+                              64 < B <= #CUs; superseded by TIP_PLAN_FUSEDH (round 2) and TIP_PLAN_FUSED1S (round 4), whose
+                              kernel is the same template with one window per workgroup set. */
 #define TIP_PLAN_FUSEDH  6 /* TIP_PLAN_FUSED with a hybrid row tiling: rows 0-31 on 16x16x4 MFMAs, rows 32-39 on 4x4x1 MFMAs fed by the
                               same weight fragments — no matrix-core work on the pad rows 40-47 outside the QKV projection.  No
                               inter-workgroup hand-off in the encoder.  Rows 0-31 bit-identical to TIP_PLAN_FUSED. */

@@ -30,9 +30,11 @@ def test_measurement_build_host_side():
 
 @pytest.mark.gpu
 def test_exploratory_plans_on_the_gpu():
-    """MI355X: tests/test_fused16_gpu.py (properties of the split-fp16 plan) against the measurement build."""
+    """MI355X: tests/test_fused16_gpu.py (properties of the split-fp16 plan) and the superseded pair-split plan's parity / fault
+    cases against the measurement build."""
     if not os.path.exists(MEASURE_LIB):
         pytest.skip("libtip_hip_measure.so is not built")
-    res = _run(["tests/test_fused16_gpu.py", "-m", "gpu"], 1200)
+    res = _run(["tests/test_fused16_gpu.py", "tests/test_hip_parity.py", "tests/test_handoff_fault_gpu.py", "-m", "gpu",
+                "-k", "fused16 or split16 or fused2s or pair_split or keep_mask"], 1500)
     assert res.returncode == 0, res.stdout[-3000:]
     assert " passed" in res.stdout and "skipped" not in res.stdout.splitlines()[-1], res.stdout[-500:]

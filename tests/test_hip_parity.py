@@ -45,7 +45,7 @@ PLANS = ["general", "fused"]
 ALL_PLANS = ["general", "fused", "latency", "fusedh"] + (["fused16"] if tlib.MEASURE else [])   # fused16: exploratory split-fp16 plan (measurement build), same tolerances
 
 
-@pytest.mark.parametrize("plan", ALL_PLANS + ["fused2s"])
+@pytest.mark.parametrize("plan", ALL_PLANS + (["fused2s"] if tlib.MEASURE else []))   # fused2s: superseded pair-split plan (measurement build)
 def test_golden_vectors(golden, plan):
     _dev()
     models = {}
@@ -274,7 +274,7 @@ def test_keep_mask_semantics(golden):
     p = float(case["p"][0])
     y = torch.empty(2, 40, 131, device="cuda")
     ws = torch.empty(h.workspace_bytes(2, 40), dtype=torch.uint8, device="cuda")
-    for plan in (tlib.TIP_PLAN_AUTO, tlib.TIP_PLAN_FUSED, tlib.TIP_PLAN_FUSED2, tlib.TIP_PLAN_FUSED2S):
+    for plan in (tlib.TIP_PLAN_AUTO, tlib.TIP_PLAN_FUSED, tlib.TIP_PLAN_FUSED2) + ((tlib.TIP_PLAN_FUSED2S,) if tlib.MEASURE else ()):
         h.set_option(tlib.TIP_OPT_PLAN, plan)
         y.zero_()
         h.forward(xi.data_ptr(), xs.data_ptr(), y.data_ptr(), 2, 40, tlib.TIP_FWD_KEEP_MASK, mask.data_ptr(),
@@ -462,8 +462,10 @@ def test_cluster_handoffs_under_uneven_load():
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     cases = [("fused", 200), ("fused", 40), ("latency", 9), ("fused2", 600)]
     cases += [("auto", 256)]   # the bench launch: hybrid one-window encoder + 16-workgroup RNN clusters
-    if ncu >= 256:   # the pair-split plan needs every workgroup resident
+    if ncu >= 256 and tlib.MEASURE:   # the pair-split plan needs every workgroup resident (measurement build only since round 5)
         cases += [("fused2s", 128)]
+    if ncu >= 256:
+        cases += [("fused1s2", 100), ("fused1s4", 60)]
     for plan, B in cases:
         m.set_plan(plan)
         x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=31)
@@ -594,6 +596,7 @@ def test_very_long_window_properties():
     assert np.abs(y300 - y[:, :300]).max() < 5e-6
 
 
+@pytest.mark.skipif(not tlib.MEASURE, reason="the pair-split plan exists in the measurement build only (round 5); tests/test_exploratory_build.py runs this file there")
 @pytest.mark.parametrize("B", [1, 2, 7, 65, 128, 255, 256])
 def test_pair_split_plan(B):
     """"fused2s": a window pair on two co-resident workgroups, columns split, partial sums exchanged twice per layer.
@@ -629,6 +632,23 @@ def test_pair_split_plan(B):
     assert tip_amd.lib.spin_timeouts() == t0
 
 
+def test_default_library_refuses_the_superseded_and_exploratory_plans():
+    """Round 5: the pair-split plan and the split-fp16 plans are compiled into the measurement build only; the default library says
+    so at set_option time (host: RuntimeError) instead of carrying their kernels."""
+    if tlib.MEASURE:
+        pytest.skip("measurement build: the plans exist")
+    m, _ = _gpu_model(synth.PAPER, 0)
+    h = m._ensure_handle()
+    for plan in (tlib.TIP_PLAN_FUSED2S, 7, 8):
+        assert tlib.load().tip_set_option(h._h, tlib.TIP_OPT_PLAN, plan) == tlib.TIP_ERR_UNSUPPORTED_CONFIG
+    assert tlib.load().tip_set_option(h._h, tlib.TIP_OPT_PLAN, 9) < 0          # reserved value
+    for name in ("fused2s", "fused16", "general16"):
+        with pytest.raises(RuntimeError):
+            m.set_plan(name)
+    m.set_plan("auto")
+
+
+@pytest.mark.skipif(not tlib.MEASURE, reason="pair-split plan: measurement build only")
 def test_pair_split_plan_refuses_what_it_cannot_hold():
     cfg = synth.PAPER
     m, _ = _gpu_model(cfg, 0)

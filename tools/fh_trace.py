@@ -16,7 +16,7 @@ m.load_state_dict({k: torch.tensor(v) for k, v in synth.make_weights(cfg, seed=0
 TRAIN = "--train" in sys.argv     # the training forward (stash + the four dropout sites, p = 0.1) instead of the inference kernel
 m = m.cuda().train() if TRAIN else m.cuda().eval()
 if TRAIN:
-    m.ENCODER_DROPOUT = 0.1
+    m.ENCODER_DROPOUT = float(os.environ.get("FH_P", "0.1"))
 else:
     m.set_plan("fusedh")
 x_imu, x_s = synth.make_inputs(cfg, 256, 40)

@@ -16,7 +16,7 @@ for B in [int(a) for a in sys.argv[1:]] or [256]:
     x_imu, x_s = synth.make_inputs(cfg, min(B, 256), 40)
     xi = torch.tensor(np.tile(x_imu, ((B + 255) // 256, 1, 1))[:B]).cuda()
     xs = torch.tensor(np.tile(x_s, ((B + 255) // 256, 1, 1))[:B]).cuda()
-    for plan in ("fused", "fusedh", "fused2s", "fused2", "latency", "auto"):
+    for plan in ("fused", "fusedh", "fused1s", "fused2", "latency", "auto"):
         try:
             m.set_plan(plan, profile=0)
             with torch.no_grad():

@@ -352,7 +352,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
         case TIP_OPT_PLAN:
             if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED1S || value == 9 /* reserved */) return TIP_ERR_INVALID_ARG;
 #ifndef TIP_EXPLORATORY
-            if (value == TIP_PLAN_FUSED16 || value == TIP_PLAN_GENERAL16) return TIP_ERR_UNSUPPORTED_CONFIG;   // measurement build only
+            if (value == TIP_PLAN_FUSED16 || value == TIP_PLAN_GENERAL16 || value == TIP_PLAN_FUSED2S) return TIP_ERR_UNSUPPORTED_CONFIG;   // measurement build only
 #endif
             h->plan = value;
             return TIP_OK;
@@ -800,6 +800,9 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     }
     if ((plan == TIP_PLAN_FUSED || plan == TIP_PLAN_FUSEDH) && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
+#ifndef TIP_EXPLORATORY
+    if (plan == TIP_PLAN_FUSED2S) return TIP_ERR_UNSUPPORTED_CONFIG;   // measurement build only (round 5)
+#endif
     if (plan == TIP_PLAN_FUSED2S && !(fused2_supported(d, T) && fused2s_fits(B, cus) && B <= 256)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED1S && !(fused2_supported(d, T) && fused1s_fits(B, cus) && (h->f1s_parts != 4 || fused1s_quad_fits(B, cus))))
         return TIP_ERR_UNSUPPORTED_CONFIG;

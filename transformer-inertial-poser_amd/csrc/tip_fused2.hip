@@ -905,7 +905,11 @@ static hipError_t launch_fused_encoder_split(const Dims& d, const float* fused_w
 hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                   const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
                                   int B, int num_cus, const Guard& gd, hipStream_t s) {
+#ifdef TIP_EXPLORATORY   // superseded by the hybrid one-window kernel (round 2) and the window-split plan (round 4): measurement build only
     return launch_fused_encoder_split<2>(d, fused_w, x_imu, x_s, keep_mask, keep_scale, ih_out, hall_sentinel, xchg, B, num_cus, gd, s);
+#else
+    return hipErrorNotSupported;
+#endif
 }
 hipError_t launch_fused_encoder1s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                   const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,

@@ -386,8 +386,8 @@ class TF_RNN_Past_State(nn.Module):
         workgroups per 16-window tile (1: no inter-workgroup hand-off in the recurrence).  profile: 1 = per-stage timers
         (profile_read())."""
         h = self._ensure_handle()
-        if plan in ("fused16", "general16") and not _lib.MEASURE:
-            raise RuntimeError(f"tip_amd: plan '{plan}' is exploratory and exists in the measurement build of the library only "
+        if plan in ("fused16", "general16", "fused2s") and not _lib.MEASURE:
+            raise RuntimeError(f"tip_amd: plan '{plan}' is exploratory / superseded and exists in the measurement build of the library only "
                                "(make -C csrc measure; TIP_LIB=measure)")
         # the exploratory split-fp16 plans read weight copies the packed image carries only on request
         want = {"fused16": _lib.TIP_PACK_SPLIT16_FUSED, "general16": _lib.TIP_PACK_SPLIT16_GENERAL}.get(plan, 0)
