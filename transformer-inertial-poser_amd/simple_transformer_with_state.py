@@ -221,7 +221,14 @@ class TF_RNN_Past_State(nn.Module):
             # (few windows) or written out by tip_draw_keep_mask (_hash_keep_mask), never by three torch kernels per call.
             seeds = torch.randint(0, 2 ** 62, (2,), dtype=torch.int64).tolist()
             mask = seeds[1] if 0.0 < self.past_state_dropout < 1.0 else self._draw_keep_mask(x_s)
-            y = _HipTrainFunction.apply(self, xi, x_s, mask, float(self.ENCODER_DROPOUT), seeds[0], *plist)
+            # A few windows (the unedited runner's call): the kernels are queued HERE, before autograd's bookkeeping for the 56
+            # parameter inputs (~20 us of host time that then runs beside the GPU instead of in front of it); the Function below
+            # picks the launched forward up instead of launching its own.
+            self._pre_launched = self._few_window_train_launch(xi, x_s, mask, float(self.ENCODER_DROPOUT), seeds[0]) or False
+            try:
+                y = _HipTrainFunction.apply(self, xi, x_s, mask, float(self.ENCODER_DROPOUT), seeds[0], *plist)
+            finally:
+                self._pre_launched = None
             return y[:, -1] if last_row_only else y
         if (needs_grad and (self.training or not x_imu.is_cuda)) or (self.training and self.ENCODER_DROPOUT > 0.0 and x_imu.is_cuda):
             # not covered by the HIP training step: the torch-op composite, with the encoder dropout .train() implies
@@ -246,6 +253,40 @@ class TF_RNN_Past_State(nn.Module):
         return _HipForwardTorchBackward.apply(self, last_row_only, xi, x_s, mask, *plist)
 
     LAZY_STASH_MAX_BATCH = 32   # .train()-mode calls of up to this many windows run without an activation stash (see _HipTrainFunction)
+    _pre_launched = None
+
+    def _few_window_train_launch(self, x_imu, x_s, mask, p_drop, seed):
+        """.train()-mode call of a few windows (the unedited runner's B = 1 call, real_time_runner_minimal.py:149, on a module that
+        never left .train() mode): the same function on the few-stream kernels (tip_forward_dropout: same dropout decisions as
+        tip_train_forward, no activation stash, ~0.2 ms instead of ~0.8 at one window per CU).  Returns (y, xi, xs, mask or its
+        seed, scale) with the kernels queued, or None when the call is not served that way (batch, precision, configuration,
+        keep_train_stash): _HipTrainFunction then runs tip_train_forward.  If .backward() is called after all, the stash is
+        produced then."""
+        B = int(x_imu.shape[0])
+        if B > self.LAZY_STASH_MAX_BATCH or self.keep_train_stash or x_imu.dtype != torch.float32:
+            return None
+        n_imu = self.input_size_imu + (18 if self.with_acc_sum else 0)
+        if x_imu.shape[2] != n_imu or x_s.shape[2] != self.size_s:
+            return None                                   # _HipTrainFunction.forward raises the reference's shape error
+        h = self._ensure_handle()
+        dev = x_imu.device
+        T = int(x_imu.shape[1])
+        with torch.cuda.device(dev):
+            xi, xs = x_imu.contiguous(), x_s.contiguous()
+            pd = self.past_state_dropout
+            mask_ptr, scale = None, (1.0 / (1.0 - pd) if pd < 1.0 else 0.0) if mask is not None else 1.0
+            state_seed = mask if isinstance(mask, int) else None     # the keep mask as (p, seed): drawn by the library
+            if state_seed is not None:
+                mask = None
+            elif mask is not None:
+                mask = mask.to(torch.float32).contiguous()
+                mask_ptr = mask.data_ptr()
+            y = torch.empty((B, T, self.size_s), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if not self._forward_dropout_hip(h, xi, xs, y, B, T, mask_ptr, scale, pd if state_seed is not None else 0.0,
+                                             state_seed or 0, p_drop, seed, stream):
+                return None
+        return y, xi, xs, (mask if state_seed is None else state_seed), scale
 
     def _forward_dropout_hip(self, h, xi, xs, y, B, T, mask_ptr, scale, p_state, state_seed, p_drop, seed, stream) -> bool:
         """tip_forward_dropout into `y`; False when the library does not serve this call that way (configuration, window length,
@@ -628,29 +669,31 @@ class _HipTrainFunction(torch.autograd.Function):
                                f"{x_imu.shape[2]}+{x_s.shape[2]}, in_linear expects {n_imu}+{module.size_s}")
         pdt = x_imu.dtype                                  # fp32, or fp64 for a module built under --double (_hip_train_ok: no mixes)
         f64 = pdt == torch.float64
-        with torch.cuda.device(dev):
-            xi, xs = x_imu.contiguous(), x_s.contiguous()
-            pd = module.past_state_dropout
-            mask_ptr, scale = None, (1.0 / (1.0 - pd) if pd < 1.0 else 0.0) if mask is not None else 1.0
-            state_seed = mask if isinstance(mask, int) else None     # the keep mask as (p, seed): drawn by the library
-            if state_seed is not None:
-                mask = None
-            elif mask is not None:
-                mask = mask.to(pdt).contiguous()
-                mask_ptr = mask.data_ptr()
-            y = torch.empty((B, T, module.size_s), dtype=pdt, device=dev)
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            saved = None
-            # A few windows (the unedited runner's B = 1 call, real_time_runner_minimal.py:149, on a module that never left .train()
-            # mode): the same function on the few-stream kernels (tip_forward_dropout: same dropout decisions, no activation stash,
-            # ~0.2 ms instead of ~0.8 at one window per CU).  If .backward() is called after all, the stash is produced then.
-            lazy = (not f64 and B <= module.LAZY_STASH_MAX_BATCH and not module.keep_train_stash
-                    and module._forward_dropout_hip(h, xi, xs, y, B, T, mask_ptr, scale, pd if state_seed is not None else 0.0,
-                                                    state_seed or 0, p_drop, seed, stream))
-            if not lazy:
+        # a few windows: already on the GPU's queue (module._few_window_train_launch, called by _dispatch in front of this apply;
+        # False = tried, not served that way)
+        pre, module._pre_launched = module._pre_launched, None
+        if pre is None:
+            pre = module._few_window_train_launch(x_imu, x_s, mask, p_drop, seed)
+        lazy = bool(pre)
+        saved = None
+        if lazy:
+            y, xi, xs, lazy_mask, scale = pre
+            state_seed = lazy_mask if isinstance(lazy_mask, int) else None
+            mask = None if state_seed is not None else lazy_mask
+        else:
+            with torch.cuda.device(dev):
+                xi, xs = x_imu.contiguous(), x_s.contiguous()
+                pd = module.past_state_dropout
+                mask_ptr, scale = None, (1.0 / (1.0 - pd) if pd < 1.0 else 0.0) if mask is not None else 1.0
+                state_seed = mask if isinstance(mask, int) else None     # the keep mask as (p, seed): drawn by the library
                 if state_seed is not None:
                     mask = module._hash_keep_mask(xs, state_seed)
                     mask_ptr = mask.data_ptr()
+                elif mask is not None:
+                    mask = mask.to(pdt).contiguous()
+                    mask_ptr = mask.data_ptr()
+                y = torch.empty((B, T, module.size_s), dtype=pdt, device=dev)
+                stream = torch.cuda.current_stream(dev).cuda_stream
                 saved_bytes, _ = h.train_bytes(B, T, fp64=f64)
                 saved = torch.empty(saved_bytes, dtype=torch.uint8, device=dev)
                 pc = [p.detach().contiguous() for p in params]
