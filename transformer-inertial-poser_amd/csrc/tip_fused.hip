@@ -1322,15 +1322,29 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
         {
             const float4 gg = *reinterpret_cast<const float4*>(a.g2 + lane * 4);
             float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg, dm = dg;
-#pragma unroll 2
-            for (int i = 0; i < RP / 8; ++i) {
+            // every row's operands are requested BEFORE the first row is worked on: written as one load -> compute -> store body
+            // per row, the stores of row i stood between the optimiser and the loads of row i + 1 (it may not move a load across a
+            // store it cannot prove disjoint), and the phase was three HBM round trips long (14 000 cycles for 5 rows per wave)
+            constexpr int NR = RP / 8;
+            float4 zq[NR], dq_[NR];
+            float2 sq_[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = wave + 8 * i;
+                const size_t gr = grow0 + (r < T ? r : 0);      // pad rows: a valid address, the values are not used
+                zq[i] = *reinterpret_cast<const float4*>(a.z2 + gr * D + lane * 4);
+                dq_[i] = *reinterpret_cast<const float4*>(a.dy + gr * D + lane * 4);
+                sq_[i] = *reinterpret_cast<const float2*>(a.st2 + gr * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
                 const int r = wave + 8 * i;
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f), m = o;
                 if (r < T) {
                     const size_t gr = grow0 + r;
-                    const float4 zv = *reinterpret_cast<const float4*>(a.z2 + gr * D + lane * 4);
-                    const float4 dyv = *reinterpret_cast<const float4*>(a.dy + gr * D + lane * 4);
-                    const float mean = a.st2[gr * 2], rstd = a.st2[gr * 2 + 1];
+                    const float4 zv = zq[i];
+                    const float4 dyv = dq_[i];
+                    const float mean = sq_[i].x, rstd = sq_[i].y;
                     float4 xh;
                     xh.x = (zv.x - mean) * rstd; xh.y = (zv.y - mean) * rstd; xh.z = (zv.z - mean) * rstd; xh.w = (zv.w - mean) * rstd;
                     const float ax = dyv.x * gg.x, ay = dyv.y * gg.y, az = dyv.z * gg.z, aw = dyv.w * gg.w;
@@ -1536,15 +1550,27 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
         {
             const float4 gg = *reinterpret_cast<const float4*>(a.g1 + lane * 4);
             float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg, dm = dg;
-#pragma unroll 2
-            for (int i = 0; i < RP / 8; ++i) {
+            // all rows' operands first (ffn_bwd_kernel: the stores of row i otherwise fence the loads of row i + 1)
+            constexpr int NR = RP / 8;
+            float4 zq[NR], dq_[NR];
+            float2 sq_[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = wave + 8 * i;
+                const size_t gr = grow0 + (r < T ? r : 0);
+                zq[i] = *reinterpret_cast<const float4*>(a.z1 + gr * D + lane * 4);
+                dq_[i] = *reinterpret_cast<const float4*>(a.dx1 + gr * D + lane * 4);
+                sq_[i] = *reinterpret_cast<const float2*>(a.st1 + gr * 2);
+            }
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
                 const int r = wave + 8 * i;
                 float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (r < T) {
                     const size_t gr = grow0 + r;
-                    const float4 zv = *reinterpret_cast<const float4*>(a.z1 + gr * D + lane * 4);
-                    const float4 dyv = *reinterpret_cast<const float4*>(a.dx1 + gr * D + lane * 4);
-                    const float mean = a.st1[gr * 2], rstd = a.st1[gr * 2 + 1];
+                    const float4 zv = zq[i];
+                    const float4 dyv = dq_[i];
+                    const float mean = sq_[i].x, rstd = sq_[i].y;
                     float4 xh;
                     xh.x = (zv.x - mean) * rstd; xh.y = (zv.y - mean) * rstd; xh.z = (zv.z - mean) * rstd; xh.w = (zv.w - mean) * rstd;
                     const float ax = dyv.x * gg.x, ay = dyv.y * gg.y, az = dyv.z * gg.z, aw = dyv.w * gg.w;
