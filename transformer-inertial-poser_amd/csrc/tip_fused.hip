@@ -293,6 +293,65 @@ __device__ __forceinline__ void rows_to_hbm(const float* lds, int ld, int cols, 
     }
 }
 
+// The same with a FIXED number of stores per thread (T <= 40: the hybrid kernel), rows >= T dropped by the buffer's range check instead
+// of by the loop bound.  With the run-time trip count above the compiler cannot count the stores in flight, and the `s_waitcnt vmcnt(N)`
+// of the weight ring behind such a loop (vector memory retires in order, stores included) degenerates to "all but the last few":
+// every stash point waited for its own stores' acknowledgement before the next phase's first MFMA.
+template <int COLS>
+__device__ __forceinline__ void rows_to_hbm_fixed(const float* lds, int ld, float* dst, int dst_ld, int T, int tid) {
+    constexpr int C4 = COLS / 4, NP = (40 * C4 + fz::THREADS - 1) / fz::THREADS;
+    static_assert((NP * fz::THREADS + C4 - 1) / C4 <= fz::RP, "the passes stay inside the LDS tile's rows");
+    const __amdgpu_buffer_rsrc_t rs = tip_rows_buffer(dst, T * dst_ld * 4);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int i = tid + j * fz::THREADS, r = i / C4, c4 = i - r * C4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + r * ld + c4 * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ln_u32x4, v), rs, (r * dst_ld + c4 * 4) * 4, 0, kTipNT);
+    }
+}
+
+// The training forward's hidden chunk [T][256] (after ReLU and dropout): rows to HBM as rows_to_hbm does, plus the chunk's gates
+// (hidden > 0) as BITS for the fused FFN backward.  gb points at row 0 of the window in the gate-bit array [M][32 dwords]:
+//   dword (row, f*8 + 2*e + (c4 >> 5)), bit (c4 & 31)  =  hidden[row][f*256 + 4*c4 + e] > 0      (c4 = 0..63: column quad)
+// One wave iteration is one row (64 lanes = its 64 column quads): four ballots, 32 bytes stored by lane 0.  Round 5: ffn_bwd_kernel
+// read the gates as the saved fp32 hidden rows — 42 MB per layer that arrive cold from HBM in front of each chunk's weight ring
+// (vector memory returns in order: every chunk stalled ~4 000 cycles behind them); as bits they are 1.3 MB, staged into LDS once per window.
+template <bool FIXED>   // FIXED: five stores per thread whatever T <= 40 is (rows_to_hbm_fixed), lanes other than 0 drop the bit stores
+__device__ __forceinline__ void hidden_to_hbm(const float* lds, int ld, float* dst, int dst_ld, unsigned* gb, int f, int T, int tid) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63;
+    if (FIXED) {
+        const __amdgpu_buffer_rsrc_t rs = tip_rows_buffer(dst, T * dst_ld * 4);
+        const __amdgpu_buffer_rsrc_t gs = tip_rows_buffer(reinterpret_cast<const float*>(gb), T * 128);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int r = (tid >> 6) + 8 * j;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(lds + r * ld + lane * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ln_u32x4, v), rs, (r * dst_ld + lane * 4) * 4, 0, kTipNT);
+            const unsigned long long b0 = __builtin_amdgcn_ballot_w64(v[0] > 0.f), b1 = __builtin_amdgcn_ballot_w64(v[1] > 0.f);
+            const unsigned long long b2 = __builtin_amdgcn_ballot_w64(v[2] > 0.f), b3 = __builtin_amdgcn_ballot_w64(v[3] > 0.f);
+            const int off = lane == 0 ? r * 128 + f * 32 : 0x7fffff00;      // one lane writes the row's 32 bytes; the others fall outside the buffer
+            const u32x4 lo = {(unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32)};
+            const u32x4 hi = {(unsigned)b2, (unsigned)(b2 >> 32), (unsigned)b3, (unsigned)(b3 >> 32)};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ln_u32x4, lo), gs, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ln_u32x4, hi), gs, off, 16, 0);
+        }
+        return;
+    }
+    for (int i = tid; i < T * 64; i += fz::THREADS) {
+        const int r = i >> 6;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + r * ld + lane * 4);
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (size_t)r * dst_ld + lane * 4));
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(v[0] > 0.f), b1 = __builtin_amdgcn_ballot_w64(v[1] > 0.f);
+        const unsigned long long b2 = __builtin_amdgcn_ballot_w64(v[2] > 0.f), b3 = __builtin_amdgcn_ballot_w64(v[3] > 0.f);
+        if (lane == 0) {
+            u32x4* o = reinterpret_cast<u32x4*>(gb + (size_t)r * 32 + f * 8);
+            o[0] = (u32x4){(unsigned)b0, (unsigned)(b0 >> 32), (unsigned)b1, (unsigned)(b1 >> 32)};
+            o[1] = (u32x4){(unsigned)b2, (unsigned)(b2 >> 32), (unsigned)b3, (unsigned)(b3 >> 32)};
+        }
+    }
+}
+
 // ABL != 0 builds are MEASUREMENT-ONLY ablations (wrong results): 1 = no attention, 2 = no LayerNorm, 4 = no MFMA,
 // 8 = no epilogue LDS traffic.  Selected with TIP_FUSED_ABLATE=<mask>; the product path always runs ABL = 0.
 template <int ABL>
@@ -489,7 +548,9 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_kernel(
                     }
                 }
                 __syncthreads();
-                if (TR) rows_to_hbm(Hc, LDX, 256, svl + (size_t)tr.hid * 64 + grow0 * F + f * 256, F, T, opaque(tid));
+                if (TR)
+                    hidden_to_hbm<false>(Hc, LDX, svl + (size_t)tr.hid * 64 + grow0 * F + f * 256, F,
+                                  reinterpret_cast<unsigned*>(svl + (size_t)tr.hid * 64 + (size_t)B * T * F) + grow0 * 32, f, T, opaque(tid));
                 {
                     const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                     // ... and the tail of linear2(f) primes it with linear1(f+1)'s (its own again after the last chunk)
@@ -845,7 +906,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
         FH_STAMP(1);
         // training forward: the staged input rows are dW_in's operand in the backward — stashed from here instead of by a launch of
         // their own (tip_train.hip)
-        if (TR && tr.u) rows_to_hbm(U, LDU, KIN, tr.sv + (size_t)tr.u * 64 + (size_t)win * T * KIN, KIN, T, opaque(tid));
+        if (TR && tr.u) rows_to_hbm_fixed<KIN>(U, LDU, tr.sv + (size_t)tr.u * 64 + (size_t)win * T * KIN, KIN, T, opaque(tid));
         // ---- P1 in_linear (:79) + channel shuffle (folded) -------------------------------------------------------------
         {
             f32x4 acc[RBM][2], acct[RBT][2];
@@ -869,7 +930,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
         FH_STAMP(2);
         }
         const size_t grow0 = (size_t)win * T;           // first global row (b*T + t) of this window
-        if (TR) rows_to_hbm(X, LDX, D, tr.sv + (size_t)tr.x0 * 64 + grow0 * D, D, T, tid);
+        if (TR) rows_to_hbm_fixed<D>(X, LDX, tr.sv + (size_t)tr.x0 * 64 + grow0 * D, D, T, opaque(tid));
 #pragma unroll 1
         for (int layer = 0; layer < L; ++layer) {
             FH_STAMP(8);
@@ -965,7 +1026,7 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
             }
             __syncthreads();
             FH_STAMP(15);
-            if (TR) rows_to_hbm(Oc, LDX, D, svl + (size_t)tr.att * 64 + grow0 * D, D, T, opaque(tid));
+            if (TR) rows_to_hbm_fixed<D>(Oc, LDX, svl + (size_t)tr.att * 64 + grow0 * D, D, T, opaque(tid));
             ring_prefetch<2>(g_f, rsrc, voff, lbase + (int)(W1_W * 4) + (wave * 2) * 16 * 1024, 16 * 1024);
             f32x4 acc_o[RBM][2], acc_ot[RBT][2];
             zero_acc_h<2>(acc_o, acc_ot);
@@ -1061,7 +1122,9 @@ __global__ __launch_bounds__(fz::THREADS) void fused_encoder_h_kernel(
                 FH_STAMP(19 + 3 * f);
                 __syncthreads();
                 FH_STAMP(20 + 3 * f);
-                if (TR) rows_to_hbm(Hc, LDX, 256, svl + (size_t)tr.hid * 64 + grow0 * F + f * 256, F, T, opaque(tid));
+                if (TR)   // (the gate bits sit behind the layer's [M][F] hidden rows: saved_layout, tip_train.hip)
+                    hidden_to_hbm<true>(Hc, LDX, svl + (size_t)tr.hid * 64 + grow0 * F + f * 256, F,
+                                  reinterpret_cast<unsigned*>(svl + (size_t)tr.hid * 64 + (size_t)B * T * F) + grow0 * 32, f, T, opaque(tid));
                 {
                     const int w2off = lbase + (int)(W2_W * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                     const int nxt = f < 3 ? lbase + (int)(W1_W * 4) + ((f + 1) * 16 + wave * 2) * 16 * 1024 : w2off;
@@ -1294,6 +1357,10 @@ __device__ __forceinline__ void bwd_stamp(int on, int slot) {
 }
 
 
+// BITS: the ReLU / dropout gates come as the bit array the fused training forward wrote (hidden_to_hbm), staged into LDS once per
+// window; otherwise (layer-by-layer forward) from the saved fp32 hidden rows.
+constexpr int kGateLd = 36;   // dwords per row of the LDS copy (32 + 4: the 16 rows a lane group reads sit on distinct bank quads)
+template <bool BITS>
 __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int B, int T) {
     using namespace fz;
     using namespace fzh;   // hybrid row tiling as in fused_encoder_h_kernel: rows 0-31 on 16x16x4, rows 32-39 on 4x4x1 MFMAs, nothing on pad rows
@@ -1301,6 +1368,8 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
     float* G = smem;                       // dy -> dz2 -> dx1
     float* Mb = smem + RP * LDX;           // dff2 (masked dz2)
     float* Hc = smem + 2 * RP * LDX;       // dpre chunk; scratch for the LayerNorm parameter partials before that
+    unsigned* GB = reinterpret_cast<unsigned*>(smem + 3 * RP * LDX);   // BITS: this window's gate bits [RP][kGateLd], dword f*8 + half*4 + e
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
@@ -1318,6 +1387,8 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
         bwd_stamp(a.trace, 0);
         WRing<2> g_f;
         ring_prefetch<2>(g_f, rsrc, voff, lbase + (int)(fb::W2T * 4) + (wave * 2) * 16 * 1024, 16 * 1024);
+        u32x4 gq = {0u, 0u, 0u, 0u};   // BITS: 16 bytes of this window's 40 x 128 B of gate bits per thread (tid < 8 T), to LDS below
+        if (BITS && tid < 8 * T) gq = *reinterpret_cast<const u32x4*>(a.gbits + (grow0 + (tid >> 3)) * 32 + (tid & 7) * 4);
         // ---- LayerNorm2 backward, one wave per row (rows w, w+8, ...) ------------------------------------------------------
         {
             const float4 gg = *reinterpret_cast<const float4*>(a.g2 + lane * 4);
@@ -1374,6 +1445,12 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
             *reinterpret_cast<float4*>(red + (wave * 3 + 1) * D + lane * 4) = db;
             *reinterpret_cast<float4*>(red + (wave * 3 + 2) * D + lane * 4) = dm;
         }
+        if (BITS && tid < 8 * T) {
+            // global dwords (f*8 + 2 e + half) -> LDS dwords (f*8 + 4 half + e): a lane's four e of one half are then one 16-byte read
+            const int row = tid >> 3, q = tid & 7, fq = q >> 1, e0 = (q & 1) * 2;
+            unsigned* g = GB + row * kGateLd + fq * 8;
+            g[e0] = gq[0]; g[4 + e0] = gq[1]; g[e0 + 1] = gq[2]; g[4 + e0 + 1] = gq[3];
+        }
         __syncthreads();
         for (int i = tid; i < 3 * D; i += THREADS) {
             float s = 0.f;
@@ -1399,6 +1476,16 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
                 // optimiser, so they stay here) and consumed after.
                 f32x4 gate[RBM][2];
                 float gatet[RBT][2];   // the tail comes out in the plain orientation: lane (lg, l15) = row 32 + 4 rb + lg, channel l15
+                u32x4 gw[RBM];         // BITS: row r*16 + l15, dword e: bit ((wave & 3)*2 + n)*4 + lg is the gate of element (r, n, e)
+                unsigned gwt[RBT];     // BITS: row 32 + 4 rb + lg, dword of e = l15 & 3: bit ((wave & 3)*2 + n)*4 + (l15 >> 2)
+                if (BITS) {
+                    const int half = wave >> 2;
+#pragma unroll
+                    for (int r = 0; r < RBM; ++r) gw[r] = *reinterpret_cast<const u32x4*>(GB + (r * 16 + l15) * kGateLd + f * 8 + half * 4);
+#pragma unroll
+                    for (int rb = 0; rb < RBT; ++rb) gwt[rb] = GB[(TAIL0 + 4 * rb + lg) * kGateLd + f * 8 + half * 4 + (l15 & 3)];
+                }
+                if (!BITS) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
 #pragma unroll
@@ -1414,6 +1501,7 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
                         gatet[rb][n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(hrs, (int)off, 0, 0));
                     }
                 }
+                }
                 // the tail of this phase primes the ring with the dx1 phase's first fragments
                 gemm_phase_h<2, 16, 2, true>(acc, acct, Mb + am(LDX), Mb + at(LDX), LDX, rsrc, voff, w2off, 16 * 1024, g_f, w1off, 64 * 1024);
 #pragma unroll
@@ -1424,7 +1512,10 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
                         const int row = r * 16 + l15;
                         f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = (row < T && gate[r][n][e] > 0.f) ? acc[r][n][e] * a.gate_scale : 0.f;
+                        for (int e = 0; e < 4; ++e) {
+                            const bool open = BITS ? ((gw[r][e] >> (((wave & 3) * 2 + n) * 4 + lg)) & 1u) != 0u : gate[r][n][e] > 0.f;
+                            v[e] = (row < T && open) ? acc[r][n][e] * a.gate_scale : 0.f;
+                        }
                         *reinterpret_cast<f32x4*>(Hc + row * LDX + (wave * 2 + n) * 16 + lg * 4) = v;
                         bs += v;
                     }
@@ -1433,7 +1524,8 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
                     for (int rb = 0; rb < RBT; ++rb) {
                         const int row = TAIL0 + 4 * rb + lg;
                         const float x = tail_reduce(acct[rb][n], lg);
-                        const float v = (row < T && gatet[rb][n] > 0.f) ? x * a.gate_scale : 0.f;
+                        const bool open = BITS ? ((gwt[rb] >> (((wave & 3) * 2 + n) * 4 + (l15 >> 2))) & 1u) != 0u : gatet[rb][n] > 0.f;
+                        const float v = (row < T && open) ? x * a.gate_scale : 0.f;
                         Hc[row * LDX + (wave * 2 + n) * 16 + l15] = v;
                         ts += v;
                     }
@@ -1453,7 +1545,7 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
             if (f == 0) bwd_stamp(a.trace, 2);     // first chunk: d(hidden) product done
             __syncthreads();
             if (f == 0) bwd_stamp(a.trace, 3);
-            rows_to_hbm(Hc, LDX, 256, a.dpre + grow0 * F + f * 256, F, T, tid);
+            rows_to_hbm_fixed<256>(Hc, LDX, a.dpre + grow0 * F + f * 256, F, T, tid);   // (a counted number of stores in front of the dx1 phase's ring)
             {
                 const int w1off = lbase + (int)(fb::W1T * 4) + ((wave * 2) * 64 + f * 16) * 1024;
                 const int nxt = f < 3 ? lbase + (int)(fb::W2T * 4) + ((f + 1) * 16 + wave * 2) * 16 * 1024 : w1off;
@@ -1484,7 +1576,7 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
             for (int rb = 0; rb < RBT; ++rb) G[(TAIL0 + 4 * rb + lg) * LDX + col] = gt_[rb] + tail_reduce(acc_xt[rb][n], lg);
         }
         __syncthreads();
-        rows_to_hbm(G, LDX, D, a.dx1 + grow0 * D, D, T, tid);
+        rows_to_hbm_fixed<D>(G, LDX, a.dx1 + grow0 * D, D, T, tid);
         bwd_stamp(a.trace, 7);
         __syncthreads();
     }
@@ -1493,10 +1585,12 @@ __global__ __launch_bounds__(fz::THREADS) void ffn_bwd_kernel(FfnBwdArgs a, int 
 hipError_t launch_ffn_bwd(const Dims& d, const FfnBwdArgs& a, int B, int T, int num_cus, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (!fused_supported(d, T) || (long long)B * T * d.F * 4 > 0x7fffffffLL) return hipErrorInvalidValue;
-    constexpr int lds = 3 * fz::RP * fz::LDX * 4;
+    constexpr int lds = (3 * fz::RP * fz::LDX + fz::RP * kGateLd) * 4;
+    static_assert(lds <= 160 * 1024, "LDS of one CU");
     static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -1505,7 +1599,8 @@ hipError_t launch_ffn_bwd(const Dims& d, const FfnBwdArgs& a, int B, int T, int 
     static int trace = -1;
     if (trace < 0) trace = tip_env("TIP_BWD_TRACE") ? 1 : 0;
     aa.trace = trace;
-    hipLaunchKernelGGL(ffn_bwd_kernel, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
+    if (aa.gbits) hipLaunchKernelGGL(ffn_bwd_kernel<true>, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
+    else hipLaunchKernelGGL(ffn_bwd_kernel<false>, dim3(B < num_cus ? B : num_cus), dim3(fz::THREADS), lds, s, aa, B, T);
     return hipGetLastError();
 }
 

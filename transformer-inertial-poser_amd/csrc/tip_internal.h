@@ -359,6 +359,8 @@ struct FfnBwdArgs {
     const float* st2;
     const float* g2;        // LayerNorm2 weight
     const float* hid;       // [M,F] saved hidden (after ReLU and dropout)
+    const unsigned* gbits;  // [M][32 dwords] the same rows' gates (hidden > 0) as bits, written by the fused training forward
+                            // (tip_fused.hip: hidden_to_hbm), or null: the kernel then reads the gates from `hid`
     int hid_bytes;          // (set by the launcher)
     int trace;              // (set by the launcher) TIP_BWD_TRACE=1: phase stamps of workgroup 0 (measurement)
     float gate_scale;       // 1 / (1 - p)

@@ -1347,6 +1347,14 @@ static size_t take(size_t& off, size_t n) {
     return o;
 }
 
+// the encoder of the training forward runs as the one fused kernel (paper configuration with the RNN; tip_train_forward), which also
+// writes the FFN gates as bits for ffn_bwd_kernel; tip_train_backward asks the same question
+static bool train_forward_is_fused(const Dims& d, int T) {
+    static int use_fused = -1;   // TIP_TRAIN_FUSED=0: layer-by-layer forward (measurement)
+    if (use_fused < 0) use_fused = (tip_env("TIP_TRAIN_FUSED") && tip_env("TIP_TRAIN_FUSED")[0] == '0') ? 0 : 1;
+    return use_fused && fused_supported(d, T) && fused_has_rnn_ih(d) && fused_packed_floats(d) > 0;
+}
+
 static TrainSaved saved_layout(const Dims& d, int B, int T) {
     TrainSaved L;
     const size_t M = (size_t)B * T;
@@ -1377,7 +1385,8 @@ static TrainSaved saved_layout(const Dims& d, int B, int T) {
         t.z1 = take(off, M * d.D);
         t.st1 = take(off, M * 2);
         t.x1 = take(off, M * d.D);
-        t.hid = take(off, M * d.F);
+        // + the fused FFN backward's gate bits, one bit per hidden element, behind the rows (tip_fused.hip: hidden_to_hbm)
+        t.hid = take(off, M * d.F + (fused_supported(d, T) ? M * (d.F / 32) : 0));
         t.z2 = take(off, M * d.D);
         t.st2 = take(off, M * 2);
         t.xo = take(off, M * d.D);
@@ -1622,9 +1631,7 @@ int tip_train_forward(tip_handle* h, const float* const* params, int n_params, c
     // Paper configuration: the encoder runs as ONE kernel — the fused inference kernel with its activations stashed and the
     // dropout sites live (tip_fused.hip, fused_encoder_kernel<8>) — on a weight image packed on the GPU from the live
     // parameters.  Any other supported configuration takes the layer-by-layer path below.
-    static int use_fused = -1;   // TIP_TRAIN_FUSED=0: layer-by-layer forward (measurement)
-    if (use_fused < 0) use_fused = (tip_env("TIP_TRAIN_FUSED") && tip_env("TIP_TRAIN_FUSED")[0] == '0') ? 0 : 1;
-    const bool fused = use_fused && fused_supported(d, T) && fused_has_rnn_ih(d) && fused_packed_floats(d) > 0;
+    const bool fused = train_forward_is_fused(d, T);
     bool hall_armed = false;
     if (fused) {
         std::vector<PackOp> ops;
@@ -1923,6 +1930,7 @@ int tip_train_backward(tip_handle* h, const float* const* params, int n_params, 
             FfnBwdArgs fa;
             fa.wimg = X + S.bwimg; fa.wbytes = (int)(fused_bwd_image_floats(d) * 4); fa.layer = l;
             fa.dy = gx; fa.z2 = W + t.z2; fa.st2 = W + t.st2; fa.g2 = lp[PL_N2_W]; fa.hid = W + t.hid;
+            fa.gbits = train_forward_is_fused(d, T) ? reinterpret_cast<const unsigned*>(W + t.hid + (size_t)M * d.F) : nullptr;
             fa.gate_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.f;
             float* lnw_f = X + S.lnwin + (size_t)l * B * (9 * d.D + d.F);        // this layer's FFN-half partials
             float* lnw_a = lnw_f + (size_t)B * (3 * d.D + d.F);                   // ... and attention-half partials
