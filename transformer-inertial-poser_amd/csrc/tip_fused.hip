@@ -1634,6 +1634,7 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
     float* Qs = Sc + wave * (3 * RP * LDT);             // this wave's head: Q rows [48][16] (row-major) ...
     float* Ks = Qs + RP * LDT;                          // ... and K rows: read back as (row 4*lg + e, channel l15) B fragments
     float* Gs = Ks + RP * LDT;                          // dO tile: written in the accumulator layout, read back as row fragments
+    float* Ts = Gs;                                     // ... and, once it has been read, the P | dS transposition tiles [2][16][20]
     const unsigned dkey0 = tip_drop_key_s(a.seed, a.site0), dkey1 = tip_drop_key_s(a.seed, a.site1);
 
     for (int win = blockIdx.x; win < B; win += gridDim.x) {
@@ -1774,23 +1775,17 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const int q = r * 16 + l15;
-                float m2[4], i2[4], d2[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    m2[e] = __shfl(mq[r], lg * 4 + e, 64);
-                    i2[e] = __shfl(iq[r], lg * 4 + e, 64);
-                    d2[e] = __shfl(dd[r], lg * 4 + e, 64);
-                }
                 f32x4 dq = zero4;
 #pragma unroll
                 for (int cb = 0; cb <= r; ++cb) {
-                    // layout 1: (key 4*lg + e, query l15) -> dQ
+                    // (key 4*lg + e, query l15): scores and dP once, on the matrix pipe
                     f32x4 s1 = zero4, p1 = zero4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[cb][e], qf[r][e], s1, 0, 0, 0);
                         p1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[cb][e], gs[r][e], p1, 0, 0, 0);
                     }
+                    f32x4 pd, ds;   // dropped probabilities, dS: the operands of dV / dK in the transposed layout
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int kk = cb * 16 + lg * 4 + e;
@@ -1799,27 +1794,31 @@ __global__ __launch_bounds__(fz::THREADS) void attn_bwd_kernel(AttnBwdArgs a, in
                         const float p = __expf((kk <= q && q < T) ? s1[e] * a.q_scale - mq[r] : -INFINITY) * iq[r];
                         float kf_ = 1.f;
                         if (DROP) kf_ = tip_drop_hash_k(dkey0, (bh * T + q) * T + kk) >= a.thresh ? a.scale : 0.f;
-                        const float v = p * (p1[e] * kf_ - dd[r]);
-                        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(v, Ks[(cb * 16 + lg * 4 + e) * LDT + l15], dq, 0, 0, 0);
+                        pd[e] = p * kf_;
+                        ds[e] = p * (p1[e] * kf_ - dd[r]);
                     }
-                    // layout 2: (query 4*lg + e, key l15) -> dK, dV
-                    f32x4 s2 = zero4, p2 = zero4;
+                    // The same two tiles with the roles of the lane and the register swapped — (query 4*lg + e, key l15), what dV and
+                    // dK reduce over — through the wave's scratch (the dO tile's, free since gs was read): 8 LDS writes + 2 reads.
+                    // Vector-ALU work does not issue under fp32 MFMAs on this part (tools/probes/coissue_probe.hip), LDS traffic
+                    // does: until round 5 this layout was COMPUTED a second time (8 MFMAs, 4 exponentials, 4 dropout hashes and 12
+                    // cross-lane reads per block pair), and the heads ran at 52 % of their MFMA time.
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        s2 = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[r][e], kf[cb][e], s2, 0, 0, 0);
-                        p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(gs[r][e], vf[cb][e], p2, 0, 0, 0);
+                        Ts[(lg * 4 + e) * LDT + l15] = pd[e];
+                        Ts[(16 + lg * 4 + e) * LDT + l15] = ds[e];
                     }
-                    const int key = cb * 16 + l15;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        dq = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[e], Ks[(cb * 16 + lg * 4 + e) * LDT + l15], dq, 0, 0, 0);
+                    __builtin_amdgcn_wave_barrier();
+                    const f32x4 pdt = *reinterpret_cast<const f32x4*>(Ts + l15 * LDT + lg * 4);
+                    const f32x4 dst = *reinterpret_cast<const f32x4*>(Ts + (16 + l15) * LDT + lg * 4);
+                    __builtin_amdgcn_wave_barrier();   // (the next block pair's writes stay behind these reads)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int qq = r * 16 + lg * 4 + e;
-                        const float p = __expf((key <= qq && qq < T) ? s2[e] * a.q_scale - m2[e] : -INFINITY) * i2[e];
-                        float kf_ = 1.f;
-                        if (DROP) kf_ = tip_drop_hash_k(dkey0, (bh * T + qq) * T + key) >= a.thresh ? a.scale : 0.f;
-                        const float pdv = p * kf_;
-                        const float dsv = p * (p2[e] * kf_ - d2[e]);
-                        dv[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pdv, gp[r][e], dv[cb], 0, 0, 0);
-                        dk[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dsv, Qs[qq * LDT + l15], dk[cb], 0, 0, 0);
+                        dv[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(pdt[e], gp[r][e], dv[cb], 0, 0, 0);
+                        dk[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(dst[e], Qs[qq * LDT + l15], dk[cb], 0, 0, 0);
                     }
                 }
                 // dQ rows of block r: (queries 4*lg + e, channel l15)
