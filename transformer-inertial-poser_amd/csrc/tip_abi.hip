@@ -739,6 +739,68 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
             };
             // (a part never needs more workspace than the whole — carve_workspace is monotone, tests/test_host_cpu.py — but a caller's
             // buffer sized by an older library must fall through to the single launch sequence, not fail)
+            // Round 5: a remainder that takes the window-split encoder shares ONE recurrence and ONE output projection with the whole
+            // rounds — the two encoders write their windows' input terms (and arm their HALL rows) side by side in the whole batch's
+            // workspace — instead of bringing a 62-us recurrence + a projection launch of its own: the recurrence serves the extra
+            // tiles next to the ones it has (their hops overlap), ~35 us for up to 128 more windows.  rnn_hidden 512 only (the
+            // four-window recurrence, whose per-window results do not depend on the tiling); bit-identical to the two sequences.
+            const bool rem_f1s = r >= 1 && !(r <= (quad ? 32 : 48) && latency_supported(d, r, T)) && fused2_supported(d, T) && fused1s_fits(r, cus);
+            static const bool merge_on = !(tip_env("TIP_AUTO_MERGE") && tip_env("TIP_AUTO_MERGE")[0] == '0');   // measurement
+            // (the recurrence advances 1, 2 or 4 tiles per cluster together: a third tile costs a fourth's time, and a fifth a second
+            // pass — B = 556 measured 1 533 us merged against 1 509: merge only where the remainder does not push the whole rounds'
+            // tile count per cluster across such a step, or the rounds have a single tile)
+            const int tpg_b = ((B + 3) / 4 + 63) / 64, tpg_m = ((bm + 3) / 4 + 63) / 64;
+            const bool tiles_ok = cus == 256 && (tpg_b <= 2 || (tpg_b <= 4 && tpg_m >= 3));
+            if (merge_on && rem_f1s && tiles_ok && d.with_rnn && d.R == 512 && h->rnn_cluster == 0 && single(bm) + (quad ? 232 : 375) + 35 < single(B)) {
+                CoopSerial serial(h->device, s);
+                if (serial.status != hipSuccess) return fail_hip(h, serial.status, "stream serialisation");
+                const float* P = h->packed_dev;
+                const PackedLayout& L = h->lay;
+                float* W0 = static_cast<float*>(workspace);
+                float* big = W0 + ws.big;
+                float* hall = W0 + ws.hall;
+                const float* mask = (flags & TIP_FWD_KEEP_MASK) ? keep_mask : nullptr;
+                const float ks = mask ? keep_scale : 1.f;
+                const size_t row_i = (size_t)T * d.n_imu_total, row_s = (size_t)T * d.S, row_r = (size_t)T * d.R;
+                const bool armed = rnn_uses_sentinel(d, B, T, kRnnRows4);
+                hipError_t e;
+                {
+                    StageScope sc(h, s, "fused_encoder");
+                    const long long cusl = cus, rounds_h = (bm + cusl - 1) / cusl, rounds_2 = ((bm + 1) / 2 + cusl - 1) / cusl;
+                    if (fused2_supported(d, T) && rounds_2 * 1049 < rounds_h * 527)
+                        e = launch_fused_encoder2(d, P + L.fused_off, x_imu, x_s, mask, ks, big, armed ? hall : nullptr, bm, cus, s);
+                    else
+                        e = launch_fused_encoder_h(d, P + L.fused_off, x_imu, x_s, mask, ks, nullptr, big, armed ? hall : nullptr, bm, T, cus, s);
+                    if (e != hipSuccess) return fail_hip(h, e, "fused_encoder");
+                }
+                {
+                    StageScope sc(h, s, "fused_encoder");   // (the remainder's encoder: a stage of its own in the profile, as in the two-sequence form)
+                    e = launch_fused_encoder1s(d, P + L.fused_off, x_imu + bm * row_i, x_s + bm * row_s, mask ? mask + bm * row_s : nullptr, ks,
+                                               big + bm * row_r, armed ? hall + bm * row_r : nullptr, W0 + ws.xchg, r, cus, h->f1s_parts, gd, s);
+                    if (e != hipSuccess) return fail_hip(h, e, "fused_encoder1s");
+                }
+                {
+                    StageScope sc(h, s, "rnn_recurrence");
+                    e = launch_rnn(d, big, P + L.whh_frag_off, hall, reinterpret_cast<unsigned*>(W0 + ws.flags), B, T, kRnnRows4, cus, armed, gd, s);
+                    if (e != hipSuccess) return fail_hip(h, e, "rnn_recurrence");
+                }
+                {
+                    StageScope sc(h, s, "out_linear");
+                    const bool last_only = (flags & TIP_FWD_LAST_ROW_ONLY) != 0;
+                    const float* hA = last_only ? hall + (size_t)(T - 1) * d.R : hall;
+                    const long long hlda = last_only ? (long long)T * d.R : d.R;
+                    const int hM = last_only ? B : B * T;
+                    static const bool ksplit = !(tip_env("TIP_HEAD") && tip_env("TIP_HEAD")[0] == 'o');   // TIP_HEAD=old: measurement
+                    e = hipErrorInvalidValue;
+                    if (ksplit && T % 40 == 0)
+                        e = launch_head_ksplit(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, hM, d.S, d.R, last_only, cus, s);
+                    if (e == hipErrorInvalidValue)
+                        e = launch_head_gemm(hA, hlda, P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, hM, d.S, d.R, s);
+                    if (e != hipSuccess) return fail_hip(h, e, "out_linear");
+                }
+                h->forward_count++;
+                return TIP_OK;
+            }
             if (single(bm) + rem < single(B) && carve_workspace(d, bm, T).total_bytes <= workspace_bytes &&
                 carve_workspace(d, r, T).total_bytes <= workspace_bytes) {
                 const size_t row_i = (size_t)T * d.n_imu_total, row_s = (size_t)T * d.S;
