@@ -20,7 +20,7 @@ with contextlib.redirect_stdout(sys.stderr):
 w = synth.make_weights(cfg, seed=1)
 m.load_state_dict({k: torch.tensor(v) for k, v in w.items()})
 m = m.cuda().eval()
-BS = [1, 2, 3, 5, 8, 31, 32, 33, 40, 48, 49, 63, 64, 65, 66, 100, 127, 128, 129, 255, 256, 257, 258, 288, 289, 300, 320, 321, 384, 511, 512, 513, 600, 767, 768, 769, 1000, 1023, 1024, 1025, 1064, 1100, 1537, 2049]
+BS = [1, 2, 3, 5, 8, 31, 32, 33, 40, 48, 49, 63, 64, 65, 66, 100, 127, 128, 129, 255, 256, 257, 258, 288, 289, 300, 320, 321, 384, 511, 512, 513, 556, 600, 767, 768, 769, 801, 832, 896, 1000, 1023, 1024, 1025, 1064, 1100, 1537, 2049]
 cases = worst = 0
 unsupported = set()
 worst_case = None
