@@ -1245,21 +1245,27 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_rows4_kernel(const float* __re
                     // for the first fragment used covers the whole batch — one s_waitcnt per 32 MFMAs instead of one per 4 (a wave
                     // issues in order, and with a wait + a read between every four 8-cycle MFMAs it reached 73 % of the pipe's rate).
                     // The order of the sum over k is unchanged.
-                    constexpr int AB = 8;
+                    // A fragments in batches of AB k-blocks, NBUF batches in flight (LDS latency is 2-4 k-blocks of 4x4x1 issue time).  A batch
+                    // is REQUESTED last k-block first and CONSUMED first k-block first: LDS returns in order, so the wait for the first
+                    // fragment used covers the whole batch — one s_waitcnt per batch instead of one per k-block (a wave issues in order,
+                    // and with a wait + a read between every four 8-cycle MFMAs it reached 73 % of the pipe's rate).  Measured (B = 256 /
+                    // 1024, us): one k-block at a time 76.5 / 234; batches of 2: 75.4 / 244; of 8: 73.8 / 235.5; of 4, two in flight: 72.0-73.1 /
+                    // 233 — the first MFMA of a step waits for four fragments, not eight.  The order of the sum over k is unchanged.
+                    constexpr int AB = 4, NBUF = 2;
                     const float* ap = buf + n * kQ4Rows * LD + aoff;
-                    float4 a[2][AB];
+                    float4 a[NBUF][AB];
                     auto request = [&](int b) {
 #pragma unroll
-                        for (int j = AB - 1; j >= 0; --j) a[b & 1][j] = *reinterpret_cast<const float4*>(ap + (b * AB + j) * 16);
+                        for (int j = AB - 1; j >= 0; --j) a[b % NBUF][j] = *reinterpret_cast<const float4*>(ap + (b * AB + j) * 16);
                     };
-                    request(0);
-                    request(1);
+#pragma unroll
+                    for (int b = 0; b < NBUF; ++b) request(b);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int b = 0; b < KB / AB; ++b) {
 #pragma unroll
                         for (int j = 0; j < AB; ++j) {
-                            const float4 ak = a[b & 1][j];
+                            const float4 ak = a[b % NBUF][j];
                             const int k = b * AB + j;
                             c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.x, wreg[k].x, c0, 0, 0, 0);
                             c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.y, wreg[k].y, c1, 0, 0, 0);
@@ -1267,7 +1273,7 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_rows4_kernel(const float* __re
                             c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.w, wreg[k].w, c3, 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        if (b + 2 < KB / AB) request(b + 2);
+                        if (b + NBUF < KB / AB) request(b + NBUF);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }

@@ -13,6 +13,8 @@ CSRC = os.path.join(_HERE, "csrc")
 # environment switches are alive (csrc/Makefile: `make measure`); the default library ignores the environment.
 MEASURE = os.environ.get("TIP_LIB", "") == "measure"
 LIB_PATH = os.path.join(CSRC, "libtip_hip_measure.so" if MEASURE else "libtip_hip.so")
+if os.environ.get("TIP_LIB", "").endswith(".so"):   # (tools/: an A/B build of the library by path, e.g. gpurun_ab/libtip_x.so)
+    LIB_PATH = os.path.abspath(os.environ["TIP_LIB"])
 
 TIP_FWD_LAST_ROW_ONLY = 0x1
 TIP_FWD_KEEP_MASK = 0x2
