@@ -79,6 +79,28 @@ def test_reference_import_lines_resolve_to_the_dropin(tmp_path):
     assert out.stdout.strip().splitlines()[-1] == "KEYS 20"
 
 
+def test_top_k_logits_keeps_the_k_largest_per_row(tmp_path):
+    """learning_utils.py:88-92 semantics: everything below a row's k-th largest logit becomes -inf, the rest is untouched
+    (ties with the k-th value stay)."""
+    out = run_dropin("""
+        import torch
+        from learning_utils import top_k_logits
+        x = torch.tensor([[0.5, -1.0, 3.0, 2.0, 2.0], [1.0, 1.0, 1.0, 0.0, -2.0]])
+        y = top_k_logits(x, 2)
+        inf = float("inf")
+        assert y.tolist() == [[-inf, -inf, 3.0, 2.0, 2.0], [1.0, 1.0, 1.0, -inf, -inf]], y
+        assert x[0, 0] == 0.5          # the input is not modified
+        g = torch.Generator().manual_seed(3)
+        z = torch.randn(7, 33, generator=g)
+        for k in (1, 5, 33):
+            w = top_k_logits(z, k)
+            assert ((w > -inf).sum(1) == k).all() and torch.equal(w[w > -inf], z[w > -inf])
+        print("TOPK OK")
+        """, str(tmp_path))
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert out.stdout.strip().splitlines()[-1] == "TOPK OK"
+
+
 def test_old_recipe_is_gone():
     """The package directory itself must not be usable as a shadowing directory any more (its
     learning_utils.py shadowed the reference's and failed to import)."""

@@ -134,8 +134,7 @@ def set_seed(seed):
 
 
 def top_k_logits(logits, k):
-    """learning_utils.py:88-92 (unused by the training / inference scripts; kept so `from learning_utils import *` is whole)."""
-    v, ix = torch.topk(logits, k)
-    out = logits.clone()
-    out[out < v[:, [-1]]] = -float('Inf')
-    return out
+    """Rows of `logits` with everything below the row's k-th largest value set to -inf (the behaviour of learning_utils.py:88-92;
+    unused by the training / inference scripts, kept so that `from learning_utils import *` is whole)."""
+    kth = torch.topk(logits, k, dim=-1).values[..., -1:]
+    return torch.where(logits < kth, torch.full_like(logits, float("-inf")), logits)
