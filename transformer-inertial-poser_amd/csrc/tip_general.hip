@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 #include <random>
 
 #include "tip_internal.h"
@@ -1163,149 +1164,185 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_rows4_kernel(const float* __re
         g_rnn_trace[1024 + blockIdx.x] = (unsigned long long)hwid | ((unsigned long long)(xccid & 0xf) << 32);
     }
 
-    for (int q0 = dead ? tpg : 0; q0 < tpg; q0 += NT) {
-        if (q0 > 0) {
-            set_tiles(q0);
-            request_inputs(BWD ? T - 1 : 0);
-            touch_rows(BWD ? T - 1 : 0);
-        }
-        retire_touch();
-        if (T > 1) touch_rows(BWD ? T - 2 : 1);
-#pragma unroll 1
-        for (int t = 0; t < T; ++t) {
-            const int te = BWD ? T - 1 - t : t;        // time index this step produces
-            const int tp = BWD ? te + 1 : te - 1;      // time index of the state it consumes
-            float ihv[NT], gv[NT];
+    u32x4 pv[PL];                                                  // early-requested pull of the next tile (NT > 1)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) ihv[n] = ihn[n], gv[n] = gn[n];
-            float* buf = smem + (t & 1) * (NT * kQ4Rows * LD);
-            if (t > 0) {
-                // pull h_{t-1}: 16 bytes per thread and tile, sc1 loads (agent-scope coherent); the wave re-asks while any of
-                // its lanes still sees a sentinel word
-                const int so = tp * (R * 4);
-                u32x4 v[NT * PL];
-                bool gave_up = true;
-                const unsigned pull_lim = poisoned ? 1u : spin_pull;
-                for (unsigned spins = 0; spins < pull_lim; ++spins) {
-                    bool pend = false;
-                    asm volatile("" ::: "memory");   // the addresses are loop invariant: without this the optimiser polls a register
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-#pragma unroll
-                        for (int i = 0; i < PL; ++i) v[n * PL + i] = __builtin_amdgcn_raw_buffer_load_b128(hrs, vpull[n] + 16 * i, so, 16);
-#pragma unroll
-                    for (int n = 0; n < NT * PL; ++n)
-                        pend |= v[n].x == kRnnSentinel || v[n].y == kRnnSentinel || v[n].z == kRnnSentinel || v[n].w == kRnnSentinel;
-                    if (TRACE && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 24) {
-                        if (spins == 0) g_rnn_trace[160 + (t - 1) * 4 + 0] = __builtin_amdgcn_s_memtime();
-                        g_rnn_trace[160 + (t - 1) * 4 + 3] = spins + 1;
-                    }
-                    if (__builtin_amdgcn_ballot_w64(pend) == 0 || (abl & 1)) { gave_up = false; break; }
-                    if (!same_xcd) __builtin_amdgcn_s_sleep(2);   // cross-XCD polls travel the fabric: pace them
-                }
-                if (TRACE && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 24) g_rnn_trace[160 + (t - 1) * 4 + 1] = __builtin_amdgcn_s_memtime();
-                if (TRACE && (abl & 128) && ((abl >> 8) & 7) == 3 && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
-                if (gave_up) {   // (wave-uniform)
-                    if (!poisoned && lane == 0) note_spin_timeout(gd.err);
-                    poisoned = true;
-#pragma unroll
-                    for (int n = 0; n < NT * PL; ++n) {   // what never arrived becomes NaN, not the sentinel
-                        if (v[n].x == kRnnSentinel) v[n].x = kPoisonBits;
-                        if (v[n].y == kRnnSentinel) v[n].y = kPoisonBits;
-                        if (v[n].z == kRnnSentinel) v[n].z = kPoisonBits;
-                        if (v[n].w == kRnnSentinel) v[n].w = kPoisonBits;
-                    }
-                }
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int i = 0; i < PL; ++i) *reinterpret_cast<u32x4*>(buf + n * kQ4Rows * LD + lds_w + 4 * i) = v[n * PL + i];
-                if (TRACE && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 24) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    g_rnn_trace[160 + (t - 1) * 4 + 2] = __builtin_amdgcn_s_memtime();
-                }
-                __syncthreads();   // the only barrier of a step: the tile buffers alternate, so nobody overwrites what a slow wave still reads
+    for (int i = 0; i < PL; ++i) pv[i] = (u32x4){kRnnSentinel, kRnnSentinel, kRnnSentinel, kRnnSentinel};
+    // The whole step loop exists twice, for partners on this XCD (plain stores) and elsewhere (sc1 stores, paced polls): as a
+    // branch around the store inside the loop, the structurised control flow has a path without a store, and the compiler then
+    // cannot count the stores in flight — every wait behind it (the next tile's early pull) became vmcnt(0), i.e. waited for
+    // the store's acknowledgement.
+    auto run_steps = [&](auto same_tag) {
+        constexpr bool SAME_XCD = decltype(same_tag)::value;
+        for (int q0 = dead ? tpg : 0; q0 < tpg; q0 += NT) {
+            if (q0 > 0) {
+                set_tiles(q0);
+                request_inputs(BWD ? T - 1 : 0);
+                touch_rows(BWD ? T - 1 : 0);
             }
-            if (TRACE && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 0] = __builtin_amdgcn_s_memtime();
-            if (TRACE && (abl & 128) && ((abl >> 8) & 7) == 1 && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
             retire_touch();
-            {   // (clamped to the last step instead of skipped: branch-free; the extra loads hit rows this launch owns)
-                const int tn = t + 1 < T ? t + 1 : t, tn2 = t + 2 < T ? t + 2 : t;
-                request_inputs(BWD ? T - 1 - tn : tn);
-                if (!(abl & 4)) touch_rows(BWD ? T - 1 - tn2 : tn2);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const int so_out = te * (R * 4);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
-                if (t > 0 && !(abl & 2)) {
-                    // A fragments in batches of 8 k-blocks, two batches in flight (LDS latency is 2-4 k-blocks of 4x4x1 issue time).
-                    // A batch is REQUESTED last k-block first and CONSUMED first k-block first: LDS returns in order, so the wait
-                    // for the first fragment used covers the whole batch — one s_waitcnt per 32 MFMAs instead of one per 4 (a wave
-                    // issues in order, and with a wait + a read between every four 8-cycle MFMAs it reached 73 % of the pipe's rate).
-                    // The order of the sum over k is unchanged.
-                    // A fragments in batches of AB k-blocks, NBUF batches in flight (LDS latency is 2-4 k-blocks of 4x4x1 issue time).  A batch
-                    // is REQUESTED last k-block first and CONSUMED first k-block first: LDS returns in order, so the wait for the first
-                    // fragment used covers the whole batch — one s_waitcnt per batch instead of one per k-block (a wave issues in order,
-                    // and with a wait + a read between every four 8-cycle MFMAs it reached 73 % of the pipe's rate).  Measured (B = 256 /
-                    // 1024, us): one k-block at a time 76.5 / 234; batches of 2: 75.4 / 244; of 8: 73.8 / 235.5; of 4, two in flight: 72.0-73.1 /
-                    // 233 — the first MFMA of a step waits for four fragments, not eight.  The order of the sum over k is unchanged.
-                    constexpr int AB = 4, NBUF = 2;
-                    const float* ap = buf + n * kQ4Rows * LD + aoff;
-                    float4 a[NBUF][AB];
-                    auto request = [&](int b) {
-#pragma unroll
-                        for (int j = AB - 1; j >= 0; --j) a[b % NBUF][j] = *reinterpret_cast<const float4*>(ap + (b * AB + j) * 16);
-                    };
-#pragma unroll
-                    for (int b = 0; b < NBUF; ++b) request(b);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int b = 0; b < KB / AB; ++b) {
-#pragma unroll
-                        for (int j = 0; j < AB; ++j) {
-                            const float4 ak = a[b % NBUF][j];
-                            const int k = b * AB + j;
-                            c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.x, wreg[k].x, c0, 0, 0, 0);
-                            c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.y, wreg[k].y, c1, 0, 0, 0);
-                            c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.z, wreg[k].z, c2, 0, 0, 0);
-                            c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.w, wreg[k].w, c3, 0, 0, 0);
+            if (T > 1) touch_rows(BWD ? T - 2 : 1);
+    #pragma unroll 1
+            for (int t = 0; t < T; ++t) {
+                const int te = BWD ? T - 1 - t : t;        // time index this step produces
+                const int tp = BWD ? te + 1 : te - 1;      // time index of the state it consumes
+                float ihv[NT], gv[NT];
+    #pragma unroll
+                for (int n = 0; n < NT; ++n) ihv[n] = ihn[n], gv[n] = gn[n];
+                float* buf = smem + (t & 1) * (NT * kQ4Rows * LD);
+                const int so_out = te * (R * 4);
+                // Tile by tile: pull -> LDS -> barrier -> MFMAs -> tanh -> store.  With several tiles per cluster (NT > 1) the pull of the
+                // NEXT tile (the first tile's of the next step behind the last one) is requested in front of this tile's matrix phase:
+                // that tile's state was stored one to NT - 1 matrix phases ago, so the request finds it in L2 and its round trip runs
+                // under the MFMAs; only a request that still saw a sentinel falls back to the polling loop.  Pulling every tile at the
+                // top of the step left the last tile's hop exposed on every step (first version); pulling tile by tile WITHOUT the early
+                // request exposed an L2 round trip + LDS write + barrier per tile (B = 1024: 251 us against 235).  One barrier per
+                // tile and step: the tile buffers alternate with t, so nobody overwrites what a slow wave still reads.  Same
+                // arithmetic per tile, bit-identical.
+    #pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if (t > 0) {
+                        // pull h_{t-1}: 16 bytes per thread, sc1 loads (agent-scope coherent); the wave re-asks while any of its lanes
+                        // still sees a sentinel word
+                        const int so = tp * (R * 4);
+                        u32x4 v[PL];
+                        bool pend = true;
+                        if (NT > 1) {
+                            pend = false;
+    #pragma unroll
+                            for (int i = 0; i < PL; ++i) {
+                                v[i] = pv[i];
+                                pend |= v[i].x == kRnnSentinel || v[i].y == kRnnSentinel || v[i].z == kRnnSentinel || v[i].w == kRnnSentinel;
+                            }
                         }
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (b + NBUF < KB / AB) request(b + NBUF);
-                        __builtin_amdgcn_sched_barrier(0);
+                        bool gave_up = false;
+                        if (NT == 1 || (__builtin_amdgcn_ballot_w64(pend) != 0 && !(abl & 1))) {   // (wave-uniform)
+                            gave_up = true;
+                            const unsigned pull_lim = poisoned ? 1u : spin_pull;
+                            for (unsigned spins = 0; spins < pull_lim; ++spins) {
+                                pend = false;
+                                asm volatile("" ::: "memory");   // the addresses are loop invariant: without this the optimiser polls a register
+    #pragma unroll
+                                for (int i = 0; i < PL; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(hrs, vpull[n] + 16 * i, so, 16);
+    #pragma unroll
+                                for (int i = 0; i < PL; ++i)
+                                    pend |= v[i].x == kRnnSentinel || v[i].y == kRnnSentinel || v[i].z == kRnnSentinel || v[i].w == kRnnSentinel;
+                                if (TRACE && n == 0 && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 24) {
+                                    if (spins == 0) g_rnn_trace[160 + (t - 1) * 4 + 0] = __builtin_amdgcn_s_memtime();
+                                    g_rnn_trace[160 + (t - 1) * 4 + 3] = spins + 1;
+                                }
+                                if (__builtin_amdgcn_ballot_w64(pend) == 0 || (abl & 1)) { gave_up = false; break; }
+                                if (!SAME_XCD) __builtin_amdgcn_s_sleep(2);   // cross-XCD polls travel the fabric: pace them
+                            }
+                        }
+                        if (TRACE && n == 0 && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 24) g_rnn_trace[160 + (t - 1) * 4 + 1] = __builtin_amdgcn_s_memtime();
+                        if (TRACE && n == 0 && (abl & 128) && ((abl >> 8) & 7) == 3 && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
+                        if (gave_up) {   // (wave-uniform)
+                            if (!poisoned && lane == 0) note_spin_timeout(gd.err);
+                            poisoned = true;
+    #pragma unroll
+                            for (int i = 0; i < PL; ++i) {   // what never arrived becomes NaN, not the sentinel
+                                if (v[i].x == kRnnSentinel) v[i].x = kPoisonBits;
+                                if (v[i].y == kRnnSentinel) v[i].y = kPoisonBits;
+                                if (v[i].z == kRnnSentinel) v[i].z = kPoisonBits;
+                                if (v[i].w == kRnnSentinel) v[i].w = kPoisonBits;
+                            }
+                        }
+    #pragma unroll
+                        for (int i = 0; i < PL; ++i) *reinterpret_cast<u32x4*>(buf + n * kQ4Rows * LD + lds_w + 4 * i) = v[i];
+                        if (TRACE && n == 0 && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 24) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            g_rnn_trace[160 + (t - 1) * 4 + 2] = __builtin_amdgcn_s_memtime();
+                        }
+                        __syncthreads();
                     }
+                    if (TRACE && n == 0 && !(abl & 128) && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 0] = __builtin_amdgcn_s_memtime();
+                    if (TRACE && n == 0 && (abl & 128) && ((abl >> 8) & 7) == 1 && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
+                    if (n == NT - 1) {
+                        // the next step's input terms and the row touches of the step after it, behind the LAST pull of this step: vector
+                        // memory returns in order, so in front of a pull they would hold it back by their HBM latency
+                        // (clamped to the last step instead of skipped: branch-free; the extra loads hit rows this launch owns)
+                        retire_touch();
+                        const int tn = t + 1 < T ? t + 1 : t, tn2 = t + 2 < T ? t + 2 : t;
+                        request_inputs(BWD ? T - 1 - tn : tn);
+                        if (!(abl & 4)) touch_rows(BWD ? T - 1 - tn2 : tn2);
+                    }
+                    if (NT > 1) {
+                        // early request of the next pull: tile n + 1 of this step, or tile 0 of the next one
+                        const int nn = (n + 1) % NT;
+                        const int tq = n == NT - 1 ? t + 1 : t;              // the step that will consume it
+                        // (always requested, never behind a branch: a loaded value that meets a constant at a join makes the compiler wait
+                        // for it there; steps 0 and T do not pull — their request is clamped to a row of this launch and dropped)
+                        const int tqc = tq < 1 ? 1 : (tq > T - 1 ? (T > 1 ? T - 1 : 1) : tq);
+                        const int soq = (BWD ? T - tqc : tqc - 1) * (R * 4);
+    #pragma unroll
+                        for (int i = 0; i < PL; ++i) pv[i] = __builtin_amdgcn_raw_buffer_load_b128(hrs, vpull[nn] + 16 * i, soq, 16);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+                    if (t > 0 && !(abl & 2)) {
+                        // A fragments in batches of AB k-blocks, NBUF batches in flight (LDS latency is 2-4 k-blocks of 4x4x1 issue time).  A batch
+                        // is REQUESTED last k-block first and CONSUMED first k-block first: LDS returns in order, so the wait for the first
+                        // fragment used covers the whole batch — one s_waitcnt per batch instead of one per k-block (a wave issues in order,
+                        // and with a wait + a read between every four 8-cycle MFMAs it reached 73 % of the pipe's rate).  Measured (B = 256 /
+                        // 1024, us): one k-block at a time 76.5 / 234; batches of 2: 75.4 / 244; of 8: 73.8 / 235.5; of 4, two in flight: 72.0-73.1 /
+                        // 233 — the first MFMA of a step waits for four fragments, not eight.  The order of the sum over k is unchanged.
+                        constexpr int AB = 4, NBUF = 2;
+                        const float* ap = buf + n * kQ4Rows * LD + aoff;
+                        float4 a[NBUF][AB];
+                        auto request = [&](int b) {
+    #pragma unroll
+                            for (int j = AB - 1; j >= 0; --j) a[b % NBUF][j] = *reinterpret_cast<const float4*>(ap + (b * AB + j) * 16);
+                        };
+    #pragma unroll
+                        for (int b = 0; b < NBUF; ++b) request(b);
+                        __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                        for (int b = 0; b < KB / AB; ++b) {
+    #pragma unroll
+                            for (int j = 0; j < AB; ++j) {
+                                const float4 ak = a[b % NBUF][j];
+                                const int k = b * AB + j;
+                                c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.x, wreg[k].x, c0, 0, 0, 0);
+                                c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.y, wreg[k].y, c1, 0, 0, 0);
+                                c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.z, wreg[k].z, c2, 0, 0, 0);
+                                c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.w, wreg[k].w, c3, 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (b + NBUF < KB / AB) request(b + NBUF);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    const f32x4 p = (c0 + c1) + (c2 + c3);   // registers = rows 0..3, one k-partial per lane group
+                    // reduce-scatter over the lane groups: lane (lg, l15) ends with row lg (as tip_fused.hip's tail_reduce)
+                    float a0 = p[0], a2 = p[2];
+                    swap32(a0, a2);
+                    float k0 = a0 + a2;
+                    float a1 = p[1], a3 = p[3];
+                    swap32(a1, a3);
+                    float k1 = a1 + a3;
+                    swap16(k0, k1);
+                    const float acc = k0 + k1;
+                    if (TRACE && !(abl & 128) && n == 0 && blockIdx.x == 0 && tid == 0 && t < 64) {
+                        asm volatile("" :: "v"(acc));
+                        g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
+                    }
+                    if (TRACE && (abl & 128) && ((abl >> 8) & 7) == 2 && n == 0 && blockIdx.x == 0 && tid == 0 && t < 64) {
+                        asm volatile("" :: "v"(c0[0]), "v"(c1[0]), "v"(c2[0]), "v"(c3[0]));   // MFMAs of tile 0 done, before the reduction
+                        g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
+                    }
+                    float hv = BWD ? (acc + ihv[n]) * (1.0f - gv[n] * gv[n]) : tip_tanh(acc + ihv[n]);
+                    if (hv != hv) hv = __uint_as_float(kPoisonBits);   // poison travels as the canonical NaN, never as the sentinel
+                    // same XCD (verified): a plain store lands in the shared L2 (L1 is write-through); otherwise sc1 = write-through
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), hrs, vout[n], so_out, SAME_XCD ? 0 : 16);
                 }
-                const f32x4 p = (c0 + c1) + (c2 + c3);   // registers = rows 0..3, one k-partial per lane group
-                // reduce-scatter over the lane groups: lane (lg, l15) ends with row lg (as tip_fused.hip's tail_reduce)
-                float a0 = p[0], a2 = p[2];
-                swap32(a0, a2);
-                float k0 = a0 + a2;
-                float a1 = p[1], a3 = p[3];
-                swap32(a1, a3);
-                float k1 = a1 + a3;
-                swap16(k0, k1);
-                const float acc = k0 + k1;
-                if (TRACE && !(abl & 128) && n == 0 && blockIdx.x == 0 && tid == 0 && t < 64) {
-                    asm volatile("" :: "v"(acc));
-                    g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
-                }
-                if (TRACE && (abl & 128) && ((abl >> 8) & 7) == 2 && n == 0 && blockIdx.x == 0 && tid == 0 && t < 64) {
-                    asm volatile("" :: "v"(c0[0]), "v"(c1[0]), "v"(c2[0]), "v"(c3[0]));   // MFMAs of tile 0 done, before the reduction
-                    g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
-                }
-                float hv = BWD ? (acc + ihv[n]) * (1.0f - gv[n] * gv[n]) : tip_tanh(acc + ihv[n]);
-                if (hv != hv) hv = __uint_as_float(kPoisonBits);   // poison travels as the canonical NaN, never as the sentinel
-                // same XCD (verified): a plain store lands in the shared L2 (L1 is write-through); otherwise sc1 = write-through
-                if (same_xcd) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), hrs, vout[n], so_out, 0);
-                else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), hrs, vout[n], so_out, 16);
+                if (TRACE && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 2] = __builtin_amdgcn_s_memtime();
             }
-            if (TRACE && blockIdx.x == 0 && tid == 0 && t < 64) g_rnn_trace[t * 4 + 2] = __builtin_amdgcn_s_memtime();
+            retire_touch();
+            __syncthreads();   // the next batch's second step rewrites the buffer the last step of this one may still be reading
         }
-        retire_touch();
-        __syncthreads();   // the next batch's second step rewrites the buffer the last step of this one may still be reading
-    }
+    };
+    if (same_xcd) run_steps(std::true_type{});
+    else run_steps(std::false_type{});
     // leave the XCC-exchange word cleared for a replay of this launch from a HIP graph (same tag): see rnn_resident_kernel
     if (T >= 2 && tid == 0 && !dead) __hip_atomic_store(flags + group * CLUSTER + cid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
