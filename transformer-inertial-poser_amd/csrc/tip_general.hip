@@ -1308,7 +1308,14 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_rows4_kernel(const float* __re
                                 c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(ak.w, wreg[k].w, c3, 0, 0, 0);
                             }
                             __builtin_amdgcn_sched_barrier(0);
+#ifdef TIP_MEASURE
+                            // MEASUREMENT (TIP_RNN_ABLATE bit 4, wrong results): only the first NBUF batches of A fragments are read from
+                            // LDS, the MFMAs of the later ones reuse their registers — 8 instead of 32 ds_read_b128 per wave and tile:
+                            // what the matrix phase costs without its LDS traffic
+                            if (b + NBUF < KB / AB && !(abl & 16)) request(b + NBUF);
+#else
                             if (b + NBUF < KB / AB) request(b + NBUF);
+#endif
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
