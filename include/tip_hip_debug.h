@@ -9,7 +9,7 @@
  *   traces (fill the arrays the readers below copy): TIP_FUSEDH_TRACE, TIP_FUSED2_TRACE, TIP_BWD_TRACE, TIP_RNN_TRACE, TIP_HEAD_TRACE,
  *     TIP_S16_TRACE
  *   ablations (wrong results, timing only): TIP_FUSED_ABLATE, TIP_RNN_ABLATE (bits: 1 polls never wait, 2 no MFMAs, 4 no row touches,
- *     16 A fragments of the first two batches only — a quarter of the LDS reads; 128+ trace stamp selection)
+ *     16 A fragments of the first two batches only — a quarter of the LDS reads, 32 clamp instead of tanh; 128+ trace stamp selection)
  *   A/B selections: TIP_AUTO_SPLIT=0 (no rounds + remainder split), TIP_RNN_ROWS4=0 / TIP_RNN_W4=0|1 / TIP_RNN_C16=4 / TIP_RNN_HANDOFF=0 /
  *     TIP_RNN_PREPOLL=0 / TIP_RNN_ROTATE=0 (recurrence variants), TIP_HEAD=old (streaming projection kernel), TIP_GENERAL_PGEMM=0 /
  *     TIP_GENERAL_GEMM=32 / TIP_GENERAL_ATTN=v (general plan), TIP_TRAIN_FUSED=0 / TIP_TRAIN_FUSED_BWD=0 / TIP_TRAIN_FWD_PADDED /

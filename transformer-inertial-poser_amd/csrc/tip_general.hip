@@ -1337,7 +1337,14 @@ __global__ __launch_bounds__(WAVES * 64) void rnn_rows4_kernel(const float* __re
                         asm volatile("" :: "v"(c0[0]), "v"(c1[0]), "v"(c2[0]), "v"(c3[0]));   // MFMAs of tile 0 done, before the reduction
                         g_rnn_trace[t * 4 + 1] = __builtin_amdgcn_s_memtime();
                     }
+#ifdef TIP_MEASURE
+                    // MEASUREMENT (TIP_RNN_ABLATE bit 5, wrong results): a clamp instead of tanh (exp + IEEE division, ~25 dependent
+                    // vector instructions between the last MFMA and the state store): what the activation costs on the serial chain
+                    float hv = BWD ? (acc + ihv[n]) * (1.0f - gv[n] * gv[n])
+                                   : ((abl & 32) ? fminf(fmaxf(acc + ihv[n], -1.0f), 1.0f) : tip_tanh(acc + ihv[n]));
+#else
                     float hv = BWD ? (acc + ihv[n]) * (1.0f - gv[n] * gv[n]) : tip_tanh(acc + ihv[n]);
+#endif
                     if (hv != hv) hv = __uint_as_float(kPoisonBits);   // poison travels as the canonical NaN, never as the sentinel
                     // same XCD (verified): a plain store lands in the shared L2 (L1 is write-through); otherwise sc1 = write-through
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hv), hrs, vout[n], so_out, SAME_XCD ? 0 : 16);
