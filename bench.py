@@ -565,8 +565,7 @@ def main():
     ap.add_argument("--config", default="paper256", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="windows (IMU streams) per GPU; 0 = the configuration's own")
     ap.add_argument("--seq-len", type=int, default=0)
-    ap.add_argument("--plan", default="auto", choices=["auto", "general", "fused", "latency", "fused2", "fused2s", "fusedh", "fused16", "fused1s"],
-                    help="fused16: exploratory, measurement build only (TIP_LIB=measure)")
+    ap.add_argument("--plan", default="auto", choices=["auto", "general", "fused", "latency", "fused2", "fusedh", "fused1s"])
     ap.add_argument("--rnn-cluster", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.configs / extra.sustained (headline line only)")

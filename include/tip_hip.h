@@ -23,10 +23,11 @@
 extern "C" {
 #endif
 
-#define TIP_ABI_VERSION 3 /* 2: packed image without the exploratory split-fp16 section unless asked for (TIP_CREATE_S16, tip_create_ex);
+#define TIP_ABI_VERSION 4 /* 2: packed image without the exploratory split-fp16 section unless asked for (TIP_CREATE_S16, tip_create_ex);
                              tip_max_batch; export list = this header (+ tip_hip_debug.h), everything else hidden
                              3: tip_forward_dropout, tip_draw_keep_mask, tip_train_input_grads; plan 9 (persistent latency kernel) and its 1 KiB of sync words in the packed image
-                             removed; TIP_OPT_FUSE_HEAD reserved */
+                             removed; TIP_OPT_FUSE_HEAD reserved
+                             4: plans 5 / 7 / 8 (pair-split, split-fp16) and TIP_OPT_PACK_SPLIT16 retired (and the split-fp16 trace hook of tip_hip_debug.h with them) */
 
 /* The library is built with -fvisibility=hidden: the functions declared here (and the measurement hooks of
  * tip_hip_debug.h) are its whole dynamic symbol table (tests/test_host_cpu.py compares `nm -D` with the two headers). */
@@ -75,25 +76,18 @@ typedef enum tip_status {
 #define TIP_PLAN_FUSED   2 /* one workgroup = one window through all encoder layers (paper configuration) */
 #define TIP_PLAN_FUSED2  4 /* two windows per workgroup (80 rows = 5 MFMA row blocks, no padding); AUTO picks it for
                               B >= 2 x CUs; bit-identical results to TIP_PLAN_FUSED */
-#define TIP_PLAN_FUSED2S 5 /* MEASUREMENT BUILD ONLY since round 5 (csrc: `make measure`; the default library answers
-                              TIP_ERR_UNSUPPORTED_CONFIG): pair-split, a window pair on TWO co-resident workgroups, columns split,
-                              partial sums exchanged twice per layer; needs 2*ceil(B/2) <= #CUs.  Round 1's choice for
-                              64 < B <= #CUs; superseded by TIP_PLAN_FUSEDH (round 2) and TIP_PLAN_FUSED1S (round 4), whose
-                              kernel is the same template with one window per workgroup set. */
+/* plan value 5 is RETIRED (rounds 1-5: TIP_PLAN_FUSED2S, a window pair on two co-resident workgroups; superseded by TIP_PLAN_FUSEDH
+   and TIP_PLAN_FUSED1S, removed in round 6): tip_set_option answers TIP_ERR_UNSUPPORTED_CONFIG */
 #define TIP_PLAN_FUSEDH  6 /* TIP_PLAN_FUSED with a hybrid row tiling: rows 0-31 on 16x16x4 MFMAs, rows 32-39 on 4x4x1 MFMAs fed by the
                               same weight fragments — no matrix-core work on the pad rows 40-47 outside the QKV projection.  No
                               inter-workgroup hand-off in the encoder.  Rows 0-31 bit-identical to TIP_PLAN_FUSED. */
-#define TIP_PLAN_FUSED16 7 /* EXPLORATORY, MEASUREMENT BUILD ONLY (csrc: `make measure`; the default library answers TIP_ERR_UNSUPPORTED_CONFIG — round 5), opt-in (never AUTO's choice; needs TIP_OPT_PACK_SPLIT16 bit 0 set before packing): TIP_PLAN_FUSED with every GEMM's fp32 operands emulated on the
-                              fp16 matrix cores — operands split hi + lo * 2^-11 (22 significant bits), three f16 MFMAs per product,
-                              fp32 accumulation; attention core, LayerNorm, residual stream and epilogues in fp32 (csrc/tip_s16.hip) */
-#define TIP_PLAN_GENERAL16 8 /* EXPLORATORY, MEASUREMENT BUILD ONLY, opt-in: TIP_PLAN_GENERAL with the big linears (panel GEMM shapes) on split-fp16 operands as in
-                               TIP_PLAN_FUSED16; needs TIP_OPT_PACK_SPLIT16 bit 1 set before packing (the split weight copies double the
-                               packed image of a big model, so they are not packed by default) */
+/* plan values 7 and 8 are RETIRED (rounds 3-5: exploratory split-fp16 emulation of the fp32 GEMM operands — narrower arithmetic than the
+   reference's fp32, never a default; removed in round 6): tip_set_option answers TIP_ERR_UNSUPPORTED_CONFIG */
 #define TIP_PLAN_LATENCY 3 /* one window spread over up to 64 CUs per stage + GEMV-cluster RNN (paper config, B <= 64);
                               AUTO picks it for B <= 32 (up to 48 where four CUs per window are not to be had, and up to 64 where
                               TIP_PLAN_FUSED1S does not apply: T < 40) */
 
-#define TIP_PLAN_FUSED1S 10 /* window-split: ONE window on TWO co-resident workgroups of one XCD — TIP_PLAN_FUSED2S's column split and
+#define TIP_PLAN_FUSED1S 10 /* window-split: ONE window on TWO co-resident workgroups of one XCD — a column split with two partial-sum
                                hand-offs at 48 rows (3/5 of the matrix work per workgroup) — for batches that leave at least half of the
                                CUs idle: needs 2 B <= #CUs and B <= 128.  Its own summation order (K-halves of out-proj / linear2 summed
                                across the partners).  While 4 B <= #CUs (and B <= 64) the window is carried by FOUR workgroups instead (quads
@@ -110,7 +104,7 @@ typedef enum tip_status {
                                  the form a timed region carries).  Setting it resets the accumulated times. */
 #define TIP_OPT_RNN_CLUSTER 3 /* workgroups cooperating on one RNN window-tile (1,2,4,8,16); 0 = auto */
 #define TIP_RNN_CLUSTER_ROWS4 0x44 /* TIP_OPT_RNN_CLUSTER value: 4-window tiles on 4-workgroup clusters (4x4x1 MFMAs; rnn_hidden 512 only) */
-#define TIP_OPT_FAULT_INJECT 4 /* TESTS ONLY.  Bit 0: the pair-split encoder drops one workgroup of pair 0; bit 1: the clustered
+#define TIP_OPT_FAULT_INJECT 4 /* TESTS ONLY.  Bit 0: the window-split encoder drops one workgroup of its first window; bit 1: the clustered
                                  RNN drops member 1 of its first cluster; bit 2: the latency plan's GEMV RNN drops member 1 of
                                  stream 0.  The partners' waits then MUST give up (after a shortened spin): the error path of
                                  tip_check is exercised deterministically.  Bit 3: nobody is dropped, but every cooperating kernel
@@ -122,15 +116,7 @@ typedef enum tip_status {
                                kernel (measured neutral, removed in round 5); round 5: the projection inside the recurrence's hop wait
                                with an L2-ring hand-off (correct, measured slower than the separate kernels: CHANGELOG.md). */
 
-#define TIP_OPT_PACK_SPLIT16 6 /* which EXPLORATORY split-fp16 weight copies the packed image carries (default 0: none).  Bit 0
-                                 (TIP_PACK_SPLIT16_FUSED): the fused section's, for TIP_PLAN_FUSED16 (+15 MB for the paper configuration);
-                                 bit 1 (TIP_PACK_SPLIT16_GENERAL): the big linears', for TIP_PLAN_GENERAL16 (doubles a big model's image).
-                                 Changing it changes tip_packed_bytes() and the image layout and DETACHES the attached image
-                                 (tip_forward returns TIP_ERR_NOT_READY until an image packed under the new setting is attached).
-                                 The choice lives in the handle, not in the environment: ranks that exchange images (RCCL broadcast)
-                                 set the same value. */
-#define TIP_PACK_SPLIT16_FUSED   1
-#define TIP_PACK_SPLIT16_GENERAL 2
+/* option 6 is RETIRED (rounds 3-5: TIP_OPT_PACK_SPLIT16, the split-fp16 sections of the packed image): TIP_ERR_INVALID_ARG */
 #define TIP_OPT_AUTO_DEMOTE 7 /* 1 (default): hosts may answer the first TIP_ERR_HANDOFF of this handle by demoting it (TIP_OPT_DEMOTED)
                                  and re-issuing the call; 0: they report the error.  A flag for the host layer (the library itself never
                                  re-issues a call); the Python host honours it. */

@@ -25,8 +25,6 @@ pytestmark = pytest.mark.gpu
 
 from tip_amd import lib as _tlib
 PLANS = ["latency", "fusedh", "fused", "fused2", "general"]      # AUTO's candidates for the paper configuration
-if _tlib.MEASURE:
-    PLANS.append("fused16")                                      # + the exploratory split-fp16 plan (measurement build), held to the same bar
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

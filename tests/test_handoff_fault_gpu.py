@@ -29,17 +29,12 @@ def _model():
     return m
 
 
-# the pair-split plan (superseded) exists in the measurement build only since round 5: tests/test_exploratory_build.py runs these there
-_PAIR_SPLIT = pytest.mark.skipif(not tlib.MEASURE, reason="pair-split plan: measurement build only")
-
-
 def _fault(m, bits):
     m._ensure_handle().set_option(tlib.TIP_OPT_FAULT_INJECT, bits)
 
 
 @pytest.mark.handoff_fault
 @pytest.mark.parametrize("plan,B,bits,hit,cluster", [
-    pytest.param("fused2s", 64, 1, "pair0", 0, marks=_PAIR_SPLIT),   # pair-split encoder: workgroup (pair 0, half 1) never arrives
     ("fused1s2", 40, 1, "win0", 0),     # window-split encoder (AUTO's choice for 33..128 windows): workgroup (window 0, part 1) never arrives
     ("fused", 40, 2, "tile0", 0),       # RNN clusters (AUTO: 4 workgroups per 4-window tile): member 1 of cluster 0 never arrives
     ("fusedh", 40, 2, "tile0", 16),     # the 16-workgroup clusters on 16-window tiles (sentinel hand-off)
@@ -49,8 +44,6 @@ def _fault(m, bits):
 ])
 def test_lost_handoff_poisons_and_raises(plan, B, bits, hit, cluster):
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    if plan == "fused2s" and 2 * ((B + 1) // 2) > ncu:
-        pytest.skip("needs every workgroup resident")
     m = _model()
     m.set_plan(plan, rnn_cluster=cluster)
     x_imu, x_s = synth.make_inputs(synth.PAPER, B, 40, seed=5)
@@ -198,10 +191,10 @@ def test_cu_masked_stream_window_split(plan, B):
         hip.hipStreamDestroy(stream)
 
 
-@pytest.mark.parametrize("plan,B,cluster", [("fused1s4", 20, 0), ("fused1s2", 40, 0), pytest.param("fused2s", 60, 0, marks=_PAIR_SPLIT), ("fusedh", 256, 0), ("fusedh", 100, 0),
+@pytest.mark.parametrize("plan,B,cluster", [("fused1s4", 20, 0), ("fused1s2", 40, 0), ("fusedh", 256, 0), ("fusedh", 100, 0),
                                             ("fused", 64, 16), ("fused", 64, 4), ("latency", 5, 0)])
 def test_cross_xcd_paths_are_bit_identical(plan, B, cluster):
-    """TIP_OPT_FAULT_INJECT bit 3: every cooperating kernel (window-split / pair-split encoder, four-window and 16-window recurrence
+    """TIP_OPT_FAULT_INJECT bit 3: every cooperating kernel (window-split encoder, four-window and 16-window recurrence
     clusters, the latency plan's GEMV cluster) treats its partners as sitting on different XCDs — agent-scope stores, L1-bypassing loads,
     paced polls — wherever they really are.  That is the path a placement across XCDs takes (a CU-masked stream, a partitioned part);
     on an idle full part the dispatcher never produces it, so it is forced here: bit-identical results, no time-out."""

@@ -42,10 +42,10 @@ def _run(m, x_imu, x_s, last=False):
 
 
 PLANS = ["general", "fused"]
-ALL_PLANS = ["general", "fused", "latency", "fusedh"] + (["fused16"] if tlib.MEASURE else [])   # fused16: exploratory split-fp16 plan (measurement build), same tolerances
+ALL_PLANS = ["general", "fused", "latency", "fusedh"]
 
 
-@pytest.mark.parametrize("plan", ALL_PLANS + (["fused2s"] if tlib.MEASURE else []))   # fused2s: superseded pair-split plan (measurement build)
+@pytest.mark.parametrize("plan", ALL_PLANS)
 def test_golden_vectors(golden, plan):
     _dev()
     models = {}
@@ -56,8 +56,6 @@ def test_golden_vectors(golden, plan):
         key = (tag.split("_B")[0])
         if plan != "general" and not tag.startswith("paper"):
             continue   # fused / latency plans specialise the paper configuration; other configs take the general plan
-        if plan == "fused2s" and case["x_imu"].shape[1] != 40:
-            continue   # the two-window kernels are built for T = 40
         if key not in models:
             models[key] = _gpu_model(cfg, seed_for_tag(tag))[0]
             models[key].set_plan(plan)
@@ -274,7 +272,7 @@ def test_keep_mask_semantics(golden):
     p = float(case["p"][0])
     y = torch.empty(2, 40, 131, device="cuda")
     ws = torch.empty(h.workspace_bytes(2, 40), dtype=torch.uint8, device="cuda")
-    for plan in (tlib.TIP_PLAN_AUTO, tlib.TIP_PLAN_FUSED, tlib.TIP_PLAN_FUSED2) + ((tlib.TIP_PLAN_FUSED2S,) if tlib.MEASURE else ()):
+    for plan in (tlib.TIP_PLAN_AUTO, tlib.TIP_PLAN_FUSED, tlib.TIP_PLAN_FUSED2):
         h.set_option(tlib.TIP_OPT_PLAN, plan)
         y.zero_()
         h.forward(xi.data_ptr(), xs.data_ptr(), y.data_ptr(), 2, 40, tlib.TIP_FWD_KEEP_MASK, mask.data_ptr(),
@@ -462,8 +460,6 @@ def test_cluster_handoffs_under_uneven_load():
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     cases = [("fused", 200), ("fused", 40), ("latency", 9), ("fused2", 600)]
     cases += [("auto", 256)]   # the bench launch: hybrid one-window encoder + 16-workgroup RNN clusters
-    if ncu >= 256 and tlib.MEASURE:   # the pair-split plan needs every workgroup resident (measurement build only since round 5)
-        cases += [("fused2s", 128)]
     if ncu >= 256:
         cases += [("fused1s2", 100), ("fused1s4", 60)]
     for plan, B in cases:
@@ -596,71 +592,20 @@ def test_very_long_window_properties():
     assert np.abs(y300 - y[:, :300]).max() < 5e-6
 
 
-@pytest.mark.skipif(not tlib.MEASURE, reason="the pair-split plan exists in the measurement build only (round 5); tests/test_exploratory_build.py runs this file there")
-@pytest.mark.parametrize("B", [1, 2, 7, 65, 128, 255, 256])
-def test_pair_split_plan(B):
-    """"fused2s": a window pair on two co-resident workgroups, columns split, partial sums exchanged twice per layer.
-    Sums are formed in a different order than in the one-window plan (half 0's heads / hidden units + half 1's), so the
-    comparison with it is by tolerance; within the plan a window's result is bit-identical whatever shares the launch, and
-    run to run (the hand-offs are counted, bounded spins: no time-out may be recorded)."""
-    cfg = synth.PAPER
-    m, w = _gpu_model(cfg, 1)
-    ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    if 2 * ((B + 1) // 2) > ncu:
-        pytest.skip("needs every workgroup resident")
-    x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=900 + B, nan_frac=0.01)
-    t0 = tip_amd.lib.spin_timeouts()
-    m.set_plan("fused2s")
-    y = _run(m, x_imu, x_s)
-    for _ in range(3):
-        assert np.array_equal(y, _run(m, x_imu, x_s)), "hand-off race: run-to-run difference"
-    m.set_plan("fused")
-    yf = _run(m, x_imu, x_s)
-    assert np.abs(y - yf).max() < 5e-6
-    if B <= 7:
-        yo = oracle.forward(cfg, w, x_imu, x_s, dtype=np.float64)
-        assert np.abs(y - yo).max() < TOL_TIGHT
-    if B >= 65:
-        # batch independence inside the plan: a sub-batch (different pairing, different partner CUs) gives the same bits
-        sel = np.array([0, 1, 2, B // 2, B - 2, B - 1])
-        sub = np.concatenate([sel, np.arange(3, min(B - 3, 3 + 64))])   # a different pairing of the same windows
-        m.set_plan("fused2s")
-        ysub = _run(m, x_imu[sub], x_s[sub])
-        assert np.array_equal(ysub[:len(sel)], y[sel])
-        yl = _run(m, x_imu, x_s, last=True)
-        assert np.array_equal(yl, y[:, -1])
-    assert tip_amd.lib.spin_timeouts() == t0
-
-
-def test_default_library_refuses_the_superseded_and_exploratory_plans():
-    """Round 5: the pair-split plan and the split-fp16 plans are compiled into the measurement build only; the default library says
-    so at set_option time (host: RuntimeError) instead of carrying their kernels."""
-    if tlib.MEASURE:
-        pytest.skip("measurement build: the plans exist")
+def test_library_refuses_the_retired_plans():
+    """Round 6: the pair-split plan (5) and the split-fp16 plans (7, 8) are gone from every build; the library says so at set_option
+    time (host: RuntimeError); 9 (the persistent latency kernel, round 5) stays reserved; option 6 (the split-fp16 image sections) is
+    no option any more."""
     m, _ = _gpu_model(synth.PAPER, 0)
     h = m._ensure_handle()
-    for plan in (tlib.TIP_PLAN_FUSED2S, 7, 8):
+    for plan in (5, 7, 8):
         assert tlib.load().tip_set_option(h._h, tlib.TIP_OPT_PLAN, plan) == tlib.TIP_ERR_UNSUPPORTED_CONFIG
     assert tlib.load().tip_set_option(h._h, tlib.TIP_OPT_PLAN, 9) < 0          # reserved value
+    assert tlib.load().tip_set_option(h._h, 6, 1) < 0
     for name in ("fused2s", "fused16", "general16"):
         with pytest.raises(RuntimeError):
             m.set_plan(name)
     m.set_plan("auto")
-
-
-@pytest.mark.skipif(not tlib.MEASURE, reason="pair-split plan: measurement build only")
-def test_pair_split_plan_refuses_what_it_cannot_hold():
-    cfg = synth.PAPER
-    m, _ = _gpu_model(cfg, 0)
-    ncu = torch.cuda.get_device_properties(0).multi_processor_count
-    m.set_plan("fused2s")
-    B = ncu + 2                      # more workgroups than CUs: partners could wait for a workgroup that is not resident
-    x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=3)
-    with pytest.raises(RuntimeError):
-        _run(m, x_imu, x_s)
-    with pytest.raises(RuntimeError):   # T != 40
-        with torch.no_grad():
-            m(torch.tensor(x_imu[:4, :17]).cuda(), torch.tensor(x_s[:4, :17]).cuda())
 
 
 @pytest.mark.parametrize("B", [65, 256])

@@ -87,20 +87,20 @@ def test_c_abi_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(tip_[a-z0-9_]+)\s*\(", hdr)) - {"tip_stream_t"}
     assert declared == set(tlib.EXPORTS), declared ^ set(tlib.EXPORTS)
     dbg = set(re.findall(r"\b(tip_debug_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "tip_hip_debug.h")).read()))
-    assert len(dbg) == 12
+    assert len(dbg) == 11
     lib = ctypes.CDLL(tlib.LIB_PATH)
     for name in declared | dbg:
         assert hasattr(lib, name), name
     out = subprocess.run(["nm", "-D", "--defined-only", tlib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
     assert exported == declared | dbg, exported ^ (declared | dbg)
-    assert tlib.load().tip_abi_version() == tlib.TIP_ABI_VERSION == 3
-    assert int(re.search(r"#define TIP_ABI_VERSION (\d+)", hdr).group(1)) == 3
+    assert tlib.load().tip_abi_version() == tlib.TIP_ABI_VERSION == 4
+    assert int(re.search(r"#define TIP_ABI_VERSION (\d+)", hdr).group(1)) == 4
 
 
 def test_max_batch_and_pack_options_without_a_gpu():
-    """ABI 2: tip_max_batch (the host chunks by the library's own limit), TIP_OPT_PACK_SPLIT16 (the exploratory split-fp16
-    sections are not in the image unless asked for; the choice lives in the handle), TIP_OPT_AUTO_DEMOTE / TIP_OPT_DEMOTED."""
+    """tip_max_batch (the host chunks by the library's own limit), the retired plan / option values, TIP_OPT_AUTO_DEMOTE /
+    TIP_OPT_DEMOTED, TIP_OPT_F1S_PARTS."""
     m = make_model(synth.PAPER)
     h = m._ensure_handle()
     assert h.max_batch(40) == (2 ** 31 - 1) // (4 * 1024 * 40) == 13107          # widest row: the 1024-wide FFN hidden
@@ -111,37 +111,22 @@ def test_max_batch_and_pack_options_without_a_gpu():
     hs = make_model(synth.SCALED)._ensure_handle()
     assert hs.max_batch(80) == (2 ** 31 - 1) // (4 * 4096 * 80) == 1638            # BASELINE config 5 (B = 4096) runs as >= 3 chunks
     base = h.packed_bytes()
-    assert h.get_option(tlib.TIP_OPT_PACK_SPLIT16) == 0
-    if tlib.MEASURE:     # the exploratory split-fp16 sections exist in the measurement build only (round 5)
-        h.set_option(tlib.TIP_OPT_PACK_SPLIT16, tlib.TIP_PACK_SPLIT16_FUSED)
-        assert h.packed_bytes() == base + 3352320 * 4                                    # + the fused section's split copy
-        h.set_option(tlib.TIP_OPT_PACK_SPLIT16, 0)
-        assert h.packed_bytes() == base
-        b0 = hs.packed_bytes()
-        hs.set_option(tlib.TIP_OPT_PACK_SPLIT16, tlib.TIP_PACK_SPLIT16_GENERAL)
-        assert hs.packed_bytes() > b0 + 12 * (3 * 1024 * 1024 + 1024 * 1024 + 2 * 4096 * 1024) * 4 * 0.99
-    else:                # the default library: unsupported configuration, image unchanged, and no such plan
-        for v in (tlib.TIP_PACK_SPLIT16_FUSED, tlib.TIP_PACK_SPLIT16_GENERAL):
-            with pytest.raises(tlib.TipStatusError) as ei:
-                h.set_option(tlib.TIP_OPT_PACK_SPLIT16, v)
-            assert ei.value.status == tlib.TIP_ERR_UNSUPPORTED_CONFIG
-        for pl in (tlib.TIP_PLAN_FUSED16, tlib.TIP_PLAN_GENERAL16):
-            with pytest.raises(tlib.TipStatusError) as ei:
-                h.set_option(tlib.TIP_OPT_PLAN, pl)
-            assert ei.value.status == tlib.TIP_ERR_UNSUPPORTED_CONFIG
-        assert h.packed_bytes() == base and h.get_option(tlib.TIP_OPT_PACK_SPLIT16) == 0
-        with pytest.raises(RuntimeError, match="measurement build"):
-            m.set_plan("fused16")
-    with pytest.raises(tlib.TipStatusError):
-        hs.set_option(tlib.TIP_OPT_PACK_SPLIT16, 4)
+    # round 6: the split-fp16 sections / plans are retired in every build — no such option, no such plan, image unchanged
+    for v in (0, 1, 2):
+        with pytest.raises(tlib.TipStatusError):
+            h.set_option(6, v)
+    for pl in (5, 7, 8):
+        with pytest.raises(tlib.TipStatusError) as ei:
+            h.set_option(tlib.TIP_OPT_PLAN, pl)
+        assert ei.value.status == tlib.TIP_ERR_UNSUPPORTED_CONFIG
+    assert h.packed_bytes() == base
+    with pytest.raises(RuntimeError, match="retired"):
+        m.set_plan("fused16")
     assert h.get_option(tlib.TIP_OPT_AUTO_DEMOTE) == 1 and h.get_option(tlib.TIP_OPT_DEMOTED) == 0
     h.set_option(tlib.TIP_OPT_DEMOTED, 1)
     assert m.is_demoted()
     m.undemote()
     assert not m.is_demoted()
-    if tlib.MEASURE:     # set_plan("fused16") asks for the section and invalidates the attached image
-        m.set_plan("fused16")
-        assert h.get_option(tlib.TIP_OPT_PACK_SPLIT16) == tlib.TIP_PACK_SPLIT16_FUSED and m._packed_dev is None
     # TIP_OPT_F1S_PARTS: workgroups per window of the window-split plan (0 = the library's choice); the plan names pin it
     assert h.get_option(tlib.TIP_OPT_F1S_PARTS) == 0
     m.set_plan("fused1s4")
@@ -259,49 +244,6 @@ def test_packed_image_folds():
     blk = flat[off + (nb * 32 + kb) * 256: off + (nb * 32 + kb + 1) * 256].reshape(64, 4)
     exp = np.array([[whh[nb * 16 + (l & 15), kb * 16 + 4 * (l >> 4) + s] for s in range(4)] for l in range(64)])
     assert np.array_equal(blk, exp)
-
-
-@pytest.mark.skipif(not tlib.MEASURE, reason="exploratory plans: measurement build only (tests/test_exploratory_build.py re-runs this under TIP_LIB=measure)")
-def test_packed_image_split_fp16_section():
-    """The exploratory split-fp16 copy of the fused section (csrc/tip_s16.hip, plan "fused16"): the last section of the packed
-    image holds, at the fused section's own float offsets, every weight matrix as [column block][32-k block][hi | lo][64 lanes][8
-    halfs] with hi = fp16(w), lo = fp16((w - hi) * 2^11) — so hi + lo * 2^-11 reproduces w to 22 bits and every fold of the fp32
-    image carries over."""
-    cfg = synth.PAPER
-    m = make_model(cfg)
-    load_synth(m, cfg, 0)
-    plain = m.pack_host().numpy()
-    m.set_plan("fused16")                               # TIP_OPT_PACK_SPLIT16 bit 0: the image now carries the split copy
-    img = m.pack_host().numpy()
-    assert img.size == plain.size + 3352320 * 4 and np.array_equal(img[:plain.size], plain)
-    f32 = img.view(np.float32)
-    NF = 3352320                                        # fused_packed_floats of the paper configuration (64-float aligned)
-    assert f32.size >= 2 * NF
-    fused, s16 = f32[-(2 * NF):-NF], f32[-NF:].view(np.float16)   # (ABI 3: nothing behind the split copy any more)
-    LAYER0, LAYER_FLOATS = 57600, 789760
-    W1_W = 3 * 256 * 256 + 3 * 256 + 256 * 256 + 256
-    for (off, N, K) in ((0, 256, 224), (LAYER0, 768, 256), (LAYER0 + 2 * LAYER_FLOATS + W1_W, 1024, 256),
-                        (LAYER0 + 4 * LAYER_FLOATS, 512, 256)):
-        KB = K // 32
-        rng = np.random.RandomState(off % 1000)
-        for _ in range(6):
-            nb, kb = int(rng.randint(N // 16)), int(rng.randint(KB))
-            lane = np.arange(64)[:, None]
-            i = np.arange(8)[None, :]
-            n, k = nb * 16 + (lane & 15), kb * 32 + (lane >> 4) * 8 + i
-            src = (((n >> 4) * (K >> 4) + (k >> 4)) * 64 + ((k & 15) >> 2) * 16 + (n & 15)) * 4 + (k & 3)   # 16x16x4 fragment order
-            w = fused[off + src]
-            base = off * 2 + ((nb * KB + kb) * 2) * 512
-            hi = s16[base: base + 512].reshape(64, 8)
-            lo = s16[base + 512: base + 1024].reshape(64, 8)
-            eh = w.astype(np.float16)
-            assert np.array_equal(hi, eh)
-            assert np.array_equal(lo, ((w - eh.astype(np.float32)) * np.float32(2048.0)).astype(np.float16))
-            rec = hi.astype(np.float64) + lo.astype(np.float64) / 2048.0
-            assert np.abs(rec - w).max() <= 2.0 ** -21 * np.abs(w).max() + 1e-12
-    # the scaled configuration has no fused section, hence no split copy: the image is what it was
-    ms = make_model(synth.TINY)
-    assert ms._ensure_handle().packed_bytes() % 256 == 0
 
 
 def test_zero_edit_drop_in_import_path():

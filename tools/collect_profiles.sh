@@ -87,12 +87,8 @@ timeout 300 python tools/plan_bench.py 256 300 512 1024 2> /dev/null | grep "^B=
 # round 3: output projection tile stamps / per-workgroup lifetimes, launch-ramp probe, the exploratory split-fp16 plan
 TIP_HEAD_TRACE=1 timeout 300 python tools/head_trace.py 256 2> /dev/null | grep -v "^model\|^number" > "$OUT/head_trace_B256.txt"
 TIP_HEAD_TRACE=1 timeout 300 python tools/head_trace.py 1024 2> /dev/null | grep -v "^model\|^number" > "$OUT/head_trace_B1024.txt"
-TIP_S16_TRACE=1 timeout 300 python tools/s16_trace.py 2> /dev/null | grep -v "^model\|^number" > "$OUT/s16_trace_B256.txt"
 timeout 300 python tools/stream_latency.py 1 400 2> /dev/null | grep "^{" > "$OUT/stream_latency_n1.json"
 d=/tmp/prof_f16; rm -rf $d
-(cd /tmp && TIP_LIB=measure timeout 600 rocprofv3 --kernel-trace --output-format csv -d $d -- $BENCH --plan fused16 > "$OUT/bench_fused16_under_rocprof.json" 2> /dev/null)
-t=$(find $d -name '*kernel_trace.csv' | head -1); [ -n "$t" ] && python tools/kstats_table.py "$t" > "$OUT/kernel_medians_bench_fused16_B256_T40.txt"
-TIP_LIB=measure timeout 300 python bench.py --plan fused16 --no-cpu-baseline --no-extra --steps 300 --warmup 20 > "$OUT/bench_fused16_n1.json" 2> /dev/null
 # round 4: AUTO over a batch sweep against the round-3 selection (remainder split, window-split plan), the persistent latency kernel
 { echo "AUTO (round 4)"; timeout 300 python tools/auto_sweep.py 2> /dev/null; echo "round-3 selection (TIP_PLAN_BASE=1)"; TIP_PLAN_BASE=1 timeout 300 python tools/auto_sweep.py 2> /dev/null; } > "$OUT/auto_sweep.txt"
 timeout 300 python tools/f1s_bench.py 2> /dev/null | grep "^B=\|fused1s vs" > "$OUT/f1s_bench.txt"
@@ -100,5 +96,5 @@ timeout 300 python tools/f1s_parts.py 2> /dev/null | grep "^B=" > "$OUT/f1s_part
 { echo "8-wave members"; TIP_RNN_W4=0 timeout 200 python tools/rnn_ab.py 2> /dev/null | grep "^B="; echo "4-wave members (TIP_RNN_W4=1)"; TIP_RNN_W4=1 timeout 200 python tools/rnn_ab.py 2> /dev/null | grep "^B="; } > "$OUT/rnn_w4.txt"
 timeout 300 python tools/plan_bench.py 257 272 300 356 1000 2> /dev/null | grep "^B=" > "$OUT/plan_bench_split.txt"
 timeout 300 python tools/f64_bench.py 2> /dev/null | grep "^{" > "$OUT/f64_bench_n1.json"
-for p in mfma4x4_probe hop_probe permlane_probe launch_probe ffn_split16_probe mfma_f64_probe imul_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
+for p in mfma4x4_probe hop_probe permlane_probe launch_probe mfma_f64_probe imul_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
 ls -la "$OUT"

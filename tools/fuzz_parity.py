@@ -36,7 +36,6 @@ while time.time() < t_end:
     if B <= 64: plans.append("latency")
     if T == 40 and B <= 128: plans += ["fused1s", "fused1s2"]       # one window on several workgroups (round 4)
     if T == 40 and B <= 64: plans.append("fused1s4")
-    if T == 40 and B <= 256 and tlib.MEASURE: plans.append("fused2s")   # superseded pair-split plan: measurement build only
     plan = str(rng.choice(plans))
     cluster = int(rng.choice([0, 0, 0, 1, 2, 4, 8, 16])) if plan in ("fusedh", "fused", "general") else 0
     last = bool(rng.rand() < 0.3)

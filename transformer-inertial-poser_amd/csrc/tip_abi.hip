@@ -66,10 +66,6 @@ void build_layout(tip_handle* h) {
         // big linears also in MFMA fragment order for the panel GEMM (tip_fused2.hip, launch_pgemm)
         for (PackedLinear* p : {&pl.qkv, &pl.out, &pl.ff1, &pl.ff2})
             if (pgemm_shape_ok(1 << 20, p->N, p->K)) p->f_off = c.take((size_t)p->N * p->K);
-        // exploratory TIP_PLAN_GENERAL16: split-fp16 copies of the same matrices, only on request (they double a big model's image)
-        if (h->pack_split16 & TIP_PACK_SPLIT16_GENERAL)
-            for (PackedLinear* p : {&pl.qkv, &pl.out, &pl.ff1, &pl.ff2})
-                if (p->f_off && pgemm16_shape_ok(1 << 20, p->N, p->K)) p->s_off = c.take((size_t)p->N * p->K);
     }
     if (d.with_rnn) {
         L.rnn_ih = carve_linear(c, d.R, d.D);
@@ -84,9 +80,6 @@ void build_layout(tip_handle* h) {
     }
     L.fused_floats = fused_packed_floats(d);
     L.fused_off = c.take(L.fused_floats);
-    // exploratory TIP_PLAN_FUSED16: split-fp16 copy of the fused section, only on request (TIP_OPT_PACK_SPLIT16)
-    L.s16_floats = (h->pack_split16 & TIP_PACK_SPLIT16_FUSED) ? s16_packed_floats(d) : 0;
-    L.s16_off = L.s16_floats ? c.take(L.s16_floats) : 0;
     L.total_floats = c.off;
 }
 
@@ -210,9 +203,7 @@ struct StageScope {
 // y = epi(x W^T + b (+ res)) for one packed linear of the general plan: the panel GEMM on the fragment copy when the layer
 // has one and the batch is big enough, else the LDS-tiled GEMM on the row-major copy
 static hipError_t linear_gemm(const float* P, const tip::PackedLinear& p, const float* A, int lda, const float* res, int ldres,
-                              float* C, int ldc, int M, int flags, hipStream_t s, bool s16 = false) {
-    if (s16 && p.s_off && tip::pgemm16_shape_ok(M, p.N, p.K))   // TIP_PLAN_GENERAL16 (exploratory): split-fp16 operands
-        return tip::launch_pgemm16(A, lda, P + p.s_off, (size_t)p.N * p.K, P + p.b_off, res, ldres, C, ldc, M, p.N, p.K, flags, s);
+                              float* C, int ldc, int M, int flags, hipStream_t s) {
     static int use_pg = -1;   // TIP_GENERAL_PGEMM=0 keeps the LDS-tiled kernel (measurement)
     if (use_pg < 0) use_pg = (tip_env("TIP_GENERAL_PGEMM") && tip_env("TIP_GENERAL_PGEMM")[0] == '0') ? 0 : 1;
     // (the panel kernel's epilogue moves 16 bytes per lane: bias / residual / output rows must be 16-byte aligned — they are for
@@ -351,9 +342,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
     switch (option) {
         case TIP_OPT_PLAN:
             if (value < TIP_PLAN_AUTO || value > TIP_PLAN_FUSED1S || value == 9 /* reserved */) return TIP_ERR_INVALID_ARG;
-#ifndef TIP_EXPLORATORY
-            if (value == TIP_PLAN_FUSED16 || value == TIP_PLAN_GENERAL16 || value == TIP_PLAN_FUSED2S) return TIP_ERR_UNSUPPORTED_CONFIG;   // measurement build only
-#endif
+            if (value == 5 || value == 7 || value == 8) return TIP_ERR_UNSUPPORTED_CONFIG;   // retired plans (ABI 4): pair-split, split-fp16
             h->plan = value;
             return TIP_OK;
         case TIP_OPT_PROFILE:
@@ -373,18 +362,6 @@ int tip_set_option(tip_handle* h, int option, int value) {
         case TIP_OPT_FUSE_HEAD:
             if (value < 0 || value > 1) return TIP_ERR_INVALID_ARG;
             h->fuse_head = value;
-            return TIP_OK;
-        case TIP_OPT_PACK_SPLIT16:
-            if (value < 0 || value > (TIP_PACK_SPLIT16_FUSED | TIP_PACK_SPLIT16_GENERAL)) return TIP_ERR_INVALID_ARG;
-#ifndef TIP_EXPLORATORY
-            if (value != 0) return TIP_ERR_UNSUPPORTED_CONFIG;   // the split-fp16 sections exist in the measurement build only
-#endif
-            if (value != h->pack_split16) {
-                // the layout of the packed image changes: whatever was attached no longer matches it
-                h->pack_split16 = value;
-                build_layout(h);
-                h->packed_dev = nullptr;
-            }
             return TIP_OK;
         case TIP_OPT_AUTO_DEMOTE:
             if (value < 0 || value > 1) return TIP_ERR_INVALID_ARG;
@@ -418,7 +395,6 @@ int tip_get_option(const tip_handle* h, int option, int* value) {
         case TIP_OPT_RNN_CLUSTER: *value = h->rnn_cluster; return TIP_OK;
         case TIP_OPT_FAULT_INJECT: *value = h->fault_inject; return TIP_OK;
         case TIP_OPT_FUSE_HEAD: *value = h->fuse_head; return TIP_OK;
-        case TIP_OPT_PACK_SPLIT16: *value = h->pack_split16; return TIP_OK;
         case TIP_OPT_AUTO_DEMOTE: *value = h->auto_demote; return TIP_OK;
         case TIP_OPT_DEMOTED: *value = h->demoted; return TIP_OK;
         case TIP_OPT_F1S_PARTS: *value = h->f1s_parts; return TIP_OK;
@@ -493,7 +469,6 @@ int tip_pack_weights(const tip_handle* h, const float* const* t, int n, void* pa
                         for (int s4 = 0; s4 < 4; ++s4)
                             f[((size_t)(nb * KBn + kb) * 64 + lane) * 4 + s4] =
                                 w[(size_t)(nb * 16 + (lane & 15)) * p->Kpad + kb * 16 + 4 * (lane >> 4) + s4];
-            if (p->s_off) s16_convert_host(f, img + p->s_off, p->N, p->K);
         }
         memcpy(img + pl.g1_off, lw[8], sizeof(float) * d.D);
         memcpy(img + pl.be1_off, lw[9], sizeof(float) * d.D);
@@ -531,7 +506,6 @@ int tip_pack_weights(const tip_handle* h, const float* const* t, int n, void* pa
                     }
     }
     if (L.fused_floats) fused_pack(d, t, img + L.fused_off);
-    if (L.s16_floats) s16_pack_host(d, img + L.fused_off, img + L.s16_off);
     return TIP_OK;
 }
 
@@ -612,12 +586,6 @@ int tip_pack_weights_device(const tip_handle* h, const float* const* t, int n, v
     if (L.fused_floats) fused_pack_ops(d, t, L.fused_off, ops);
     if (hipMemsetAsync(packed_dev, 0, L.total_floats * sizeof(float), s) != hipSuccess) return TIP_ERR_HIP;
     if (run_pack_ops(ops, static_cast<float*>(packed_dev), s) != hipSuccess) return TIP_ERR_HIP;
-    if (L.s16_floats && launch_s16_repack(d, static_cast<const float*>(packed_dev) + L.fused_off, static_cast<float*>(packed_dev) + L.s16_off, s) != hipSuccess)
-        return TIP_ERR_HIP;
-    for (const PackedLayer& pl : L.layers)
-        for (const PackedLinear* p : {&pl.qkv, &pl.out, &pl.ff1, &pl.ff2})
-            if (p->s_off && launch_s16_convert(static_cast<const float*>(packed_dev) + p->f_off, static_cast<float*>(packed_dev) + p->s_off, p->N, p->K, s) != hipSuccess)
-                return TIP_ERR_HIP;
     return TIP_OK;
 }
 
@@ -862,17 +830,9 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     }
     if ((plan == TIP_PLAN_FUSED || plan == TIP_PLAN_FUSEDH) && !fused_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED2 && !fused2_supported(d, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
-#ifndef TIP_EXPLORATORY
-    if (plan == TIP_PLAN_FUSED2S) return TIP_ERR_UNSUPPORTED_CONFIG;   // measurement build only (round 5)
-#endif
-    if (plan == TIP_PLAN_FUSED2S && !(fused2_supported(d, T) && fused2s_fits(B, cus) && B <= 256)) return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_FUSED1S && !(fused2_supported(d, T) && fused1s_fits(B, cus) && (h->f1s_parts != 4 || fused1s_quad_fits(B, cus))))
         return TIP_ERR_UNSUPPORTED_CONFIG;
     if (plan == TIP_PLAN_LATENCY && !latency_supported(d, B, T)) return TIP_ERR_UNSUPPORTED_CONFIG;
-    if (plan == TIP_PLAN_FUSED16 && !(s16_supported(d, T) && L.s16_floats)) return TIP_ERR_UNSUPPORTED_CONFIG;
-
-    const bool g16 = plan == TIP_PLAN_GENERAL16;   // exploratory: the general plan with split-fp16 panel GEMMs
-    if (g16) plan = TIP_PLAN_GENERAL;
     float* enc_out = xa;  // encoder output [M, D]
     bool ih_done = false;  // the fused plan also emits the RNN input projection
     bool rnn_done = false;
@@ -903,24 +863,12 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         hall_armed = arm_hall();
         TIP_TRY(launch_fused_encoder1s(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr,
                                        W0 + ws.xchg, B, cus, h->f1s_parts, gd, s), "fused_encoder1s");
-    } else if (plan == TIP_PLAN_FUSED2S) {
-        StageScope sc(h, s, "fused_encoder");
-        ih_done = true;
-        hall_armed = arm_hall();
-        TIP_TRY(launch_fused_encoder2s(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr,
-                                       W0 + ws.xchg, B, cus, gd, s), "fused_encoder2s");
     } else if (plan == TIP_PLAN_FUSED2) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = true;
         hall_armed = arm_hall();
         TIP_TRY(launch_fused_encoder2(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr, B,
                                       cus, s), "fused_encoder2");
-    } else if (plan == TIP_PLAN_FUSED16) {
-        StageScope sc(h, s, "fused_encoder");
-        ih_done = true;
-        hall_armed = arm_hall();
-        TIP_TRY(launch_fused_encoder_s16(d, P + L.fused_off, P + L.s16_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr,
-                                         B, T, cus, s), "fused_encoder_s16");
     } else if (plan == TIP_PLAN_FUSEDH) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = fused_has_rnn_ih(d);
@@ -949,7 +897,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
             const PackedLayer& pl = L.layers[l];
             {
                 StageScope sc(h, s, "qkv_gemm");
-                TIP_TRY(linear_gemm(P, pl.qkv, xa, d.D, nullptr, 0, big, 3 * d.D, M, 0, s, g16), "qkv_gemm");
+                TIP_TRY(linear_gemm(P, pl.qkv, xa, d.D, nullptr, 0, big, 3 * d.D, M, 0, s), "qkv_gemm");
             }
             {
                 StageScope sc(h, s, "attention");
@@ -957,7 +905,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
             }
             {
                 StageScope sc(h, s, "out_proj_gemm");
-                TIP_TRY(linear_gemm(P, pl.out, att, d.D, xa, d.D, xb, d.D, M, 2, s, g16), "out_proj_gemm");
+                TIP_TRY(linear_gemm(P, pl.out, att, d.D, xa, d.D, xb, d.D, M, 2, s), "out_proj_gemm");
             }
             {
                 StageScope sc(h, s, "layernorm1");
@@ -965,11 +913,11 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
             }
             {
                 StageScope sc(h, s, "ffn1_gemm");
-                TIP_TRY(linear_gemm(P, pl.ff1, xb, d.D, nullptr, 0, big, d.F, M, 1, s, g16), "ffn1_gemm");
+                TIP_TRY(linear_gemm(P, pl.ff1, xb, d.D, nullptr, 0, big, d.F, M, 1, s), "ffn1_gemm");
             }
             {
                 StageScope sc(h, s, "ffn2_gemm");
-                TIP_TRY(linear_gemm(P, pl.ff2, big, d.F, xb, d.D, xa, d.D, M, 2, s, g16), "ffn2_gemm");
+                TIP_TRY(linear_gemm(P, pl.ff2, big, d.F, xb, d.D, xa, d.D, M, 2, s), "ffn2_gemm");
             }
             {
                 StageScope sc(h, s, "layernorm2");

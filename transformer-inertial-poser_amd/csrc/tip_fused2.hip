@@ -859,18 +859,19 @@ hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const floa
     return hipGetLastError();
 }
 
-bool fused2s_fits(int B, int num_cus) { return B >= 1 && 2 * ((B + 1) / 2) <= num_cus; }
 bool fused1s_fits(int B, int num_cus) { return B >= 1 && 2 * B <= num_cus && B <= 128; }
 // one window on FOUR workgroups (the fused1s plan takes this form when it fits; TIP_OPT_F1S_PARTS = 2 keeps two)
 bool fused1s_quad_fits(int B, int num_cus) { return B >= 1 && 4 * B <= num_cus && B <= 64; }
 
-// nwin = 2: a window pair per two workgroups (TIP_PLAN_FUSED2S); nwin = 1: ONE window per two workgroups (TIP_PLAN_FUSED1S)
+// ONE window per two (or four) workgroups (TIP_PLAN_FUSED1S).  Only NWIN = 1 is instantiated: the window-PAIR form (NWIN = 2, the pair-split
+// plan of round 1) was retired in round 6 — the kernel template keeps the parameter, its 80-row paths are dead code the compiler drops.
 template <int NWIN, int NPART = 2>
 static hipError_t launch_fused_encoder_split(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                              const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
                                              int B, int num_cus, const Guard& gd, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (!(NWIN == 2 ? fused2s_fits(B, num_cus) : NPART == 4 ? fused1s_quad_fits(B, num_cus) : fused1s_fits(B, num_cus))) return hipErrorInvalidValue;   // every workgroup must be resident: partners wait for each other
+    static_assert(NWIN == 1, "the window-pair form was retired (round 6)");
+    if (!(NPART == 4 ? fused1s_quad_fits(B, num_cus) : fused1s_fits(B, num_cus))) return hipErrorInvalidValue;   // every workgroup must be resident: partners wait for each other
     static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fused_encoder2s_kernel<NWIN, NPART>),
@@ -902,15 +903,6 @@ static hipError_t launch_fused_encoder_split(const Dims& d, const float* fused_w
     return hipGetLastError();
 }
 
-hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
-                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
-                                  int B, int num_cus, const Guard& gd, hipStream_t s) {
-#ifdef TIP_EXPLORATORY   // superseded by the hybrid one-window kernel (round 2) and the window-split plan (round 4): measurement build only
-    return launch_fused_encoder_split<2>(d, fused_w, x_imu, x_s, keep_mask, keep_scale, ih_out, hall_sentinel, xchg, B, num_cus, gd, s);
-#else
-    return hipErrorNotSupported;
-#endif
-}
 hipError_t launch_fused_encoder1s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                   const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
                                   int B, int num_cus, int parts, const Guard& gd, hipStream_t s) {

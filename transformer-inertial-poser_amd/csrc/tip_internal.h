@@ -15,7 +15,7 @@
 namespace tip {
 
 // Measurement switches.  The launchers' A/B selections, in-kernel traces and ablations are driven by TIP_* environment variables —
-// in a build with -DTIP_MEASURE only (`make MEASURE=1` -> libtip_hip_measure.so, loaded by the tools under tools/ through
+// in a build with -DTIP_MEASURE only (`make measure` -> libtip_hip_measure.so, loaded by the tools under tools/ through
 // TIP_LIB=measure).  In the default build tip_env() is a constant nullptr: every switch sits at its default and the kernels a handle
 // launches depend on tip_set_option alone, never on the process environment.  The switches are listed in include/tip_hip_debug.h.
 inline const char* tip_env(const char* name) {
@@ -112,7 +112,6 @@ struct PackedLinear {
     size_t b_off;
     int N, K, Npad, Kpad;
     size_t f_off = 0;   // the same weight in 16x16x4 B-fragment order (+ tail padding) for launch_pgemm; 0 = not packed
-    size_t s_off = 0;   // ... and as split fp16 [N/16][K/32][hi | lo][64][8] for launch_pgemm16 (TIP_OPT_PACK_SPLIT16 bit 2 only); 0 = not packed
 };
 
 struct PackedLayer {
@@ -130,9 +129,6 @@ struct PackedLayout {
     // fused-plan section (paper configuration): weights in 16x16x4 B-fragment order, see tip_fused.hip
     size_t fused_off;
     size_t fused_floats;
-    // split-fp16 copy of the fused section's weight matrices (tip_s16.hip, TIP_PLAN_FUSED16): same float offsets, hi | lo halfs
-    size_t s16_off = 0;
-    size_t s16_floats = 0;
     size_t total_floats;
 };
 
@@ -287,7 +283,6 @@ struct tip_handle {
     unsigned* err_dev = nullptr;    // the device's address of it
     int fault_inject = 0;           // TIP_OPT_FAULT_INJECT (tests)
     int fuse_head = 0;              // TIP_OPT_FUSE_HEAD
-    int pack_split16 = 0;           // TIP_OPT_PACK_SPLIT16: which exploratory split-fp16 sections the packed image carries
     int auto_demote = 1;            // TIP_OPT_AUTO_DEMOTE
     int f1s_parts = 0;              // TIP_OPT_F1S_PARTS: 0 = auto, 2, 4
     int demoted = 0;                // TIP_OPT_DEMOTED: set by tip_demote after a lost hand-off: AUTO then avoids every cooperating kernel
@@ -428,20 +423,6 @@ hipError_t launch_head_gemm(const float* A, long long lda, const float* wfrag, c
 hipError_t launch_head_ksplit(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy, int M, int N,
                               int K, bool last_only, int num_cus, hipStream_t s);
 
-// ---- exploratory split-fp16 plan (tip_s16.hip) ----
-bool pgemm16_shape_ok(int M, int N, int K);
-hipError_t launch_pgemm16(const float* A, int lda, const float* w16, size_t w_floats, const float* bias, const float* res, int ldres,
-                          float* C, int ldc, int M, int N, int K, int flags, hipStream_t s);
-void s16_convert_host(const float* src_frag, float* dst, int N, int K);
-hipError_t launch_s16_convert(const float* src_frag, float* dst, int N, int K, hipStream_t s);
-bool s16_supported(const Dims& d, int T);
-size_t s16_packed_floats(const Dims& d);
-void s16_pack_host(const Dims& d, const float* fused_src, float* dst);
-hipError_t launch_s16_repack(const Dims& d, const float* fused_src, float* dst, hipStream_t s);
-hipError_t launch_fused_encoder_s16(const Dims& d, const float* fused_w, const float* s16_w, const float* x_imu, const float* x_s,
-                                    const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, int B, int T,
-                                    int num_cus, hipStream_t s);
-
 // ---- latency plan (tip_latency.hip): one window spread over many CUs, for few concurrent streams ----
 bool latency_supported(const Dims& d, int B, int T);
 size_t latency_workspace_floats(int B, int T);
@@ -470,12 +451,8 @@ hipError_t read_spin_timeouts_fused2(unsigned* out);
 
 // ---- two-window fused encoder (tip_fused2.hip): 80 rows = 5 MFMA row blocks, no padding; for >= 2 windows per CU ----
 bool fused2_supported(const Dims& d, int T);
-// pair-split form: a window pair on two co-resident workgroups (columns split), for B <= #CUs (tip_fused2.hip)
-bool fused2s_fits(int B, int num_cus);
+// partial-sum exchange images of the window-split forms below (sized for the larger of the two)
 size_t fused2s_xchg_floats(int B);
-hipError_t launch_fused_encoder2s(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
-                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, float* xchg,
-                                  int B, int num_cus, const Guard& gd, hipStream_t s);
 hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, int B,
                                  int num_cus, hipStream_t s);

@@ -18,16 +18,13 @@ if os.environ.get("TIP_LIB", "").endswith(".so"):   # (tools/: an A/B build of t
 
 TIP_FWD_LAST_ROW_ONLY = 0x1
 TIP_FWD_KEEP_MASK = 0x2
-TIP_PLAN_AUTO, TIP_PLAN_GENERAL, TIP_PLAN_FUSED, TIP_PLAN_LATENCY, TIP_PLAN_FUSED2, TIP_PLAN_FUSED2S, TIP_PLAN_FUSEDH = 0, 1, 2, 3, 4, 5, 6
+TIP_PLAN_AUTO, TIP_PLAN_GENERAL, TIP_PLAN_FUSED, TIP_PLAN_LATENCY, TIP_PLAN_FUSED2, TIP_PLAN_FUSEDH = 0, 1, 2, 3, 4, 6   # 5, 7, 8, 9: retired
 TIP_PLAN_FUSED1S = 10   # one window on two co-resident workgroups (64 < B <= 128)
-TIP_PLAN_GENERAL16 = 8  # exploratory: general plan with split-fp16 panel GEMMs (needs TIP_OPT_PACK_SPLIT16 bit 1 before packing)
-TIP_PLAN_FUSED16 = 7   # exploratory: fp32 operands emulated as split fp16 on the f16 matrix cores (csrc/tip_s16.hip); opt-in only
 TIP_SAVED_QKV, TIP_SAVED_ATT, TIP_SAVED_X1, TIP_SAVED_HID, TIP_SAVED_XOUT, TIP_SAVED_HALL = range(6)
 TIP_STREAM_FRAME_AUTO = -1   # tip_stream_ingest / tip_stream_consume: continue from the counter in the state buffer (HIP graphs)
 TIP_OPT_PLAN, TIP_OPT_PROFILE, TIP_OPT_RNN_CLUSTER, TIP_OPT_FAULT_INJECT, TIP_OPT_FUSE_HEAD = 1, 2, 3, 4, 5
-TIP_OPT_PACK_SPLIT16, TIP_OPT_AUTO_DEMOTE, TIP_OPT_DEMOTED, TIP_OPT_F1S_PARTS = 6, 7, 8, 9
-TIP_PACK_SPLIT16_FUSED, TIP_PACK_SPLIT16_GENERAL = 1, 2
-TIP_ABI_VERSION = 3
+TIP_OPT_AUTO_DEMOTE, TIP_OPT_DEMOTED, TIP_OPT_F1S_PARTS = 7, 8, 9   # 6: retired
+TIP_ABI_VERSION = 4
 TIP_RNN_CLUSTER_ROWS4 = 0x44   # TIP_OPT_RNN_CLUSTER value: 4-window tiles on 4-workgroup clusters (AUTO's choice for rnn_hidden 512)
 TIP_ERR_HANDOFF = -8
 TIP_ERR_UNSUPPORTED_CONFIG = -2
@@ -69,7 +66,9 @@ class TipConfig(ctypes.Structure):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into csrc/libtip_hip.so (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC, "-j4"] + (["-B"] if force else []) + [os.path.basename(LIB_PATH)]
+    if os.path.dirname(LIB_PATH) != CSRC:      # TIP_LIB=<path>.so: an A/B build somebody made by hand — nothing here knows its recipe
+        return LIB_PATH
+    cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else []) + [os.path.basename(LIB_PATH)]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)
@@ -79,8 +78,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 def build_measure(verbose: bool = False) -> str:
-    """Compile the measurement build (csrc/libtip_hip_measure.so: TIP_* environment switches alive, exploratory plans compiled in)."""
-    cmd = ["make", "-C", CSRC, "-j4", "libtip_hip_measure.so"]
+    """Compile the measurement build (csrc/libtip_hip_measure.so: TIP_* environment switches of the launchers alive)."""
+    cmd = ["make", "-C", CSRC, "-j8", "libtip_hip_measure.so"]
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise TipLibraryError("building libtip_hip_measure.so failed:\n" + res.stdout[-4000:])

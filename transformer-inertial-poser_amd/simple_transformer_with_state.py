@@ -427,18 +427,11 @@ class TF_RNN_Past_State(nn.Module):
         workgroups per 16-window tile (1: no inter-workgroup hand-off in the recurrence).  profile: 1 = per-stage timers
         (profile_read())."""
         h = self._ensure_handle()
-        if plan in ("fused16", "general16", "fused2s") and not _lib.MEASURE:
-            raise RuntimeError(f"tip_amd: plan '{plan}' is exploratory / superseded and exists in the measurement build of the library only "
-                               "(make -C csrc measure; TIP_LIB=measure)")
-        # the exploratory split-fp16 plans read weight copies the packed image carries only on request
-        want = {"fused16": _lib.TIP_PACK_SPLIT16_FUSED, "general16": _lib.TIP_PACK_SPLIT16_GENERAL}.get(plan, 0)
-        have = h.get_option(_lib.TIP_OPT_PACK_SPLIT16)
-        if want and not (have & want):
-            h.set_option(_lib.TIP_OPT_PACK_SPLIT16, have | want)    # new image layout: detach, re-pack on the next forward
-            self._packed_dev, self._packed_key = None, None
+        if plan in ("fused16", "general16", "fused2s"):
+            raise RuntimeError(f"tip_amd: plan '{plan}' was retired in round 6 (exploratory split-fp16 emulation / superseded pair-split plan)")
         # "fused1s": one window on four workgroups while 4 B <= #CUs, on two otherwise; "fused1s2" / "fused1s4" pin the form
         h.set_option(_lib.TIP_OPT_F1S_PARTS, {"fused1s2": 2, "fused1s4": 4}.get(plan, 0))
-        h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fused2s": 5, "fusedh": 6, "fused16": 7, "general16": 8, "fused1s": 10, "fused1s2": 10, "fused1s4": 10}[plan])
+        h.set_option(_lib.TIP_OPT_PLAN, {"auto": 0, "general": 1, "fused": 2, "latency": 3, "fused2": 4, "fusedh": 6, "fused1s": 10, "fused1s2": 10, "fused1s4": 10}[plan])
         h.set_option(_lib.TIP_OPT_RNN_CLUSTER, int(rnn_cluster))
         h.set_option(_lib.TIP_OPT_PROFILE, int(profile))
 
