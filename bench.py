@@ -499,7 +499,8 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
     try:
         sc = synth.SCALED
         torch.manual_seed(0)
-        ms_model = build_model(sc, 0, load=False).to(dev).eval()
+        with torch.device(dev):                       # 152 M parameters: drawn on the GPU
+            ms_model = build_model(sc, 0, load=False).eval()
         Bs, Ts = 512, 80
         s_imu, s_s = synth.make_inputs(sc, 64, Ts, seed=99)
         si = torch.tensor(s_imu).to(dev).repeat(Bs // 64, 1, 1)
@@ -510,26 +511,92 @@ def extra_configs(model, cfg, xi, xs, dev, seconds_budget=40.0):
         out["scaled_b512_t80"] = {"batch": Bs, "T": Ts, "ms_per_step": ms, "frames_per_s": Bs / (ms * 1e-3),
                                   "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(sc, Ts, Bs / (ms * 1e-3)),
                                   "tflops": Bs / (ms * 1e-3) * synth.flops_per_window(sc, Ts) / 1e12}
-        # -- configs[4] at its own batch on ONE GPU: B = 4096 as one call (the host runs it in chunks of at most tip_max_batch
-        #    windows: 32-bit buffer offsets) — the absolute single-GPU number next to the 512-window per-GPU share
-        try:
-            B4 = 4096
-            si4, ss4 = si.repeat(B4 // Bs, 1, 1), ss.repeat(B4 // Bs, 1, 1)
-            ms_model(si4, ss4)
-            ms4 = timed_loop(lambda: ms_model(si4, ss4), 2)
-            out["scaled_b4096_one_gpu"] = {"batch": B4, "T": Ts, "ms_per_step": ms4, "frames_per_s": B4 / (ms4 * 1e-3),
-                                           "chunk": int(ms_model.chunk_batch(Ts)), "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(sc, Ts, B4 / (ms4 * 1e-3)),
-                                           "tflops": B4 / (ms4 * 1e-3) * synth.flops_per_window(sc, Ts) / 1e12,
-                                           "vs_8x_the_512_share": ms4 / (8 * ms)}
-            del si4, ss4
-        except Exception as e2:
-            out["scaled_b4096_one_gpu"] = {"error": f"{type(e2).__name__}: {e2}"}
+        # (configs[4] at its own batch, B = 4096 in total, is `extra.scaling_table.scaled_b4096_total` — at N = 1 all of it on this GPU, chunked by
+        #  tip_max_batch)
         del ms_model, si, ss
         torch.cuda.empty_cache()
     except Exception as e:
         out["scaled_b512_t80"] = {"error": f"{type(e).__name__}: {e}"}
     del fpw
     return out
+
+
+def scaled_row(rank, world, dev, args, timed_row, shard):
+    """BASELINE configs[4] on this run's N GPUs: the scaled model (12 layers, d = 1024, ffn = 4096, 16 heads, rnn 512, T = 80), 4096
+    windows in total = 4096 / N per GPU, full output.  Rank 0 draws the 152 M parameters (the module's own random init) on its GPU,
+    packs them there and broadcasts the 609-MB image once (RCCL over xGMI; timed as `weight_broadcast_ms`, off the timed steps);
+    the other ranks never initialise parameters of their own."""
+    sc = synth.SCALED
+    Ts = 80
+    lo, hi = shard
+    bt = hi - lo
+    torch.manual_seed(0)
+    with torch.device(dev if rank == 0 else "meta"):
+        m = build_model(sc, 0, load=False)            # rank 0: torch.empty + uniform_ on the GPU; the others: shapes only
+    if rank != 0:
+        m = m.to_empty(device=dev)                    # (their parameters are never read: broadcast_packed attaches rank 0's image)
+    m = m.eval()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    packed = tdist.broadcast_packed(m, src=0, device=dev)
+    torch.cuda.synchronize()
+    bms = (time.perf_counter() - t0) * 1e3
+    # a caller-selected plan without cooperating kernels (the shared-GPU rehearsal) maps to the general plan here: the fused plans
+    # are the paper configuration's
+    m.set_plan("auto" if args.plan == "auto" else "general", rnn_cluster=args.rnn_cluster)
+    s_imu, s_s = synth.make_inputs(sc, 64, Ts, seed=99 + rank)
+    reps = (max(bt, 1) + 63) // 64
+    si = torch.tensor(s_imu).to(dev).repeat(reps, 1, 1)[:bt].contiguous()
+    ss = torch.tensor(s_s).to(dev).repeat(reps, 1, 1)[:bt].contiguous()
+    row = timed_row(m, sc, lambda: m(si, ss), 4096, Ts, 3, 2, False)
+    row["weight_broadcast_ms"] = bms
+    row["packed_image_mb"] = packed.numel() / 1e6
+    row["tflops"] = row["frames_per_s"] * synth.flops_per_window(sc, Ts) / 1e12
+    row["chunk"] = int(m.chunk_batch(Ts))
+    del m, si, ss, packed
+    torch.cuda.empty_cache()
+    return row
+
+
+def pin_to_gpu_numa_node(dev_index):
+    """Pin this rank's host threads to the CPUs of its GPU's NUMA node (VERDICT r05 #1b: at B = 1 a forward is ~20 launches and
+    ~0.12 ms of host time per call, and with eight ranks on one node the scheduler otherwise parks some of them across the socket
+    link from their GPU).  PCI address from the HIP device properties -> /sys/bus/pci/devices/<bdf>/{numa_node,local_cpulist};
+    the set is intersected with what this process may use (cgroup / taskset) and applied to every thread the process already has
+    (runtime threads inherit from then on).  TIP_BENCH_NO_PIN=1 disables.  Returns what was done, for the JSON line."""
+    info = {"pinned": False}
+    try:
+        if os.environ.get("TIP_BENCH_NO_PIN", "0") == "1":
+            info["reason"] = "TIP_BENCH_NO_PIN=1"
+            return info
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        base = os.path.join("/sys/bus/pci/devices", bdf)
+        info["pci"] = bdf
+        node = int(open(os.path.join(base, "numa_node")).read().strip())
+        info["numa_node"] = node
+        cpus = set()
+        src = os.path.join("/sys/devices/system/node", f"node{node}", "cpulist") if node >= 0 else os.path.join(base, "local_cpulist")
+        for part in open(src).read().strip().split(","):
+            if not part:
+                continue
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0)
+        use = cpus & allowed
+        info["node_cpus"], info["allowed_cpus"] = len(cpus), len(allowed)
+        if not use or use == allowed:
+            info["reason"] = "node CPUs == allowed CPUs" if use else "no overlap with the allowed CPUs"
+            return info
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), use)
+            except OSError:
+                pass
+        info["pinned"], info["cpus"] = True, len(use)
+    except Exception as e:     # no sysfs entry (container), no permission: run unpinned and say so
+        info["reason"] = f"{type(e).__name__}: {e}"
+    return info
 
 
 def spawn_ranks(n):
@@ -568,7 +635,8 @@ def main():
     ap.add_argument("--plan", default="auto", choices=["auto", "general", "fused", "latency", "fused2", "fusedh", "fused1s"])
     ap.add_argument("--rnn-cluster", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip extra.configs / extra.sustained (headline line only)")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra.configs / extra.sustained / extra.scaling_table (headline line only)")
+    ap.add_argument("--no-scaled", action="store_true", help="scaling table without the scaled-model row (BASELINE configs[4])")
     ap.add_argument("--sustain-s", type=float, default=3.0)
     ap.add_argument("--prewarm-s", type=float, default=0.5, help="untimed seconds of the same step before the warm-up (clock ramp)")
     ap.add_argument("--profile-all", action="store_true", help="print a per-stage time table (separate pass)")
@@ -577,6 +645,7 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))   # `python bench.py --gpus N` starts its own N ranks (one per GPU)
 
+    t_main0 = time.perf_counter()
     rank, local_rank, world = tdist.env_rank()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # TIP_BENCH_SHARE_GPU=1 + TIP_BENCH_BACKEND=gloo: every rank on cuda:0 over gloo — how tests/test_dist_gpu.py rehearses the
@@ -586,6 +655,7 @@ def main():
     dev_index = 0 if share_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    pin = pin_to_gpu_numa_node(dev_index)      # before the process group / the first kernel: threads created later inherit the mask
     use_pg = "RANK" in os.environ          # launched by torch.distributed.run (also exercised with one rank)
     if use_pg:
         if backend == "nccl":
@@ -681,6 +751,9 @@ def main():
 
     global_b = B * world
     value = global_b * args.steps / elapsed
+    nodes = gather_all(torch.tensor([pin.get("numa_node", -2), 1 if pin.get("pinned") else 0, pin.get("cpus", 0)], device=dev, dtype=torch.int64))
+    pins = {"rank0": pin, "numa_node_per_rank": [int(v[0].item()) for v in nodes], "pinned_per_rank": [bool(v[1].item()) for v in nodes],
+            "cpus_per_rank": [int(v[2].item()) for v in nodes]}
 
     roofline = None
     if prof:
@@ -708,28 +781,50 @@ def main():
 
     extra = {}
     if args.config == "paper256" and not args.no_extra:
-        # north_star's table: frames/s at batch 1 and at 8192 streams in total (strong-scaled: 8192 / N per GPU, last-row output,
-        # BASELINE configs[3]) on this run's N GPUs, same barrier + max-over-ranks timing as the headline (which is batch 256/GPU)
+        # north_star's table on this run's N GPUs, every row with the headline's barrier + max-over-ranks timing:
+        #   batch1_per_gpu      one stream per GPU (the latency case; frames/s = N / step time)
+        #   batch256_total      256 windows in total, 256 / N per GPU, full output: the headline workload STRONG-scaled (the headline
+        #                       itself is weak: 256 per GPU)
+        #   streams8192_total   BASELINE configs[3]: 8192 concurrent streams in total, 8192 / N per GPU, last-row output
+        #   scaled_b4096_total  BASELINE configs[4]: 12 layers, d = 1024, ffn = 4096, T = 80, 4096 windows in total, 4096 / N per GPU,
+        #                       full output, with its own one-time broadcast of the 609-MB image (below)
         table = {}
+
+        def timed_row(mdl, c, fn, total, Tt, nst, nwarm, lastrow):
+            for _ in range(nwarm):
+                fn()
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(nst):
+                fn()
+            sync_all()
+            el = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            els = gather_all(el)
+            el_max = max(float(v.item()) for v in els)
+            mdl.check_handoffs()
+            tot = sum(shard_sizes(total))
+            return {"streams_per_gpu": shard_sizes(total)[0], "streams_total": tot, "T": Tt, "steps": nst, "ms_per_step": el_max / nst * 1e3,
+                    "frames_per_s": tot * nst / el_max, "output": "last row" if lastrow else "full",
+                    "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(c, Tt, tot * nst / el_max, world)}
+
+        def shard_sizes(total):     # contiguous split of `total` streams over the ranks (tdist.shard_range): the first total % N get one more
+            return [hi - lo for lo, hi in (tdist.shard_range(total, r, world) for r in range(world))]
+
         with torch.no_grad():
-            for name, bt, lastrow, nst in (("batch1_per_gpu", 1, True, 200), ("streams8192_total", max(8192 // world, 1), True, 10)):
-                reps = (bt + xi.shape[0] - 1) // xi.shape[0]
+            for name, total, lastrow, nst in (("batch1_per_gpu", world, True, 200), ("batch256_total", 256, False, 50),
+                                              ("streams8192_total", 8192, True, 10)):
+                lo, hi = tdist.shard_range(total, rank, world)
+                bt = hi - lo
+                reps = (max(bt, 1) + xi.shape[0] - 1) // xi.shape[0]
                 ti, ts_ = xi.repeat(reps, 1, 1)[:bt].contiguous(), xs.repeat(reps, 1, 1)[:bt].contiguous()
                 fn = (lambda: model.forward_last(ti, ts_)) if lastrow else (lambda: model(ti, ts_))
-                for _ in range(3):
-                    fn()
-                sync_all()
-                t1 = time.perf_counter()
-                for _ in range(nst):
-                    fn()
-                sync_all()
-                el = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-                els = gather_all(el)
-                el_max = max(float(v.item()) for v in els)
-                table[name] = {"streams_per_gpu": bt, "streams_total": bt * world, "steps": nst, "ms_per_step": el_max / nst * 1e3,
-                               "frames_per_s": bt * world * nst / el_max, "output": "last row" if lastrow else "full",
-                               "whole_forward_frac_of_fp32_mfma_peak": frac_of_peak(cfg, T, bt * world * nst / el_max, world)}
+                table[name] = timed_row(model, cfg, fn, total, T, nst, 3, lastrow)
                 del ti, ts_
+            if not args.no_scaled:
+                try:
+                    table["scaled_b4096_total"] = scaled_row(rank, world, dev, args, timed_row, tdist.shard_range(4096, rank, world))
+                except Exception as e:     # the extras never take the headline line down (every rank fails or passes alike: same code, same sizes)
+                    table["scaled_b4096_total"] = {"error": f"{type(e).__name__}: {e}"}
         model.check_handoffs()
         extra["scaling_table"] = table
     with torch.no_grad():
@@ -757,8 +852,10 @@ def main():
     model.check_handoffs()
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:     # off the timed path; other ranks wait at the final barrier
-        cpu = cpu_baseline(synth.PAPER, 256, 40, budget_s=10.0 if world == 1 else 6.0)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:     # N = 1 only (the N > 1 lines carry the GPU table; the host cores are the same box's)
+        if pin.get("pinned"):                                       # the CPU leg may use every core the process was given
+            os.sched_setaffinity(0, range(os.cpu_count()))
+        cpu = cpu_baseline(synth.PAPER, 256, 40, budget_s=10.0)
 
     if rank == 0:
         fpw = synth.flops_per_window(cfg, T)
@@ -779,6 +876,7 @@ def main():
             "packed_image_identical_on_all_ranks": image_equal,
             "ranks_output_identical": outputs_equal, "probe_output_digest": [int(v) for v in digs[0].tolist()],
             "weight_broadcast_ms": bcast_ms, "prewarm_s": args.prewarm_s,
+            "host_pinning": pins, "wall_s": time.perf_counter() - t_main0,
             "extra": extra,
         }
         # one-line summaries of the other benchmarked shapes LAST, so that they survive a reader that keeps only the tail of stdout
@@ -796,6 +894,10 @@ def main():
             "train_b256_fwd_bwd_ms": pick(cfgs.get("train_b256"), "fwd_bwd_ms"),
             "train_b256_frac": pick(cfgs.get("train_b256"), "fwd_bwd_frac_of_fp32_mfma_peak"),
             "scaled_b512_frac": pick(cfgs.get("scaled_b512_t80"), "whole_forward_frac_of_fp32_mfma_peak"),
+            # north_star's table on this run's N GPUs (totals over all ranks; ms per step, frames/s, fraction of N x fp32-MFMA peak)
+            "table_" + str(world) + "gpu": {k: [round(v["ms_per_step"], 4), round(v["frames_per_s"], 1), round(v["whole_forward_frac_of_fp32_mfma_peak"], 4)]
+                                            if isinstance(v, dict) and "ms_per_step" in v else v
+                                            for k, v in (extra.get("scaling_table") or {}).items()},
             "cpu_frames_per_s": cpu["value"] if cpu else None, "cpu_model": cpu.get("cpu_model") if cpu else None,
         }
         print(json.dumps(line))

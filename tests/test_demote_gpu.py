@@ -161,3 +161,59 @@ def test_launch_by_launch_streaming_engine_raises_and_reprimes_after_a_lost_fram
     assert out is not None and out["T"] == 40 and bool(torch.isfinite(out["y_last"]).all())
     m.check_handoffs()
     h.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)
+
+
+@pytest.mark.handoff_fault
+def test_train_mode_runner_call_demotes_after_a_lost_handoff():
+    """the unedited runner's call (.train() mode, B = 1: tip_forward_dropout on the cooperating latency kernels) had no
+    demote flow — after a lost hand-off every following frame raised.  Now as in _forward_hip: the first TipHandoffError clears the
+    word, demotes the handle and the call falls back to tip_train_forward (one-workgroup recurrence tiles); later frames are finite."""
+    m = make_model(synth.PAPER, p_state=0.8)
+    load_synth(m, synth.PAPER, 0)
+    m = m.cuda()                                           # stays in .train() mode
+    h = m._ensure_handle()
+    x_imu, x_s = synth.make_inputs(synth.PAPER, 1, 40, seed=9)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.nan_to_num(torch.tensor(x_s)).cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(3):                                 # slow path, then the fast path twice
+            assert bool(torch.isfinite(m(xi, xs)).all())
+        assert m._fast_state is not None
+        h.set_option(tlib.TIP_OPT_FAULT_INJECT, 4)         # the GEMV recurrence loses member 1 of stream 0 from here on
+        y_bad = m(xi, xs)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(y_bad).any()) and not m.is_demoted()
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        y1 = m(xi, xs)                                     # entry check trips -> demote -> tip_train_forward serves this call
+        torch.cuda.synchronize()
+    assert any("lost an inter-workgroup hand-off" in str(r.message) for r in rec)
+    assert m.is_demoted() and m.demotions == 1 and bool(torch.isfinite(y1).all())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(3):                                 # the fault is still injected: nothing cooperating runs any more
+            assert bool(torch.isfinite(m(xi, xs)).all())
+        y1.sum().backward()                                # and the demoted step differentiates
+        torch.cuda.synchronize()
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+        m.check_handoffs()
+        h.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)
+        m.undemote()
+        m._backward_seen = False
+        assert bool(torch.isfinite(m(xi, xs)).all())
+        m.check_handoffs()
+    # AUTO_DEMOTE off: the error is reported
+    m2 = make_model(synth.PAPER, p_state=0.8)
+    load_synth(m2, synth.PAPER, 0)
+    m2 = m2.cuda()
+    h2 = m2._ensure_handle()
+    h2.set_option(tlib.TIP_OPT_AUTO_DEMOTE, 0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m2(xi, xs)
+        h2.set_option(tlib.TIP_OPT_FAULT_INJECT, 4)
+        m2(xi, xs)
+        torch.cuda.synchronize()
+        h2.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)
+        with pytest.raises(tlib.TipHandoffError):
+            m2(xi, xs)

@@ -67,6 +67,8 @@ def test_bench_world_size_2_on_one_gpu():
     tab = d["extra"]["scaling_table"]
     assert tab["batch1_per_gpu"]["streams_total"] == 2 and tab["streams8192_total"]["streams_per_gpu"] == 4096
     assert tab["streams8192_total"]["frames_per_s"] > 1000
+    assert tab["batch256_total"]["streams_per_gpu"] == 128 and tab["batch256_total"]["output"] == "full"
+    assert tab["scaled_b4096_total"]["streams_per_gpu"] == 2048 and tab["scaled_b4096_total"]["weight_broadcast_ms"] > 0
 
 
 def test_two_ranks_one_gpu_shards_equal_single_process(tmp_path):
@@ -110,6 +112,44 @@ def test_plain_bench_command_spawns_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["world_size"] == 2 and len(d["per_rank_ms_per_step"]["all"]) == 2
     assert d["config"]["global_batch"] == 512 and d["ranks_output_identical"] is True
+
+
+def test_plain_bench_command_gpus_8_carries_the_whole_north_star_table():
+    """The driver's 8-GPU invocation, `python bench.py --gpus 8` (no launcher, default steps), rehearsed with eight ranks on the one GPU
+    this box has (TIP_BENCH_SHARE_GPU=1, gloo, a plan without cooperating kernels): the line says n_gpus == world_size == 8 and its
+    scaling table has every row of north_star's table — batch 1 per GPU, 256 windows in total (strong), 8192 streams in total (BASELINE
+    configs[3]) and the scaled model at 4096 windows in total (configs[4], with its own 609-MB broadcast) — finite, and every rank's
+    outputs for the probe windows identical; the whole run inside the wall-time bound (5 minutes; eight ranks SHARING one GPU are
+    slower than eight GPUs)."""
+    import math
+    import time
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", TIP_BENCH_SHARE_GPU="1", TIP_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plan", "fusedh", "--rnn-cluster", "1"]
+    t0 = time.time()
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, env=env, cwd=ROOT)
+    wall = time.time() - t0
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["world_size"] == 8 and len(d["per_rank_ms_per_step"]["all"]) == 8
+    assert d["config"]["global_batch"] == 2048 and d["scaling"] == "weak"
+    assert d["ranks_output_identical"] is True and d["packed_image_identical_on_all_ranks"] is True
+    tab = d["extra"]["scaling_table"]
+    want = {"batch1_per_gpu": (1, 8), "batch256_total": (32, 256), "streams8192_total": (1024, 8192), "scaled_b4096_total": (512, 4096)}
+    assert set(tab) == set(want)
+    for k, (per, tot) in want.items():
+        row = tab[k]
+        assert "error" not in row, (k, row)
+        assert row["streams_per_gpu"] == per and row["streams_total"] == tot
+        for f in ("ms_per_step", "frames_per_s", "whole_forward_frac_of_fp32_mfma_peak"):
+            assert math.isfinite(row[f]) and row[f] > 0, (k, f, row[f])
+    assert tab["scaled_b4096_total"]["weight_broadcast_ms"] > 0 and tab["scaled_b4096_total"]["packed_image_mb"] > 600
+    assert len(d["host_pinning"]["numa_node_per_rank"]) == 8
+    assert d["tail_summary"]["table_8gpu"]["scaled_b4096_total"][0] > 0
+    assert wall < 300 and d["wall_s"] < 300, (wall, d["wall_s"])
 
 
 def test_plain_bench_command_refuses_more_gpus_than_the_box_has():

@@ -371,3 +371,49 @@ def test_default_library_does_not_read_the_environment():
         if n:
             hits.append((os.path.basename(f), n))
     assert hits == [("tip_internal.h", 1)], hits
+
+
+def test_parameter_list_cache_follows_swapped_parameters():
+    """the module keeps list(self.parameters()) between calls (the tree walk costs ~40 us per forward) and must notice
+    every way a Parameter or a submodule can be swapped WITHOUT going through its own _apply: torch.func.functional_call (writes
+    `_parameters[name]` directly), load_state_dict(assign=True), re-assigning a leaf's weight, replacing a submodule, a submodule's own
+    .double().  The cached list is validated by identity on every call; the dtype signature follows the storage pointers."""
+    import copy
+    cfg = synth.TINY
+    m = make_model(cfg)
+    load_synth(m, cfg, 0)
+    ids = lambda ps: [id(p) for p in ps]   # noqa: E731
+    pl = m._plist()
+    assert ids(pl) == ids(m.parameters()) and m._plist() is pl                       # cached, in state-dict order
+    assert [n for n, _ in m.named_parameters()] == list(m.state_dict().keys())
+    # (1) re-assigning a leaf's parameter
+    m.rnn.weight_hh_l0 = torch.nn.Parameter(torch.zeros_like(m.rnn.weight_hh_l0))
+    assert ids(m._plist()) == ids(m.parameters())
+    # (2) load_state_dict(assign=True): every Parameter object is replaced
+    before = ids(m._plist())
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}, assign=True)
+    assert ids(m._plist()) == ids(m.parameters()) and ids(m._plist()) != before
+    # (3) replacing a submodule
+    m.tf_encode.layers[1] = copy.deepcopy(m.tf_encode.layers[0])
+    assert ids(m._plist()) == ids(m.parameters())
+    # (4) torch.func.functional_call: inside the call the module must see the substituted tensors (gradients reach THEM), and the
+    #     originals again afterwards
+    x_imu, x_s = synth.make_inputs(cfg, 2, 5, seed=3)
+    xi, xs = torch.tensor(x_imu), torch.nan_to_num(torch.tensor(x_s))
+    m.eval()
+    subst = {k: (v.detach().clone() * 0.5).requires_grad_(True) for k, v in m.named_parameters()}
+    y_sub = torch.func.functional_call(m, subst, (xi, xs))
+    y_own = m(xi, xs)
+    assert not torch.allclose(y_sub, y_own)
+    y_sub.sum().backward()
+    assert all(v.grad is not None for v in subst.values()) and all(p.grad is None for p in m.parameters())
+    assert ids(m._plist()) == ids(m.parameters())
+    # (5) a submodule's own .double(): same Parameter objects, new storage and dtype -> the HIP training path must say no (mixed dtypes)
+    m.rnn.double()
+    assert ids(m._plist()) == ids(m.parameters())
+    assert m._hip_train_ok(xi, xs) is False
+    # (6) deleting a parameter / a submodule does not crash the validation
+    m2 = make_model(cfg)
+    m2._plist()
+    del m2.tf_encode.layers[1]
+    assert ids(m2._plist()) == ids(m2.parameters())

@@ -2,6 +2,8 @@
 the training oracle and the reference's golden gradient digests."""
 import os
 
+import warnings
+
 import numpy as np
 import pytest
 import torch
@@ -39,11 +41,7 @@ def _hip_step(m, x_imu, x_s, cot, seed=None):
     """One model call + backward through the HIP path; returns (y, grads, seed used)."""
     used = {}
     if seed is not None:
-        orig = torch.randint
-
-        def fixed(*a, **k):
-            return torch.tensor([seed], dtype=torch.int64)
-        torch.randint = fixed
+        m._draw_seeds = lambda: [seed, seed]          # (the module's seed source: two draws from torch's CPU generator)
     try:
         n0 = m.hip_forward_count()
         m.zero_grad(set_to_none=True)
@@ -54,7 +52,7 @@ def _hip_step(m, x_imu, x_s, cot, seed=None):
         torch.cuda.synchronize()
     finally:
         if seed is not None:
-            torch.randint = orig
+            del m._draw_seeds
     return y.detach().cpu().numpy(), {n: p.grad.detach().cpu().numpy() for n, p in m.named_parameters()}, used
 
 
@@ -392,13 +390,14 @@ def test_few_window_train_mode_forward_runs_without_a_stash(B, T):
 
     def run(lazy_max):
         m.LAZY_STASH_MAX_BATCH = lazy_max
+        m._backward_seen = False                     # (a module that has seen a .backward() stops taking the stash-free forward)
         torch.manual_seed(1234)                      # the keep mask (device generator) and the dropout seed (CPU generator)
         m.zero_grad(set_to_none=True)
         n0 = m.hip_forward_count()
         y = m(xi, xs)
         nf = m.hip_forward_count() - n0
         assert type(y.grad_fn).__name__.startswith("_HipTrainFunction")
-        lazy = y.grad_fn.lazy_inputs is not None
+        lazy = y.grad_fn.lazy is not None
         (y * cot).sum().backward()
         torch.cuda.synchronize()
         return y.detach().cpu().numpy(), {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters()}, lazy, nf
@@ -502,7 +501,7 @@ def test_input_gradients_run_on_the_hip_step(B, train):
     # the same function through the torch-op composite with the same keep mask
     torch.manual_seed(11)
     if train:
-        seeds = torch.randint(0, 2 ** 62, (2,), dtype=torch.int64).tolist()
+        seeds = m._draw_seeds()                    # (same generator state as the call above: torch.manual_seed(11))
         mask = m._hash_keep_mask(xs.detach(), seeds[1])
     else:
         mask = m._draw_keep_mask(xs.detach())
@@ -523,3 +522,79 @@ def test_input_gradients_run_on_the_hip_step(B, train):
         err = (g_hip[k].double() - ref).norm() / (ref.norm() + 1e-30)
         assert err < REL, (k, float(err))
     m.check_handoffs()
+
+
+def test_unedited_runner_call_fast_path_is_the_validated_slow_path():
+    """Round 6: once a few-window .train()-mode call has been validated the slow way, the next ones queue their kernels first and
+    validate the parameters beside the GPU (_few_window_fast).  Same seeds -> same bits as the slow path, for every window length of
+    a run's first 40 frames; an in-place weight update, a swapped storage and a swapped Parameter object are all noticed (the stale
+    launch's result is dropped and the call re-run); frozen parameters give a plain tensor; a .backward() still works and ends the
+    stash-free mode for this module."""
+    cfg = synth.PAPER
+    ms = []
+    for _ in range(2):
+        m = make_model(cfg, p_state=0.8)
+        load_synth(m, cfg, 0)
+        ms.append(m.cuda())                               # no .eval(): offline_testing_simple.py:98
+    fast, slow = ms
+    x_imu, x_s = synth.make_inputs(cfg, 1, 40, seed=1234)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.nan_to_num(torch.tensor(x_s)).cuda()
+
+    def call(m, seed, T=40, force_slow=False):
+        if force_slow:
+            m._fast_state = None
+        torch.manual_seed(seed)
+        y = m(xi[:, :T], xs[:, :T])
+        torch.cuda.synchronize()
+        return y
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y0 = call(fast, 1)
+        assert fast._fast_state is not None and y0.grad_fn is not None
+        for T in list(range(1, 41)) + [40, 40]:
+            n0 = fast.hip_forward_count()
+            yf = call(fast, 100 + T, T)
+            assert fast._fast_state is not None and fast.hip_forward_count() == n0 + 1, T     # served by the fast path, one launch sequence
+            ys = call(slow, 100 + T, T, force_slow=True)
+            assert type(yf.grad_fn).__name__.startswith("_HipTrainFunction") and torch.equal(yf, ys), T
+        # (a) in-place update (what an optimizer step does): version counters move
+        y_old = call(fast, 7)
+        for m in ms:
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.mul_(0.9)
+        yf, ys = call(fast, 7), call(slow, 7, force_slow=True)
+        assert torch.equal(yf, ys) and not torch.equal(yf, y_old)
+        assert fast._fast_state is not None                 # re-validated by the slow re-run
+        # (b) storage swapped under the same Parameter object
+        for m in ms:
+            m.linear.bias.data = m.linear.bias.data + 1.0
+        yf2, ys2 = call(fast, 7), call(slow, 7, force_slow=True)
+        assert torch.equal(yf2, ys2) and float((yf2 - yf).abs().min()) > 0.5
+        # (c) a swapped Parameter object
+        for m in ms:
+            m.linear.bias = torch.nn.Parameter(m.linear.bias.detach() - 1.0)
+        yf3, ys3 = call(fast, 7), call(slow, 7, force_slow=True)
+        assert torch.equal(yf3, ys3) and torch.allclose(yf3, yf, atol=1e-5)
+        # (d) nothing requires grad: the same values, no graph
+        call(fast, 7)
+        for p in fast.parameters():
+            p.requires_grad_(False)
+        yf4 = call(fast, 7)
+        assert yf4.grad_fn is None and torch.equal(yf4, yf3)
+        for p in fast.parameters():
+            p.requires_grad_(True)
+        # (e) a .backward() through a fast-path call: gradients as from the slow path, bit for bit; then no more stash-free forwards
+        call(fast, 9)
+        yf5 = call(fast, 9)
+        ys5 = call(slow, 9, force_slow=True)
+        yf5.square().sum().backward()
+        ys5.square().sum().backward()
+        torch.cuda.synchronize()
+        for (n, a), (_, b) in zip(fast.named_parameters(), slow.named_parameters()):
+            assert torch.equal(a.grad, b.grad), n
+        assert fast._backward_seen and fast._fast_state is None
+        y6 = call(fast, 11)
+        assert y6.grad_fn.lazy is None and fast._fast_state is None
+    fast.check_handoffs()

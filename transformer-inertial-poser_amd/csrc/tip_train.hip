@@ -1426,7 +1426,7 @@ static TrainScratch scratch_layout(const Dims& d, int B, int T) {
     S.ga = take(off, M * d.D);
     S.gb = take(off, M * d.D);
     S.gc = take(off, M * d.D);
-    S.gbig = take(off, M * (size_t)(3 * d.D > d.F ? 3 * d.D : d.F));
+    S.gbig = take(off, M * (size_t)std::max(std::max(3 * d.D, d.F), d.InPad));   // (InPad: tip_train_input_grads writes dU [M][InPad] here)
     S.datt = take(off, M * d.D);
     S.gbig2 = take(off, M * 3 * d.D);
     size_t wmax = (size_t)d.F * d.D;

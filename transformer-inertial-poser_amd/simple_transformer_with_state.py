@@ -41,6 +41,7 @@ Bernoulli keep-mask with torch's device RNG and hands it to the kernel (TIP_FWD_
 from __future__ import annotations
 
 import math
+import operator
 import warnings
 from typing import Optional
 
@@ -49,6 +50,13 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import lib as _lib
+
+
+_req_grad = operator.attrgetter("requires_grad")
+_version = operator.attrgetter("_version")
+_data_ptr = torch.Tensor.data_ptr
+_is = operator.is_
+_getitem = operator.getitem
 
 
 class _Leaf(nn.Module):
@@ -128,9 +136,13 @@ class TF_RNN_Past_State(nn.Module):
         self.t_max = 80                  # sizing hint handed to the handle; any window length is served (general plan beyond T = 40)
         self._plist_cache = None         # list(self.parameters()): nn.Module.parameters() walks the module tree on every call (~0.6 us per
                                          # parameter and call site; the forward asks several times per frame), see _plist()
+        self._pslots = None              # where every entry of _plist_cache lives: ([_parameters dict], [name]) + ([_modules dict], [name], [module])
         self._train_ok_cache = {}
-        self._params_sig = None
+        self._params_sig = None          # (dtype, all on the GPU) of the parameters ...
+        self._sig_ptrs = None            # ... valid while their storage pointers are these
         self._ws_bytes_cache = {}
+        self._fast_state = None          # few-window .train()-mode call (the unedited runner's): what the last fully validated call saw
+        self._backward_seen = False      # a .backward() has gone through this module's .train()-mode call: real training, not a runner
 
     # ------------------------------------------------------------------------------------------
     # initialisation: same distributions torch's nn.Linear / nn.MultiheadAttention / nn.LayerNorm / nn.RNN use
@@ -188,23 +200,61 @@ class TF_RNN_Past_State(nn.Module):
         return self._ensure_handle().workspace_bytes(int(B), int(T))
 
     def _plist(self):
-        """The module's parameters as a cached list (state-dict order).  Parameters are created in the constructor only; conversions
-        (.cuda(), .double(), ...) go through _apply, which drops the cache."""
+        """The module's parameters as a cached list (state-dict order), VALIDATED on every call: each entry must still be the object
+        its owner's `_parameters` dict holds and every submodule the one its parent's `_modules` holds (one identity test each through
+        C-level maps: ~2.5 us for the 56 + 33 slots).  Whatever swaps a Parameter or a submodule without going through this module's
+        own `_apply` — torch.func.functional_call (writes `_parameters[name]` directly), load_state_dict(assign=True), re-assigning
+        `model.rnn.weight_hh_l0`, replacing a submodule — is seen by the next call, which rebuilds the list and drops everything
+        derived from it.  nn.Module.parameters() walks the module tree (~40 us): that is what the cache is for."""
         pl = self._plist_cache
-        if pl is None:
-            pl = self._plist_cache = list(self.parameters())
+        if pl is not None:
+            (pd, pn), (md, mn, ml) = self._pslots
+            try:
+                if all(map(_is, map(_getitem, pd, pn), pl)) and all(map(_is, map(_getitem, md, mn), ml)):
+                    return pl
+            except KeyError:          # a parameter / submodule was deleted
+                pass
+        return self._rebuild_plist()
+
+    def _rebuild_plist(self):
+        pd, pn, pl, md, mn, ml = [], [], [], [], [], []
+
+        def walk(mod):                # the traversal order of nn.Module.named_parameters(): own parameters, then the children in order
+            for n, q in mod._parameters.items():
+                if q is not None:
+                    pd.append(mod._parameters), pn.append(n), pl.append(q)
+            for n, c in mod._modules.items():
+                if c is not None:
+                    md.append(mod._modules), mn.append(n), ml.append(c)
+                    walk(c)
+        walk(self)
+        if len({id(q) for q in pl}) != len(pl) or [id(q) for q in pl] != [id(q) for q in self.parameters()]:   # tied / unusual layouts: no slots
+            pl = list(self.parameters())
+            pd, pn, md, mn, ml = [self.__dict__], ["_never_valid"], [], [], []    # validation always fails -> rebuilt on every call
+        self._plist_cache, self._pslots = pl, ((pd, pn), (md, mn, ml))
+        self._params_sig = self._sig_ptrs = None
+        self._train_ok_cache = {}
+        self._fast_state = None
+        self._packed_key = None       # the packed image is re-validated against the new list
         return pl
 
     def _apply(self, fn, *args, **kwargs):
         self._plist_cache = None
-        self._params_sig = None
+        self._params_sig = self._sig_ptrs = None
         self._train_ok_cache = {}
+        self._fast_state = None
         return super()._apply(fn, *args, **kwargs)
 
     def _dispatch(self, x_imu, x_s, last_row_only: bool):
+        drawn = None
+        if self._fast_state is not None and self.training:      # the unedited runner's call, seen and validated before
+            y = self._few_window_fast(x_imu, x_s)
+            if y is not None:
+                return y[:, -1] if last_row_only else y
+            # (seeds the dropped attempt took from the generator: the re-run uses THEM, so a call draws once whichever way it is served)
+            drawn, self._drawn_seeds = self._drawn_seeds, None
         plist = self._plist()
-        needs_grad = torch.is_grad_enabled() and (x_imu.requires_grad or x_s.requires_grad or
-                                                  any([p.requires_grad for p in plist]))
+        needs_grad = torch.is_grad_enabled() and (x_imu.requires_grad or x_s.requires_grad or any(map(_req_grad, plist)))
         # .train() mode draws the encoder's dropout whether or not autograd records (nn.TransformerEncoderLayer p = 0.1): with
         # gradients wanted, or with dropout to apply, the call goes to the training kernels; .train() + no_grad + p = 0 is the
         # same function as .eval() and takes the inference kernels below
@@ -219,16 +269,20 @@ class TF_RNN_Past_State(nn.Module):
             # :77 and the encoder's dropout: two seeds from torch's CPU generator (torch.manual_seed governs them; no device sync).
             # The past-state keep mask is a function of (p, seed) — the library's counter-based hash — drawn inside the first kernel
             # (few windows) or written out by tip_draw_keep_mask (_hash_keep_mask), never by three torch kernels per call.
-            seeds = torch.randint(0, 2 ** 62, (2,), dtype=torch.int64).tolist()
+            seeds = drawn or self._draw_seeds()
             mask = seeds[1] if 0.0 < self.past_state_dropout < 1.0 else self._draw_keep_mask(x_s)
             # A few windows (the unedited runner's call): the kernels are queued HERE, before autograd's bookkeeping for the 56
             # parameter inputs (~20 us of host time that then runs beside the GPU instead of in front of it); the Function below
             # picks the launched forward up instead of launching its own.
             self._pre_launched = self._few_window_train_launch(xi, x_s, mask, float(self.ENCODER_DROPOUT), seeds[0]) or False
+            served_few = bool(self._pre_launched)
             try:
                 y = _HipTrainFunction.apply(self, xi, x_s, mask, float(self.ENCODER_DROPOUT), seeds[0], *plist)
             finally:
                 self._pre_launched = None
+            if served_few and isinstance(mask, int) and self.in_dropout <= 0.0 and not self._frozen:
+                # everything about this call was checked the slow way: the next ones of the same kind take _few_window_fast
+                self._fast_state = (x_imu.device, list(map(_data_ptr, plist)), sum(map(_version, plist)))
             return y[:, -1] if last_row_only else y
         if (needs_grad and (self.training or not x_imu.is_cuda)) or (self.training and self.ENCODER_DROPOUT > 0.0 and x_imu.is_cuda):
             # not covered by the HIP training step: the torch-op composite, with the encoder dropout .train() implies
@@ -252,10 +306,56 @@ class TF_RNN_Past_State(nn.Module):
             return _HipForwardHipBackward.apply(self, last_row_only, xi, x_s, mask, *plist)
         return _HipForwardTorchBackward.apply(self, last_row_only, xi, x_s, mask, *plist)
 
+    _seed_buf = None
+    _drawn_seeds = None
+
+    def _draw_seeds(self):
+        """Two 62-bit seeds (encoder dropout, past-state keep mask) from torch's CPU generator: torch.manual_seed governs them, no
+        device sync.  One in-place draw into a cached two-element tensor (1.1 us; torch.randint + tolist: 2.3)."""
+        b = self._seed_buf
+        if b is None:
+            b = self._seed_buf = torch.empty(2, dtype=torch.int64)
+        return b.random_(0, 2 ** 62).tolist()
+
+    def _few_window_fast(self, x_imu, x_s):
+        """The unedited runner's call (real_time_runner_minimal.py:149 on a module that never left .train(): B = 1, T <= 40, autograd
+        recording, nobody differentiates) once a call of the same kind has been validated the slow way (_dispatch sets _fast_state).
+        The kernels go on the GPU's queue FIRST, behind a handful of attribute tests; what the slow path checks in front of its launch
+        — every parameter still the object the cache holds, storage pointers and version counters those the packed image was built
+        from, requires_grad flags (~12 us of host time) — is checked HERE while the GPU works.  If any of it fails, the result is
+        dropped, the state forgotten and the slow path runs the call again (its launch overwrites nothing the caller has seen).
+        Returns y, or None when the call is not of that kind any more."""
+        dev, ptrs, vsum = self._fast_state
+        pk = self._packed_dev
+        if not (x_imu.is_cuda and x_s.is_cuda and x_imu.dtype is torch.float32 and x_s.dtype is torch.float32 and x_imu.dim() == 3
+                and x_s.dim() == 3 and x_imu.shape[0] <= self.LAZY_STASH_MAX_BATCH and x_imu.shape[:2] == x_s.shape[:2]
+                and x_imu.device == dev and pk is not None and pk.device == dev and self.use_hip_training and not self.keep_train_stash
+                and not self._backward_seen and not x_imu.requires_grad and not x_s.requires_grad and self.in_dropout <= 0.0
+                and self._handle is not None and 0.0 < self.past_state_dropout < 1.0 and torch.cuda.current_device() == dev.index):
+            self._fast_state = None
+            return None
+        seeds = self._draw_seeds()
+        p_drop = float(self.ENCODER_DROPOUT)
+        pre = self._few_window_train_launch(x_imu, x_s, seeds[1], p_drop, seeds[0], trusted=True)
+        # -- beside the GPU from here on --
+        plist = self._plist()
+        if not pre or list(map(_data_ptr, plist)) != ptrs or sum(map(_version, plist)) != vsum or self._fast_state is None:
+            self._fast_state = None
+            self._drawn_seeds = seeds
+            return None
+        if not (torch.is_grad_enabled() and any(map(_req_grad, plist))):
+            # (.train() under no_grad, or every parameter frozen: the same values; no graph to record)
+            return pre[0]
+        self._pre_launched = pre
+        try:
+            return _HipTrainFunction.apply(self, x_imu, x_s, seeds[1], p_drop, seeds[0], *plist)
+        finally:
+            self._pre_launched = None
+
     LAZY_STASH_MAX_BATCH = 32   # .train()-mode calls of up to this many windows run without an activation stash (see _HipTrainFunction)
     _pre_launched = None
 
-    def _few_window_train_launch(self, x_imu, x_s, mask, p_drop, seed):
+    def _few_window_train_launch(self, x_imu, x_s, mask, p_drop, seed, trusted=False):
         """.train()-mode call of a few windows (the unedited runner's B = 1 call, real_time_runner_minimal.py:149, on a module that
         never left .train() mode): the same function on the few-stream kernels (tip_forward_dropout: same dropout decisions as
         tip_train_forward, no activation stash, ~0.2 ms instead of ~0.8 at one window per CU).  Returns (y, xi, xs, mask or its
@@ -263,7 +363,9 @@ class TF_RNN_Past_State(nn.Module):
         keep_train_stash): _HipTrainFunction then runs tip_train_forward.  If .backward() is called after all, the stash is
         produced then."""
         B = int(x_imu.shape[0])
-        if B > self.LAZY_STASH_MAX_BATCH or self.keep_train_stash or x_imu.dtype != torch.float32:
+        # (once a .backward() has been seen on this module the caller is training, not streaming: a lazy forward would be paid twice —
+        #  here and again, with the stash, inside backward — and the weight image re-packed after every optimizer step: ADVICE r05)
+        if B > self.LAZY_STASH_MAX_BATCH or self.keep_train_stash or x_imu.dtype != torch.float32 or self._backward_seen:
             return None
         n_imu = self.input_size_imu + (18 if self.with_acc_sum else 0)
         if x_imu.shape[2] != n_imu or x_s.shape[2] != self.size_s:
@@ -271,7 +373,11 @@ class TF_RNN_Past_State(nn.Module):
         h = self._ensure_handle()
         dev = x_imu.device
         T = int(x_imu.shape[1])
-        with torch.cuda.device(dev):
+        # (the library launches on the CURRENT device: switch only when it is another one — the context manager costs ~3 us)
+        ctx = torch.cuda.device(dev) if torch.cuda.current_device() != dev.index else None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
             xi, xs = x_imu.contiguous(), x_s.contiguous()
             pd = self.past_state_dropout
             mask_ptr, scale = None, (1.0 / (1.0 - pd) if pd < 1.0 else 0.0) if mask is not None else 1.0
@@ -284,15 +390,20 @@ class TF_RNN_Past_State(nn.Module):
             y = torch.empty((B, T, self.size_s), dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             if not self._forward_dropout_hip(h, xi, xs, y, B, T, mask_ptr, scale, pd if state_seed is not None else 0.0,
-                                             state_seed or 0, p_drop, seed, stream):
+                                             state_seed or 0, p_drop, seed, stream, trusted):
                 return None
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
         return y, xi, xs, (mask if state_seed is None else state_seed), scale
 
-    def _forward_dropout_hip(self, h, xi, xs, y, B, T, mask_ptr, scale, p_state, state_seed, p_drop, seed, stream) -> bool:
+    def _forward_dropout_hip(self, h, xi, xs, y, B, T, mask_ptr, scale, p_state, state_seed, p_drop, seed, stream, trusted=False) -> bool:
         """tip_forward_dropout into `y`; False when the library does not serve this call that way (configuration, window length,
-        demoted handle): the caller then runs tip_train_forward."""
+        demoted handle): the caller then runs tip_train_forward.  trusted: the packed image was validated by the caller's protocol
+        (_few_window_fast checks the parameters AFTER the launch and discards the result if they changed)."""
         dev = xi.device
-        if self._packed_dev is None or self._packed_dev.device != dev or (not self._frozen and self._packed_key != self._param_key(dev)):
+        if not trusted and (self._packed_dev is None or self._packed_dev.device != dev or
+                            (not self._frozen and self._packed_key != self._param_key(dev))):
             self.refresh_packed(dev)
         try:
             need = self._ws_bytes_cache.get((B, T))
@@ -302,7 +413,20 @@ class TF_RNN_Past_State(nn.Module):
             h.forward_dropout(xi.data_ptr(), xs.data_ptr(), y.data_ptr(), B, T, _lib.TIP_FWD_KEEP_MASK if mask_ptr else 0, mask_ptr,
                               scale, p_state, state_seed, p_drop, seed, ws.data_ptr(), ws.numel(), stream)
         except _lib.TipHandoffError:
-            raise
+            # An EARLIER launch of this handle lost an inter-workgroup hand-off (a co-tenant held CUs): same answer as _forward_hip's —
+            # the first time, clear the word, demote the handle to the plans without cooperating kernels and let THIS call run there
+            # (False: the caller takes tip_train_forward, whose recurrence then runs one workgroup per tile); with TIP_OPT_AUTO_DEMOTE
+            # off, or on a handle that is demoted already, report it.
+            if not h.get_option(_lib.TIP_OPT_AUTO_DEMOTE) or h.get_option(_lib.TIP_OPT_DEMOTED):
+                raise
+            warnings.warn("tip_amd: an earlier forward lost an inter-workgroup hand-off (is another process or stream holding "
+                          "CUs of this GPU?) — its outputs were NaN.  This model now runs the plans that need no co-resident "
+                          "workgroups (TIP_OPT_DEMOTED: slower, safe under co-tenancy); model.undemote() restores the default")
+            h.check_clear()
+            h.set_option(_lib.TIP_OPT_DEMOTED, 1)
+            self.demotions += 1
+            self._fast_state = None
+            return False
         except _lib.TipStatusError as e:
             if e.status == _lib.TIP_ERR_UNSUPPORTED_CONFIG:
                 return False
@@ -324,11 +448,15 @@ class TF_RNN_Past_State(nn.Module):
             return False          # gradients w.r.t. the inputs: tip_train_input_grads (fp32 step only)
         if x_imu.dim() != 3 or x_s.dim() != 3 or x_imu.shape[:2] != x_s.shape[:2]:
             return False
+        # (dtype, every parameter of that dtype on the GPU): valid while the parameters' storage pointers are the ones it was computed
+        # for — a submodule's own .double() / .cuda() keeps the Parameter objects and swaps their storage
+        plist = self._plist()
+        ptrs = list(map(_data_ptr, plist))
         sig = self._params_sig
-        if sig is None:   # (dtype, every parameter of that dtype on the GPU): recomputed after every _apply (.cuda(), .double(), ...)
-            plist = self._plist()
+        if sig is None or ptrs != self._sig_ptrs:
             d0 = plist[0].dtype
             sig = self._params_sig = (d0, all([p.dtype == d0 and p.is_cuda for p in plist]))
+            self._sig_ptrs = ptrs
         if not sig[1] or sig[0] != pdt or not self.in_linear.weight.is_cuda:
             return False
         key = (int(x_imu.shape[0]), int(x_imu.shape[1]), pdt)
@@ -380,7 +508,7 @@ class TF_RNN_Past_State(nn.Module):
 
     def _param_key(self, device):
         plist = self._plist()
-        return (str(device), [p.data_ptr() for p in plist], [p._version for p in plist])
+        return (str(device), list(map(_data_ptr, plist)), list(map(_version, plist)))
 
     def pack_host(self) -> torch.Tensor:
         """Build the packed weight image (uint8 CPU tensor) from the current parameters."""
@@ -694,18 +822,32 @@ class _HipTrainFunction(torch.autograd.Function):
                                 y.data_ptr(), saved.data_ptr(), saved.numel(), B, T, stream, fp64=f64)
         ctx.module, ctx.dims, ctx.p_drop, ctx.seed, ctx.f64 = module, (B, T), p_drop, seed, f64
         ctx.saved_stash = saved
-        ctx.lazy_inputs = (xi, xs, mask if state_seed is None else state_seed, scale) if lazy else None
+        # no stash yet: backward re-runs the forward on (xi, xs, keep mask or its seed) — the tensors go through save_for_backward, so
+        # an in-place edit of the inputs between forward and backward is an autograd error, not a silently different gradient
+        lazy_mask_t = mask if (lazy and state_seed is None and mask is not None) else None
+        ctx.lazy = (state_seed, scale, lazy_mask_t is not None) if lazy else None
         # what gradients w.r.t. the inputs need (tip_train_input_grads): x_s (NaN positions), the keep mask (tensor, or its seed), its scale
         ctx.bwd_inputs = (xs, mask if mask is not None else state_seed, scale) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
         if module.keep_train_stash:
             module.last_train_stash = (saved, B, T)
-        ctx.save_for_backward(*params)
+        if lazy:
+            ctx.save_for_backward(xi, xs, *([lazy_mask_t] if lazy_mask_t is not None else []), *params)
+        else:
+            ctx.save_for_backward(*params)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         module, (B, T) = ctx.module, ctx.dims
-        params = ctx.saved_tensors          # raises if a parameter was modified in place since the forward
+        params = ctx.saved_tensors          # raises if a parameter (or a lazily kept input) was modified in place since the forward
+        module._backward_seen = True        # this caller differentiates its .train()-mode calls: no more stash-free forwards (see _few_window_train_launch)
+        module._fast_state = None
+        lazy_in = None
+        if ctx.lazy is not None:
+            state_seed, lscale, has_mask_t = ctx.lazy
+            n_in = 3 if has_mask_t else 2
+            lazy_in = (params[0], params[1], params[2] if has_mask_t else state_seed, lscale)
+            params = params[n_in:]
         h = module._ensure_handle()
         dev = gy.device
         with torch.cuda.device(dev):
@@ -713,10 +855,10 @@ class _HipTrainFunction(torch.autograd.Function):
             f64 = ctx.f64
             pdt = torch.float64 if f64 else torch.float32
             stream = torch.cuda.current_stream(dev).cuda_stream
-            if saved is None and ctx.lazy_inputs is not None:
+            if saved is None and lazy_in is not None and not getattr(ctx, "lazy_done", False):
                 # the forward ran without a stash (few windows, tip_forward_dropout): produce it now — tip_train_forward with the same
                 # inputs, keep mask, dropout probability and seed evaluates the same function with the same keep decisions
-                xi, xs, mask, scale = ctx.lazy_inputs
+                xi, xs, mask, scale = lazy_in
                 if isinstance(mask, int):
                     mask = module._hash_keep_mask(xs, mask)
                 saved_bytes, _ = h.train_bytes(B, T, fp64=f64)
@@ -725,7 +867,7 @@ class _HipTrainFunction(torch.autograd.Function):
                 pc0 = [p.detach().contiguous() for p in params]
                 h.train_forward([p.data_ptr() for p in pc0], xi.data_ptr(), xs.data_ptr(), mask.data_ptr() if mask is not None else None,
                                 scale, ctx.p_drop, ctx.seed, y2.data_ptr(), saved.data_ptr(), saved.numel(), B, T, stream, fp64=f64)
-                ctx.lazy_inputs = None
+                ctx.lazy_done = True
             if saved is None:
                 raise RuntimeError("tip_amd: backward through the HIP training step a second time — the activation stash "
                                    "is released after the first backward (retain_graph=True is not supported; run the "
@@ -757,16 +899,19 @@ class _HipForwardHipBackward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, last_row_only, x_imu, x_s, mask, *params):
         ctx.module, ctx.last = module, last_row_only
-        ctx.inputs = (x_imu.contiguous(), x_s.contiguous(), mask)
-        ctx.save_for_backward(*params)
+        ctx.has_mask = mask is not None
+        # (inputs and keep mask through save_for_backward: an in-place edit between forward and backward is an autograd error)
+        ctx.save_for_backward(x_imu.contiguous(), x_s.contiguous(), *([mask] if mask is not None else []), *params)
         with torch.no_grad():
             return module._forward_hip(x_imu, x_s, last_row_only, keep_mask=mask, apply_in_dropout=False)
 
     @staticmethod
     def backward(ctx, gy):
         module = ctx.module
-        params = ctx.saved_tensors
-        xi, xs, mask = ctx.inputs
+        sv = ctx.saved_tensors
+        xi, xs = sv[0], sv[1]
+        mask = sv[2] if ctx.has_mask else None
+        params = sv[3:] if ctx.has_mask else sv[2:]
         h = module._ensure_handle()
         dev = gy.device
         B, T = int(xi.shape[0]), int(xi.shape[1])
