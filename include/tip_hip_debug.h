@@ -31,6 +31,7 @@ TIP_API int tip_debug_read_bwd_trace(unsigned long long* out, int n);  /* fused 
 TIP_API int tip_debug_pgemm_launches(unsigned long long* out);         /* panel-GEMM launches since load (tests: the scaled widths take it) */
 TIP_API int tip_debug_read_f2s_cross_xcd(unsigned* out);               /* pair-split plan: pairs whose halves sat on different XCDs */
 TIP_API int tip_debug_read_f2_trace(unsigned long long* out, int n);   /* two-window encoder phase stamps (tools/f2_trace.py) */
+TIP_API int tip_debug_read_flow_trace(unsigned long long* out, int n);  /* few-stream dataflow kernel: (entry, inputs ready, stored, published) stamps per stage (tools/flow_trace.py) */
 TIP_API int tip_debug_read_f2s_trace(unsigned long long* out, int n);  /* window-split hand-off stamps */
 TIP_API int tip_debug_read_rnn_trace(unsigned long long* out, int n);  /* clustered recurrence hand-off stamps (tools/rnn_trace.py) */
 TIP_API int tip_debug_clock_probe(unsigned long long* dev_out, void* stream); /* s_memtime / s_memrealtime pair (bench.py: clock under load) */

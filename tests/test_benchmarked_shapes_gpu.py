@@ -193,3 +193,47 @@ def test_auto_over_a_batch_sweep_matches_the_one_window_plan():
             yl = m.forward_last(xi, xs)
             assert torch.equal(yl, y[:, -1]), B
     m.check_handoffs()
+
+
+def test_few_stream_plan_over_changing_layouts():
+    """The one-launch form of the few-stream plan (B <= 8: stages, recurrence and output projection as roles of ONE launch, flags and
+    launch counters at the front of the workspace) over a schedule whose batch size and window length change from call to call — every
+    change moves the activations inside the workspace; the flag area must not move with them (round 6: it did at first, and a window
+    found its own earlier stamps current: finite-but-wrong rows, tools/flow_soak.py).  Bit-identical results pass after pass, against
+    the launch chain's numbers at B > 8 for the same windows (same kernels' bodies, same summation orders), no wait gives up."""
+    cfg = synth.PAPER
+    m = make_model(cfg)
+    load_synth(m, cfg, 0)
+    m = m.cuda().eval()
+    h = m._ensure_handle()
+    h.set_option(tlib.TIP_OPT_AUTO_DEMOTE, 0)
+    assert h.workspace_bytes(1, 40) > 34 * 64 * 64 * 8      # the flag area is part of every paper-configuration workspace
+    rng = np.random.RandomState(11)
+    sched = [(int(rng.choice([1, 2, 3, 5, 8])), int(rng.randint(1, 41)), bool(rng.randint(2))) for _ in range(60)]
+    sched += [(1, t, True) for t in range(1, 41)] + [(8, 39, True), (2, 40, True), (8, 39, True)]
+    data = {}
+    for B, T, _ in sched:
+        if (B, T) not in data:
+            x_imu, x_s = synth.make_inputs(cfg, B, T, seed=100 * B + T)
+            data[(B, T)] = (torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda())
+    t0 = tlib.spin_timeouts()
+    ref = []
+    with torch.no_grad():
+        for p in range(6):
+            for i, (B, T, last) in enumerate(sched):
+                xi, xs = data[(B, T)]
+                y = (m.forward_last(xi, xs) if last else m(xi, xs)).clone()
+                if p == 0:
+                    assert bool(torch.isfinite(y).all())
+                    ref.append(y)
+                else:
+                    assert torch.equal(y, ref[i]), (p, i, B, T, last)
+        # the same windows through the launch chain (B = 9 > 8: window 0..7 of the batch are the B = 8 case's): same bits
+        xi8, xs8 = data[(8, 39)]
+        xi9, xs9 = torch.cat([xi8, xi8[:1]]), torch.cat([xs8, xs8[:1]])
+        y9 = m.forward_last(xi9, xs9)
+        y8 = m.forward_last(xi8, xs8)
+        assert torch.equal(y9[:8], y8) and torch.equal(y9[8], y8[0])
+    torch.cuda.synchronize()
+    m.check_handoffs()
+    assert tlib.spin_timeouts() == t0

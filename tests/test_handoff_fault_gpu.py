@@ -41,6 +41,9 @@ def _fault(m, bits):
     ("general", 37, 2, "tile0", 0),     # AUTO through the general plan
     ("general", 37, 2, "tile0", 8),     # 8-workgroup clusters
     ("latency", 3, 4, "win0", 0),       # GEMV RNN of the latency plan: member 1 of stream 0 never arrives
+    ("latency", 3, 1, "win0", 0),       # one-launch form of the latency plan (B <= 8): the out-projection workgroup of column block 1 of
+                                        # window 0, layer 0, never arrives — its consumers' flag waits give up and poison the window
+    ("latency", 20, 4, "win0", 0),      # the launch chain (B > 8) with the 8-member GEMV recurrence
 ])
 def test_lost_handoff_poisons_and_raises(plan, B, bits, hit, cluster):
     ncu = torch.cuda.get_device_properties(0).multi_processor_count

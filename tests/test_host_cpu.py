@@ -87,7 +87,7 @@ def test_c_abi_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(tip_[a-z0-9_]+)\s*\(", hdr)) - {"tip_stream_t"}
     assert declared == set(tlib.EXPORTS), declared ^ set(tlib.EXPORTS)
     dbg = set(re.findall(r"\b(tip_debug_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "tip_hip_debug.h")).read()))
-    assert len(dbg) == 11
+    assert len(dbg) == 12
     lib = ctypes.CDLL(tlib.LIB_PATH)
     for name in declared | dbg:
         assert hasattr(lib, name), name

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Race screen for the one-launch form of the few-stream plan (lat_flow_kernel: stages, recurrence and output projection as roles of
+one launch, hand-offs through the XCD's L2, launch counter in the workspace).  Window lengths and batch sizes CHANGE from call to call
+(every change moves the flag area inside the workspace: stale words of other layouts lie under it), a side stream keeps a varying set
+of CUs busy, and every result is compared bit for bit with the first pass over the same schedule.
+usage: python tools/flow_soak.py [passes = 30]"""
+import contextlib, os, sys, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import tip_amd
+from tip_amd import synth, lib as tlib
+cfg = synth.PAPER
+warnings.simplefilter("ignore")
+with contextlib.redirect_stdout(sys.stderr):
+    m = tip_amd.TF_RNN_Past_State(72, 131, rnn_hid_size=512, tf_hid_size=1024, tf_in_dim=256, n_heads=16, tf_layers=4,
+                                  dropout=0.0, in_dropout=0.0, past_state_dropout=0.0, with_acc_sum=True)
+m.load_state_dict({k: torch.tensor(v) for k, v in synth.make_weights(cfg, seed=0).items()})
+m = m.cuda().eval()
+m._ensure_handle().set_option(tlib.TIP_OPT_AUTO_DEMOTE, 0)      # a lost hand-off is an error here, not a demotion
+passes = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.RandomState(7)
+sched = [(int(rng.choice([1, 1, 2, 3, 5, 8])), int(rng.randint(1, 41)), bool(rng.randint(2))) for _ in range(150)]
+sched += [(1, t, True) for t in range(1, 41)] + [(2, 40, True)] * 30 + [(8, 40, False)] * 10
+data = {}
+for B, T, last in sched:
+    if (B, T) not in data:
+        x_imu, x_s = synth.make_inputs(cfg, B, T, seed=100 * B + T)
+        data[(B, T)] = (torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda())
+side = torch.cuda.Stream()
+noise = torch.randn(2048, 2048, device="cuda")
+t0 = tlib.spin_timeouts()
+ref, bad, nonfinite = [], 0, 0
+with torch.no_grad():
+    for p in range(passes):
+        for i, (B, T, last) in enumerate(sched):
+            if p % 2 == 1 and i % 7 == 0:
+                with torch.cuda.stream(side):
+                    for _ in range(1 + (i % 3)):
+                        noise @ noise
+            xi, xs = data[(B, T)]
+            y = (m.forward_last(xi, xs) if last else m(xi, xs)).clone()
+            if p == 0:
+                ref.append(y)
+                nonfinite += int(not bool(torch.isfinite(y).all()))
+            elif not torch.equal(y, ref[i]):
+                bad += 1
+                if bad <= 5:
+                    print(f"   pass {p} call {i} (B={B}, T={T}, last={last}): differs, max |diff| {(y - ref[i]).abs().max().item():.3e}", flush=True)
+        torch.cuda.synchronize()
+        m.check_handoffs()
+print(f"one-launch few-stream plan: {passes} passes x {len(sched)} calls, {bad} differing, {nonfinite} non-finite in the reference pass, "
+      f"spin time-outs {tlib.spin_timeouts() - t0}")

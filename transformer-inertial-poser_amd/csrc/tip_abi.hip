@@ -7,6 +7,8 @@
 
 #include <mutex>
 #include "tip_internal.h"
+#include <atomic>
+#include <chrono>
 
 using namespace tip;
 
@@ -137,6 +139,7 @@ Workspace carve_workspace(const Dims& d, int B, int T) {
     if (d.F > big) big = d.F;
     if (d.R > big) big = d.R;
     if (d.InPad > big) big = d.InPad;
+    w.flow = take(fused_supported(d, 40) && fused_has_rnn_ih(d) ? latency_flow_flag_floats() : 0);   // first: offset 0 whatever B and T are
     w.xa = take(Mp * d.D);
     w.xb = take(Mp * d.D);
     w.big = take(Mp * big);
@@ -298,6 +301,15 @@ int tip_create(const tip_config* cfg, tip_handle** out) {
     build_tensor_table(h);
     build_layout(h);
     h->fuse_head = 0;   // TIP_OPT_FUSE_HEAD: reserved (accepted, no effect)
+    {
+        // base of the dataflow launches' epoch stamps: different per handle and per process start, so that flag words another handle
+        // (or an earlier life of the same address) left in a caller's workspace never read as this handle's (48 bits of splitmix64)
+        static std::atomic<unsigned long long> serial{0};
+        unsigned long long z = (unsigned long long)reinterpret_cast<uintptr_t>(h) ^ (serial.fetch_add(1) << 40) ^
+                               (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+        z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        h->flow_epoch = z & 0x0000ffffffffffffull;
+    }
     int dev = -1;
     if (hipGetDevice(&dev) == hipSuccess && dev >= 0) {
         h->device = dev;
@@ -854,8 +866,10 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     auto arm_hall = [&]() { return rnn_uses_sentinel(d, B, T, rnn_cluster); };
     if (plan == TIP_PLAN_LATENCY) {
         StageScope sc(h, s, "latency_chain");
+        const LatencyHead lh{P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, d.S, (flags & TIP_FWD_LAST_ROW_ONLY) != 0, h->flow_epoch, &head_done,
+                             reinterpret_cast<unsigned long long*>(W0 + ws.flow)};
         TIP_TRY(launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall,
-                                    B, T, cus, gd, s), "latency_chain");
+                                    B, T, cus, gd, s, nullptr, cus == h->num_cus ? &lh : nullptr), "latency_chain");
         rnn_done = true;
     } else if (plan == TIP_PLAN_FUSED1S) {
         StageScope sc(h, s, "fused_encoder");
@@ -1008,13 +1022,16 @@ int tip_forward_dropout(tip_handle* h, const float* x_imu, const float* x_s, flo
     td.mkey = mkey;
     td.mthresh = mthresh;
     hipError_t e;
+    bool head_done = false;
     {
         StageScope sc(h, s, "latency_chain");
+        const LatencyHead lh{P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, d.S, (flags & TIP_FWD_LAST_ROW_ONLY) != 0, h->flow_epoch, &head_done,
+                             reinterpret_cast<unsigned long long*>(W0 + ws.flow)};
         e = launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall, B, T, cus,
-                                h->guard(), s, &td);
+                                h->guard(), s, &td, cus == h->num_cus ? &lh : nullptr);
         if (e != hipSuccess) return fail_hip(h, e, "latency_chain");
     }
-    {
+    if (!head_done) {
         StageScope sc(h, s, "out_linear");
         const bool last_only = (flags & TIP_FWD_LAST_ROW_ONLY) != 0;
         const float* hA = last_only ? hall + (size_t)(T - 1) * d.R : hall;

@@ -155,7 +155,8 @@ struct PackBatch {
 
 // Workspace carve-up for the general plan (float offsets), M = B*T rows.
 struct Workspace {
-    size_t xa, xb, big, att, hall, flags, lat, xchg;  // float offsets
+    size_t flow, xa, xb, big, att, hall, flags, lat, xchg;  // float offsets (flow: ALWAYS 0 — the one-launch few-stream form's flags and launch
+                                                            // counters must not move when B or T change: tip_latency.hip)
     size_t total_bytes;
 };
 
@@ -285,6 +286,7 @@ struct tip_handle {
     int fuse_head = 0;              // TIP_OPT_FUSE_HEAD
     int auto_demote = 1;            // TIP_OPT_AUTO_DEMOTE
     int f1s_parts = 0;              // TIP_OPT_F1S_PARTS: 0 = auto, 2, 4
+    unsigned long long flow_epoch = 0;   // launches of lat_flow_kernel so far (+ a per-handle base): stamps the completion flags of a launch
     int demoted = 0;                // TIP_OPT_DEMOTED: set by tip_demote after a lost hand-off: AUTO then avoids every cooperating kernel
     tip::Guard guard() const { return tip::Guard{err_dev, fault_inject}; }
 };
@@ -438,9 +440,20 @@ constexpr unsigned kStateMaskSite = 0xFFFFFFF0u;   // hash site of the past-stat
 // (key, thresh) of a keep mask with drop probability p under `seed`; false for p outside [0, 1)
 bool state_mask_params(float p, unsigned long long seed, unsigned* key, unsigned* thresh);
 hipError_t launch_keep_mask(float* mask, size_t n, unsigned key, unsigned thresh, hipStream_t s);
+// What the ONE-launch form of the plan (lat_flow_kernel, few windows: stages, recurrence and output projection as roles of one
+// launch) needs beyond the chain's arguments; null = launch chain.  *done says whether the projection ran inside (then the caller
+// launches no launch_latency_head).
+struct LatencyHead {
+    const float* wfrag; const float* bias; float* y; int ldy; int N; bool last_only;
+    unsigned long long nonce;   // the handle's stamp base (tip_handle::flow_epoch)
+    bool* done;
+    unsigned long long* flags;  // the workspace's flag / launch-counter area (Workspace::flow; latency_flow_flag_floats() floats)
+};
+size_t latency_flow_flag_floats();
 hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float* whh_frag, const float* x_imu,
                                const float* x_s, const float* keep_mask, float keep_scale, float* ws, float* hall, int B,
-                               int T, int num_cus, const Guard& gd, hipStream_t s, const TrainDropout* td = nullptr);
+                               int T, int num_cus, const Guard& gd, hipStream_t s, const TrainDropout* td = nullptr,
+                               const LatencyHead* head = nullptr);
 
 hipError_t launch_latency_head(const float* A, long long lda, const float* wfrag, const float* bias, float* Y, int ldy,
                                int M, int N, hipStream_t s);
