@@ -708,9 +708,12 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         // #CUs / 2 (0.45 ms)
         long long rem = -1;
         const bool quad = fused2_supported(d, T) && h->f1s_parts != 2 && fused1s_quad_fits(r, cus);
-        if (r >= 1 && r <= (quad ? 32 : 48) && latency_supported(d, r, T)) rem = r <= 8 ? 162 + 2 * r : 178 + (long long)(6.6 * (r - 8));
+        // (round 6, the few-stream plan as one launch: 147 / 149 / 181 / 241 us for <= 1 / 8 / 16 / 24 windows — a step per window that shares
+        //  an XCD — and the launch chain's 286 at 32, 372 at 44; tools/auto_calibrate.py --stages re-measures every constant here)
+        auto lat_us = [](int n) { return n <= 8 ? 147LL + n / 4 : n <= 16 ? 181LL : n <= 24 ? 241LL : n <= 32 ? 200LL + (long long)(3.6 * (n - 8)) : 286LL + 10LL * (n - 32); };
+        if (r >= 1 && r <= (quad ? 32 : 48) && latency_supported(d, r, T)) rem = lat_us(r);
         else if (r >= 1 && fused2_supported(d, T) && fused1s_fits(r, cus)) rem = quad ? 305 : 452;
-        else if (r >= 1 && latency_supported(d, r, T)) rem = 178 + (long long)(6.6 * (r - 8));
+        else if (r >= 1 && latency_supported(d, r, T)) rem = lat_us(r);
         if (split_on && rem >= 0) {
             auto single = [&](long long b) {   // encoder rounds of the cheaper of the two fused kernels + recurrence / projection rounds
                 const long long rh = (b + cus - 1) / cus, r2 = ((b + 1) / 2 + cus - 1) / cus;

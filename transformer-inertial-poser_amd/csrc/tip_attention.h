@@ -19,7 +19,9 @@ typedef float f32x4_att __attribute__((ext_vector_type(4)));
 // beyond row_limit are not written (the two-window kernel packs another window's rows right behind).
 // DROP (the training step's dropout on the probabilities, as attention_head_regs<.., TRAIN> below): keep = hash(dkey, (bh * T + query) *
 // T + key) >= thresh, kept probabilities times dscale; thresh 0 = off.
-template <int LDC, int LDV, bool DROP = false>
+// R0, R1: the query row blocks [R0, R1) this wave takes (default: all three; the few-stream plan gives each of three waves one — a
+// query's arithmetic does not depend on which wave carries its block)
+template <int LDC, int LDV, bool DROP = false, int R0 = 0, int R1 = 3>
 __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const float* Vt, int c0, int lane, int row_limit = 48,
                                                     unsigned dkey = 0, unsigned thresh = 0, float dscale = 1.f,
                                                     unsigned long long bh = 0, int T = 0) {
@@ -27,13 +29,13 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
     const int l15 = lane & 15, lg = lane >> 4;
     float4 qf[RB], kf[RB];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
+    for (int r = 0; r < R1; ++r) {
         qf[r] = *reinterpret_cast<const float4*>(Qc + (r * 16 + l15) * LDC + c0 + lg * 4);
         kf[r] = *reinterpret_cast<const float4*>(Kc + (r * 16 + l15) * LDC + c0 + lg * 4);
     }
     f32x4_att S[RB][RB];   // S[r][cb]: queries of block r (column l15) x keys of block cb (rows 4*lg + e)
 #pragma unroll
-    for (int r = 0; r < RB; ++r)
+    for (int r = R0; r < R1; ++r)
 #pragma unroll
         for (int cb = 0; cb <= r; ++cb) {
             f32x4_att t = {0.f, 0.f, 0.f, 0.f};
@@ -47,7 +49,7 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
     // key-in-block 4*lg + e <= query-in-block l15.  The three row-block reductions advance together through each shuffle.
     float mx[RB], rsum[RB];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
+    for (int r = R0; r < R1; ++r) {
         float m = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -58,9 +60,9 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
         mx[r] = m;
     }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) mx[r] = lg4_max(mx[r]);
+    for (int r = R0; r < R1; ++r) mx[r] = lg4_max(mx[r]);
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
+    for (int r = R0; r < R1; ++r) {
         float sm = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -77,12 +79,12 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
         rsum[r] = sm;
     }
 #pragma unroll
-    for (int r = 0; r < RB; ++r) rsum[r] = lg4_sum(rsum[r]);
+    for (int r = R0; r < R1; ++r) rsum[r] = lg4_sum(rsum[r]);
 #pragma unroll
-    for (int r = 0; r < RB; ++r) rsum[r] = 1.0f / rsum[r];
+    for (int r = R0; r < R1; ++r) rsum[r] = 1.0f / rsum[r];
     if (DROP && thresh) {
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
+        for (int r = R0; r < R1; ++r) {
             const unsigned pb = (unsigned)((bh * T + (r * 16 + l15)) * T);
 #pragma unroll
             for (int cb = 0; cb <= r; ++cb)
@@ -93,7 +95,7 @@ __device__ __forceinline__ void attention_head_mfma(float* Qc, float* Kc, const 
     }
     // P V per query block: A = P tiles from registers, B = V^T fragments
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
+    for (int r = R0; r < R1; ++r) {
         f32x4_att o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb <= r; ++kb) {

@@ -437,14 +437,15 @@ __device__ __forceinline__ void lat_qkv_attn_body(const LatQkvArgs& a, int head,
         }
         __syncthreads();
     }
-    // attention on the matrix cores by wave 0 (48 MFMAs + a 16-lane-shuffle softmax: ~2 us; the other waves idle)
-    if (wave == 0) {
+    // attention on the matrix cores, ONE QUERY ROW BLOCK PER WAVE (waves 0-2: 1 / 2 / 3 key blocks; one wave for all three took ~2 us
+    // of the stage's 6.8).  A wave reads its own Q rows and the K / V rows at or below them and writes O over its own Q rows only.
+    {
         const LatDrop dr = a.dr;
-        if (DROP)
-            attention_head_mfma<DH + 4, RP + 4, true>(Qs, Ks, Vts, 0, lane, 48, tip_drop_key_s(dr.seed, dr.site), dr.thresh, dr.scale,
-                                                      (unsigned long long)win * 16 + head, T);
-        else
-            attention_head_mfma<DH + 4, RP + 4>(Qs, Ks, Vts, 0, lane);
+        const unsigned dk = DROP ? tip_drop_key_s(dr.seed, dr.site) : 0u;
+        const unsigned long long bh = (unsigned long long)win * 16 + head;
+        if (wave == 0) attention_head_mfma<DH + 4, RP + 4, DROP, 0, 1>(Qs, Ks, Vts, 0, lane, 48, dk, dr.thresh, dr.scale, bh, T);
+        else if (wave == 1) attention_head_mfma<DH + 4, RP + 4, DROP, 1, 2>(Qs, Ks, Vts, 0, lane, 48, dk, dr.thresh, dr.scale, bh, T);
+        else if (wave == 2) attention_head_mfma<DH + 4, RP + 4, DROP, 2, 3>(Qs, Ks, Vts, 0, lane, 48, dk, dr.thresh, dr.scale, bh, T);
     }
     __syncthreads();
     // O (in the Q plane) -> K-blocked global layout [16 heads][T][16]
@@ -1044,8 +1045,9 @@ size_t latency_workspace_floats(int B, int T) {
 
 // B up to which the stages run as roles of ONE launch (lat_flow_kernel): a window's roles share the 32 CUs of one XCD, so windows
 // beyond 8 queue behind each other on their XCD; the launch chain spreads every stage over the whole device instead.
-// Measured (tools/b1_chain.py): see CHANGELOG round 6.
-constexpr int kFlowMaxBatch = 8;
+// Measured back to back on one box (tools/b1_chain.py; one launch / chain, us per forward): B = 1 147 / 158, 8 149 / 173, 12 180 / 191,
+// 16 181 / 199, 24 241 / 262, 32 298 / 286.  Both forms give the same bits (same stage bodies, same summation orders).
+constexpr int kFlowMaxBatch = 24;
 
 hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float* whh_frag, const float* x_imu,
                                const float* x_s, const float* keep_mask, float keep_scale, float* ws, float* hall, int B,
