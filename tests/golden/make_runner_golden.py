@@ -14,7 +14,17 @@ The model is the reference TF_RNN_Past_State with the build's synthetic weights,
 Recorded per frame: raw IMU in, the tensors the runner hands to the model, the row it consumes, and the history
 row it feeds back.  Only data is written.
 
-usage: python tests/golden/make_runner_golden.py
+Second fixture, tip_rotation_branches.npz: the reference's OWN two converters of the feedback path —
+data_utils.batch_rot_mat_2axis_to_aa (:164-179, calls conversions.R2A) and data_utils.batch_to_rot_mat_2axis (:182-187,
+conversions.A2R) — evaluated at the branch points of an axis-angle convention: angles 0, 1e-8, 1e-4, around the small-angle
+switch (1e-3), pi/2, pi - 1e-2, pi - 1e-3, pi - 1e-6, pi, and beyond pi (a rotation vector longer than pi wraps), each about
+an axis AND its negative (both hemispheres: where the sign of a near-pi rotation vector is decided).  The fixture records
+which implementation of `fairmotion.ops.conversions` produced it (`conversions_impl`): today the scipy stand-in below, i.e.
+"parity unpinned" for the fork's conventions.  With the author's fork installed, `--real-fairmotion` skips the stand-in for
+`conversions` / `quaternion`; regenerating the two fixtures and re-running tests/test_streaming_oracle.py +
+tests/test_streaming_gpu.py is then the whole pinning step.
+
+usage: python tests/golden/make_runner_golden.py [--real-fairmotion]
 """
 import os
 import sys
@@ -30,7 +40,76 @@ sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
 
-def install_stubs():
+# Which functions of the (absent) fairmotion fork are stood in, by what, and whether the accelerated path (SURVEY.md section 8
+# rows a12 / a13) reaches them.  check_stand_ins_cover_the_reference() compares this table with what the reference's two files
+# on the path actually call.
+FAIRMOTION_STAND_INS = {
+    # name                      (stand-in,                                             on the path?)
+    "conversions.R2A": ("scipy Rotation.from_matrix(R).as_rotvec()", "yes: real_time_runner_minimal.py:161, data_utils.py:177 (6D -> axis-angle)"),
+    "conversions.A2R": ("scipy Rotation.from_rotvec(a).as_matrix()", "yes: data_utils.py:185 (axis-angle -> 6D history row)"),
+    "conversions.A2Q": ("scipy Rotation.from_rotvec(a).as_quat()   [xyzw]", "no: data_utils.py:274-279 (PyBullet state), :318 (metrics)"),
+    "conversions.Q2A": ("scipy Rotation.from_quat(q).as_rotvec()", "no: data generation / metrics"),
+    "conversions.Q2R": ("scipy Rotation.from_quat(q).as_matrix()", "no: SBP labels, root correction, IK"),
+    "conversions.R2Q": ("scipy Rotation.from_matrix(R).as_quat()", "no: not called by the two files"),
+    "quaternion.Q_mult": ("Hamilton product, xyzw", "no: data_utils.py:400 (root correction)"),
+}
+NOT_STOOD_IN = {"conversions.T2Qp": "data generation only (data_utils.py:132-146)", "quaternion.Q_diff": "metrics only (data_utils.py:318,347)"}
+
+
+def check_stand_ins_cover_the_reference():
+    """Every `conversions.X` / `quaternion.X` the reference's runner and data_utils call is either stood in or listed as off-path."""
+    import re
+    used = set()
+    for f in ("real_time_runner_minimal.py", "data_utils.py"):
+        for ln in open(os.path.join(REF, f)):
+            code = ln.split("#", 1)[0]
+            used |= {"conversions." + m for m in re.findall(r"conversions\.(\w+)", code)}
+            used |= {"quaternion." + m for m in re.findall(r"quaternion\.(\w+)", code)}
+            if re.search(r"\bQ_mult\(", code):
+                used.add("quaternion.Q_mult")
+    missing = used - set(FAIRMOTION_STAND_INS) - set(NOT_STOOD_IN)
+    assert not missing, f"the reference calls {sorted(missing)}: add a stand-in (or list it as off-path)"
+    on_path = {k for k, (_, where) in FAIRMOTION_STAND_INS.items() if where.startswith("yes")}
+    assert on_path == {"conversions.R2A", "conversions.A2R"}, on_path
+    return used
+
+
+def rotation_branch_fixture(conv_impl: str):
+    """The reference's 6D <-> axis-angle converters at the branch points of the convention (see the module docstring)."""
+    import data_utils          # the reference's, with whatever `fairmotion.ops.conversions` is installed (stand-in or the fork)
+    rng = np.random.RandomState(2026)
+    angles = [0.0, 1e-8, 1e-4, 0.999e-3, 1.001e-3, 0.5, np.pi / 2, np.pi - 1e-2, np.pi - 1e-3, np.pi - 1e-6, np.pi]
+    axes = rng.randn(6, 3)
+    axes /= np.linalg.norm(axes, axis=1, keepdims=True)
+    axes = np.concatenate([axes, np.eye(3)])                    # coordinate axes too (exact zeros in R)
+    aa_in = np.array([s * ang * ax for ang in angles for ax in axes for s in (1.0, -1.0)])     # both hemispheres
+    aa_long = np.array([s * ang * ax for ang in (np.pi + 1e-3, 1.5 * np.pi, 2 * np.pi - 1e-3) for ax in axes[:3] for s in (1.0, -1.0)])
+    aa_all = np.concatenate([aa_in, aa_long])
+    n = aa_all.shape[0]
+    pad = (-n) % 18                                             # the converters work on whole poses of 18 joints
+    aa_all = np.concatenate([aa_all, np.zeros((pad, 3))])
+    poses = np.concatenate([aa_all.reshape(-1, 54), np.zeros((aa_all.shape[0] // 18, 3))], axis=1)                 # (b, 57): + the root xyz slot
+    six = data_utils.batch_to_rot_mat_2axis(poses)[:, :108]                                                         # A2R
+    back = data_utils.batch_rot_mat_2axis_to_aa(six)                                                                # R2A
+    # and R2A on 6D rows that are NOT exactly orthonormal (what the network emits): scaled columns, a slightly skewed second axis
+    six_noisy = six.reshape(-1, 3, 2) * np.array([1.7, 0.4]) + 0.02 * rng.randn(aa_all.shape[0], 3, 2)
+    back_noisy = data_utils.batch_rot_mat_2axis_to_aa(six_noisy.reshape(-1, 108))
+    out = {"aa_in": aa_all, "six_from_aa": six.reshape(-1, 6), "aa_from_six": back.reshape(-1, 3),
+           "six_noisy": six_noisy.reshape(-1, 6), "aa_from_six_noisy": back_noisy.reshape(-1, 3), "n_real": np.array([n]),
+           "conversions_impl": np.frombuffer(conv_impl.encode(), dtype=np.uint8).copy()}
+    path = os.path.join(HERE, "tip_rotation_branches.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", n, "rotations; conversions:", conv_impl)
+
+
+def install_stubs(real_fairmotion: bool = False):
+    if real_fairmotion:                                          # only what is still missing: the simulator
+        import fairmotion  # noqa: F401  (must be the author's fork, README.md:37-42)
+        sys.modules["pybullet"] = types.ModuleType("pybullet")
+        ba = types.ModuleType("bullet_agent")
+        ba.SimAgent = type("SimAgent", (), {})
+        sys.modules["bullet_agent"] = ba
+        return
     conv = types.ModuleType("fairmotion.ops.conversions")
     conv.A2R = lambda a: Rotation.from_rotvec(np.asarray(a)).as_matrix()
     conv.R2A = lambda r: Rotation.from_matrix(np.asarray(r)).as_rotvec()
@@ -111,8 +190,11 @@ def smooth_imu_sequence(n_frames, seed):
 
 
 def main():
-    install_stubs()
+    real = "--real-fairmotion" in sys.argv
+    install_stubs(real)
     sys.path.insert(0, REF)
+    print("fairmotion functions the reference's runner / data_utils call:", sorted(check_stand_ins_cover_the_reference()))
+    impl = "fairmotion (installed package)" if real else "scipy stand-in (fairmotion fork absent: parity UNPINNED for A2R / R2A conventions)"
     import tip_amd  # noqa: F401
     from tip_amd import synth
     import amass_char_info
@@ -171,9 +253,11 @@ def main():
         out[tag + "/x_s_last_rows"] = np.array([c[1][0, -1] for c in calls])
         out[tag + "/y_last_rows"] = np.array([c[2][0, -1] for c in calls])
         print(tag, "frames", n_frames, "model calls", len(calls), "T:", out[tag + "/call_T"][:8], "...")
+    out["conversions_impl"] = np.frombuffer(impl.encode(), dtype=np.uint8).copy()
     path = os.path.join(HERE, "tip_runner_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
+    rotation_branch_fixture(impl)
 
 
 if __name__ == "__main__":
