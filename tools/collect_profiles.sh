@@ -28,7 +28,7 @@ for cfg in "256:" "1:--batch 1" "1024:--batch 1024"; do
     [ -n "$t" ] && python tools/kstats_table.py "$t" > "$OUT/kernel_medians_bench_B${tag}_T40.txt"
     if [ "$tag" = 1 ]; then   # kernel timeline of one single-stream forward (latency plan)
         t=$(find $d -name '*kernel_trace.csv' | head -1)
-        [ -n "$t" ] && python tools/timeline.py "$t" lat_in_kernel > "$OUT/timeline_B1.txt" 2> /dev/null
+        [ -n "$t" ] && python tools/timeline.py "$t" lat_flow_kernel > "$OUT/timeline_B1.txt" 2> /dev/null
     fi
 done
 
@@ -98,3 +98,14 @@ timeout 300 python tools/plan_bench.py 257 272 300 356 1000 2> /dev/null | grep 
 timeout 300 python tools/f64_bench.py 2> /dev/null | grep "^{" > "$OUT/f64_bench_n1.json"
 for p in mfma4x4_probe hop_probe permlane_probe launch_probe mfma_f64_probe imul_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
 ls -la "$OUT"
+
+# round 6: the few-stream plan as one launch (stage stamps, one launch vs launch chain, race screen), AUTO's cost model against this box,
+# the unedited runner's call (percentiles, growing window), what a kernel boundary / an in-launch hand-off costs on this part
+python tools/flow_trace.py 2> /dev/null | grep -v "^model\|^number" > "$OUT/flow_trace_B1.txt"
+{ for b in 1 8 16 24 32; do TIP_LAT_FLOW=0 python tools/b1_chain.py $b 2> /dev/null; TIP_LAT_FLOW=64 python tools/b1_chain.py $b 2> /dev/null; done; } > "$OUT/flow_vs_chain.txt"
+timeout 600 python tools/flow_soak.py 300 2> /dev/null | grep -v "^model\|^number" > "$OUT/flow_soak.txt"
+timeout 600 python tools/auto_calibrate.py --stages 2> /dev/null > "$OUT/auto_calibrate_stages.txt"
+timeout 900 python tools/auto_calibrate.py 2> /dev/null > "$OUT/auto_calibrate_sweep.txt"
+timeout 300 python tools/zero_edit_loop.py 600 2> /dev/null | grep -v "^model\|^number" > "$OUT/zero_edit_loop.txt"
+timeout 300 python tools/zero_edit_breakdown.py 400 2> /dev/null | grep -v "^model\|^number" > "$OUT/zero_edit_breakdown.txt"
+for p in l2_probe dataflow_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
