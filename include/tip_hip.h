@@ -155,6 +155,12 @@ TIP_API int tip_pack_weights_device(const tip_handle* h, const float* const* ten
 TIP_API int tip_attach_packed(tip_handle* h, const void* packed_device, size_t bytes);
 
 /* ---- forward: replaces TF_RNN_Past_State.forward(x_imu, x_s) (simple_transformer_with_state.py:60-102) ---- */
+/* Scratch of one forward, 256-byte aligned, caller-owned; its contents need not survive between calls (the caller may reuse the
+ * memory for anything).  Two forwards in flight must not share one (the library serialises forwards of different streams on the
+ * device, but see the module's per-stream buffers).  For the paper configuration the first 1.06 MiB hold the completion flags and
+ * launch counters of the one-launch few-stream plan (B <= 24): a flag counts as set only if it equals a 56-bit stamp (per-handle
+ * nonce + the counter kept in the same area), so stale or foreign contents are harmless; the area sits at offset 0 for every
+ * (B, T), so that a workspace used with changing batch sizes / window lengths keeps its counters. */
 TIP_API int tip_workspace_bytes(const tip_handle* h, int B, int T, size_t* bytes);
 /* largest batch one tip_forward (fp64 = 0) / tip_forward_f64 (fp64 = 1) call serves at window length T (32-bit buffer offsets
  * and grid limits); beyond it the calls return TIP_ERR_UNSUPPORTED_CONFIG.  Windows are independent (:60-102 has no op across

@@ -196,11 +196,11 @@ def test_auto_over_a_batch_sweep_matches_the_one_window_plan():
 
 
 def test_few_stream_plan_over_changing_layouts():
-    """The one-launch form of the few-stream plan (B <= 8: stages, recurrence and output projection as roles of ONE launch, flags and
+    """The one-launch form of the few-stream plan (B <= 24: stages, recurrence and output projection as roles of ONE launch, flags and
     launch counters at the front of the workspace) over a schedule whose batch size and window length change from call to call — every
     change moves the activations inside the workspace; the flag area must not move with them (round 6: it did at first, and a window
     found its own earlier stamps current: finite-but-wrong rows, tools/flow_soak.py).  Bit-identical results pass after pass, against
-    the launch chain's numbers at B > 8 for the same windows (same kernels' bodies, same summation orders), no wait gives up."""
+    the launch chain's numbers at B > 24 for the same windows (same kernels' bodies, same summation orders), no wait gives up."""
     cfg = synth.PAPER
     m = make_model(cfg)
     load_synth(m, cfg, 0)
@@ -228,12 +228,20 @@ def test_few_stream_plan_over_changing_layouts():
                     ref.append(y)
                 else:
                     assert torch.equal(y, ref[i]), (p, i, B, T, last)
-        # the same windows through the launch chain (B = 9 > 8: window 0..7 of the batch are the B = 8 case's): same bits
+        # the same windows through the launch chain (B = 9 <= 24 takes the one-launch form too: batch neighbours do not matter): same bits
         xi8, xs8 = data[(8, 39)]
         xi9, xs9 = torch.cat([xi8, xi8[:1]]), torch.cat([xs8, xs8[:1]])
         y9 = m.forward_last(xi9, xs9)
         y8 = m.forward_last(xi8, xs8)
         assert torch.equal(y9[:8], y8) and torch.equal(y9[8], y8[0])
+        # two and three windows per XCD (B = 16, 24: the one-launch form's limit) against the launch chain at B = 25, full output
+        x25i, x25s = synth.make_inputs(cfg, 25, 40, seed=77)
+        x25i, x25s = torch.tensor(x25i).cuda(), torch.tensor(x25s).cuda()
+        y25 = m(x25i, x25s)
+        for Bf in (9, 16, 24):
+            yf = m(x25i[:Bf].contiguous(), x25s[:Bf].contiguous())
+            assert torch.equal(yf, y25[:Bf]), Bf
+            assert torch.equal(m.forward_last(x25i[:Bf].contiguous(), x25s[:Bf].contiguous()), y25[:Bf, -1]), Bf
     torch.cuda.synchronize()
     m.check_handoffs()
     assert tlib.spin_timeouts() == t0

@@ -20,7 +20,7 @@ m = m.cuda().eval()
 m._ensure_handle().set_option(tlib.TIP_OPT_AUTO_DEMOTE, 0)      # a lost hand-off is an error here, not a demotion
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.RandomState(7)
-sched = [(int(rng.choice([1, 1, 2, 3, 5, 8])), int(rng.randint(1, 41)), bool(rng.randint(2))) for _ in range(150)]
+sched = [(int(rng.choice([1, 1, 2, 3, 5, 8, 12, 16, 24])), int(rng.randint(1, 41)), bool(rng.randint(2))) for _ in range(150)]
 sched += [(1, t, True) for t in range(1, 41)] + [(2, 40, True)] * 30 + [(8, 40, False)] * 10
 data = {}
 for B, T, last in sched:
