@@ -21,12 +21,14 @@ xi, xs = torch.tensor(x_imu).cuda(), torch.nan_to_num(torch.tensor(x_s)).cuda()
 names = ["in"] + [f"L{l}.{r}" for l in range(4) for r in ("qkv+attn", "out-proj", "ffn1", "ffn2")] + ["rnn-ih", "rnn", "head"]
 rows = []
 step = []
+inst = []
 with torch.no_grad():
     for it in range(30):
         m.forward_last(xi, xs); torch.cuda.synchronize()
-        buf = (ctypes.c_ulonglong * (len(names) * 4 + 8))()
-        assert tlib.load().tip_debug_read_flow_trace(buf, len(names) * 4 + 8) == 0
+        buf = (ctypes.c_ulonglong * (len(names) * 4 + 12))()
+        assert tlib.load().tip_debug_read_flow_trace(buf, len(names) * 4 + 12) == 0
         step.append(np.array(buf[len(names) * 4: len(names) * 4 + 6], dtype=np.float64))
+        inst.append(np.array([buf[1]] + list(buf[len(names) * 4 + 8: len(names) * 4 + 11]) + [buf[2]], dtype=np.float64))
         a = np.array(buf[:len(names) * 4], dtype=np.float64).reshape(-1, 4)
         rows.append(a - a[0, 0])                      # relative to this forward's first stamp (every workgroup of window 0 sits on XCD 0)
 r = np.median(np.stack(rows[10:]), axis=0)
@@ -41,3 +43,5 @@ print(f"total (head stored) {r[-1,2]-t0:.0f} cycles = {(r[-1,2]-t0)/2400:.1f} us
 st = np.median(np.stack(step[10:]) - np.stack(step[10:])[:, :1], axis=0)
 print("recurrence, member 0, step 20: poll starts 0 | own granules seen %.0f | all threads through the barrier %.0f | dot products + reduction %.0f | "
       "tanh + granule stored %.0f | step 21 stored %.0f (= one step)" % tuple(st[1:]))
+ii = np.median(np.stack(inst[10:]) - np.stack(inst[10:])[:, :1], axis=0)
+print("in_linear role, workgroup 0: body starts 0 | window staged in LDS %.0f | MFMAs %.0f | partials reduced %.0f | stored %.0f" % tuple(ii[1:]))

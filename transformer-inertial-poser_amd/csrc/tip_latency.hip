@@ -228,7 +228,7 @@ struct LatInArgs {
     unsigned long long* gran; unsigned* xcc_words; unsigned mkey, mthresh;
 };
 template <bool FLOW>
-__device__ __forceinline__ void lat_in_body(const LatInArgs& a, int nb, int win, float* smem, bool poisoned) {
+__device__ __forceinline__ void lat_in_body(const LatInArgs& a, int nb, int win, float* smem, bool poisoned, unsigned long long* tr = nullptr) {
     using namespace lz;
     float* U = smem;
     float* red = smem + RP * LDU;
@@ -294,9 +294,12 @@ __device__ __forceinline__ void lat_in_body(const LatInArgs& a, int nb, int win,
             }
     }
     __syncthreads();
+    if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memtime();
     f32x4 acc[RB] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     mma_kslice<4>(acc, U + l15 * LDU + lg * 4 + kb0 * 16, LDU, w, nkb);
+    if (tr && tid == 0) tr[1] = __builtin_amdgcn_s_memtime();
     const f32x4 s = reduce_partials<4>(red, acc, wave, lane);
+    if (tr && tid == 0) tr[2] = __builtin_amdgcn_s_memtime();
     if (wave < RB) {
         const int col = nb * 16 + l15;
         const float bv = bv_in;
@@ -961,7 +964,7 @@ __global__ __launch_bounds__(256) void lat_flow_kernel(LatFlowArgs a) {
         LatInArgs ia{a.wts, a.wbytes, a.x_imu, a.x_s, a.keep_mask, a.keep_scale, a.xa, T, a.NI, a.S, (int)(IN_W * 4), (int)IN_B,
                      a.gran, a.xccw, a.mkey, a.mthresh};
         FLOW_STAMP(1);
-        lat_in_body<true>(ia, nb, win, smem, false);
+        lat_in_body<true>(ia, nb, win, smem, false, (a.trace && win == 0 && nb == 0) ? g_flow_trace + (nenc + 2) * 4 + 8 : nullptr);
         FLOW_STAMP(2);
         flow_done(fc, 0, nb);
         FLOW_STAMP(3);
