@@ -94,6 +94,8 @@ __device__ __forceinline__ void flow_wait(FlowCtx& fc, int stage, int G, int* s_
         for (unsigned spin = 0; spin < lim; ++spin) {
             const u64 v = tid < G ? __hip_atomic_load(f + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : fc.want;
             if (__builtin_amdgcn_ballot_w64(v != fc.want) == 0) { ok = true; break; }
+            // this launch's stamp from ANOTHER XCD: the placement rule (id % 8 = XCD) does not hold here — no point in waiting
+            if (__builtin_amdgcn_ballot_w64(v != fc.want && (v >> 8) == (fc.want >> 8)) != 0) break;
             __builtin_amdgcn_s_sleep(1);
         }
         if (tid == 0) {
@@ -1078,7 +1080,7 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
     static const int flow_max = tip_env("TIP_LAT_FLOW") ? atoi(tip_env("TIP_LAT_FLOW")) : kFlowMaxBatch;
     const size_t ws_bytes = latency_workspace_floats(B, T) * sizeof(float);
     if (head && head->done) *head->done = false;
-    if (head && head->flags && B <= flow_max && num_cus % 8 == 0 && num_cus >= 64 && 5 + 4 * d.L <= kFlowMaxStages && ws_bytes < 0x7fffffffull &&
+    if (head && head->flags && B <= flow_max && !(gd.fault & 8) &&   // (fault bit 3 = "partners on different XCDs": the chain's territory) num_cus % 8 == 0 && num_cus >= 64 && 5 + 4 * d.L <= kFlowMaxStages && ws_bytes < 0x7fffffffull &&
         (head->N + 15) / 16 <= 64 && (size_t)T * R * 4 < 0x7fffffffull) {
         static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
         if (!attr_set) {
