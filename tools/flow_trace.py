@@ -8,27 +8,29 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import tip_amd
 from tip_amd import synth, lib as tlib
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+TRAIN = "--train" in sys.argv      # the .train()-mode call (tip_forward_dropout: four dropout sites + the keep mask drawn in the first role)
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(argv[0]) if argv else 1
 cfg = synth.PAPER
 warnings.simplefilter("ignore")
 with contextlib.redirect_stdout(sys.stderr):
     m = tip_amd.TF_RNN_Past_State(72, 131, rnn_hid_size=512, tf_hid_size=1024, tf_in_dim=256, n_heads=16, tf_layers=4, dropout=0.0,
-                                  in_dropout=0.0, past_state_dropout=0.0, with_acc_sum=True)
+                                  in_dropout=0.0, past_state_dropout=0.8 if TRAIN else 0.0, with_acc_sum=True)
 m.load_state_dict({k: torch.tensor(v) for k, v in synth.make_weights(cfg, seed=0).items()})
-m = m.cuda().eval()
+m = m.cuda().train() if TRAIN else m.cuda().eval()
 x_imu, x_s = synth.make_inputs(cfg, B, 40, seed=1234)
 xi, xs = torch.tensor(x_imu).cuda(), torch.nan_to_num(torch.tensor(x_s)).cuda()
-names = ["in"] + [f"L{l}.{r}" for l in range(4) for r in ("qkv+attn", "out-proj", "ffn1", "ffn2")] + ["rnn-ih", "rnn", "head"]
+names = ["prologue", "in"] + [f"L{l}.{r}" for l in range(4) for r in ("qkv+attn", "out-proj", "ffn1", "ffn2")] + ["rnn-ih", "rnn", "head"]
 rows = []
 step = []
 inst = []
 with torch.no_grad():
     for it in range(30):
-        m.forward_last(xi, xs); torch.cuda.synchronize()
+        (m(xi, xs) if TRAIN else m.forward_last(xi, xs)); torch.cuda.synchronize()
         buf = (ctypes.c_ulonglong * (len(names) * 4 + 12))()
         assert tlib.load().tip_debug_read_flow_trace(buf, len(names) * 4 + 12) == 0
         step.append(np.array(buf[len(names) * 4: len(names) * 4 + 6], dtype=np.float64))
-        inst.append(np.array([buf[1]] + list(buf[len(names) * 4 + 8: len(names) * 4 + 11]) + [buf[2]], dtype=np.float64))
+        inst.append(np.array([buf[5]] + list(buf[len(names) * 4 + 8: len(names) * 4 + 11]) + [buf[6]], dtype=np.float64))
         a = np.array(buf[:len(names) * 4], dtype=np.float64).reshape(-1, 4)
         rows.append(a - a[0, 0])                      # relative to this forward's first stamp (every workgroup of window 0 sits on XCD 0)
 r = np.median(np.stack(rows[10:]), axis=0)

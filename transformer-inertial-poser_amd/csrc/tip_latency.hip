@@ -228,9 +228,53 @@ struct LatInArgs {
     const float* x_imu; const float* x_s; const float* keep_mask; float keep_scale;
     float* xpre; int T, NI, S, in_w_off_b, in_b_off;
     unsigned long long* gran; unsigned* xcc_words; unsigned mkey, mthresh;
+    const float* ubuf;       // one-launch form: the window rows [T][224] as the prologue role left them (:63-78 applied); null: gather here
 };
-template <bool FLOW>
-__device__ __forceinline__ void lat_in_body(const LatInArgs& a, int nb, int win, float* smem, bool poisoned, unsigned long long* tr = nullptr) {
+// The value the prologue (:63-78) puts at column c of row `row` of window `win`: x_imu | NaN-scrubbed, kept, scaled x_s | zero pad.
+// ONE expression for the launch chain's gather (lat_in_body) and the one-launch form's prologue role: same bits.
+__device__ __forceinline__ float lat_prologue_value(const LatInArgs& a, int win, int row, int c, bool skip_hash) {
+    const int T = a.T, NI = a.NI, S = a.S;
+    const float* xi = a.x_imu + (size_t)win * T * NI;
+    const float* xs = a.x_s + (size_t)win * T * S;
+    const float* km = a.keep_mask ? a.keep_mask + (size_t)win * T * S : nullptr;
+    // One unconditional load per element from a SELECTED (clamped, always valid) address, the result masked by selects: with
+    // `if (row < T) { if (c < NI) .. else if (c < NI + S) .. }` around each of the 48 loads the compiler emitted 160 exec-mask
+    // branches and waited for each load inside its own region.
+    const int rc = row < T ? row : T - 1;
+    const bool imu = c < NI;
+    const int cs = c - NI < 0 ? 0 : (c - NI < S ? c - NI : S - 1);
+    const float* pa = imu ? xi + (size_t)rc * NI + c : xs + (size_t)rc * S + cs;
+    const float x = *pa;
+    float kv = 1.f;
+    if (km) kv = *(imu ? pa : km + (size_t)rc * S + cs);                  // :77 (km: wave-uniform; IMU lanes read a dummy)
+    // ... or the keep decision drawn here (tip_forward_dropout with a state seed): element index of x_s [B][T][S], the
+    // same decisions tip_draw_keep_mask writes out
+    // (32-bit index arithmetic: the hash takes the index mod 2^32 anyway; chunks that hold IMU columns only — NI >= 64 — skip it)
+    if (a.mthresh && !skip_hash)
+        kv = tip_drop_hash_k(a.mkey, ((unsigned)win * (unsigned)T + (unsigned)rc) * (unsigned)S + (unsigned)cs) >= a.mthresh ? 1.f : 0.f;
+    const float xs_v = (x != x ? 0.f : x) * kv * ((km || a.mthresh) ? a.keep_scale : 1.f); // :65, then (x * mask) * scale as before
+    return (row < T && c < NI + S) ? (imu ? x : xs_v) : 0.f;
+}
+
+// ---- prologue role of the one-launch form: 8 workgroups write the window's rows [T][224] ONCE (the chain's lat_in gathers them in
+// each of its 16 workgroups: 48 scalar loads + up to 36 hashes per lane — 4.5 us of the in_linear stage, 9.8 us with the keep mask drawn) ----
+__device__ __forceinline__ void lat_pre_role(const LatInArgs& a, float* ubuf, int p, int win) {
+    using namespace lz;
+    const int c = threadIdx.x;
+    if (c < KIN) {
+        float v[(RP + 7) / 8];
+#pragma unroll
+        for (int i = 0; i < (RP + 7) / 8; ++i) v[i] = lat_prologue_value(a, win, p + 8 * i, c, false);
+#pragma unroll
+        for (int i = 0; i < (RP + 7) / 8; ++i)
+            if (p + 8 * i < a.T) ubuf[((size_t)win * a.T + p + 8 * i) * KIN + c] = v[i];
+    }
+}
+
+struct NoWait { __device__ void operator()() const {} };
+template <bool FLOW, typename WAIT = NoWait>
+__device__ __forceinline__ void lat_in_body(const LatInArgs& a, int nb, int win, float* smem, const FlowCtx* fcp, unsigned long long* tr = nullptr,
+                                            const Act* act = nullptr, WAIT&& wait = WAIT()) {
     using namespace lz;
     float* U = smem;
     float* red = smem + RP * LDU;
@@ -238,7 +282,7 @@ __device__ __forceinline__ void lat_in_body(const LatInArgs& a, int nb, int win,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lg = lane >> 4;
     const float* __restrict__ wts = a.wts;
-    const int T = a.T, NI = a.NI, S = a.S;
+    const int T = a.T, NI = a.NI;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, a.wbytes, 0x00020000);
     constexpr int KB = KIN / 16;  // 14 k-blocks: waves take 4,4,4,2
     const int kb0 = wave * 4;
@@ -252,41 +296,32 @@ __device__ __forceinline__ void lat_in_body(const LatInArgs& a, int nb, int win,
         for (int i = tid; i < 2 * R; i += 256) gq[i] = 0ull;
         if (tid < kRnnGemvMaxMembers) a.xcc_words[win * kRnnGemvMaxMembers + tid] = 0u;
     }
+    if (FLOW) {
+        wait();                                                            // (weights and bias are on their way)
+        // the rows as the prologue role wrote them: 16-byte loads, not from L1 (another CU of this XCD produced them during this launch)
+        constexpr int F4 = KIN / 4;                                        // 56 float4 per row
+        const float* ub = a.ubuf + (size_t)win * T * KIN;
+        float4 v[(RP * F4 + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (RP * F4 + 255) / 256; ++i) {
+            const int f = tid + i * 256, row = f / F4, c4 = f - row * F4;
+            v[i] = (f < RP * F4 && row < T) ? ld_act4<true>(*act, ub + (size_t)row * KIN + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < (RP * F4 + 255) / 256; ++i) {
+            const int f = tid + i * 256, row = f / F4, c4 = f - row * F4;
+            if (f < RP * F4) *reinterpret_cast<float4*>(U + row * LDU + c4 * 4) = v[i];
+        }
+        if (tid < RP) *reinterpret_cast<float4*>(U + tid * LDU + KIN) = make_float4(0.f, 0.f, 0.f, 0.f);   // (the pad columns 224..227)
+    } else {
     // window inputs -> U[row][0:NI | NI:NI+S | zero pad]; wave w stages rows w, w+4, ...; lanes walk the columns.
     // All global loads of a wave are requested before its first LDS store.
-    {
-        const float* xi = a.x_imu + (size_t)win * T * NI;
-        const float* xs = a.x_s + (size_t)win * T * S;
-        const float* km = a.keep_mask ? a.keep_mask + (size_t)win * T * S : nullptr;
-        const unsigned mkey = a.mkey, mthresh = a.mthresh;
-        const float keep_scale = a.keep_scale;
         constexpr int RPW = RP / 4, NCH = (KIN + 4 + 63) / 64;   // 12 rows per wave, 4 column chunks of 64
         float v[RPW][NCH];
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int row = wave + i * 4;
+        for (int i = 0; i < RPW; ++i)
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                // One unconditional load per element from a SELECTED (clamped, always valid) address, the result masked by selects: with
-                // `if (row < T) { if (c < NI) .. else if (c < NI + S) .. }` around each of the 48 loads the compiler emitted 160 exec-mask
-                // branches and waited for each load inside its own region.
-                const int c = ch * 64 + lane;
-                const int rc = row < T ? row : T - 1;
-                const bool imu = c < NI;
-                const int cs = c - NI < 0 ? 0 : (c - NI < S ? c - NI : S - 1);
-                const float* pa = imu ? xi + (size_t)rc * NI + c : xs + (size_t)rc * S + cs;
-                const float x = *pa;
-                float kv = 1.f;
-                if (km) kv = *(imu ? pa : km + (size_t)rc * S + cs);                  // :77 (km: wave-uniform; IMU lanes read a dummy)
-                // ... or the keep decision drawn here (tip_forward_dropout with a state seed): element index of x_s [B][T][S], the
-                // same decisions tip_draw_keep_mask writes out
-                // (32-bit index arithmetic: the hash takes the index mod 2^32 anyway; chunks that hold IMU columns only — NI >= 64 — skip it)
-                if (mthresh && (ch + 1) * 64 > NI)
-                    kv = tip_drop_hash_k(mkey, ((unsigned)win * (unsigned)T + (unsigned)rc) * (unsigned)S + (unsigned)cs) >= mthresh ? 1.f : 0.f;
-                const float xs_v = (x != x ? 0.f : x) * kv * ((km || mthresh) ? keep_scale : 1.f); // :65, then (x * mask) * scale as before
-                v[i][ch] = (row < T && c < NI + S) ? (imu ? x : xs_v) : 0.f;
-            }
-        }
+            for (int ch = 0; ch < NCH; ++ch) v[i][ch] = lat_prologue_value(a, win, wave + i * 4, ch * 64 + lane, (ch + 1) * 64 <= NI);
 #pragma unroll
         for (int i = 0; i < RPW; ++i)
 #pragma unroll
@@ -309,13 +344,13 @@ __device__ __forceinline__ void lat_in_body(const LatInArgs& a, int nb, int win,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = wave * 16 + lg * 4 + e;
-            if (row < T) o[(size_t)row * D + col] = FLOW ? poison_if(poisoned, s[e] + bv) : s[e] + bv;
+            if (row < T) o[(size_t)row * D + col] = FLOW ? poison_if(fcp->poisoned, s[e] + bv) : s[e] + bv;
         }
     }
 }
 __global__ __launch_bounds__(256) void lat_in_kernel(LatInArgs a) {
     __shared__ __attribute__((aligned(16))) float smem[kLatInSmem];
-    lat_in_body<false>(a, blockIdx.x, blockIdx.y, smem, false);
+    lat_in_body<false>(a, blockIdx.x, blockIdx.y, smem, nullptr);
 }
 
 // ---- generic "LN(optional) -> one 16-column block of X W^T" stage: QKV, FFN1 (+ReLU), RNN-ih ----------------
@@ -886,8 +921,8 @@ __device__ __forceinline__ void rnn_flow_role(const float* __restrict__ ih, cons
 // flags), every stage has its OWN workgroups (weights in registers long before the inputs exist), and the ids are stage-major: a
 // workgroup only ever waits for LOWER ids, which the dispatcher has placed before it — no co-residency requirement.
 // Window w lives on XCD w % 8; the windows of one XCD share its stage-major list.
-// Stage numbers: 0 IN | 1 + 4 l: QKV + attention, 2 + 4 l: out-projection, 3 + 4 l: FFN1, 4 + 4 l: FFN2 | 1 + 4 L: RNN input projection |
-// 2 + 4 L: recurrence (16 workgroups per stream) | 3 + 4 L: output projection (one workgroup per 16 output columns).
+// Stage numbers: 0 prologue (8 workgroups) | 1 in_linear | 2 + 4 l: QKV + attention, 3 + 4 l: out-projection, 4 + 4 l: FFN1, 5 + 4 l: FFN2 |
+// 2 + 4 L: RNN input projection | 3 + 4 L: recurrence (16 workgroups per stream) | 4 + 4 L: output projection (one workgroup per 16 output columns).
 // What stamps a launch's flags: (per-handle nonce + launch counter) where the COUNTER LIVES IN THE WORKSPACE (behind the flags) and is
 // advanced by the launch itself — a kernel argument would be frozen into a captured HIP graph and every replay would find the
 // previous replay's flags "done".  One counter PER WINDOW (the XCD lanes dispatch their lists independently of each other: a counter
@@ -909,7 +944,7 @@ struct LatFlowArgs {
     const float* wts; int wbytes;
     const float* x_imu; const float* x_s; const float* keep_mask; float keep_scale;
     float* ws; int ws_bytes;               // the latency workspace (activation loads of the roles are offsets from it)
-    float *xa, *xb, *o, *hid, *ihb, *st0, *st1;
+    float *xa, *xb, *o, *hid, *ihb, *st0, *st1, *ubuf;
     unsigned long long* gran; unsigned* xccw;
     u64* flags;                            // [B][kFlowMaxStages][64]; a window's slot kFlowMaxStages - 1 holds its launch counter
     u64 nonce;                             // per-handle constant mixed into the stamps
@@ -933,18 +968,18 @@ __global__ __launch_bounds__(256) void lat_flow_kernel(LatFlowArgs a) {
     int p = blockIdx.x >> 3;
     const int nw = (a.B - x + 7) >> 3;                  // windows on this XCD: x, x + 8, ...
     if (nw <= 0) return;
-    const int L = a.L, nenc = 2 + 4 * L, nstage = nenc + 2;
+    const int L = a.L, nenc = 3 + 4 * L, nstage = nenc + 2;
     const int nhead = (a.N + 15) >> 4;
     int stage = -1, j = 0, nb = 0;
     for (int st = 0; st < nstage; ++st) {
-        const int G = st == 0 ? 16 : st == nenc - 1 ? 32 : st == nenc ? kFlowRnnMembers : st == nenc + 1 ? nhead : (((st - 1) & 3) == 2 ? 64 : 16);
+        const int G = st == 0 ? 8 : st == 1 ? 16 : st == nenc - 1 ? 32 : st == nenc ? kFlowRnnMembers : st == nenc + 1 ? nhead : (((st - 2) & 3) == 2 ? 64 : 16);
         const int cnt = G * nw;
         if (p < cnt) { stage = st; j = p / G; nb = p - j * G; break; }
         p -= cnt;
     }
     if (stage < 0) return;                               // (grid padding)
     const int win = x + 8 * j;
-    if ((a.gd.fault & 1) && win == 0 && stage == 2 && nb == 1) return;   // TIP_OPT_FAULT_INJECT bit 0: this producer never arrives
+    if ((a.gd.fault & 1) && win == 0 && stage == 3 && nb == 1) return;   // TIP_OPT_FAULT_INJECT bit 0: this producer (out-projection of layer 0, column block 1) never arrives
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     FlowCtx fc;
@@ -962,13 +997,18 @@ __global__ __launch_bounds__(256) void lat_flow_kernel(LatFlowArgs a) {
     constexpr size_t QKV_W = 0, QKV_B = QKV_W + (size_t)3 * D * D, WO_W = QKV_B + 3 * D, WO_B = WO_W + (size_t)D * D;
     constexpr size_t W1_W = WO_B + D, W1_B = W1_W + (size_t)F * D, W2_W = W1_B + F, W2_B = W2_W + (size_t)D * F;
     constexpr size_t G1 = W2_B + D, BE1 = G1 + D, G2 = BE1 + D, BE2 = G2 + D, LAYER_FLOATS = BE2 + D;
-    if (stage == 0) {
+    if (stage <= 1) {
         LatInArgs ia{a.wts, a.wbytes, a.x_imu, a.x_s, a.keep_mask, a.keep_scale, a.xa, T, a.NI, a.S, (int)(IN_W * 4), (int)IN_B,
-                     a.gran, a.xccw, a.mkey, a.mthresh};
-        FLOW_STAMP(1);
-        lat_in_body<true>(ia, nb, win, smem, false, (a.trace && win == 0 && nb == 0) ? g_flow_trace + (nenc + 2) * 4 + 8 : nullptr);
+                     a.gran, a.xccw, a.mkey, a.mthresh, a.ubuf};
+        if (stage == 0) {                                 // prologue (:63-78): the window's rows, once
+            FLOW_STAMP(1);
+            lat_pre_role(ia, a.ubuf, nb, win);
+        } else {                                          // in_linear (:79, shuffle folded); its weights are requested in front of the wait
+            lat_in_body<true>(ia, nb, win, smem, &fc, (a.trace && win == 0 && nb == 0) ? g_flow_trace + (nenc + 2) * 4 + 8 : nullptr, &act,
+                              [&] { flow_wait(fc, 0, 8, &s_ok); FLOW_STAMP(1); });
+        }
         FLOW_STAMP(2);
-        flow_done(fc, 0, nb);
+        flow_done(fc, stage, nb);
         FLOW_STAMP(3);
         return;
     }
@@ -1003,7 +1043,7 @@ __global__ __launch_bounds__(256) void lat_flow_kernel(LatFlowArgs a) {
         FLOW_STAMP(3);
         return;
     }
-    const int l = (stage - 1) >> 2, role = (stage - 1) & 3;
+    const int l = (stage - 2) >> 2, role = (stage - 2) & 3;
     const size_t lo = LAYER0 + (size_t)l * LAYER_FLOATS;
     const float* LW = a.wts + lo;
     const float* pg = l > 0 ? a.wts + lo - LAYER_FLOATS + G2 : nullptr;   // LayerNorm pending on the residual stream (norm2 of the previous layer)
@@ -1080,8 +1120,9 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
     static const int flow_max = tip_env("TIP_LAT_FLOW") ? atoi(tip_env("TIP_LAT_FLOW")) : kFlowMaxBatch;
     const size_t ws_bytes = latency_workspace_floats(B, T) * sizeof(float);
     if (head && head->done) *head->done = false;
-    if (head && head->flags && B <= flow_max && !(gd.fault & 8) &&   // (fault bit 3 = "partners on different XCDs": the chain's territory) num_cus % 8 == 0 && num_cus >= 64 && 5 + 4 * d.L <= kFlowMaxStages && ws_bytes < 0x7fffffffull &&
-        (head->N + 15) / 16 <= 64 && (size_t)T * R * 4 < 0x7fffffffull) {
+    // (fault bit 3 = "partners on different XCDs": the chain's territory)
+    if (head && head->flags && B <= flow_max && !(gd.fault & 8) && num_cus % 8 == 0 && num_cus >= 64 && 6 + 4 * d.L <= kFlowMaxStages &&
+        ws_bytes < 0x7fffffffull && (head->N + 15) / 16 <= 64 && (size_t)T * R * 4 < 0x7fffffffull) {
         static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
         if (!attr_set) {
             for (const void* f : {reinterpret_cast<const void*>(lat_flow_kernel<false>), reinterpret_cast<const void*>(lat_flow_kernel<true>)}) {
@@ -1095,6 +1136,7 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
         fa.x_imu = x_imu; fa.x_s = x_s; fa.keep_mask = keep_mask; fa.keep_scale = keep_scale;
         fa.ws = ws; fa.ws_bytes = (int)ws_bytes;
         fa.xa = xa; fa.xb = xb; fa.o = o; fa.hid = hid; fa.ihb = ihb; fa.st0 = st0; fa.st1 = st1;
+        fa.ubuf = xb + bt * 256;                                 // the [B][T][768] slot nobody else uses: [B][T][224] prologue rows
         fa.gran = gran; fa.xccw = xccw; fa.flags = flags;
         fa.nonce = head->nonce;
         fa.whh_frag = whh_frag; fa.hall = hall;
@@ -1106,7 +1148,7 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
         fa.gd = gd;
         static const int trace_on = (tip_env("TIP_FLOW_TRACE") && tip_env("TIP_FLOW_TRACE")[0] == '1') ? 1 : 0;
         fa.trace = trace_on;
-        const int per_win = 16 + d.L * 112 + 32 + kFlowRnnMembers + (head->N + 15) / 16;   // workgroups of one window
+        const int per_win = 8 + 16 + d.L * 112 + 32 + kFlowRnnMembers + (head->N + 15) / 16;   // workgroups of one window
         const int grid = 8 * per_win * ((B + 7) / 8);
         if (drop) hipLaunchKernelGGL(lat_flow_kernel<true>, dim3(grid), dim3(256), kFlowSmem * sizeof(float), s, fa);
         else hipLaunchKernelGGL(lat_flow_kernel<false>, dim3(grid), dim3(256), kFlowSmem * sizeof(float), s, fa);
@@ -1115,7 +1157,7 @@ hipError_t launch_latency_plan(const Dims& d, const float* fused_w, const float*
     } else {
         hipLaunchKernelGGL(lat_in_kernel, dim3(16, B), dim3(256), 0, s,
                            LatInArgs{fused_w, wbytes, x_imu, x_s, keep_mask, keep_scale, xa, T, d.n_imu_total, d.S, (int)(IN_W * 4), (int)IN_B,
-                                     gran, xccw, td ? td->mkey : 0u, td && !keep_mask ? td->mthresh : 0u});
+                                     gran, xccw, td ? td->mkey : 0u, td && !keep_mask ? td->mthresh : 0u, nullptr});
         const float* pg = nullptr;   // LayerNorm pending on the residual stream (norm2 of the previous layer)
         const float* pb = nullptr;
         for (int l = 0; l < d.L; ++l) {
