@@ -1,25 +1,30 @@
-// tip_latency.hip — "latency" execution plan for few concurrent streams (B <= 64), paper configuration.
+// tip_latency.hip — the few-stream ("latency") execution plan, B <= 64 windows, paper configuration.
 //
-// The fused plan gives one window to one CU (0.75 ms): fine for throughput, 13x too slow for a single 60-Hz
-// stream.  Here ONE window is spread over up to 64 CUs per GEMM: every workgroup owns ONE 16-column block of the
-// output, its 4 (or 8) waves split K, partial accumulators meet in LDS.  Stages are cut at every all-to-all seam
-// (kernel boundary ~1.5 us is cheaper on this chip than an in-kernel grid exchange, cdna_hip_programming.md 5.6):
+// The fused plan gives one window to one CU (0.53 ms): fine for throughput, 10x too slow for a single 60-Hz stream.  Here ONE
+// window is spread over 16-64 CUs per stage: every workgroup owns ONE 16-column block of a stage's output, its 4 waves split K,
+// partial accumulators meet in LDS.  Stages are cut at every all-to-all seam:
 //
-//   lat_in        prologue (:63-78) + in_linear (:79, shuffle folded)           grid (16, B)
-//   per layer:    lat_qkv   [LN2 of previous layer] + QKV projection            grid (48, B)
-//                 lat_attn  causal attention, keys split over 4 waves           grid (16, B)
-//                 lat_out   out-proj + residual (pre-LN1 sum)                   grid (16, B)
-//                 lat_ffn1  LN1 + linear1 + ReLU                                grid (64, B)
-//                 lat_ffn2  linear2 + residual (pre-LN2 sum), 8 waves split K   grid (16, B)
-//   lat_ih        LN2 of the last layer + RNN input projection                  grid (32, B)
-//   rnn_gemv      tanh recurrence (:98-99) as a VALU GEMV (M = 1 per stream: MFMA would idle 15/16 rows);
-//                 4 workgroups per stream keep W_hh in VGPRs (128 per lane) and exchange the 512-float hidden
-//                 vector through 8-byte {step tag, value} granules (the data is the flag; no fence, no counter)
-//   head_gemm     output projection (tip_general.hip)
+//   prologue   :63-78 (NaN scrub, root-velocity columns, keep mask, concatenation)                   8 workgroups per window  (one-launch form)
+//   in         in_linear (:79, shuffle folded); the chain's lat_in_kernel gathers the prologue itself 16
+//   per layer: qkv+attn  [LN2 of the previous layer] + Q/K/V projection of ONE head + its attention   16 (one per head)
+//              out       out-projection + residual (pre-LN1 sum)                                      16
+//              ffn1      LN1 + linear1 + ReLU                                                         64
+//              ffn2      linear2 + residual (pre-LN2 sum), K = 1024                                   16
+//   ih         LN2 of the last layer + RNN input projection                                           32
+//   rnn        tanh recurrence (:98-99) as a VALU GEMV (M = 1 per stream: MFMA would idle 15/16 rows): 8 (chain) / 16 (role)
+//              workgroups per stream keep W_hh in VGPRs and exchange the 512-float hidden vector through 8-byte {step tag, value}
+//              granules (the data is the flag; no fence, no counter)
+//   head       output projection (:102)                                                               9
 //
-// LayerNorm is never a kernel of its own: producers store the pre-norm sum, every consumer re-normalises the
-// rows it stages (40 x 256, ~1 us) and the first workgroup publishes (mean, rstd) per row for the kernels that
-// only need the normalised residual of their own 16 columns.
+// Two forms of the SAME stage bodies (`template <bool FLOW>`: same arithmetic, same summation orders, same bits):
+//   * one launch (lat_flow_kernel, round 6, B <= 24): every stage is a ROLE of one launch, all workgroups of a window on the window's
+//     XCD, stage-to-stage hand-off through that XCD's L2 (0.86 us per hop; a kernel boundary costs 2.6-3.4 us on this part and a
+//     hand-off across XCDs 2.6-2.9: tools/probes/l2_probe.hip, dataflow_probe.hip) — see the comment above lat_flow_kernel;
+//   * a chain of 20 launches over the whole device (24 < B <= 64, CU-masked streams, fault bit 3).
+//
+// LayerNorm is never a stage of its own: producers store the pre-norm sum, every consumer re-normalises the rows it stages
+// (40 x 256, ~1 us) and the first workgroup publishes (mean, rstd) per row for the stages that only need the normalised residual
+// of their own 16 columns.
 // Weights: the fused plan's fragment-ordered image (tip_fused.hip) — nothing is packed twice.
 #include "tip_internal.h"
 #include "tip_attention.h"
