@@ -94,8 +94,8 @@ def test_c_abi_exports_every_declared_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", tlib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
     assert exported == declared | dbg, exported ^ (declared | dbg)
-    assert tlib.load().tip_abi_version() == tlib.TIP_ABI_VERSION == 4
-    assert int(re.search(r"#define TIP_ABI_VERSION (\d+)", hdr).group(1)) == 4
+    assert tlib.load().tip_abi_version() == tlib.TIP_ABI_VERSION == 5
+    assert int(re.search(r"#define TIP_ABI_VERSION (\d+)", hdr).group(1)) == 5
 
 
 def test_max_batch_and_pack_options_without_a_gpu():

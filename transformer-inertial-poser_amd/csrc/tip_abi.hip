@@ -672,9 +672,51 @@ int tip_spin_timeouts(unsigned* count) {
     return TIP_OK;
 }
 
+// The ring of tip_forward_reuse, when the forward below is that entry point's (null: tip_forward)
+struct ReuseCtx {
+    float* cache;
+    const int* frame_ctr;
+    int frame_idx;
+};
+static int forward_impl(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
+                        const float* keep_mask, float keep_scale, void* workspace, size_t workspace_bytes,
+                        tip_stream_t stream, const ReuseCtx* reuse);
+
 int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
                 const float* keep_mask, float keep_scale, void* workspace, size_t workspace_bytes,
                 tip_stream_t stream) {
+    return forward_impl(h, x_imu, x_s, y, B, T, flags, keep_mask, keep_scale, workspace, workspace_bytes, stream, nullptr);
+}
+
+int tip_reuse_cache_bytes(const tip_handle* h, int n_streams, size_t* bytes) {
+    if (!h || !bytes || n_streams < 0) return TIP_ERR_INVALID_ARG;
+    if (!fused2_supported(h->d, 40)) return TIP_ERR_UNSUPPORTED_CONFIG;
+    *bytes = reuse_cache_floats(n_streams) * sizeof(float);
+    return TIP_OK;
+}
+
+int tip_reuse_reset(void* cache, size_t cache_bytes, tip_stream_t stream) {
+    if (!cache || cache_bytes < reuse_cache_floats(0) * sizeof(float)) return TIP_ERR_INVALID_ARG;
+    // every slot's tag <- INT_MIN: no frame index a caller may pass (>= 0) makes a window's 40 tags match
+    return hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cache), (int)0x80000000, reuse_cache_floats(0), static_cast<hipStream_t>(stream)) == hipSuccess
+               ? TIP_OK
+               : TIP_ERR_HIP;
+}
+
+int tip_forward_reuse(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags, void* cache,
+                      size_t cache_bytes, int frame_idx, const int* frame_ctr, void* workspace, size_t workspace_bytes,
+                      tip_stream_t stream) {
+    if (!h || !cache || B < 0 || T < 1 || (flags & TIP_FWD_KEEP_MASK) || (!frame_ctr && frame_idx < 0)) return TIP_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(cache) % 256 || cache_bytes < reuse_cache_floats(B) * sizeof(float)) return TIP_ERR_WORKSPACE;
+    if (!fused2_supported(h->d, 40) || T > 40) return TIP_ERR_UNSUPPORTED_CONFIG;
+    if (T == 40 && !frame_ctr && frame_idx < 39) return TIP_ERR_INVALID_ARG;   // a full window has 39 earlier frames
+    const ReuseCtx rc{static_cast<float*>(cache), frame_ctr, frame_idx};
+    return forward_impl(h, x_imu, x_s, y, B, T, flags, nullptr, 1.f, workspace, workspace_bytes, stream, &rc);
+}
+
+static int forward_impl(tip_handle* h, const float* x_imu, const float* x_s, float* y, int B, int T, int flags,
+                        const float* keep_mask, float keep_scale, void* workspace, size_t workspace_bytes,
+                        tip_stream_t stream, const ReuseCtx* reuse) {
     if (!h || !x_imu || !x_s || !y || B < 0 || T < 1) return TIP_ERR_INVALID_ARG;
     // (cfg.t_max is a sizing hint, not a limit: the reference builds its causal mask for any window length, :56-58,85; what
     // bounds B * T here are the 32-bit byte offsets of the buffer descriptors)
@@ -700,7 +742,9 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
     // 163 / 177 / 201 / 282 / 372 us for 1 / 8 / 16 / 32 / 44 windows behind it); TIP_AUTO_SPLIT=0 disables (measurement).
     // (the cost model below is calibrated at T = 40 — the only window length the window-split plans serve — and its constants scale
     // with the CU count only through `cus`, which is the device's: other window lengths take whole rounds)
-    if (h->plan == TIP_PLAN_AUTO && !h->demoted && cus == h->num_cus && B > cus && T == 40 && fused_supported(d, T) && fused_has_rnn_ih(d)) {
+    // (tip_forward_reuse, full windows: ONE launch sequence on the two-window encoder's reuse form, whatever the batch)
+    const bool reuse_full = reuse && T == 40;
+    if (!reuse_full && h->plan == TIP_PLAN_AUTO && !h->demoted && cus == h->num_cus && B > cus && T == 40 && fused_supported(d, T) && fused_has_rnn_ih(d)) {
         static const bool split_on = !(tip_env("TIP_AUTO_SPLIT") && tip_env("TIP_AUTO_SPLIT")[0] == '0');
         const int r = B % cus, bm = B - r;
         // what the remainder costs on its own (us; AUTO's choice for that many windows, below): the latency plan up to 32 windows
@@ -821,7 +865,13 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         if (e != hipSuccess) return fail_hip(h, e, what); \
     } while (0)
 
-    int plan = h->plan;
+    if (reuse) {
+        // the newest row of every window -> slot (frame mod 40) of its stream's ring; while the windows still grow (T < 40) that is all
+        // the reuse form does, and the forward below is tip_forward's
+        StageScope sc(h, s, "reuse_update");
+        TIP_TRY(launch_reuse_update(d, P + L.fused_off, x_imu, x_s, reuse->cache, reuse->frame_ctr, reuse->frame_idx, B, T, s), "reuse_update");
+    }
+    int plan = reuse_full ? TIP_PLAN_FUSED2 : h->plan;
     if (plan == TIP_PLAN_AUTO) {
         // (a demoted handle — TIP_OPT_DEMOTED, after a lost hand-off — takes no cooperating kernel: the latency plan's GEMV recurrence is one)
         // few streams: the latency plan up to 32 windows (0.17-0.28 ms), then ONE window on FOUR CUs up to #CUs / 4 windows (0.30 ms
@@ -833,7 +883,7 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         else if (!h->demoted && latency_supported(d, B, T)) plan = TIP_PLAN_LATENCY;   // <= 64 streams: spread each window over many CUs
         else plan = fused_supported(d, T) ? TIP_PLAN_FUSED : TIP_PLAN_GENERAL;
     }
-    if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO) {
+    if (plan == TIP_PLAN_FUSED && h->plan == TIP_PLAN_AUTO && !reuse_full) {
         // One window per workgroup with the hybrid row tiling (no hand-offs, 0.527 ms per round of #CUs windows at T = 40), or
         // two windows per workgroup (80 rows = 5 full MFMA row blocks, 1.049 ms per round of 2 x #CUs windows; only the RATIO of
         // the two matters, and #CUs is the stream's effective count): whichever
@@ -885,7 +935,8 @@ int tip_forward(tip_handle* h, const float* x_imu, const float* x_s, float* y, i
         ih_done = true;
         hall_armed = arm_hall();
         TIP_TRY(launch_fused_encoder2(d, P + L.fused_off, x_imu, x_s, mask, keep_scale, big, hall_armed ? hall : nullptr, B,
-                                      cus, s), "fused_encoder2");
+                                      cus, s, reuse_full ? reuse->cache : nullptr, reuse_full ? reuse->frame_ctr : nullptr,
+                                      reuse_full ? reuse->frame_idx : 0), "fused_encoder2");
     } else if (plan == TIP_PLAN_FUSEDH) {
         StageScope sc(h, s, "fused_encoder");
         ih_done = fused_has_rnn_ih(d);

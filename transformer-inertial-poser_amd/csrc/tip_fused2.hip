@@ -94,11 +94,58 @@ __device__ __forceinline__ int prow(int r) { return r + (r >= f2::T ? 8 : 0); }
 __device__ unsigned long long g_f2_trace[64];
 #define F2_STAMP(slot) do { if (TRACE && blockIdx.x == 0 && tid == 0 && pair == (int)blockIdx.x && layer == 1) g_f2_trace[slot] = __builtin_amdgcn_s_memtime(); } while (0)
 
-template <bool TRACE>
+// REUSE (exact streaming reuse; tip_forward_reuse): a frame's model inputs never change once recorded
+// (real_time_runner_minimal.py:74,85,137: the history buffers are append-only), and its in_linear row and layer-0 Q / K / V rows are
+// functions of that one input row alone — the same numbers in each of the 40 windows the frame appears in.  With the encoder's
+// dropout and the past-state dropout off they are computed ONCE, when the frame enters (reuse_update_kernel below: the same MFMA
+// instruction, packed fragments, k order and bias add as this kernel, so the same bits — every row of this kernel goes through
+// v_mfma_f32_16x16x4_f32, whose per-element sum does not depend on the element's position in the tile), and kept per stream in a
+// ring of 40 slots [x 256 | q 256 | k 256 | v 256].  This instantiation then runs layer 0 without prologue, in_linear and QKV
+// projection: the residual rows and the quads' Q / K / V^T planes come from the ring.  Slot of window row p at frame c: (c + 1 + p)
+// mod 40.  Each slot carries the frame index it was written for (the ring's header); a window whose 40 tags are not c - 39 .. c —
+// a skipped frame, a ring that was never primed — gets NaN rows, never another frame's numbers.
+struct ReuseArgs {
+    const float* cache = nullptr;    // ring header (64 floats: 40 frame tags) + [B][40][1024]
+    const int* frame_ctr = nullptr;  // device counter holding c (what a captured HIP graph needs), or null: frame_idx
+    int frame_idx = 0;
+};
+namespace ru {
+constexpr int SLOT = 1024, HDR = 64, TILE = 16, THREADS = 256, PARTS = 4;
+}
+
+// L2 warm-up for the ring reads ("touch": one dword per 128-byte line, the value is never used): the ring is 4 KiB per stream and
+// frame, read once per call — every read is an HBM / Infinity-Cache miss of ~2 us in front of the LDS stores that need it.  Touching
+// the NEXT quad's lines in front of the current quad's attention moves that latency under the attention; the real 16-byte reads then
+// hit this XCD's L2.  ring: buffer over the pair's rings; slot of row r as in the kernel.
+__device__ __forceinline__ unsigned ring_touch_planes(__amdgpu_buffer_rsrc_t ring, int ru_base, int q, int tid) {
+    const int i = tid < f2::ROWS * 6 ? tid : f2::ROWS * 6 - 1;      // 80 rows x (q | k | v) x two lines of the quad's 64 channels
+    const int r = i / 6, seg = i - r * 6;
+    const int w = r >= f2::T ? 1 : 0;
+    int sl = ru_base + r - w * f2::T;
+    sl -= sl >= f2::T ? f2::T : 0;
+    return __builtin_amdgcn_raw_buffer_load_b32(ring, ((w * f2::T + sl) * ru::SLOT + f2::D + (seg >> 1) * f2::D + q * 64 + (seg & 1) * 32) * 4, 0, 0);
+}
+__device__ __forceinline__ unsigned ring_touch_rows(__amdgpu_buffer_rsrc_t ring, int ru_base, int tid) {   // the in_linear rows: 80 x 8 lines
+    unsigned acc = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int i = tid + j * f2::THREADS;
+        i = i < f2::ROWS * 8 ? i : f2::ROWS * 8 - 1;
+        const int r = i >> 3, seg = i & 7;
+        const int w = r >= f2::T ? 1 : 0;
+        int sl = ru_base + r - w * f2::T;
+        sl -= sl >= f2::T ? f2::T : 0;
+        acc |= __builtin_amdgcn_raw_buffer_load_b32(ring, ((w * f2::T + sl) * ru::SLOT + seg * 32) * 4, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ void touch_sink(unsigned v) { asm volatile("" ::"v"(v)); }   // (the wait for a touch sits HERE, long after it)
+
+template <bool TRACE, bool REUSE = false>
 __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
     const float* __restrict__ wts, const float* __restrict__ x_imu, const float* __restrict__ x_s,
     const float* __restrict__ keep_mask, float keep_scale, float* __restrict__ ih_out, unsigned* __restrict__ hall_sentinel,
-    int B, int NI, int S, int L, int wbytes, int ih_off_b) {
+    int B, int NI, int S, int L, int wbytes, int ih_off_b, ReuseArgs rua) {
     using namespace f2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;
@@ -121,9 +168,53 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
     for (int i = tid; i < C_FLOATS; i += THREADS) C[i] = 0.f;   // pad rows of the planes must never hold NaN patterns
     __syncthreads();
 
+    // REUSE: the frame index c, the slot of window row 0 and whether the ring holds frames c - 39 .. c (wave-uniform, once per launch)
+    int ru_base = 0;
+    bool ru_ok = true;
+    if (REUSE) {
+        const int c = __builtin_amdgcn_readfirstlane(rua.frame_ctr ? *rua.frame_ctr : rua.frame_idx);
+        ru_base = (c % T + T + 1) % T;
+        const int p = lane < T ? lane : 0;
+        int sl = ru_base + p;
+        sl -= sl >= T ? T : 0;
+        const bool good = c >= T - 1 && reinterpret_cast<const int*>(rua.cache)[sl] == c - (T - 1) + p;
+        ru_ok = __builtin_amdgcn_ballot_w64(!good) == 0ull;
+    }
+
     for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
         const int win0 = pair * 2;
         const int nwin = (win0 + 1 < B) ? 2 : 1;
+        WRing2<1> g_q;   // Q|K projection ring of the next quad
+        if (REUSE) {
+            // ---- residual stream of layer 0: the 80 in_linear rows from the ring (10 x 16 bytes per thread, all requested before the
+            //      first is stored; an absent second window reads as zeros, an unprimed ring as NaN) --------------------------------
+            // (a buffer over the pair's one or two rings: an absent second window is out of range and reads as zeros)
+            const __amdgpu_buffer_rsrc_t ring = __builtin_amdgcn_make_buffer_rsrc(
+                uniform_ptr(const_cast<float*>(rua.cache) + ru::HDR + (size_t)win0 * T * ru::SLOT), 0,
+                __builtin_amdgcn_readfirstlane(nwin * T * ru::SLOT * 4), 0x00020000);
+            // (an OPAQUE copy of the thread index, as in the prologue below: with the plain one every row / slot / address split of these
+            // loops is hoisted out of the pair loop and carried across the whole kernel — the ten requests then went out one by one
+            // between scratch spills)
+            int to = tid;
+            asm volatile("" : "+v"(to));
+            const unsigned t0 = ring_touch_planes(ring, ru_base, 0, to);   // quad 0's planes: their latency runs beside the rows'
+            f32x4 xv[10];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int i = to + j * THREADS, r = i >> 6, c4 = i & 63;
+                const int w = r >= T ? 1 : 0;
+                int sl = ru_base + r - w * T;
+                sl -= sl >= T ? T : 0;
+                xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring, ((w * T + sl) * ru::SLOT + c4 * 4) * 4, 0, 0));
+                if (!ru_ok) xv[j] = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+            }
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int i = to + j * THREADS, r = i >> 6, c4 = i & 63;
+                *reinterpret_cast<f32x4*>(X + r * LDX + c4 * 4) = xv[j];
+            }
+            touch_sink(t0);
+        } else {
         const int in_soff = (int)(IN_W * 4) + (wave * 2) * (KIN / 16) * 1024;
         WRing2<2> g_in;
         ring2_prefetch<2>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
@@ -180,7 +271,6 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
         }
         __syncthreads();
         // ---- in_linear (:79) + channel shuffle (folded) -----------------------------------------------------------------
-        WRing2<1> g_q;   // Q|K projection ring of the next quad
         {
             f32x4 acc[RB][2];
             zero_acc2<RB, 2>(acc);
@@ -200,6 +290,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                     for (int e = 0; e < 4; ++e) X[(r * 16 + lg * 4 + e) * LDX + col] = acc[r][n][e] + bv;
             }
         }
+        }   // !REUSE
         __syncthreads();
 
 #pragma unroll 1
@@ -210,10 +301,51 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
             zero_acc2<RB, 2>(acc_o);
             WRing2<2> g_o, g_f2r;
             WRing2<1> g_v, g_f1;
+            unsigned ru_touch = 0;
 #pragma unroll 1
             for (int q = 0; q < 4; ++q) {
                 const int hl = wave & 3;              // head inside the quad
                 const int head = q * 4 + hl;
+                if (REUSE && layer == 0) {
+                    // ---- layer 0 of the reuse form: the quad's Q / K planes and V^T from the ring.  Per plane 80 rows x 16 float4
+                    //      (channels 64 q .. 64 q + 63), nine requests per thread in flight before the first LDS store ------------
+                    const __amdgpu_buffer_rsrc_t ring = __builtin_amdgcn_make_buffer_rsrc(
+                        uniform_ptr(const_cast<float*>(rua.cache) + ru::HDR + (size_t)win0 * T * ru::SLOT), 0,
+                        __builtin_amdgcn_readfirstlane(nwin * T * ru::SLOT * 4), 0x00020000);
+                    int to = tid;
+                    asm volatile("" : "+v"(to));
+                    f32x4 pv[3][3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        int i = to + j * THREADS;
+                        i = i < ROWS * 16 ? i : ROWS * 16 - 1;
+                        const int r = i >> 4, c4 = i & 15;
+                        const int w = r >= T ? 1 : 0;
+                        int sl = ru_base + r - w * T;
+                        sl -= sl >= T ? T : 0;
+                        const int off = ((w * T + sl) * ru::SLOT + D + q * 64 + c4 * 4) * 4;
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            pv[pl][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring, off, pl * D * 4, 0));
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int i = to + j * THREADS;
+                        if (i < ROWS * 16) {
+                            const int r = i >> 4, c4 = i & 15, pr = prow(r);
+                            *reinterpret_cast<f32x4*>(Qp + pr * LDQ + c4 * 4) = pv[0][j];
+                            *reinterpret_cast<f32x4*>(Kp + pr * LDQ + c4 * 4) = pv[1][j];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) Vt[(c4 * 4 + e) * LDV + pr] = pv[2][j][e];
+                        }
+                    }
+                    for (int i = to; i < 64 * 16; i += THREADS) {
+                        const int ch = i >> 4, k = i & 15;
+                        Vt[ch * LDV + (k < 8 ? T + k : 48 + T + (k - 8))] = 0.f;
+                    }
+                    ring2_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + q * 4) * 1024, 16 * 1024);
+                    if (q < 3) ru_touch = ring_touch_planes(ring, ru_base, q + 1, to);   // sunk behind this quad's attention
+                } else
                 // ---- Q | K projection: one 16-column block per wave, all 5 row blocks -------------------------------
                 {
                     const int isk = wave >> 2;        // 0: Q, 1: K
@@ -274,6 +406,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                         attention_head_mfma<LDQ, LDV>(Qp + w * 48 * LDQ, Kp + w * 48 * LDQ, Vt + w * 48, hl * 16, lane, T);
                 }
                 F2_STAMP(3 + 5 * q);
+                if (REUSE) touch_sink(ru_touch);
                 __syncthreads();
                 F2_STAMP(4 + 5 * q);
                 // next Q|K ring (next quad of this layer) goes out before the out-projection MFMAs
@@ -379,6 +512,17 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
             const int isoff = ih_off_b + (wave * 4) * 16 * 1024;
             WRing2<4> g_ih;
             ring2_prefetch<4>(g_ih, rsrc, voff, isoff, 16 * 1024);
+            unsigned tn = 0;
+            if (REUSE && pair + (int)gridDim.x < npairs) {
+                // the workgroup's NEXT pair: its in_linear rows and quad 0's planes on their way into L2 under this projection
+                const int nw0 = (pair + (int)gridDim.x) * 2, nn = (nw0 + 1 < B) ? 2 : 1;
+                const __amdgpu_buffer_rsrc_t nring = __builtin_amdgcn_make_buffer_rsrc(
+                    uniform_ptr(const_cast<float*>(rua.cache) + ru::HDR + (size_t)nw0 * T * ru::SLOT), 0,
+                    __builtin_amdgcn_readfirstlane(nn * T * ru::SLOT * 4), 0x00020000);
+                int to = tid;
+                asm volatile("" : "+v"(to));
+                tn = ring_touch_rows(nring, ru_base, to) | ring_touch_planes(nring, ru_base, 0, to);
+            }
             int ax[RB];
             rows_off(ax, 0, LDX);
             // Swapped operands: transposed accumulators, lane (l15, lg) = row 16 r + l15, columns 16 n + 4 lg ..: ONE 16-byte store per
@@ -387,6 +531,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
             // the four bias vectors requested before the first store (a load cannot be hoisted over a store that may alias).
             // Was 80 guarded 4-byte stores per lane, each behind its own 64-bit address computation, and a bias round trip per block.
             gemm_phase2<RB, 4, 16, true>(acc, smem, ax, rsrc, voff, isoff, 16 * 1024, g_ih, isoff, 16 * 1024);
+            if (REUSE) touch_sink(tn);
             const int nrows = nwin * T;                  // the two windows are consecutive: rows 0..79 map 1:1
             const __amdgpu_buffer_rsrc_t io_rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(ih_out + (size_t)win0 * T * R), 0,
                                                                                     __builtin_amdgcn_readfirstlane(nrows * R * 4), 0x00020000);
@@ -831,13 +976,139 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2s_kernel(
 
 bool fused2_supported(const Dims& d, int T) { return fused_supported(d, T) && fused_has_rnn_ih(d) && T == f2::T; }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The ring's writer: the NEWEST row (window row T - 1) of every stream -> its in_linear row and layer-0 Q | K | V row, into slot
+// c mod 40 of the stream's ring; the tag of that slot <- c.  16 streams form one 16-row MFMA block; four 256-thread workgroups
+// share a tile — each computes the tile's in_linear rows (the QKV projection's A operand, 224 x 256) and a quarter of the 768 QKV
+// columns — so that 1024 streams are 256 workgroups of ~6 us.  Arithmetic per output element exactly as fused_encoder2_kernel's
+// (and reuse's contract with it): gemm_phase2 -> mfma_block2 in the plain orientation over the same packed fragments, k-blocks in
+// ascending order from a zero accumulator, `+ bias` last; the prologue's NaN scrub (:65) on the way in.  No keep mask, no dropout:
+// tip_forward_reuse refuses them.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ru::THREADS) void reuse_update_kernel(const float* __restrict__ wts, const float* __restrict__ x_imu,
+                                                                  const float* __restrict__ x_s, float* __restrict__ cache,
+                                                                  const int* __restrict__ frame_ctr, int frame_idx, int B, int T, int NI,
+                                                                  int S, int wbytes) {
+    using namespace f2;
+    __shared__ __attribute__((aligned(16))) float sm[ru::TILE * LDU + ru::TILE * LDX + 64];
+    float* U = sm;
+    float* Xs = sm + ru::TILE * LDU;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int tile = blockIdx.x / ru::PARTS, part = blockIdx.x % ru::PARTS;
+    const int s0 = tile * ru::TILE;
+    const int c = __builtin_amdgcn_readfirstlane(frame_ctr ? *frame_ctr : frame_idx);
+    const int slot = (c % f2::T + f2::T) % f2::T;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, wbytes, 0x00020000);
+    const int voff = lane * 16;
+    const int in_soff = (int)(IN_W * 4) + (wave * 4) * (KIN / 16) * 1024;
+    WRing2<4> g_in;
+    ring2_prefetch<4>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
+    // L2 warm-up: this kernel is the first of a frame to read W_in and layer 0's W_qkv (1 MB that the previous frame's encoder pushed out
+    // of every L2), and with one wave per SIMD a miss in front of a k-block is fully exposed.  One dword per 128-byte line of the wave's
+    // 56 + 48 KiB of fragments goes out NOW — the whole image arrives at memory bandwidth while the input rows are staged.
+    const int nb0 = part * (48 / ru::PARTS) + wave * 3;                // this wave's three of the 48 QKV column blocks
+    const int q_soff = (int)(LAYER0 * 4) + (int)(QKV_W * 4) + nb0 * 16 * 1024;
+    unsigned warm = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) warm |= __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 128, in_soff + j * 8192, 0);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) warm |= __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 128, q_soff + j * 8192, 0);
+    // (the biases of both epilogues are requested here too: a load behind a GEMM phase is a round trip with the matrix pipe idle)
+    float b_in[4], b_qkv[3];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) b_in[n] = wts[IN_B + (wave * 4 + n) * 16 + l15];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) b_qkv[n] = wts[LAYER0 + QKV_B + (nb0 + n) * 16 + l15];
+    for (int i = tid; i < (ru::TILE * LDU + ru::TILE * LDX + 64) / 4; i += ru::THREADS) reinterpret_cast<float4*>(sm)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    {
+        float vi[4][2], vs[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int st = s0 + wave + 4 * j < B ? s0 + wave + 4 * j : B - 1;
+            const float* xi = x_imu + ((size_t)st * T + (T - 1)) * NI;
+            const float* xs = x_s + ((size_t)st * T + (T - 1)) * S;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) vi[j][q] = xi[lane + 64 * q < NI ? lane + 64 * q : NI - 1];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) vs[j][q] = xs[lane + 64 * q < S ? lane + 64 * q : S - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* pu = U + (wave + 4 * j) * LDU + lane;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (lane + 64 * q < NI) pu[64 * q] = vi[j][q];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (lane + 64 * q < S) {
+                    float v = vs[j][q];
+                    if (v != v) v = 0.f;                               // :65
+                    pu[NI + 64 * q] = v;
+                }
+        }
+    }
+    __syncthreads();
+    float* slot_rows = cache + ru::HDR + (size_t)slot * ru::SLOT;      // + stream * 40 * SLOT
+    {
+        f32x4 acc[1][4];
+        zero_acc2<1, 4>(acc);
+        const int au[1] = {l15 * LDU + lg * 4};
+        gemm_phase2<1, 4, KIN / 16>(acc, sm, au, rsrc, voff, in_soff, (KIN / 16) * 1024, g_in, in_soff, (KIN / 16) * 1024);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int col = (wave * 4 + n) * 16 + l15;
+            const float bv = b_in[n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc[0][n][e] + bv;
+                Xs[(lg * 4 + e) * LDX + col] = v;
+                if (part == 0 && s0 + lg * 4 + e < B) slot_rows[(size_t)(s0 + lg * 4 + e) * f2::T * ru::SLOT + col] = v;
+            }
+        }
+    }
+    WRing2<3> g_qkv;
+    ring2_prefetch<3>(g_qkv, rsrc, voff, q_soff, 16 * 1024);
+    __syncthreads();
+    {
+        f32x4 acc[1][3];
+        zero_acc2<1, 3>(acc);
+        const int ax[1] = {ru::TILE * LDU + l15 * LDX + lg * 4};
+        gemm_phase2<1, 3, 16>(acc, sm, ax, rsrc, voff, q_soff, 16 * 1024, g_qkv, q_soff, 16 * 1024);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            const int col = (nb0 + n) * 16 + l15;                      // 0 .. 767: q | k | v, the slot's floats 256 ..
+            const float bv = b_qkv[n];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (s0 + lg * 4 + e < B) slot_rows[(size_t)(s0 + lg * 4 + e) * f2::T * ru::SLOT + D + col] = acc[0][n][e] + bv;
+        }
+    }
+    touch_sink(warm);
+    if (blockIdx.x == 0 && tid == 0) reinterpret_cast<int*>(cache)[slot] = c;
+}
+
+size_t reuse_cache_floats(int B) { return ru::HDR + (size_t)B * f2::T * ru::SLOT; }
+
+hipError_t launch_reuse_update(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s, float* cache, const int* frame_ctr,
+                               int frame_idx, int B, int T, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    const int tiles = (B + ru::TILE - 1) / ru::TILE;
+    hipLaunchKernelGGL(reuse_update_kernel, dim3(tiles * ru::PARTS), dim3(ru::THREADS), 0, s, fused_w, x_imu, x_s, cache, frame_ctr, frame_idx,
+                       B, T, d.n_imu_total, d.S, (int)(fused_packed_floats(d) * 4));
+    return hipGetLastError();
+}
+
 hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, int B,
-                                 int num_cus, hipStream_t s) {
+                                 int num_cus, hipStream_t s, const float* reuse_cache, const int* frame_ctr, int frame_idx) {
     if (B <= 0) return hipSuccess;
     static PerDeviceFlag attr_flag; bool& attr_set = attr_flag.cur();
     if (!attr_set) {
-        for (const void* f : {reinterpret_cast<const void*>(fused_encoder2_kernel<false>), reinterpret_cast<const void*>(fused_encoder2_kernel<true>)}) {
+        for (const void* f : {reinterpret_cast<const void*>(fused_encoder2_kernel<false>), reinterpret_cast<const void*>(fused_encoder2_kernel<true>),
+                              reinterpret_cast<const void*>(fused_encoder2_kernel<false, true>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, f2::LDS_BYTES);
             if (e != hipSuccess) return e;
         }
@@ -848,14 +1119,20 @@ hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const floa
     const int npairs = (B + 1) / 2;
     const int grid = npairs < num_cus ? npairs : num_cus;
     const size_t ih_off = f2::LAYER0 + (size_t)d.L * f2::LAYER_FLOATS;
-    if (trace)
+    ReuseArgs rua;
+    rua.cache = reuse_cache; rua.frame_ctr = frame_ctr; rua.frame_idx = frame_idx;
+    if (reuse_cache)
+        hipLaunchKernelGGL((fused_encoder2_kernel<false, true>), dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
+                           keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, d.n_imu_total, d.S, d.L,
+                           (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4), rua);
+    else if (trace)
         hipLaunchKernelGGL(fused_encoder2_kernel<true>, dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
                            keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, d.n_imu_total, d.S, d.L,
-                           (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4));
+                           (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4), rua);
     else
         hipLaunchKernelGGL(fused_encoder2_kernel<false>, dim3(grid), dim3(f2::THREADS), f2::LDS_BYTES, s, fused_w, x_imu, x_s, keep_mask,
                            keep_scale, ih_out, reinterpret_cast<unsigned*>(hall_sentinel), B, d.n_imu_total, d.S, d.L,
-                           (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4));
+                           (int)(fused_packed_floats(d) * 4), (int)(ih_off * 4), rua);
     return hipGetLastError();
 }
 

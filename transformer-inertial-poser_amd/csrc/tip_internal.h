@@ -466,9 +466,18 @@ hipError_t read_spin_timeouts_fused2(unsigned* out);
 bool fused2_supported(const Dims& d, int T);
 // partial-sum exchange images of the window-split forms below (sized for the larger of the two)
 size_t fused2s_xchg_floats(int B);
+// reuse_cache != null: the exact-streaming-reuse form (tip_forward_reuse) — layer 0 takes its in_linear rows and
+// Q / K / V rows from the per-stream ring that launch_reuse_update maintains instead of computing them (x_imu / x_s are not read);
+// the frame index comes from *frame_ctr (device) when given, else from frame_idx
 hipError_t launch_fused_encoder2(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s,
                                  const float* keep_mask, float keep_scale, float* ih_out, float* hall_sentinel, int B,
-                                 int num_cus, hipStream_t s);
+                                 int num_cus, hipStream_t s, const float* reuse_cache = nullptr, const int* frame_ctr = nullptr,
+                                 int frame_idx = 0);
+// ring of the reuse form: 64 floats of header (one frame tag per slot) + [B][40 slots][x 256 | q 256 | k 256 | v 256]
+size_t reuse_cache_floats(int B);
+// row T - 1 of every window -> slot (frame mod 40) of its stream's ring, tag <- frame
+hipError_t launch_reuse_update(const Dims& d, const float* fused_w, const float* x_imu, const float* x_s, float* cache, const int* frame_ctr,
+                               int frame_idx, int B, int T, hipStream_t s);
 // window-split form: ONE window on two co-resident workgroups (columns split, 48 rows each), for 2 B <= #CUs, B <= 128
 bool fused1s_fits(int B, int num_cus);
 // ... or on FOUR (round 4: quads of heads, quarters of the hidden units and of the RNN input projection), for 4 B <= #CUs, B <= 64

@@ -405,6 +405,12 @@ int tip_stream_reset(void* state, const float* s_init, int n_streams, tip_stream
     return hipGetLastError() == hipSuccess ? TIP_OK : TIP_ERR_HIP;
 }
 
+int tip_stream_frame_counter_offset(size_t* bytes) {   // where stream 0's block keeps the index of the last ingested frame (an int)
+    if (!bytes) return TIP_ERR_INVALID_ARG;
+    *bytes = (size_t)sz::CTR * sizeof(float);
+    return TIP_OK;
+}
+
 int tip_stream_window_len(int frame_idx) {   // T of the model call issued for frame `frame_idx`; 0 while priming
     if (frame_idx < 5) return 0;
     const int t = frame_idx - 4;

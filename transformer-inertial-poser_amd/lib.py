@@ -24,7 +24,7 @@ TIP_SAVED_QKV, TIP_SAVED_ATT, TIP_SAVED_X1, TIP_SAVED_HID, TIP_SAVED_XOUT, TIP_S
 TIP_STREAM_FRAME_AUTO = -1   # tip_stream_ingest / tip_stream_consume: continue from the counter in the state buffer (HIP graphs)
 TIP_OPT_PLAN, TIP_OPT_PROFILE, TIP_OPT_RNN_CLUSTER, TIP_OPT_FAULT_INJECT, TIP_OPT_FUSE_HEAD = 1, 2, 3, 4, 5
 TIP_OPT_AUTO_DEMOTE, TIP_OPT_DEMOTED, TIP_OPT_F1S_PARTS = 7, 8, 9   # 6: retired
-TIP_ABI_VERSION = 4
+TIP_ABI_VERSION = 5
 TIP_RNN_CLUSTER_ROWS4 = 0x44   # TIP_OPT_RNN_CLUSTER value: 4-window tiles on 4-workgroup clusters (AUTO's choice for rnn_hidden 512)
 TIP_ERR_HANDOFF = -8
 TIP_ERR_UNSUPPORTED_CONFIG = -2
@@ -36,6 +36,7 @@ EXPORTS = (
     "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
     "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_max_batch", "tip_forward", "tip_forward_dropout", "tip_draw_keep_mask", "tip_forward_f64_bytes", "tip_forward_f64", "tip_forward_count", "tip_profile_read",
     "tip_spin_timeouts", "tip_check", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
+    "tip_reuse_cache_bytes", "tip_reuse_reset", "tip_forward_reuse", "tip_stream_frame_counter_offset",
     "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward", "tip_train_input_grads",
     "tip_train_bytes_f64", "tip_train_forward_f64", "tip_train_backward_f64",
     "tip_combine_frames", "tip_combine_scratch_bytes", "tip_combine_sequence", "tip_gather_windows",
@@ -142,6 +143,10 @@ def load() -> ctypes.CDLL:
     lib.tip_stream_window_len.argtypes = [i32]
     lib.tip_stream_ingest.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.tip_stream_consume.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    lib.tip_reuse_cache_bytes.argtypes = [vp, i32, ctypes.POINTER(sz)]
+    lib.tip_reuse_reset.argtypes = [vp, sz, vp]
+    lib.tip_forward_reuse.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, sz, i32, vp, vp, sz, vp]
+    lib.tip_stream_frame_counter_offset.argtypes = [ctypes.POINTER(sz)]
     u64 = ctypes.c_ulonglong
     f32 = ctypes.c_float
     lib.tip_train_bytes.argtypes = [vp, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
@@ -244,6 +249,18 @@ class Handle:
                 keep_scale: float, workspace: int, workspace_bytes: int, stream: int):
         self._check(self.lib.tip_forward(self._h, x_imu, x_s, y, B, T, flags, keep_mask, keep_scale, workspace,
                                          workspace_bytes, stream))
+
+    def reuse_cache_bytes(self, n_streams: int) -> int:
+        n = ctypes.c_size_t()
+        self._check(self.lib.tip_reuse_cache_bytes(self._h, n_streams, ctypes.byref(n)))
+        return n.value
+
+    def forward_reuse(self, x_imu: int, x_s: int, y: int, B: int, T: int, flags: int, cache: int, cache_bytes: int, frame_idx: int,
+                      frame_ctr: Optional[int], workspace: int, workspace_bytes: int, stream: int):
+        """tip_forward_reuse: exact streaming reuse — the newest row's in_linear / layer-0 QKV rows into the ring,
+        full windows on the two-window encoder's ring-reading form."""
+        self._check(self.lib.tip_forward_reuse(self._h, x_imu, x_s, y, B, T, flags, cache, cache_bytes, frame_idx, frame_ctr,
+                                               workspace, workspace_bytes, stream))
 
     def train_input_grads(self, param_ptrs, x_s: int, keep_mask: Optional[int], keep_scale: float, scratch: int, scratch_bytes: int,
                           dx_imu: Optional[int], dx_s: Optional[int], B: int, T: int, stream: int):

@@ -195,6 +195,57 @@ class TF_RNN_Past_State(nn.Module):
             return self._forward_hip(x_imu, x_s, True, workspace=workspace, out=out)
         return self._dispatch(x_imu, x_s, last_row_only=True)
 
+    def reuse_cache(self, n_streams: int) -> torch.Tensor:
+        """A cleared ring for forward_last_reuse: 40 slots x 4 KiB per stream (in_linear row + layer-0 q | k | v row of each of the
+        last 40 frames) behind a 256-byte header of frame tags."""
+        h = self._ensure_handle()
+        dev = self.in_linear.weight.device
+        cache = torch.empty(h.reuse_cache_bytes(int(n_streams)), dtype=torch.uint8, device=dev)
+        self.reuse_reset(cache)
+        return cache
+
+    def reuse_reset(self, cache: torch.Tensor):
+        """Forget every frame in the ring (the streams restart, or the parameters changed: the rows in it belong to the old weights)."""
+        st = _lib.load().tip_reuse_reset(cache.data_ptr(), cache.numel(), torch.cuda.current_stream(cache.device).cuda_stream)
+        if st < 0:
+            raise _lib.TipStatusError(st, _lib.load().tip_strerror(st).decode())
+
+    def forward_last_reuse(self, x_imu, x_s, cache: torch.Tensor, frame_idx: int, *, frame_ctr_ptr=None, workspace=None, out=None):
+        """forward_last for lock-stepped streams whose windows slide by one frame per call, with SURVEY.md 7-7's exact reuse
+        (include/tip_hip.h: tip_forward_reuse): a frame's in_linear row and layer-0 Q / K / V rows are computed once, when the frame
+        enters, and read from `cache` (reuse_cache(B)) in the 39 later windows it appears in.  frame_idx: consecutive across calls
+        (rows 0 .. T-2 of this call's windows must be rows 1 .. T-1 of the previous call's); frame_ctr_ptr: device address of an int
+        that holds it instead (HIP graphs).  Valid only where those rows are a function of the frame alone: .eval(), past_state_dropout
+        = 0, in_dropout = 0 — anything else raises.  Bit-identical to forward_last under set_plan("fused2") (AUTO's choice at 1024
+        streams)."""
+        if self.training or torch.is_grad_enabled() or self.past_state_dropout > 0.0 or self.in_dropout > 0.0:
+            raise RuntimeError("tip_amd: forward_last_reuse caches per-frame rows across windows, which is exact only without the "
+                               "stochastic parts: .eval() under torch.no_grad(), past_state_dropout = 0, in_dropout = 0 "
+                               "(the reference's fresh nn.Dropout at :77 is live even in .eval())")
+        if not (x_imu.is_cuda and x_s.is_cuda) or x_imu.dtype != torch.float32 or x_s.dtype != torch.float32:
+            raise RuntimeError("tip_amd: forward_last_reuse serves fp32 windows on the GPU")
+        dev = x_imu.device
+        B, T = int(x_imu.shape[0]), int(x_imu.shape[1])
+        h = self._ensure_handle()
+        with (torch.cuda.device(dev) if torch.cuda.current_device() != dev.index else _NO_CTX):
+            if self._packed_dev is None or self._packed_dev.device != dev or (not self._frozen and self._packed_key != self._param_key(dev)):
+                stale = self._packed_dev is not None and self._packed_dev.device == dev
+                self.refresh_packed(dev)
+                if stale:
+                    self.reuse_reset(cache)
+                    raise RuntimeError("tip_amd: the parameters changed while the reuse ring held rows computed with the old ones — "
+                                       "the ring was cleared; re-prime it with 40 consecutive frames (StreamingEngine.reset())")
+            x_imu_c, x_s_c = x_imu.contiguous(), x_s.contiguous()
+            y = out if out is not None else torch.empty((B, self.size_s), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            need = self._ws_bytes_cache.get((B, T))
+            if need is None:
+                need = self._ws_bytes_cache[(B, T)] = h.workspace_bytes(B, T)
+            ws = workspace if workspace is not None else self._stream_buffer(self._workspace, dev, stream, need)
+            h.forward_reuse(x_imu_c.data_ptr(), x_s_c.data_ptr(), y.data_ptr(), B, T, _lib.TIP_FWD_LAST_ROW_ONLY, cache.data_ptr(),
+                            cache.numel(), int(frame_idx), frame_ctr_ptr, ws.data_ptr(), ws.numel(), stream)
+        return y
+
     def chunk_batch(self, T: int, fp64: bool = False) -> int:
         """Windows per launch sequence when a batch exceeds what one tip_forward call serves (tip_max_batch): the library's
         limit, rounded down to whole rounds of 256 windows when it is that large (full waves of one-window workgroups)."""

@@ -36,9 +36,10 @@ from . import lib as _lib
 
 
 class StreamingEngine:
-    def __init__(self, model, s_init: torch.Tensor, use_graph: bool = False):
+    def __init__(self, model, s_init: torch.Tensor, use_graph: bool = False, reuse: bool = False):
         self.model = model
         self.use_graph = bool(use_graph)
+        self.reuse = bool(reuse)
         self._graph = None
         self.lib = _lib.load()
         s_init = torch.as_tensor(s_init, dtype=torch.float32)
@@ -65,6 +66,18 @@ class StreamingEngine:
         self.raw = torch.empty((self.n, 72), dtype=torch.float32, device=self.device)    # static input of the captured graph
         self._graph_ws = None
         self._graph_y = None
+        self._ring = None
+        self._ctr_ptr = None
+        if self.reuse:
+            # a frame's in_linear row and layer-0 Q / K / V rows are kept across the 40 windows it appears in
+            # (model.forward_last_reuse; exact only with the stochastic parts off — it raises otherwise)
+            if model.training or model.past_state_dropout > 0.0 or model.in_dropout > 0.0:
+                raise RuntimeError("tip_amd.StreamingEngine(reuse=True) needs model.eval() and a model built with past_state_dropout = 0, "
+                                   "in_dropout = 0: with dropout live a frame's rows differ from window to window")
+            self._ring = model.reuse_cache(self.n)
+            off = ctypes.c_size_t()
+            self._check(self.lib.tip_stream_frame_counter_offset(ctypes.byref(off)))
+            self._ctr_ptr = self.state.data_ptr() + off.value      # the frame index the ingest kernel keeps (stream 0's block)
         self.reset()
 
     def _check(self, status: int):
@@ -79,6 +92,8 @@ class StreamingEngine:
         self._graph = None
         self._graph_refs = None      # (workspace, packed weight image, y_last): what the captured kernels point at
         self._y_last = None
+        if self._ring is not None:
+            self.model.reuse_reset(self._ring)
         with torch.cuda.device(self.device):
             self._check(self.lib.tip_stream_reset(self.state.data_ptr(), self.s_init.data_ptr(), self.n, self._stream()))
 
@@ -100,7 +115,11 @@ class StreamingEngine:
         st = self._stream()
         self._check(self.lib.tip_stream_ingest(self.state.data_ptr(), self.raw.data_ptr(), self.n, _lib.TIP_STREAM_FRAME_AUTO,
                                                self.x_imu.data_ptr(), self.x_s.data_ptr(), st))
-        y_last = self.model.forward_last(self.x_imu, self.x_s, workspace=self._graph_ws, out=self._graph_y)
+        if self.reuse:
+            y_last = self.model.forward_last_reuse(self.x_imu, self.x_s, self._ring, 0, frame_ctr_ptr=self._ctr_ptr,
+                                                   workspace=self._graph_ws, out=self._graph_y)
+        else:
+            y_last = self.model.forward_last(self.x_imu, self.x_s, workspace=self._graph_ws, out=self._graph_y)
         self._check(self.lib.tip_stream_consume(self.state.data_ptr(), y_last.data_ptr(), self.n, _lib.TIP_STREAM_FRAME_AUTO,
                                                 self.s_rest.data_ptr(), self.c_t.data_ptr(), st))
         return y_last
@@ -119,7 +138,7 @@ class StreamingEngine:
                     # packs / attaches outside the capture.  The device RNG is put back afterwards: with past_state_dropout or
                     # in_dropout live this warm-up would otherwise draw once more than the launch-by-launch loop does
                     rng = torch.cuda.get_rng_state(self.device)
-                    self.model.forward_last(self.x_imu, self.x_s, workspace=self._graph_ws, out=self._graph_y)
+                    self.model.forward_last(self.x_imu, self.x_s, workspace=self._graph_ws, out=self._graph_y)   # (never touches the ring)
                     torch.cuda.set_rng_state(rng, self.device)
                     torch.cuda.current_stream(self.device).synchronize()
                     self._poll_handoff()
@@ -146,7 +165,7 @@ class StreamingEngine:
             x_imu = self.x_imu.view(-1)[: self.n * T * 90].view(self.n, T, 90)
             x_s = self.x_s.view(-1)[: self.n * T * 131].view(self.n, T, 131)
             demotions = self.model.demotions
-            y_last = self.model.forward_last(x_imu, x_s)
+            y_last = self.model.forward_last_reuse(x_imu, x_s, self._ring, f) if self.reuse else self.model.forward_last(x_imu, x_s)
             if self.model.demotions != demotions:
                 # tip_forward's entry check found that an EARLIER frame lost a hand-off: the model demoted itself and served this
                 # call, but that frame's NaN row already went into the history ring (the prologue would scrub it to 0 for the
