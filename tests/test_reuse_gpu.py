@@ -196,3 +196,20 @@ def test_reuse_is_refused_where_it_would_not_be_exact():
         m3.in_linear.weight.mul_(1.5)
         with pytest.raises(RuntimeError, match="parameters changed"):
             m3.forward_last_reuse(xi[:, :2], xs[:, :2], ring, 1)
+
+
+def test_reuse_auto_engages_only_where_it_pays_and_is_exact():
+    """reuse="auto": on where the two-window encoder is AUTO's plan anyway (>= two windows per CU) and the model has no stochastic
+    part; off (silently: it is an optimisation, not a request) everywhere else."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    m = _model()
+    z = lambda n: np.zeros((n, 114), np.float32)   # noqa: E731
+    assert tip_amd.streaming.StreamingEngine(m, z(4 * cus), reuse="auto").reuse is True
+    assert tip_amd.streaming.StreamingEngine(m, z(2 * cus), reuse="auto").reuse is True
+    assert tip_amd.streaming.StreamingEngine(m, z(3 * cus), reuse="auto").reuse is False    # three rounds of the one-window kernel win
+    assert tip_amd.streaming.StreamingEngine(m, z(cus), reuse="auto").reuse is False
+    assert tip_amd.streaming.StreamingEngine(m, z(3), reuse="auto").reuse is False
+    cfg = synth.PAPER
+    mp = make_model(cfg, p_state=0.8)
+    load_synth(mp, cfg, 0)
+    assert tip_amd.streaming.StreamingEngine(mp.cuda().eval(), z(4 * cus), reuse="auto").reuse is False

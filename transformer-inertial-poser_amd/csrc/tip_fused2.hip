@@ -125,20 +125,6 @@ __device__ __forceinline__ unsigned ring_touch_planes(__amdgpu_buffer_rsrc_t rin
     sl -= sl >= f2::T ? f2::T : 0;
     return __builtin_amdgcn_raw_buffer_load_b32(ring, ((w * f2::T + sl) * ru::SLOT + f2::D + (seg >> 1) * f2::D + q * 64 + (seg & 1) * 32) * 4, 0, 0);
 }
-__device__ __forceinline__ unsigned ring_touch_rows(__amdgpu_buffer_rsrc_t ring, int ru_base, int tid) {   // the in_linear rows: 80 x 8 lines
-    unsigned acc = 0;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        int i = tid + j * f2::THREADS;
-        i = i < f2::ROWS * 8 ? i : f2::ROWS * 8 - 1;
-        const int r = i >> 3, seg = i & 7;
-        const int w = r >= f2::T ? 1 : 0;
-        int sl = ru_base + r - w * f2::T;
-        sl -= sl >= f2::T ? f2::T : 0;
-        acc |= __builtin_amdgcn_raw_buffer_load_b32(ring, ((w * f2::T + sl) * ru::SLOT + seg * 32) * 4, 0, 0);
-    }
-    return acc;
-}
 __device__ __forceinline__ void touch_sink(unsigned v) { asm volatile("" ::"v"(v)); }   // (the wait for a touch sits HERE, long after it)
 
 template <bool TRACE, bool REUSE = false>
@@ -186,34 +172,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
         const int nwin = (win0 + 1 < B) ? 2 : 1;
         WRing2<1> g_q;   // Q|K projection ring of the next quad
         if (REUSE) {
-            // ---- residual stream of layer 0: the 80 in_linear rows from the ring (10 x 16 bytes per thread, all requested before the
-            //      first is stored; an absent second window reads as zeros, an unprimed ring as NaN) --------------------------------
-            // (a buffer over the pair's one or two rings: an absent second window is out of range and reads as zeros)
-            const __amdgpu_buffer_rsrc_t ring = __builtin_amdgcn_make_buffer_rsrc(
-                uniform_ptr(const_cast<float*>(rua.cache) + ru::HDR + (size_t)win0 * T * ru::SLOT), 0,
-                __builtin_amdgcn_readfirstlane(nwin * T * ru::SLOT * 4), 0x00020000);
-            // (an OPAQUE copy of the thread index, as in the prologue below: with the plain one every row / slot / address split of these
-            // loops is hoisted out of the pair loop and carried across the whole kernel — the ten requests then went out one by one
-            // between scratch spills)
-            int to = tid;
-            asm volatile("" : "+v"(to));
-            const unsigned t0 = ring_touch_planes(ring, ru_base, 0, to);   // quad 0's planes: their latency runs beside the rows'
-            f32x4 xv[10];
-#pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                const int i = to + j * THREADS, r = i >> 6, c4 = i & 63;
-                const int w = r >= T ? 1 : 0;
-                int sl = ru_base + r - w * T;
-                sl -= sl >= T ? T : 0;
-                xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring, ((w * T + sl) * ru::SLOT + c4 * 4) * 4, 0, 0));
-                if (!ru_ok) xv[j] = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-            }
-#pragma unroll
-            for (int j = 0; j < 10; ++j) {
-                const int i = to + j * THREADS, r = i >> 6, c4 = i & 63;
-                *reinterpret_cast<f32x4*>(X + r * LDX + c4 * 4) = xv[j];
-            }
-            touch_sink(t0);
+            // (layer 0 of the reuse form brings its own rows in: the residual stream arrives under the last quad's attention, below)
         } else {
         const int in_soff = (int)(IN_W * 4) + (wave * 2) * (KIN / 16) * 1024;
         WRing2<2> g_in;
@@ -301,20 +260,21 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
             zero_acc2<RB, 2>(acc_o);
             WRing2<2> g_o, g_f2r;
             WRing2<1> g_v, g_f1;
-            unsigned ru_touch = 0;
-#pragma unroll 1
-            for (int q = 0; q < 4; ++q) {
-                const int hl = wave & 3;              // head inside the quad
-                const int head = q * 4 + hl;
-                if (REUSE && layer == 0) {
-                    // ---- layer 0 of the reuse form: the quad's Q / K planes and V^T from the ring.  Per plane 80 rows x 16 float4
-                    //      (channels 64 q .. 64 q + 63), nine requests per thread in flight before the first LDS store ------------
-                    const __amdgpu_buffer_rsrc_t ring = __builtin_amdgcn_make_buffer_rsrc(
-                        uniform_ptr(const_cast<float*>(rua.cache) + ru::HDR + (size_t)win0 * T * ru::SLOT), 0,
-                        __builtin_amdgcn_readfirstlane(nwin * T * ru::SLOT * 4), 0x00020000);
-                    int to = tid;
-                    asm volatile("" : "+v"(to));
-                    f32x4 pv[3][3];
+            if (REUSE && layer == 0) {
+                // ---- layer 0 of the reuse form.  No projection: a quad's Q / K planes and V^T (80 rows x 64 channels each) come from the
+                //      ring, and with no GEMM in front of them their read latency would sit in front of every quad's attention.  The
+                //      residual stream is not needed before this block's end, so the X region serves as a SECOND set of planes: quads
+                //      0 / 2 live there, quads 1 / 3 in C; the requests of quad q + 1 (nine 16-byte loads per thread) go out in front of
+                //      attention(q) and are stored behind it; the 80 in_linear rows themselves take that slot of quad 3 and land in X
+                //      when quad 2 is done with it.  Barriers as in the projection form: one behind the attention, one behind the
+                //      out-projection (whose O operand the next stores would overwrite). ---------------------------------------------
+                const __amdgpu_buffer_rsrc_t ring = __builtin_amdgcn_make_buffer_rsrc(
+                    uniform_ptr(const_cast<float*>(rua.cache) + ru::HDR + (size_t)win0 * T * ru::SLOT), 0,
+                    __builtin_amdgcn_readfirstlane(nwin * T * ru::SLOT * 4), 0x00020000);
+                int to = tid;     // (opaque: keeps the row / slot / address splits below out of the pair loop's live registers)
+                asm volatile("" : "+v"(to));
+                f32x4 rv[10];
+                auto request_planes = [&](int q) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         int i = to + j * THREADS;
@@ -326,26 +286,89 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                         const int off = ((w * T + sl) * ru::SLOT + D + q * 64 + c4 * 4) * 4;
 #pragma unroll
                         for (int pl = 0; pl < 3; ++pl)
-                            pv[pl][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring, off, pl * D * 4, 0));
+                            rv[pl * 3 + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring, off, pl * D * 4, 0));
                     }
+                };
+                auto store_planes = [&](float* base, bool pads) {
+                    float* Qb = base;
+                    float* Kb = base + PROWS * LDQ;
+                    float* Vb = base + 2 * PROWS * LDQ;
 #pragma unroll
                     for (int j = 0; j < 3; ++j) {
                         const int i = to + j * THREADS;
                         if (i < ROWS * 16) {
                             const int r = i >> 4, c4 = i & 15, pr = prow(r);
-                            *reinterpret_cast<f32x4*>(Qp + pr * LDQ + c4 * 4) = pv[0][j];
-                            *reinterpret_cast<f32x4*>(Kp + pr * LDQ + c4 * 4) = pv[1][j];
+                            *reinterpret_cast<f32x4*>(Qb + pr * LDQ + c4 * 4) = rv[j];
+                            *reinterpret_cast<f32x4*>(Kb + pr * LDQ + c4 * 4) = rv[3 + j];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) Vt[(c4 * 4 + e) * LDV + pr] = pv[2][j][e];
+                            for (int e = 0; e < 4; ++e) Vb[(c4 * 4 + e) * LDV + pr] = rv[6 + j][e];
                         }
                     }
-                    for (int i = to; i < 64 * 16; i += THREADS) {
+                    for (int i = to; i < 64 * 16; i += THREADS) {          // the pad keys of V^T: multiplied by P = 0, must be finite
                         const int ch = i >> 4, k = i & 15;
-                        Vt[ch * LDV + (k < 8 ? T + k : 48 + T + (k - 8))] = 0.f;
+                        Vb[ch * LDV + (k < 8 ? T + k : 48 + T + (k - 8))] = 0.f;
                     }
+                    if (pads)                                              // the X region held anything: pad rows 40-47 / 88-95 of Q and K
+                        for (int i = to; i < 2 * 16 * (LDQ / 4); i += THREADS) {
+                            const int pl = i / (16 * (LDQ / 4)), k = i - pl * (16 * (LDQ / 4));
+                            const int r = k / (LDQ / 4), c4 = k - r * (LDQ / 4);
+                            *reinterpret_cast<f32x4*>(base + pl * PROWS * LDQ + (r < 8 ? T + r : 48 + T + (r - 8)) * LDQ + c4 * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        }
+                };
+                request_planes(0);
+                store_planes(smem, true);
+                __syncthreads();
+#pragma unroll 1
+                for (int q = 0; q < 4; ++q) {
+                    const int hl = wave & 3;
+                    float* cur = (q & 1) ? C : smem;
+                    float* nxt = (q & 1) ? smem : C;
                     ring2_prefetch<2>(g_o, rsrc, voff, lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + q * 4) * 1024, 16 * 1024);
-                    if (q < 3) ru_touch = ring_touch_planes(ring, ru_base, q + 1, to);   // sunk behind this quad's attention
-                } else
+                    if (q < 3) {
+                        request_planes(q + 1);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) {
+                            const int i = to + j * THREADS, r = i >> 6, c4 = i & 63;
+                            const int w = r >= T ? 1 : 0;
+                            int sl = ru_base + r - w * T;
+                            sl -= sl >= T ? T : 0;
+                            rv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ring, ((w * T + sl) * ru::SLOT + c4 * 4) * 4, 0, 0));
+                        }
+                    }
+                    {
+                        const int w = wave >> 2;
+                        if (w < nwin)
+                            attention_head_mfma<LDQ, LDV>(cur + w * 48 * LDQ, cur + PROWS * LDQ + w * 48 * LDQ, cur + 2 * PROWS * LDQ + w * 48, hl * 16, lane, T);
+                    }
+                    if (q < 3) {
+                        store_planes(nxt, (q & 1) != 0);
+                    } else {
+                        // (an unprimed ring — a window whose 40 tags are not frames c - 39 .. c — poisons the residual stream: NaN rows out)
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) {
+                            const int i = to + j * THREADS, r = i >> 6, c4 = i & 63;
+                            if (!ru_ok) rv[j] = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+                            *reinterpret_cast<f32x4*>(X + r * LDX + c4 * 4) = rv[j];
+                        }
+                    }
+                    __syncthreads();
+                    if (q == 3) ring2_prefetch<1>(g_f1, rsrc, voff, lbase + (int)(W1_W * 4) + wave * 16 * 1024, 0);
+                    {
+                        const int osoff = lbase + (int)(WO_W * 4) + ((wave * 2) * 16 + q * 4) * 1024;
+                        const int cb = (int)(cur - smem);
+                        int ao[RB];   // O rows live in the (remapped) Q plane of the quad's buffer
+#pragma unroll
+                        for (int r = 0; r < RB; ++r) ao[r] = cb + prow(r * 16 + l15) * LDQ + lg * 4;
+                        gemm_phase2<RB, 2, 4>(acc_o, smem, ao, rsrc, voff, osoff, 16 * 1024, g_o, osoff, 16 * 1024);
+                    }
+                    __syncthreads();
+                }
+            } else
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {
+                const int hl = wave & 3;              // head inside the quad
+                const int head = q * 4 + hl;
                 // ---- Q | K projection: one 16-column block per wave, all 5 row blocks -------------------------------
                 {
                     const int isk = wave >> 2;        // 0: Q, 1: K
@@ -406,7 +429,6 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
                         attention_head_mfma<LDQ, LDV>(Qp + w * 48 * LDQ, Kp + w * 48 * LDQ, Vt + w * 48, hl * 16, lane, T);
                 }
                 F2_STAMP(3 + 5 * q);
-                if (REUSE) touch_sink(ru_touch);
                 __syncthreads();
                 F2_STAMP(4 + 5 * q);
                 // next Q|K ring (next quad of this layer) goes out before the out-projection MFMAs
@@ -514,14 +536,14 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
             ring2_prefetch<4>(g_ih, rsrc, voff, isoff, 16 * 1024);
             unsigned tn = 0;
             if (REUSE && pair + (int)gridDim.x < npairs) {
-                // the workgroup's NEXT pair: its in_linear rows and quad 0's planes on their way into L2 under this projection
+                // the workgroup's NEXT pair: quad 0's planes on their way into L2 under this projection
                 const int nw0 = (pair + (int)gridDim.x) * 2, nn = (nw0 + 1 < B) ? 2 : 1;
                 const __amdgpu_buffer_rsrc_t nring = __builtin_amdgcn_make_buffer_rsrc(
                     uniform_ptr(const_cast<float*>(rua.cache) + ru::HDR + (size_t)nw0 * T * ru::SLOT), 0,
                     __builtin_amdgcn_readfirstlane(nn * T * ru::SLOT * 4), 0x00020000);
                 int to = tid;
                 asm volatile("" : "+v"(to));
-                tn = ring_touch_rows(nring, ru_base, to) | ring_touch_planes(nring, ru_base, 0, to);
+                tn = ring_touch_planes(nring, ru_base, 0, to);
             }
             int ax[RB];
             rows_off(ax, 0, LDX);
