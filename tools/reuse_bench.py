@@ -31,7 +31,8 @@ def timed(eng, frames, reps=3, n=40):
 
 def main():
     from scipy.spatial.transform import Rotation
-    ns = [int(a) for a in sys.argv[1:]] or [512, 1024, 2048, 8192]
+    frames_only = "--frames-only" in sys.argv      # (tools/stream_kernels_by_n.sh: a short closed loop under rocprofv3, no timing)
+    ns = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [512, 1024, 2048, 8192]
     cfg = synth.PAPER
     m = tip_amd.TF_RNN_Past_State(cfg["input_size_imu"], cfg["size_s"], rnn_hid_size=cfg["rnn_hid_size"], tf_hid_size=cfg["tf_hid_size"],
                                   tf_in_dim=cfg["tf_in_dim"], n_heads=cfg["n_heads"], tf_layers=cfg["tf_layers"], dropout=0.0,
@@ -39,6 +40,16 @@ def main():
     m.load_state_dict({k: torch.tensor(v) for k, v in synth.make_weights(cfg, seed=0).items()})
     m = m.cuda().eval()
     m.freeze_packed(True)
+    if frames_only:
+        for n in ns:
+            rng = np.random.RandomState(n)
+            base = Rotation.random(n * 6, random_state=n).as_matrix().reshape(n, 54).astype(np.float32)
+            fr = torch.tensor(np.concatenate([base, rng.randn(n, 18).astype(np.float32)], axis=1)).cuda()
+            eng = tip_amd.streaming.StreamingEngine(m, (rng.randn(n, 114) * 0.2).astype(np.float32), reuse=n >= 512)
+            for f in range(104):
+                eng.step(fr)
+            torch.cuda.synchronize()
+        return
     for n in ns:
         rng = np.random.RandomState(n)
         base = Rotation.random(n * 6, random_state=n).as_matrix().reshape(n, 54).astype(np.float32)

@@ -113,10 +113,11 @@ namespace ru {
 constexpr int SLOT = 1024, HDR = 64, TILE = 16, THREADS = 256, PARTS = 4;
 }
 
-// L2 warm-up for the ring reads ("touch": one dword per 128-byte line, the value is never used): the ring is 4 KiB per stream and
-// frame, read once per call — every read is an HBM / Infinity-Cache miss of ~2 us in front of the LDS stores that need it.  Touching
-// the NEXT quad's lines in front of the current quad's attention moves that latency under the attention; the real 16-byte reads then
-// hit this XCD's L2.  ring: buffer over the pair's rings; slot of row r as in the kernel.
+// L2 warm-up for ring reads ("touch": one dword per 128-byte line, the value is never used).  The ring is 4 KiB per stream and frame,
+// read once per call: every first read is an HBM / Infinity-Cache miss.  Inside a pair the reuse form hides that by requesting a
+// quad's planes one attention ahead; the FIRST quad of a workgroup's next pair has no attention in front of it, so its lines are
+// touched under the current pair's RNN input projection and the real 16-byte reads then hit this XCD's L2.
+// ring: buffer over the pair's rings; slot of row r as in the kernel.
 __device__ __forceinline__ unsigned ring_touch_planes(__amdgpu_buffer_rsrc_t ring, int ru_base, int q, int tid) {
     const int i = tid < f2::ROWS * 6 ? tid : f2::ROWS * 6 - 1;      // 80 rows x (q | k | v) x two lines of the quad's 64 channels
     const int r = i / 6, seg = i - r * 6;
@@ -171,9 +172,7 @@ __global__ __launch_bounds__(f2::THREADS) void fused_encoder2_kernel(
         const int win0 = pair * 2;
         const int nwin = (win0 + 1 < B) ? 2 : 1;
         WRing2<1> g_q;   // Q|K projection ring of the next quad
-        if (REUSE) {
-            // (layer 0 of the reuse form brings its own rows in: the residual stream arrives under the last quad's attention, below)
-        } else {
+        if (!REUSE) {   // (layer 0 of the reuse form brings its own rows in: the residual stream arrives under its last quad's attention)
         const int in_soff = (int)(IN_W * 4) + (wave * 2) * (KIN / 16) * 1024;
         WRing2<2> g_in;
         ring2_prefetch<2>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
