@@ -28,7 +28,8 @@ extern "C" {
                              3: tip_forward_dropout, tip_draw_keep_mask, tip_train_input_grads; plan 9 (persistent latency kernel) and its 1 KiB of sync words in the packed image
                              removed; TIP_OPT_FUSE_HEAD reserved
                              4: plans 5 / 7 / 8 (pair-split, split-fp16) and TIP_OPT_PACK_SPLIT16 retired (and the split-fp16 trace hook of tip_hip_debug.h with them)
-                             5: exact streaming reuse — tip_reuse_cache_bytes, tip_reuse_reset, tip_forward_reuse, tip_stream_frame_counter_offset */
+                             5: exact streaming reuse — tip_reuse_cache_bytes, tip_reuse_reset, tip_forward_reuse, tip_stream_frame_counter_offset,
+                                tip_stream_ingest_newest */
 
 /* The library is built with -fvisibility=hidden: the functions declared here (and the measurement hooks of
  * tip_hip_debug.h) are its whole dynamic symbol table (tests/test_host_cpu.py compares `nm -D` with the two headers). */
@@ -256,6 +257,11 @@ TIP_API int tip_stream_ingest(void* state, const float* raw_imu, int n_streams, 
                       tip_stream_t stream);
 TIP_API int tip_stream_consume(void* state, const float* y_last, int n_streams, int call_idx, float* s_rest, float* c_t,
                        tip_stream_t stream);
+/* tip_stream_ingest for a frame whose forward is tip_forward_reuse on FULL windows: the state is advanced exactly as by
+ * tip_stream_ingest, but only row T-1 of x_imu / x_s [n,T,*] is written (rows 0 .. T-2 keep whatever they held) — the reuse forward
+ * takes every older row from its ring, and at >= 1024 streams gathering the 35-KB windows is most of the ingest's time. */
+TIP_API int tip_stream_ingest_newest(void* state, const float* raw_imu, int n_streams, int frame_idx, float* x_imu, float* x_s,
+                             tip_stream_t stream);
 
 /* ---- exact streaming reuse: tip_forward for lock-stepped streams whose windows slide by one frame per call.
  *      In the runner a frame's model inputs never change once recorded (real_time_runner_minimal.py:74,85,137: raw_imu_buffer,

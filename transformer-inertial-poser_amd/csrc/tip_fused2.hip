@@ -1006,6 +1006,39 @@ bool fused2_supported(const Dims& d, int T) { return fused_supported(d, T) && fu
 // ascending order from a zero accumulator, `+ bias` last; the prologue's NaN scrub (:65) on the way in.  No keep mask, no dropout:
 // tip_forward_reuse refuses them.
 // ---------------------------------------------------------------------------------------------------------------------
+// acc[0][n] += A[16 x 16 KB] (LDS) * Wblock(n, kb), kb ascending from 0 — gemm_phase2's sums for ONE row block, with a weight ring DEPTH
+// k-blocks deep.  16 NBW MFMAs per k-block (512 / 384 cycles at NBW = 4 / 3) do not cover a first-touch L2 miss (~900 cycles) two
+// k-blocks ahead, and this kernel runs one wave per SIMD on weights the previous frame's encoder pushed out of every L2: measured
+// (s_memtime stamps, 1024 streams) the two GEMMs of the writer at 1.2x their MFMA time only after 416 KB of warm-up loads per
+// workgroup that cost 4.9 us up front.  Fully unrolled: the ring slot of a k-block is a compile-time register set.
+template <int NBW, int DEPTH>
+struct DeepRing {
+    float4 w[DEPTH][NBW];
+};
+template <int NBW, int DEPTH>
+__device__ __forceinline__ void deep_prefetch(DeepRing<NBW, DEPTH>& g, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff, int nstride_b) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int n = 0; n < NBW; ++n) g.w[d][n] = ldfrag2(rsrc, voff, soff + n * nstride_b + d * 1024);
+}
+template <int NBW, int KB, int DEPTH>   // the ring holds k-blocks 0 .. DEPTH-1 on entry (deep_prefetch, called a phase early)
+__device__ __forceinline__ void gemm_rows16_deep(f32x4 (&acc)[1][NBW], const float* As, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff,
+                                                 int nstride_b, DeepRing<NBW, DEPTH>& g) {
+    float4 a[2][1];
+    a[0][0] = *reinterpret_cast<const float4*>(As);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        if (kb + 1 < KB) a[(kb + 1) & 1][0] = *reinterpret_cast<const float4*>(As + (kb + 1) * 16);
+        mfma_block2<1, NBW>(acc, a[kb & 1], g.w[kb % DEPTH]);
+        if (kb + DEPTH < KB) {
+#pragma unroll
+            for (int n = 0; n < NBW; ++n) g.w[kb % DEPTH][n] = ldfrag2(rsrc, voff, soff + n * nstride_b + (kb + DEPTH) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (keeps every refill behind the block that freed its registers, DEPTH k-blocks ahead of its use)
+    }
+}
+
 __global__ __launch_bounds__(ru::THREADS) void reuse_update_kernel(const float* __restrict__ wts, const float* __restrict__ x_imu,
                                                                   const float* __restrict__ x_s, float* __restrict__ cache,
                                                                   const int* __restrict__ frame_ctr, int frame_idx, int B, int T, int NI,
@@ -1024,19 +1057,11 @@ __global__ __launch_bounds__(ru::THREADS) void reuse_update_kernel(const float* 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, wbytes, 0x00020000);
     const int voff = lane * 16;
     const int in_soff = (int)(IN_W * 4) + (wave * 4) * (KIN / 16) * 1024;
-    WRing2<4> g_in;
-    ring2_prefetch<4>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
-    // L2 warm-up: this kernel is the first of a frame to read W_in and layer 0's W_qkv (1 MB that the previous frame's encoder pushed out
-    // of every L2), and with one wave per SIMD a miss in front of a k-block is fully exposed.  One dword per 128-byte line of the wave's
-    // 56 + 48 KiB of fragments goes out NOW — the whole image arrives at memory bandwidth while the input rows are staged.
     const int nb0 = part * (48 / ru::PARTS) + wave * 3;                // this wave's three of the 48 QKV column blocks
     const int q_soff = (int)(LAYER0 * 4) + (int)(QKV_W * 4) + nb0 * 16 * 1024;
-    unsigned warm = 0;
-#pragma unroll
-    for (int j = 0; j < 7; ++j) warm |= __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 128, in_soff + j * 8192, 0);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) warm |= __builtin_amdgcn_raw_buffer_load_b32(rsrc, lane * 128, q_soff + j * 8192, 0);
-    // (the biases of both epilogues are requested here too: a load behind a GEMM phase is a round trip with the matrix pipe idle)
+    DeepRing<4, 4> g_in;
+    deep_prefetch<4, 4>(g_in, rsrc, voff, in_soff, (KIN / 16) * 1024);
+    // (the biases of both epilogues are requested here: a load behind a GEMM phase is a round trip with the matrix pipe idle)
     float b_in[4], b_qkv[3];
 #pragma unroll
     for (int n = 0; n < 4; ++n) b_in[n] = wts[IN_B + (wave * 4 + n) * 16 + l15];
@@ -1077,7 +1102,7 @@ __global__ __launch_bounds__(ru::THREADS) void reuse_update_kernel(const float* 
         f32x4 acc[1][4];
         zero_acc2<1, 4>(acc);
         const int au[1] = {l15 * LDU + lg * 4};
-        gemm_phase2<1, 4, KIN / 16>(acc, sm, au, rsrc, voff, in_soff, (KIN / 16) * 1024, g_in, in_soff, (KIN / 16) * 1024);
+        gemm_rows16_deep<4, KIN / 16, 4>(acc, sm + au[0], rsrc, voff, in_soff, (KIN / 16) * 1024, g_in);
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int col = (wave * 4 + n) * 16 + l15;
@@ -1090,14 +1115,14 @@ __global__ __launch_bounds__(ru::THREADS) void reuse_update_kernel(const float* 
             }
         }
     }
-    WRing2<3> g_qkv;
-    ring2_prefetch<3>(g_qkv, rsrc, voff, q_soff, 16 * 1024);
+    DeepRing<3, 4> g_qkv;   // (in flight across the barrier)
+    deep_prefetch<3, 4>(g_qkv, rsrc, voff, q_soff, 16 * 1024);
     __syncthreads();
     {
         f32x4 acc[1][3];
         zero_acc2<1, 3>(acc);
         const int ax[1] = {ru::TILE * LDU + l15 * LDX + lg * 4};
-        gemm_phase2<1, 3, 16>(acc, sm, ax, rsrc, voff, q_soff, 16 * 1024, g_qkv, q_soff, 16 * 1024);
+        gemm_rows16_deep<3, 16, 4>(acc, sm + ax[0], rsrc, voff, q_soff, 16 * 1024, g_qkv);
 #pragma unroll
         for (int n = 0; n < 3; ++n) {
             const int col = (nb0 + n) * 16 + l15;                      // 0 .. 767: q | k | v, the slot's floats 256 ..
@@ -1107,7 +1132,6 @@ __global__ __launch_bounds__(ru::THREADS) void reuse_update_kernel(const float* 
                 if (s0 + lg * 4 + e < B) slot_rows[(size_t)(s0 + lg * 4 + e) * f2::T * ru::SLOT + D + col] = acc[0][n][e] + bv;
         }
     }
-    touch_sink(warm);
     if (blockIdx.x == 0 && tid == 0) reinterpret_cast<int*>(cache)[slot] = c;
 }
 

@@ -177,8 +177,11 @@ __global__ __launch_bounds__(64) void stream_reset_kernel(float* __restrict__ st
 }
 
 // ---- ingest one raw frame per stream and emit the model inputs -----------------------------------------------
+// newest != 0 (tip_stream_ingest_newest): only row T - 1 of every window is written — what the exact-reuse forward reads
+// (tip_forward_reuse takes every older row from its ring).  At >= 1024 streams the window gather IS this kernel: 35 KB read and 35 KB
+// written per stream, 18 us at 1024 streams and 53 us at 4096 against 8-9 us for the smoothing chain.
 __global__ __launch_bounds__(256) void stream_ingest_kernel(float* __restrict__ state, const float* __restrict__ raw_in, int B,
-                                                            int f, float* __restrict__ x_imu, float* __restrict__ x_s, int T) {
+                                                            int f, float* __restrict__ x_imu, float* __restrict__ x_s, int T, int newest) {
     using namespace sz;
     __shared__ float sm[NIMU], loc[NIMU];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -199,6 +202,10 @@ __global__ __launch_bounds__(256) void stream_ingest_kernel(float* __restrict__ 
         // (compile-time trip counts, every load of a loop requested before its first store: 36 round trips in flight together)
         constexpr int XS_IT = (WIN * NS + 255) / 256, XI_IT = (WIN * NX + 255) / 256;
         float* xs = x_s + (size_t)b * T * NS;
+        float* xi = x_imu + (size_t)b * T * NX;
+        if (newest) {
+            if (tid < NS) xs[(T - 1) * NS + tid] = S[HIST + (k % WIN) * NS + tid];     // history entry k (:144)
+        } else {
         float vs[XS_IT];
 #pragma unroll
         for (int u = 0; u < XS_IT; ++u) {
@@ -206,7 +213,6 @@ __global__ __launch_bounds__(256) void stream_ingest_kernel(float* __restrict__ 
             const int t = ic / NS, c = ic - t * NS, j = k + 1 - T + t;   // history entries k+1-T .. k (:144)
             vs[u] = S[HIST + (j % WIN) * NS + c];
         }
-        float* xi = x_imu + (size_t)b * T * NX;
         float vi[XI_IT];
 #pragma unroll
         for (int u = 0; u < XI_IT; ++u) {
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(256) void stream_ingest_kernel(float* __restrict__ 
 #pragma unroll
         for (int u = 0; u < XI_IT; ++u)
             if (tid + 256 * u < (T - 1) * NX) xi[tid + 256 * u] = vi[u];
+        }
         if (tid < 18) {   // all (up to 39) loads first, then the sum in the reference's order: one round trip, not one per frame
             float av[WIN - 1];
 #pragma unroll
@@ -417,15 +424,25 @@ int tip_stream_window_len(int frame_idx) {   // T of the model call issued for f
     return t < sz::WIN ? t : sz::WIN;
 }
 
-int tip_stream_ingest(void* state, const float* raw_imu, int n_streams, int frame_idx, float* x_imu, float* x_s,
-                      tip_stream_t stream) {
+static int stream_ingest(void* state, const float* raw_imu, int n_streams, int frame_idx, float* x_imu, float* x_s, tip_stream_t stream,
+                         int newest) {
     if (!state || !raw_imu || n_streams < 0 || frame_idx < TIP_STREAM_FRAME_AUTO) return TIP_ERR_INVALID_ARG;
     const int T = frame_idx == TIP_STREAM_FRAME_AUTO ? sz::WIN : tip_stream_window_len(frame_idx);
     if (T > 0 && (!x_imu || !x_s)) return TIP_ERR_INVALID_ARG;
     if (n_streams == 0) return TIP_OK;
     hipLaunchKernelGGL(stream_ingest_kernel, dim3(n_streams), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<float*>(state), raw_imu, n_streams, frame_idx, x_imu, x_s, T);
+                       static_cast<float*>(state), raw_imu, n_streams, frame_idx, x_imu, x_s, T, newest);
     return hipGetLastError() == hipSuccess ? TIP_OK : TIP_ERR_HIP;
+}
+
+int tip_stream_ingest(void* state, const float* raw_imu, int n_streams, int frame_idx, float* x_imu, float* x_s,
+                      tip_stream_t stream) {
+    return stream_ingest(state, raw_imu, n_streams, frame_idx, x_imu, x_s, stream, 0);
+}
+
+int tip_stream_ingest_newest(void* state, const float* raw_imu, int n_streams, int frame_idx, float* x_imu, float* x_s,
+                             tip_stream_t stream) {
+    return stream_ingest(state, raw_imu, n_streams, frame_idx, x_imu, x_s, stream, 1);
 }
 
 int tip_stream_consume(void* state, const float* y_last, int n_streams, int call_idx, float* s_rest, float* c_t,

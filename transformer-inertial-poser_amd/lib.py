@@ -36,7 +36,7 @@ EXPORTS = (
     "tip_get_option", "tip_num_tensors", "tip_tensor_info", "tip_packed_bytes", "tip_pack_weights",
     "tip_pack_weights_device", "tip_attach_packed", "tip_workspace_bytes", "tip_max_batch", "tip_forward", "tip_forward_dropout", "tip_draw_keep_mask", "tip_forward_f64_bytes", "tip_forward_f64", "tip_forward_count", "tip_profile_read",
     "tip_spin_timeouts", "tip_check", "tip_stream_state_bytes", "tip_stream_reset", "tip_stream_window_len", "tip_stream_ingest", "tip_stream_consume",
-    "tip_reuse_cache_bytes", "tip_reuse_reset", "tip_forward_reuse", "tip_stream_frame_counter_offset",
+    "tip_reuse_cache_bytes", "tip_reuse_reset", "tip_forward_reuse", "tip_stream_frame_counter_offset", "tip_stream_ingest_newest",
     "tip_train_bytes", "tip_train_saved_view", "tip_train_forward", "tip_train_backward", "tip_train_input_grads",
     "tip_train_bytes_f64", "tip_train_forward_f64", "tip_train_backward_f64",
     "tip_combine_frames", "tip_combine_scratch_bytes", "tip_combine_sequence", "tip_gather_windows",
@@ -143,6 +143,7 @@ def load() -> ctypes.CDLL:
     lib.tip_stream_window_len.argtypes = [i32]
     lib.tip_stream_ingest.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     lib.tip_stream_consume.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    lib.tip_stream_ingest_newest.argtypes = lib.tip_stream_ingest.argtypes
     lib.tip_reuse_cache_bytes.argtypes = [vp, i32, ctypes.POINTER(sz)]
     lib.tip_reuse_reset.argtypes = [vp, sz, vp]
     lib.tip_forward_reuse.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, sz, i32, vp, vp, sz, vp]

@@ -130,8 +130,10 @@ class StreamingEngine:
     def _frame_auto(self):
         """ingest -> forward_last -> consume with the frame index taken from the state buffer (capturable)."""
         st = self._stream()
-        self._check(self.lib.tip_stream_ingest(self.state.data_ptr(), self.raw.data_ptr(), self.n, _lib.TIP_STREAM_FRAME_AUTO,
-                                               self.x_imu.data_ptr(), self.x_s.data_ptr(), st))
+        # (full windows: the reuse forward reads only the newest row of x_imu / x_s — the 35-KB window gather per stream is skipped)
+        ingest = self.lib.tip_stream_ingest_newest if self.reuse else self.lib.tip_stream_ingest
+        self._check(ingest(self.state.data_ptr(), self.raw.data_ptr(), self.n, _lib.TIP_STREAM_FRAME_AUTO,
+                           self.x_imu.data_ptr(), self.x_s.data_ptr(), st))
         if self.reuse:
             y_last = self.model.forward_last_reuse(self.x_imu, self.x_s, self._ring, 0, frame_ctr_ptr=self._ctr_ptr,
                                                    workspace=self._graph_ws, out=self._graph_y)
@@ -174,8 +176,8 @@ class StreamingEngine:
         T = int(self.lib.tip_stream_window_len(f))
         with torch.cuda.device(self.device):
             # windows are written densely as [n, T, *] at the head of the preallocated buffers
-            self._check(self.lib.tip_stream_ingest(self.state.data_ptr(), raw.data_ptr(), self.n, f, self.x_imu.data_ptr(),
-                                                   self.x_s.data_ptr(), self._stream()))
+            ingest = self.lib.tip_stream_ingest_newest if (self.reuse and T == 40) else self.lib.tip_stream_ingest
+            self._check(ingest(self.state.data_ptr(), raw.data_ptr(), self.n, f, self.x_imu.data_ptr(), self.x_s.data_ptr(), self._stream()))
             self.frame += 1
             if T == 0:
                 return None
