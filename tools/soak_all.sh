@@ -8,4 +8,5 @@ timeout 300 python tools/latency_soak.py 2>/dev/null | tail -8 > $O/latency_soak
 timeout 300 python tools/f1s_soak.py 2>/dev/null | tail -8 > $O/f1s_soak.txt
 timeout 300 python tools/train_soak.py 2>/dev/null | tail -8 > $O/train_soak.txt
 timeout 300 python tools/options_soak.py 1 2000 2>/dev/null | tail -6 > $O/options_soak.txt
+timeout 300 python tools/reuse_soak.py 1500 2>/dev/null | tail -6 > $O/reuse_soak.txt
 for f in $O/*.txt; do echo "== $f"; cat $f; done
