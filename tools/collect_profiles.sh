@@ -109,3 +109,7 @@ timeout 900 python tools/auto_calibrate.py 2> /dev/null > "$OUT/auto_calibrate_s
 timeout 300 python tools/zero_edit_loop.py 600 2> /dev/null | grep -v "^model\|^number" > "$OUT/zero_edit_loop.txt"
 timeout 300 python tools/zero_edit_breakdown.py 400 2> /dev/null | grep -v "^model\|^number" > "$OUT/zero_edit_breakdown.txt"
 for p in l2_probe dataflow_probe; do [ -x tools/probes/$p.out ] && timeout 120 tools/probes/$p.out > "$OUT/$p.txt" 2>&1; done
+# exact streaming reuse: both engines in one run, the front / back end kernels by stream count, the race screen
+timeout 400 python tools/reuse_bench.py 2> /dev/null | grep "^{" > "$OUT/reuse_bench.txt"
+timeout 400 bash tools/stream_kernels_by_n.sh > "$OUT/stream_kernels_by_n.txt" 2> /dev/null
+timeout 300 python tools/reuse_soak.py 1500 2> /dev/null | grep "^{\|^reuse" > "$OUT/reuse_soak.txt"

@@ -56,6 +56,10 @@ timeout 600 python tools/train_bench.py > "$OUT/train_bench_n1.json" 2> /dev/nul
 timeout 600 bash tools/train_profile.sh $ROUND > "$OUT/kernel_avgs_train_B256_T40.txt" 2> /dev/null
 timeout 300 python tools/stream_latency.py 1 400 2> /dev/null | grep "^{" > "$OUT/stream_latency_n1.json"
 timeout 300 python tools/auto_sweep.py 2> /dev/null > "$OUT/auto_sweep.txt"
+# exact streaming reuse: both engines in one run, the front / back end kernels by stream count, the race screen
+timeout 400 python tools/reuse_bench.py 2> /dev/null | grep "^{" > "$OUT/reuse_bench.txt"
+timeout 400 bash tools/stream_kernels_by_n.sh > "$OUT/stream_kernels_by_n.txt" 2> /dev/null
+timeout 300 python tools/reuse_soak.py 1500 2> /dev/null | grep "^{\|^reuse" > "$OUT/reuse_soak.txt"
 ls -la "$OUT"
 
 # round 6: the few-stream plan as one launch (stage stamps, one launch vs launch chain, race screen), AUTO's cost model against this box,
