@@ -10,6 +10,9 @@
  *   gcc -O2 -D__HIP_PLATFORM_AMD__ -I include -I /opt/rocm/include examples/c_host.c -o c_host \
  *       -L transformer-inertial-poser_amd/csrc -ltip_hip -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/transformer-inertial-poser_amd/csrc
  *   ./c_host y.bin [B] [T]         # writes B*T*131 float32, prints a checksum
+ *   ./c_host y.bin B 40 reuse F    # F frames of B lock-stepped streams through tip_forward_reuse (a frame's in_linear
+ *                                  # and layer-0 Q / K / V rows computed once, kept in a ring for the 40 windows it appears in):
+ *                                  # windows grow 1 .. 40, then slide; writes F*B*131 float32 (row T-1 of every call)
  */
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -64,6 +67,52 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipMemcpy(packed_dev, packed_host, packed_bytes, hipMemcpyHostToDevice));
     CHECK_TIP(tip_attach_packed(h, packed_dev, packed_bytes));
 
+    if (argc > 5 && !strcmp(argv[4], "reuse")) {
+        /* ---- sliding windows with exact reuse.  Frame f of stream b has ONE input row (x_imu 90 + x_s 131 values, a hash of (b, f, column));
+         *      call f sees frames max(0, f - 39) .. f.  The ring belongs to the caller, like every other buffer. ---- */
+        const int F = atoi(argv[5]);
+        size_t ring_bytes = 0, ws_bytes = 0;
+        CHECK_TIP(tip_reuse_cache_bytes(h, B, &ring_bytes));
+        CHECK_TIP(tip_workspace_bytes(h, B, 40, &ws_bytes));     /* (sizes grow with T: the full window's serves the growing ones) */
+        void *ring = NULL, *ws = NULL;
+        float *xi_d = NULL, *xs_d = NULL, *y_d = NULL;
+        CHECK_HIP(hipMalloc(&ring, ring_bytes));
+        CHECK_HIP(hipMalloc(&ws, ws_bytes));
+        CHECK_HIP(hipMalloc((void**)&xi_d, (size_t)B * 40 * 90 * sizeof(float)));
+        CHECK_HIP(hipMalloc((void**)&xs_d, (size_t)B * 40 * 131 * sizeof(float)));
+        CHECK_HIP(hipMalloc((void**)&y_d, (size_t)B * 131 * sizeof(float)));
+        float* xi = (float*)malloc((size_t)B * 40 * 90 * sizeof(float));
+        float* xs = (float*)malloc((size_t)B * 40 * 131 * sizeof(float));
+        float* y = (float*)malloc((size_t)B * 131 * sizeof(float));
+        hipStream_t stream;
+        CHECK_HIP(hipStreamCreate(&stream));
+        CHECK_TIP(tip_reuse_reset(ring, ring_bytes, stream));
+        FILE* fo = fopen(out_path, "wb");
+        if (!fo) return 4;
+        double sum = 0.0;
+        for (int f = 0; f < F; ++f) {
+            const int Tf = f + 1 < 40 ? f + 1 : 40, f0 = f + 1 - Tf;
+            for (int b = 0; b < B; ++b)
+                for (int t = 0; t < Tf; ++t) {
+                    for (int c = 0; c < 90; ++c) xi[((size_t)b * Tf + t) * 90 + c] = unit(2000u + (uint32_t)b, (uint32_t)((f0 + t) * 90 + c));
+                    for (int c = 0; c < 131; ++c) xs[((size_t)b * Tf + t) * 131 + c] = 0.5f * unit(3000u + (uint32_t)b, (uint32_t)((f0 + t) * 131 + c));
+                }
+            CHECK_HIP(hipMemcpy(xi_d, xi, (size_t)B * Tf * 90 * sizeof(float), hipMemcpyHostToDevice));
+            CHECK_HIP(hipMemcpy(xs_d, xs, (size_t)B * Tf * 131 * sizeof(float), hipMemcpyHostToDevice));
+            CHECK_TIP(tip_forward_reuse(h, xi_d, xs_d, y_d, B, Tf, TIP_FWD_LAST_ROW_ONLY, ring, ring_bytes, f, NULL, ws, ws_bytes, stream));
+            CHECK_HIP(hipStreamSynchronize(stream));
+            CHECK_HIP(hipMemcpy(y, y_d, (size_t)B * 131 * sizeof(float), hipMemcpyDeviceToHost));
+            if (fwrite(y, sizeof(float), (size_t)B * 131, fo) != (size_t)B * 131) return 4;
+            for (int e = 0; e < B * 131; ++e) sum += (double)y[e];
+        }
+        fclose(fo);
+        CHECK_TIP(tip_check(h, 0));
+        uint64_t nf = 0;
+        CHECK_TIP(tip_forward_count(h, &nf));
+        printf("c_host reuse: B=%d frames=%d sum=%.9g forwards=%llu\n", B, F, sum, (unsigned long long)nf);
+        tip_destroy(h);
+        return 0;
+    }
     /* windows: x_imu [B,T,90] (72 IMU readings + the 18 acc-sum columns), x_s [B,T,131] */
     const size_t ni = (size_t)B * T * 90, ns = (size_t)B * T * 131;
     float* xi = (float*)malloc(ni * sizeof(float));

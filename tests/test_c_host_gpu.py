@@ -79,3 +79,35 @@ def test_c_host_matches_python_host(B, T):
     w = {k: v.numpy() for k, v in sd.items()}
     yo = oracle.forward(cfg, w, x_imu[:2], x_s[:2], dtype=np.float64)
     assert np.abs(yc[:2] - yo).max() < 2e-5
+
+
+def test_c_host_reuse_matches_recomputation():
+    """tip_forward_reuse from plain C: 60 frames of 3 lock-stepped streams (windows growing 1 .. 40, then sliding) — every call's last
+    rows equal what the Python module computes for the same window WITHOUT the ring (two-window encoder for full windows)."""
+    gcc = shutil.which("gcc")
+    B, F = 3, 60
+    with tempfile.TemporaryDirectory() as td:
+        exe, out = os.path.join(td, "c_host"), os.path.join(td, "y.bin")
+        cmd = [gcc, "-O2", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+               os.path.join(ROOT, "examples", "c_host.c"), "-o", exe, "-L", CSRC, "-ltip_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+               "-Wl,-rpath," + CSRC, "-Wl,-rpath,/opt/rocm/lib"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        r = subprocess.run([exe, out, str(B), "40", "reuse", str(F)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+        assert f"forwards={F}" in r.stdout
+        yc = np.fromfile(out, dtype=np.float32).reshape(F, B, 131)
+    m = make_model(synth.PAPER)
+    m.load_state_dict(_weights(m))
+    m = m.cuda().eval()
+    rows_i = np.stack([_unit(2000 + b, F * 90).reshape(F, 90) for b in range(B)])          # [B, F, 90]: one input row per frame
+    rows_s = np.stack([np.float32(0.5) * _unit(3000 + b, F * 131).reshape(F, 131) for b in range(B)])
+    assert np.isfinite(yc).all()
+    with torch.no_grad():
+        for f in range(F):
+            T = min(f + 1, 40)
+            m.set_plan("fused2" if T == 40 else "auto")
+            xi = torch.tensor(rows_i[:, f + 1 - T: f + 1]).cuda()
+            xs = torch.tensor(rows_s[:, f + 1 - T: f + 1]).cuda()
+            yp = m.forward_last(xi, xs).cpu().numpy()
+            assert np.array_equal(yc[f], yp), (f, np.abs(yc[f] - yp).max())
