@@ -138,7 +138,8 @@ def test_plain_bench_command_gpus_8_carries_the_whole_north_star_table():
     assert d["config"]["global_batch"] == 2048 and d["scaling"] == "weak"
     assert d["ranks_output_identical"] is True and d["packed_image_identical_on_all_ranks"] is True
     tab = d["extra"]["scaling_table"]
-    want = {"batch1_per_gpu": (1, 8), "batch256_total": (32, 256), "streams8192_total": (1024, 8192), "scaled_b4096_total": (512, 4096)}
+    want = {"batch1_per_gpu": (1, 8), "batch256_total": (32, 256), "streams8192_total": (1024, 8192),
+            "streams8192_closed_loop_total": (1024, 8192), "scaled_b4096_total": (512, 4096)}
     assert set(tab) == set(want)
     for k, (per, tot) in want.items():
         row = tab[k]
@@ -147,6 +148,7 @@ def test_plain_bench_command_gpus_8_carries_the_whole_north_star_table():
         for f in ("ms_per_step", "frames_per_s", "whole_forward_frac_of_fp32_mfma_peak"):
             assert math.isfinite(row[f]) and row[f] > 0, (k, f, row[f])
     assert tab["scaled_b4096_total"]["weight_broadcast_ms"] > 0 and tab["scaled_b4096_total"]["packed_image_mb"] > 600
+    assert tab["streams8192_closed_loop_total"]["reuse_engaged"] is True and tab["streams8192_closed_loop_total"]["recompute_ms_per_step"] > 0
     assert len(d["host_pinning"]["numa_node_per_rank"]) == 8
     assert d["tail_summary"]["table_8gpu"]["scaled_b4096_total"][0] > 0
     assert wall < 300 and d["wall_s"] < 300, (wall, d["wall_s"])
