@@ -196,6 +196,15 @@ def test_reuse_is_refused_where_it_would_not_be_exact():
         m3.in_linear.weight.mul_(1.5)
         with pytest.raises(RuntimeError, match="parameters changed"):
             m3.forward_last_reuse(xi[:, :2], xs[:, :2], ring, 1)
+        # ... also when somebody else re-packed the image in between (a plain forward after the update): the ring is tied to the
+        # packed image it was filled under, not to this call noticing the change itself
+        m3.forward_last_reuse(xi[:, :1], xs[:, :1], ring, 0)          # (cleared ring, current image: fine)
+        m3.in_linear.weight.mul_(0.5)
+        m3(xi, xs)                                                     # re-packs
+        with pytest.raises(RuntimeError, match="parameters changed"):
+            m3.forward_last_reuse(xi[:, :2], xs[:, :2], ring, 1)
+        with pytest.raises(RuntimeError, match="feature widths"):
+            m3.forward_last_reuse(xi[:, :1, :80], xs[:, :1], ring, 0)
 
 
 def test_reuse_auto_engages_only_where_it_pays_and_is_exact():

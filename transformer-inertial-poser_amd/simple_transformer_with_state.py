@@ -126,6 +126,8 @@ class TF_RNN_Past_State(nn.Module):
         self._handle: Optional[_lib.Handle] = None
         self._packed_dev: Optional[torch.Tensor] = None
         self._packed_key = None
+        self._pack_epoch = 0             # bumped by every attach_packed: a reuse ring is only good for the image it was filled under
+        self._ring_epoch = {}            # ring data_ptr -> _pack_epoch at its last reuse_reset()
         self._workspace = {}             # (device index, stream handle) -> uint8 tensor: calls on different streams never share one
         self._frozen = False
         self._warned_autograd = False
@@ -200,6 +202,8 @@ class TF_RNN_Past_State(nn.Module):
         last 40 frames) behind a 256-byte header of frame tags."""
         h = self._ensure_handle()
         dev = self.in_linear.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("tip_amd: the reuse ring lives in HBM — move the module to the GPU first (.cuda())")
         cache = torch.empty(h.reuse_cache_bytes(int(n_streams)), dtype=torch.uint8, device=dev)
         self.reuse_reset(cache)
         return cache
@@ -209,6 +213,9 @@ class TF_RNN_Past_State(nn.Module):
         st = _lib.load().tip_reuse_reset(cache.data_ptr(), cache.numel(), torch.cuda.current_stream(cache.device).cuda_stream)
         if st < 0:
             raise _lib.TipStatusError(st, _lib.load().tip_strerror(st).decode())
+        if len(self._ring_epoch) > 64:
+            self._ring_epoch.clear()
+        self._ring_epoch[cache.data_ptr()] = None      # filled under whatever image the next forward_last_reuse runs on
 
     def forward_last_reuse(self, x_imu, x_s, cache: torch.Tensor, frame_idx: int, *, frame_ctr_ptr=None, workspace=None, out=None):
         """forward_last for lock-stepped streams whose windows slide by one frame per call, with SURVEY.md 7-7's exact reuse
@@ -225,16 +232,24 @@ class TF_RNN_Past_State(nn.Module):
         if not (x_imu.is_cuda and x_s.is_cuda) or x_imu.dtype != torch.float32 or x_s.dtype != torch.float32:
             raise RuntimeError("tip_amd: forward_last_reuse serves fp32 windows on the GPU")
         dev = x_imu.device
+        if x_imu.dim() != 3 or x_s.dim() != 3 or x_imu.shape[:2] != x_s.shape[:2]:
+            raise RuntimeError("expected x_imu [B,T,n_imu] and x_s [B,T,size_s]")
         B, T = int(x_imu.shape[0]), int(x_imu.shape[1])
+        if x_imu.shape[2] != self.input_size_imu + (18 if self.with_acc_sum else 0) or x_s.shape[2] != self.size_s:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied: got feature widths {x_imu.shape[2]}+{x_s.shape[2]}")
         h = self._ensure_handle()
         with (torch.cuda.device(dev) if torch.cuda.current_device() != dev.index else _NO_CTX):
             if self._packed_dev is None or self._packed_dev.device != dev or (not self._frozen and self._packed_key != self._param_key(dev)):
-                stale = self._packed_dev is not None and self._packed_dev.device == dev
                 self.refresh_packed(dev)
-                if stale:
-                    self.reuse_reset(cache)
-                    raise RuntimeError("tip_amd: the parameters changed while the reuse ring held rows computed with the old ones — "
-                                       "the ring was cleared; re-prime it with 40 consecutive frames (StreamingEngine.reset())")
+            # The ring's rows are functions of the WEIGHTS too: it is good for the packed image it was filled under and no other —
+            # whoever re-packed in between (this call, a plain forward after an optimiser step, attach_packed of a broadcast image)
+            ep = self._ring_epoch.get(cache.data_ptr())
+            if ep is None:
+                self._ring_epoch[cache.data_ptr()] = self._pack_epoch
+            elif ep != self._pack_epoch:
+                self.reuse_reset(cache)
+                raise RuntimeError("tip_amd: the parameters changed while the reuse ring held rows computed with the old ones — "
+                                   "the ring was cleared; re-prime it with 40 consecutive frames (StreamingEngine.reset())")
             x_imu_c, x_s_c = x_imu.contiguous(), x_s.contiguous()
             y = out if out is not None else torch.empty((B, self.size_s), dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -588,6 +603,7 @@ class TF_RNN_Past_State(nn.Module):
         h.attach_packed(packed_dev.data_ptr(), packed_dev.numel())
         self._packed_dev = packed_dev
         self._packed_key = self._param_key(packed_dev.device)
+        self._pack_epoch += 1
 
     def pack_device(self, device=None) -> torch.Tensor:
         """Build the packed weight image ON the GPU from the live parameters (tip_pack_weights_device): same bytes as
