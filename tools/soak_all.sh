@@ -1,5 +1,5 @@
-mkdir -p gpurun_out/r05s
-O=gpurun_out/r05s
+mkdir -p gpurun_out/r06s
+O=gpurun_out/r06s
 timeout 400 python tools/fuzz_parity.py 300 5 2>/dev/null | tail -6 > $O/fuzz_parity.txt
 timeout 300 python tools/fuzz_train.py 200 5 2>/dev/null | tail -6 > $O/fuzz_train.txt
 timeout 300 python tools/fuzz_stream.py 150 5 2>/dev/null | tail -6 > $O/fuzz_stream.txt
