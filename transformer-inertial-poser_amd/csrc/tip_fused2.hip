@@ -1025,17 +1025,30 @@ __device__ __forceinline__ void deep_prefetch(DeepRing<NBW, DEPTH>& g, __amdgpu_
 template <int NBW, int KB, int DEPTH>   // the ring holds k-blocks 0 .. DEPTH-1 on entry (deep_prefetch, called a phase early)
 __device__ __forceinline__ void gemm_rows16_deep(f32x4 (&acc)[1][NBW], const float* As, __amdgpu_buffer_rsrc_t rsrc, int voff, int soff,
                                                  int nstride_b, DeepRing<NBW, DEPTH>& g) {
+    // A ROLLED loop over groups of DEPTH k-blocks (+ a tail of KB % DEPTH): this kernel's code is fetched by all 128 instruction caches of
+    // the chip at the same moment and executed once — fully unrolled (10 KB) the fetch alone was worth more than the MFMAs
+    // (stream_consume_kernel: 2.4 us of rotation math cost 13-25 us the first time through, profiles/r06/stream_glue_probe.txt).
     float4 a[2][1];
     a[0][0] = *reinterpret_cast<const float4*>(As);
+    constexpr int FULL = KB / DEPTH * DEPTH;
+#pragma unroll 1
+    for (int kb0 = 0; kb0 < FULL; kb0 += DEPTH) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        if (kb + 1 < KB) a[(kb + 1) & 1][0] = *reinterpret_cast<const float4*>(As + (kb + 1) * 16);
-        mfma_block2<1, NBW>(acc, a[kb & 1], g.w[kb % DEPTH]);
-        if (kb + DEPTH < KB) {
+        for (int d = 0; d < DEPTH; ++d) {
+            const int kb = kb0 + d;
+            const int ka = kb + 1 < KB ? kb + 1 : KB - 1, kw = kb + DEPTH < KB ? kb + DEPTH : KB - 1;   // (past the end: harmless reloads)
+            a[(d + 1) & 1][0] = *reinterpret_cast<const float4*>(As + ka * 16);
+            mfma_block2<1, NBW>(acc, a[d & 1], g.w[d]);
 #pragma unroll
-            for (int n = 0; n < NBW; ++n) g.w[kb % DEPTH][n] = ldfrag2(rsrc, voff, soff + n * nstride_b + (kb + DEPTH) * 1024);
+            for (int n = 0; n < NBW; ++n) g.w[d][n] = ldfrag2(rsrc, voff, soff + n * nstride_b + kw * 1024);
+            __builtin_amdgcn_sched_barrier(0);   // (keeps every refill behind the block that freed its registers, DEPTH k-blocks ahead of its use)
         }
-        __builtin_amdgcn_sched_barrier(0);   // (keeps every refill behind the block that freed its registers, DEPTH k-blocks ahead of its use)
+    }
+    static_assert(DEPTH % 2 == 0, "the A double buffer's parity restarts with every group");
+#pragma unroll
+    for (int d = 0; d < KB - FULL; ++d) {
+        if (FULL + d + 1 < KB) a[(d + 1) & 1][0] = *reinterpret_cast<const float4*>(As + (FULL + d + 1) * 16);
+        mfma_block2<1, NBW>(acc, a[d & 1], g.w[d]);
     }
 }
 
