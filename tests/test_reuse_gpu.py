@@ -222,3 +222,26 @@ def test_reuse_auto_engages_only_where_it_pays_and_is_exact():
     mp = make_model(cfg, p_state=0.8)
     load_synth(mp, cfg, 0)
     assert tip_amd.streaming.StreamingEngine(mp.cuda().eval(), z(4 * cus), reuse="auto").reuse is False
+
+
+def test_reuse_on_a_demoted_handle_and_with_an_explicit_rnn_cluster():
+    """The reuse form only replaces the encoder: whatever the handle says about the recurrence (TIP_OPT_DEMOTED after a lost hand-off:
+    single-workgroup tiles; an explicit cluster size) applies to both engines alike, and they stay bit-identical."""
+    m = _model()
+    raw, s_init = _raw_frames(40, 60, 21)
+    h = m._ensure_handle()
+    for setup in ("demoted", "cluster2"):
+        if setup == "demoted":
+            h.set_option(tlib.TIP_OPT_DEMOTED, 1)
+        ref = tip_amd.streaming.StreamingEngine(m, s_init)
+        eng = tip_amd.streaming.StreamingEngine(m, s_init, reuse=True)
+        lib = tlib.load()
+        for f in range(raw.shape[0]):
+            full = lib.tip_stream_window_len(f) == 40
+            m.set_plan("fused2" if full else "auto", rnn_cluster=2 if setup == "cluster2" else 0)
+            a, b = ref.step(raw[f]), eng.step(raw[f])
+            if a is not None:
+                assert torch.equal(a["y_last"], b["y_last"]) and torch.equal(a["s_rest"], b["s_rest"]), (setup, f)
+        h.set_option(tlib.TIP_OPT_DEMOTED, 0)
+        m.set_plan("auto")
+    m.check_handoffs()
