@@ -164,6 +164,40 @@ def test_launch_by_launch_streaming_engine_raises_and_reprimes_after_a_lost_fram
 
 
 @pytest.mark.handoff_fault
+def test_reuse_streaming_engine_raises_demotes_and_reprimes_after_a_lost_frame():
+    """StreamingEngine(reuse=True): the encoder's reuse form has no hand-off, the clustered recurrence behind it has.  A lost frame's NaN
+    row is in the history ring AND in the reuse ring: the next step demotes the handle, clears both (reset()) and raises; the stream
+    then runs on — single-workgroup recurrence tiles — finite, with the fault still injected."""
+    m, _ = _model()
+    h = m._ensure_handle()
+    n = 40
+    rng = np.random.RandomState(6)
+    eng = streaming.StreamingEngine(m, torch.zeros(n, 114), reuse=True)
+
+    def frame():
+        R = np.tile(np.eye(3).reshape(-1), (n, 6)).astype(np.float32)
+        return torch.tensor(np.concatenate([R, rng.randn(n, 18).astype(np.float32)], axis=1)).cuda()
+
+    for _ in range(50):
+        out = eng.step(frame())
+    torch.cuda.synchronize()
+    assert out["T"] == 40 and bool(torch.isfinite(out["y_last"]).all()) and not m.is_demoted()
+    h.set_option(tlib.TIP_OPT_FAULT_INJECT, 2)                # clustered recurrence: this frame is lost
+    out = eng.step(frame())
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(out["y_last"]).any())
+    with pytest.raises(tlib.TipHandoffError):
+        eng.step(frame())
+    assert eng.frame == 0 and m.is_demoted() and m.demotions == 1
+    for _ in range(60):
+        out = eng.step(frame())
+    torch.cuda.synchronize()
+    assert out is not None and out["T"] == 40 and bool(torch.isfinite(out["y_last"]).all())
+    m.check_handoffs()
+    h.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)
+
+
+@pytest.mark.handoff_fault
 def test_train_mode_runner_call_demotes_after_a_lost_handoff():
     """the unedited runner's call (.train() mode, B = 1: tip_forward_dropout on the cooperating latency kernels) had no
     demote flow — after a lost hand-off every following frame raised.  Now as in _forward_hip: the first TipHandoffError clears the

@@ -184,7 +184,21 @@ class StreamingEngine:
             x_imu = self.x_imu.view(-1)[: self.n * T * 90].view(self.n, T, 90)
             x_s = self.x_s.view(-1)[: self.n * T * 131].view(self.n, T, 131)
             demotions = self.model.demotions
-            y_last = self.model.forward_last_reuse(x_imu, x_s, self._ring, f) if self.reuse else self.model.forward_last(x_imu, x_s)
+            if self.reuse:
+                try:
+                    y_last = self.model.forward_last_reuse(x_imu, x_s, self._ring, f)
+                except _lib.TipHandoffError:
+                    # an EARLIER frame lost an inter-workgroup hand-off (its NaN row is in the history ring and in the reuse ring): same
+                    # contract as the other paths — demote the handle to the plans without hand-offs when allowed, re-prime, raise
+                    h = self.model._ensure_handle()
+                    h.check_clear()
+                    if h.get_option(_lib.TIP_OPT_AUTO_DEMOTE) and not h.get_option(_lib.TIP_OPT_DEMOTED):
+                        h.set_option(_lib.TIP_OPT_DEMOTED, 1)
+                        self.model.demotions += 1
+                    self.reset()
+                    raise
+            else:
+                y_last = self.model.forward_last(x_imu, x_s)
             if self.model.demotions != demotions:
                 # tip_forward's entry check found that an EARLIER frame lost a hand-off: the model demoted itself and served this
                 # call, but that frame's NaN row already went into the history ring (the prologue would scrub it to 0 for the
