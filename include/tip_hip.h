@@ -112,7 +112,9 @@ typedef enum tip_status {
                                  tip_check is exercised deterministically.  Bit 3: nobody is dropped, but every cooperating kernel
                                  treats its partners as sitting on DIFFERENT XCDs (agent-scope stores, L1-bypassing loads, paced
                                  polls) wherever they really are: the path a placement across XCDs takes, bit-identical results.
-                                 0 = off (default). */
+                                 Bit 4: in the one-launch few-stream form one producer of window 0 stamps its completion flag as a
+                                 workgroup on ANOTHER XCD would (what kernels of a foreign stream running beside it can cause): its
+                                 consumers give up at once and report TIP_OPT_HANDOFF_KIND = 2.  0 = off (default). */
 
 #define TIP_OPT_FUSE_HEAD 5 /* RESERVED: accepted (0 / 1) and ignored.  Rounds 3-4: the output projection as the epilogue of the recurrence
                                kernel (measured neutral, removed in round 5); round 5: the projection inside the recurrence's hop wait
@@ -126,6 +128,14 @@ typedef enum tip_status {
                                  (hybrid one-window / two-window encoder or the general plan, single-workgroup recurrence tiles): no
                                  co-residency needed, a co-tenant costs throughput instead of frames.  Explicit plans / cluster sizes are
                                  still honoured.  The training step's two recurrences likewise run on single-workgroup tiles.  Default 0. */
+#define TIP_OPT_NO_FLOW    10 /* 1: the few-stream plan never takes its ONE-launch form (B <= 24: stages, recurrence and projection as roles of one
+                                 launch, every workgroup of a window on the window's XCD) but the launch chain for every batch it serves —
+                                 what a host answers a placement loss with (TIP_OPT_HANDOFF_KIND = 2: kernels of another stream were
+                                 dispatched beside the launch and broke the id mod 8 = XCD rule).  The chain needs co-residency only.
+                                 Default 0. */
+#define TIP_OPT_HANDOFF_KIND 11 /* READ ONLY (tip_get_option): what the sticky hand-off word of tip_check says.  0: nothing pending; 1: a
+                                 cooperating kernel's wait gave up (co-residency lost: the answer is TIP_OPT_DEMOTED); 2: only the
+                                 one-launch few-stream form found a producer on another XCD (the answer is TIP_OPT_NO_FLOW). */
 #define TIP_OPT_F1S_PARTS   9 /* workgroups that share ONE window under TIP_PLAN_FUSED1S: 2, 4, or 0 (default) = four while 4 B <= #CUs and
                                  B <= 64, two otherwise.  An explicit 4 outside that range is TIP_ERR_UNSUPPORTED_CONFIG at the forward. */
 

@@ -251,3 +251,75 @@ def test_train_mode_runner_call_demotes_after_a_lost_handoff():
         h2.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)
         with pytest.raises(tlib.TipHandoffError):
             m2(xi, xs)
+
+
+@pytest.mark.handoff_fault
+@pytest.mark.parametrize("B", [1, 9])
+def test_placement_loss_of_the_one_launch_form_falls_back_to_the_launch_chain(B):
+    """The one-launch few-stream form needs every workgroup of a window on the window's XCD; kernels of another stream dispatched
+    beside it can break that (tests/test_hip_parity.py: test_one_launch_form_under_foreign_stream_load).  Simulated deterministically
+    (TIP_OPT_FAULT_INJECT bit 4: one producer stamps its flag as another XCD's): the launch is NaN + reported with
+    TIP_OPT_HANDOFF_KIND = 2, and the host's answer is the MILD one — TIP_OPT_NO_FLOW, the same plan as a launch chain (bit-identical
+    outputs, co-residency only) — not the plans without any hand-off; a later loss of another kind still demotes fully."""
+    m, w = _model()
+    h = m._ensure_handle()
+    x_imu, x_s = synth.make_inputs(synth.PAPER, B, 40, seed=11)
+    xi, xs = torch.tensor(x_imu).cuda(), torch.tensor(x_s).cuda()
+    with torch.no_grad():
+        ref = m(xi, xs).cpu().numpy()                          # one-launch form
+        h.set_option(tlib.TIP_OPT_NO_FLOW, 1)
+        ref_chain = m(xi, xs).cpu().numpy()
+        h.set_option(tlib.TIP_OPT_NO_FLOW, 0)
+        assert np.array_equal(ref, ref_chain), "the launch chain and the one-launch form share their stage bodies: same bits"
+        assert h.get_option(tlib.TIP_OPT_HANDOFF_KIND) == 0
+        h.set_option(tlib.TIP_OPT_FAULT_INJECT, 16)
+        y_bad = m(xi, xs)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(y_bad).any())
+        assert h.get_option(tlib.TIP_OPT_HANDOFF_KIND) == 2
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            y1 = m(xi, xs)                                     # entry check trips -> launch chain -> this call runs
+            torch.cuda.synchronize()
+        assert any("spread over several XCDs" in str(r.message) for r in rec)
+        assert m.flow_demotions == 1 and m.demotions == 0 and not m.is_demoted() and h.get_option(tlib.TIP_OPT_NO_FLOW) == 1
+        assert np.array_equal(y1.cpu().numpy(), ref)
+        for _ in range(3):                                     # the fault is still injected: the chain does not care
+            assert np.array_equal(m.forward_last(xi, xs).cpu().numpy(), ref[:, -1])
+        m.check_handoffs()
+        # a loss of the OTHER kind on top (the chain's GEMV recurrence drops a member): now the full demotion
+        h.set_option(tlib.TIP_OPT_FAULT_INJECT, 4)
+        y_bad = m(xi, xs)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(y_bad).any()) and h.get_option(tlib.TIP_OPT_HANDOFF_KIND) == 1
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            y2 = m(xi, xs)
+            torch.cuda.synchronize()
+        assert m.is_demoted() and m.demotions == 1 and bool(torch.isfinite(y2).all())
+        h.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)
+        m.undemote()
+        assert h.get_option(tlib.TIP_OPT_NO_FLOW) == 0 and not m.is_demoted()
+        assert np.array_equal(m(xi, xs).cpu().numpy(), ref)
+        m.check_handoffs()
+    # the unedited runner's call (.train() mode: tip_forward_dropout) takes the same mild step
+    mt = make_model(synth.PAPER, p_state=0.8)
+    load_synth(mt, synth.PAPER, 0)
+    mt = mt.cuda()
+    ht = mt._ensure_handle()
+    xs1 = torch.nan_to_num(xs[:1])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(3):
+            assert bool(torch.isfinite(mt(xi[:1], xs1)).all())
+        ht.set_option(tlib.TIP_OPT_FAULT_INJECT, 16)
+        y_bad = mt(xi[:1], xs1)
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(y_bad).any())
+        y1 = mt(xi[:1], xs1)
+        torch.cuda.synchronize()
+        assert mt.flow_demotions == 1 and not mt.is_demoted() and bool(torch.isfinite(y1).all())
+        for _ in range(3):
+            assert bool(torch.isfinite(mt(xi[:1], xs1)).all())
+        mt.check_handoffs()
+        ht.set_option(tlib.TIP_OPT_FAULT_INJECT, 0)

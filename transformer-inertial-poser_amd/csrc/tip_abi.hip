@@ -368,7 +368,7 @@ int tip_set_option(tip_handle* h, int option, int value) {
             h->rnn_cluster = value;
             return TIP_OK;
         case TIP_OPT_FAULT_INJECT:
-            if (value < 0 || value > 15) return TIP_ERR_INVALID_ARG;
+            if (value < 0 || value > 31) return TIP_ERR_INVALID_ARG;
             h->fault_inject = value;
             return TIP_OK;
         case TIP_OPT_FUSE_HEAD:
@@ -387,6 +387,10 @@ int tip_set_option(tip_handle* h, int option, int value) {
             if (value != 0 && value != 2 && value != 4) return TIP_ERR_INVALID_ARG;
             h->f1s_parts = value;
             return TIP_OK;
+        case TIP_OPT_NO_FLOW:
+            if (value < 0 || value > 1) return TIP_ERR_INVALID_ARG;
+            h->no_flow = value;
+            return TIP_OK;
         default: return TIP_ERR_INVALID_ARG;
     }
 }
@@ -394,8 +398,9 @@ int tip_set_option(tip_handle* h, int option, int value) {
 int tip_check(tip_handle* h, int clear) {
     if (!h) return TIP_ERR_INVALID_ARG;
     if (!h->err_host) return TIP_OK;
-    const unsigned v = *const_cast<volatile unsigned*>(h->err_host);
-    if (clear) *const_cast<volatile unsigned*>(h->err_host) = 0u;
+    volatile unsigned* w = const_cast<volatile unsigned*>(h->err_host);
+    const unsigned v = w[0] | w[1];
+    if (clear) w[0] = w[1] = 0u;
     return v ? TIP_ERR_HANDOFF : TIP_OK;
 }
 
@@ -410,6 +415,12 @@ int tip_get_option(const tip_handle* h, int option, int* value) {
         case TIP_OPT_AUTO_DEMOTE: *value = h->auto_demote; return TIP_OK;
         case TIP_OPT_DEMOTED: *value = h->demoted; return TIP_OK;
         case TIP_OPT_F1S_PARTS: *value = h->f1s_parts; return TIP_OK;
+        case TIP_OPT_NO_FLOW: *value = h->no_flow; return TIP_OK;
+        case TIP_OPT_HANDOFF_KIND: {
+            const volatile unsigned* w = const_cast<const volatile unsigned*>(h->err_host);
+            *value = !w ? 0 : w[0] ? 1 : w[1] ? 2 : 0;
+            return TIP_OK;
+        }
         default: return TIP_ERR_INVALID_ARG;
     }
 }
@@ -922,7 +933,7 @@ static int forward_impl(tip_handle* h, const float* x_imu, const float* x_s, flo
         const LatencyHead lh{P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, d.S, (flags & TIP_FWD_LAST_ROW_ONLY) != 0, h->flow_epoch, &head_done,
                              reinterpret_cast<unsigned long long*>(W0 + ws.flow)};
         TIP_TRY(launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall,
-                                    B, T, cus, gd, s, nullptr, cus == h->num_cus ? &lh : nullptr), "latency_chain");
+                                    B, T, cus, gd, s, nullptr, cus == h->num_cus && !h->no_flow ? &lh : nullptr), "latency_chain");
         rnn_done = true;
     } else if (plan == TIP_PLAN_FUSED1S) {
         StageScope sc(h, s, "fused_encoder");
@@ -1082,7 +1093,7 @@ int tip_forward_dropout(tip_handle* h, const float* x_imu, const float* x_s, flo
         const LatencyHead lh{P + L.out_frag_off, P + L.out_lin.b_off, y, d.S, d.S, (flags & TIP_FWD_LAST_ROW_ONLY) != 0, h->flow_epoch, &head_done,
                              reinterpret_cast<unsigned long long*>(W0 + ws.flow)};
         e = launch_latency_plan(d, P + L.fused_off, P + L.whh_frag_off, x_imu, x_s, mask, keep_scale, W0 + ws.lat, hall, B, T, cus,
-                                h->guard(), s, &td, cus == h->num_cus ? &lh : nullptr);
+                                h->guard(), s, &td, cus == h->num_cus && !h->no_flow ? &lh : nullptr);
         if (e != hipSuccess) return fail_hip(h, e, "latency_chain");
     }
     if (!head_done) {

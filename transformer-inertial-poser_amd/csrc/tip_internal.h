@@ -280,7 +280,8 @@ struct tip_handle {
     std::string last_hip_error;
     std::vector<tip::StageTimer> timers;
     int cur_timer = -1;
-    unsigned* err_host = nullptr;   // 64-byte pinned, device-mapped host block: word 0 = "a hand-off wait gave up" (sticky)
+    unsigned* err_host = nullptr;   // 64-byte pinned, device-mapped host block: word 0 = "a hand-off wait gave up" (sticky); word 1 = "the
+                                    // one-launch few-stream form found a producer on another XCD" (sticky; TIP_OPT_HANDOFF_KIND tells them apart)
     unsigned* err_dev = nullptr;    // the device's address of it
     int fault_inject = 0;           // TIP_OPT_FAULT_INJECT (tests)
     int fuse_head = 0;              // TIP_OPT_FUSE_HEAD
@@ -288,6 +289,7 @@ struct tip_handle {
     int f1s_parts = 0;              // TIP_OPT_F1S_PARTS: 0 = auto, 2, 4
     unsigned long long flow_epoch = 0;   // launches of lat_flow_kernel so far (+ a per-handle base): stamps the completion flags of a launch
     int demoted = 0;                // TIP_OPT_DEMOTED: set by tip_demote after a lost hand-off: AUTO then avoids every cooperating kernel
+    int no_flow = 0;                // TIP_OPT_NO_FLOW: the few-stream plan never takes its one-launch form (launch chain for every B)
     tip::Guard guard() const { return tip::Guard{err_dev, fault_inject}; }
 };
 

@@ -68,6 +68,7 @@ __device__ unsigned g_spin_timeouts_latency;   // see tip_spin_timeouts()
 struct FlowCtx {
     u64* wflags = nullptr;     // this window's completion flags [stage][64]
     u64 want = 0;              // what a finished workgroup of THIS launch on THIS XCD stores: (epoch << 8) | (xcc id + 1)
+    u64 publish = 0;           // what THIS workgroup stores (= want, unless TIP_OPT_FAULT_INJECT bit 4 makes it pose as another XCD's)
     unsigned spin_lim = 0;
     unsigned* err = nullptr;
     bool poisoned = false;     // a wait gave up (or a producer sits on another XCD): everything this workgroup stores is NaN from here on
@@ -94,20 +95,22 @@ __device__ __forceinline__ void flow_wait(FlowCtx& fc, int stage, int G, int* s_
     const int tid = threadIdx.x;
     if (tid < 64) {
         const u64* f = fc.wflags + (size_t)stage * 64;
-        bool ok = false;
+        bool ok = false, foreign = false;
         const unsigned lim = fc.poisoned ? 1u : fc.spin_lim;
         for (unsigned spin = 0; spin < lim; ++spin) {
             const u64 v = tid < G ? __hip_atomic_load(f + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : fc.want;
             if (__builtin_amdgcn_ballot_w64(v != fc.want) == 0) { ok = true; break; }
             // this launch's stamp from ANOTHER XCD: the placement rule (id % 8 = XCD) does not hold here — no point in waiting
-            if (__builtin_amdgcn_ballot_w64(v != fc.want && (v >> 8) == (fc.want >> 8)) != 0) break;
+            if (__builtin_amdgcn_ballot_w64(v != fc.want && (v >> 8) == (fc.want >> 8)) != 0) { foreign = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
         if (tid == 0) {
             *s_ok = ok ? 1 : 0;
             if (!ok && !fc.poisoned) {
                 atomicAdd(&g_spin_timeouts_latency, 1u);
-                guard_report(fc.err);
+                // word 1 of the handle's error block: "only the one-launch form's placement" (hosts then fall back to the launch chain,
+                // TIP_OPT_NO_FLOW, instead of giving up every cooperating kernel); a producer that never arrives is word 0 like any other
+                guard_report(fc.err ? fc.err + (foreign ? 1 : 0) : nullptr);
             }
         }
     }
@@ -118,7 +121,7 @@ __device__ __forceinline__ void flow_wait(FlowCtx& fc, int stage, int G, int* s_
 __device__ __forceinline__ void flow_done(const FlowCtx& fc, int stage, int nb) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's stores are acknowledged by the L2 ...
     __syncthreads();                                   // ... before the one flag store that publishes them
-    if (threadIdx.x == 0) fc.wflags[(size_t)stage * 64 + nb] = fc.want;
+    if (threadIdx.x == 0) fc.wflags[(size_t)stage * 64 + nb] = fc.publish;
 }
 __device__ __forceinline__ float poison_if(bool p, float v) { return p ? __uint_as_float(kPoisonBits) : v; }
 
@@ -992,6 +995,9 @@ __global__ __launch_bounds__(256) void lat_flow_kernel(LatFlowArgs a) {
     u64* const counter = fc.wflags + (size_t)(kFlowMaxStages - 1) * 64;   // this WINDOW's launch counter (the last flag slot: no stage uses it)
     const u64 launch = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     fc.want = (((a.nonce + launch) & 0x00ffffffffffffffull) << 8) | (u64)((xcc & 0xf) + 1u);
+    fc.publish = fc.want;
+    // TIP_OPT_FAULT_INJECT bit 4: this producer (out-projection of layer 0, column block 1) stamps its flag as another XCD's would
+    if ((a.gd.fault & 16) && win == 0 && stage == 3 && nb == 1) fc.publish = (fc.want & ~0xffull) | (u64)(((xcc + 1u) & 0xf) + 1u);
     fc.spin_lim = guard_spin_limit(a.gd.fault, 1u << 22);
     fc.err = a.gd.err;
     const Act act{__builtin_amdgcn_make_buffer_rsrc(a.ws, 0, a.ws_bytes, 0x00020000), a.ws};

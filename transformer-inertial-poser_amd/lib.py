@@ -24,6 +24,7 @@ TIP_SAVED_QKV, TIP_SAVED_ATT, TIP_SAVED_X1, TIP_SAVED_HID, TIP_SAVED_XOUT, TIP_S
 TIP_STREAM_FRAME_AUTO = -1   # tip_stream_ingest / tip_stream_consume: continue from the counter in the state buffer (HIP graphs)
 TIP_OPT_PLAN, TIP_OPT_PROFILE, TIP_OPT_RNN_CLUSTER, TIP_OPT_FAULT_INJECT, TIP_OPT_FUSE_HEAD = 1, 2, 3, 4, 5
 TIP_OPT_AUTO_DEMOTE, TIP_OPT_DEMOTED, TIP_OPT_F1S_PARTS = 7, 8, 9   # 6: retired
+TIP_OPT_NO_FLOW, TIP_OPT_HANDOFF_KIND = 10, 11   # few-stream plan without its one-launch form; (read only) 0 none / 1 a wait gave up / 2 one-launch placement only
 TIP_ABI_VERSION = 5
 TIP_RNN_CLUSTER_ROWS4 = 0x44   # TIP_OPT_RNN_CLUSTER value: 4-window tiles on 4-workgroup clusters (AUTO's choice for rnn_hidden 512)
 TIP_ERR_HANDOFF = -8

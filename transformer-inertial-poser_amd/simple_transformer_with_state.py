@@ -126,6 +126,7 @@ class TF_RNN_Past_State(nn.Module):
         self._handle: Optional[_lib.Handle] = None
         self._packed_dev: Optional[torch.Tensor] = None
         self._packed_key = None
+        self.flow_demotions = 0          # times _answer_handoff switched the one-launch few-stream form off (TIP_OPT_NO_FLOW)
         self._pack_epoch = 0             # bumped by every attach_packed: a reuse ring is only good for the image it was filled under
         self._ring_epoch = {}            # ring data_ptr -> _pack_epoch at its last reuse_reset()
         self._workspace = {}             # (device index, stream handle) -> uint8 tensor: calls on different streams never share one
@@ -495,15 +496,14 @@ class TF_RNN_Past_State(nn.Module):
             # the first time, clear the word, demote the handle to the plans without cooperating kernels and let THIS call run there
             # (False: the caller takes tip_train_forward, whose recurrence then runs one workgroup per tile); with TIP_OPT_AUTO_DEMOTE
             # off, or on a handle that is demoted already, report it.
-            if not h.get_option(_lib.TIP_OPT_AUTO_DEMOTE) or h.get_option(_lib.TIP_OPT_DEMOTED):
+            how = self._answer_handoff(h)
+            if how is None:
                 raise
-            warnings.warn("tip_amd: an earlier forward lost an inter-workgroup hand-off (is another process or stream holding "
-                          "CUs of this GPU?) — its outputs were NaN.  This model now runs the plans that need no co-resident "
-                          "workgroups (TIP_OPT_DEMOTED: slower, safe under co-tenancy); model.undemote() restores the default")
-            h.check_clear()
-            h.set_option(_lib.TIP_OPT_DEMOTED, 1)
-            self.demotions += 1
             self._fast_state = None
+            if how == "chain":      # only the one-launch form is gone: the same entry point serves this call on the launch chain
+                h.forward_dropout(xi.data_ptr(), xs.data_ptr(), y.data_ptr(), B, T, _lib.TIP_FWD_KEEP_MASK if mask_ptr else 0, mask_ptr,
+                                  scale, p_state, state_seed, p_drop, seed, ws.data_ptr(), ws.numel(), stream)
+                return True
             return False
         except _lib.TipStatusError as e:
             if e.status == _lib.TIP_ERR_UNSUPPORTED_CONFIG:
@@ -659,10 +659,39 @@ class TF_RNN_Past_State(nn.Module):
                 except _lib.TipHandoffError:
                     pass
 
+    def _answer_handoff(self, h):
+        """A TipHandoffError is pending on `h` (an EARLIER launch lost an inter-workgroup hand-off: its outputs were NaN and flagged).
+        What the host does about it, once per kind: if only the one-launch few-stream form lost its XCD placement (kernels of another
+        stream were dispatched beside it: TIP_OPT_HANDOFF_KIND = 2), switch THAT form off — the launch chain needs co-residency only and
+        costs 10 us per forward; anything else (or a second loss): the plans without any hand-off (TIP_OPT_DEMOTED).  Returns "chain" /
+        "demoted" with the sticky word cleared, or None when the error is to be reported (TIP_OPT_AUTO_DEMOTE off, nothing left to
+        give up)."""
+        if not h.get_option(_lib.TIP_OPT_AUTO_DEMOTE):
+            return None
+        if h.get_option(_lib.TIP_OPT_HANDOFF_KIND) == 2 and not h.get_option(_lib.TIP_OPT_NO_FLOW):
+            warnings.warn("tip_amd: an earlier few-stream forward found its workgroups spread over several XCDs (kernels of another stream "
+                          "or process were dispatched beside it) — its outputs were NaN.  This model now runs the few-stream plan as a "
+                          "launch chain (TIP_OPT_NO_FLOW: ~10 us per forward slower, no placement requirement); model.undemote() "
+                          "restores the default")
+            h.check_clear()
+            h.set_option(_lib.TIP_OPT_NO_FLOW, 1)
+            self.flow_demotions += 1
+            return "chain"
+        if h.get_option(_lib.TIP_OPT_DEMOTED):
+            return None
+        warnings.warn("tip_amd: an earlier forward lost an inter-workgroup hand-off (is another process or stream holding "
+                      "CUs of this GPU?) — its outputs were NaN.  This model now runs the plans that need no co-resident "
+                      "workgroups (TIP_OPT_DEMOTED: slower, safe under co-tenancy); model.undemote() restores the default")
+        h.check_clear()
+        h.set_option(_lib.TIP_OPT_DEMOTED, 1)
+        self.demotions += 1
+        return "demoted"
+
     def undemote(self):
-        """Back to the default (cooperating) plans after a self-demotion (see _forward_hip): the GPU is this process's again."""
+        """Back to the default (cooperating) plans after a self-demotion (see _answer_handoff): the GPU is this process's again."""
         if self._handle is not None:
             self._handle.set_option(_lib.TIP_OPT_DEMOTED, 0)
+            self._handle.set_option(_lib.TIP_OPT_NO_FLOW, 0)
 
     def is_demoted(self) -> bool:
         return bool(self._handle is not None and self._handle.get_option(_lib.TIP_OPT_DEMOTED))
@@ -794,14 +823,8 @@ class TF_RNN_Past_State(nn.Module):
                 # NaN-poisoned and flagged.  First time: demote the handle to the plans that need no co-residency (hybrid
                 # encoder + single-workgroup recurrence tiles), clear the word and run THIS call — a co-tenant then costs
                 # throughput, not every following frame.  TIP_OPT_AUTO_DEMOTE = 0 (or a second loss) reports the error.
-                if not h.get_option(_lib.TIP_OPT_AUTO_DEMOTE) or h.get_option(_lib.TIP_OPT_DEMOTED):
+                if self._answer_handoff(h) is None:
                     raise
-                warnings.warn("tip_amd: an earlier forward lost an inter-workgroup hand-off (is another process or stream holding "
-                              "CUs of this GPU?) — its outputs were NaN.  This model now runs the plans that need no co-resident "
-                              "workgroups (TIP_OPT_DEMOTED: slower, safe under co-tenancy); model.undemote() restores the default")
-                h.check_clear()
-                h.set_option(_lib.TIP_OPT_DEMOTED, 1)
-                self.demotions += 1
                 h.forward(x_imu_c.data_ptr(), x_s_c.data_ptr(), y.data_ptr(), B, T, flags, mask_ptr, scale,
                           ws.data_ptr(), ws.numel(), stream)
             if not self._frozen and B <= self.LAZY_STASH_MAX_BATCH:

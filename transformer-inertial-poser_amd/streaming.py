@@ -120,11 +120,9 @@ class StreamingEngine:
             self.model.check_handoffs(synchronize=False)
         except _lib.TipHandoffError:
             h = self.model._ensure_handle()
-            h.check_clear()
-            if h.get_option(_lib.TIP_OPT_AUTO_DEMOTE) and not h.get_option(_lib.TIP_OPT_DEMOTED):
-                h.set_option(_lib.TIP_OPT_DEMOTED, 1)
-                self.model.demotions += 1
-            self.reset()          # the NaN row of the lost frame is in the history ring: re-prime (and re-capture, demoted)
+            if self.model._answer_handoff(h) is None:     # (launch chain instead of the one-launch form, or the plans without hand-offs)
+                h.check_clear()
+            self.reset()          # the NaN row of the lost frame is in the history ring: re-prime (and re-capture on the new plan)
             raise
 
     def _frame_auto(self):
@@ -183,7 +181,7 @@ class StreamingEngine:
                 return None
             x_imu = self.x_imu.view(-1)[: self.n * T * 90].view(self.n, T, 90)
             x_s = self.x_s.view(-1)[: self.n * T * 131].view(self.n, T, 131)
-            demotions = self.model.demotions
+            demotions = self.model.demotions + self.model.flow_demotions
             if self.reuse:
                 try:
                     y_last = self.model.forward_last_reuse(x_imu, x_s, self._ring, f)
@@ -191,15 +189,13 @@ class StreamingEngine:
                     # an EARLIER frame lost an inter-workgroup hand-off (its NaN row is in the history ring and in the reuse ring): same
                     # contract as the other paths — demote the handle to the plans without hand-offs when allowed, re-prime, raise
                     h = self.model._ensure_handle()
-                    h.check_clear()
-                    if h.get_option(_lib.TIP_OPT_AUTO_DEMOTE) and not h.get_option(_lib.TIP_OPT_DEMOTED):
-                        h.set_option(_lib.TIP_OPT_DEMOTED, 1)
-                        self.model.demotions += 1
+                    if self.model._answer_handoff(h) is None:
+                        h.check_clear()
                     self.reset()
                     raise
             else:
                 y_last = self.model.forward_last(x_imu, x_s)
-            if self.model.demotions != demotions:
+            if self.model.demotions + self.model.flow_demotions != demotions:
                 # tip_forward's entry check found that an EARLIER frame lost a hand-off: the model demoted itself and served this
                 # call, but that frame's NaN row already went into the history ring (the prologue would scrub it to 0 for the
                 # next 40 windows: finite, degraded poses).  Same contract as the graph path: re-prime and raise.
