@@ -290,7 +290,9 @@ TIP_API int tip_stream_ingest_newest(void* state, const float* raw_imu, int n_st
  *        tip_stream_frame_counter_offset() of `state`.
  *      Every slot is tagged with the frame it was written for: a window whose 40 slots are not frames c-39 .. c (a skipped or repeated
  *      call, a ring that was reset or never primed) yields NaN rows, never another frame's numbers.  tip_reuse_reset clears the tags
- *      (required once before the first call, and whenever the streams restart).  flags: TIP_FWD_LAST_ROW_ONLY; a keep mask is refused
+ *      (required once before the first call, whenever the streams restart, and after tip_attach_packed of a new weight image: the
+ *      ring's rows are functions of the weights — the Python host ties a ring to the image it was filled under and refuses a stale
+ *      one).  flags: TIP_FWD_LAST_ROW_ONLY; a keep mask is refused
  *      (TIP_ERR_INVALID_ARG), other configurations than the paper's answer TIP_ERR_UNSUPPORTED_CONFIG.  Reference for what is reused:
  *      simple_transformer_with_state.py:63-79 (row-wise prologue + in_linear), torch functional.py:5785 (_in_projection_packed). */
 TIP_API int tip_reuse_cache_bytes(const tip_handle* h, int n_streams, size_t* bytes);
